@@ -1,0 +1,595 @@
+/*
+ * dsvt_oracle.c -- CPU restatement of the DSVT-AI-TRT plugin arithmetic.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (dsvt-ai-trt_amd/,
+ * include/, bench.py's GPU leg) may call into this file.  It is the checker the
+ * HIP kernels are compared against (tests/, __graft_entry__.smoke(), and
+ * bench.py's cpu_baseline leg).
+ *
+ * Every function restates one reference plugin / host function as plain serial C
+ * and cites the reference file:line it follows (paths relative to the reference
+ * tree).  The reference kernels are racy (atomic arrival order decides pillar /
+ * window / set / box numbering); this restatement fixes the canonical order of
+ * SURVEY.md section 8(a):
+ *   pillars ascending by cell key y*GX+x; points inside a pillar in input order,
+ *   first T kept; compact point ids pillar-major then slot; windows ascending by
+ *   window linear id; voxels inside a window in ascending voxel id; sets
+ *   ascending by (window, j); box rows ascending by candidate rank.
+ *
+ * PARITY PINNING.  The reference cannot be built here (needs nvcc + TensorRT
+ * 8.2 headers, neither present; no stand-ins are written).  This oracle is
+ * pinned against the reference's own known answers: the author's in-source
+ * counts for data/bin/000000.bin (5504 pillars: plugins/src/windowPartition.cu:212,
+ * plugins/src/getValueByIndex.cu:176; 454 sets for 12x12 windows:
+ * src/dsvt-ai-trt.cpp:291,302,308) and the count table + FNV-1a fingerprints
+ * recorded in SURVEY.md section 8(a)/(c) -- see tests/test_oracle_known_answers.py.
+ * The dense TensorRT layers (FC / conv / softmax / top-k) have no reference
+ * vectors at all: for those, parity is UNPINNED (oracle/dense_ref.py header).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC (oracle/Makefile).
+ * -ffp-contract=off keeps every a*b+c as two roundings (plain IEEE C semantics).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* loadData: include/helper.h:28-72.  Reads the file image into a zero-padded  */
+/* buffer of max_points*16 bytes; points_size = len/16 (src/dsvt-ai-trt.cpp:1909) */
+ORC_API int orc_load_data(const uint8_t* file_bytes, uint32_t len, int max_points,
+                          float* out_points, uint32_t* points_size)
+{
+    uint32_t cap = (uint32_t)max_points * 16u;
+    if (len > cap) return -1;                 /* helper.h:47-53: reference exit(-1)s */
+    memset(out_points, 0, cap);               /* helper.h:55-58 */
+    memcpy(out_points, file_bytes, len);      /* helper.h:66 */
+    *points_size = len / sizeof(float) / 4;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Points2Features: plugins/src/points2Features.cu:669-990                     */
+typedef struct {
+    int max_points_num, max_points_num_voxel_filter, max_pillars_num;
+    int point_feature_num, feature_num, max_num_points_per_voxel;
+    float min_x, max_x, min_y, max_y, min_z, max_z;
+    float vx, vy, vz;
+    int gx, gy, gz;
+} orc_p2f_cfg;
+
+ORC_API int orc_points2features(const orc_p2f_cfg* c, const float* points, uint32_t n_points,
+                                float* feat,      /* [max_points_num_voxel_filter, 10] */
+                                uint32_t* pidx,   /* [max_pillars_num, T] */
+                                uint32_t* coords, /* [max_pillars_num, 4] = (0,0,y,x) */
+                                uint32_t* pcnt,   /* [max_pillars_num] */
+                                uint32_t* pillar_num, uint32_t* point_num)
+{
+    const int T = c->max_num_points_per_voxel;
+    const int ncell = c->gx * c->gy;
+    const int F = c->feature_num;
+    uint32_t* mask = (uint32_t*)calloc((size_t)ncell, sizeof(uint32_t));
+    uint32_t* cell_of = (uint32_t*)malloc((size_t)(n_points ? n_points : 1) * sizeof(uint32_t));
+    /* every enqueue zero-fills all outputs: points2Features.cu:919-937 */
+    memset(feat, 0, (size_t)c->max_points_num_voxel_filter * F * sizeof(float));
+    memset(pidx, 0, (size_t)c->max_pillars_num * T * sizeof(uint32_t));
+    memset(coords, 0, (size_t)c->max_pillars_num * 4 * sizeof(uint32_t));
+    memset(pcnt, 0, (size_t)c->max_pillars_num * sizeof(uint32_t));
+
+    /* pass 1 = generateVoxels_random_kernel :669-704 executed in input order */
+    for (uint32_t i = 0; i < n_points; i++) {
+        float x = points[i * 4 + 0], y = points[i * 4 + 1], z = points[i * 4 + 2];
+        cell_of[i] = 0xffffffffu;
+        if (x < c->min_x || x >= c->max_x || y < c->min_y || y >= c->max_y ||
+            z < c->min_z || z >= c->max_z) continue;                       /* :683-685 */
+        int ix = (int)floorf((x - c->min_x) / c->vx);                      /* :687 */
+        int iy = (int)floorf((y - c->min_y) / c->vy);                      /* :688 */
+        uint32_t cell = (uint32_t)(iy * c->gx + ix);                       /* :689-690 */
+        uint32_t slot = mask[cell]++;                                      /* :697 */
+        if (slot >= (uint32_t)T) continue;                                 /* :699 */
+        cell_of[i] = cell;                                                 /* kept point */
+    }
+    /* pass 2 = generateBaseFeatures_kernel :732-765 in canonical (ascending cell) order */
+    uint32_t* cell_pid = (uint32_t*)malloc((size_t)ncell * sizeof(uint32_t));
+    uint32_t* pt_off = (uint32_t*)malloc((size_t)(c->max_pillars_num + 1) * sizeof(uint32_t));
+    uint32_t P = 0, Nk = 0;
+    memset(cell_pid, 0xff, (size_t)ncell * sizeof(uint32_t));
+    for (int cell = 0; cell < ncell; cell++) {
+        uint32_t cnt = mask[cell];
+        if (!(cnt > 0)) continue;                                          /* :746 */
+        cnt = cnt < (uint32_t)T ? cnt : (uint32_t)T;                       /* :748 */
+        /* capacity guard the reference lacks: truncate the
+         * pillar list at the first pillar overflowing either cap */
+        if (P >= (uint32_t)c->max_pillars_num ||
+            Nk + cnt > (uint32_t)c->max_points_num_voxel_filter) break;
+        cell_pid[cell] = P;
+        pcnt[P] = cnt;                                                     /* :753 */
+        coords[P * 4 + 0] = 0; coords[P * 4 + 1] = 0;
+        coords[P * 4 + 2] = (uint32_t)(cell / c->gx);
+        coords[P * 4 + 3] = (uint32_t)(cell % c->gx);                      /* :755-756 */
+        pt_off[P] = Nk;
+        Nk += cnt; P++;
+    }
+    /* gather kept points into pillar-major, slot-minor compact order */
+    float* vox = (float*)calloc((size_t)(Nk ? Nk : 1) * 4, sizeof(float));
+    uint32_t* fill = (uint32_t*)calloc((size_t)(P ? P : 1), sizeof(uint32_t));
+    for (uint32_t i = 0; i < n_points; i++) {
+        if (cell_of[i] == 0xffffffffu) continue;
+        uint32_t pid = cell_pid[cell_of[i]];
+        if (pid == 0xffffffffu) continue;
+        uint32_t s = fill[pid]++;
+        memcpy(vox + (size_t)(pt_off[pid] + s) * 4, points + (size_t)i * 4, 16);  /* :758-762 */
+    }
+    /* pass 3 = generateFeatures_kernel :792-864 */
+    for (uint32_t p = 0; p < P; p++) {
+        int n = (int)pcnt[p];
+        const float* v = vox + (size_t)pt_off[p] * 4;
+        float cx = 0, cy = 0, cz = 0;
+        for (int i = 0; i < n; i++) { cx += v[i * 4 + 0]; cy += v[i * 4 + 1]; cz += v[i * 4 + 2]; }  /* :813-821 */
+        cx = cx / n; cy = cy / n; cz = cz / n;                              /* :822-824 */
+        for (int i = 0; i < n; i++) {
+            uint32_t point_index = pt_off[p] + (uint32_t)i;                 /* :829 atomicAdd, canonical */
+            pidx[(size_t)p * T + i] = point_index;                          /* :830 */
+            float x = v[i * 4 + 0], y = v[i * 4 + 1], z = v[i * 4 + 2], in = v[i * 4 + 3];
+            float* f = feat + (size_t)point_index * F;
+            f[0] = x; f[1] = y; f[2] = z; f[3] = in;                        /* :838-841 */
+            int index_x = (int)floorf((x - c->min_x) / c->vx);              /* :844-846 */
+            int index_y = (int)floorf((y - c->min_y) / c->vy);
+            int index_z = (int)floorf((z - c->min_z) / c->vz);
+            /* :849-851: "0.5" is a double literal => the bracket is evaluated in double */
+            float fx = (float)((double)x - ((index_x + 0.5) * (double)c->vx + (double)c->min_x));
+            float fy = (float)((double)y - ((index_y + 0.5) * (double)c->vy + (double)c->min_y));
+            float fz = (float)((double)z - ((index_z + 0.5) * (double)c->vz + (double)c->min_z));
+            f[7] = fx; f[8] = fy; f[9] = fz;                                /* :854-856 */
+            f[4] = x - cx; f[5] = y - cy; f[6] = z - cz;                    /* :859-861 */
+        }
+    }
+    *pillar_num = P; *point_num = Nk;
+    free(mask); free(cell_of); free(cell_pid); free(pt_off); free(vox); free(fill);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* TorchScatterMax: plugins/src/torchScatterMax.cu:201-309                     */
+ORC_API int orc_scatter_max(const float* feat, const uint32_t* pidx, const uint32_t* pcnt,
+                            uint32_t pillar_num, int max_points_num, int max_pillars_num,
+                            int feature_num, int T,
+                            float* max_point /* [max_points_num, C] */,
+                            float* max_voxel /* [max_pillars_num, C] */)
+{
+    const int C = feature_num;
+    memset(max_point, 0, (size_t)max_points_num * C * sizeof(float));      /* :300-301 */
+    memset(max_voxel, 0, (size_t)max_pillars_num * C * sizeof(float));
+    float* arr = (float*)malloc((size_t)C * sizeof(float));
+    for (uint32_t p = 0; p < pillar_num; p++) {
+        for (int k = 0; k < C; k++) arr[k] = -1000000.0f;                   /* :213-216 */
+        const uint32_t* idx = pidx + (size_t)p * T;
+        uint32_t n = pcnt[p];
+        for (uint32_t i = 0; i < n; i++)
+            for (int k = 0; k < C; k++) {
+                float v = feat[(size_t)idx[i] * C + k];
+                if (v > arr[k]) arr[k] = v;                                 /* :226-236 */
+            }
+        for (int k = 0; k < C; k++) max_voxel[(size_t)p * C + k] = arr[k];  /* :240-243 */
+        for (uint32_t i = 0; i < n; i++)
+            for (int k = 0; k < C; k++) max_point[(size_t)idx[i] * C + k] = arr[k];  /* :246-257 */
+    }
+    free(arr);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* WindowPartition: plugins/src/windowPartition.cu:278-470                     */
+typedef struct {
+    int max_win_num, max_voxel_num_per_win;
+    int sparse_x, sparse_y, sparse_z;
+    int win_x, win_y, win_z;
+    int shift_x, shift_y, shift_z;
+    int max_pillars_num;   /* reference uses the MAX_PILLARS_NUM macro (:441-442) */
+} orc_wp_cfg;
+
+ORC_API int orc_window_partition(const orc_wp_cfg* c, const uint32_t* coords, uint32_t voxel_num,
+                                 uint32_t* gidx,  /* [max_win, Vw] */
+                                 uint32_t* cinw,  /* [max_win, Vw, 3] (z,y,x) */
+                                 uint32_t* vcnt,  /* [max_win] */
+                                 uint32_t* win_num,
+                                 uint32_t* c2d,   /* [max_pillars, 3] */
+                                 float* xy        /* [max_pillars, 2] */)
+{
+    const int Vw = c->max_voxel_num_per_win;
+    /* :425-427 -- integer division inside ceilf */
+    int nwx = (int)(ceilf((float)(c->sparse_x / c->win_x)) + 1);
+    int nwy = (int)(ceilf((float)(c->sparse_y / c->win_y)) + 1);
+    int nwz = (int)(ceilf((float)(c->sparse_z / c->win_z)) + 1);
+    int dense = nwx * nwy * nwz;
+    memset(gidx, 0, (size_t)c->max_win_num * Vw * sizeof(uint32_t));       /* :445-450 */
+    memset(cinw, 0, (size_t)c->max_win_num * Vw * 3 * sizeof(uint32_t));
+    memset(vcnt, 0, (size_t)c->max_win_num * sizeof(uint32_t));
+    memset(c2d, 0, (size_t)c->max_pillars_num * 3 * sizeof(uint32_t));
+    memset(xy, 0, (size_t)c->max_pillars_num * 2 * sizeof(float));
+    uint32_t* cnt = (uint32_t*)calloc((size_t)dense, sizeof(uint32_t));
+    uint32_t* rank = (uint32_t*)malloc((size_t)dense * sizeof(uint32_t));
+    uint32_t* widx = (uint32_t*)malloc((size_t)(voxel_num ? voxel_num : 1) * sizeof(uint32_t));
+    for (uint32_t v = 0; v < voxel_num; v++) {
+        uint32_t sx = coords[v * 4 + 3] + (uint32_t)c->shift_x;            /* :292-294 */
+        uint32_t sy = coords[v * 4 + 2] + (uint32_t)c->shift_y;
+        uint32_t sz = coords[v * 4 + 1] + (uint32_t)c->shift_z;
+        uint32_t wx = sx / (uint32_t)c->win_x, wy = sy / (uint32_t)c->win_y, wz = sz / (uint32_t)c->win_z;  /* :296-298 */
+        widx[v] = wz * (uint32_t)(nwy * nwx) + wy * (uint32_t)nwx + wx;    /* :301 */
+        cnt[widx[v]]++;
+    }
+    /* canonical window numbering: ascending window linear id (reference: atomic arrival :311) */
+    uint32_t W = 0;
+    for (int w = 0; w < dense; w++) {
+        rank[w] = 0xffffffffu;
+        if (cnt[w] == 0) continue;
+        if (W >= (uint32_t)c->max_win_num) continue;   /* capacity guard the reference lacks */
+        rank[w] = W;
+        vcnt[W] = cnt[w] > (uint32_t)Vw ? (uint32_t)Vw : cnt[w];           /* :336-340 */
+        W++;
+    }
+    memset(cnt, 0, (size_t)dense * sizeof(uint32_t));
+    for (uint32_t v = 0; v < voxel_num; v++) {
+        uint32_t sx = coords[v * 4 + 3] + (uint32_t)c->shift_x;
+        uint32_t sy = coords[v * 4 + 2] + (uint32_t)c->shift_y;
+        uint32_t sz = coords[v * 4 + 1] + (uint32_t)c->shift_z;
+        uint32_t ix = sx % (uint32_t)c->win_x, iy = sy % (uint32_t)c->win_y, iz = sz % (uint32_t)c->win_z;  /* :352-354 */
+        uint32_t slot = cnt[widx[v]]++;                                    /* :304 arrival = ascending voxel id */
+        uint32_t w = rank[widx[v]];
+        if (slot >= (uint32_t)Vw || w == 0xffffffffu) continue;           /* :305 (reference returns before c2d/xy too) */
+        gidx[(size_t)w * Vw + slot] = v;                                   /* :343-344 */
+        cinw[((size_t)w * Vw + slot) * 3 + 0] = iz;                        /* :357-359 */
+        cinw[((size_t)w * Vw + slot) * 3 + 1] = iy;
+        cinw[((size_t)w * Vw + slot) * 3 + 2] = ix;
+        c2d[(size_t)v * 3 + 0] = iz; c2d[(size_t)v * 3 + 1] = iy; c2d[(size_t)v * 3 + 2] = ix;   /* :362-364 */
+        xy[(size_t)v * 2 + 0] = (float)ix - (float)c->win_x / 2;           /* :367-368 */
+        xy[(size_t)v * 2 + 1] = (float)iy - (float)c->win_y / 2;
+    }
+    *win_num = W;
+    free(cnt); free(rank); free(widx);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* GetSet: plugins/src/getSet.cu:267-704                                       */
+static void orc_swap(uint32_t* a, uint32_t* b) { uint32_t t = *a; *a = *b; *b = t; }   /* :267-272 */
+static int orc_partition(uint32_t* arr, uint32_t* key, int l, int h)                     /* :274-291 */
+{
+    int x = (int)key[h];
+    int i = l - 1;
+    for (int j = l; j <= h - 1; j++) {
+        if ((int)key[j] <= x) { i++; orc_swap(&key[i], &key[j]); orc_swap(&arr[i], &arr[j]); }
+    }
+    orc_swap(&key[i + 1], &key[h]); orc_swap(&arr[i + 1], &arr[h]);
+    return i + 1;
+}
+static void orc_quicksort(uint32_t* arr, uint32_t* key, int l, int h)                    /* :293-324 */
+{
+    if (h <= l) return;
+    int* stack = (int*)malloc((size_t)(2 * (h - l + 2)) * sizeof(int));
+    int top = -1;
+    stack[++top] = l; stack[++top] = h;
+    while (top >= 0) {
+        h = stack[top--]; l = stack[top--];
+        int p = orc_partition(arr, key, l, h);
+        if (p - 1 > l) { stack[++top] = l; stack[++top] = p - 1; }
+        if (p + 1 < h) { stack[++top] = p + 1; stack[++top] = h; }
+    }
+    free(stack);
+}
+
+typedef struct {
+    int max_win_num, max_voxel_num_per_win, voxel_num_set;
+    int win_x, win_y, win_z;
+    int num_heads;   /* reference: NUM_HEADS macro */
+} orc_gs_cfg;
+
+ORC_API int orc_get_set(const orc_gs_cfg* c, const uint32_t* gidx, const uint32_t* cinw,
+                        const uint32_t* vcnt, uint32_t win_num,
+                        uint32_t* inds,   /* [2, max_win, L] */
+                        float* mask,      /* [2, max_win, L] */
+                        uint32_t* set_num,
+                        float* mask0_h,   /* [max_win, H, L] */
+                        float* mask1_h    /* [max_win, H, L] */)
+{
+    const int L = c->voxel_num_set, Vw = c->max_voxel_num_per_win, MW = c->max_win_num, H = c->num_heads;
+    memset(inds, 0, (size_t)2 * MW * L * sizeof(uint32_t));                /* :681-686 */
+    memset(mask, 0, (size_t)2 * MW * L * sizeof(float));
+    memset(mask0_h, 0, (size_t)MW * H * L * sizeof(float));
+    memset(mask1_h, 0, (size_t)MW * H * L * sizeof(float));
+    uint32_t* sy = (uint32_t*)malloc((size_t)Vw * sizeof(uint32_t));
+    uint32_t* sx = (uint32_t*)malloc((size_t)Vw * sizeof(uint32_t));
+    uint32_t* key = (uint32_t*)malloc((size_t)Vw * sizeof(uint32_t));
+    uint32_t S = 0;
+    for (uint32_t w = 0; w < win_num; w++) {
+        int n = (int)vcnt[w];
+        int ns = (int)ceilf((float)n / L);                                 /* :335 */
+        if (S + (uint32_t)ns > (uint32_t)MW) break;    /* capacity guard the reference lacks (:337) */
+        const uint32_t* g = gidx + (size_t)w * Vw;
+        const uint32_t* cw = cinw + (size_t)w * Vw * 3;
+        for (int m = 0; m < n; m++) {                                      /* sortY :382-388 */
+            sy[m] = g[m];
+            key[m] = cw[m * 3 + 1] * (uint32_t)(c->win_x * c->win_z) + cw[m * 3 + 2] * (uint32_t)c->win_z + cw[m * 3 + 0];
+        }
+        orc_quicksort(sy, key, 0, n - 1);                                  /* :425 */
+        for (int m = 0; m < n; m++) {                                      /* sortX :457-463 */
+            sx[m] = g[m];
+            key[m] = cw[m * 3 + 2] * (uint32_t)(c->win_y * c->win_z) + cw[m * 3 + 1] * (uint32_t)c->win_z + cw[m * 3 + 0];
+        }
+        orc_quicksort(sx, key, 0, n - 1);                                  /* :498 */
+        for (int j = 0; j < ns; j++) {
+            uint32_t s = S + (uint32_t)j;
+            for (int k = 0; k < L; k++) {
+                int local = (j * L + k) * n / L / ns;                      /* :346, paper eq.(3), int arithmetic */
+                inds[(size_t)0 * MW * L + (size_t)s * L + k] = sy[local];  /* :535-538 */
+                inds[(size_t)1 * MW * L + (size_t)s * L + k] = sx[local];
+            }
+            for (int a = 0; a < 2; a++)                                    /* :544-565 */
+                for (int k = 0; k < L; k++) {
+                    const uint32_t* r = inds + (size_t)a * MW * L + (size_t)s * L;
+                    float mv = (k > 0 && r[k] == r[k - 1]) ? -3.4028235e+38f : 0.0f;
+                    mask[(size_t)a * MW * L + (size_t)s * L + k] = mv;
+                }
+            for (int k = 0; k < L; k++)                                    /* splitAndExpandMask :589-606 */
+                for (int h = 0; h < H; h++) {
+                    mask0_h[((size_t)s * H + h) * L + k] = mask[(size_t)0 * MW * L + (size_t)s * L + k];
+                    mask1_h[((size_t)s * H + h) * L + k] = mask[(size_t)1 * MW * L + (size_t)s * L + k];
+                }
+        }
+        S += (uint32_t)ns;
+    }
+    *set_num = S;
+    free(sy); free(sx); free(key);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* GetValueByIndex: plugins/src/getValueByIndex.cu:282-355                     */
+ORC_API int orc_get_value_by_index(const float* feat, const float* pos, const uint32_t* inds,
+                                   uint32_t set_num, int max_win_num, int L, int C, int axis_id,
+                                   float* q, float* k, float* v /* each [max_win, L, C] */)
+{
+    size_t total = (size_t)max_win_num * L * C;
+    memset(q, 0, total * sizeof(float)); memset(k, 0, total * sizeof(float)); memset(v, 0, total * sizeof(float)); /* :347-349 */
+    const uint32_t* ind = inds + (size_t)axis_id * max_win_num * L;        /* :292 */
+    for (size_t r = 0; r < (size_t)set_num * L; r++) {
+        uint32_t vid = ind[r];
+        for (int ch = 0; ch < C; ch++) {
+            float f = feat[(size_t)vid * C + ch], p = pos[(size_t)vid * C + ch];
+            q[r * C + ch] = f + p;                                          /* :299-301 */
+            k[r * C + ch] = f + p;
+            v[r * C + ch] = f;
+        }
+    }
+    return 0;
+}
+
+/* MapSetFeature2Voxel: plugins/src/mapSetFeature2voxel.cu:258-320              */
+ORC_API int orc_map_set_feature2voxel(const float* set_feat, const uint32_t* inds, uint32_t set_num,
+                                      int max_win_num, int L, int C, int axis_id, int max_pillars_num,
+                                      float* out /* [max_pillars, C] */)
+{
+    memset(out, 0, (size_t)max_pillars_num * C * sizeof(float));           /* :314 */
+    const uint32_t* ind = inds + (size_t)axis_id * max_win_num * L;        /* :265 */
+    for (size_t r = 0; r < (size_t)set_num * L; r++)                        /* serial order: last writer = highest slot; */
+        memcpy(out + (size_t)ind[r] * C, set_feat + r * C, (size_t)C * sizeof(float));  /* duplicates carry equal rows :271-273 */
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* LayerNorm: plugins/src/layerNorm.cu:261-402 (eps is 0 in effect, see       */
+/* creator advertises "pes", factory sends "eps")           */
+ORC_API int orc_layer_norm(const float* in, uint32_t voxel_num, int max_pillars_num, int C, float eps,
+                           const float* gamma, const float* beta, float* out)
+{
+    memset(out, 0, (size_t)max_pillars_num * C * sizeof(float));           /* :395 */
+    for (uint32_t p = 0; p < voxel_num; p++) {
+        const float* x = in + (size_t)p * C;
+        float avg = 0.0f;
+        for (int j = 0; j < C; j++) avg += x[j];                            /* :304-307 */
+        float mean = avg / C;                                               /* :308 */
+        float var = 0.0f;
+        for (int j = 0; j < C; j++) var += (x[j] - mean) * (x[j] - mean);   /* :333-336 */
+        var = var / C;                                                      /* :337 */
+        for (int j = 0; j < C; j++) {
+            float t = (x[j] - mean) / sqrtf(var + eps);                     /* :274 */
+            t *= gamma[j]; t += beta[j];                                    /* :275-276 */
+            out[(size_t)p * C + j] = t;
+        }
+    }
+    return 0;
+}
+
+/* GeLU: plugins/src/gelu.cu:201-250, constants include/params.h:75-77 (double) */
+ORC_API int orc_gelu(const float* in, uint32_t voxel_num, int max_pillars_num, int C, float* out)
+{
+    const double GELU_A = 0.5, GELU_B = 0.7978845608028654, GELU_C = 0.035677408136300125;
+    memset(out, 0, (size_t)max_pillars_num * C * sizeof(float));           /* :245 */
+    for (size_t i = 0; i < (size_t)voxel_num * C; i++) {
+        float x = in[i];
+        out[i] = (float)((GELU_A + GELU_A * tanh(x * (GELU_C * x * x + GELU_B))) * x);   /* :208-209 */
+    }
+    return 0;
+}
+
+/* Map2Bev: plugins/src/map2bev.cu:250-310                                     */
+ORC_API int orc_map2bev(const float* feat, const uint32_t* coords, uint32_t voxel_num, int C,
+                        int gx, int gy, float* bev /* [gy, gx, C] */)
+{
+    memset(bev, 0, (size_t)gx * gy * C * sizeof(float));                    /* :303 */
+    for (uint32_t p = 0; p < voxel_num; p++) {
+        uint32_t y = coords[p * 4 + 2], x = coords[p * 4 + 3];              /* :259-261 */
+        memcpy(bev + ((size_t)y * gx + x) * C, feat + (size_t)p * C, (size_t)C * sizeof(float));   /* :264 */
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* FilterBoxByScore: plugins/src/filterBoxByScore.cu:266-379.  range order    */
+/* here is (xmin,xmax,ymin,ymax,zmin,zmax) as serialized (:420-435).          */
+ORC_API int orc_filter_box_by_score(const float* scores, const uint32_t* classes, const uint32_t* xs,
+                                    const uint32_t* ys, const float* center, const float* center_z,
+                                    const float* angle, const float* dim, int max_top_k,
+                                    float min_x, float max_x, float min_y, float max_y, float min_z, float max_z,
+                                    float vx, float vy, float score_threshold,
+                                    float* out /* [max_top_k, 9] */, uint32_t* valid_num)
+{
+    memset(out, 0, (size_t)max_top_k * 9 * sizeof(float));                 /* :361 */
+    uint32_t n = 0;
+    for (int i = 0; i < max_top_k; i++) {       /* reference launches 512 threads for 500 rows; rows >= top_k are OOB there */
+        float score = scores[i];
+        float nx = (float)xs[i] + center[i * 2 + 0];                        /* :278-279 */
+        float ny = (float)ys[i] + center[i * 2 + 1];
+        nx = nx * vx + min_x;                                               /* :280-281 */
+        ny = ny * vy + min_y;
+        float cz = center_z[i];
+        if (!(nx >= min_x && nx < max_x && ny >= min_y && ny < max_y && cz >= min_z && cz < max_z)) continue;   /* :287-291 */
+        if (score >= score_threshold) {                                     /* :293 */
+            float* o = out + (size_t)n * 9;                                 /* :295 atomicAdd -> candidate order */
+            o[0] = nx; o[1] = ny; o[2] = cz;
+            o[3] = dim[i * 3 + 0]; o[4] = dim[i * 3 + 1]; o[5] = dim[i * 3 + 2];
+            o[6] = angle[i];
+            o[7] = (float)classes[i];                                       /* :305 uint -> float */
+            o[8] = scores[i];
+            n++;
+        }
+    }
+    *valid_num = n;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Host post-processing: include/helper.h:93-283 (rotated BEV NMS), :470-481   */
+typedef struct { float x, y, z, w, l, h, rt; int id; float score; } orc_bndbox;   /* helper.h:93-106 */
+typedef struct { float x, y; } orc_f2;
+static const float ORC_THRESH = 1e-8f;                                             /* helper.h:26 */
+
+static inline float orc_cross(orc_f2 p1, orc_f2 p2, orc_f2 p0)                     /* :109-111 */
+{ return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y); }
+
+static inline int orc_check_box2d(const orc_bndbox* box, orc_f2 p)                 /* :113-123 */
+{
+    const float MARGIN = 1e-2f;
+    float angle_cos = (float)cos(-box->rt), angle_sin = (float)sin(-box->rt);
+    float rot_x = (p.x - box->x) * angle_cos + (p.y - box->y) * (-angle_sin);
+    float rot_y = (p.x - box->x) * angle_sin + (p.y - box->y) * angle_cos;
+    return (fabs(rot_x) < box->w / 2 + MARGIN && fabs(rot_y) < box->l / 2 + MARGIN);
+}
+
+static inline float fminf2(float a, float b) { return a < b ? a : b; }
+static inline float fmaxf2(float a, float b) { return a > b ? a : b; }
+
+static int orc_intersection(orc_f2 p1, orc_f2 p0, orc_f2 q1, orc_f2 q0, orc_f2* ans)  /* :125-156 */
+{
+    if ((fminf2(p0.x, p1.x) <= fmaxf2(q0.x, q1.x) && fminf2(q0.x, q1.x) <= fmaxf2(p0.x, p1.x) &&
+         fminf2(p0.y, p1.y) <= fmaxf2(q0.y, q1.y) && fminf2(q0.y, q1.y) <= fmaxf2(p0.y, p1.y)) == 0)
+        return 0;
+    float s1 = orc_cross(q0, p1, p0), s2 = orc_cross(p1, q1, p0);
+    float s3 = orc_cross(p0, q1, q0), s4 = orc_cross(q1, p1, q0);
+    if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0;
+    float s5 = orc_cross(q1, p1, p0);
+    if (fabs(s5 - s1) > ORC_THRESH) {
+        ans->x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+        ans->y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+    } else {
+        float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+        float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+        float D = a0 * b1 - a1 * b0;
+        ans->x = (b0 * c1 - b1 * c0) / D;
+        ans->y = (a1 * c0 - a0 * c1) / D;
+    }
+    return 1;
+}
+
+static inline void orc_rotate(orc_f2 c, float ac, float as, orc_f2* p)             /* :158-163 */
+{
+    float nx = (p->x - c.x) * ac + (p->y - c.y) * (-as) + c.x;
+    float ny = (p->x - c.x) * as + (p->y - c.y) * ac + c.y;
+    p->x = nx; p->y = ny;
+}
+
+static float orc_box_overlap(const orc_bndbox* a, const orc_bndbox* b)             /* :166-255 */
+{
+    float a_dx = a->w / 2, b_dx = b->w / 2, a_dy = a->l / 2, b_dy = b->l / 2;
+    orc_f2 ac[5], bc[5], cp[16], pc = {0, 0}, ca = {a->x, a->y}, cb = {b->x, b->y};
+    int cnt = 0;
+    ac[0] = (orc_f2){a->x - a_dx, a->y - a_dy}; ac[1] = (orc_f2){a->x + a_dx, a->y - a_dy};
+    ac[2] = (orc_f2){a->x + a_dx, a->y + a_dy}; ac[3] = (orc_f2){a->x - a_dx, a->y + a_dy};
+    bc[0] = (orc_f2){b->x - b_dx, b->y - b_dy}; bc[1] = (orc_f2){b->x + b_dx, b->y - b_dy};
+    bc[2] = (orc_f2){b->x + b_dx, b->y + b_dy}; bc[3] = (orc_f2){b->x - b_dx, b->y + b_dy};
+    float a_cos = (float)cos(a->rt), a_sin = (float)sin(a->rt);
+    float b_cos = (float)cos(b->rt), b_sin = (float)sin(b->rt);
+    for (int k = 0; k < 4; k++) { orc_rotate(ca, a_cos, a_sin, &ac[k]); orc_rotate(cb, b_cos, b_sin, &bc[k]); }
+    ac[4] = ac[0]; bc[4] = bc[0];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            if (orc_intersection(ac[i + 1], ac[i], bc[j + 1], bc[j], &cp[cnt])) {
+                pc.x += cp[cnt].x; pc.y += cp[cnt].y; cnt++;
+            }
+    for (int k = 0; k < 4; k++) {
+        if (orc_check_box2d(a, bc[k])) { pc.x += bc[k].x; pc.y += bc[k].y; cp[cnt++] = bc[k]; }
+        if (orc_check_box2d(b, ac[k])) { pc.x += ac[k].x; pc.y += ac[k].y; cp[cnt++] = ac[k]; }
+    }
+    pc.x /= cnt; pc.y /= cnt;
+    for (int j = 0; j < cnt - 1; j++)
+        for (int i = 0; i < cnt - j - 1; i++)
+            if (atan2(cp[i].y - pc.y, cp[i].x - pc.x) > atan2(cp[i + 1].y - pc.y, cp[i + 1].x - pc.x)) {
+                orc_f2 t = cp[i]; cp[i] = cp[i + 1]; cp[i + 1] = t;
+            }
+    float area = 0;
+    for (int k = 0; k < cnt - 1; k++) {
+        orc_f2 u = {cp[k].x - cp[0].x, cp[k].y - cp[0].y}, v = {cp[k + 1].x - cp[0].x, cp[k + 1].y - cp[0].y};
+        area += (u.x * v.y - u.y * v.x);
+    }
+    return (float)(fabs(area) / 2.0);
+}
+
+ORC_API float orc_box_overlap_rows(const float* a9, const float* b9)
+{
+    orc_bndbox a = {a9[0], a9[1], a9[2], a9[4], a9[3], a9[5], a9[6], (int)a9[7], a9[8]};
+    orc_bndbox b = {b9[0], b9[1], b9[2], b9[4], b9[3], b9[5], b9[6], (int)b9[7], b9[8]};
+    return orc_box_overlap(&a, &b);
+}
+
+/* save_result (helper.h:470-481: dim0->l, dim1->w) + nms_cpu (helper.h:257-283).
+ * std::sort in the reference is unstable; ties are resolved here by input row
+ * order (stable), which is one of the orders the reference may produce.
+ * out_rows: 9 floats per kept box as save_txt prints them: x,y,z,l,w,h,rt,id,score
+ * (helper.h:452-460).  keep_idx: input row of each kept box. */
+ORC_API int orc_nms_cpu(const float* boxes9, int n, float nms_thresh, float* out_rows, int32_t* keep_idx)
+{
+    orc_bndbox* bb = (orc_bndbox*)malloc((size_t)(n ? n : 1) * sizeof(orc_bndbox));
+    int32_t* order = (int32_t*)malloc((size_t)(n ? n : 1) * sizeof(int32_t));
+    for (int i = 0; i < n; i++) {
+        const float* o = boxes9 + (size_t)i * 9;
+        bb[i] = (orc_bndbox){o[0], o[1], o[2], o[4], o[3], o[5], o[6], (int)o[7], o[8]};
+        order[i] = i;
+    }
+    for (int i = 1; i < n; i++) {              /* stable insertion sort, score descending */
+        int32_t t = order[i]; int j = i - 1;
+        while (j >= 0 && bb[order[j]].score < bb[t].score) { order[j + 1] = order[j]; j--; }
+        order[j + 1] = t;
+    }
+    uint8_t* sup = (uint8_t*)calloc((size_t)(n ? n : 1), 1);
+    int kept = 0;
+    for (int i = 0; i < n; i++) {
+        if (sup[i]) continue;
+        const orc_bndbox* bi = &bb[order[i]];
+        float* r = out_rows + (size_t)kept * 9;
+        r[0] = bi->x; r[1] = bi->y; r[2] = bi->z; r[3] = bi->l; r[4] = bi->w; r[5] = bi->h;
+        r[6] = bi->rt; r[7] = (float)bi->id; r[8] = bi->score;
+        keep_idx[kept++] = order[i];
+        for (int j = i + 1; j < n; j++) {
+            if (sup[j]) continue;
+            const orc_bndbox* bj = &bb[order[j]];
+            float sa = bi->w * bi->l, sb = bj->w * bj->l;
+            float so = orc_box_overlap(bi, bj);
+            float iou = so / fmaxf(sa + sb - so, ORC_THRESH);
+            if (iou >= nms_thresh) sup[j] = 1;
+        }
+    }
+    free(bb); free(order); free(sup);
+    return kept;
+}
