@@ -1,0 +1,70 @@
+"""Builds libdsvt_hip.so (gfx950) in-tree with hipcc.  No JIT cache: the .so sits next to this
+file so that it travels with the source snapshot."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libdsvt_hip.so")
+OBJ = os.path.join(HERE, "build")
+
+# (source, extra flags).  -ffp-contract=off where results must follow the reference's
+# expression order (cell indices, features, LayerNorm); the MFMA kernels use explicit fma.
+SOURCES = [
+    ("c_api.hip", []),
+    ("points2features.hip", ["-ffp-contract=off"]),
+    ("pillar_ops.hip", ["-ffp-contract=off"]),
+    ("partition_ops.hip", ["-ffp-contract=off"]),
+    ("linear.hip", []),
+    ("attention.hip", []),
+]
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math",
+          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(HERE, "..", "include", "dsvt_plugin.h"))
+    objs = []
+    procs = []
+    for src, extra in SOURCES:
+        s = os.path.join(CSRC, src)
+        if not os.path.exists(s):
+            continue
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            cmd = [hipcc()] + COMMON + extra + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
+        if verbose and out:
+            print(out.decode(), file=sys.stderr)
+    if force or procs or _stale(OUT, objs):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,61 @@
+// device_utils.h -- small wave64 / workgroup primitives shared by the HIP kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace dsvt {
+
+constexpr int kWave = 64;   // CDNA wavefront width
+
+__device__ __forceinline__ int laneId() { return threadIdx.x & (kWave - 1); }
+
+template <class T> __device__ __forceinline__ T waveSum(T v) {
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+__device__ __forceinline__ uint32_t waveMinU(uint32_t v) {
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o, kWave); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ float waveMaxF(float v) {
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+    return v;
+}
+
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v) {
+    const int lane = laneId();
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        uint32_t t = __shfl_up(v, o, kWave);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// Exclusive scan of one uint32 per thread over a workgroup of NT threads (NT multiple of 64,
+// <= 1024).  `smem` needs NT/64 + 1 words.  Returns the exclusive prefix; *total = sum.
+template <int NT>
+__device__ __forceinline__ uint32_t blockExclusiveScan(uint32_t v, uint32_t* smem, uint32_t* total) {
+    constexpr int NW = NT / kWave;
+    const int lane = laneId(), wave = threadIdx.x / kWave;
+    uint32_t inc = waveInclusiveScan(v);
+    if (lane == kWave - 1) smem[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t w = lane < NW ? smem[lane] : 0;
+        uint32_t wi = waveInclusiveScan(w);
+        if (lane < NW) smem[lane] = wi - w;
+        if (lane == NW - 1) smem[NW] = wi;
+    }
+    __syncthreads();
+    uint32_t res = smem[wave] + inc - v;
+    *total = smem[NW];
+    __syncthreads();
+    return res;
+}
+
+}  // namespace dsvt

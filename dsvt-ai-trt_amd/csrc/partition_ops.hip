@@ -1,0 +1,419 @@
+// partition_ops.hip -- rotated-set partitioning for gfx950:
+//   WindowPartitionPlugin  plugins/src/windowPartition.cu:278-470
+//   GetSetPlugin           plugins/src/getSet.cu:267-704
+//
+// The reference assigns window ids with an atomic counter plus a spin-wait hack
+// (windowPartition.cu:308-331, a real data race) and sorts each window with a per-THREAD
+// iterative quicksort on 4.6 kB of local memory (getSet.cu:293-324, <=406 threads active on
+// the whole GPU).  Here nothing depends on arrival order:
+//   * windows are numbered by an exclusive scan over the dense window grid (ascending
+//     window linear id); a window's voxels are ordered by voxel id with a workgroup bitonic
+//     sort in LDS (= the serial arrival order of the reference);
+//   * the two per-window sorts use the fact that the in-window keys are unique and smaller
+//     than the window volume: each voxel is dropped into an LDS table at its key and the
+//     table is compacted with a workgroup scan -- no comparison sort at all;
+//   * set bases come from a scan over windows (ascending (window, j)).
+// All integer work; results are bit-exact against the oracle.
+#include "plugin_base.h"
+#include "device_utils.h"
+
+namespace dsvt {
+
+constexpr uint32_t kNoneU = 0xffffffffu;
+static bool f32L(const DsvtPluginTensorDesc& t) { return t.type == DSVT_FLOAT && t.format == DSVT_FORMAT_LINEAR; }
+static bool i32L(const DsvtPluginTensorDesc& t) { return t.type == DSVT_INT32 && t.format == DSVT_FORMAT_LINEAR; }
+
+struct WPParams {
+    int max_win_num, max_voxel_num_per_win;
+    int sx, sy, sz;       // sparse_shape
+    int wx, wy, wz;       // win_shape
+    int hx, hy, hz;       // shift_list
+    int nwx, nwy, nwz;    // dense window grid (windowPartition.cu:425-427)
+};
+
+__device__ __forceinline__ void winOf(const uint4 co, const WPParams& p, uint32_t& win, uint32_t& ix, uint32_t& iy, uint32_t& iz) {
+    uint32_t x = co.w + (uint32_t)p.hx, y = co.z + (uint32_t)p.hy, z = co.y + (uint32_t)p.hz;       // :292-294
+    uint32_t cx = x / (uint32_t)p.wx, cy = y / (uint32_t)p.wy, cz = z / (uint32_t)p.wz;            // :296-298
+    win = cz * (uint32_t)(p.nwy * p.nwx) + cy * (uint32_t)p.nwx + cx;                               // :301
+    if (cx >= (uint32_t)p.nwx || cy >= (uint32_t)p.nwy || cz >= (uint32_t)p.nwz) win = kNoneU;      // outside the dense grid
+    ix = x % (uint32_t)p.wx; iy = y % (uint32_t)p.wy; iz = z % (uint32_t)p.wz;                      // :352-354
+}
+
+__global__ void __launch_bounds__(256)
+wp_count(const uint4* __restrict__ coords, const uint32_t* __restrict__ voxel_num, int max_pillars, WPParams p,
+         uint32_t* __restrict__ win_cnt, uint32_t* __restrict__ vox_win, uint32_t* __restrict__ vox_slot)
+{
+    uint32_t n = *voxel_num; if (n > (uint32_t)max_pillars) n = max_pillars;
+    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    uint32_t win, ix, iy, iz;
+    winOf(coords[v], p, win, ix, iy, iz);
+    vox_win[v] = win;
+    vox_slot[v] = win == kNoneU ? 0u : atomicAdd(&win_cnt[win], 1u);     // count only; order fixed in wp_fill
+}
+
+// single workgroup: scan the dense window grid
+__global__ void __launch_bounds__(1024)
+wp_scan(const uint32_t* __restrict__ win_cnt, int dense, WPParams p, uint32_t* __restrict__ win_seg,
+        uint32_t* __restrict__ rank2win, uint32_t* __restrict__ vcnt, uint32_t* __restrict__ win_num, bool zero_fill)
+{
+    __shared__ uint32_t smem[1024 / kWave + 1];
+    uint32_t carry_o = 0, carry_f = 0;
+    for (int b = 0; b < dense; b += 1024) {
+        int w = b + threadIdx.x;
+        uint32_t c = w < dense ? win_cnt[w] : 0, tot;
+        uint32_t eo = blockExclusiveScan<1024>(c > 0 ? 1u : 0u, smem, &tot) + carry_o; carry_o += tot;
+        uint32_t ef = blockExclusiveScan<1024>(c, smem, &tot) + carry_f; carry_f += tot;
+        if (w < dense) {
+            win_seg[w] = ef;
+            if (c > 0 && eo < (uint32_t)p.max_win_num) {          // capacity guard the reference lacks (:311)
+                rank2win[eo] = (uint32_t)w;
+                vcnt[eo] = c > (uint32_t)p.max_voxel_num_per_win ? (uint32_t)p.max_voxel_num_per_win : c;    // :336-340
+            }
+        }
+    }
+    uint32_t W = carry_o < (uint32_t)p.max_win_num ? carry_o : (uint32_t)p.max_win_num;
+    if (zero_fill) for (uint32_t r = W + threadIdx.x; r < (uint32_t)p.max_win_num; r += 1024) vcnt[r] = 0;
+    if (threadIdx.x == 0) *win_num = W;
+}
+
+__global__ void __launch_bounds__(256)
+wp_scatter(const uint32_t* __restrict__ voxel_num, int max_pillars, const uint32_t* __restrict__ vox_win,
+           const uint32_t* __restrict__ vox_slot, const uint32_t* __restrict__ win_seg, uint32_t* __restrict__ sorted_vox)
+{
+    uint32_t n = *voxel_num; if (n > (uint32_t)max_pillars) n = max_pillars;
+    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    uint32_t w = vox_win[v];
+    if (w != kNoneU) sorted_vox[win_seg[w] + vox_slot[v]] = v;
+}
+
+// workgroup bitonic sort of m (power of two) uint32 in LDS, ascending
+__device__ __forceinline__ void bitonicSortLds(uint32_t* a, int m) {
+    for (int k = 2; k <= m; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < m; i += blockDim.x) {
+                int l = i ^ j;
+                if (l > i) {
+                    uint32_t x = a[i], y = a[l];
+                    bool up = (i & k) == 0;
+                    if ((x > y) == up) { a[i] = y; a[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+// one workgroup per non-empty window (rank order)
+__global__ void __launch_bounds__(256)
+wp_fill(const uint4* __restrict__ coords, WPParams p, const uint32_t* __restrict__ win_num, const uint32_t* __restrict__ rank2win,
+        const uint32_t* __restrict__ win_cnt, const uint32_t* __restrict__ win_seg, const uint32_t* __restrict__ sorted_vox,
+        uint32_t* __restrict__ gidx, uint32_t* __restrict__ cinw, uint32_t* __restrict__ c2d, float* __restrict__ xy)
+{
+    extern __shared__ uint32_t lds[];
+    const uint32_t r = blockIdx.x;
+    if (r >= *win_num) return;
+    const uint32_t w = rank2win[r], n = win_cnt[w], seg = win_seg[w];
+    int m = 1; while ((uint32_t)m < n) m <<= 1;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) lds[i] = (uint32_t)i < n ? sorted_vox[seg + i] : kNoneU;
+    __syncthreads();
+    bitonicSortLds(lds, m);
+    const uint32_t Vw = p.max_voxel_num_per_win;
+    for (uint32_t s = threadIdx.x; s < n; s += blockDim.x) {
+        uint32_t v = lds[s], win, ix, iy, iz;
+        winOf(coords[v], p, win, ix, iy, iz);
+        if (s < Vw) {                                                                  // :305
+            gidx[(size_t)r * Vw + s] = v;                                              // :343-344
+            uint32_t* c = cinw + ((size_t)r * Vw + s) * 3;
+            c[0] = iz; c[1] = iy; c[2] = ix;                                           // :357-359
+            c2d[(size_t)v * 3 + 0] = iz; c2d[(size_t)v * 3 + 1] = iy; c2d[(size_t)v * 3 + 2] = ix;   // :362-364
+            xy[(size_t)v * 2 + 0] = (float)ix - (float)p.wx / 2;                       // :367-368
+            xy[(size_t)v * 2 + 1] = (float)iy - (float)p.wy / 2;
+        } else {                                                                       // dropped voxel: the reference returns early
+            c2d[(size_t)v * 3 + 0] = 0; c2d[(size_t)v * 3 + 1] = 0; c2d[(size_t)v * 3 + 2] = 0;
+            xy[(size_t)v * 2 + 0] = 0.f; xy[(size_t)v * 2 + 1] = 0.f;
+        }
+    }
+}
+
+class WindowPartitionPlugin : public Plugin {
+public:
+    WPParams p_;
+    explicit WindowPartitionPlugin(const WPParams& p) : p_(p) {}
+    const char* type() const override { return "WindowPartitionPlugin"; }
+    int nbOutputs() const override { return 6; }
+    int dense() const { return p_.nwx * p_.nwy * p_.nwz; }
+    int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {    // windowPartition.cu: getOutputDimensions
+        int b = in[0].d[0], mp = in[0].d[1];          // reference: MAX_PILLARS_NUM macro; here the coords tensor's row count
+        switch (i) {
+            case 0: *out = dims3(b, p_.max_win_num, p_.max_voxel_num_per_win); return 0;
+            case 1: *out = dims4(b, p_.max_win_num, p_.max_voxel_num_per_win, 3); return 0;
+            case 2: *out = dims2(b, p_.max_win_num); return 0;
+            case 3: *out = dims1(b); return 0;
+            case 4: *out = dims3(b, mp, 3); return 0;
+            case 5: *out = dims3(b, mp, 2); return 0;
+        }
+        return -1;
+    }
+    int outputType(int i, const int32_t*, int) const override { return i == 5 ? DSVT_FLOAT : DSVT_INT32; }
+    bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int, int) const override {
+        return pos == 7 ? f32L(io[pos]) : pos >= 0 && pos <= 6 && i32L(io[pos]);
+    }
+    size_t workspaceSize(const DsvtPluginTensorDesc* in, int, const DsvtPluginTensorDesc*, int) const override {
+        int mp = in[0].dims.d[1];
+        return 2 * alignUp(sizeof(uint32_t) * dense()) + alignUp(sizeof(uint32_t) * p_.max_win_num) + 3 * alignUp(sizeof(uint32_t) * mp);
+    }
+    int enqueue(const DsvtPluginTensorDesc* inDesc, const DsvtPluginTensorDesc*, const void* const* in, void* const* out,
+                void* workspace, hipStream_t stream) override {
+        const int mp = inDesc[0].dims.d[1];
+        const uint4* coords = static_cast<const uint4*>(in[0]);
+        const uint32_t* voxel_num = static_cast<const uint32_t*>(in[1]);
+        uint32_t* gidx = static_cast<uint32_t*>(out[0]);
+        uint32_t* cinw = static_cast<uint32_t*>(out[1]);
+        uint32_t* vcnt = static_cast<uint32_t*>(out[2]);
+        uint32_t* win_num = static_cast<uint32_t*>(out[3]);
+        uint32_t* c2d = static_cast<uint32_t*>(out[4]);
+        float* xy = static_cast<float*>(out[5]);
+        WsCarver ws(workspace);
+        uint32_t* win_cnt = ws.take<uint32_t>(dense());
+        uint32_t* win_seg = ws.take<uint32_t>(dense());
+        uint32_t* rank2win = ws.take<uint32_t>(p_.max_win_num);
+        uint32_t* vox_win = ws.take<uint32_t>(mp);
+        uint32_t* vox_slot = ws.take<uint32_t>(mp);
+        uint32_t* sorted_vox = ws.take<uint32_t>(mp);
+        DSVT_CHECK(hipMemsetAsync(win_cnt, 0, sizeof(uint32_t) * dense(), stream));
+        if (zeroFill) {                                                                // :445-450
+            size_t wv = (size_t)p_.max_win_num * p_.max_voxel_num_per_win;
+            DSVT_CHECK(hipMemsetAsync(gidx, 0, sizeof(uint32_t) * wv, stream));
+            DSVT_CHECK(hipMemsetAsync(cinw, 0, sizeof(uint32_t) * wv * 3, stream));
+            DSVT_CHECK(hipMemsetAsync(c2d, 0, sizeof(uint32_t) * (size_t)mp * 3, stream));
+            DSVT_CHECK(hipMemsetAsync(xy, 0, sizeof(float) * (size_t)mp * 2, stream));
+        }
+        hipLaunchKernelGGL(wp_count, dim3(cdiv(mp, 256)), dim3(256), 0, stream, coords, voxel_num, mp, p_, win_cnt, vox_win, vox_slot);
+        hipLaunchKernelGGL(wp_scan, dim3(1), dim3(1024), 0, stream, win_cnt, dense(), p_, win_seg, rank2win, vcnt, win_num, zeroFill);
+        hipLaunchKernelGGL(wp_scatter, dim3(cdiv(mp, 256)), dim3(256), 0, stream, voxel_num, mp, vox_win, vox_slot, win_seg, sorted_vox);
+        int vol = p_.wx * p_.wy * p_.wz, cap = 1; while (cap < vol) cap <<= 1;
+        hipLaunchKernelGGL(wp_fill, dim3(p_.max_win_num), dim3(256), sizeof(uint32_t) * cap, stream, coords, p_, win_num, rank2win,
+                           win_cnt, win_seg, sorted_vox, gidx, cinw, c2d, xy);
+        return lastError();
+    }
+    size_t serializationSize() const override { return 11 * sizeof(int); }
+    void serialize(void* b) const override {                                           // windowPartition.cu:511-525
+        char* d = static_cast<char*>(b);
+        wr<int>(d, p_.sx); wr<int>(d, p_.sy); wr<int>(d, p_.sz); wr<int>(d, p_.wx); wr<int>(d, p_.wy); wr<int>(d, p_.wz);
+        wr<int>(d, p_.hx); wr<int>(d, p_.hy); wr<int>(d, p_.hz); wr<int>(d, p_.max_win_num); wr<int>(d, p_.max_voxel_num_per_win);
+    }
+    Plugin* clone() const override { return new WindowPartitionPlugin(p_); }
+};
+static Plugin* wpNew(WPParams p) {
+    if (p.max_win_num <= 0 || p.max_voxel_num_per_win <= 0 || p.wx <= 0 || p.wy <= 0 || p.wz <= 0 ||
+        p.sx <= 0 || p.sy <= 0 || p.sz <= 0 || p.hx < 0 || p.hy < 0 || p.hz < 0) return nullptr;
+    if ((long)p.wx * p.wy * p.wz > 8192) return nullptr;           // LDS sort capacity
+    // windowPartition.cu:425-427: int(ceilf(shape / win) + 1) with INTEGER division inside
+    p.nwx = (int)(ceilf((float)(p.sx / p.wx)) + 1);
+    p.nwy = (int)(ceilf((float)(p.sy / p.wy)) + 1);
+    p.nwz = (int)(ceilf((float)(p.sz / p.wz)) + 1);
+    return new WindowPartitionPlugin(p);
+}
+static Plugin* wpCreate(const DsvtPluginFieldCollection* fc) {
+    WPParams p{}; int s[3], w[3], h[3];
+    p.max_win_num = fieldInt(fc, "max_win_num"); p.max_voxel_num_per_win = fieldInt(fc, "max_voxel_num_per_win");
+    fieldInts(fc, "sparse_shape", s, 3); fieldInts(fc, "win_shape", w, 3); fieldInts(fc, "shift_list", h, 3);
+    p.sx = s[0]; p.sy = s[1]; p.sz = s[2]; p.wx = w[0]; p.wy = w[1]; p.wz = w[2]; p.hx = h[0]; p.hy = h[1]; p.hz = h[2];
+    return wpNew(p);
+}
+static Plugin* wpDeser(const void* data, size_t len) {
+    if (len < 11 * sizeof(int)) return nullptr;
+    const char* d = static_cast<const char*>(data); WPParams p{};
+    p.sx = rd<int>(d); p.sy = rd<int>(d); p.sz = rd<int>(d); p.wx = rd<int>(d); p.wy = rd<int>(d); p.wz = rd<int>(d);
+    p.hx = rd<int>(d); p.hy = rd<int>(d); p.hz = rd<int>(d); p.max_win_num = rd<int>(d); p.max_voxel_num_per_win = rd<int>(d);
+    return wpNew(p);
+}
+static Creator g_wpCreator{"WindowPartitionPlugin",
+    {{"max_win_num", DSVT_FIELD_INT32}, {"max_voxel_num_per_win", DSVT_FIELD_INT32}, {"sparse_shape", DSVT_FIELD_INT32},
+     {"win_shape", DSVT_FIELD_INT32}, {"shift_list", DSVT_FIELD_INT32}},               // :549-553
+    wpCreate, wpDeser, {}, {}};
+static Registrar g_wpReg(&g_wpCreator);
+
+// =====================================================================================
+// GetSet
+// =====================================================================================
+struct GSParams { int max_win_num, max_voxel_num_per_win, voxel_num_set, wx, wy, wz, num_heads; };
+
+__device__ __forceinline__ uint32_t setsOf(uint32_t n, uint32_t L) { return (uint32_t)(int)ceilf((float)n / (float)(int)L); }   // getSet.cu:335
+
+// single workgroup: set base of every window
+__global__ void __launch_bounds__(1024)
+gs_scan(const uint32_t* __restrict__ vcnt, const uint32_t* __restrict__ win_num, GSParams p, uint32_t* __restrict__ set_base,
+        uint32_t* __restrict__ set_num)
+{
+    __shared__ uint32_t smem[1024 / kWave + 1];
+    __shared__ uint32_t smax;
+    if (threadIdx.x == 0) smax = 0;
+    __syncthreads();
+    uint32_t W = *win_num; if (W > (uint32_t)p.max_win_num) W = p.max_win_num;
+    uint32_t carry = 0;
+    for (uint32_t b = 0; b < W; b += 1024) {
+        uint32_t w = b + threadIdx.x, tot;
+        uint32_t ns = w < W ? setsOf(vcnt[w], p.voxel_num_set) : 0;
+        uint32_t base = blockExclusiveScan<1024>(ns, smem, &tot) + carry; carry += tot;
+        if (w < W) {
+            // capacity guard the reference lacks (:337): the set list stops at the first window that does not fit
+            bool ok = base + ns <= (uint32_t)p.max_win_num;
+            set_base[w] = ok ? base : kNoneU;
+            if (ok && ns) atomicMax(&smax, base + ns);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *set_num = smax;
+}
+
+// one workgroup per window
+__global__ void __launch_bounds__(256)
+gs_sets(const uint32_t* __restrict__ gidx, const uint32_t* __restrict__ cinw, const uint32_t* __restrict__ vcnt,
+        const uint32_t* __restrict__ win_num, const uint32_t* __restrict__ set_base, GSParams p,
+        uint32_t* __restrict__ inds, float* __restrict__ mask, float* __restrict__ mask0_h, float* __restrict__ mask1_h)
+{
+    extern __shared__ uint32_t lds[];
+    __shared__ uint32_t smem[256 / kWave + 1];
+    const uint32_t w = blockIdx.x;
+    uint32_t W = *win_num; if (W > (uint32_t)p.max_win_num) W = p.max_win_num;
+    if (w >= W) return;
+    const uint32_t base = set_base[w];
+    if (base == kNoneU) return;
+    const uint32_t Vw = p.max_voxel_num_per_win, L = p.voxel_num_set, MW = p.max_win_num;
+    const uint32_t n = vcnt[w] < Vw ? vcnt[w] : Vw;
+    const uint32_t vol = (uint32_t)(p.wx * p.wy * p.wz);
+    uint32_t* ty = lds;             // [vol]  key_y -> voxel id
+    uint32_t* tx = lds + vol;       // [vol]  key_x -> voxel id
+    uint32_t* sy = lds + 2 * vol;   // [Vw]   voxel ids ascending by key_y
+    uint32_t* sx = sy + Vw;         // [Vw]   voxel ids ascending by key_x
+    for (uint32_t i = threadIdx.x; i < vol; i += blockDim.x) { ty[i] = kNoneU; tx[i] = kNoneU; }
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { sy[i] = 0; sx[i] = 0; }
+    __syncthreads();
+    for (uint32_t m = threadIdx.x; m < n; m += blockDim.x) {
+        uint32_t v = gidx[(size_t)w * Vw + m];
+        const uint32_t* c = cinw + ((size_t)w * Vw + m) * 3;
+        uint32_t z = c[0], y = c[1], x = c[2];
+        uint32_t ky = y * (uint32_t)(p.wx * p.wz) + x * (uint32_t)p.wz + z;          // getSet.cu:386-387
+        uint32_t kx = x * (uint32_t)(p.wy * p.wz) + y * (uint32_t)p.wz + z;          // :461-462
+        if (ky < vol) ty[ky] = v;
+        if (kx < vol) tx[kx] = v;
+    }
+    __syncthreads();
+    // compact both tables in key order (ascending sort of unique keys)
+    uint32_t cy = 0, cx = 0;
+    for (uint32_t b = 0; b < vol; b += blockDim.x) {
+        uint32_t i = b + threadIdx.x, tot;
+        uint32_t vy = i < vol ? ty[i] : kNoneU, vx = i < vol ? tx[i] : kNoneU;
+        uint32_t ey = blockExclusiveScan<256>(vy != kNoneU ? 1u : 0u, smem, &tot) + cy; cy += tot;
+        uint32_t ex = blockExclusiveScan<256>(vx != kNoneU ? 1u : 0u, smem, &tot) + cx; cx += tot;
+        if (vy != kNoneU && ey < Vw) sy[ey] = vy;
+        if (vx != kNoneU && ex < Vw) sx[ex] = vx;
+    }
+    __syncthreads();
+    const uint32_t ns = setsOf(n, L);
+    const int ni = (int)n, Li = (int)L, nsi = (int)ns, H = p.num_heads;
+    for (uint32_t t = threadIdx.x; t < ns * L; t += blockDim.x) {
+        int j = (int)(t / L), k = (int)(t % L);
+        int local = (j * Li + k) * ni / Li / nsi;                                     // :346 paper eq.(3), int arithmetic
+        int prev = k > 0 ? (j * Li + k - 1) * ni / Li / nsi : -1;
+        size_t s = base + (uint32_t)j;
+        uint32_t iy = sy[local], ix = sx[local];
+        inds[(size_t)0 * MW * L + s * L + k] = iy;                                    // :535-538
+        inds[(size_t)1 * MW * L + s * L + k] = ix;
+        // :544-565 slot k>0 holding the same voxel as slot k-1 is a padding key
+        float my = (k > 0 && iy == sy[prev]) ? -3.4028235e+38f : 0.0f;
+        float mx = (k > 0 && ix == sx[prev]) ? -3.4028235e+38f : 0.0f;
+        mask[(size_t)0 * MW * L + s * L + k] = my;
+        mask[(size_t)1 * MW * L + s * L + k] = mx;
+        for (int h = 0; h < H; ++h) {                                                 // splitAndExpandMask :589-606
+            mask0_h[(s * H + h) * L + k] = my;
+            mask1_h[(s * H + h) * L + k] = mx;
+        }
+    }
+}
+
+class GetSetPlugin : public Plugin {
+public:
+    GSParams p_;
+    explicit GetSetPlugin(const GSParams& p) : p_(p) {}
+    const char* type() const override { return "GetSetPlugin"; }
+    int nbOutputs() const override { return 5; }
+    int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
+        int b = in[0].d[0];
+        switch (i) {
+            case 0: case 1: *out = dims4(b, 2, p_.max_win_num, p_.voxel_num_set); return 0;
+            case 2: *out = dims1(b); return 0;
+            case 3: case 4: *out = dims4(b, p_.max_win_num, p_.num_heads, p_.voxel_num_set); return 0;
+        }
+        return -1;
+    }
+    int outputType(int i, const int32_t*, int) const override { return (i == 1 || i == 3 || i == 4) ? DSVT_FLOAT : DSVT_INT32; }   // getSet.cu:706-713
+    bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int, int) const override {
+        if (pos == 5 || pos == 7 || pos == 8) return f32L(io[pos]);
+        return pos >= 0 && pos <= 6 && i32L(io[pos]);
+    }
+    size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override {
+        return alignUp(sizeof(uint32_t) * p_.max_win_num);
+    }
+    int enqueue(const DsvtPluginTensorDesc*, const DsvtPluginTensorDesc*, const void* const* in, void* const* out,
+                void* workspace, hipStream_t stream) override {
+        const uint32_t* gidx = static_cast<const uint32_t*>(in[0]);
+        const uint32_t* cinw = static_cast<const uint32_t*>(in[1]);
+        const uint32_t* vcnt = static_cast<const uint32_t*>(in[2]);
+        const uint32_t* win_num = static_cast<const uint32_t*>(in[3]);
+        uint32_t* inds = static_cast<uint32_t*>(out[0]);
+        float* mask = static_cast<float*>(out[1]);
+        uint32_t* set_num = static_cast<uint32_t*>(out[2]);
+        float* m0 = static_cast<float*>(out[3]);
+        float* m1 = static_cast<float*>(out[4]);
+        uint32_t* set_base = static_cast<uint32_t*>(workspace);
+        if (zeroFill) {                                                                // getSet.cu:681-686
+            size_t e = (size_t)2 * p_.max_win_num * p_.voxel_num_set, eh = (size_t)p_.max_win_num * p_.num_heads * p_.voxel_num_set;
+            DSVT_CHECK(hipMemsetAsync(inds, 0, sizeof(uint32_t) * e, stream));
+            DSVT_CHECK(hipMemsetAsync(mask, 0, sizeof(float) * e, stream));
+            DSVT_CHECK(hipMemsetAsync(m0, 0, sizeof(float) * eh, stream));
+            DSVT_CHECK(hipMemsetAsync(m1, 0, sizeof(float) * eh, stream));
+        }
+        hipLaunchKernelGGL(gs_scan, dim3(1), dim3(1024), 0, stream, vcnt, win_num, p_, set_base, set_num);
+        size_t lds = sizeof(uint32_t) * (2 * (size_t)p_.wx * p_.wy * p_.wz + 2 * (size_t)p_.max_voxel_num_per_win);
+        hipLaunchKernelGGL(gs_sets, dim3(p_.max_win_num), dim3(256), lds, stream, gidx, cinw, vcnt, win_num, set_base, p_, inds, mask, m0, m1);
+        return lastError();
+    }
+    size_t serializationSize() const override { return 6 * sizeof(int); }
+    void serialize(void* b) const override {                                           // getSet.cu:749-758
+        char* d = static_cast<char*>(b);
+        wr<int>(d, p_.voxel_num_set); wr<int>(d, p_.max_win_num); wr<int>(d, p_.max_voxel_num_per_win);
+        wr<int>(d, p_.wx); wr<int>(d, p_.wy); wr<int>(d, p_.wz);
+    }
+    Plugin* clone() const override { return new GetSetPlugin(p_); }
+};
+static Plugin* gsNew(GSParams p) {
+    p.num_heads = 8;                                                                   // NUM_HEADS, include/params.h:73
+    if (p.max_win_num <= 0 || p.max_voxel_num_per_win <= 0 || p.voxel_num_set <= 0 || p.wx <= 0 || p.wy <= 0 || p.wz <= 0) return nullptr;
+    size_t lds = sizeof(uint32_t) * (2 * (size_t)p.wx * p.wy * p.wz + 2 * (size_t)p.max_voxel_num_per_win);
+    if (lds > 150 * 1024) return nullptr;
+    return new GetSetPlugin(p);
+}
+static Plugin* gsCreate(const DsvtPluginFieldCollection* fc) {
+    GSParams p{}; int w[3];
+    p.max_win_num = fieldInt(fc, "max_win_num"); p.max_voxel_num_per_win = fieldInt(fc, "max_voxel_num_per_win");
+    p.voxel_num_set = fieldInt(fc, "voxel_num_set"); fieldInts(fc, "win_shape", w, 3);
+    p.wx = w[0]; p.wy = w[1]; p.wz = w[2];
+    return gsNew(p);
+}
+static Plugin* gsDeser(const void* data, size_t len) {
+    if (len < 6 * sizeof(int)) return nullptr;
+    const char* d = static_cast<const char*>(data); GSParams p{};
+    p.voxel_num_set = rd<int>(d); p.max_win_num = rd<int>(d); p.max_voxel_num_per_win = rd<int>(d);
+    p.wx = rd<int>(d); p.wy = rd<int>(d); p.wz = rd<int>(d);
+    return gsNew(p);
+}
+static Creator g_gsCreator{"GetSetPlugin",
+    {{"max_win_num", DSVT_FIELD_INT32}, {"max_voxel_num_per_win", DSVT_FIELD_INT32}, {"voxel_num_set", DSVT_FIELD_INT32},
+     {"win_shape", DSVT_FIELD_INT32}},                                                 // :782-785
+    gsCreate, gsDeser, {}, {}};
+static Registrar g_gsReg(&g_gsCreator);
+
+}  // namespace dsvt

@@ -1,0 +1,360 @@
+// points2features.hip -- Points2FeaturesPlugin for gfx950.
+//
+// Replaces plugins/src/points2Features.cu:669-990 (generateVoxels_random_kernel,
+// generateBaseFeatures_kernel, generateFeatures_kernel).  Same tensors, different machine:
+// the reference scatters every point into a dense 468x468x48x4 float scratch (168 MB, zeroed
+// every frame) with racy atomic slot order.  Here
+//   1. p2f_count     one coalesced float4 read per point, range filter, cell key, one atomic
+//                    per in-range point on a 0.9 MB cell histogram (order-independent counts);
+//   2. p2f_tile_sums / p2f_scan_top / p2f_apply   exclusive scan over the cells gives, in
+//                    ascending cell-key order, pillar ids, point-segment offsets and the
+//                    compact point offsets (no atomics => deterministic pillar order);
+//   3. p2f_scatter   point ids land in their cell's segment (arbitrary order inside it);
+//   4. p2f_pillar    one wavefront per pillar ranks the segment by point id (= input order),
+//                    keeps the first T, sums the cluster mean sequentially in slot order like
+//                    the reference, and writes the 10-d features / point-id rows.
+// Canonical order: pillars ascending by y*GX+x, points in input order, first T.
+//
+// Compiled with -ffp-contract=off: cell indices and features follow the reference's
+// expression order exactly (fp32 subtract, IEEE divide, floorf; the centre offset in double).
+#include "plugin_base.h"
+#include "device_utils.h"
+
+namespace dsvt {
+
+struct P2FParams {
+    int max_points_num, max_points_num_voxel_filter, max_pillars_num;
+    int point_feature_num, feature_num, max_num_points_per_voxel;
+    float min_x, max_x, min_y, max_y, min_z, max_z;
+    float vx, vy, vz;
+    int gx, gy, gz;
+};
+
+constexpr uint32_t kNone = 0xffffffffu;
+constexpr int kTile = 1024;     // cells per scan tile (256 threads x 4)
+
+__global__ void __launch_bounds__(256)
+p2f_count(const float4* __restrict__ pts, const uint32_t* __restrict__ n_ptr, P2FParams p,
+          uint32_t* __restrict__ cell_cnt, uint32_t* __restrict__ pt_cell, uint32_t* __restrict__ pt_slot)
+{
+    uint32_t n = *n_ptr;
+    if (n > (uint32_t)p.max_points_num) n = p.max_points_num;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 q = pts[i];
+    uint32_t cell = kNone, slot = 0;
+    if (!(q.x < p.min_x || q.x >= p.max_x || q.y < p.min_y || q.y >= p.max_y ||
+          q.z < p.min_z || q.z >= p.max_z)) {                     // points2Features.cu:683-685
+        int ix = (int)floorf((q.x - p.min_x) / p.vx);             // :687
+        int iy = (int)floorf((q.y - p.min_y) / p.vy);             // :688
+        // fp32 rounding can give ix == gx for a point just below max_x; like the reference
+        // (:689-690) the linear index then aliases the first cell of the next row.  Only an
+        // index past the last cell (undefined behaviour in the reference) is dropped.
+        uint32_t c = (uint32_t)(iy * p.gx + ix);
+        if (c < (uint32_t)(p.gx * p.gy)) {
+            cell = c;
+            slot = atomicAdd(&cell_cnt[cell], 1u);                // count only; order fixed later
+        }
+    }
+    pt_cell[i] = cell;
+    pt_slot[i] = slot;
+}
+
+__device__ __forceinline__ void cellTriple(uint32_t c, uint32_t T, uint32_t& occ, uint32_t& full, uint32_t& kept) {
+    occ = c > 0 ? 1u : 0u; full = c; kept = c < T ? c : T;        // :746-748
+}
+
+// per-tile sums of (occupied, full count, kept count)
+__global__ void __launch_bounds__(256)
+p2f_tile_sums(const uint32_t* __restrict__ cell_cnt, int ncell, uint32_t T, uint32_t* __restrict__ tile_sums, int ntiles)
+{
+    __shared__ uint32_t red[3][4];
+    int base = blockIdx.x * kTile + threadIdx.x * 4;
+    uint32_t so = 0, sf = 0, sk = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int c = base + j;
+        if (c < ncell) { uint32_t o, f, k; cellTriple(cell_cnt[c], T, o, f, k); so += o; sf += f; sk += k; }
+    }
+    so = waveSum(so); sf = waveSum(sf); sk = waveSum(sk);
+    int w = threadIdx.x / kWave;
+    if (laneId() == 0) { red[0][w] = so; red[1][w] = sf; red[2][w] = sk; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        uint32_t s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        tile_sums[threadIdx.x * ntiles + blockIdx.x] = s;
+    }
+}
+
+// single workgroup: exclusive scan of the tile sums (3 rows), zero the device-side counts
+__global__ void __launch_bounds__(1024)
+p2f_scan_top(uint32_t* __restrict__ tile_sums, int ntiles, uint32_t* __restrict__ pillar_num, uint32_t* __restrict__ point_num)
+{
+    __shared__ uint32_t smem[1024 / kWave + 1];
+    for (int r = 0; r < 3; ++r) {
+        uint32_t carry = 0;
+        for (int b = 0; b < ntiles; b += 1024) {
+            int i = b + threadIdx.x;
+            uint32_t v = i < ntiles ? tile_sums[r * ntiles + i] : 0, tot;
+            uint32_t ex = blockExclusiveScan<1024>(v, smem, &tot);
+            if (i < ntiles) tile_sums[r * ntiles + i] = carry + ex;
+            carry += tot;
+        }
+    }
+    if (threadIdx.x == 0) { *pillar_num = 0; *point_num = 0; }
+}
+
+// per tile: finish the scan; emit per-cell segment offsets and per-pillar records
+__global__ void __launch_bounds__(256)
+p2f_apply(const uint32_t* __restrict__ cell_cnt, int ncell, P2FParams p, const uint32_t* __restrict__ tile_pref, int ntiles,
+          uint32_t* __restrict__ cell_seg, uint32_t* __restrict__ pil_seg, uint32_t* __restrict__ pil_full,
+          uint32_t* __restrict__ pil_ptoff, uint32_t* __restrict__ coords, uint32_t* __restrict__ pcnt,
+          uint32_t* __restrict__ pillar_num, uint32_t* __restrict__ point_num)
+{
+    __shared__ uint32_t smem[256 / kWave + 1];
+    const uint32_t T = p.max_num_points_per_voxel;
+    int base = blockIdx.x * kTile + threadIdx.x * 4;
+    uint32_t c[4], o[4], f[4], k[4], so = 0, sf = 0, sk = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        c[j] = (base + j) < ncell ? cell_cnt[base + j] : 0;
+        cellTriple(c[j], T, o[j], f[j], k[j]);
+        so += o[j]; sf += f[j]; sk += k[j];
+    }
+    uint32_t tot;
+    uint32_t eo = blockExclusiveScan<256>(so, smem, &tot) + tile_pref[0 * ntiles + blockIdx.x];
+    uint32_t ef = blockExclusiveScan<256>(sf, smem, &tot) + tile_pref[1 * ntiles + blockIdx.x];
+    uint32_t ek = blockExclusiveScan<256>(sk, smem, &tot) + tile_pref[2 * ntiles + blockIdx.x];
+    uint32_t maxP = 0, maxN = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int cell = base + j;
+        if (cell < ncell) {
+            cell_seg[cell] = ef;
+            if (o[j]) {
+                // capacity guard the reference lacks: the pillar list is truncated at the first
+                // pillar that overflows max_pillars_num or max_points_num_voxel_filter
+                bool valid = eo < (uint32_t)p.max_pillars_num && ek + k[j] <= (uint32_t)p.max_points_num_voxel_filter;
+                if (valid) {
+                    pil_seg[eo] = ef; pil_full[eo] = f[j]; pil_ptoff[eo] = ek;
+                    pcnt[eo] = k[j];                                              // :753
+                    reinterpret_cast<uint4*>(coords)[eo] = make_uint4(0u, 0u, (uint32_t)(cell / p.gx), (uint32_t)(cell % p.gx));  // :755-756
+                    maxP = eo + 1; maxN = ek + k[j];
+                }
+            }
+        }
+        eo += o[j]; ef += f[j]; ek += k[j];
+    }
+    // valid pillars form a prefix, so max(pid+1) / max(ptoff+kept) over them are P and Nk
+    if (maxP) { atomicMax(pillar_num, maxP); atomicMax(point_num, maxN); }
+}
+
+__global__ void __launch_bounds__(256)
+p2f_scatter(const uint32_t* __restrict__ n_ptr, int max_points, const uint32_t* __restrict__ pt_cell,
+            const uint32_t* __restrict__ pt_slot, const uint32_t* __restrict__ cell_seg, uint32_t* __restrict__ sorted_idx)
+{
+    uint32_t n = *n_ptr;
+    if (n > (uint32_t)max_points) n = max_points;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t cell = pt_cell[i];
+    if (cell == kNone) return;
+    sorted_idx[cell_seg[cell] + pt_slot[i]] = i;
+}
+
+// one wavefront per pillar
+__global__ void __launch_bounds__(256)
+p2f_pillar(const float4* __restrict__ pts, P2FParams p, const uint32_t* __restrict__ pillar_num,
+           const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ pil_seg,
+           const uint32_t* __restrict__ pil_full, const uint32_t* __restrict__ pil_ptoff,
+           float* __restrict__ feat, uint32_t* __restrict__ pidx)
+{
+    const int lane = laneId();
+    const uint32_t pid = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    if (pid >= *pillar_num) return;
+    const uint32_t T = p.max_num_points_per_voxel;
+    const uint32_t seg = pil_seg[pid], nfull = pil_full[pid], ptoff = pil_ptoff[pid];
+    const uint32_t kept = nfull < T ? nfull : T;
+
+    // lane s (< kept) ends up holding the point id with the s-th smallest index in the cell
+    uint32_t sel = kNone;
+    if (nfull <= (uint32_t)kWave) {
+        uint32_t mine = lane < (int)nfull ? sorted_idx[seg + lane] : kNone;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < nfull; ++j) rank += (__shfl(mine, (int)j, kWave) < mine) ? 1u : 0u;
+        if (lane >= (int)nfull) rank = lane;              // idle lanes push onto themselves
+        sel = (uint32_t)__builtin_amdgcn_ds_permute((int)(rank * 4), (int)mine);
+    } else {
+        // over-full cell (more than 64 points): select the `kept` smallest ids one by one
+        uint32_t last = 0; bool first = true;
+        for (uint32_t s = 0; s < kept; ++s) {
+            uint32_t m = kNone;
+            for (uint32_t j = lane; j < nfull; j += kWave) {
+                uint32_t v = sorted_idx[seg + j];
+                if ((first || v > last) && v < m) m = v;
+            }
+            m = waveMinU(m);
+            if (lane == (int)s) sel = m;
+            last = m; first = false;
+        }
+    }
+
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < (int)kept) q = pts[sel];
+    // cluster mean: sequential fp32 sum in slot order, then divide by the int count (:813-824)
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    for (uint32_t s = 0; s < kept; ++s) {
+        cx += __shfl(q.x, (int)s, kWave);
+        cy += __shfl(q.y, (int)s, kWave);
+        cz += __shfl(q.z, (int)s, kWave);
+    }
+    const int ni = (int)kept;
+    cx = cx / ni; cy = cy / ni; cz = cz / ni;
+
+    if (lane < (int)T) pidx[(size_t)pid * T + lane] = lane < (int)kept ? ptoff + lane : 0u;   // :829-830
+    if (lane < (int)kept) {
+        float* f = feat + (size_t)(ptoff + lane) * p.feature_num;
+        int index_x = (int)floorf((q.x - p.min_x) / p.vx);                                     // :844-846
+        int index_y = (int)floorf((q.y - p.min_y) / p.vy);
+        int index_z = (int)floorf((q.z - p.min_z) / p.vz);
+        // :849-851 -- the 0.5 literal is a double, so the bracket is evaluated in double
+        float fx = (float)((double)q.x - ((index_x + 0.5) * (double)p.vx + (double)p.min_x));
+        float fy = (float)((double)q.y - ((index_y + 0.5) * (double)p.vy + (double)p.min_y));
+        float fz = (float)((double)q.z - ((index_z + 0.5) * (double)p.vz + (double)p.min_z));
+        f[0] = q.x; f[1] = q.y; f[2] = q.z; f[3] = q.w;                                        // :838-841
+        f[4] = q.x - cx; f[5] = q.y - cy; f[6] = q.z - cz;                                     // :859-861
+        f[7] = fx; f[8] = fy; f[9] = fz;                                                       // :854-856
+    }
+}
+
+class Points2FeaturesPlugin : public Plugin {
+public:
+    P2FParams p_;
+    explicit Points2FeaturesPlugin(const P2FParams& p) : p_(p) {}
+    const char* type() const override { return "Points2FeaturesPlugin"; }
+    int nbOutputs() const override { return 6; }                                               // :1018-1021
+    int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {            // :133-189
+        int b = in[0].d[0];
+        switch (i) {
+            case 0: *out = dims3(b, p_.max_points_num_voxel_filter, p_.feature_num); return 0;
+            case 1: *out = dims3(b, p_.max_pillars_num, p_.max_num_points_per_voxel); return 0;
+            case 2: *out = dims3(b, p_.max_pillars_num, 4); return 0;
+            case 3: *out = dims3(b, p_.max_pillars_num, 1); return 0;
+            case 4: case 5: *out = dims1(b); return 0;
+        }
+        return -1;
+    }
+    int outputType(int i, const int32_t* t, int) const override { return i == 0 ? t[0] : t[1]; }   // :1000-1006
+    bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int, int) const override {   // :203-255
+        if (io[pos].format != DSVT_FORMAT_LINEAR) return false;
+        if (pos == 0 || pos == 2) return io[pos].type == DSVT_FLOAT;
+        return pos >= 1 && pos <= 7 && io[pos].type == DSVT_INT32;
+    }
+    int ncell() const { return p_.gx * p_.gy; }
+    int ntiles() const { return cdiv(ncell(), kTile); }
+    size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override {
+        size_t s = 0;
+        s += 2 * alignUp(sizeof(uint32_t) * ncell());                 // cell_cnt, cell_seg
+        s += 3 * alignUp(sizeof(uint32_t) * p_.max_points_num);       // pt_cell, pt_slot, sorted_idx
+        s += alignUp(sizeof(uint32_t) * 3 * ntiles());                // tile sums
+        s += 3 * alignUp(sizeof(uint32_t) * p_.max_pillars_num);      // pil_seg, pil_full, pil_ptoff
+        return s;                                                     // ~4.6 MB at 180k caps (reference: 176.8 MB, :262-277)
+    }
+    int enqueue(const DsvtPluginTensorDesc* inDesc, const DsvtPluginTensorDesc*, const void* const* inputs,
+                void* const* outputs, void* workspace, hipStream_t stream) override {
+        if (inDesc && inDesc[0].dims.d[0] != 1) return -2;            // batch 1 only, as the reference
+        const float4* pts = static_cast<const float4*>(inputs[0]);
+        const uint32_t* n_ptr = static_cast<const uint32_t*>(inputs[1]);
+        float* feat = static_cast<float*>(outputs[0]);
+        uint32_t* pidx = static_cast<uint32_t*>(outputs[1]);
+        uint32_t* coords = static_cast<uint32_t*>(outputs[2]);
+        uint32_t* pcnt = static_cast<uint32_t*>(outputs[3]);
+        uint32_t* pillar_num = static_cast<uint32_t*>(outputs[4]);
+        uint32_t* point_num = static_cast<uint32_t*>(outputs[5]);
+        WsCarver ws(workspace);
+        uint32_t* cell_cnt = ws.take<uint32_t>(ncell());
+        uint32_t* cell_seg = ws.take<uint32_t>(ncell());
+        uint32_t* pt_cell = ws.take<uint32_t>(p_.max_points_num);
+        uint32_t* pt_slot = ws.take<uint32_t>(p_.max_points_num);
+        uint32_t* sorted_idx = ws.take<uint32_t>(p_.max_points_num);
+        uint32_t* tile_sums = ws.take<uint32_t>(3 * ntiles());
+        uint32_t* pil_seg = ws.take<uint32_t>(p_.max_pillars_num);
+        uint32_t* pil_full = ws.take<uint32_t>(p_.max_pillars_num);
+        uint32_t* pil_ptoff = ws.take<uint32_t>(p_.max_pillars_num);
+
+        DSVT_CHECK(hipMemsetAsync(cell_cnt, 0, sizeof(uint32_t) * ncell(), stream));
+        if (zeroFill) {   // reference zero-fills every output each call (:928-937)
+            DSVT_CHECK(hipMemsetAsync(feat, 0, sizeof(float) * (size_t)p_.max_points_num_voxel_filter * p_.feature_num, stream));
+            DSVT_CHECK(hipMemsetAsync(pidx, 0, sizeof(uint32_t) * (size_t)p_.max_pillars_num * p_.max_num_points_per_voxel, stream));
+            DSVT_CHECK(hipMemsetAsync(coords, 0, sizeof(uint32_t) * (size_t)p_.max_pillars_num * 4, stream));
+            DSVT_CHECK(hipMemsetAsync(pcnt, 0, sizeof(uint32_t) * (size_t)p_.max_pillars_num, stream));
+        }
+        const int nt = ntiles();
+        hipLaunchKernelGGL(p2f_count, dim3(cdiv(p_.max_points_num, 256)), dim3(256), 0, stream, pts, n_ptr, p_, cell_cnt, pt_cell, pt_slot);
+        hipLaunchKernelGGL(p2f_tile_sums, dim3(nt), dim3(256), 0, stream, cell_cnt, ncell(), (uint32_t)p_.max_num_points_per_voxel, tile_sums, nt);
+        hipLaunchKernelGGL(p2f_scan_top, dim3(1), dim3(1024), 0, stream, tile_sums, nt, pillar_num, point_num);
+        hipLaunchKernelGGL(p2f_apply, dim3(nt), dim3(256), 0, stream, cell_cnt, ncell(), p_, tile_sums, nt, cell_seg,
+                           pil_seg, pil_full, pil_ptoff, coords, pcnt, pillar_num, point_num);
+        hipLaunchKernelGGL(p2f_scatter, dim3(cdiv(p_.max_points_num, 256)), dim3(256), 0, stream, n_ptr, p_.max_points_num,
+                           pt_cell, pt_slot, cell_seg, sorted_idx);
+        hipLaunchKernelGGL(p2f_pillar, dim3(cdiv(p_.max_pillars_num, 4)), dim3(256), 0, stream, pts, p_, pillar_num,
+                           sorted_idx, pil_seg, pil_full, pil_ptoff, feat, pidx);
+        return lastError();
+    }
+    size_t serializationSize() const override { return 9 * sizeof(float) + 9 * sizeof(int); }      // :1033-1036
+    void serialize(void* buffer) const override {                                                  // :1038-1060
+        char* d = static_cast<char*>(buffer);
+        wr<int>(d, p_.max_points_num); wr<int>(d, p_.max_points_num_voxel_filter); wr<int>(d, p_.max_pillars_num);
+        wr<int>(d, p_.point_feature_num); wr<int>(d, p_.feature_num); wr<int>(d, p_.max_num_points_per_voxel);
+        wr<float>(d, p_.min_x); wr<float>(d, p_.max_x); wr<float>(d, p_.min_y); wr<float>(d, p_.max_y);
+        wr<float>(d, p_.min_z); wr<float>(d, p_.max_z); wr<float>(d, p_.vx); wr<float>(d, p_.vy); wr<float>(d, p_.vz);
+        wr<int>(d, p_.gx); wr<int>(d, p_.gy); wr<int>(d, p_.gz);
+    }
+    Plugin* clone() const override { return new Points2FeaturesPlugin(p_); }
+};
+
+static bool validP2F(const P2FParams& p) {
+    return p.max_points_num > 0 && p.max_points_num_voxel_filter > 0 && p.max_pillars_num > 0 &&
+           p.point_feature_num == 4 && p.feature_num == 10 &&
+           p.max_num_points_per_voxel > 0 && p.max_num_points_per_voxel <= kWave &&
+           p.gx > 0 && p.gy > 0 && p.vx > 0 && p.vy > 0 && p.vz > 0;
+}
+
+static Plugin* p2fCreate(const DsvtPluginFieldCollection* fc) {                                    // :1113-1195
+    P2FParams p{};
+    p.max_points_num = fieldInt(fc, "max_points_num");
+    p.max_points_num_voxel_filter = fieldInt(fc, "max_points_num_voxel_filter");
+    p.max_pillars_num = fieldInt(fc, "max_pillars_num");
+    p.point_feature_num = fieldInt(fc, "point_feature_num");
+    p.feature_num = fieldInt(fc, "feature_num");
+    p.max_num_points_per_voxel = fieldInt(fc, "max_num_points_per_voxel");
+    float r[6], v[3]; int g[3];
+    fieldFloats(fc, "point_cloud_range", r, 6);   // (xmin,ymin,zmin,xmax,ymax,zmax) plugin_helper.h:33-38
+    fieldFloats(fc, "voxel_size", v, 3);
+    fieldInts(fc, "grid_size", g, 3);
+    p.min_x = r[0]; p.max_x = r[3]; p.min_y = r[1]; p.max_y = r[4]; p.min_z = r[2]; p.max_z = r[5];
+    p.vx = v[0]; p.vy = v[1]; p.vz = v[2]; p.gx = g[0]; p.gy = g[1]; p.gz = g[2];
+    return validP2F(p) ? new Points2FeaturesPlugin(p) : nullptr;
+}
+static Plugin* p2fDeserialize(const void* data, size_t len) {                                      // ctor :60-84
+    if (len < 9 * sizeof(float) + 9 * sizeof(int)) return nullptr;
+    const char* d = static_cast<const char*>(data);
+    P2FParams p{};
+    p.max_points_num = rd<int>(d); p.max_points_num_voxel_filter = rd<int>(d); p.max_pillars_num = rd<int>(d);
+    p.point_feature_num = rd<int>(d); p.feature_num = rd<int>(d); p.max_num_points_per_voxel = rd<int>(d);
+    p.min_x = rd<float>(d); p.max_x = rd<float>(d); p.min_y = rd<float>(d); p.max_y = rd<float>(d);
+    p.min_z = rd<float>(d); p.max_z = rd<float>(d); p.vx = rd<float>(d); p.vy = rd<float>(d); p.vz = rd<float>(d);
+    p.gx = rd<int>(d); p.gy = rd<int>(d); p.gz = rd<int>(d);
+    return validP2F(p) ? new Points2FeaturesPlugin(p) : nullptr;
+}
+
+static Creator g_p2fCreator{"Points2FeaturesPlugin",
+    {{"max_points_num", DSVT_FIELD_INT32}, {"max_points_num_voxel_filter", DSVT_FIELD_INT32},
+     {"max_pillars_num", DSVT_FIELD_INT32}, {"point_feature_num", DSVT_FIELD_INT32},
+     {"feature_num", DSVT_FIELD_INT32}, {"max_num_points_per_voxel", DSVT_FIELD_INT32},
+     {"point_cloud_range", DSVT_FIELD_FLOAT32}, {"voxel_size", DSVT_FIELD_FLOAT32},
+     {"grid_size", DSVT_FIELD_INT32}},                                                             // :1084-1092
+    p2fCreate, p2fDeserialize, {}, {}};
+static Registrar g_p2fReg(&g_p2fCreator);
+
+}  // namespace dsvt

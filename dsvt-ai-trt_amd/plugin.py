@@ -1,0 +1,353 @@
+"""Host-side mirror of the reference's plugin interface, on top of the C ABI of
+libdsvt_hip.so (include/dsvt_plugin.h).
+
+`Plugin` plays the role of nvinfer1::IPluginV2DynamicExt: created from a
+PluginFieldCollection through the creator protocol (getFieldNames -> createPlugin), asked
+for output dims / workspace size, and run with enqueue(inputs, outputs, workspace, stream).
+The `add_*_op` functions have the names, argument order and argument meaning of the
+reference factories in include/plugin_helper.h:15-678 (minus the TensorRT `network`
+handle: they return the plugin object, and calling it enqueues on the current stream).
+
+PyTorch is used for device memory and streams only.  There is no CPU fallback: if the
+HIP library is missing, import fails.
+"""
+import ctypes as C
+import os
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libdsvt_hip.so")
+
+FIELD_INT32, FIELD_FLOAT32 = 3, 5
+DT_FLOAT, DT_HALF, DT_INT32 = 0, 1, 3
+MAX_DIMS = 8
+
+
+class PluginField(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("type", C.c_int32), ("length", C.c_int32)]
+
+
+class PluginFieldCollection(C.Structure):
+    _fields_ = [("nbFields", C.c_int32), ("fields", C.POINTER(PluginField))]
+
+
+class Dims(C.Structure):
+    _fields_ = [("nbDims", C.c_int32), ("d", C.c_int32 * MAX_DIMS)]
+
+
+class PluginTensorDesc(C.Structure):
+    _fields_ = [("dims", Dims), ("type", C.c_int32), ("format", C.c_int32), ("scale", C.c_float)]
+
+
+def _load():
+    if not os.path.exists(_SO):
+        raise ImportError(
+            f"{_SO} is missing: the HIP extension must be built first "
+            "(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
+    lib = C.CDLL(_SO)
+    lib.dsvtGetNbPluginTypes.restype = C.c_int32
+    lib.dsvtGetPluginTypeName.restype = C.c_char_p
+    lib.dsvtGetPluginTypeName.argtypes = [C.c_int32]
+    lib.dsvtGetFieldNames.restype = C.POINTER(PluginFieldCollection)
+    lib.dsvtGetFieldNames.argtypes = [C.c_char_p, C.c_char_p]
+    lib.dsvtCreatePlugin.restype = C.c_void_p
+    lib.dsvtCreatePlugin.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(PluginFieldCollection)]
+    lib.dsvtDeserializePlugin.restype = C.c_void_p
+    lib.dsvtDeserializePlugin.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t]
+    lib.dsvtPluginGetType.restype = C.c_char_p
+    lib.dsvtPluginGetType.argtypes = [C.c_void_p]
+    lib.dsvtPluginGetVersion.restype = C.c_char_p
+    lib.dsvtPluginGetVersion.argtypes = [C.c_void_p]
+    lib.dsvtPluginGetNbOutputs.restype = C.c_int32
+    lib.dsvtPluginGetNbOutputs.argtypes = [C.c_void_p]
+    lib.dsvtPluginGetOutputDimensions.restype = C.c_int32
+    lib.dsvtPluginGetOutputDimensions.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Dims), C.c_int32, C.POINTER(Dims)]
+    lib.dsvtPluginGetOutputDataType.restype = C.c_int32
+    lib.dsvtPluginGetOutputDataType.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_int32]
+    lib.dsvtPluginSupportsFormatCombination.restype = C.c_int32
+    lib.dsvtPluginSupportsFormatCombination.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PluginTensorDesc), C.c_int32, C.c_int32]
+    lib.dsvtPluginGetWorkspaceSize.restype = C.c_size_t
+    lib.dsvtPluginGetWorkspaceSize.argtypes = [C.c_void_p, C.POINTER(PluginTensorDesc), C.c_int32, C.POINTER(PluginTensorDesc), C.c_int32]
+    lib.dsvtPluginEnqueue.restype = C.c_int32
+    lib.dsvtPluginEnqueue.argtypes = [C.c_void_p, C.POINTER(PluginTensorDesc), C.POINTER(PluginTensorDesc),
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]
+    lib.dsvtPluginGetSerializationSize.restype = C.c_size_t
+    lib.dsvtPluginGetSerializationSize.argtypes = [C.c_void_p]
+    lib.dsvtPluginSerialize.argtypes = [C.c_void_p, C.c_void_p]
+    lib.dsvtPluginClone.restype = C.c_void_p
+    lib.dsvtPluginClone.argtypes = [C.c_void_p]
+    lib.dsvtPluginDestroy.argtypes = [C.c_void_p]
+    lib.dsvtPluginSetZeroFill.argtypes = [C.c_void_p, C.c_int32]
+    lib.dsvtGetBuildInfo.restype = C.c_char_p
+    return lib
+
+
+LIB = _load()
+
+EXPORTED_SYMBOLS = [
+    "dsvtGetNbPluginTypes", "dsvtGetPluginTypeName", "dsvtGetFieldNames", "dsvtCreatePlugin",
+    "dsvtDeserializePlugin", "dsvtPluginGetType", "dsvtPluginGetVersion", "dsvtPluginGetNbOutputs",
+    "dsvtPluginGetOutputDimensions", "dsvtPluginGetOutputDataType", "dsvtPluginSupportsFormatCombination",
+    "dsvtPluginGetWorkspaceSize", "dsvtPluginEnqueue", "dsvtPluginGetSerializationSize",
+    "dsvtPluginSerialize", "dsvtPluginClone", "dsvtPluginDestroy", "dsvtPluginSetZeroFill", "dsvtGetBuildInfo",
+]
+
+
+def plugin_types():
+    return [LIB.dsvtGetPluginTypeName(i).decode() for i in range(LIB.dsvtGetNbPluginTypes())]
+
+
+def get_field_names(plugin_type, version="1"):
+    """IPluginCreator::getFieldNames(): [(name, type)] in the creator's advertised order."""
+    fc = LIB.dsvtGetFieldNames(plugin_type.encode(), version.encode())
+    if not fc:
+        return None
+    return [(fc.contents.fields[i].name.decode(), fc.contents.fields[i].type) for i in range(fc.contents.nbFields)]
+
+
+def _torch_dtype(t):
+    return {DT_FLOAT: torch.float32, DT_HALF: torch.float16, DT_INT32: torch.int32}[t]
+
+
+def _dt_code(t):
+    if t.dtype == torch.float32:
+        return DT_FLOAT
+    if t.dtype == torch.float16:
+        return DT_HALF
+    if t.dtype in (torch.int32, torch.uint32):
+        return DT_INT32
+    raise TypeError(f"unsupported tensor dtype {t.dtype}")
+
+
+def _desc(shape, code):
+    d = PluginTensorDesc()
+    d.dims.nbDims = len(shape)
+    for i, s in enumerate(shape):
+        d.dims.d[i] = int(s)
+    d.type, d.format, d.scale = code, 0, 1.0
+    return d
+
+
+class Plugin:
+    """One plugin instance (nvinfer1::IPluginV2DynamicExt)."""
+
+    def __init__(self, plugin_type, fields=None, layer_name="", version="1", _handle=None):
+        self.plugin_type = plugin_type
+        self._keep = []
+        if _handle is None:
+            advertised = get_field_names(plugin_type, version)
+            if advertised is None:
+                raise ValueError(f"no plugin creator registered for ({plugin_type!r}, {version!r})")
+            # like plugin_helper.h: walk the creator's advertised names and supply those we have
+            fields = dict(fields or {})
+            flist = []
+            names = [n for n, _ in advertised] + [n for n in fields if n not in dict(advertised)]
+            for name in names:
+                if name not in fields:
+                    continue
+                val = fields[name]
+                if isinstance(val, torch.Tensor):
+                    val = val.detach().cpu().numpy()
+                if isinstance(val, np.ndarray):
+                    arr = np.ascontiguousarray(val.reshape(-1), np.int32 if val.dtype.kind in "iu" else np.float32)
+                elif isinstance(val, (list, tuple)):
+                    isint = all(isinstance(v, (int, np.integer)) for v in val)
+                    arr = np.asarray(val, np.int32 if isint else np.float32)
+                elif isinstance(val, (int, np.integer)):
+                    arr = np.asarray([val], np.int32)
+                else:
+                    arr = np.asarray([val], np.float32)
+                self._keep.append(arr)
+                ftype = FIELD_INT32 if arr.dtype == np.int32 else FIELD_FLOAT32
+                flist.append(PluginField(name.encode(), arr.ctypes.data, ftype, arr.size))
+            arr_t = (PluginField * max(len(flist), 1))(*flist)
+            fc = PluginFieldCollection(len(flist), arr_t)
+            _handle = LIB.dsvtCreatePlugin(plugin_type.encode(), version.encode(), layer_name.encode(), C.byref(fc))
+            if not _handle:
+                raise ValueError(f"createPlugin({plugin_type}) rejected fields {fields}")
+        self._h = C.c_void_p(_handle)
+        self.nb_outputs = LIB.dsvtPluginGetNbOutputs(self._h)
+        self._cache = {}
+
+    # ---- IPluginV2DynamicExt surface --------------------------------------------------
+    def get_plugin_type(self):
+        return LIB.dsvtPluginGetType(self._h).decode()
+
+    def get_output_dimensions(self, index, input_shapes):
+        ins = (Dims * len(input_shapes))()
+        for i, s in enumerate(input_shapes):
+            ins[i].nbDims = len(s)
+            for j, v in enumerate(s):
+                ins[i].d[j] = int(v)
+        out = Dims()
+        rc = LIB.dsvtPluginGetOutputDimensions(self._h, index, ins, len(input_shapes), C.byref(out))
+        if rc != 0:
+            raise IndexError(f"{self.plugin_type}: no output {index}")
+        return tuple(out.d[i] for i in range(out.nbDims))
+
+    def get_output_data_type(self, index, input_types):
+        arr = (C.c_int32 * len(input_types))(*input_types)
+        return LIB.dsvtPluginGetOutputDataType(self._h, index, arr, len(input_types))
+
+    def supports_format_combination(self, pos, descs, nb_in, nb_out):
+        arr = (PluginTensorDesc * len(descs))(*descs)
+        return bool(LIB.dsvtPluginSupportsFormatCombination(self._h, pos, arr, nb_in, nb_out))
+
+    def get_workspace_size(self, in_descs, out_descs):
+        a = (PluginTensorDesc * len(in_descs))(*in_descs)
+        b = (PluginTensorDesc * len(out_descs))(*out_descs)
+        return LIB.dsvtPluginGetWorkspaceSize(self._h, a, len(in_descs), b, len(out_descs))
+
+    def serialize(self):
+        n = LIB.dsvtPluginGetSerializationSize(self._h)
+        buf = (C.c_char * n)()
+        LIB.dsvtPluginSerialize(self._h, buf)
+        return bytes(buf)
+
+    @classmethod
+    def deserialize(cls, plugin_type, data, layer_name="", version="1"):
+        h = LIB.dsvtDeserializePlugin(plugin_type.encode(), version.encode(), layer_name.encode(), data, len(data))
+        if not h:
+            raise ValueError(f"deserializePlugin({plugin_type}) failed")
+        return cls(plugin_type, _handle=h)
+
+    def clone(self):
+        return Plugin(self.plugin_type, _handle=LIB.dsvtPluginClone(self._h))
+
+    def set_zero_fill(self, enable):
+        LIB.dsvtPluginSetZeroFill(self._h, 1 if enable else 0)
+        return self
+
+    def enqueue(self, inputs, outputs, workspace=None, stream=None):
+        """enqueue(inputDesc, outputDesc, inputs, outputs, workspace, stream); tensors are device
+        tensors owned by the caller.  Raises on a non-zero return."""
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        ind = (PluginTensorDesc * len(inputs))(*[_desc(t.shape, _dt_code(t)) for t in inputs])
+        outd = (PluginTensorDesc * len(outputs))(*[_desc(t.shape, _dt_code(t)) for t in outputs])
+        inp = (C.c_void_p * len(inputs))(*[t.data_ptr() for t in inputs])
+        outp = (C.c_void_p * len(outputs))(*[t.data_ptr() for t in outputs])
+        ws = workspace.data_ptr() if workspace is not None else None
+        rc = LIB.dsvtPluginEnqueue(self._h, ind, outd, inp, outp, ws, C.c_void_p(stream))
+        if rc != 0:
+            raise RuntimeError(f"{self.plugin_type}.enqueue returned {rc}")
+
+    # ---- convenience: allocate outputs/workspace once per input signature, then enqueue ----
+    def __call__(self, *inputs):
+        for t in inputs:
+            if not t.is_cuda:
+                raise RuntimeError(f"{self.plugin_type}: inputs must be device tensors (no CPU path exists)")
+            if not t.is_contiguous():
+                raise RuntimeError(f"{self.plugin_type}: inputs must be contiguous (kLINEAR)")
+        key = tuple((tuple(t.shape), t.dtype) for t in inputs)
+        ent = self._cache.get(key)
+        if ent is None:
+            shapes = [tuple(t.shape) for t in inputs]
+            codes = [_dt_code(t) for t in inputs]
+            outs = []
+            for i in range(self.nb_outputs):
+                shp = self.get_output_dimensions(i, shapes)
+                dt = _torch_dtype(self.get_output_data_type(i, codes))
+                outs.append(torch.zeros(shp, dtype=dt, device=inputs[0].device))
+            wsz = self.get_workspace_size([_desc(s, c) for s, c in zip(shapes, codes)],
+                                          [_desc(o.shape, _dt_code(o)) for o in outs])
+            ws = torch.empty(max(wsz, 256), dtype=torch.uint8, device=inputs[0].device)
+            ent = (outs, ws)
+            self._cache[key] = ent
+        outs, ws = ent
+        self.enqueue(list(inputs), outs, ws)
+        return outs
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                LIB.dsvtPluginDestroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+# --------------------------------------------------------------------------------------
+# the reference's factory functions (include/plugin_helper.h), minus `network`
+# --------------------------------------------------------------------------------------
+def add_voxel_generator(max_points_num, max_points_num_voxel_filter, max_pillars_num, point_feature_num,
+                        feature_num, max_num_points_per_voxel, x_min, x_max, y_min, y_max, z_min, z_max,
+                        voxel_size_x, voxel_size_y, voxel_size_z, grid_size_x, grid_size_y, grid_size_z):
+    """plugin_helper.h:15-123.  Inputs at call time: points[1,N,4] f32, points_size[1] i32."""
+    return Plugin("Points2FeaturesPlugin", dict(
+        max_points_num=max_points_num, max_points_num_voxel_filter=max_points_num_voxel_filter,
+        max_pillars_num=max_pillars_num, point_feature_num=point_feature_num, feature_num=feature_num,
+        max_num_points_per_voxel=max_num_points_per_voxel,
+        point_cloud_range=[float(x_min), float(y_min), float(z_min), float(x_max), float(y_max), float(z_max)],   # :33-38
+        voxel_size=[float(voxel_size_x), float(voxel_size_y), float(voxel_size_z)],
+        grid_size=[grid_size_x, grid_size_y, grid_size_z]), "voxelGeneratorlayer")
+
+
+def add_torch_scatter_max(max_points_num, max_pillars_num, feature_num):
+    """plugin_helper.h:125-172.  Inputs: feat, pidx, pcnt, pillar_num."""
+    return Plugin("TorchScatterMaxPlugin", dict(max_points_num=max_points_num, max_pillars_num=max_pillars_num,
+                                                feature_num=feature_num), "torch_scatter_max_layer")
+
+
+def add_window_partition(max_win_num, max_voxel_num_per_win, sparse_shape_x, sparse_shape_y, sparse_shape_z,
+                         win_shape_x, win_shape_y, win_shape_z, shift_x, shift_y, shift_z):
+    """plugin_helper.h:174-251.  Inputs: coords, pillar_num."""
+    return Plugin("WindowPartitionPlugin", dict(
+        max_win_num=max_win_num, max_voxel_num_per_win=max_voxel_num_per_win,
+        sparse_shape=[sparse_shape_x, sparse_shape_y, sparse_shape_z],
+        win_shape=[win_shape_x, win_shape_y, win_shape_z], shift_list=[shift_x, shift_y, shift_z]),
+        "window_partition_layer")
+
+
+def add_get_set_op(max_win_num, max_voxel_num_per_win, voxel_num_set, win_shape_x, win_shape_y, win_shape_z):
+    """plugin_helper.h:253-314.  Inputs: gidx, cinw, vcnt, win_num."""
+    return Plugin("GetSetPlugin", dict(max_win_num=max_win_num, max_voxel_num_per_win=max_voxel_num_per_win,
+                                       voxel_num_set=voxel_num_set,
+                                       win_shape=[win_shape_x, win_shape_y, win_shape_z]), "get_set_layer")
+
+
+def add_get_value_by_index_op(max_win_num, voxel_num_set, channel_num, axis_id):
+    """plugin_helper.h:316-369.  Inputs: voxel_features, pose_features, voxel_inds, valid_set_num."""
+    return Plugin("GetValueByIndexPlugin", dict(max_win_num=max_win_num, voxel_num_set=voxel_num_set,
+                                                channel_num=channel_num, axis_id=axis_id), "get_value_by_index_layer")
+
+
+def add_map_2_bev_op(max_pillars_num, channel_num, grid_size_x, grid_size_y):
+    """plugin_helper.h:371-425.  Inputs: voxel_features, coors, valid_voxel_num."""
+    return Plugin("Map2BevPlugin", dict(max_pillars_num=max_pillars_num, channel_num=channel_num,
+                                        grid_size_x=grid_size_x, grid_size_y=grid_size_y), "map2bev_layer")
+
+
+def add_map_set_feature2voxel_op(max_win_num, voxel_num_set, channel_num, axis_id, max_pillars_num):
+    """plugin_helper.h:427-487.  Inputs: set features, voxel_inds, valid_set_num."""
+    return Plugin("MapSetFeature2VoxelPlugin", dict(max_win_num=max_win_num, voxel_num_set=voxel_num_set,
+                                                    channel_num=channel_num, axis_id=axis_id,
+                                                    max_pillars_num=max_pillars_num), "map_set_feature2voxel_layer")
+
+
+def add_layer_norm_op(weights, bias, max_pillars_num, channel_num, weights_size, eps):
+    """plugin_helper.h:489-555.  Inputs: voxel_features, valid_voxel_num.
+    NOTE the reference quirk kept on purpose: the creator advertises the field "pes", the
+    factory offers "eps" only for names the creator advertises (plugin_helper.h:527), so `eps`
+    is never delivered and the plugin runs with eps = 0 (layerNorm.cu:497 vs :558)."""
+    offered = dict(max_pillars_num=max_pillars_num, channel_num=channel_num, weights_size=weights_size,
+                   eps=float(eps), weights=np.asarray(weights, np.float32), bias=np.asarray(bias, np.float32))
+    advertised = {n for n, _ in get_field_names("LayerNormPlugin")}
+    return Plugin("LayerNormPlugin", {k: v for k, v in offered.items() if k in advertised}, "layer_norm_layer")
+
+
+def add_gelu_op(max_pillars_num, channel_num):
+    """plugin_helper.h:557-605.  Inputs: voxel_features, valid_voxel_num."""
+    return Plugin("GeluPlugin", dict(max_pillars_num=max_pillars_num, channel_num=channel_num), "gelu_layer")
+
+
+def add_filter_box_by_score_op(max_top_k, min_x_range, max_x_range, min_y_range, max_y_range, min_z_range,
+                               max_z_range, voxel_x_size, voxel_y_size, voxel_z_size, score_threshold):
+    """plugin_helper.h:607-678.  Inputs: scores, classes, xs, ys, center, center_z, angle, dim."""
+    return Plugin("FilterBoxByScorePlugin", dict(
+        max_top_k=max_top_k,
+        point_cloud_range=[float(min_x_range), float(max_x_range), float(min_y_range), float(max_y_range),
+                           float(min_z_range), float(max_z_range)],                       # :627-632
+        voxel_size=[float(voxel_x_size), float(voxel_y_size), float(voxel_z_size)],
+        score_threshold=float(score_threshold)), "filter_box_by_score_layer")

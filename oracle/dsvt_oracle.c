@@ -87,6 +87,7 @@ ORC_API int orc_points2features(const orc_p2f_cfg* c, const float* points, uint3
         int ix = (int)floorf((x - c->min_x) / c->vx);                      /* :687 */
         int iy = (int)floorf((y - c->min_y) / c->vy);                      /* :688 */
         uint32_t cell = (uint32_t)(iy * c->gx + ix);                       /* :689-690 */
+        if (cell >= (uint32_t)ncell) continue;   /* out-of-bounds write in the reference (ix==gx on the last row) */
         uint32_t slot = mask[cell]++;                                      /* :697 */
         if (slot >= (uint32_t)T) continue;                                 /* :699 */
         cell_of[i] = cell;                                                 /* kept point */

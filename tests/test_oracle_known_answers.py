@@ -1,0 +1,99 @@
+"""Pins the CPU oracle to the reference's own known answers (no GPU).
+
+Sources of truth:
+  * the reference author's in-source counts for data/bin/000000.bin: 5504 pillars
+    (plugins/src/windowPartition.cu:212, plugins/src/getValueByIndex.cu:176) and 454 sets of
+    36 for the 12x12 windows (src/dsvt-ai-trt.cpp:291,302,308);
+  * the count table and FNV-1a fingerprints recorded in SURVEY.md section 8(a)/(c), which were
+    captured from the reference's plugin sources executed serially (survey phase).
+"""
+import numpy as np
+import pytest
+
+from tests import cases
+
+# frame: (N, P, Nk, max/pillar, W12, maxvox12, S12, masked12, W24, maxvox24, S24, masked24)
+FRAMES = {
+    "000000": (34537, 5504, 25109, 48, 406, 124, 454, 10840, 172, 355, 272, 4288),
+    "000003": (34569, 5529, 25499, 48, 396, 117, 446, 10527, 166, 383, 268, 4119),
+    "000004": (34569, 5211, 24846, 48, 412, 120, 455, 11169, 172, 353, 264, 4293),
+}
+FP_000000 = dict(pillars="2e0bbb803eea4abd", w12a0="24ff90494f6fada1", w12a1="2c3b7e269cf80861",
+                 w24a0="c85b087b358e7466", w24a1="2bb0d2ab237e3cb9")
+# lidar_like(N, 0): (in-range, P, Nk, W12, maxvox12, S12, masked12, W24, maxvox24, S24, masked24)
+SYNTH = {
+    60000: (57577, 19445, 57577, 1250, 144, 1471, 33511, 363, 551, 741, 7231),
+    180000: (172733, 34483, 166924, 1314, 144, 1714, 27221, 378, 552, 1158, 7205),
+}
+
+
+def _partition(O, vox, c):
+    out = []
+    for i in range(2):
+        wp = O.window_partition(vox["coords"], vox["P"], cases.wp_cfg(c, i))
+        gs = O.get_set(wp["gidx"], wp["cinw"], wp["vcnt"], wp["W"], cases.gs_cfg(c, i))
+        out.append((wp, gs))
+    return out
+
+
+@pytest.mark.parametrize("frame", sorted(FRAMES))
+def test_reference_frames(oracle, frame):
+    O = oracle
+    c = cases.caps("ref")
+    exp = FRAMES[frame]
+    with open(f"{cases.GOLDEN}/{frame}.bin", "rb") as f:
+        pts, n = O.load_data(f.read(), c["N"])
+    assert n == exp[0]
+    vox = O.points2features(pts, n, cases.p2f_cfg(c))
+    assert (vox["P"], vox["Nk"]) == (exp[1], exp[2])
+    assert int(vox["pcnt"][:vox["P"]].max()) == exp[3]
+    parts = _partition(O, vox, c)
+    for (wp, gs), e in zip(parts, (exp[4:8], exp[8:12])):
+        S = gs["S"]
+        assert (wp["W"], int(wp["vcnt"].max()), S, int((gs["mask"][0, :S] < 0).sum())) == e
+        # invariant: every pillar is covered by the sets of either axis
+        for a in range(2):
+            assert np.unique(gs["inds"][a, :S]).size == vox["P"]
+        # both axes mask the same slots (SURVEY 2.3 mask note)
+        assert np.array_equal(gs["mask"][0, :S], gs["mask"][1, :S])
+    if frame == "000000":
+        assert O.pillar_key_fingerprint(vox["coords"], vox["P"], 468) == FP_000000["pillars"]
+        for (wp, gs), tag in zip(parts, ("w12", "w24")):
+            for a in range(2):
+                assert O.set_fingerprint(gs["inds"][a], gs["mask"][a], gs["S"], vox["coords"], 468) == FP_000000[f"{tag}a{a}"]
+
+
+@pytest.mark.parametrize("n_pts", sorted(SYNTH))
+def test_synthetic_clouds(oracle, pkg, n_pts):
+    O = oracle
+    exp = SYNTH[n_pts]
+    c = cases.caps("waymo")
+    p = pkg.synth.lidar_like(n_pts, 0)
+    pts, n = cases.pad_points(p, c["N"])
+    vox = O.points2features(pts, n, cases.p2f_cfg(c))
+    assert (vox["P"], vox["Nk"]) == (exp[1], exp[2])
+    parts = _partition(O, vox, c)
+    for (wp, gs), e in zip(parts, (exp[3:7], exp[7:11])):
+        S = gs["S"]
+        assert (wp["W"], int(wp["vcnt"].max()), S, int((gs["mask"][0, :S] < 0).sum())) == e
+
+
+def test_generator_md5(pkg):
+    import hashlib
+    assert hashlib.md5(pkg.synth.lidar_like(180000, 0).tobytes()).hexdigest() == "e32dd9edc87e98309e13b53cf912f849"
+
+
+def test_point_order_invariance(oracle):
+    """permuting the input points changes racy numberings but not the pillar key set
+    nor the set partition expressed in cell keys."""
+    O = oracle
+    c = cases.caps("ref")
+    raw, n = cases.load_frame("000000", c["N"])
+    rng = np.random.default_rng(7)
+    perm = rng.permutation(n)
+    for order in (np.arange(n)[::-1], perm):
+        pts = np.zeros_like(raw); pts[:n] = raw[:n][order]
+        vox = O.points2features(pts, n, cases.p2f_cfg(c))
+        assert O.pillar_key_fingerprint(vox["coords"], vox["P"], 468) == FP_000000["pillars"]
+        (wp, gs), _ = _partition(O, vox, c)
+        assert O.set_fingerprint(gs["inds"][0], gs["mask"][0], gs["S"], vox["coords"], 468) == FP_000000["w12a0"]

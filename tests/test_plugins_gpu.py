@@ -1,0 +1,319 @@
+"""Parity of every reference plugin's HIP replacement against the CPU oracle, through the C ABI
+(dsvt-ai-trt_amd/plugin.py -> libdsvt_hip.so).  Integer outputs bit-exact; float outputs to the
+tolerance written at each assert."""
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    if t.dtype == torch.uint32:
+        t = t.view(torch.int32)
+    return t.to(DEV)
+
+
+def host(t):
+    a = t.detach().cpu().numpy()
+    return a.view(np.uint32) if a.dtype == np.int32 else a
+
+
+def scalar(v):
+    return torch.tensor([v], dtype=torch.int32, device=DEV)
+
+
+def make_voxelizer(P, c):
+    return P.add_voxel_generator(c["N"], c["Nk"], c["P"], 4, 10, 48, -74.88, 74.88, -74.88, 74.88, -5.0, 3.0,
+                                 0.32, 0.32, 8.0, 468, 468, 1)
+
+
+def run_voxelizer(P, c, pts, n):
+    op = make_voxelizer(P, c)
+    outs = op(dev(pts[None]), scalar(n))
+    torch.cuda.synchronize()
+    return op, outs
+
+
+def check_voxelizer(outs, ref, exact_feat_tol=0.0):
+    feat, pidx, coords, pcnt, Pn, Nk = [host(o) for o in outs]
+    assert int(Pn[0]) == ref["P"] and int(Nk[0]) == ref["Nk"]
+    assert np.array_equal(coords[0], ref["coords"])          # bit-exact incl. zero padding
+    assert np.array_equal(pcnt[0], ref["pcnt"])
+    assert np.array_equal(pidx[0], ref["pidx"])
+    # features: same expression order as the reference (no FMA contraction) => exact
+    assert np.array_equal(feat[0], ref["feat"]), float(np.abs(feat[0] - ref["feat"]).max())
+
+
+FRAME_CASES = [("000000", "ref"), ("000003", "ref"), ("000004", "ref")]
+
+
+@pytest.mark.parametrize("frame,capname", FRAME_CASES)
+def test_points2features_frames(pkg, oracle, frame, capname):
+    c = cases.caps(capname)
+    pts, n = cases.load_frame(frame, c["N"])
+    ref = oracle.points2features(pts, n, cases.p2f_cfg(c))
+    _, outs = run_voxelizer(pkg.plugin, c, pts, n)
+    check_voxelizer(outs, ref)
+
+
+@pytest.mark.parametrize("n_pts,capname", [(60000, "mid"), (180000, "waymo"), (300000, None)])
+def test_points2features_synthetic(pkg, oracle, n_pts, capname):
+    c = cases.caps(capname) if capname else dict(N=327680, Nk=327680, P=65536, W=4096, Vw=576)
+    pts, n = cases.pad_points(pkg.synth.lidar_like(n_pts, 0), c["N"])
+    ref = oracle.points2features(pts, n, cases.p2f_cfg(c))
+    if n_pts >= 180000:
+        assert ref["pcnt"].max() == 48                        # over-full cells exist (first-48 rule exercised)
+    _, outs = run_voxelizer(pkg.plugin, c, pts, n)
+    check_voxelizer(outs, ref)
+
+
+def test_points2features_edge_cases(pkg, oracle):
+    P = pkg.plugin
+    c = dict(N=4096, Nk=1024, P=64, W=64, Vw=576)
+    cfg = cases.p2f_cfg(c)
+    rng = np.random.default_rng(3)
+    # (a) empty cloud
+    pts = np.zeros((c["N"], 4), np.float32)
+    op = make_voxelizer(P, c)
+    outs = op(dev(pts[None]), scalar(0)); torch.cuda.synchronize()
+    check_voxelizer(outs, oracle.points2features(pts, 0, cfg))
+    # (b) one cell holding 300 points (> 64: selection path), all others out of range, plus borders
+    pts = np.zeros((c["N"], 4), np.float32)
+    pts[:300, 0] = 10.0 + rng.uniform(0, 0.3, 300); pts[:300, 1] = -3.0 + rng.uniform(0, 0.3, 300)
+    pts[:300, 2] = rng.uniform(-4, 2, 300); pts[:300, 3] = rng.random(300)
+    pts[300:310, :3] = [[-74.88, -74.88, -5.0]] * 10           # exactly on the lower border: in range
+    pts[310:320, :3] = [[74.88, 0.0, 0.0]] * 10                # x == max: out of range
+    pts[320:330, :3] = [[74.879997, 74.879997, 2.9999]] * 10   # just inside the upper border
+    pts[330:340, :3] = [[0.0, 0.0, 3.0]] * 10                  # z == max: out of range
+    outs = op(dev(pts[None]), scalar(340)); torch.cuda.synchronize()
+    ref = oracle.points2features(pts, 340, cfg)
+    assert ref["pcnt"].max() == 48
+    check_voxelizer(outs, ref)
+    # (c) capacity overflow: more pillars than max_pillars_num and more kept points than the filter cap
+    pts = np.zeros((c["N"], 4), np.float32)
+    m = 3000
+    pts[:m, 0] = rng.uniform(-70, 70, m); pts[:m, 1] = rng.uniform(-70, 70, m); pts[:m, 2] = rng.uniform(-4, 2, m)
+    ref = oracle.points2features(pts, m, cfg)
+    assert ref["P"] == c["P"]                                  # truncated by the pillar cap
+    outs = op(dev(pts[None]), scalar(m)); torch.cuda.synchronize()
+    check_voxelizer(outs, ref)
+    c2 = dict(c, P=4096, Nk=100)
+    op2 = make_voxelizer(P, c2)
+    ref = oracle.points2features(pts, m, cases.p2f_cfg(c2))
+    assert ref["Nk"] <= 100 and ref["P"] < 4096
+    outs = op2(dev(pts[None]), scalar(m)); torch.cuda.synchronize()
+    check_voxelizer(outs, ref)
+
+
+def test_points2features_is_deterministic_and_order_invariant(pkg, oracle):
+    c = cases.caps("ref")
+    raw, n = cases.load_frame("000000", c["N"])
+    op = make_voxelizer(pkg.plugin, c)
+    a = [host(o).copy() for o in op(dev(raw[None]), scalar(n))]
+    for _ in range(3):
+        b = [host(o) for o in op(dev(raw[None]), scalar(n))]
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    rev = np.zeros_like(raw); rev[:n] = raw[:n][::-1]
+    b = [host(o) for o in op(dev(rev[None]), scalar(n))]
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])     # coords, counts
+    assert oracle.pillar_key_fingerprint(b[2][0], int(b[4][0]), 468) == "2e0bbb803eea4abd"
+
+
+@pytest.mark.parametrize("frame,capname,n_pts", [("000000", "ref", 0), (None, "waymo", 180000)])
+def test_partition_chain(pkg, oracle, frame, capname, n_pts):
+    """WindowPartition + GetSet, both window configs, against the oracle (bit-exact), fed from
+    the HIP voxelizer's own outputs."""
+    P, O = pkg.plugin, oracle
+    c = cases.caps(capname)
+    if frame:
+        pts, n = cases.load_frame(frame, c["N"])
+    else:
+        pts, n = cases.pad_points(pkg.synth.lidar_like(n_pts, 0), c["N"])
+    vox = O.points2features(pts, n, cases.p2f_cfg(c))
+    _, outs = run_voxelizer(P, c, pts, n)
+    coords_d, pn_d = outs[2], outs[4]
+    for i, (win, shift) in enumerate(cases.WINS):
+        wp_op = P.add_window_partition(c["W"], c["Vw"], 468, 468, 1, *win, *shift)
+        gs_op = P.add_get_set_op(c["W"], c["Vw"], 36, *win)
+        wpo = wp_op(coords_d, pn_d)
+        gso = gs_op(wpo[0], wpo[1], wpo[2], wpo[3])
+        torch.cuda.synchronize()
+        rw = O.window_partition(vox["coords"], vox["P"], cases.wp_cfg(c, i))
+        rg = O.get_set(rw["gidx"], rw["cinw"], rw["vcnt"], rw["W"], cases.gs_cfg(c, i))
+        gidx, cinw, vcnt, W, c2d, xy = [host(o) for o in wpo]
+        assert int(W[0]) == rw["W"]
+        assert np.array_equal(vcnt[0], rw["vcnt"]) and np.array_equal(gidx[0], rw["gidx"])
+        assert np.array_equal(cinw[0], rw["cinw"]) and np.array_equal(c2d[0], rw["c2d"])
+        assert np.array_equal(xy[0], rw["xy"])                    # small exact floats
+        inds, mask, S, m0, m1 = [host(o) for o in gso]
+        assert int(S[0]) == rg["S"]
+        assert np.array_equal(inds[0], rg["inds"]) and np.array_equal(mask[0], rg["mask"])
+        assert np.array_equal(m0[0], rg["mask0_h"]) and np.array_equal(m1[0], rg["mask1_h"])
+        if frame == "000000":
+            fp = {0: ("24ff90494f6fada1", "2c3b7e269cf80861"), 1: ("c85b087b358e7466", "2bb0d2ab237e3cb9")}[i]
+            for a in range(2):
+                assert O.set_fingerprint(inds[0][a], mask[0][a], int(S[0]), host(coords_d)[0], 468) == fp[a]
+
+
+def test_partition_generic_inputs(pkg, oracle):
+    """GetSet / WindowPartition must not rely on canonical pillar order: shuffled coords, window
+    and set capacity overflow, 3-D windows (config 5 style)."""
+    P, O = pkg.plugin, oracle
+    rng = np.random.default_rng(5)
+    MP = 8192
+    # random unique cells in shuffled order
+    cells = rng.choice(468 * 468, 6000, replace=False)
+    coords = np.zeros((MP, 4), np.uint32)
+    coords[:6000, 2] = cells // 468; coords[:6000, 3] = cells % 468
+    for (mw, vw) in [(2048, 576), (300, 576), (2048, 40)]:       # plenty / window+set overflow / per-window overflow
+        for i, (win, shift) in enumerate(cases.WINS):
+            cfgw = dict(max_win_num=mw, max_voxel_num_per_win=vw, sparse_shape=cases.GRID, win_shape=win,
+                        shift_list=shift, max_pillars_num=MP)
+            cfgg = dict(max_win_num=mw, max_voxel_num_per_win=vw, voxel_num_set=36, win_shape=win)
+            rw = O.window_partition(coords, 6000, cfgw)
+            rg = O.get_set(rw["gidx"], rw["cinw"], rw["vcnt"], rw["W"], cfgg)
+            wpo = P.add_window_partition(mw, vw, 468, 468, 1, *win, *shift)(dev(coords[None]), scalar(6000))
+            gso = P.add_get_set_op(mw, vw, 36, *win)(wpo[0], wpo[1], wpo[2], wpo[3])
+            torch.cuda.synchronize()
+            for got, exp in zip([host(o)[0] for o in wpo], [rw["gidx"], rw["cinw"], rw["vcnt"], np.array(rw["W"]), rw["c2d"], rw["xy"]]):
+                assert np.array_equal(got, exp)
+            for got, exp in zip([host(o)[0] for o in gso], [rg["inds"], rg["mask"], np.array(rg["S"]), rg["mask0_h"], rg["mask1_h"]]):
+                assert np.array_equal(got, exp)
+    # 3-D windows: z is carried generically (windowPartition.cu:294-301, getSet.cu:386,461)
+    n3 = 5000
+    coords = np.zeros((MP, 4), np.uint32)
+    cells3 = rng.choice(96 * 96 * 8, n3, replace=False)
+    coords[:n3, 1] = cells3 % 8; coords[:n3, 2] = (cells3 // 8) // 96; coords[:n3, 3] = (cells3 // 8) % 96
+    win, shift, sp = [12, 12, 8], [6, 6, 0], [96, 96, 8]
+    cfgw = dict(max_win_num=512, max_voxel_num_per_win=1152, sparse_shape=sp, win_shape=win, shift_list=shift, max_pillars_num=MP)
+    cfgg = dict(max_win_num=512, max_voxel_num_per_win=1152, voxel_num_set=36, win_shape=win)
+    rw = O.window_partition(coords, n3, cfgw)
+    rg = O.get_set(rw["gidx"], rw["cinw"], rw["vcnt"], rw["W"], cfgg)
+    wpo = P.add_window_partition(512, 1152, *sp, *win, *shift)(dev(coords[None]), scalar(n3))
+    gso = P.add_get_set_op(512, 1152, 36, *win)(wpo[0], wpo[1], wpo[2], wpo[3])
+    torch.cuda.synchronize()
+    assert np.array_equal(host(wpo[0])[0], rw["gidx"]) and np.array_equal(host(wpo[1])[0], rw["cinw"])
+    assert np.array_equal(host(gso[0])[0], rg["inds"]) and np.array_equal(host(gso[1])[0], rg["mask"])
+    assert int(host(gso[2])[0]) == rg["S"]
+
+
+@pytest.mark.parametrize("C", [96, 192])
+def test_scatter_max(pkg, oracle, C):
+    P, O = pkg.plugin, oracle
+    c = cases.caps("ref")
+    pts, n = cases.load_frame("000003", c["N"])
+    vox = O.points2features(pts, n, cases.p2f_cfg(c))
+    rng = np.random.default_rng(C)
+    feat = np.zeros((c["Nk"], C), np.float32)
+    feat[:vox["Nk"]] = np.maximum(rng.standard_normal((vox["Nk"], C)), 0).astype(np.float32)   # post-ReLU like the PFN
+    mp, mv = O.scatter_max(feat, vox["pidx"], vox["pcnt"], vox["P"], c["Nk"], c["P"], C)
+    op = P.add_torch_scatter_max(c["Nk"], c["P"], C)
+    o = op(dev(feat[None]), dev(vox["pidx"][None]), dev(vox["pcnt"][None]), scalar(vox["P"]))
+    torch.cuda.synchronize()
+    assert np.array_equal(host(o[0])[0], mp) and np.array_equal(host(o[1])[0], mv)            # max is exact
+
+
+def _sets_for(O, frame="000000"):
+    c = cases.caps("ref")
+    pts, n = cases.load_frame(frame, c["N"])
+    vox = O.points2features(pts, n, cases.p2f_cfg(c))
+    rw = O.window_partition(vox["coords"], vox["P"], cases.wp_cfg(c, 0))
+    rg = O.get_set(rw["gidx"], rw["cinw"], rw["vcnt"], rw["W"], cases.gs_cfg(c, 0))
+    return c, vox, rg
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+def test_gather_scatter(pkg, oracle, axis):
+    P, O = pkg.plugin, oracle
+    c, vox, rg = _sets_for(O)
+    rng = np.random.default_rng(11 + axis)
+    feat = np.zeros((c["P"], 192), np.float32); feat[:vox["P"]] = rng.standard_normal((vox["P"], 192))
+    pos = np.zeros((c["P"], 192), np.float32); pos[:vox["P"]] = rng.standard_normal((vox["P"], 192))
+    q, k, v = O.get_value_by_index(feat, pos, rg["inds"], rg["S"], axis)
+    op = P.add_get_value_by_index_op(c["W"], 36, 192, axis)
+    o = op(dev(feat[None]), dev(pos[None]), dev(rg["inds"][None]), scalar(rg["S"]))
+    torch.cuda.synchronize()
+    for got, exp in zip(o, (q, k, v)):
+        assert np.array_equal(host(got)[0], exp)                                              # one fp32 add: exact
+    sf = np.zeros((c["W"], 36, 192), np.float32); sf[:rg["S"]] = rng.standard_normal((rg["S"], 36, 192))
+    exp = O.map_set_feature2voxel(sf, rg["inds"], rg["S"], axis, c["P"])
+    op = P.add_map_set_feature2voxel_op(c["W"], 36, 192, axis, c["P"])
+    o = op(dev(sf[None]), dev(rg["inds"][None]), scalar(rg["S"]))
+    torch.cuda.synchronize()
+    assert np.array_equal(host(o[0])[0], exp)
+
+
+def test_layer_norm_and_gelu(pkg, oracle):
+    P, O = pkg.plugin, oracle
+    rng = np.random.default_rng(2)
+    MP, n = 10000, 5504
+    x = np.zeros((MP, 192), np.float32); x[:n] = rng.standard_normal((n, 192)) * 2 + 0.3
+    g = rng.uniform(0.8, 1.2, 192).astype(np.float32); b = (rng.standard_normal(192) * 0.05).astype(np.float32)
+    op = P.add_layer_norm_op(g, b, MP, 192, 192, 1e-5)
+    o = host(op(dev(x[None]), scalar(n))[0])[0]
+    torch.cuda.synchronize()
+    exp = O.layer_norm(x, n, g, b, 0.0)          # eps = 0 in effect (reference "pes" quirk)
+    # wave-parallel sums instead of the reference's sequential ones: 2e-6 absolute on O(1) values
+    assert np.abs(o - exp).max() < 2e-6
+    assert not o[n:].any()
+    # serialisation carries eps = 0 and the weights (layerNorm.cu:446-470)
+    blob = op.serialize()
+    assert len(blob) == 3 * 4 + 4 + 2 * 4 * 192
+    assert np.frombuffer(blob[12:16], np.float32)[0] == 0.0
+    op2 = P.Plugin.deserialize("LayerNormPlugin", blob)
+    o2 = host(op2(dev(x[None]), scalar(n))[0])[0]
+    assert np.array_equal(o, o2)
+    h = np.zeros((MP, 384), np.float32); h[:n] = rng.standard_normal((n, 384)) * 3
+    go = host(P.add_gelu_op(MP, 384)(dev(h[None]), scalar(n))[0])[0]
+    ge = O.gelu(h, n)
+    assert np.abs(go - ge).max() < 1e-6          # double-precision tanh on both sides
+    assert not go[n:].any()
+
+
+def test_map2bev(pkg, oracle):
+    P, O = pkg.plugin, oracle
+    c, vox, _ = _sets_for(O, "000004")
+    rng = np.random.default_rng(4)
+    feat = np.zeros((c["P"], 192), np.float32); feat[:vox["P"]] = rng.standard_normal((vox["P"], 192))
+    o = P.add_map_2_bev_op(c["P"], 192, 468, 468)(dev(feat[None]), dev(vox["coords"][None]), scalar(vox["P"]))
+    torch.cuda.synchronize()
+    assert np.array_equal(host(o[0])[0], O.map2bev(feat, vox["coords"], vox["P"], 468, 468))
+
+
+def test_filter_box_by_score(pkg, oracle):
+    P, O = pkg.plugin, oracle
+    rng = np.random.default_rng(9)
+    K = 500
+    scores = np.sort(rng.uniform(0.05, 0.9, K).astype(np.float32))[::-1].copy()
+    classes = rng.integers(0, 10, K).astype(np.uint32)
+    xs = rng.integers(0, 468, K).astype(np.uint32); ys = rng.integers(0, 468, K).astype(np.uint32)
+    center = rng.uniform(-1.5, 1.5, (K, 2)).astype(np.float32)       # pushes some candidates out of range
+    center_z = rng.uniform(-6, 4, (K, 1)).astype(np.float32)
+    angle = rng.uniform(-1.5, 1.5, (K, 1)).astype(np.float32)
+    dim = rng.uniform(0.3, 5, (K, 3)).astype(np.float32)
+    cfg = dict(max_top_k=K, point_cloud_range=cases.RANGE_FB, voxel_size=cases.VOXEL, score_threshold=0.3)
+    exp, cnt = O.filter_box_by_score(scores, classes, xs, ys, center, center_z, angle, dim, cfg)
+    assert 0 < cnt < K
+    op = P.add_filter_box_by_score_op(K, -74.88, 74.88, -74.88, 74.88, -5.0, 3.0, 0.32, 0.32, 8.0, 0.3)
+    o = op(dev(scores[None]), dev(classes[None]), dev(xs[None]), dev(ys[None]), dev(center[None, None]),
+           dev(center_z[None, None]), dev(angle[None, None]), dev(dim[None, None]))
+    torch.cuda.synchronize()
+    assert int(host(o[1])[0]) == cnt
+    assert np.array_equal(host(o[0])[0], exp)      # -ffp-contract=off on both sides: exact
+    # nothing passes / everything passes
+    for thr, expect in ((2.0, 0), (0.0, None)):
+        cfg2 = dict(cfg, score_threshold=thr)
+        e2, c2 = O.filter_box_by_score(scores, classes, xs, ys, center, center_z, angle, dim, cfg2)
+        op2 = P.add_filter_box_by_score_op(K, -74.88, 74.88, -74.88, 74.88, -5.0, 3.0, 0.32, 0.32, 8.0, thr)
+        o2 = op2(dev(scores[None]), dev(classes[None]), dev(xs[None]), dev(ys[None]), dev(center[None, None]),
+                 dev(center_z[None, None]), dev(angle[None, None]), dev(dim[None, None]))
+        assert int(host(o2[1])[0]) == c2 and np.array_equal(host(o2[0])[0], e2)
+        if expect is not None:
+            assert c2 == expect
