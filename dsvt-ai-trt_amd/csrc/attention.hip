@@ -1,0 +1,340 @@
+// attention.hip -- window multi-head attention over sets of 36 voxels, for gfx950.
+//
+//   MultiHeadAttentionPlugin   drop-in for the ~35 TensorRT layers built by multHeadAttention()
+//                              (src/dsvt-ai-trt.cpp:288-458): inputs q,k,v [1,S,36,C] and the
+//                              per-head key-padding mask [1,S,H,36] from GetSet output 3, output
+//                              [1,S,36,C].  in-proj -> per-head softmax(QK^T + mask)V -> out-proj.
+//   DsvtSetAttentionPlugin     fused GetValueByIndex + attention core + MapSetFeature2Voxel
+//                              (plugins/src/getValueByIndex.cu:282-355, src/dsvt-ai-trt.cpp:352-417,
+//                              plugins/src/mapSetFeature2voxel.cu:258-320) on Q/K/V that were projected
+//                              per VOXEL ROW (DsvtLinearPlugin with add_cols): a set's 36 slots only
+//                              repeat voxels, so projecting P rows instead of 36*S slots does the
+//                              same arithmetic once per voxel.
+//
+// One 256-thread workgroup = one set x four heads; each wavefront owns one head.
+//   * the 36 gathered Q/K/V row slices (4 heads x 24 ch) are staged in LDS with coalesced float4
+//     reads (36 x 3 x 384 B); rows padded to 100 floats => conflict-free fragment reads;
+//   * S^T = K Q^T on v_mfma_f32_16x16x4_f32, keys as rows: a lane then holds 12 keys of ONE
+//     query column, the softmax needs 2 cross-lane steps (xor 16, 32) instead of 6;
+//   * the S^T accumulator layout (lane group g <-> keys 4g..4g+3) is exactly the A-operand
+//     layout of the PV product, so P never leaves registers;
+//   * duplicate (masked) slots are not written back: their rows equal the first occurrence.
+// The 36x36 score matrix (71 MB/layer in the reference) never exists in memory.
+#include "plugin_base.h"
+#include "device_utils.h"
+#include "linear.h"
+
+namespace dsvt {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int AL = 36;        // voxels per set (VOXEL_NUM_SET, include/params.h:70)
+constexpr int ADH = 24;       // head dim (192 / 8)
+constexpr int AHB = 4;        // heads per workgroup
+constexpr int ALD = 100;      // LDS row stride in floats (96 + 4)
+
+struct AttnArgs {
+    const float* qkv; int qkv_ld;        // rows x [q(C) | k(C) | v(C)]
+    const uint32_t* inds;                // [S, 36] voxel row of each slot, or nullptr: row = set*36 + slot
+    const float* mask; int mask_set_stride, mask_head_stride;
+    const uint32_t* set_num; int max_sets;
+    float* out; int out_ld;
+    int C, H;
+};
+
+__global__ void __launch_bounds__(256)
+set_attention_f32_kernel(AttnArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float sQ[AL * ALD];
+    __shared__ __attribute__((aligned(16))) float sK[AL * ALD];
+    __shared__ __attribute__((aligned(16))) float sV[AL * ALD];
+    __shared__ uint32_t sRow[AL];
+    __shared__ float sMask[AHB][AL];
+
+    const int nhb = a.H / AHB;
+    const int set = blockIdx.x / nhb, hq = blockIdx.x % nhb;
+    uint32_t S = *a.set_num; if (S > (uint32_t)a.max_sets) S = a.max_sets;
+    if ((uint32_t)set >= S) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+
+    if (tid < AL) sRow[tid] = a.inds ? a.inds[(size_t)set * AL + tid] : (uint32_t)(set * AL + tid);
+    if (tid < AHB * AL) {
+        int h = tid / AL, k = tid % AL;
+        sMask[h][k] = a.mask[(size_t)set * a.mask_set_stride + (size_t)(hq * AHB + h) * a.mask_head_stride + k];
+    }
+    __syncthreads();
+    // ---- stage the 36 gathered rows: 3 segments x 24 float4 each -----------------------------
+    for (int i = tid; i < AL * 3 * 24; i += 256) {
+        int slot = i / 72, rem = i % 72, seg = rem / 24, c4 = (rem % 24) * 4;
+        const float* src = a.qkv + (size_t)sRow[slot] * a.qkv_ld + seg * a.C + hq * (AHB * ADH) + c4;
+        float4 v = *reinterpret_cast<const float4*>(src);
+        float* dst = (seg == 0 ? sQ : seg == 1 ? sK : sV) + slot * ALD + c4;
+        *reinterpret_cast<float4*>(dst) = v;
+    }
+    __syncthreads();
+
+    const int hoff = wave * ADH;
+    // ---- S^T[key][query] = sum_d K[key][d] Q[query][d]; lane group g carries d = 6g..6g+5 ------
+    floatx4 sc[3][3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) sc[t][u] = floatx4{0.f, 0.f, 0.f, 0.f};
+    {
+        float kf[3][6], qf[3][6];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            int row = 16 * t + r; row = row < AL ? row : AL - 1;          // rows >= 36 are padding: clamp, mask later
+            const float2* pk = reinterpret_cast<const float2*>(&sK[row * ALD + hoff + g * 6]);
+            const float2* pq = reinterpret_cast<const float2*>(&sQ[row * ALD + hoff + g * 6]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float2 kk = pk[j], qq = pq[j];
+                kf[t][2 * j] = kk.x; kf[t][2 * j + 1] = kk.y; qf[t][2 * j] = qq.x; qf[t][2 * j + 1] = qq.y;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 6; ++s)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    sc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t][s], qf[u][s], sc[t][u], 0, 0, 0);
+    }
+    // ---- softmax over keys for each query column (lane holds keys 16t + 4g + i, query 16u + r) ----
+    // logits + mask broadcast over queries (src/dsvt-ai-trt.cpp:412), softmax over the key axis (:414-415)
+    float mk[3][4];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { int key = 16 * t + 4 * g + i; mk[t][i] = key < AL ? sMask[wave][key] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int key = 16 * t + 4 * g + i;
+                float v = key < AL ? sc[t][u][i] + mk[t][i] : -INFINITY;
+                sc[t][u][i] = v; mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, kWave)); mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int key = 16 * t + 4 * g + i;
+                float e = key < AL ? expf(sc[t][u][i] - mx) : 0.f;
+                sc[t][u][i] = e; sum += e;
+            }
+        sum += __shfl_xor(sum, 16, kWave); sum += __shfl_xor(sum, 32, kWave);
+        float inv = 1.0f / sum;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sc[t][u][i] *= inv;
+    }
+    // ---- O[query][d] = sum_key P[query][key] V[key][d]  (:417) --------------------------------
+    floatx4 oc[3][2];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { oc[u][0] = floatx4{0.f, 0.f, 0.f, 0.f}; oc[u][1] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int key = 16 * t + 4 * g + i; key = key < AL ? key : AL - 1;  // P is 0 for padded keys
+            float v0 = sV[key * ALD + hoff + r];
+            float v1 = (16 + r) < ADH ? sV[key * ALD + hoff + 16 + r] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                oc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[t][u][i], v0, oc[u][0], 0, 0, 0);
+                oc[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[t][u][i], v1, oc[u][1], 0, 0, 0);
+            }
+        }
+    // ---- write back: lane holds queries 16u + 4g + i, channels 16dt + r -------------------------
+    const int h = hq * AHB + wave;
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int q = 16 * u + 4 * g + i;
+            if (q >= AL) continue;
+            if (a.inds && sMask[wave][q] < 0.f) continue;      // duplicate slot: the first occurrence writes the identical row
+            float* dst = a.out + (size_t)sRow[q] * a.out_ld + h * ADH;
+            dst[r] = oc[u][0][i];
+            if (16 + r < ADH) dst[16 + r] = oc[u][1][i];
+        }
+}
+
+static int launchAttention(const AttnArgs& a, hipStream_t stream) {
+    dim3 grid((unsigned)(a.max_sets * (a.H / AHB))), block(256);
+    hipLaunchKernelGGL(set_attention_f32_kernel, grid, block, 0, stream, a);
+    return lastError();
+}
+
+static bool f32Lin(const DsvtPluginTensorDesc& t) { return t.type == DSVT_FLOAT && t.format == DSVT_FORMAT_LINEAR; }
+static bool i32Lin(const DsvtPluginTensorDesc& t) { return t.type == DSVT_INT32 && t.format == DSVT_FORMAT_LINEAR; }
+
+// =====================================================================================
+// MultiHeadAttentionPlugin
+// =====================================================================================
+class MultiHeadAttentionPlugin : public Plugin {
+public:
+    int max_win_num_, L_, C_, H_;
+    std::vector<float> wi_, bi_, wo_, bo_;         // as in the .wts file (un-scaled)
+    float *wi_dev_ = nullptr, *bi_dev_ = nullptr, *wo_dev_ = nullptr, *bo_dev_ = nullptr;
+    bool ok_ = false;
+    MultiHeadAttentionPlugin(int mw, int L, int C, int H, const float* wi, const float* bi, const float* wo, const float* bo)
+        : max_win_num_(mw), L_(L), C_(C), H_(H), wi_(wi, wi + 3 * (size_t)C * C), bi_(bi, bi + 3 * C),
+          wo_(wo, wo + (size_t)C * C), bo_(bo, bo + C) {
+        // Q is divided by sqrt(head_dim) after the bias (src/dsvt-ai-trt.cpp:386-405); the constant
+        // is folded into the Q rows of in_proj (rows 0..C-1, include/helper.h:369-433)
+        std::vector<float> wis(wi_), bis(bi_);
+        const float scale = sqrtf((float)(C / H));
+        for (size_t i = 0; i < (size_t)C * C; ++i) wis[i] = wis[i] / scale;
+        for (int i = 0; i < C; ++i) bis[i] = bis[i] / scale;
+        auto up = [](const std::vector<float>& h, float** d) {
+            if (hipMalloc(d, sizeof(float) * h.size()) != hipSuccess) return false;
+            return hipMemcpy(*d, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice) == hipSuccess;
+        };
+        ok_ = up(wis, &wi_dev_) && up(bis, &bi_dev_) && up(wo_, &wo_dev_) && up(bo_, &bo_dev_);
+    }
+    ~MultiHeadAttentionPlugin() override { for (float* p : {wi_dev_, bi_dev_, wo_dev_, bo_dev_}) if (p) (void)hipFree(p); }
+    const char* type() const override { return "MultiHeadAttentionPlugin"; }
+    int nbOutputs() const override { return 1; }
+    int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
+        if (i != 0) return -1;
+        *out = dims4(in[0].d[0], max_win_num_, L_, C_); return 0;                  // src/dsvt-ai-trt.cpp:455
+    }
+    int outputType(int, const int32_t* t, int) const override { return t[0]; }
+    bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int, int) const override {
+        return pos == 4 ? i32Lin(io[pos]) : pos >= 0 && pos <= 5 && f32Lin(io[pos]);
+    }
+    size_t rows() const { return (size_t)max_win_num_ * L_; }
+    size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override {
+        return alignUp(sizeof(float) * rows() * 3 * C_) + alignUp(sizeof(float) * rows() * C_);
+    }
+    int enqueue(const DsvtPluginTensorDesc*, const DsvtPluginTensorDesc*, const void* const* in, void* const* out,
+                void* workspace, hipStream_t stream) override {
+        if (!ok_) return static_cast<int>(hipErrorOutOfMemory);
+        WsCarver ws(workspace);
+        float* qkv = ws.take<float>(rows() * 3 * C_);
+        float* att = ws.take<float>(rows() * C_);
+        const uint32_t* S = static_cast<const uint32_t*>(in[4]);
+        for (int p = 0; p < 3; ++p) {                                              // :328-330 three FullyConnected
+            LinearArgs la{};
+            la.A = static_cast<const float*>(in[p]); la.W = wi_dev_ + (size_t)p * C_ * C_; la.bias = bi_dev_ + p * C_;
+            la.out = qkv + p * C_; la.out_ld = 3 * C_; la.count = S; la.row_mult = L_; la.max_rows = (int)rows();
+            la.K = C_; la.N = C_;
+            int rc = launchLinearF32(la, stream); if (rc) return rc;
+        }
+        AttnArgs aa{};
+        aa.qkv = qkv; aa.qkv_ld = 3 * C_; aa.inds = nullptr;
+        aa.mask = static_cast<const float*>(in[3]); aa.mask_set_stride = H_ * L_; aa.mask_head_stride = L_;   // [S,H,36]
+        aa.set_num = S; aa.max_sets = max_win_num_; aa.out = att; aa.out_ld = C_; aa.C = C_; aa.H = H_;
+        int rc = launchAttention(aa, stream); if (rc) return rc;
+        if (zeroFill) DSVT_CHECK(hipMemsetAsync(out[0], 0, sizeof(float) * rows() * C_, stream));
+        LinearArgs lo{};                                                           // :448 out_proj
+        lo.A = att; lo.W = wo_dev_; lo.bias = bo_dev_; lo.out = static_cast<float*>(out[0]); lo.out_ld = C_;
+        lo.count = S; lo.row_mult = L_; lo.max_rows = (int)rows(); lo.K = C_; lo.N = C_;
+        return launchLinearF32(lo, stream);
+    }
+    size_t serializationSize() const override { return 4 * sizeof(int) + sizeof(float) * (wi_.size() + bi_.size() + wo_.size() + bo_.size()); }
+    void serialize(void* buf) const override {
+        char* d = static_cast<char*>(buf);
+        wr<int>(d, max_win_num_); wr<int>(d, L_); wr<int>(d, C_); wr<int>(d, H_);
+        for (const std::vector<float>* v : {&wi_, &bi_, &wo_, &bo_}) { memcpy(d, v->data(), sizeof(float) * v->size()); d += sizeof(float) * v->size(); }
+    }
+    Plugin* clone() const override { return new MultiHeadAttentionPlugin(max_win_num_, L_, C_, H_, wi_.data(), bi_.data(), wo_.data(), bo_.data()); }
+};
+static bool attnShapeOk(int mw, int L, int C, int H) {
+    return mw > 0 && L == AL && H > 0 && H % AHB == 0 && C == H * ADH;            // 36-voxel sets, 24-channel heads
+}
+static Plugin* mhaCreate(const DsvtPluginFieldCollection* fc) {
+    int mw = fieldInt(fc, "max_win_num"), L = fieldInt(fc, "voxel_num_set"), C = fieldInt(fc, "channel_num"), H = fieldInt(fc, "num_heads");
+    const DsvtPluginField* wi = findField(fc, "in_proj_weight"); const DsvtPluginField* bi = findField(fc, "in_proj_bias");
+    const DsvtPluginField* wo = findField(fc, "out_proj_weight"); const DsvtPluginField* bo = findField(fc, "out_proj_bias");
+    if (!attnShapeOk(mw, L, C, H) || !wi || !bi || !wo || !bo) return nullptr;
+    if (wi->length != 3 * C * C || bi->length != 3 * C || wo->length != C * C || bo->length != C) return nullptr;
+    return new MultiHeadAttentionPlugin(mw, L, C, H, static_cast<const float*>(wi->data), static_cast<const float*>(bi->data),
+                                        static_cast<const float*>(wo->data), static_cast<const float*>(bo->data));
+}
+static Plugin* mhaDeser(const void* data, size_t len) {
+    if (len < 4 * sizeof(int)) return nullptr;
+    const char* d = static_cast<const char*>(data);
+    int mw = rd<int>(d), L = rd<int>(d), C = rd<int>(d), H = rd<int>(d);
+    if (!attnShapeOk(mw, L, C, H)) return nullptr;
+    size_t need = 4 * (size_t)C * C + 4 * (size_t)C;
+    if (len < 4 * sizeof(int) + need * sizeof(float)) return nullptr;
+    std::vector<float> all(need); memcpy(all.data(), d, need * sizeof(float));
+    const float* wi = all.data(); const float* bi = wi + 3 * (size_t)C * C; const float* wo = bi + 3 * C; const float* bo = wo + (size_t)C * C;
+    return new MultiHeadAttentionPlugin(mw, L, C, H, wi, bi, wo, bo);
+}
+static Creator g_mhaCreator{"MultiHeadAttentionPlugin",
+    {{"max_win_num", DSVT_FIELD_INT32}, {"voxel_num_set", DSVT_FIELD_INT32}, {"channel_num", DSVT_FIELD_INT32},
+     {"num_heads", DSVT_FIELD_INT32}, {"in_proj_weight", DSVT_FIELD_FLOAT32}, {"in_proj_bias", DSVT_FIELD_FLOAT32},
+     {"out_proj_weight", DSVT_FIELD_FLOAT32}, {"out_proj_bias", DSVT_FIELD_FLOAT32}},
+    mhaCreate, mhaDeser, {}, {}};
+static Registrar g_mhaReg(&g_mhaCreator);
+
+// =====================================================================================
+// DsvtSetAttentionPlugin: inputs qkv[1,P,3C], inds[1,2,S,36], mask[1,2,S,36], S[1] -> out[1,P,C]
+// =====================================================================================
+class DsvtSetAttentionPlugin : public Plugin {
+public:
+    int max_win_num_, L_, C_, H_, axis_id_, max_pillars_num_;
+    DsvtSetAttentionPlugin(int mw, int L, int C, int H, int axis, int mp) : max_win_num_(mw), L_(L), C_(C), H_(H), axis_id_(axis), max_pillars_num_(mp) {}
+    const char* type() const override { return "DsvtSetAttentionPlugin"; }
+    int nbOutputs() const override { return 1; }
+    int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
+        if (i != 0) return -1;
+        *out = dims3(in[0].d[0], max_pillars_num_, C_); return 0;
+    }
+    int outputType(int, const int32_t* t, int) const override { return t[0]; }
+    bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int, int) const override {
+        return (pos == 1 || pos == 3) ? i32Lin(io[pos]) : pos >= 0 && pos <= 4 && f32Lin(io[pos]);
+    }
+    size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override { return 0; }
+    int enqueue(const DsvtPluginTensorDesc*, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void*,
+                hipStream_t stream) override {
+        if (zeroFill) DSVT_CHECK(hipMemsetAsync(out[0], 0, sizeof(float) * (size_t)max_pillars_num_ * C_, stream));   // mapSetFeature2voxel.cu:314
+        AttnArgs aa{};
+        aa.qkv = static_cast<const float*>(in[0]); aa.qkv_ld = 3 * C_;
+        aa.inds = static_cast<const uint32_t*>(in[1]) + (size_t)axis_id_ * max_win_num_ * L_;    // getValueByIndex.cu:292
+        // the reference feeds the axis-0 mask to both layers of a block (src/dsvt-ai-trt.cpp:658,708);
+        // the two axes mask the same slots, so axis 0 is used here too
+        aa.mask = static_cast<const float*>(in[2]); aa.mask_set_stride = L_; aa.mask_head_stride = 0;
+        aa.set_num = static_cast<const uint32_t*>(in[3]); aa.max_sets = max_win_num_;
+        aa.out = static_cast<float*>(out[0]); aa.out_ld = C_; aa.C = C_; aa.H = H_;
+        return launchAttention(aa, stream);
+    }
+    size_t serializationSize() const override { return 6 * sizeof(int); }
+    void serialize(void* buf) const override {
+        char* d = static_cast<char*>(buf);
+        wr<int>(d, max_win_num_); wr<int>(d, L_); wr<int>(d, C_); wr<int>(d, H_); wr<int>(d, axis_id_); wr<int>(d, max_pillars_num_);
+    }
+    Plugin* clone() const override { return new DsvtSetAttentionPlugin(max_win_num_, L_, C_, H_, axis_id_, max_pillars_num_); }
+};
+static Plugin* saNew(int mw, int L, int C, int H, int axis, int mp) {
+    return (attnShapeOk(mw, L, C, H) && (axis == 0 || axis == 1) && mp > 0) ? new DsvtSetAttentionPlugin(mw, L, C, H, axis, mp) : nullptr;
+}
+static Plugin* saCreate(const DsvtPluginFieldCollection* fc) {
+    return saNew(fieldInt(fc, "max_win_num"), fieldInt(fc, "voxel_num_set"), fieldInt(fc, "channel_num"), fieldInt(fc, "num_heads"),
+                 fieldInt(fc, "axis_id"), fieldInt(fc, "max_pillars_num"));
+}
+static Plugin* saDeser(const void* data, size_t len) {
+    if (len < 6 * sizeof(int)) return nullptr;
+    const char* d = static_cast<const char*>(data);
+    int mw = rd<int>(d), L = rd<int>(d), C = rd<int>(d), H = rd<int>(d), axis = rd<int>(d), mp = rd<int>(d);
+    return saNew(mw, L, C, H, axis, mp);
+}
+static Creator g_saCreator{"DsvtSetAttentionPlugin",
+    {{"max_win_num", DSVT_FIELD_INT32}, {"voxel_num_set", DSVT_FIELD_INT32}, {"channel_num", DSVT_FIELD_INT32},
+     {"num_heads", DSVT_FIELD_INT32}, {"axis_id", DSVT_FIELD_INT32}, {"max_pillars_num", DSVT_FIELD_INT32}},
+    saCreate, saDeser, {}, {}};
+static Registrar g_saReg(&g_saCreator);
+
+}  // namespace dsvt

@@ -351,3 +351,45 @@ def add_filter_box_by_score_op(max_top_k, min_x_range, max_x_range, min_y_range,
                            float(min_z_range), float(max_z_range)],                       # :627-632
         voxel_size=[float(voxel_x_size), float(voxel_y_size), float(voxel_z_size)],
         score_threshold=float(score_threshold)), "filter_box_by_score_layer")
+
+
+# --------------------------------------------------------------------------------------
+# ops with no plugin in the reference (it builds them out of TensorRT layers)
+# --------------------------------------------------------------------------------------
+def add_multi_head_attention_op(in_proj_weight, in_proj_bias, out_proj_weight, out_proj_bias, max_win_num,
+                                voxel_num_set, channel_num, num_heads):
+    """Drop-in for multHeadAttention() (src/dsvt-ai-trt.cpp:288-458).
+    Inputs: q, k, v [1,S,36,C], attn_mask [1,S,H,36] (GetSet output 3), valid_set_num [1]."""
+    f = lambda a: np.asarray(a, np.float32).reshape(-1)
+    return Plugin("MultiHeadAttentionPlugin", dict(
+        max_win_num=max_win_num, voxel_num_set=voxel_num_set, channel_num=channel_num, num_heads=num_heads,
+        in_proj_weight=f(in_proj_weight), in_proj_bias=f(in_proj_bias),
+        out_proj_weight=f(out_proj_weight), out_proj_bias=f(out_proj_bias)), "multi_head_attention_layer")
+
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+
+def add_linear_op(weight, bias, max_rows, row_mult=1, activation=ACT_NONE, add_cols=0, layer_norms=(), ln_eps=0.0):
+    """FC with fused prologue/epilogue (csrc/linear.hip), used where the reference calls
+    addFullyConnected (src/dsvt-ai-trt.cpp:283,476,490,506,525) + ElementWise/LayerNorm/GELU.
+    Inputs: A [1,rows,K], count [1], (A2 if add_cols), then one residual per LayerNorm stage.
+    layer_norms: sequence of (gamma, beta)."""
+    weight = np.asarray(weight, np.float32)
+    N, K = weight.shape
+    fields = dict(max_rows=max_rows, in_features=K, out_features=N, row_mult=row_mult, activation=activation,
+                  add_cols=add_cols, num_layer_norms=len(layer_norms), ln_eps=float(ln_eps), weight=weight.reshape(-1))
+    if bias is not None:
+        fields["bias"] = np.asarray(bias, np.float32).reshape(-1)
+    if layer_norms:
+        fields["ln_weights"] = np.concatenate([np.asarray(g, np.float32).reshape(-1) for g, _ in layer_norms])
+        fields["ln_bias"] = np.concatenate([np.asarray(b, np.float32).reshape(-1) for _, b in layer_norms])
+    return Plugin("DsvtLinearPlugin", fields, "linear_layer")
+
+
+def add_set_attention_op(max_win_num, voxel_num_set, channel_num, num_heads, axis_id, max_pillars_num):
+    """GetValueByIndex + attention core + MapSetFeature2Voxel fused (csrc/attention.hip).
+    Inputs: qkv [1,P,3C] (per-voxel projections), inds [1,2,S,36], mask [1,2,S,36], valid_set_num [1]."""
+    return Plugin("DsvtSetAttentionPlugin", dict(max_win_num=max_win_num, voxel_num_set=voxel_num_set,
+                                                 channel_num=channel_num, num_heads=num_heads, axis_id=axis_id,
+                                                 max_pillars_num=max_pillars_num), "set_attention_layer")

@@ -1,0 +1,115 @@
+"""MFMA linear / attention kernels against the fp32 oracle (torch CPU restatement of the
+reference's TensorRT layers).  fp32 MFMA is an exact-product fp32 FMA chain; the only
+differences from the oracle are summation order => tolerances of a few 1e-6 relative."""
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+from tests.test_plugins_gpu import dev, host, scalar, _sets_for
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.mark.parametrize("K,N,act", [(192, 192, 0), (192, 384, 2), (384, 192, 0), (10, 96, 1), (2, 192, 1), (192, 576, 0)])
+def test_linear_plain(pkg, K, N, act):
+    P = pkg.plugin
+    rng = np.random.default_rng(K * 1000 + N)
+    MR, n = 4096, 3001                      # ragged: not a multiple of the 64-row tile
+    A = np.zeros((MR, K), np.float32); A[:n] = rng.standard_normal((n, K))
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    op = P.add_linear_op(W, b, MR, activation=act)
+    o = host(op(dev(A[None]), scalar(n))[0])[0]
+    y = A[:n].astype(np.float64) @ W.T.astype(np.float64) + b
+    if act == 1:
+        y = np.maximum(y, 0)
+    elif act == 2:
+        y = (0.5 + 0.5 * np.tanh(y * (0.035677408136300125 * y * y + 0.7978845608028654))) * y
+    assert rel_err(o[:n], y) < 5e-6
+    assert not o[n:].any()                  # rows >= count stay zero (reference plugins zero-fill)
+
+
+def test_linear_fused_epilogues(pkg, oracle):
+    """add_cols prologue (q=k=x+pos, v=x) and the chained residual+LayerNorm epilogue."""
+    P, O = pkg.plugin, oracle
+    rng = np.random.default_rng(77)
+    MR, n, C = 8192, 5504, 192
+    x = np.zeros((MR, C), np.float32); x[:n] = rng.standard_normal((n, C))
+    pos = np.zeros((MR, C), np.float32); pos[:n] = rng.standard_normal((n, C))
+    W = (rng.standard_normal((3 * C, C)) / np.sqrt(C)).astype(np.float32); b = (rng.standard_normal(3 * C) * 0.1).astype(np.float32)
+    o = host(P.add_linear_op(W, b, MR, add_cols=2 * C)(dev(x[None]), scalar(n), dev(pos[None]))[0])[0]
+    xp = (x + pos)[:n].astype(np.float64)
+    y = np.concatenate([xp @ W[:2 * C].T.astype(np.float64), x[:n].astype(np.float64) @ W[2 * C:].T.astype(np.float64)], 1) + b
+    assert rel_err(o[:n], y) < 5e-6
+    # three chained LayerNorm stages, eps = 0 like the reference
+    W2 = (rng.standard_normal((C, 2 * C)) / np.sqrt(2 * C)).astype(np.float32); b2 = (rng.standard_normal(C) * 0.1).astype(np.float32)
+    h = np.zeros((MR, 2 * C), np.float32); h[:n] = rng.standard_normal((n, 2 * C))
+    res = [np.zeros((MR, C), np.float32) for _ in range(3)]
+    for r_ in res:
+        r_[:n] = rng.standard_normal((n, C))
+    lns = [(rng.uniform(0.8, 1.2, C).astype(np.float32), (rng.standard_normal(C) * 0.05).astype(np.float32)) for _ in range(3)]
+    op = P.add_linear_op(W2, b2, MR, layer_norms=lns, ln_eps=0.0)
+    o = host(op(dev(h[None]), scalar(n), *[dev(r_[None]) for r_ in res])[0])[0]
+    y = np.zeros((MR, C), np.float32)
+    y[:n] = (h[:n].astype(np.float64) @ W2.T.astype(np.float64) + b2).astype(np.float32)
+    for (g, be), r_ in zip(lns, res):
+        y = O.layer_norm(y + r_, n, g, be, 0.0)
+    assert np.abs(o[:n] - y[:n]).max() < 2e-5
+    # serialise / deserialise round trip gives the same bits
+    op2 = P.Plugin.deserialize("DsvtLinearPlugin", op.serialize())
+    o2 = host(op2(dev(h[None]), scalar(n), *[dev(r_[None]) for r_ in res])[0])[0]
+    assert np.array_equal(o, o2)
+
+
+def _mha_inputs(O, rng, c, vox, rg, axis):
+    feat = np.zeros((c["P"], 192), np.float32); feat[:vox["P"]] = rng.standard_normal((vox["P"], 192))
+    pos = np.zeros((c["P"], 192), np.float32); pos[:vox["P"]] = rng.standard_normal((vox["P"], 192)) * 0.5
+    return feat, pos, O.get_value_by_index(feat, pos, rg["inds"], rg["S"], axis)
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+def test_multi_head_attention_plugin(pkg, oracle, axis):
+    """Drop-in MHA op vs the restatement of multHeadAttention() (oracle/dense_ref.py:mha)."""
+    from oracle import dense_ref as D
+    P, O = pkg.plugin, oracle
+    c, vox, rg = _sets_for(O)
+    rng = np.random.default_rng(21 + axis)
+    w = pkg.synth.make_weights(with_bev=False)
+    pre = "module.backbone_3d.stage_0.0.encoder_list.%d.win_attn.self_attn" % axis
+    feat, pos, (q, k, v) = _mha_inputs(O, rng, c, vox, rg, axis)
+    S = rg["S"]
+    ref = D.mha(D.T(q[:S]), D.T(k[:S]), D.T(v[:S]), D.T(rg["mask0_h"][:S]), w, pre).numpy()
+    op = P.add_multi_head_attention_op(w[pre + ".in_proj_weight"], w[pre + ".in_proj_bias"], w[pre + ".out_proj.weight"],
+                                       w[pre + ".out_proj.bias"], c["W"], 36, 192, 8)
+    o = host(op(dev(q[None]), dev(k[None]), dev(v[None]), dev(rg["mask0_h"][None]), scalar(S))[0])[0]
+    assert np.abs(o[:S] - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+    assert not o[S:].any()
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+def test_fused_set_attention_equals_unfused_chain(pkg, oracle, axis):
+    """Linear(add_cols) on voxel rows + DsvtSetAttention + out-proj == GetValueByIndex -> MHA ->
+    MapSetFeature2Voxel of the reference wiring (src/dsvt-ai-trt.cpp:653-663)."""
+    from oracle import dense_ref as D
+    P, O = pkg.plugin, oracle
+    c, vox, rg = _sets_for(O)
+    rng = np.random.default_rng(31 + axis)
+    w = pkg.synth.make_weights(with_bev=False)
+    pre = "module.backbone_3d.stage_0.1.encoder_list.%d.win_attn.self_attn" % axis
+    feat, pos, (q, k, v) = _mha_inputs(O, rng, c, vox, rg, axis)
+    S, Pn, C = rg["S"], vox["P"], 192
+    a = D.mha(D.T(q[:S]), D.T(k[:S]), D.T(v[:S]), D.T(rg["mask0_h"][:S]), w, pre).numpy()
+    a_full = np.zeros((c["W"], 36, C), np.float32); a_full[:S] = a
+    ref = O.map_set_feature2voxel(a_full, rg["inds"], S, axis, c["P"])
+    wi, bi = w[pre + ".in_proj_weight"].copy(), w[pre + ".in_proj_bias"].copy()
+    wi[:C] /= np.float32(np.sqrt(24.0)); bi[:C] /= np.float32(np.sqrt(24.0))       # q / sqrt(head_dim), :386-405
+    qkv = P.add_linear_op(wi, bi, c["P"], add_cols=2 * C)(dev(feat[None]), scalar(Pn), dev(pos[None]))[0]
+    att = P.add_set_attention_op(c["W"], 36, C, 8, axis, c["P"])(qkv, dev(rg["inds"][None]), dev(rg["mask"][None]), scalar(S))[0]
+    out = P.add_linear_op(w[pre + ".out_proj.weight"], w[pre + ".out_proj.bias"], c["P"])(att, scalar(Pn))[0]
+    o = host(out)[0]
+    assert np.abs(o[:Pn] - ref[:Pn]).max() < 2e-5 * max(1.0, np.abs(ref).max())
