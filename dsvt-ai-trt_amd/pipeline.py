@@ -1,0 +1,235 @@
+"""Frame pipeline: replays the reference's network wiring (createEngine,
+src/dsvt-ai-trt.cpp:532-1762) on the HIP plugins of libdsvt_hip.so.
+
+  points[1,N,4], n[1]
+    Points2Features -> PFN (2 x FC+BN+ReLU) with TorchScatterMax            (:571-589)
+    WindowPartition x2, GetSet x2, 8 position-embedding MLPs                (:592-637)
+    4 DSVT blocks x 2 encoder layers:                                       (:653-756)
+        qkv  = Linear(x, +pos on q/k columns)          [DsvtLinear, per voxel row]
+        attn = SetAttention(qkv, sets)                 [gather + MHA core + scatter]
+        s1   = LN1(attn Wo + bo + x)                   [DsvtLinear epilogue]
+        h    = GELU(s1 W1 + b1)                        [DsvtLinear epilogue]
+        x'   = LN3(LN2(s1 + h W2 + b2) + x) (+ block residual LN)   [DsvtLinear epilogue]
+    Map2Bev -> BEV ResNet + CenterHead + top-K decode   (dense glue: PyTorch-ROCm / MIOpen,
+                                                         SURVEY section 8f "next")
+    FilterBoxByScore -> boxes[1,500,9], count[1]                            (:1684-1736)
+
+Device-side counts (P, Nk, W, S, box count) never visit the host; every op is enqueued on the
+current stream, so a whole frame can be captured in a HIP graph.  The product path has no CPU
+fallback: every stage above the dense glue is a HIP kernel behind the C ABI.
+"""
+import math
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import plugin as P
+
+X_MIN, X_MAX, Y_MIN, Y_MAX, Z_MIN, Z_MAX = -74.88, 74.88, -74.88, 74.88, -5.0, 3.0
+VX, VY, VZ = 0.32, 0.32, 8.0
+GX, GY, GZ = 468, 468, 1
+WINS = [((12, 12, 1), (0, 0, 0)), ((24, 24, 1), (6, 6, 0))]      # include/params.h:47-66
+L_SET, C, H, C_FFN = 36, 192, 8, 384                              # params.h:70,73,80-84
+TOP_K, SCORE_THR = 500, 0.3                                       # params.h:327-328
+
+
+class Caps:
+    """Runtime replacement of the reference's compile-time caps (include/params.h:24-27,68-69)."""
+
+    def __init__(self, max_points=196608, max_points_filter=196608, max_pillars=65536, max_win=2048,
+                 max_vox_per_win=576):
+        self.N, self.Nk, self.P, self.W, self.Vw = max_points, max_points_filter, max_pillars, max_win, max_vox_per_win
+
+    @classmethod
+    def reference(cls):
+        return cls(50000, 30000, 10000, 800, 576)
+
+
+def bn_fold(w, prefix, eps):
+    """src/dsvt-ai-trt.cpp:99-122: scale = gamma / sqrt(var + eps), shift = beta - mean * scale."""
+    g, b = w[prefix + ".weight"], w[prefix + ".bias"]
+    m, v = w[prefix + ".running_mean"], w[prefix + ".running_var"]
+    e = np.float32(eps)
+    scale = (g / np.sqrt(v + e)).astype(np.float32)
+    shift = (b - m * g / np.sqrt(v + e)).astype(np.float32)
+    return scale, shift
+
+
+def fold_linear_bn(w, lin, bn, eps, bias=False):
+    """FC followed by a per-channel scale/shift == FC with scaled rows and a bias."""
+    s, sh = bn_fold(w, bn, eps)
+    W = w[lin + ".weight"] * s[:, None]
+    b = sh + (w[lin + ".bias"] * s if bias else 0)
+    return W.astype(np.float32), b.astype(np.float32)
+
+
+class DsvtPipeline:
+    def __init__(self, weights, caps=None, blocks=4, with_head=True, ln_eps=0.0, head_dtype=torch.float32,
+                 device="cuda:0", zero_fill=False):
+        self.caps = c = caps or Caps()
+        self.blocks, self.with_head, self.device = blocks, with_head, torch.device(device)
+        self.head_dtype = head_dtype
+        w = weights
+        zf = lambda op: op.set_zero_fill(zero_fill)
+        self.voxelizer = zf(P.add_voxel_generator(c.N, c.Nk, c.P, 4, 10, 48, X_MIN, X_MAX, Y_MIN, Y_MAX, Z_MIN, Z_MAX,
+                                                  VX, VY, VZ, GX, GY, GZ))
+        # PFN: FC (no bias) + BN1d(1e-5) + ReLU, BN folded into the FC           (:268-286, :577, :587)
+        W0, b0 = fold_linear_bn(w, "module.vfe.pfn_layers.0.linear", "module.vfe.pfn_layers.0.norm", 1e-5)
+        W1, b1 = fold_linear_bn(w, "module.vfe.pfn_layers.1.linear", "module.vfe.pfn_layers.1.norm", 1e-5)
+        self.pfn0 = zf(P.add_linear_op(W0, b0, c.Nk, activation=P.ACT_RELU))
+        self.pfn1 = zf(P.add_linear_op(W1, b1, c.Nk, activation=P.ACT_RELU))
+        self.smax0 = zf(P.add_torch_scatter_max(c.Nk, c.P, 96))
+        self.smax1 = zf(P.add_torch_scatter_max(c.Nk, c.P, 192))
+        self.wp = [zf(P.add_window_partition(c.W, c.Vw, GX, GY, GZ, *win, *shift)) for win, shift in WINS]
+        self.gs = [zf(P.add_get_set_op(c.W, c.Vw, L_SET, *win)) for win, _ in WINS]
+        self.pe, self.layers, self.res_ln = {}, {}, {}
+        scale = np.float32(math.sqrt(C / H))
+        for b in range(blocks):
+            for l in range(2):
+                pre = f"module.backbone_3d.input_layer.posembed_layers.0.{b}.{l}.position_embedding_head"
+                Wa, ba = fold_linear_bn(w, pre + ".0", pre + ".1", 1e-5, bias=True)                 # :461-492
+                self.pe[(b, l)] = (zf(P.add_linear_op(Wa, ba, c.P, activation=P.ACT_RELU)),
+                                   zf(P.add_linear_op(w[pre + ".3.weight"], w[pre + ".3.bias"], c.P)))
+                lp = f"module.backbone_3d.stage_0.{b}.encoder_list.{l}"
+                wi = w[lp + ".win_attn.self_attn.in_proj_weight"].copy()
+                bi = w[lp + ".win_attn.self_attn.in_proj_bias"].copy()
+                wi[:C] /= scale; bi[:C] /= scale          # Q / sqrt(head_dim) after the bias (:386-405)
+                ln = lambda n: (w[lp + n + ".weight"], w[lp + n + ".bias"])
+                lns2 = [ln(".win_attn.norm2"), ln(".norm")]
+                if l == 1:                                # block residual LayerNorm (:750-756)
+                    lns2.append((w[f"module.backbone_3d.residual_norm_stage_0.{b}.weight"],
+                                 w[f"module.backbone_3d.residual_norm_stage_0.{b}.bias"]))
+                self.layers[(b, l)] = dict(
+                    qkv=zf(P.add_linear_op(wi, bi, c.P, add_cols=2 * C)),
+                    attn=zf(P.add_set_attention_op(c.W, L_SET, C, H, l, c.P)),
+                    out=zf(P.add_linear_op(w[lp + ".win_attn.self_attn.out_proj.weight"],
+                                           w[lp + ".win_attn.self_attn.out_proj.bias"], c.P,
+                                           layer_norms=[ln(".win_attn.norm1")], ln_eps=ln_eps)),
+                    fc1=zf(P.add_linear_op(w[lp + ".win_attn.linear1.weight"], w[lp + ".win_attn.linear1.bias"], c.P,
+                                           activation=P.ACT_GELU)),
+                    fc2=zf(P.add_linear_op(w[lp + ".win_attn.linear2.weight"], w[lp + ".win_attn.linear2.bias"], c.P,
+                                           layer_norms=lns2, ln_eps=ln_eps)))
+        self.cat = torch.zeros((1, c.Nk, 192), dtype=torch.float32, device=self.device)
+        if with_head:
+            self.map2bev = P.add_map_2_bev_op(c.P, C, GX, GY)
+            self.filter = P.add_filter_box_by_score_op(TOP_K, X_MIN, X_MAX, Y_MIN, Y_MAX, Z_MIN, Z_MAX, VX, VY, VZ, SCORE_THR)
+            self._build_dense(w)
+
+    # ---- dense glue: BN folded into the convolutions, channels-last ----------
+    def _conv_params(self, w, conv, bn):
+        s, sh = bn_fold(w, bn, 1e-3)                                                               # :191,208,239
+        W = torch.from_numpy(w[conv + ".weight"] * s[:, None, None, None])
+        return (W.to(self.device, self.head_dtype).contiguous(memory_format=torch.channels_last),
+                torch.from_numpy(sh).to(self.device, self.head_dtype))
+
+    def _build_dense(self, w):
+        d = self.dense = {}
+        for (i, nb) in ((0, 2), (1, 3), (2, 3)):
+            for j in range(nb):
+                p = f"module.backbone_2d.blocks.{i}.{j}"
+                d[p + ".1"] = self._conv_params(w, p + ".conv1", p + ".bn1")
+                d[p + ".2"] = self._conv_params(w, p + ".conv2", p + ".bn2")
+                if j == 0:
+                    d[p + ".d"] = self._conv_params(w, p + ".downsample_layer.0", p + ".downsample_layer.1")
+        for i in range(3):
+            p = f"module.backbone_2d.deblocks.{i}"
+            s, sh = bn_fold(w, p + ".1", 1e-3)
+            W = torch.from_numpy(w[p + ".0.weight"] * s[None, :, None, None])                       # ConvTranspose [in,out,k,k]
+            d[p] = (W.to(self.device, self.head_dtype), torch.from_numpy(sh).to(self.device, self.head_dtype))
+        d["shared"] = self._conv_params(w, "module.dense_head.shared_conv.0", "module.dense_head.shared_conv.1")
+        # the five live heads' first convs share their input: one 64 -> 320 convolution (iou head is dead, :1440-1452)
+        names = ["center", "center_z", "dim", "rot", "hm"]
+        Ws, bs = zip(*[self._conv_params(w, f"module.dense_head.heads_list.0.{n}.0.0", f"module.dense_head.heads_list.0.{n}.0.1")
+                       for n in names])
+        d["heads0"] = (torch.cat(Ws, 0).contiguous(memory_format=torch.channels_last), torch.cat(bs, 0))
+        outs = [2, 1, 3, 2, 10]
+        W2 = torch.zeros((sum(outs), 64 * 5, 3, 3), dtype=torch.float32)
+        b2 = torch.zeros((sum(outs),), dtype=torch.float32)
+        o = 0
+        for k, (n, no) in enumerate(zip(names, outs)):                                              # block-diagonal second convs
+            W2[o:o + no, 64 * k:64 * (k + 1)] = torch.from_numpy(w[f"module.dense_head.heads_list.0.{n}.1.weight"])
+            b2[o:o + no] = torch.from_numpy(w[f"module.dense_head.heads_list.0.{n}.1.bias"])
+            o += no
+        d["heads1"] = (W2.to(self.device, self.head_dtype).contiguous(memory_format=torch.channels_last),
+                       b2.to(self.device, self.head_dtype))
+
+    def _bev(self, x):
+        d = self.dense
+        ups = []
+        for (i, stride, nb, k) in ((0, 1, 2, 1), (1, 2, 3, 2), (2, 2, 3, 4)):
+            for j in range(nb):
+                p = f"module.backbone_2d.blocks.{i}.{j}"
+                s = stride if j == 0 else 1
+                y = F.relu(F.conv2d(x, *d[p + ".1"], stride=s, padding=1))
+                y = F.conv2d(y, *d[p + ".2"], stride=1, padding=1)
+                idn = F.conv2d(x, *d[p + ".d"], stride=s) if j == 0 else x
+                x = F.relu(y + idn)
+            Wd, bd = d[f"module.backbone_2d.deblocks.{i}"]
+            ups.append(F.relu(F.conv_transpose2d(x, Wd, bd, stride=k)))
+        f = torch.cat(ups, 1)
+        sh = F.relu(F.conv2d(f, *d["shared"], padding=1))
+        h0 = F.relu(F.conv2d(sh, *d["heads0"], padding=1))
+        return F.conv2d(h0, *d["heads1"], padding=1).float()       # [1, 18, 468, 468]: center2 cz1 dim3 rot2 hm10
+
+    def _decode(self, o):
+        """sigmoid / exp / two-stage top-K / gathers / atan(sin/cos)  (src/dsvt-ai-trt.cpp:1479-1669)"""
+        o = o[0]
+        hm = torch.sigmoid(o[8:18]).reshape(10, -1)
+        sc1, idx1 = torch.topk(hm, TOP_K, dim=1)
+        sc2, idx2 = torch.topk(sc1.reshape(-1), TOP_K)
+        cls = (idx2 // TOP_K).to(torch.int32)
+        ind = idx1.reshape(-1)[idx2]
+        ys, xs = (ind // GX).to(torch.int32), (ind % GX).to(torch.int32)
+        g = o.reshape(18, -1)[:, ind]                               # [18, K]
+        center = g[0:2].T.contiguous(); center_z = g[2:3].T.contiguous()
+        dim = torch.exp(g[3:6]).T.contiguous()
+        angle = torch.atan(g[7:8] / g[6:7]).T.contiguous()          # rot[1]/rot[0]: sin/cos slices :1494-1501
+        return (sc2.reshape(1, -1), cls.reshape(1, -1), xs.reshape(1, -1), ys.reshape(1, -1), center.reshape(1, 1, -1, 2),
+                center_z.reshape(1, 1, -1, 1), angle.reshape(1, 1, -1, 1), dim.reshape(1, 1, -1, 3))
+
+    # ---- stages -------------------------------------------------------------------------------
+    def voxel_stage(self, points, n):
+        feat, pidx, coords, pcnt, Pn, Nk = self.voxelizer(points, n)
+        x0 = self.pfn0(feat, Nk)[0]                                                                 # :577
+        mp0, _ = self.smax0(x0, pidx, pcnt, Pn)                                                     # :579
+        self.cat[..., :96].copy_(x0); self.cat[..., 96:].copy_(mp0)                                 # concat :583-585
+        x1 = self.pfn1(self.cat, Nk)[0]                                                             # :587
+        _, vfeat = self.smax1(x1, pidx, pcnt, Pn)                                                   # :589
+        wps = [op(coords, Pn) for op in self.wp]                                                    # :592-597
+        gss = [op(wp[0], wp[1], wp[2], wp[3]) for op, wp in zip(self.gs, wps)]                      # :598-601
+        return dict(feat=feat, pidx=pidx, coords=coords, pcnt=pcnt, P=Pn, Nk=Nk, vfeat=vfeat, wps=wps, gss=gss)
+
+    def backbone(self, st, trace=None):
+        Pn = st["P"]
+        x = st["vfeat"]
+        for b in range(self.blocks):
+            xb = x
+            inds, mask, S = st["gss"][b % 2][0], st["gss"][b % 2][1], st["gss"][b % 2][2]
+            for l in range(2):
+                a, fc = self.pe[(b, l)]
+                pos = fc(a(st["wps"][l][5], Pn)[0], Pn)[0]           # pos-embed input = window config l (:603-637)
+                L = self.layers[(b, l)]
+                qkv = L["qkv"](x, Pn, pos)[0]
+                att = L["attn"](qkv, inds, mask, S)[0]
+                s1 = L["out"](att, Pn, x)[0]
+                h = L["fc1"](s1, Pn)[0]
+                x = L["fc2"](h, Pn, s1, x, xb)[0] if l == 1 else L["fc2"](h, Pn, s1, x)[0]
+                if trace is not None:
+                    trace[(b, l)] = x.clone()
+        return x
+
+    def head(self, x, st):
+        bev = self.map2bev(x, st["coords"], st["P"])[0]               # [1, 468(y), 468(x), 192] NHWC
+        bev = bev.permute(0, 3, 1, 2)                                 # NCHW view of channels-last memory (:1131-1133)
+        if self.head_dtype != torch.float32:
+            bev = bev.to(self.head_dtype)
+        o = self._bev(bev)
+        return self.filter(*self._decode(o))
+
+    def forward(self, points, n):
+        """points [1, max_points, 4] f32 (zero padded), n [1] i32 -> boxes [1,500,9] f32, count [1] i32"""
+        st = self.voxel_stage(points, n)
+        x = self.backbone(st)
+        if not self.with_head:
+            return x, st
+        return self.head(x, st)
