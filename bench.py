@@ -1,0 +1,175 @@
+"""bench.py -- frames/s + p50 per-frame ms of the DSVT hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one frame through the whole pipeline (BASELINE.json configs[2]: Waymo-shaped
+180k-point synthetic cloud `lidar_like(180000, seed)`, 0.32 m pillars, 468x468 BEV grid, full
+4-block DSVT pillar backbone + BEV backbone + CenterHead + FilterBoxByScore), inputs already
+resident in HBM when the timed region starts.  Frame-batch data parallelism: every rank
+processes K frames of its own (weak scaling) and the per-frame results are gathered to rank 0
+with ONE collective inside the timed region.  Rank 0 prints one JSON line.
+
+Extra objects in the line:
+  roofline      the dominant hand-written kernel (the MFMA linear kernel): algorithmic flops per
+                launch / average launch duration, measured with HIP events around every launch
+                during the timed steps, against the dense fp32-matrix peak of gfx950.
+  cpu_baseline  the CPU oracle (oracle/, a port of the reference's arithmetic) run on the host
+                cores of the same box on one frame of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import __graft_entry__ as G  # noqa: E402
+
+PEAK_F32_MATRIX_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+N_POINTS = 180000
+FRAME_POOL = 4                      # distinct synthetic clouds cycled through by the steps
+
+
+def cpu_baseline(pkg, weights, caps, points, n):
+    """The oracle (port of the reference arithmetic) on the host cores, one frame of the workload."""
+    from oracle import oracle as O, dense_ref as D
+    cfg = D.OracleCfg(max_points=caps.N, max_points_filter=caps.Nk, max_pillars=caps.P, max_win=caps.W,
+                      max_vox_per_win=caps.Vw)
+    t0 = time.perf_counter()
+    vox = O.points2features(points, n, cfg.p2f)
+    for wc, gc in zip(cfg.wp, cfg.gs):
+        wp = O.window_partition(vox["coords"], vox["P"], wc)
+        O.get_set(wp["gidx"], wp["cinw"], wp["vcnt"], wp["W"], gc)
+    t_pre = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    boxes, cnt = D.forward(points, n, weights, cfg)
+    t_frame = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.nms_cpu(boxes, cnt, 0.01)                       # include/helper.h:257-283, NMS_THRESH params.h:334
+    t_nms = time.perf_counter() - t0
+    return dict(value=round(1.0 / (t_frame + t_nms), 4), unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"1 frame lidar_like({N_POINTS},0): whole network fp32 on the CPU oracle + host NMS "
+                       f"(dense layers on {torch.get_num_threads()} torch threads, plugin restatement on 1 core)",
+                frame_ms=round(1e3 * t_frame, 1), preprocess_voxelize_partition_ms_1core=round(1e3 * t_pre, 2),
+                nms_ms_1core=round(1e3 * t_nms, 3), boxes=int(cnt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--points", type=int, default=N_POINTS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline = null)")
+    args = ap.parse_args()
+
+    G.build()
+    pkg = G.load_package()
+    par = pkg.parallel
+    rank, local_rank, world = par.init()
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    caps = pkg.pipeline.Caps()                      # 196608 points / 65536 pillars / 2048 windows+sets
+    weights = pkg.synth.make_weights()
+    pipe = pkg.pipeline.DsvtPipeline(weights, caps=caps, device=dev)
+
+    # synthetic frames of this rank, resident in HBM before the timed region
+    K = args.steps
+    pool = []
+    for i in range(min(FRAME_POOL, max(K, 1))):
+        p = pkg.synth.lidar_like(args.points, seed=rank * FRAME_POOL + i)
+        buf = np.zeros((1, caps.N, 4), np.float32)
+        buf[0, :p.shape[0]] = p
+        pool.append((torch.from_numpy(buf).to(dev), torch.tensor([p.shape[0]], dtype=torch.int32, device=dev)))
+    results = torch.zeros((K, par.ROW), dtype=torch.float32, device=dev)
+
+    def run_frame(i, row):
+        pts, n = pool[i % len(pool)]
+        boxes, cnt = pipe.forward(pts, n)
+        par.pack_result(boxes[0], cnt, row)
+
+    scratch = torch.zeros((par.ROW,), dtype=torch.float32, device=dev)
+    for i in range(args.warmup):
+        run_frame(i, scratch)
+    torch.cuda.synchronize()
+    # device-side counts of each pooled frame (for the algorithmic flop count), read outside the timed region
+    counts = []
+    for pts, n in pool:
+        st = pipe.voxel_stage(pts, n)
+        counts.append(dict(P=int(st["P"][0]), Nk=int(st["Nk"][0]), S=[int(g[2][0]) for g in st["gss"]]))
+    torch.cuda.synchronize()
+
+    prof = None if args.no_kernel_events else {"DsvtLinearPlugin": []}
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+    par.barrier(); torch.cuda.synchronize()
+    pkg.plugin.PROFILE = prof
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(K):
+        run_frame(i, results[i])
+        marks[i + 1].record()
+    gathered = par.gather_results(results, K * world, rank, world)          # the one collective of the path
+    par.barrier(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pkg.plugin.PROFILE = None
+    dt = par.max_over_ranks(dt, dev)
+
+    frame_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(K)])
+    roofline = None
+    if prof is not None and prof["DsvtLinearPlugin"]:
+        per_frame = len(prof["DsvtLinearPlugin"]) // K
+        tot_ms, tot_flops = 0.0, 0.0
+        for j, (e0, e1, pl) in enumerate(prof["DsvtLinearPlugin"]):
+            c = counts[(j // per_frame) % len(pool)]
+            f = pl.fields
+            rows = c[pl.rows_kind]          # "Nk" for the two PFN linears, "P" for everything on voxel rows
+            tot_ms += e0.elapsed_time(e1)
+            tot_flops += 2.0 * rows * f["in_features"] * f["out_features"]
+        n_launch = len(prof["DsvtLinearPlugin"])
+        avg_ms = tot_ms / n_launch
+        achieved = tot_flops / n_launch / (avg_ms * 1e-3) / 1e12
+        roofline = dict(kernel="linear_f32_kernel (DsvtLinearPlugin, v_mfma_f32_16x16x4_f32)", bound="mfma",
+                        achieved=round(achieved, 2), peak=PEAK_F32_MATRIX_TFLOPS, unit="TFLOP/s",
+                        frac=round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), traffic=None,
+                        launches_per_frame=per_frame, avg_launch_us=round(1e3 * avg_ms, 2),
+                        algorithmic_gflop_per_launch=round(tot_flops / n_launch / 1e9, 3))
+
+    if rank == 0:
+        total_frames = K * world
+        if world > 1:
+            assert gathered is not None and gathered.shape[0] == total_frames
+        line = {
+            "metric": "frames/sec (p50 per-frame ms in p50_ms), 180k-pt Waymo pillar DSVT",
+            "value": round(total_frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / K, 4), "p50_ms": round(float(np.median(frame_ms)), 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]: lidar_like({args.points}, seed) Waymo-shaped cloud, 0.32 m pillars, "
+                                   "468x468 BEV, full 4-block DSVT pillar backbone + BEV ResNet + CenterHead + "
+                                   "FilterBoxByScore; seeded random weights (dsvt.wts is not shipped)",
+                       "frames_per_gpu": K, "parallelism": f"frame-batch dp{world}, one result gather",
+                       "caps": dict(points=caps.N, pillars=caps.P, windows_sets=caps.W),
+                       "frame0": counts[0]},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            p0 = pool[0][0][0].cpu().numpy()
+            line["cpu_baseline"] = cpu_baseline(pkg, weights, caps, p0, int(pool[0][1][0]))
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

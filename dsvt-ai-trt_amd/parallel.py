@@ -1,0 +1,83 @@
+"""Frame-batch data parallelism: one process per GPU, frames sharded across ranks, and ONE
+collective per batch -- the gather of the per-frame results to rank 0 (RCCL over xGMI when the
+backend is "nccl"; the same code runs on "gloo" for the CPU tests).
+
+The reference is single-GPU, batch 1 (`cudaSetDevice(DEVICE)`, src/dsvt-ai-trt.cpp:1783;
+include/params.h:333), frames are independent units of work (one enqueueV2 per frame,
+src/dsvt-ai-trt.cpp:1884-1970), so the path shards by frame with no data-path exchange at all;
+the only thing that has to meet on one rank is the tiny result: [frames, 500*9 + 1] float32
+(18 kB per frame, latency-bound -- far below the ~153 GB/s of one xGMI link).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+ROW = 500 * 9 + 1        # boxes[500,9] flattened + the valid count (as float)
+
+
+def env_world():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init(backend=None):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  No-op for a
+    single process."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_frames(n_frames, rank, world):
+    """Frame f belongs to rank f mod world.  Returns this rank's global frame ids."""
+    return list(range(rank, n_frames, world))
+
+
+def pack_result(boxes, count, out_row):
+    """boxes [500,9] f32, count [1] i32 (device) -> one row of the result buffer, no host sync."""
+    out_row[:ROW - 1].copy_(boxes.reshape(-1))
+    out_row[ROW - 1:].copy_(count.reshape(-1).to(torch.float32))
+
+
+def unpack_result(row):
+    return row[:ROW - 1].reshape(500, 9), int(round(float(row[ROW - 1])))
+
+
+def gather_results(local, n_frames, rank, world, dst=0):
+    """local: [frames_of_this_rank, ROW].  Returns on `dst` a [n_frames, ROW] tensor in global frame
+    order (None elsewhere).  One gather for the whole batch; ranks may own a different number of
+    frames, so rows are padded to the maximum."""
+    if world == 1:
+        return local
+    per = (n_frames + world - 1) // world
+    pad = torch.zeros((per, ROW), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]].copy_(local)
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    if rank != dst:
+        return None
+    out = torch.empty((n_frames, ROW), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        ids = shard_frames(n_frames, r, world)
+        out[ids] = bufs[r][:len(ids)]
+    return out
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value, device):
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0])

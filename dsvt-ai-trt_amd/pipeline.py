@@ -78,6 +78,7 @@ class DsvtPipeline:
         W1, b1 = fold_linear_bn(w, "module.vfe.pfn_layers.1.linear", "module.vfe.pfn_layers.1.norm", 1e-5)
         self.pfn0 = zf(P.add_linear_op(W0, b0, c.Nk, activation=P.ACT_RELU))
         self.pfn1 = zf(P.add_linear_op(W1, b1, c.Nk, activation=P.ACT_RELU))
+        self.pfn0.rows_kind = self.pfn1.rows_kind = "Nk"      # rows = kept points, not pillars (bench flop count)
         self.smax0 = zf(P.add_torch_scatter_max(c.Nk, c.P, 96))
         self.smax1 = zf(P.add_torch_scatter_max(c.Nk, c.P, 192))
         self.wp = [zf(P.add_window_partition(c.W, c.Vw, GX, GY, GZ, *win, *shift)) for win, shift in WINS]

@@ -85,6 +85,11 @@ def _load():
 
 LIB = _load()
 
+# Optional per-launch timing hook used by bench.py's roofline measurement: when PROFILE is a dict
+# {plugin_type: [(start_event, end_event, plugin), ...]} every enqueue of a listed plugin type is
+# bracketed by HIP events on the launching stream.
+PROFILE = None
+
 EXPORTED_SYMBOLS = [
     "dsvtGetNbPluginTypes", "dsvtGetPluginTypeName", "dsvtGetFieldNames", "dsvtCreatePlugin",
     "dsvtDeserializePlugin", "dsvtPluginGetType", "dsvtPluginGetVersion", "dsvtPluginGetNbOutputs",
@@ -132,6 +137,8 @@ def _desc(shape, code):
 class Plugin:
     """One plugin instance (nvinfer1::IPluginV2DynamicExt)."""
 
+    rows_kind = "P"      # which device-side count bounds this op's rows (bench.py flop accounting)
+
     def __init__(self, plugin_type, fields=None, layer_name="", version="1", _handle=None):
         self.plugin_type = plugin_type
         self._keep = []
@@ -167,6 +174,7 @@ class Plugin:
             if not _handle:
                 raise ValueError(f"createPlugin({plugin_type}) rejected fields {fields}")
         self._h = C.c_void_p(_handle)
+        self.fields = {k: (v if not isinstance(v, np.ndarray) or v.size <= 8 else v.shape) for k, v in (fields or {}).items()}
         self.nb_outputs = LIB.dsvtPluginGetNbOutputs(self._h)
         self._cache = {}
 
@@ -256,7 +264,15 @@ class Plugin:
             ent = (outs, ws)
             self._cache[key] = ent
         outs, ws = ent
-        self.enqueue(list(inputs), outs, ws)
+        prof = PROFILE.get(self.plugin_type) if PROFILE is not None else None
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.enqueue(list(inputs), outs, ws)
+            e1.record()
+            prof.append((e0, e1, self))
+        else:
+            self.enqueue(list(inputs), outs, ws)
         return outs
 
     def __del__(self):
