@@ -1,0 +1,127 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/dsvt_plugin.h declares;
+creators advertise the reference's field names in the reference's order; serialisation has the
+reference's byte layout.  No compute calls here."""
+import ctypes
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# (plugin type, advertised fields in creator order, reference file:line of the creator)
+REFERENCE_FIELDS = {
+    "Points2FeaturesPlugin": ["max_points_num", "max_points_num_voxel_filter", "max_pillars_num", "point_feature_num",
+                              "feature_num", "max_num_points_per_voxel", "point_cloud_range", "voxel_size",
+                              "grid_size"],                                     # points2Features.cu:1084-1092
+    "TorchScatterMaxPlugin": ["max_points_num", "max_pillars_num", "feature_num"],            # torchScatterMax.cu:376-378
+    "WindowPartitionPlugin": ["max_win_num", "max_voxel_num_per_win", "sparse_shape", "win_shape", "shift_list"],  # windowPartition.cu:549-553
+    "GetSetPlugin": ["max_win_num", "max_voxel_num_per_win", "voxel_num_set", "win_shape"],   # getSet.cu:782-785
+    "GetValueByIndexPlugin": ["max_win_num", "voxel_num_set", "channel_num", "axis_id"],      # getValueByIndex.cu:427-430
+    "MapSetFeature2VoxelPlugin": ["max_win_num", "voxel_num_set", "channel_num", "axis_id", "max_pillars_num"],  # mapSetFeature2voxel.cu:393-397
+    "LayerNormPlugin": ["max_pillars_num", "channel_num", "weights_size", "pes", "weights", "bias"],              # layerNorm.cu:494-500 ("pes" sic)
+    "GeluPlugin": ["max_pillars_num", "channel_num"],                                         # gelu.cu:325-326
+    "Map2BevPlugin": ["max_pillars_num", "channel_num", "grid_size_x", "grid_size_y"],        # map2bev.cu:383-386
+    "FilterBoxByScorePlugin": ["max_top_k", "point_cloud_range", "voxel_size", "score_threshold"],  # filterBoxByScore.cu:459-462
+}
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    hdr = open(os.path.join(ROOT, "include", "dsvt_plugin.h")).read()
+    declared = sorted(set(re.findall(r"\b(dsvt[A-Z]\w+)\s*\(", hdr)))
+    assert len(declared) >= 19
+    lib = ctypes.CDLL(os.path.join(ROOT, "dsvt-ai-trt_amd", "libdsvt_hip.so"))
+    for name in declared:
+        assert getattr(lib, name) is not None, name
+    assert sorted(pkg.plugin.EXPORTED_SYMBOLS) == declared
+    lib.dsvtGetBuildInfo.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.dsvtGetBuildInfo()
+
+
+def test_registry_and_field_names(pkg):
+    P = pkg.plugin
+    types = P.plugin_types()
+    for t, fields in REFERENCE_FIELDS.items():
+        assert t in types
+        assert [n for n, _ in P.get_field_names(t)] == fields
+    for t in ("MultiHeadAttentionPlugin", "DsvtLinearPlugin", "DsvtSetAttentionPlugin"):
+        assert t in types
+    assert P.get_field_names("Points2FeaturesPlugin", "2") is None        # only version "1" is registered
+    assert P.get_field_names("NoSuchPlugin") is None
+    with pytest.raises(ValueError):
+        P.Plugin("NoSuchPlugin", {})
+
+
+def test_serialisation_layouts_match_reference(pkg):
+    P = pkg.plugin
+    f32 = lambda *v: struct.pack("<%df" % len(v), *[np.float32(x) for x in v])
+    i32 = lambda *v: struct.pack("<%di" % len(v), *v)
+    vg = P.add_voxel_generator(50000, 30000, 10000, 4, 10, 48, -74.88, 74.88, -74.88, 74.88, -5.0, 3.0, 0.32, 0.32, 8.0, 468, 468, 1)
+    # points2Features.cu:1038-1060: 6 ints, (xmin,xmax,ymin,ymax,zmin,zmax,vx,vy,vz), 3 ints
+    assert vg.serialize() == i32(50000, 30000, 10000, 4, 10, 48) + f32(-74.88, 74.88, -74.88, 74.88, -5.0, 3.0, 0.32, 0.32, 8.0) + i32(468, 468, 1)
+    assert P.add_torch_scatter_max(30000, 10000, 96).serialize() == i32(30000, 10000, 96)
+    wp = P.add_window_partition(800, 576, 468, 468, 1, 24, 24, 1, 6, 6, 0)
+    assert wp.serialize() == i32(468, 468, 1, 24, 24, 1, 6, 6, 0, 800, 576)              # windowPartition.cu:511-525
+    assert P.add_get_set_op(800, 576, 36, 12, 12, 1).serialize() == i32(36, 800, 576, 12, 12, 1)     # getSet.cu:749-758
+    assert P.add_get_value_by_index_op(800, 36, 192, 1).serialize() == i32(36, 800, 192, 1)
+    assert P.add_map_set_feature2voxel_op(800, 36, 192, 1, 10000).serialize() == i32(36, 800, 192, 10000, 1)
+    assert P.add_gelu_op(10000, 384).serialize() == i32(10000, 384)
+    assert P.add_map_2_bev_op(10000, 192, 468, 468).serialize() == i32(10000, 192, 468, 468)
+    fb = P.add_filter_box_by_score_op(500, -74.88, 74.88, -74.88, 74.88, -5.0, 3.0, 0.32, 0.32, 8.0, 0.3)
+    assert fb.serialize() == i32(500) + f32(-74.88, 74.88, -74.88, 74.88, -5.0, 3.0, 0.32, 0.32, 8.0, 0.3)   # filterBoxByScore.cu:420-435
+    g = np.linspace(0.8, 1.2, 192).astype(np.float32); b = np.linspace(-0.1, 0.1, 192).astype(np.float32)
+    ln = P.add_layer_norm_op(g, b, 10000, 192, 192, 1e-5)
+    assert ln.serialize() == i32(10000, 192, 192) + f32(0.0) + g.tobytes() + b.tobytes()  # eps = 0: the "pes" quirk
+    # deserialize(serialize(x)) serialises to the same bytes; clone too
+    for op in (vg, wp, fb, ln):
+        blob = op.serialize()
+        assert P.Plugin.deserialize(op.plugin_type, blob).serialize() == blob
+        assert op.clone().serialize() == blob
+    with pytest.raises(ValueError):
+        P.Plugin.deserialize("GetSetPlugin", b"\x00" * 8)          # truncated blob
+
+
+def test_output_dimensions_and_types(pkg):
+    P = pkg.plugin
+    vg = P.add_voxel_generator(50000, 30000, 10000, 4, 10, 48, -74.88, 74.88, -74.88, 74.88, -5.0, 3.0, 0.32, 0.32, 8.0, 468, 468, 1)
+    ins = [(1, 50000, 4), (1,)]
+    assert [vg.get_output_dimensions(i, ins) for i in range(6)] == [(1, 30000, 10), (1, 10000, 48), (1, 10000, 4), (1, 10000, 1), (1,), (1,)]
+    assert vg.nb_outputs == 6 and vg.get_output_data_type(0, [0, 3]) == 0 and vg.get_output_data_type(2, [0, 3]) == 3
+    with pytest.raises(IndexError):
+        vg.get_output_dimensions(6, ins)
+    gs = P.add_get_set_op(800, 576, 36, 12, 12, 1)
+    ins = [(1, 800, 576), (1, 800, 576, 3), (1, 800), (1,)]
+    assert [gs.get_output_dimensions(i, ins) for i in range(5)] == [(1, 2, 800, 36), (1, 2, 800, 36), (1,), (1, 800, 8, 36), (1, 800, 8, 36)]
+    wp = P.add_window_partition(800, 576, 468, 468, 1, 12, 12, 1, 0, 0, 0)
+    ins = [(1, 10000, 4), (1,)]
+    assert [wp.get_output_dimensions(i, ins) for i in range(6)] == [(1, 800, 576), (1, 800, 576, 3), (1, 800), (1,), (1, 10000, 3), (1, 10000, 2)]
+    fb = P.add_filter_box_by_score_op(500, -74.88, 74.88, -74.88, 74.88, -5.0, 3.0, 0.32, 0.32, 8.0, 0.3)
+    assert fb.get_output_dimensions(0, [(1, 500)]) == (1, 500, 9) and fb.get_output_dimensions(1, [(1, 500)]) == (1,)
+    # invalid construction parameters are rejected by createPlugin (returns NULL)
+    with pytest.raises(ValueError):
+        P.add_get_set_op(0, 576, 36, 12, 12, 1)
+    with pytest.raises(ValueError):
+        P.add_voxel_generator(50000, 30000, 10000, 4, 10, 100, -1, 1, -1, 1, -1, 1, 0.1, 0.1, 1, 20, 20, 1)   # > 64 points per pillar unsupported
+
+
+def test_no_cpu_path(pkg):
+    """The product path refuses host tensors instead of silently computing somewhere else."""
+    import torch
+    op = pkg.plugin.add_gelu_op(16, 8)
+    with pytest.raises(RuntimeError):
+        op(torch.zeros((1, 16, 8)), torch.zeros((1,), dtype=torch.int32))
+
+
+def test_wts_roundtrip(pkg, tmp_path):
+    w = {k: v for k, v in list(pkg.synth.make_weights(with_bev=False).items())[:6]}
+    path = str(tmp_path / "t.wts")
+    pkg.synth.write_wts(path, w)
+    r = pkg.synth.read_wts(path)
+    assert list(r) == list(w)
+    for k in w:
+        assert np.array_equal(r[k], w[k].reshape(-1))
+    s = pkg.synth.split_in_proj(pkg.synth.make_weights(with_bev=False))
+    k = "module.backbone_3d.stage_0.0.encoder_list.0.win_attn.self_attn.in_proj_weight"
+    assert s[k + ".query"].shape == (192, 192) and np.array_equal(s[k + ".value"], s[k][384:])

@@ -1,0 +1,76 @@
+"""Frame-batch data parallelism on CPU: world_size 2, gloo.  Covers the sharding rule and the one
+collective of the path (the result gather), with uneven frame counts."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _fake_frame(par, f):
+    """A recognisable per-frame result row: boxes filled with f + small offsets, count = f + 1."""
+    row = torch.zeros(par.ROW)
+    boxes = torch.arange(4500, dtype=torch.float32).reshape(500, 9) * 1e-3 + f
+    par.pack_result(boxes, torch.tensor([f + 1], dtype=torch.int32), row)
+    return row
+
+
+def _worker(rank, world, port, n_frames, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, ROOT)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("par", os.path.join(ROOT, "dsvt-ai-trt_amd", "parallel.py"))
+    par = importlib.util.module_from_spec(spec); spec.loader.exec_module(par)
+    r, _, w = par.init(backend="gloo")
+    ids = par.shard_frames(n_frames, r, w)
+    local = torch.stack([_fake_frame(par, f) for f in ids]) if ids else torch.zeros((0, par.ROW))
+    par.barrier()
+    out = par.gather_results(local, n_frames, r, w)
+    t = par.max_over_ranks(float(r + 1), torch.device("cpu"))
+    ok = abs(t - w) < 1e-9
+    if r == 0:
+        for f in range(n_frames):
+            b, c = par.unpack_result(out[f])
+            ok = ok and c == f + 1 and abs(float(b[0, 0]) - f) < 1e-6 and abs(float(b[499, 8]) - (f + 4.499)) < 1e-3
+        ok = ok and out.shape == (n_frames, par.ROW)
+    else:
+        ok = ok and out is None
+    q.put((r, bool(ok)))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [5, 8, 1])
+def test_gather_world2_gloo(n_frames):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == {0: True, 1: True}
+
+
+def test_shard_frames_partition():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("par", os.path.join(ROOT, "dsvt-ai-trt_amd", "parallel.py"))
+    par = importlib.util.module_from_spec(spec); spec.loader.exec_module(par)
+    for n in (0, 1, 7, 32):
+        for w in (1, 2, 4, 8):
+            parts = [par.shard_frames(n, r, w) for r in range(w)]
+            assert sorted(sum(parts, [])) == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    assert par.ROW == 4501
