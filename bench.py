@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 import __graft_entry__ as G  # noqa: E402
 
 PEAK_F32_MATRIX_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_F16_MATRIX_TFLOPS = 2500.0     # same guide: "Peak BF16/FP16 MFMA ~2.5 PF dense"
 N_POINTS = 180000
 FRAME_POOL = 4                      # distinct synthetic clouds cycled through by the steps
 
@@ -67,6 +68,9 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=N_POINTS)
+    ap.add_argument("--dtype", choices=["f32", "f16"], default="f16",
+                    help="f16: fp16 MFMA operands / fp16 dense head, fp32 accumulate + LayerNorm/softmax/decode "
+                         "(BASELINE configs[2]); f32: fp32 everywhere (the mode the 1e-3 box-parity tests run in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline = null)")
     args = ap.parse_args()
@@ -83,7 +87,10 @@ def main():
 
     caps = pkg.pipeline.Caps()                      # 196608 points / 65536 pillars / 2048 windows+sets
     weights = pkg.synth.make_weights()
-    pipe = pkg.pipeline.DsvtPipeline(weights, caps=caps, device=dev)
+    f16 = args.dtype == "f16"
+    pipe = pkg.pipeline.DsvtPipeline(weights, caps=caps, device=dev,
+                                     linear_compute=pkg.plugin.COMPUTE_F16 if f16 else pkg.plugin.COMPUTE_F32,
+                                     head_dtype=torch.float16 if f16 else torch.float32)
 
     # synthetic frames of this rank, resident in HBM before the timed region
     K = args.steps
@@ -140,9 +147,12 @@ def main():
         n_launch = len(prof["DsvtLinearPlugin"])
         avg_ms = tot_ms / n_launch
         achieved = tot_flops / n_launch / (avg_ms * 1e-3) / 1e12
-        roofline = dict(kernel="linear_f32_kernel (DsvtLinearPlugin, v_mfma_f32_16x16x4_f32)", bound="mfma",
-                        achieved=round(achieved, 2), peak=PEAK_F32_MATRIX_TFLOPS, unit="TFLOP/s",
-                        frac=round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), traffic=None,
+        peak = PEAK_F16_MATRIX_TFLOPS if f16 else PEAK_F32_MATRIX_TFLOPS
+        kname = ("linear_f16_kernel (DsvtLinearPlugin, v_mfma_f32_16x16x32_f16)" if f16
+                 else "linear_f32_kernel (DsvtLinearPlugin, v_mfma_f32_16x16x4_f32)")
+        roofline = dict(kernel=kname, bound="mfma",
+                        achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
+                        frac=round(achieved / peak, 4), traffic=None,
                         launches_per_frame=per_frame, avg_launch_us=round(1e3 * avg_ms, 2),
                         algorithmic_gflop_per_launch=round(tot_flops / n_launch / 1e9, 3))
 
@@ -154,7 +164,7 @@ def main():
             "metric": "frames/sec (p50 per-frame ms in p50_ms), 180k-pt Waymo pillar DSVT",
             "value": round(total_frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / K, 4), "p50_ms": round(float(np.median(frame_ms)), 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2]: lidar_like({args.points}, seed) Waymo-shaped cloud, 0.32 m pillars, "
                                    "468x468 BEV, full 4-block DSVT pillar backbone + BEV ResNet + CenterHead + "
                                    "FilterBoxByScore; seeded random weights (dsvt.wts is not shipped)",

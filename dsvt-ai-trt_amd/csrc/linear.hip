@@ -39,6 +39,67 @@ __device__ __forceinline__ float rowSum16(float v) {
     return v;
 }
 
+// Epilogue shared by the fp32 and fp16 MFMA kernels.  `acc` holds a 16-row x 192-column strip in
+// the MFMA C/D layout: lane (r, g) owns rows rbase + i (i = 0..3, rbase already includes 4g) and
+// columns n0 + t*16 + r.
+__device__ __forceinline__ void linearEpilogue(floatx4 (&acc)[NT], const LinearArgs& a, int n0, int rbase, int r, int M, int N)
+{
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int col = n0 + t * 16 + r;
+        float b = (a.bias && col < N) ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = acc[t][i] + b;
+            if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
+            else if (a.act == ACT_GELU) v = geluFast(v);
+            acc[t][i] = v;
+        }
+    }
+    for (int s = 0; s < a.n_ln; ++s) {       // y = LayerNorm_s(y + res_s); needs N <= BN (checked on the host)
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int col = t * 16 + r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row = rbase + i;
+                float v = acc[t][i];
+                if (col < N && row < M) v += a.res[s][(size_t)row * N + col]; else if (col >= N) v = 0.f;
+                acc[t][i] = v; sum[i] += v;
+            }
+        }
+        float mean[4], den[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mean[i] = rowSum16(sum[i]) / N;                 // layerNorm.cu:304-308
+        float sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (t * 16 + r < N)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { float d = acc[t][i] - mean[i]; sq[i] += d * d; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) den[i] = sqrtf(rowSum16(sq[i]) / N + a.eps);     // :333-337, :274
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int col = t * 16 + r;
+            float gm = col < N ? a.gamma[s][col] : 0.f, bt = col < N ? a.beta[s][col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[t][i] = (acc[t][i] - mean[i]) / den[i] * gm + bt;   // :274-276
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int col = n0 + t * 16 + r;
+        if (col < N)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row = rbase + i;
+                if (row < M) a.out[(size_t)row * a.out_ld + col] = acc[t][i];
+            }
+    }
+}
+
 template <bool VEC>
 __global__ void __launch_bounds__(256)
 linear_f32_kernel(LinearArgs a)
@@ -129,63 +190,118 @@ linear_f32_kernel(LinearArgs a)
             }
         }
 
-        // ---- epilogue: lane holds rows m0 + wave*16 + 4g + i (i = 0..3), cols n0 + t*16 + r ----
-        const int rbase = m0 + wave * 16 + g * 4;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            int col = n0 + t * 16 + r;
-            float b = (a.bias && col < N) ? a.bias[col] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v = acc[t][i] + b;
-                if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
-                else if (a.act == ACT_GELU) v = geluFast(v);
-                acc[t][i] = v;
-            }
-        }
-        for (int s = 0; s < a.n_ln; ++s) {       // y = LayerNorm_s(y + res_s); needs N <= BN (checked on the host)
-            float sum[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                int col = t * 16 + r;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int row = rbase + i;
-                    float v = acc[t][i];
-                    if (col < N && row < M) v += a.res[s][(size_t)row * N + col]; else if (col >= N) v = 0.f;
-                    acc[t][i] = v; sum[i] += v;
-                }
-            }
-            float mean[4], den[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) mean[i] = rowSum16(sum[i]) / N;                 // layerNorm.cu:304-308
-            float sq[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (t * 16 + r < N)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { float d = acc[t][i] - mean[i]; sq[i] += d * d; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) den[i] = sqrtf(rowSum16(sq[i]) / N + a.eps);     // :333-337, :274
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                int col = t * 16 + r;
-                float gm = col < N ? a.gamma[s][col] : 0.f, bt = col < N ? a.beta[s][col] : 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[t][i] = (acc[t][i] - mean[i]) / den[i] * gm + bt;   // :274-276
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            int col = n0 + t * 16 + r;
-            if (col < N)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int row = rbase + i;
-                    if (row < M) a.out[(size_t)row * a.out_ld + col] = acc[t][i];
-                }
-        }
+        linearEpilogue(acc, a, n0, m0 + wave * 16 + g * 4, r, M, N);
     }
+}
+
+// -------------------------------------------------------------------------------------
+// fp16-MFMA variant (v_mfma_f32_16x16x32_f16, fp32 accumulate; everything outside the products --
+// bias, GELU, residuals, LayerNorm -- stays fp32).  Activations stay fp32 in HBM and are rounded
+// to fp16 once, on their way into the A fragment.
+//   * W chunk (192 output columns x K) lives in LDS for the whole workgroup: [192][K+16] halfs,
+//     the 32-byte row pad makes the per-lane ds_read_b128 of a B fragment conflict-free;
+//   * A never touches LDS: in the 16x16x32 A layout a lane needs 8 consecutive k of one row, i.e.
+//     32 contiguous bytes of an fp32 row, and the four lane groups of a row cover one full 128-byte
+//     line -- a direct global load is already perfectly coalesced and each element is used by one
+//     wave only;
+//   * a wave owns 32 rows (two 16-row MFMA tiles) so every B fragment read from LDS feeds two
+//     MFMAs: one ds_read_b128 per MFMA would need 240 B/clk/CU of LDS bandwidth (peak 256).
+// Workgroup = 4 waves = 128 rows x 192 columns; N > 192 loops over column chunks.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+constexpr int BM16 = 128;
+
+__device__ __forceinline__ half8 toHalf8(float4 x, float4 y) {
+    half8 h;
+    h[0] = (_Float16)x.x; h[1] = (_Float16)x.y; h[2] = (_Float16)x.z; h[3] = (_Float16)x.w;
+    h[4] = (_Float16)y.x; h[5] = (_Float16)y.y; h[6] = (_Float16)y.z; h[7] = (_Float16)y.w;
+    return h;
+}
+
+template <int KT>
+__global__ void __launch_bounds__(256, 2)
+linear_f16_kernel(LinearArgs a, const _Float16* __restrict__ Wh)
+{
+    extern __shared__ __attribute__((aligned(16))) _Float16 sWh[];
+    uint32_t cnt = *a.count;
+    long long Mll = (long long)cnt * a.row_mult;
+    const int M = (int)(Mll < a.max_rows ? Mll : a.max_rows);
+    const int m0 = blockIdx.x * BM16;
+    if (m0 >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int K = KT ? KT : a.K, N = a.N, LDW = K + 16, KC = K / 8;
+
+    for (int n0 = 0; n0 < N; n0 += BN) {
+        __syncthreads();
+        for (int i = tid; i < BN * KC; i += 256) {
+            int n = i / KC, c = i % KC;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (n0 + n < N) v = *reinterpret_cast<const uint4*>(Wh + (size_t)(n0 + n) * K + c * 8);
+            *reinterpret_cast<uint4*>(&sWh[n * LDW + c * 8]) = v;
+        }
+        __syncthreads();
+        floatx4 acc0[NT], acc1[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { acc0[t] = floatx4{0.f, 0.f, 0.f, 0.f}; acc1[t] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+        const bool add = n0 < a.add_cols;
+        const int ntiles = (N - n0 + 15) / 16 < NT ? (N - n0 + 15) / 16 : NT;
+        int row0 = m0 + wave * 32 + r, row1 = row0 + 16;
+        row0 = row0 < M ? row0 : M - 1; row1 = row1 < M ? row1 : M - 1;        // clamp: rows >= M are never stored
+        const float* pa0 = a.A + (size_t)row0 * K + g * 8;
+        const float* pa1 = a.A + (size_t)row1 * K + g * 8;
+        const float* pb0 = add ? a.A2 + (size_t)row0 * K + g * 8 : nullptr;
+        const float* pb1 = add ? a.A2 + (size_t)row1 * K + g * 8 : nullptr;
+        // software pipeline: the global loads of k-step s+1 are in flight while step s runs on the MFMAs
+        float4 x0 = *reinterpret_cast<const float4*>(pa0), x1 = *reinterpret_cast<const float4*>(pa0 + 4);
+        float4 y0 = *reinterpret_cast<const float4*>(pa1), y1 = *reinterpret_cast<const float4*>(pa1 + 4);
+        float4 p0, p1, q0, q1;
+        if (add) {
+            p0 = *reinterpret_cast<const float4*>(pb0); p1 = *reinterpret_cast<const float4*>(pb0 + 4);
+            q0 = *reinterpret_cast<const float4*>(pb1); q1 = *reinterpret_cast<const float4*>(pb1 + 4);
+        }
+#pragma unroll 1
+        for (int k0 = 0; k0 < K; k0 += 32) {
+            if (add) {
+                x0.x += p0.x; x0.y += p0.y; x0.z += p0.z; x0.w += p0.w; x1.x += p1.x; x1.y += p1.y; x1.z += p1.z; x1.w += p1.w;
+                y0.x += q0.x; y0.y += q0.y; y0.z += q0.z; y0.w += q0.w; y1.x += q1.x; y1.y += q1.y; y1.z += q1.z; y1.w += q1.w;
+            }
+            const half8 af0 = toHalf8(x0, x1), af1 = toHalf8(y0, y1);
+            const int kn = k0 + 32 < K ? k0 + 32 : k0;             // last step re-reads its own chunk (harmless)
+            x0 = *reinterpret_cast<const float4*>(pa0 + kn); x1 = *reinterpret_cast<const float4*>(pa0 + kn + 4);
+            y0 = *reinterpret_cast<const float4*>(pa1 + kn); y1 = *reinterpret_cast<const float4*>(pa1 + kn + 4);
+            if (add) {
+                p0 = *reinterpret_cast<const float4*>(pb0 + kn); p1 = *reinterpret_cast<const float4*>(pb0 + kn + 4);
+                q0 = *reinterpret_cast<const float4*>(pb1 + kn); q1 = *reinterpret_cast<const float4*>(pb1 + kn + 4);
+            }
+            const _Float16* pw = &sWh[r * LDW + k0 + g * 8];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (t < ntiles) {
+                    const half8 bf = *reinterpret_cast<const half8*>(pw + t * 16 * LDW);
+                    acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af0, bf, acc0[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af1, bf, acc1[t], 0, 0, 0);
+                }
+            }
+        }
+        linearEpilogue(acc0, a, n0, m0 + wave * 32 + g * 4, r, M, N);
+        linearEpilogue(acc1, a, n0, m0 + wave * 32 + 16 + g * 4, r, M, N);
+    }
+}
+
+int launchLinearF16(const LinearArgs& a, const _Float16* Wh, hipStream_t stream) {
+    static bool attr_done = false;
+    const size_t lds = sizeof(_Float16) * (size_t)BN * (a.K + 16);
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_f16_kernel<192>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_f16_kernel<384>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_f16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    dim3 grid(cdiv(a.max_rows, BM16)), block(256);
+    if (a.K == 192) hipLaunchKernelGGL(linear_f16_kernel<192>, grid, block, lds, stream, a, Wh);
+    else if (a.K == 384) hipLaunchKernelGGL(linear_f16_kernel<384>, grid, block, lds, stream, a, Wh);
+    else hipLaunchKernelGGL(linear_f16_kernel<0>, grid, block, lds, stream, a, Wh);
+    return lastError();
 }
 
 int launchLinearF32(const LinearArgs& a, hipStream_t stream) {
@@ -199,13 +315,16 @@ int launchLinearF32(const LinearArgs& a, hipStream_t stream) {
 class DsvtLinearPlugin : public Plugin {
 public:
     int max_rows_, K_, N_, row_mult_, act_, add_cols_, n_ln_; float eps_;
+    int compute_type_;                 // 0: fp32 MFMA (exact fp32 products)   1: fp16 MFMA, fp32 accumulate
     std::vector<float> w_, b_, g_, be_;
     float *w_dev_ = nullptr, *b_dev_ = nullptr, *g_dev_ = nullptr, *be_dev_ = nullptr;
+    _Float16* wh_dev_ = nullptr;
     bool ok_ = false;
-    DsvtLinearPlugin(int max_rows, int K, int N, int row_mult, int act, int add_cols, int n_ln, float eps,
+    bool useF16() const { return compute_type_ == 1 && K_ % 32 == 0 && K_ <= 384; }
+    DsvtLinearPlugin(int max_rows, int K, int N, int row_mult, int act, int add_cols, int n_ln, float eps, int compute_type,
                      const float* w, const float* b, const float* g, const float* be)
         : max_rows_(max_rows), K_(K), N_(N), row_mult_(row_mult), act_(act), add_cols_(add_cols), n_ln_(n_ln), eps_(eps),
-          w_(w, w + (size_t)N * K) {
+          compute_type_(compute_type), w_(w, w + (size_t)N * K) {
         if (b) b_.assign(b, b + N);
         if (n_ln) { g_.assign(g, g + (size_t)n_ln * N); be_.assign(be, be + (size_t)n_ln * N); }
         auto up = [](const std::vector<float>& h, float** d) {
@@ -214,9 +333,16 @@ public:
             return hipMemcpy(*d, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice) == hipSuccess;
         };
         ok_ = up(w_, &w_dev_) && up(b_, &b_dev_) && up(g_, &g_dev_) && up(be_, &be_dev_);
+        if (ok_ && useF16()) {
+            std::vector<_Float16> wh(w_.size());
+            for (size_t i = 0; i < w_.size(); ++i) wh[i] = (_Float16)w_[i];
+            ok_ = hipMalloc(&wh_dev_, sizeof(_Float16) * wh.size()) == hipSuccess &&
+                  hipMemcpy(wh_dev_, wh.data(), sizeof(_Float16) * wh.size(), hipMemcpyHostToDevice) == hipSuccess;
+        }
     }
     ~DsvtLinearPlugin() override {
         for (float* p : {w_dev_, b_dev_, g_dev_, be_dev_}) if (p) (void)hipFree(p);
+        if (wh_dev_) (void)hipFree(wh_dev_);
     }
     const char* type() const override { return "DsvtLinearPlugin"; }
     int nbOutputs() const override { return 1; }
@@ -247,30 +373,31 @@ public:
         a.row_mult = row_mult_; a.max_rows = max_rows_; a.K = K_; a.N = N_; a.add_cols = add_cols_; a.act = act_;
         a.n_ln = n_ln_; a.eps = eps_; a.out_ld = N_;
         if (zeroFill) DSVT_CHECK(hipMemsetAsync(out[0], 0, sizeof(float) * (size_t)max_rows_ * N_, stream));
-        return launchLinearF32(a, stream);
+        return useF16() ? launchLinearF16(a, wh_dev_, stream) : launchLinearF32(a, stream);
     }
     size_t serializationSize() const override {
-        return 7 * sizeof(int) + sizeof(float) + sizeof(int) + sizeof(float) * (w_.size() + b_.size() + g_.size() + be_.size());
+        return 7 * sizeof(int) + sizeof(float) + 2 * sizeof(int) + sizeof(float) * (w_.size() + b_.size() + g_.size() + be_.size());
     }
     void serialize(void* buf) const override {
         char* d = static_cast<char*>(buf);
         wr<int>(d, max_rows_); wr<int>(d, K_); wr<int>(d, N_); wr<int>(d, row_mult_); wr<int>(d, act_); wr<int>(d, add_cols_);
-        wr<int>(d, n_ln_); wr<float>(d, eps_); wr<int>(d, b_.empty() ? 0 : 1);
+        wr<int>(d, n_ln_); wr<float>(d, eps_); wr<int>(d, b_.empty() ? 0 : 1); wr<int>(d, compute_type_);
         for (const std::vector<float>* v : {&w_, &b_, &g_, &be_}) { memcpy(d, v->data(), sizeof(float) * v->size()); d += sizeof(float) * v->size(); }
     }
     Plugin* clone() const override {
-        return new DsvtLinearPlugin(max_rows_, K_, N_, row_mult_, act_, add_cols_, n_ln_, eps_, w_.data(),
+        return new DsvtLinearPlugin(max_rows_, K_, N_, row_mult_, act_, add_cols_, n_ln_, eps_, compute_type_, w_.data(),
                                     b_.empty() ? nullptr : b_.data(), g_.data(), be_.data());
     }
 };
 
-static Plugin* linNew(int max_rows, int K, int N, int row_mult, int act, int add_cols, int n_ln, float eps,
+static Plugin* linNew(int max_rows, int K, int N, int row_mult, int act, int add_cols, int n_ln, float eps, int compute_type,
                       const float* w, const float* b, const float* g, const float* be) {
     if (max_rows <= 0 || K <= 0 || N <= 0 || row_mult <= 0 || !w) return nullptr;
+    if (compute_type < 0 || compute_type > 1) return nullptr;
     if (act < 0 || act > 2 || n_ln < 0 || n_ln > 3) return nullptr;
     if (n_ln > 0 && (N > BN || !g || !be)) return nullptr;                  // a LayerNorm row must fit one tile
     if (add_cols < 0 || add_cols > N || (add_cols % BN != 0 && add_cols != N)) return nullptr;
-    DsvtLinearPlugin* p = new DsvtLinearPlugin(max_rows, K, N, row_mult, act, add_cols, n_ln, eps, w, b, g, be);
+    DsvtLinearPlugin* p = new DsvtLinearPlugin(max_rows, K, N, row_mult, act, add_cols, n_ln, eps, compute_type, w, b, g, be);
     return p;
 }
 static Plugin* linCreate(const DsvtPluginFieldCollection* fc) {
@@ -281,28 +408,30 @@ static Plugin* linCreate(const DsvtPluginFieldCollection* fc) {
     if (b && b->data && b->length != N) return nullptr;
     if (n_ln > 0 && (!g || !be || g->length != n_ln * N || be->length != n_ln * N)) return nullptr;
     return linNew(fieldInt(fc, "max_rows"), K, N, fieldInt(fc, "row_mult", 1), fieldInt(fc, "activation"),
-                  fieldInt(fc, "add_cols"), n_ln, fieldFloat(fc, "ln_eps", 0.f), static_cast<const float*>(w->data),
+                  fieldInt(fc, "add_cols"), n_ln, fieldFloat(fc, "ln_eps", 0.f), fieldInt(fc, "compute_type", 0),
+                  static_cast<const float*>(w->data),
                   (b && b->data) ? static_cast<const float*>(b->data) : nullptr,
                   g ? static_cast<const float*>(g->data) : nullptr, be ? static_cast<const float*>(be->data) : nullptr);
 }
 static Plugin* linDeser(const void* data, size_t len) {
-    if (len < 8 * sizeof(int) + sizeof(float)) return nullptr;
+    if (len < 9 * sizeof(int) + sizeof(float)) return nullptr;
     const char* d = static_cast<const char*>(data);
     int max_rows = rd<int>(d), K = rd<int>(d), N = rd<int>(d), row_mult = rd<int>(d), act = rd<int>(d), add_cols = rd<int>(d);
-    int n_ln = rd<int>(d); float eps = rd<float>(d); int has_b = rd<int>(d);
+    int n_ln = rd<int>(d); float eps = rd<float>(d); int has_b = rd<int>(d); int ctype = rd<int>(d);
     if (K <= 0 || N <= 0 || n_ln < 0 || n_ln > 3) return nullptr;
     size_t need = (size_t)K * N + (has_b ? N : 0) + 2 * (size_t)n_ln * N;
-    if (len < 8 * sizeof(int) + sizeof(float) + need * sizeof(float)) return nullptr;
+    if (len < 9 * sizeof(int) + sizeof(float) + need * sizeof(float)) return nullptr;
     std::vector<float> all(need);
     memcpy(all.data(), d, need * sizeof(float));
     const float* w = all.data(); const float* b = has_b ? w + (size_t)K * N : nullptr;
     const float* g = w + (size_t)K * N + (has_b ? N : 0); const float* be = g + (size_t)n_ln * N;
-    return linNew(max_rows, K, N, row_mult, act, add_cols, n_ln, eps, w, b, g, be);
+    return linNew(max_rows, K, N, row_mult, act, add_cols, n_ln, eps, ctype, w, b, g, be);
 }
 static Creator g_linCreator{"DsvtLinearPlugin",
     {{"max_rows", DSVT_FIELD_INT32}, {"in_features", DSVT_FIELD_INT32}, {"out_features", DSVT_FIELD_INT32},
      {"row_mult", DSVT_FIELD_INT32}, {"activation", DSVT_FIELD_INT32}, {"add_cols", DSVT_FIELD_INT32},
-     {"num_layer_norms", DSVT_FIELD_INT32}, {"ln_eps", DSVT_FIELD_FLOAT32}, {"weight", DSVT_FIELD_FLOAT32},
+     {"num_layer_norms", DSVT_FIELD_INT32}, {"ln_eps", DSVT_FIELD_FLOAT32}, {"compute_type", DSVT_FIELD_INT32},
+     {"weight", DSVT_FIELD_FLOAT32},
      {"bias", DSVT_FIELD_FLOAT32}, {"ln_weights", DSVT_FIELD_FLOAT32}, {"ln_bias", DSVT_FIELD_FLOAT32}},
     linCreate, linDeser, {}, {}};
 static Registrar g_linReg(&g_linCreator);

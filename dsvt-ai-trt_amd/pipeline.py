@@ -65,19 +65,23 @@ def fold_linear_bn(w, lin, bn, eps, bias=False):
 
 class DsvtPipeline:
     def __init__(self, weights, caps=None, blocks=4, with_head=True, ln_eps=0.0, head_dtype=torch.float32,
-                 device="cuda:0", zero_fill=False):
+                 device="cuda:0", zero_fill=False, linear_compute=P.COMPUTE_F32):
+        """linear_compute: COMPUTE_F32 = fp32 MFMA everywhere (parity mode, boxes within 1e-3 of the
+        fp32 oracle); COMPUTE_F16 = fp16 MFMA operands with fp32 accumulate/epilogues (BASELINE
+        configs[2] "fp16").  head_dtype: precision of the dense BEV glue."""
         self.caps = c = caps or Caps()
         self.blocks, self.with_head, self.device = blocks, with_head, torch.device(device)
         self.head_dtype = head_dtype
         w = weights
         zf = lambda op: op.set_zero_fill(zero_fill)
+        ct = dict(compute_type=linear_compute)
         self.voxelizer = zf(P.add_voxel_generator(c.N, c.Nk, c.P, 4, 10, 48, X_MIN, X_MAX, Y_MIN, Y_MAX, Z_MIN, Z_MAX,
                                                   VX, VY, VZ, GX, GY, GZ))
         # PFN: FC (no bias) + BN1d(1e-5) + ReLU, BN folded into the FC           (:268-286, :577, :587)
         W0, b0 = fold_linear_bn(w, "module.vfe.pfn_layers.0.linear", "module.vfe.pfn_layers.0.norm", 1e-5)
         W1, b1 = fold_linear_bn(w, "module.vfe.pfn_layers.1.linear", "module.vfe.pfn_layers.1.norm", 1e-5)
-        self.pfn0 = zf(P.add_linear_op(W0, b0, c.Nk, activation=P.ACT_RELU))
-        self.pfn1 = zf(P.add_linear_op(W1, b1, c.Nk, activation=P.ACT_RELU))
+        self.pfn0 = zf(P.add_linear_op(W0, b0, c.Nk, activation=P.ACT_RELU, **ct))
+        self.pfn1 = zf(P.add_linear_op(W1, b1, c.Nk, activation=P.ACT_RELU, **ct))
         self.pfn0.rows_kind = self.pfn1.rows_kind = "Nk"      # rows = kept points, not pillars (bench flop count)
         self.smax0 = zf(P.add_torch_scatter_max(c.Nk, c.P, 96))
         self.smax1 = zf(P.add_torch_scatter_max(c.Nk, c.P, 192))
@@ -89,8 +93,8 @@ class DsvtPipeline:
             for l in range(2):
                 pre = f"module.backbone_3d.input_layer.posembed_layers.0.{b}.{l}.position_embedding_head"
                 Wa, ba = fold_linear_bn(w, pre + ".0", pre + ".1", 1e-5, bias=True)                 # :461-492
-                self.pe[(b, l)] = (zf(P.add_linear_op(Wa, ba, c.P, activation=P.ACT_RELU)),
-                                   zf(P.add_linear_op(w[pre + ".3.weight"], w[pre + ".3.bias"], c.P)))
+                self.pe[(b, l)] = (zf(P.add_linear_op(Wa, ba, c.P, activation=P.ACT_RELU, **ct)),
+                                   zf(P.add_linear_op(w[pre + ".3.weight"], w[pre + ".3.bias"], c.P, **ct)))
                 lp = f"module.backbone_3d.stage_0.{b}.encoder_list.{l}"
                 wi = w[lp + ".win_attn.self_attn.in_proj_weight"].copy()
                 bi = w[lp + ".win_attn.self_attn.in_proj_bias"].copy()
@@ -101,15 +105,15 @@ class DsvtPipeline:
                     lns2.append((w[f"module.backbone_3d.residual_norm_stage_0.{b}.weight"],
                                  w[f"module.backbone_3d.residual_norm_stage_0.{b}.bias"]))
                 self.layers[(b, l)] = dict(
-                    qkv=zf(P.add_linear_op(wi, bi, c.P, add_cols=2 * C)),
+                    qkv=zf(P.add_linear_op(wi, bi, c.P, add_cols=2 * C, **ct)),
                     attn=zf(P.add_set_attention_op(c.W, L_SET, C, H, l, c.P)),
                     out=zf(P.add_linear_op(w[lp + ".win_attn.self_attn.out_proj.weight"],
                                            w[lp + ".win_attn.self_attn.out_proj.bias"], c.P,
-                                           layer_norms=[ln(".win_attn.norm1")], ln_eps=ln_eps)),
+                                           layer_norms=[ln(".win_attn.norm1")], ln_eps=ln_eps, **ct)),
                     fc1=zf(P.add_linear_op(w[lp + ".win_attn.linear1.weight"], w[lp + ".win_attn.linear1.bias"], c.P,
-                                           activation=P.ACT_GELU)),
+                                           activation=P.ACT_GELU, **ct)),
                     fc2=zf(P.add_linear_op(w[lp + ".win_attn.linear2.weight"], w[lp + ".win_attn.linear2.bias"], c.P,
-                                           layer_norms=lns2, ln_eps=ln_eps)))
+                                           layer_norms=lns2, ln_eps=ln_eps, **ct)))
         self.cat = torch.zeros((1, c.Nk, 192), dtype=torch.float32, device=self.device)
         if with_head:
             self.map2bev = P.add_map_2_bev_op(c.P, C, GX, GY)

@@ -113,3 +113,34 @@ def test_fused_set_attention_equals_unfused_chain(pkg, oracle, axis):
     out = P.add_linear_op(w[pre + ".out_proj.weight"], w[pre + ".out_proj.bias"], c["P"])(att, scalar(Pn))[0]
     o = host(out)[0]
     assert np.abs(o[:Pn] - ref[:Pn]).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("K,N,act,nln", [(192, 192, 0, 1), (192, 384, 2, 0), (384, 192, 0, 3), (192, 576, 0, 0)])
+def test_linear_f16_mfma(pkg, oracle, K, N, act, nln):
+    """fp16-operand MFMA variant (compute_type=1): inputs rounded to fp16 (2^-11 relative), fp32
+    accumulation and epilogues => 2e-3 of the output scale; must equal the fp32 kernel run on
+    pre-rounded operands to fp32 summation-order noise."""
+    P = pkg.plugin
+    rng = np.random.default_rng(K + N + act)
+    MR, n = 8192, 5504
+    A = np.zeros((MR, K), np.float32); A[:n] = rng.standard_normal((n, K))
+    A2 = np.zeros((MR, K), np.float32); A2[:n] = rng.standard_normal((n, K)) * 0.5
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32); b = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    res = [np.zeros((MR, N), np.float32) for _ in range(nln)]
+    for r_ in res:
+        r_[:n] = rng.standard_normal((n, N))
+    lns = [(rng.uniform(0.8, 1.2, N).astype(np.float32), (rng.standard_normal(N) * 0.05).astype(np.float32)) for _ in range(nln)]
+    add_cols = 384 if N == 576 else 0
+    extra = ([dev(A2[None])] if add_cols else []) + [dev(r_[None]) for r_ in res]
+    kw = dict(activation=act, add_cols=add_cols, layer_norms=lns)
+    o16 = host(P.add_linear_op(W, b, MR, compute_type=P.COMPUTE_F16, **kw)(dev(A[None]), scalar(n), *extra)[0])[0]
+    o32 = host(P.add_linear_op(W, b, MR, compute_type=P.COMPUTE_F32, **kw)(dev(A[None]), scalar(n), *extra)[0])[0]
+    scale = np.abs(o32[:n]).max()
+    assert np.abs(o16[:n] - o32[:n]).max() < 2e-3 * scale
+    assert not o16[n:].any()
+    if add_cols == 0:
+        # same kernel maths on operands that are already fp16-representable: only summation order differs
+        Ah = A.astype(np.float16).astype(np.float32); Wh = W.astype(np.float16).astype(np.float32)
+        e16 = host(P.add_linear_op(Wh, b, MR, compute_type=P.COMPUTE_F16, **kw)(dev(Ah[None]), scalar(n), *extra)[0])[0]
+        e32 = host(P.add_linear_op(Wh, b, MR, compute_type=P.COMPUTE_F32, **kw)(dev(Ah[None]), scalar(n), *extra)[0])[0]
+        assert np.abs(e16[:n] - e32[:n]).max() < 2e-5 * scale
