@@ -34,16 +34,19 @@ constexpr int AHB = 4;        // heads per workgroup
 constexpr int ALD = 100;      // LDS row stride in floats (96 + 4)
 
 struct AttnArgs {
-    const float* qkv; int qkv_ld;        // rows x [q(C) | k(C) | v(C)]
+    const void* qkv; int qkv_ld;         // rows x [q(C) | k(C) | v(C)], fp32 or (IO16) fp16
     const uint32_t* inds;                // [S, 36] voxel row of each slot, or nullptr: row = set*36 + slot
     const float* mask; int mask_set_stride, mask_head_stride;
     const uint32_t* set_num; int max_sets;
-    float* out; int out_ld;
+    void* out; int out_ld;               // fp32 or (IO16) fp16
     int C, H;
 };
 
+// IO16: Q/K/V rows arrive as fp16 and the result is written as fp16; the arithmetic in between
+// (fp32 LDS image, fp32 MFMA, fp32 softmax) is the same.
+template <bool IO16>
 __global__ void __launch_bounds__(256)
-set_attention_f32_kernel(AttnArgs a)
+set_attention_kernel(AttnArgs a)
 {
     __shared__ __attribute__((aligned(16))) float sQ[AL * ALD];
     __shared__ __attribute__((aligned(16))) float sK[AL * ALD];
@@ -65,12 +68,24 @@ set_attention_f32_kernel(AttnArgs a)
     }
     __syncthreads();
     // ---- stage the 36 gathered rows: 3 segments x 24 float4 each -----------------------------
-    for (int i = tid; i < AL * 3 * 24; i += 256) {
-        int slot = i / 72, rem = i % 72, seg = rem / 24, c4 = (rem % 24) * 4;
-        const float* src = a.qkv + (size_t)sRow[slot] * a.qkv_ld + seg * a.C + hq * (AHB * ADH) + c4;
-        float4 v = *reinterpret_cast<const float4*>(src);
-        float* dst = (seg == 0 ? sQ : seg == 1 ? sK : sV) + slot * ALD + c4;
-        *reinterpret_cast<float4*>(dst) = v;
+    if (IO16) {
+        typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+        for (int i = tid; i < AL * 3 * 12; i += 256) {
+            int slot = i / 36, rem = i % 36, seg = rem / 12, c8 = (rem % 12) * 8;
+            const _Float16* src = static_cast<const _Float16*>(a.qkv) + (size_t)sRow[slot] * a.qkv_ld + seg * a.C + hq * (AHB * ADH) + c8;
+            const half8v v = *reinterpret_cast<const half8v*>(src);
+            float* dst = (seg == 0 ? sQ : seg == 1 ? sK : sV) + slot * ALD + c8;
+            *reinterpret_cast<float4*>(dst) = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4((float)v[4], (float)v[5], (float)v[6], (float)v[7]);
+        }
+    } else {
+        for (int i = tid; i < AL * 3 * 24; i += 256) {
+            int slot = i / 72, rem = i % 72, seg = rem / 24, c4 = (rem % 24) * 4;
+            const float* src = static_cast<const float*>(a.qkv) + (size_t)sRow[slot] * a.qkv_ld + seg * a.C + hq * (AHB * ADH) + c4;
+            float4 v = *reinterpret_cast<const float4*>(src);
+            float* dst = (seg == 0 ? sQ : seg == 1 ? sK : sV) + slot * ALD + c4;
+            *reinterpret_cast<float4*>(dst) = v;
+        }
     }
     __syncthreads();
 
@@ -163,15 +178,22 @@ set_attention_f32_kernel(AttnArgs a)
             int q = 16 * u + 4 * g + i;
             if (q >= AL) continue;
             if (a.inds && sMask[wave][q] < 0.f) continue;      // duplicate slot: the first occurrence writes the identical row
-            float* dst = a.out + (size_t)sRow[q] * a.out_ld + h * ADH;
-            dst[r] = oc[u][0][i];
-            if (16 + r < ADH) dst[16 + r] = oc[u][1][i];
+            if (IO16) {
+                _Float16* dst = static_cast<_Float16*>(a.out) + (size_t)sRow[q] * a.out_ld + h * ADH;
+                dst[r] = (_Float16)oc[u][0][i];
+                if (16 + r < ADH) dst[16 + r] = (_Float16)oc[u][1][i];
+            } else {
+                float* dst = static_cast<float*>(a.out) + (size_t)sRow[q] * a.out_ld + h * ADH;
+                dst[r] = oc[u][0][i];
+                if (16 + r < ADH) dst[16 + r] = oc[u][1][i];
+            }
         }
 }
 
-static int launchAttention(const AttnArgs& a, hipStream_t stream) {
+static int launchAttention(const AttnArgs& a, bool io16, hipStream_t stream) {
     dim3 grid((unsigned)(a.max_sets * (a.H / AHB))), block(256);
-    hipLaunchKernelGGL(set_attention_f32_kernel, grid, block, 0, stream, a);
+    if (io16) hipLaunchKernelGGL(set_attention_kernel<true>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(set_attention_kernel<false>, grid, block, 0, stream, a);
     return lastError();
 }
 
@@ -235,7 +257,7 @@ public:
         aa.qkv = qkv; aa.qkv_ld = 3 * C_; aa.inds = nullptr;
         aa.mask = static_cast<const float*>(in[3]); aa.mask_set_stride = H_ * L_; aa.mask_head_stride = L_;   // [S,H,36]
         aa.set_num = S; aa.max_sets = max_win_num_; aa.out = att; aa.out_ld = C_; aa.C = C_; aa.H = H_;
-        int rc = launchAttention(aa, stream); if (rc) return rc;
+        int rc = launchAttention(aa, false, stream); if (rc) return rc;
         if (zeroFill) DSVT_CHECK(hipMemsetAsync(out[0], 0, sizeof(float) * rows() * C_, stream));
         LinearArgs lo{};                                                           // :448 out_proj
         lo.A = att; lo.W = wo_dev_; lo.bias = bo_dev_; lo.out = static_cast<float*>(out[0]); lo.out_ld = C_;
@@ -285,8 +307,9 @@ static Registrar g_mhaReg(&g_mhaCreator);
 // =====================================================================================
 class DsvtSetAttentionPlugin : public Plugin {
 public:
-    int max_win_num_, L_, C_, H_, axis_id_, max_pillars_num_;
-    DsvtSetAttentionPlugin(int mw, int L, int C, int H, int axis, int mp) : max_win_num_(mw), L_(L), C_(C), H_(H), axis_id_(axis), max_pillars_num_(mp) {}
+    int max_win_num_, L_, C_, H_, axis_id_, max_pillars_num_, io_half_;
+    DsvtSetAttentionPlugin(int mw, int L, int C, int H, int axis, int mp, int io_half)
+        : max_win_num_(mw), L_(L), C_(C), H_(H), axis_id_(axis), max_pillars_num_(mp), io_half_(io_half) {}
     const char* type() const override { return "DsvtSetAttentionPlugin"; }
     int nbOutputs() const override { return 1; }
     int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
@@ -295,45 +318,49 @@ public:
     }
     int outputType(int, const int32_t* t, int) const override { return t[0]; }
     bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int, int) const override {
-        return (pos == 1 || pos == 3) ? i32Lin(io[pos]) : pos >= 0 && pos <= 4 && f32Lin(io[pos]);
+        if (pos == 1 || pos == 3) return i32Lin(io[pos]);
+        if (pos == 2) return f32Lin(io[pos]);
+        return (pos == 0 || pos == 4) && io[pos].format == DSVT_FORMAT_LINEAR && io[pos].type == (io_half_ ? DSVT_HALF : DSVT_FLOAT);
     }
     size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override { return 0; }
     int enqueue(const DsvtPluginTensorDesc*, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void*,
                 hipStream_t stream) override {
-        if (zeroFill) DSVT_CHECK(hipMemsetAsync(out[0], 0, sizeof(float) * (size_t)max_pillars_num_ * C_, stream));   // mapSetFeature2voxel.cu:314
+        if (zeroFill) DSVT_CHECK(hipMemsetAsync(out[0], 0, (io_half_ ? 2 : 4) * (size_t)max_pillars_num_ * C_, stream));   // mapSetFeature2voxel.cu:314
         AttnArgs aa{};
-        aa.qkv = static_cast<const float*>(in[0]); aa.qkv_ld = 3 * C_;
+        aa.qkv = in[0]; aa.qkv_ld = 3 * C_;
         aa.inds = static_cast<const uint32_t*>(in[1]) + (size_t)axis_id_ * max_win_num_ * L_;    // getValueByIndex.cu:292
         // the reference feeds the axis-0 mask to both layers of a block (src/dsvt-ai-trt.cpp:658,708);
         // the two axes mask the same slots, so axis 0 is used here too
         aa.mask = static_cast<const float*>(in[2]); aa.mask_set_stride = L_; aa.mask_head_stride = 0;
         aa.set_num = static_cast<const uint32_t*>(in[3]); aa.max_sets = max_win_num_;
-        aa.out = static_cast<float*>(out[0]); aa.out_ld = C_; aa.C = C_; aa.H = H_;
-        return launchAttention(aa, stream);
+        aa.out = out[0]; aa.out_ld = C_; aa.C = C_; aa.H = H_;
+        return launchAttention(aa, io_half_ != 0, stream);
     }
-    size_t serializationSize() const override { return 6 * sizeof(int); }
+    size_t serializationSize() const override { return 7 * sizeof(int); }
     void serialize(void* buf) const override {
         char* d = static_cast<char*>(buf);
-        wr<int>(d, max_win_num_); wr<int>(d, L_); wr<int>(d, C_); wr<int>(d, H_); wr<int>(d, axis_id_); wr<int>(d, max_pillars_num_);
+        wr<int>(d, max_win_num_); wr<int>(d, L_); wr<int>(d, C_); wr<int>(d, H_); wr<int>(d, axis_id_); wr<int>(d, max_pillars_num_); wr<int>(d, io_half_);
     }
-    Plugin* clone() const override { return new DsvtSetAttentionPlugin(max_win_num_, L_, C_, H_, axis_id_, max_pillars_num_); }
+    Plugin* clone() const override { return new DsvtSetAttentionPlugin(max_win_num_, L_, C_, H_, axis_id_, max_pillars_num_, io_half_); }
 };
-static Plugin* saNew(int mw, int L, int C, int H, int axis, int mp) {
-    return (attnShapeOk(mw, L, C, H) && (axis == 0 || axis == 1) && mp > 0) ? new DsvtSetAttentionPlugin(mw, L, C, H, axis, mp) : nullptr;
+static Plugin* saNew(int mw, int L, int C, int H, int axis, int mp, int io_half) {
+    return (attnShapeOk(mw, L, C, H) && (axis == 0 || axis == 1) && mp > 0 && (io_half == 0 || io_half == 1))
+               ? new DsvtSetAttentionPlugin(mw, L, C, H, axis, mp, io_half) : nullptr;
 }
 static Plugin* saCreate(const DsvtPluginFieldCollection* fc) {
     return saNew(fieldInt(fc, "max_win_num"), fieldInt(fc, "voxel_num_set"), fieldInt(fc, "channel_num"), fieldInt(fc, "num_heads"),
-                 fieldInt(fc, "axis_id"), fieldInt(fc, "max_pillars_num"));
+                 fieldInt(fc, "axis_id"), fieldInt(fc, "max_pillars_num"), fieldInt(fc, "io_half", 0));
 }
 static Plugin* saDeser(const void* data, size_t len) {
-    if (len < 6 * sizeof(int)) return nullptr;
+    if (len < 7 * sizeof(int)) return nullptr;
     const char* d = static_cast<const char*>(data);
-    int mw = rd<int>(d), L = rd<int>(d), C = rd<int>(d), H = rd<int>(d), axis = rd<int>(d), mp = rd<int>(d);
-    return saNew(mw, L, C, H, axis, mp);
+    int mw = rd<int>(d), L = rd<int>(d), C = rd<int>(d), H = rd<int>(d), axis = rd<int>(d), mp = rd<int>(d), ioh = rd<int>(d);
+    return saNew(mw, L, C, H, axis, mp, ioh);
 }
 static Creator g_saCreator{"DsvtSetAttentionPlugin",
     {{"max_win_num", DSVT_FIELD_INT32}, {"voxel_num_set", DSVT_FIELD_INT32}, {"channel_num", DSVT_FIELD_INT32},
-     {"num_heads", DSVT_FIELD_INT32}, {"axis_id", DSVT_FIELD_INT32}, {"max_pillars_num", DSVT_FIELD_INT32}},
+     {"num_heads", DSVT_FIELD_INT32}, {"axis_id", DSVT_FIELD_INT32}, {"max_pillars_num", DSVT_FIELD_INT32},
+     {"io_half", DSVT_FIELD_INT32}},
     saCreate, saDeser, {}, {}};
 static Registrar g_saReg(&g_saCreator);
 

@@ -1,4 +1,4 @@
-// linear.h -- launch interface of the MFMA linear kernel (linear.hip), shared with attention.hip.
+// linear.h -- launch interface of the MFMA linear kernels (linear.hip), shared with attention.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -8,16 +8,23 @@ namespace dsvt {
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 
 struct LinearArgs {
-    const float* A; const float* A2; const float* W; const float* bias;
-    const float* res[3]; const float* gamma[3]; const float* beta[3];
-    float* out;
+    const void* A;        // [rows, K] fp32, or fp16 when a_half
+    const void* A2;       // added to A for output columns < add_cols (same dtype as A), or nullptr
+    const float* W;       // [N, K] fp32 (fp32-MFMA kernel)
+    const float* bias;    // [N] or nullptr
+    const float* res[3]; const float* gamma[3]; const float* beta[3];   // chained "add residual, LayerNorm" stages
+    float* out;           // [rows, out_ld] fp32, or nullptr
+    _Float16* out16;      // [rows, out_ld] fp16 copy of the result, or nullptr
     const uint32_t* count;
     int row_mult, max_rows, K, N, add_cols, act, n_ln;
-    int out_ld;          // row stride of `out` in floats (>= N); lets Q/K/V land in one [rows, 3C] buffer
+    int out_ld;           // row stride of out / out16 in elements (>= N); lets Q/K/V land in one [rows, 3C] buffer
+    int a_half;           // A / A2 are fp16 (fp16-MFMA kernel only)
     float eps;
 };
 
-// enqueue y = epilogue(A' W^T + b) for up to max_rows rows; returns 0 or a hipError_t
+// y = epilogue(A' W^T + b) on v_mfma_f32_16x16x4_f32 (fp32 A only); returns 0 or a hipError_t
 int launchLinearF32(const LinearArgs& a, hipStream_t stream);
+// same on v_mfma_f32_16x16x32_f16 with fp16 weights Wh [N, K]; needs K % 192 == 0
+int launchLinearF16(const LinearArgs& a, const _Float16* Wh, hipStream_t stream);
 
 }  // namespace dsvt

@@ -10,11 +10,21 @@
 //             ElementWise SUMs around it, src/dsvt-ai-trt.cpp:669-697, 750-756).
 // Rows are limited by a device-side count (count * row_mult), like every reference plugin.
 //
-// fp32 path: v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate).  Tile: 64 rows x
-// 192 columns per 256-thread workgroup, K streamed through LDS in chunks of 32; wave w owns rows
-// 16w..16w+15 and all 192 columns, so a LayerNorm row never leaves its wavefront.
-// LDS rows are padded to 40 floats and lane group g reads k-chunks {g, g+4}: the two
-// ds_read_b128 per fragment are bank-conflict free (checked by enumeration).
+// Both kernels compute the TRANSPOSED product tile  D[n][m] = sum_k W[n][k] A[m][k]  (W fragment
+// as the MFMA A operand, activation fragment as the B operand).  In the 16x16 C/D layout a lane
+// then owns ONE activation row (m = lane & 15) and four CONSECUTIVE output columns
+// (n = 16t + 4*(lane>>4) + i): bias / residual / gamma / beta / output are 16-byte vector accesses,
+// and a LayerNorm row reduction is 12 in-register adds plus two shuffles (xor 16, 32).
+//
+//   linear_f32_kernel   v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate (parity mode).
+//                       64 rows x 192 columns per workgroup, K streamed through LDS in 32-chunks,
+//                       rows padded to 40 floats => conflict-free ds_read_b128 (enumerated).
+//   linear_f16_kernel   v_mfma_f32_16x16x32_f16: operands rounded to fp16, fp32 accumulate and
+//                       fp32 epilogue.  128 rows x 192 columns per workgroup; a 192-wide K slab of
+//                       W sits in LDS ([192][208] halfs, 32-byte pad => conflict-free), activations
+//                       go straight from global memory into the B fragment (a lane needs 8
+//                       consecutive k of one row: 32 contiguous bytes of an fp32 row, 16 of an fp16
+//                       row) with the loads of a whole slab issued up front.
 #include "plugin_base.h"
 #include "device_utils.h"
 #include "linear.h"
@@ -22,98 +32,119 @@
 namespace dsvt {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 64, BN = 192, BK = 32, LDS_LD = 40, NT = BN / 16;
 
-
 __device__ __forceinline__ float geluFast(float x) {
-    // tanh-GELU of the reference (gelu.cu:208-209) in fp32
+    // tanh-GELU of the reference (gelu.cu:208-209) in fp32:  (0.5 + 0.5 tanh(u)) x  with
+    // tanh(u) = 1 - 2 / (exp(2u) + 1)  =>  x * (1 - 1 / (exp(2u) + 1)).  exp overflow gives 1/inf = 0 -> x,
+    // underflow gives 1/1 -> 0: both limits are the right ones.
     const float B = 0.7978845608028654f, C = 0.035677408136300125f;
-    return (0.5f + 0.5f * tanhf(x * (C * x * x + B))) * x;
+    const float u = x * (C * x * x + B);
+    return x * (1.0f - __builtin_amdgcn_rcpf(__expf(2.0f * u) + 1.0f));
 }
 
-// sum over the 16 lanes that share a row group (lanes differing in bits 0..3)
-__device__ __forceinline__ float rowSum16(float v) {
-    v += __shfl_xor(v, 1, kWave); v += __shfl_xor(v, 2, kWave);
-    v += __shfl_xor(v, 4, kWave); v += __shfl_xor(v, 8, kWave);
+// sum over the 4 lane groups that share an activation row (lanes differing in bits 4..5)
+__device__ __forceinline__ float rowSum4(float v) {
+    v += __shfl_xor(v, 16, kWave); v += __shfl_xor(v, 32, kWave);
     return v;
 }
 
-// Epilogue shared by the fp32 and fp16 MFMA kernels.  `acc` holds a 16-row x 192-column strip in
-// the MFMA C/D layout: lane (r, g) owns rows rbase + i (i = 0..3, rbase already includes 4g) and
-// columns n0 + t*16 + r.
-__device__ __forceinline__ void linearEpilogue(floatx4 (&acc)[NT], const LinearArgs& a, int n0, int rbase, int r, int M, int N)
+// Epilogue shared by both kernels.  `acc[t]` = output columns n0 + 16t + 4g .. +3 of activation
+// row `row` (one row per lane, g = lane >> 4).
+__device__ __forceinline__ void linearEpilogue(floatx4 (&acc)[NT], const LinearArgs& a, int n0, int row, int g, int M, int N)
 {
+    const bool valid = row < M;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        int col = n0 + t * 16 + r;
-        float b = (a.bias && col < N) ? a.bias[col] : 0.f;
+        const int col = n0 + t * 16 + 4 * g;
+        if (col < N) {
+            if (a.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(a.bias + col);
+                acc[t][0] += b.x; acc[t][1] += b.y; acc[t][2] += b.z; acc[t][3] += b.w;
+            }
+            if (a.act == ACT_RELU) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float v = acc[t][i] + b;
-            if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
-            else if (a.act == ACT_GELU) v = geluFast(v);
-            acc[t][i] = v;
-        }
-    }
-    for (int s = 0; s < a.n_ln; ++s) {       // y = LayerNorm_s(y + res_s); needs N <= BN (checked on the host)
-        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < 4; ++i) acc[t][i] = fmaxf(acc[t][i], 0.f);
+            } else if (a.act == ACT_GELU) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            int col = t * 16 + r;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int row = rbase + i;
-                float v = acc[t][i];
-                if (col < N && row < M) v += a.res[s][(size_t)row * N + col]; else if (col >= N) v = 0.f;
-                acc[t][i] = v; sum[i] += v;
+                for (int i = 0; i < 4; ++i) acc[t][i] = geluFast(acc[t][i]);
             }
         }
-        float mean[4], den[4];
+    }
+    for (int s = 0; s < a.n_ln; ++s) {       // y = LayerNorm_s(y + res_s); N <= BN (checked on the host), n0 == 0
+        const float* res = a.res[s];
+        float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) mean[i] = rowSum16(sum[i]) / N;                 // layerNorm.cu:304-308
-        float sq[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NT; ++t) {
+            const int col = t * 16 + 4 * g;
+            if (col < N) {
+                if (valid) {
+                    const float4 rv = *reinterpret_cast<const float4*>(res + (size_t)row * N + col);
+                    acc[t][0] += rv.x; acc[t][1] += rv.y; acc[t][2] += rv.z; acc[t][3] += rv.w;
+                }
+                sum += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+            }
+        }
+        const float mean = rowSum4(sum) / N;                                         // layerNorm.cu:304-308
+        float sq = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-            if (t * 16 + r < N)
+            if (t * 16 + 4 * g < N)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { float d = acc[t][i] - mean[i]; sq[i] += d * d; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) den[i] = sqrtf(rowSum16(sq[i]) / N + a.eps);     // :333-337, :274
+                for (int i = 0; i < 4; ++i) { const float d = acc[t][i] - mean; sq += d * d; }
+        const float inv = 1.0f / sqrtf(rowSum4(sq) / N + a.eps);                      // :333-337, :274
+        const float* gm = a.gamma[s]; const float* bt = a.beta[s];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            int col = t * 16 + r;
-            float gm = col < N ? a.gamma[s][col] : 0.f, bt = col < N ? a.beta[s][col] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[t][i] = (acc[t][i] - mean[i]) / den[i] * gm + bt;   // :274-276
+            const int col = t * 16 + 4 * g;
+            if (col < N) {
+                const float4 g4 = *reinterpret_cast<const float4*>(gm + col), b4 = *reinterpret_cast<const float4*>(bt + col);
+                acc[t][0] = (acc[t][0] - mean) * inv * g4.x + b4.x;                  // :274-276
+                acc[t][1] = (acc[t][1] - mean) * inv * g4.y + b4.y;
+                acc[t][2] = (acc[t][2] - mean) * inv * g4.z + b4.z;
+                acc[t][3] = (acc[t][3] - mean) * inv * g4.w + b4.w;
+            }
         }
     }
+    if (!valid) return;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        int col = n0 + t * 16 + r;
-        if (col < N)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int row = rbase + i;
-                if (row < M) a.out[(size_t)row * a.out_ld + col] = acc[t][i];
+        const int col = n0 + t * 16 + 4 * g;
+        if (col < N) {
+            if (a.out) *reinterpret_cast<float4*>(a.out + (size_t)row * a.out_ld + col) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+            if (a.out16) {
+                half4 h; h[0] = (_Float16)acc[t][0]; h[1] = (_Float16)acc[t][1]; h[2] = (_Float16)acc[t][2]; h[3] = (_Float16)acc[t][3];
+                *reinterpret_cast<half4*>(a.out16 + (size_t)row * a.out_ld + col) = h;
             }
+        }
     }
 }
 
+__device__ __forceinline__ int rowLimit(const LinearArgs& a) {
+    const long long m = (long long)(*a.count) * a.row_mult;
+    return (int)(m < a.max_rows ? m : a.max_rows);
+}
+
+// -------------------------------------------------------------------------------------
+// fp32 MFMA
+// -------------------------------------------------------------------------------------
 template <bool VEC>
 __global__ void __launch_bounds__(256)
 linear_f32_kernel(LinearArgs a)
 {
     __shared__ __attribute__((aligned(16))) float sA[BM * LDS_LD];
     __shared__ __attribute__((aligned(16))) float sW[BN * LDS_LD];
-    uint32_t cnt = *a.count;
-    long long Mll = (long long)cnt * a.row_mult;
-    const int M = (int)(Mll < a.max_rows ? Mll : a.max_rows);
+    const int M = rowLimit(a);
     const int m0 = blockIdx.x * BM;
     if (m0 >= M) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int K = a.K, N = a.N;
+    const float* A = static_cast<const float*>(a.A);
+    const float* A2 = static_cast<const float*>(a.A2);
 
     for (int n0 = 0; n0 < N; n0 += BN) {
         floatx4 acc[NT];
@@ -131,18 +162,17 @@ linear_f32_kernel(LinearArgs a)
                 if (gr < M) {
                     if (VEC) {
                         if (k < K) {
-                            v = *reinterpret_cast<const float4*>(a.A + (size_t)gr * K + k);
+                            v = *reinterpret_cast<const float4*>(A + (size_t)gr * K + k);
                             if (add) {
-                                float4 w = *reinterpret_cast<const float4*>(a.A2 + (size_t)gr * K + k);
+                                float4 w = *reinterpret_cast<const float4*>(A2 + (size_t)gr * K + k);
                                 v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
                             }
                         }
                     } else {
                         float t[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            t[j] = (k + j < K) ? a.A[(size_t)gr * K + k + j] + (add ? a.A2[(size_t)gr * K + k + j] : 0.f) : 0.f;
-                        }
+                        for (int j = 0; j < 4; ++j)
+                            t[j] = (k + j < K) ? A[(size_t)gr * K + k + j] + (add ? A2[(size_t)gr * K + k + j] : 0.f) : 0.f;
                         v = make_float4(t[0], t[1], t[2], t[3]);
                     }
                 }
@@ -184,31 +214,30 @@ linear_f32_kernel(LinearArgs a)
 #pragma unroll
                     for (int s = 0; s < 8; ++s)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[t4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[j][s], acc[t4 + j], 0, 0, 0);
+                        for (int j = 0; j < 4; ++j)      // D[n][m]: W fragment is the A operand
+                            acc[t4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j][s], av[s], acc[t4 + j], 0, 0, 0);
                 }
             }
         }
-
-        linearEpilogue(acc, a, n0, m0 + wave * 16 + g * 4, r, M, N);
+        linearEpilogue(acc, a, n0, m0 + wave * 16 + r, g, M, N);
     }
 }
 
+int launchLinearF32(const LinearArgs& a, hipStream_t stream) {
+    if (a.a_half) return -3;
+    dim3 grid(cdiv(a.max_rows, BM)), block(256);
+    if (a.K % 4 == 0) hipLaunchKernelGGL(linear_f32_kernel<true>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(linear_f32_kernel<false>, grid, block, 0, stream, a);
+    return lastError();
+}
+
 // -------------------------------------------------------------------------------------
-// fp16-MFMA variant (v_mfma_f32_16x16x32_f16, fp32 accumulate; everything outside the products --
-// bias, GELU, residuals, LayerNorm -- stays fp32).  Activations stay fp32 in HBM and are rounded
-// to fp16 once, on their way into the A fragment.
-//   * W chunk (192 output columns x K) lives in LDS for the whole workgroup: [192][K+16] halfs,
-//     the 32-byte row pad makes the per-lane ds_read_b128 of a B fragment conflict-free;
-//   * A never touches LDS: in the 16x16x32 A layout a lane needs 8 consecutive k of one row, i.e.
-//     32 contiguous bytes of an fp32 row, and the four lane groups of a row cover one full 128-byte
-//     line -- a direct global load is already perfectly coalesced and each element is used by one
-//     wave only;
-//   * a wave owns 32 rows (two 16-row MFMA tiles) so every B fragment read from LDS feeds two
-//     MFMAs: one ds_read_b128 per MFMA would need 240 B/clk/CU of LDS bandwidth (peak 256).
-// Workgroup = 4 waves = 128 rows x 192 columns; N > 192 loops over column chunks.
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-constexpr int BM16 = 128;
+// fp16 MFMA
+// -------------------------------------------------------------------------------------
+constexpr int BM16 = 128;         // rows per workgroup: 4 waves x 2 MFMA row tiles
+constexpr int KS = 192;           // K slab held in LDS
+constexpr int LDW = KS + 16;      // halfs per LDS row
+constexpr int NSTEP = KS / 32;    // MFMA k-steps per slab
 
 __device__ __forceinline__ half8 toHalf8(float4 x, float4 y) {
     half8 h;
@@ -217,116 +246,115 @@ __device__ __forceinline__ half8 toHalf8(float4 x, float4 y) {
     return h;
 }
 
-template <int KT>
+// B-operand fragment (8 consecutive k of one activation row) straight from global memory
+template <bool AHALF, bool ADD>
+__device__ __forceinline__ half8 loadFrag(const void* A, const void* A2, size_t off) {
+    if (AHALF) {
+        half8 v = *reinterpret_cast<const half8*>(static_cast<const _Float16*>(A) + off);
+        if (ADD) v += *reinterpret_cast<const half8*>(static_cast<const _Float16*>(A2) + off);
+        return v;
+    } else {
+        const float* p = static_cast<const float*>(A) + off;
+        float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
+        if (ADD) {
+            const float* q = static_cast<const float*>(A2) + off;
+            const float4 u = *reinterpret_cast<const float4*>(q), w = *reinterpret_cast<const float4*>(q + 4);
+            x.x += u.x; x.y += u.y; x.z += u.z; x.w += u.w; y.x += w.x; y.y += w.y; y.z += w.z; y.w += w.w;
+        }
+        return toHalf8(x, y);
+    }
+}
+
+template <bool AHALF>
 __global__ void __launch_bounds__(256, 2)
 linear_f16_kernel(LinearArgs a, const _Float16* __restrict__ Wh)
 {
-    extern __shared__ __attribute__((aligned(16))) _Float16 sWh[];
-    uint32_t cnt = *a.count;
-    long long Mll = (long long)cnt * a.row_mult;
-    const int M = (int)(Mll < a.max_rows ? Mll : a.max_rows);
+    __shared__ __attribute__((aligned(16))) _Float16 sWh[BN * LDW];      // 79,872 B: two workgroups per CU
+    const int M = rowLimit(a);
     const int m0 = blockIdx.x * BM16;
     if (m0 >= M) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int K = KT ? KT : a.K, N = a.N, LDW = K + 16, KC = K / 8;
+    const int K = a.K, N = a.N;
+    int row0 = m0 + wave * 32 + r, row1 = row0 + 16;
+    const int rc0 = row0 < M ? row0 : M - 1, rc1 = row1 < M ? row1 : M - 1;     // clamp loads; rows >= M are never stored
 
     for (int n0 = 0; n0 < N; n0 += BN) {
-        __syncthreads();
-        for (int i = tid; i < BN * KC; i += 256) {
-            int n = i / KC, c = i % KC;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (n0 + n < N) v = *reinterpret_cast<const uint4*>(Wh + (size_t)(n0 + n) * K + c * 8);
-            *reinterpret_cast<uint4*>(&sWh[n * LDW + c * 8]) = v;
-        }
-        __syncthreads();
         floatx4 acc0[NT], acc1[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) { acc0[t] = floatx4{0.f, 0.f, 0.f, 0.f}; acc1[t] = floatx4{0.f, 0.f, 0.f, 0.f}; }
         const bool add = n0 < a.add_cols;
         const int ntiles = (N - n0 + 15) / 16 < NT ? (N - n0 + 15) / 16 : NT;
-        int row0 = m0 + wave * 32 + r, row1 = row0 + 16;
-        row0 = row0 < M ? row0 : M - 1; row1 = row1 < M ? row1 : M - 1;        // clamp: rows >= M are never stored
-        const float* pa0 = a.A + (size_t)row0 * K + g * 8;
-        const float* pa1 = a.A + (size_t)row1 * K + g * 8;
-        const float* pb0 = add ? a.A2 + (size_t)row0 * K + g * 8 : nullptr;
-        const float* pb1 = add ? a.A2 + (size_t)row1 * K + g * 8 : nullptr;
-        // software pipeline: the global loads of k-step s+1 are in flight while step s runs on the MFMAs
-        float4 x0 = *reinterpret_cast<const float4*>(pa0), x1 = *reinterpret_cast<const float4*>(pa0 + 4);
-        float4 y0 = *reinterpret_cast<const float4*>(pa1), y1 = *reinterpret_cast<const float4*>(pa1 + 4);
-        float4 p0, p1, q0, q1;
-        if (add) {
-            p0 = *reinterpret_cast<const float4*>(pb0); p1 = *reinterpret_cast<const float4*>(pb0 + 4);
-            q0 = *reinterpret_cast<const float4*>(pb1); q1 = *reinterpret_cast<const float4*>(pb1 + 4);
-        }
-#pragma unroll 1
-        for (int k0 = 0; k0 < K; k0 += 32) {
+        for (int ks = 0; ks < K; ks += KS) {
+            // the activation fragments of the whole slab are requested first, so their HBM latency
+            // overlaps the W slab's trip L2 -> VGPR -> LDS
+            half8 f0[NSTEP], f1[NSTEP];
+            const size_t o0 = (size_t)rc0 * K + ks + g * 8, o1 = (size_t)rc1 * K + ks + g * 8;
             if (add) {
-                x0.x += p0.x; x0.y += p0.y; x0.z += p0.z; x0.w += p0.w; x1.x += p1.x; x1.y += p1.y; x1.z += p1.z; x1.w += p1.w;
-                y0.x += q0.x; y0.y += q0.y; y0.z += q0.z; y0.w += q0.w; y1.x += q1.x; y1.y += q1.y; y1.z += q1.z; y1.w += q1.w;
-            }
-            const half8 af0 = toHalf8(x0, x1), af1 = toHalf8(y0, y1);
-            const int kn = k0 + 32 < K ? k0 + 32 : k0;             // last step re-reads its own chunk (harmless)
-            x0 = *reinterpret_cast<const float4*>(pa0 + kn); x1 = *reinterpret_cast<const float4*>(pa0 + kn + 4);
-            y0 = *reinterpret_cast<const float4*>(pa1 + kn); y1 = *reinterpret_cast<const float4*>(pa1 + kn + 4);
-            if (add) {
-                p0 = *reinterpret_cast<const float4*>(pb0 + kn); p1 = *reinterpret_cast<const float4*>(pb0 + kn + 4);
-                q0 = *reinterpret_cast<const float4*>(pb1 + kn); q1 = *reinterpret_cast<const float4*>(pb1 + kn + 4);
-            }
-            const _Float16* pw = &sWh[r * LDW + k0 + g * 8];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (t < ntiles) {
-                    const half8 bf = *reinterpret_cast<const half8*>(pw + t * 16 * LDW);
-                    acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af0, bf, acc0[t], 0, 0, 0);
-                    acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af1, bf, acc1[t], 0, 0, 0);
+                for (int s = 0; s < NSTEP; ++s) { f0[s] = loadFrag<AHALF, true>(a.A, a.A2, o0 + s * 32); f1[s] = loadFrag<AHALF, true>(a.A, a.A2, o1 + s * 32); }
+            } else {
+#pragma unroll
+                for (int s = 0; s < NSTEP; ++s) { f0[s] = loadFrag<AHALF, false>(a.A, nullptr, o0 + s * 32); f1[s] = loadFrag<AHALF, false>(a.A, nullptr, o1 + s * 32); }
+            }
+            __syncthreads();                                   // previous slab's MFMAs are done with sWh
+            for (int i = tid; i < BN * (KS / 8); i += 256) {
+                const int n = i / (KS / 8), c = i % (KS / 8);
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (n0 + n < N) v = *reinterpret_cast<const uint4*>(Wh + (size_t)(n0 + n) * K + ks + c * 8);
+                *reinterpret_cast<uint4*>(&sWh[n * LDW + c * 8]) = v;
+            }
+            __syncthreads();
+            const _Float16* pw = &sWh[r * LDW + g * 8];
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (t < ntiles) {
+                        const half8 wf = *reinterpret_cast<const half8*>(pw + t * 16 * LDW + s * 32);
+                        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, f0[s], acc0[t], 0, 0, 0);
+                        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, f1[s], acc1[t], 0, 0, 0);
+                    }
                 }
             }
         }
-        linearEpilogue(acc0, a, n0, m0 + wave * 32 + g * 4, r, M, N);
-        linearEpilogue(acc1, a, n0, m0 + wave * 32 + 16 + g * 4, r, M, N);
+        linearEpilogue(acc0, a, n0, row0, g, M, N);
+        linearEpilogue(acc1, a, n0, row1, g, M, N);
     }
 }
 
 int launchLinearF16(const LinearArgs& a, const _Float16* Wh, hipStream_t stream) {
-    static bool attr_done = false;
-    const size_t lds = sizeof(_Float16) * (size_t)BN * (a.K + 16);
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_f16_kernel<192>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_f16_kernel<384>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_f16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    if (a.K % KS != 0) return -3;
     dim3 grid(cdiv(a.max_rows, BM16)), block(256);
-    if (a.K == 192) hipLaunchKernelGGL(linear_f16_kernel<192>, grid, block, lds, stream, a, Wh);
-    else if (a.K == 384) hipLaunchKernelGGL(linear_f16_kernel<384>, grid, block, lds, stream, a, Wh);
-    else hipLaunchKernelGGL(linear_f16_kernel<0>, grid, block, lds, stream, a, Wh);
-    return lastError();
-}
-
-int launchLinearF32(const LinearArgs& a, hipStream_t stream) {
-    dim3 grid(cdiv(a.max_rows, BM)), block(256);
-    if (a.K % 4 == 0) hipLaunchKernelGGL(linear_f32_kernel<true>, grid, block, 0, stream, a);
-    else hipLaunchKernelGGL(linear_f32_kernel<false>, grid, block, 0, stream, a);
+    if (a.a_half) hipLaunchKernelGGL(linear_f16_kernel<true>, grid, block, 0, stream, a, Wh);
+    else hipLaunchKernelGGL(linear_f16_kernel<false>, grid, block, 0, stream, a, Wh);
     return lastError();
 }
 
 // -------------------------------------------------------------------------------------
+// plugin
+// -------------------------------------------------------------------------------------
+enum { OUT_F32 = 0, OUT_F16 = 1, OUT_BOTH = 2 };
+
+struct LinCfg {
+    int max_rows, K, N, row_mult, act, add_cols, n_ln; float eps;
+    int compute_type;      // 0: fp32 MFMA (exact fp32 products)   1: fp16 MFMA operands, fp32 accumulate
+    int input_half;        // A / A2 tensors are fp16 (needs compute_type 1)
+    int output_mode;       // OUT_F32: one fp32 output; OUT_F16: one fp16 output; OUT_BOTH: fp32 + fp16 copy
+};
+
 class DsvtLinearPlugin : public Plugin {
 public:
-    int max_rows_, K_, N_, row_mult_, act_, add_cols_, n_ln_; float eps_;
-    int compute_type_;                 // 0: fp32 MFMA (exact fp32 products)   1: fp16 MFMA, fp32 accumulate
+    LinCfg c_;
     std::vector<float> w_, b_, g_, be_;
     float *w_dev_ = nullptr, *b_dev_ = nullptr, *g_dev_ = nullptr, *be_dev_ = nullptr;
     _Float16* wh_dev_ = nullptr;
     bool ok_ = false;
-    bool useF16() const { return compute_type_ == 1 && K_ % 32 == 0 && K_ <= 384; }
-    DsvtLinearPlugin(int max_rows, int K, int N, int row_mult, int act, int add_cols, int n_ln, float eps, int compute_type,
-                     const float* w, const float* b, const float* g, const float* be)
-        : max_rows_(max_rows), K_(K), N_(N), row_mult_(row_mult), act_(act), add_cols_(add_cols), n_ln_(n_ln), eps_(eps),
-          compute_type_(compute_type), w_(w, w + (size_t)N * K) {
-        if (b) b_.assign(b, b + N);
-        if (n_ln) { g_.assign(g, g + (size_t)n_ln * N); be_.assign(be, be + (size_t)n_ln * N); }
+    bool useF16() const { return c_.compute_type == 1 && c_.K % KS == 0; }
+    DsvtLinearPlugin(const LinCfg& c, const float* w, const float* b, const float* g, const float* be)
+        : c_(c), w_(w, w + (size_t)c.N * c.K) {
+        if (b) b_.assign(b, b + c.N);
+        if (c.n_ln) { g_.assign(g, g + (size_t)c.n_ln * c.N); be_.assign(be, be + (size_t)c.n_ln * c.N); }
         auto up = [](const std::vector<float>& h, float** d) {
             if (h.empty()) { *d = nullptr; return true; }
             if (hipMalloc(d, sizeof(float) * h.size()) != hipSuccess) return false;
@@ -345,16 +373,21 @@ public:
         if (wh_dev_) (void)hipFree(wh_dev_);
     }
     const char* type() const override { return "DsvtLinearPlugin"; }
-    int nbOutputs() const override { return 1; }
-    int nbInputs() const { return 2 + (add_cols_ > 0 ? 1 : 0) + n_ln_; }
+    int nbOutputs() const override { return c_.output_mode == OUT_BOTH ? 2 : 1; }
     int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
-        if (i != 0) return -1;
-        *out = dims3(in[0].d[0], max_rows_, N_); return 0;
+        if (i < 0 || i >= nbOutputs()) return -1;
+        *out = dims3(in[0].d[0], c_.max_rows, c_.N); return 0;
     }
-    int outputType(int, const int32_t* t, int) const override { return t[0]; }
-    bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int, int) const override {
+    int outputType(int i, const int32_t*, int) const override {
+        if (c_.output_mode == OUT_F16) return DSVT_HALF;
+        return i == 0 ? DSVT_FLOAT : DSVT_HALF;
+    }
+    bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int nbIn, int) const override {
         if (io[pos].format != DSVT_FORMAT_LINEAR) return false;
-        return pos == 1 ? io[pos].type == DSVT_INT32 : io[pos].type == DSVT_FLOAT;
+        if (pos == 1) return io[pos].type == DSVT_INT32;
+        if (pos == 0 || (pos == 2 && c_.add_cols > 0)) return io[pos].type == (c_.input_half ? DSVT_HALF : DSVT_FLOAT);
+        if (pos < nbIn) return io[pos].type == DSVT_FLOAT;                      // residuals
+        return io[pos].type == outputType(pos - nbIn, nullptr, 0);
     }
     size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override { return 0; }
     int enqueue(const DsvtPluginTensorDesc*, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void*,
@@ -362,77 +395,82 @@ public:
         if (!ok_) return static_cast<int>(hipErrorOutOfMemory);
         LinearArgs a{};
         int idx = 0;
-        a.A = static_cast<const float*>(in[idx++]);
+        a.A = in[idx++];
         a.count = static_cast<const uint32_t*>(in[idx++]);
-        a.A2 = add_cols_ > 0 ? static_cast<const float*>(in[idx++]) : nullptr;
-        for (int s = 0; s < n_ln_; ++s) {
+        a.A2 = c_.add_cols > 0 ? in[idx++] : nullptr;
+        for (int s = 0; s < c_.n_ln; ++s) {
             a.res[s] = static_cast<const float*>(in[idx++]);
-            a.gamma[s] = g_dev_ + (size_t)s * N_; a.beta[s] = be_dev_ + (size_t)s * N_;
+            a.gamma[s] = g_dev_ + (size_t)s * c_.N; a.beta[s] = be_dev_ + (size_t)s * c_.N;
         }
-        a.W = w_dev_; a.bias = b_dev_; a.out = static_cast<float*>(out[0]);
-        a.row_mult = row_mult_; a.max_rows = max_rows_; a.K = K_; a.N = N_; a.add_cols = add_cols_; a.act = act_;
-        a.n_ln = n_ln_; a.eps = eps_; a.out_ld = N_;
-        if (zeroFill) DSVT_CHECK(hipMemsetAsync(out[0], 0, sizeof(float) * (size_t)max_rows_ * N_, stream));
+        a.W = w_dev_; a.bias = b_dev_;
+        a.out = c_.output_mode == OUT_F16 ? nullptr : static_cast<float*>(out[0]);
+        a.out16 = c_.output_mode == OUT_F16 ? static_cast<_Float16*>(out[0]) : c_.output_mode == OUT_BOTH ? static_cast<_Float16*>(out[1]) : nullptr;
+        a.row_mult = c_.row_mult; a.max_rows = c_.max_rows; a.K = c_.K; a.N = c_.N; a.add_cols = c_.add_cols; a.act = c_.act;
+        a.n_ln = c_.n_ln; a.eps = c_.eps; a.out_ld = c_.N; a.a_half = c_.input_half;
+        if (zeroFill) {
+            if (a.out) DSVT_CHECK(hipMemsetAsync(a.out, 0, sizeof(float) * (size_t)c_.max_rows * c_.N, stream));
+            if (a.out16) DSVT_CHECK(hipMemsetAsync(a.out16, 0, sizeof(_Float16) * (size_t)c_.max_rows * c_.N, stream));
+        }
         return useF16() ? launchLinearF16(a, wh_dev_, stream) : launchLinearF32(a, stream);
     }
     size_t serializationSize() const override {
-        return 7 * sizeof(int) + sizeof(float) + 2 * sizeof(int) + sizeof(float) * (w_.size() + b_.size() + g_.size() + be_.size());
+        return 11 * sizeof(int) + sizeof(float) + sizeof(float) * (w_.size() + b_.size() + g_.size() + be_.size());
     }
     void serialize(void* buf) const override {
         char* d = static_cast<char*>(buf);
-        wr<int>(d, max_rows_); wr<int>(d, K_); wr<int>(d, N_); wr<int>(d, row_mult_); wr<int>(d, act_); wr<int>(d, add_cols_);
-        wr<int>(d, n_ln_); wr<float>(d, eps_); wr<int>(d, b_.empty() ? 0 : 1); wr<int>(d, compute_type_);
+        wr<int>(d, c_.max_rows); wr<int>(d, c_.K); wr<int>(d, c_.N); wr<int>(d, c_.row_mult); wr<int>(d, c_.act); wr<int>(d, c_.add_cols);
+        wr<int>(d, c_.n_ln); wr<float>(d, c_.eps); wr<int>(d, b_.empty() ? 0 : 1); wr<int>(d, c_.compute_type);
+        wr<int>(d, c_.input_half); wr<int>(d, c_.output_mode);
         for (const std::vector<float>* v : {&w_, &b_, &g_, &be_}) { memcpy(d, v->data(), sizeof(float) * v->size()); d += sizeof(float) * v->size(); }
     }
-    Plugin* clone() const override {
-        return new DsvtLinearPlugin(max_rows_, K_, N_, row_mult_, act_, add_cols_, n_ln_, eps_, compute_type_, w_.data(),
-                                    b_.empty() ? nullptr : b_.data(), g_.data(), be_.data());
-    }
+    Plugin* clone() const override { return new DsvtLinearPlugin(c_, w_.data(), b_.empty() ? nullptr : b_.data(), g_.data(), be_.data()); }
 };
 
-static Plugin* linNew(int max_rows, int K, int N, int row_mult, int act, int add_cols, int n_ln, float eps, int compute_type,
-                      const float* w, const float* b, const float* g, const float* be) {
-    if (max_rows <= 0 || K <= 0 || N <= 0 || row_mult <= 0 || !w) return nullptr;
-    if (compute_type < 0 || compute_type > 1) return nullptr;
-    if (act < 0 || act > 2 || n_ln < 0 || n_ln > 3) return nullptr;
-    if (n_ln > 0 && (N > BN || !g || !be)) return nullptr;                  // a LayerNorm row must fit one tile
-    if (add_cols < 0 || add_cols > N || (add_cols % BN != 0 && add_cols != N)) return nullptr;
-    DsvtLinearPlugin* p = new DsvtLinearPlugin(max_rows, K, N, row_mult, act, add_cols, n_ln, eps, compute_type, w, b, g, be);
-    return p;
+static Plugin* linNew(const LinCfg& c, const float* w, const float* b, const float* g, const float* be) {
+    if (c.max_rows <= 0 || c.K <= 0 || c.N <= 0 || c.N % 4 != 0 || c.row_mult <= 0 || !w) return nullptr;
+    if (c.compute_type < 0 || c.compute_type > 1 || c.output_mode < 0 || c.output_mode > 2) return nullptr;
+    if (c.act < 0 || c.act > 2 || c.n_ln < 0 || c.n_ln > 3) return nullptr;
+    if (c.n_ln > 0 && (c.N > BN || !g || !be)) return nullptr;             // a LayerNorm row must fit one tile
+    if (c.add_cols < 0 || c.add_cols > c.N || (c.add_cols % BN != 0 && c.add_cols != c.N)) return nullptr;
+    if (c.input_half && !(c.compute_type == 1 && c.K % KS == 0)) return nullptr;      // fp16 inputs only on the fp16 kernel
+    return new DsvtLinearPlugin(c, w, b, g, be);
 }
 static Plugin* linCreate(const DsvtPluginFieldCollection* fc) {
     const DsvtPluginField* w = findField(fc, "weight"); const DsvtPluginField* b = findField(fc, "bias");
     const DsvtPluginField* g = findField(fc, "ln_weights"); const DsvtPluginField* be = findField(fc, "ln_bias");
-    int K = fieldInt(fc, "in_features"), N = fieldInt(fc, "out_features"), n_ln = fieldInt(fc, "num_layer_norms");
-    if (!w || !w->data || w->length != K * N) return nullptr;
-    if (b && b->data && b->length != N) return nullptr;
-    if (n_ln > 0 && (!g || !be || g->length != n_ln * N || be->length != n_ln * N)) return nullptr;
-    return linNew(fieldInt(fc, "max_rows"), K, N, fieldInt(fc, "row_mult", 1), fieldInt(fc, "activation"),
-                  fieldInt(fc, "add_cols"), n_ln, fieldFloat(fc, "ln_eps", 0.f), fieldInt(fc, "compute_type", 0),
-                  static_cast<const float*>(w->data),
-                  (b && b->data) ? static_cast<const float*>(b->data) : nullptr,
+    LinCfg c{};
+    c.max_rows = fieldInt(fc, "max_rows"); c.K = fieldInt(fc, "in_features"); c.N = fieldInt(fc, "out_features");
+    c.row_mult = fieldInt(fc, "row_mult", 1); c.act = fieldInt(fc, "activation"); c.add_cols = fieldInt(fc, "add_cols");
+    c.n_ln = fieldInt(fc, "num_layer_norms"); c.eps = fieldFloat(fc, "ln_eps", 0.f); c.compute_type = fieldInt(fc, "compute_type", 0);
+    c.input_half = fieldInt(fc, "input_half", 0); c.output_mode = fieldInt(fc, "output_mode", 0);
+    if (!w || !w->data || c.K <= 0 || c.N <= 0 || w->length != c.K * c.N) return nullptr;
+    if (b && b->data && b->length != c.N) return nullptr;
+    if (c.n_ln > 0 && (!g || !be || g->length != c.n_ln * c.N || be->length != c.n_ln * c.N)) return nullptr;
+    return linNew(c, static_cast<const float*>(w->data), (b && b->data) ? static_cast<const float*>(b->data) : nullptr,
                   g ? static_cast<const float*>(g->data) : nullptr, be ? static_cast<const float*>(be->data) : nullptr);
 }
 static Plugin* linDeser(const void* data, size_t len) {
-    if (len < 9 * sizeof(int) + sizeof(float)) return nullptr;
+    if (len < 11 * sizeof(int) + sizeof(float)) return nullptr;
     const char* d = static_cast<const char*>(data);
-    int max_rows = rd<int>(d), K = rd<int>(d), N = rd<int>(d), row_mult = rd<int>(d), act = rd<int>(d), add_cols = rd<int>(d);
-    int n_ln = rd<int>(d); float eps = rd<float>(d); int has_b = rd<int>(d); int ctype = rd<int>(d);
-    if (K <= 0 || N <= 0 || n_ln < 0 || n_ln > 3) return nullptr;
-    size_t need = (size_t)K * N + (has_b ? N : 0) + 2 * (size_t)n_ln * N;
-    if (len < 9 * sizeof(int) + sizeof(float) + need * sizeof(float)) return nullptr;
+    LinCfg c{};
+    c.max_rows = rd<int>(d); c.K = rd<int>(d); c.N = rd<int>(d); c.row_mult = rd<int>(d); c.act = rd<int>(d); c.add_cols = rd<int>(d);
+    c.n_ln = rd<int>(d); c.eps = rd<float>(d); int has_b = rd<int>(d); c.compute_type = rd<int>(d);
+    c.input_half = rd<int>(d); c.output_mode = rd<int>(d);
+    if (c.K <= 0 || c.N <= 0 || c.n_ln < 0 || c.n_ln > 3) return nullptr;
+    size_t need = (size_t)c.K * c.N + (has_b ? c.N : 0) + 2 * (size_t)c.n_ln * c.N;
+    if (len < 11 * sizeof(int) + sizeof(float) + need * sizeof(float)) return nullptr;
     std::vector<float> all(need);
     memcpy(all.data(), d, need * sizeof(float));
-    const float* w = all.data(); const float* b = has_b ? w + (size_t)K * N : nullptr;
-    const float* g = w + (size_t)K * N + (has_b ? N : 0); const float* be = g + (size_t)n_ln * N;
-    return linNew(max_rows, K, N, row_mult, act, add_cols, n_ln, eps, ctype, w, b, g, be);
+    const float* w = all.data(); const float* b = has_b ? w + (size_t)c.K * c.N : nullptr;
+    const float* g = w + (size_t)c.K * c.N + (has_b ? c.N : 0); const float* be = g + (size_t)c.n_ln * c.N;
+    return linNew(c, w, b, g, be);
 }
 static Creator g_linCreator{"DsvtLinearPlugin",
     {{"max_rows", DSVT_FIELD_INT32}, {"in_features", DSVT_FIELD_INT32}, {"out_features", DSVT_FIELD_INT32},
      {"row_mult", DSVT_FIELD_INT32}, {"activation", DSVT_FIELD_INT32}, {"add_cols", DSVT_FIELD_INT32},
      {"num_layer_norms", DSVT_FIELD_INT32}, {"ln_eps", DSVT_FIELD_FLOAT32}, {"compute_type", DSVT_FIELD_INT32},
-     {"weight", DSVT_FIELD_FLOAT32},
-     {"bias", DSVT_FIELD_FLOAT32}, {"ln_weights", DSVT_FIELD_FLOAT32}, {"ln_bias", DSVT_FIELD_FLOAT32}},
+     {"input_half", DSVT_FIELD_INT32}, {"output_mode", DSVT_FIELD_INT32},
+     {"weight", DSVT_FIELD_FLOAT32}, {"bias", DSVT_FIELD_FLOAT32}, {"ln_weights", DSVT_FIELD_FLOAT32}, {"ln_bias", DSVT_FIELD_FLOAT32}},
     linCreate, linDeser, {}, {}};
 static Registrar g_linReg(&g_linCreator);
 

@@ -433,15 +433,19 @@ public:
     int outputType(int, const int32_t* t, int) const override { return t[0]; }
     bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int, int) const override {
         if (pos == 1 || pos == 2) return i32Linear(io[pos]);
-        return (pos == 0 || pos == 3) && f32Linear(io[pos]);
+        // fp32 like the reference, or fp16 rows (pure 16-byte moves either way)
+        return (pos == 0 || pos == 3) && io[pos].format == DSVT_FORMAT_LINEAR && (io[pos].type == DSVT_FLOAT || io[pos].type == DSVT_HALF)
+               && io[pos].type == io[0].type;
     }
     size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override { return 0; }
-    int enqueue(const DsvtPluginTensorDesc*, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void*,
+    int enqueue(const DsvtPluginTensorDesc* inDesc, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void*,
                 hipStream_t stream) override {
+        const int esz = (inDesc && inDesc[0].type == DSVT_HALF) ? 2 : 4;
+        if ((channel_num_ * esz) % 16 != 0) return -3;
         // the dense map must be zero wherever no pillar lands, so this fill is not optional (:303)
-        DSVT_CHECK(hipMemsetAsync(out[0], 0, sizeof(float) * (size_t)gx_ * gy_ * channel_num_, stream));
+        DSVT_CHECK(hipMemsetAsync(out[0], 0, (size_t)esz * gx_ * gy_ * channel_num_, stream));
         hipLaunchKernelGGL(map2bev_kernel, dim3(2048), dim3(256), 0, stream, static_cast<const float4*>(in[0]),
-                           static_cast<const uint4*>(in[1]), static_cast<const uint32_t*>(in[2]), channel_num_ / 4, gx_,
+                           static_cast<const uint4*>(in[1]), static_cast<const uint32_t*>(in[2]), channel_num_ * esz / 16, gx_,
                            static_cast<float4*>(out[0]));
         return lastError();
     }

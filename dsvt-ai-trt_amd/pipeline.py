@@ -75,6 +75,12 @@ class DsvtPipeline:
         w = weights
         zf = lambda op: op.set_zero_fill(zero_fill)
         ct = dict(compute_type=linear_compute)
+        self.f16 = f16 = linear_compute == P.COMPUTE_F16
+        # fp16 mode: GEMM operands travel as fp16 (x16, pos16, qkv, att, h); the residual stream that feeds the
+        # LayerNorms stays fp32 (the LayerNorm epilogues write both copies)
+        h_in = dict(input_half=True) if f16 else {}
+        o16 = dict(output_mode=P.OUT_F16) if f16 else {}
+        oboth = dict(output_mode=P.OUT_BOTH) if f16 else {}
         self.voxelizer = zf(P.add_voxel_generator(c.N, c.Nk, c.P, 4, 10, 48, X_MIN, X_MAX, Y_MIN, Y_MAX, Z_MIN, Z_MAX,
                                                   VX, VY, VZ, GX, GY, GZ))
         # PFN: FC (no bias) + BN1d(1e-5) + ReLU, BN folded into the FC           (:268-286, :577, :587)
@@ -94,7 +100,7 @@ class DsvtPipeline:
                 pre = f"module.backbone_3d.input_layer.posembed_layers.0.{b}.{l}.position_embedding_head"
                 Wa, ba = fold_linear_bn(w, pre + ".0", pre + ".1", 1e-5, bias=True)                 # :461-492
                 self.pe[(b, l)] = (zf(P.add_linear_op(Wa, ba, c.P, activation=P.ACT_RELU, **ct)),
-                                   zf(P.add_linear_op(w[pre + ".3.weight"], w[pre + ".3.bias"], c.P, **ct)))
+                                   zf(P.add_linear_op(w[pre + ".3.weight"], w[pre + ".3.bias"], c.P, **ct, **o16)))
                 lp = f"module.backbone_3d.stage_0.{b}.encoder_list.{l}"
                 wi = w[lp + ".win_attn.self_attn.in_proj_weight"].copy()
                 bi = w[lp + ".win_attn.self_attn.in_proj_bias"].copy()
@@ -105,15 +111,15 @@ class DsvtPipeline:
                     lns2.append((w[f"module.backbone_3d.residual_norm_stage_0.{b}.weight"],
                                  w[f"module.backbone_3d.residual_norm_stage_0.{b}.bias"]))
                 self.layers[(b, l)] = dict(
-                    qkv=zf(P.add_linear_op(wi, bi, c.P, add_cols=2 * C, **ct)),
-                    attn=zf(P.add_set_attention_op(c.W, L_SET, C, H, l, c.P)),
+                    qkv=zf(P.add_linear_op(wi, bi, c.P, add_cols=2 * C, **ct, **h_in, **o16)),
+                    attn=zf(P.add_set_attention_op(c.W, L_SET, C, H, l, c.P, io_half=f16)),
                     out=zf(P.add_linear_op(w[lp + ".win_attn.self_attn.out_proj.weight"],
                                            w[lp + ".win_attn.self_attn.out_proj.bias"], c.P,
-                                           layer_norms=[ln(".win_attn.norm1")], ln_eps=ln_eps, **ct)),
+                                           layer_norms=[ln(".win_attn.norm1")], ln_eps=ln_eps, **ct, **h_in, **oboth)),
                     fc1=zf(P.add_linear_op(w[lp + ".win_attn.linear1.weight"], w[lp + ".win_attn.linear1.bias"], c.P,
-                                           activation=P.ACT_GELU, **ct)),
+                                           activation=P.ACT_GELU, **ct, **h_in, **o16)),
                     fc2=zf(P.add_linear_op(w[lp + ".win_attn.linear2.weight"], w[lp + ".win_attn.linear2.bias"], c.P,
-                                           layer_norms=lns2, ln_eps=ln_eps, **ct)))
+                                           layer_norms=lns2, ln_eps=ln_eps, **ct, **h_in, **oboth)))
         self.cat = torch.zeros((1, c.Nk, 192), dtype=torch.float32, device=self.device)
         if with_head:
             self.map2bev = P.add_map_2_bev_op(c.P, C, GX, GY)
@@ -207,6 +213,7 @@ class DsvtPipeline:
     def backbone(self, st, trace=None):
         Pn = st["P"]
         x = st["vfeat"]
+        xh = x.to(torch.float16) if self.f16 else x        # GEMM-operand copy of the residual stream
         for b in range(self.blocks):
             xb = x
             inds, mask, S = st["gss"][b % 2][0], st["gss"][b % 2][1], st["gss"][b % 2][2]
@@ -214,19 +221,23 @@ class DsvtPipeline:
                 a, fc = self.pe[(b, l)]
                 pos = fc(a(st["wps"][l][5], Pn)[0], Pn)[0]           # pos-embed input = window config l (:603-637)
                 L = self.layers[(b, l)]
-                qkv = L["qkv"](x, Pn, pos)[0]
+                qkv = L["qkv"](xh, Pn, pos)[0]
                 att = L["attn"](qkv, inds, mask, S)[0]
-                s1 = L["out"](att, Pn, x)[0]
-                h = L["fc1"](s1, Pn)[0]
-                x = L["fc2"](h, Pn, s1, x, xb)[0] if l == 1 else L["fc2"](h, Pn, s1, x)[0]
+                o = L["out"](att, Pn, x)
+                s1, s1h = o[0], o[-1]
+                h = L["fc1"](s1h, Pn)[0]
+                o = L["fc2"](h, Pn, s1, x, xb) if l == 1 else L["fc2"](h, Pn, s1, x)
+                x, xh = o[0], o[-1]
                 if trace is not None:
                     trace[(b, l)] = x.clone()
+        self._xh = xh
         return x
 
     def head(self, x, st):
-        bev = self.map2bev(x, st["coords"], st["P"])[0]               # [1, 468(y), 468(x), 192] NHWC
+        src = self._xh if (self.f16 and self.head_dtype == torch.float16) else x
+        bev = self.map2bev(src, st["coords"], st["P"])[0]             # [1, 468(y), 468(x), 192] NHWC
         bev = bev.permute(0, 3, 1, 2)                                 # NCHW view of channels-last memory (:1131-1133)
-        if self.head_dtype != torch.float32:
+        if bev.dtype != self.head_dtype:
             bev = bev.to(self.head_dtype)
         o = self._bev(bev)
         return self.filter(*self._decode(o))

@@ -412,8 +412,11 @@ ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 COMPUTE_F32, COMPUTE_F16 = 0, 1
 
 
+OUT_F32, OUT_F16, OUT_BOTH = 0, 1, 2
+
+
 def add_linear_op(weight, bias, max_rows, row_mult=1, activation=ACT_NONE, add_cols=0, layer_norms=(), ln_eps=0.0,
-                  compute_type=COMPUTE_F32):
+                  compute_type=COMPUTE_F32, input_half=False, output_mode=OUT_F32):
     """FC with fused prologue/epilogue (csrc/linear.hip), used where the reference calls
     addFullyConnected (src/dsvt-ai-trt.cpp:283,476,490,506,525) + ElementWise/LayerNorm/GELU.
     Inputs: A [1,rows,K], count [1], (A2 if add_cols), then one residual per LayerNorm stage.
@@ -422,7 +425,7 @@ def add_linear_op(weight, bias, max_rows, row_mult=1, activation=ACT_NONE, add_c
     N, K = weight.shape
     fields = dict(max_rows=max_rows, in_features=K, out_features=N, row_mult=row_mult, activation=activation,
                   add_cols=add_cols, num_layer_norms=len(layer_norms), ln_eps=float(ln_eps), compute_type=compute_type,
-                  weight=weight.reshape(-1))
+                  input_half=int(bool(input_half)), output_mode=output_mode, weight=weight.reshape(-1))
     if bias is not None:
         fields["bias"] = np.asarray(bias, np.float32).reshape(-1)
     if layer_norms:
@@ -431,9 +434,10 @@ def add_linear_op(weight, bias, max_rows, row_mult=1, activation=ACT_NONE, add_c
     return Plugin("DsvtLinearPlugin", fields, "linear_layer")
 
 
-def add_set_attention_op(max_win_num, voxel_num_set, channel_num, num_heads, axis_id, max_pillars_num):
+def add_set_attention_op(max_win_num, voxel_num_set, channel_num, num_heads, axis_id, max_pillars_num, io_half=False):
     """GetValueByIndex + attention core + MapSetFeature2Voxel fused (csrc/attention.hip).
     Inputs: qkv [1,P,3C] (per-voxel projections), inds [1,2,S,36], mask [1,2,S,36], valid_set_num [1]."""
     return Plugin("DsvtSetAttentionPlugin", dict(max_win_num=max_win_num, voxel_num_set=voxel_num_set,
                                                  channel_num=channel_num, num_heads=num_heads, axis_id=axis_id,
-                                                 max_pillars_num=max_pillars_num), "set_attention_layer")
+                                                 max_pillars_num=max_pillars_num, io_half=int(bool(io_half))),
+                  "set_attention_layer")
