@@ -33,7 +33,7 @@ if ROOT not in sys.path:
 import __graft_entry__ as G  # noqa: E402
 
 PEAK_F32_MATRIX_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
-PEAK_F16_MATRIX_TFLOPS = 2500.0     # same guide: "Peak BF16/FP16 MFMA ~2.5 PF dense"
+PEAK_HBM_GBS = 8000.0               # same guide: "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured float4 copy)
 N_POINTS = 180000
 FRAME_POOL = 4                      # distinct synthetic clouds cycled through by the steps
 
@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "f16"], default="f16",
                     help="f16: fp16 MFMA operands / fp16 dense head, fp32 accumulate + LayerNorm/softmax/decode "
                          "(BASELINE configs[2]); f32: fp32 everywhere (the mode the 1e-3 box-parity tests run in)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every op from the host instead of replaying a HIP graph")
+    ap.add_argument("--event-every", type=int, default=10,
+                    help="every N-th timed step runs un-graphed with HIP events around each linear launch (roofline sample)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline = null)")
     args = ap.parse_args()
@@ -102,15 +105,28 @@ def main():
         pool.append((torch.from_numpy(buf).to(dev), torch.tensor([p.shape[0]], dtype=torch.int32, device=dev)))
     results = torch.zeros((K, par.ROW), dtype=torch.float32, device=dev)
 
-    def run_frame(i, row):
+    use_graph = not args.no_graph
+    static_pts, static_n = torch.zeros_like(pool[0][0]), torch.zeros_like(pool[0][1])
+
+    def run_frame(i, row, eager=False):
         pts, n = pool[i % len(pool)]
-        boxes, cnt = pipe.forward(pts, n)
+        if use_graph and not eager:
+            static_pts.copy_(pts); static_n.copy_(n)          # device-to-device refill of the graph's input buffers
+            boxes, cnt = pipe.replay()
+        else:
+            boxes, cnt = pipe.forward(pts, n)
         par.pack_result(boxes[0], cnt, row)
 
     scratch = torch.zeros((par.ROW,), dtype=torch.float32, device=dev)
-    for i in range(args.warmup):
-        run_frame(i, scratch)
+    for i in range(max(args.warmup, 1)):
+        run_frame(i, scratch, eager=True)
     torch.cuda.synchronize()
+    if use_graph:
+        static_pts.copy_(pool[0][0]); static_n.copy_(pool[0][1])
+        pipe.capture(static_pts, static_n)
+        for i in range(args.warmup):
+            run_frame(i, scratch)
+        torch.cuda.synchronize()
     # device-side counts of each pooled frame (for the algorithmic flop count), read outside the timed region
     counts = []
     for pts, n in pool:
@@ -121,11 +137,16 @@ def main():
     prof = None if args.no_kernel_events else {"DsvtLinearPlugin": []}
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
     par.barrier(); torch.cuda.synchronize()
-    pkg.plugin.PROFILE = prof
+    sampled = 0
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(K):
-        run_frame(i, results[i])
+        # roofline sample: every event_every-th step is launched op by op with HIP events around each
+        # linear launch (events cannot bracket kernels inside a graph replay); it stays inside the timed region
+        ev = prof is not None and (not use_graph or i % args.event_every == args.event_every // 2)
+        pkg.plugin.PROFILE = prof if ev else None
+        run_frame(i, results[i], eager=ev)
+        sampled += ev
         marks[i + 1].record()
     gathered = par.gather_results(results, K * world, rank, world)          # the one collective of the path
     par.barrier(); torch.cuda.synchronize()
@@ -136,25 +157,37 @@ def main():
     frame_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(K)])
     roofline = None
     if prof is not None and prof["DsvtLinearPlugin"]:
-        per_frame = len(prof["DsvtLinearPlugin"]) // K
-        tot_ms, tot_flops = 0.0, 0.0
+        per_frame = len(prof["DsvtLinearPlugin"]) // max(sampled, 1)
+        tot_ms, tot_flops, tot_bytes = 0.0, 0.0, 0.0
         for j, (e0, e1, pl) in enumerate(prof["DsvtLinearPlugin"]):
             c = counts[(j // per_frame) % len(pool)]
             f = pl.fields
             rows = c[pl.rows_kind]          # "Nk" for the two PFN linears, "P" for everything on voxel rows
+            K_, N_ = f["in_features"], f["out_features"]
             tot_ms += e0.elapsed_time(e1)
-            tot_flops += 2.0 * rows * f["in_features"] * f["out_features"]
+            tot_flops += 2.0 * rows * K_ * N_
+            # algorithmic HBM bytes: operand rows (+ the added pos rows), one fp32 residual row per LayerNorm
+            # stage, the output row(s), and the weights once
+            esz = 2 if f.get("input_half") else 4
+            out_b = {0: 4, 1: 2, 2: 6}[f.get("output_mode", 0)]
+            tot_bytes += rows * (K_ * esz * (2 if f.get("add_cols") else 1) + 4 * N_ * f.get("num_layer_norms", 0) + out_b * N_) \
+                + K_ * N_ * (2 if f16 else 4)
         n_launch = len(prof["DsvtLinearPlugin"])
         avg_ms = tot_ms / n_launch
-        achieved = tot_flops / n_launch / (avg_ms * 1e-3) / 1e12
-        peak = PEAK_F16_MATRIX_TFLOPS if f16 else PEAK_F32_MATRIX_TFLOPS
-        kname = ("linear_f16_kernel (DsvtLinearPlugin, v_mfma_f32_16x16x32_f16)" if f16
-                 else "linear_f32_kernel (DsvtLinearPlugin, v_mfma_f32_16x16x4_f32)")
-        roofline = dict(kernel=kname, bound="mfma",
-                        achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
-                        frac=round(achieved / peak, 4), traffic=None,
-                        launches_per_frame=per_frame, avg_launch_us=round(1e3 * avg_ms, 2),
-                        algorithmic_gflop_per_launch=round(tot_flops / n_launch / 1e9, 3))
+        tflops = tot_flops / n_launch / (avg_ms * 1e-3) / 1e12
+        gbs = tot_bytes / n_launch / (avg_ms * 1e-3) / 1e9
+        if f16:
+            # fp16 operands: 2.5 PF of MFMA against ~100 MB per launch -- the kernel is HBM/latency bound
+            roofline = dict(kernel="linear_f16_kernel (DsvtLinearPlugin, v_mfma_f32_16x16x32_f16)", bound="hbm",
+                            achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
+                            traffic=None, mfma_tflops=round(tflops, 2))
+        else:
+            roofline = dict(kernel="linear_f32_kernel (DsvtLinearPlugin, v_mfma_f32_16x16x4_f32)", bound="mfma",
+                            achieved=round(tflops, 2), peak=PEAK_F32_MATRIX_TFLOPS, unit="TFLOP/s",
+                            frac=round(tflops / PEAK_F32_MATRIX_TFLOPS, 4), traffic=None, hbm_gbs=round(gbs, 1))
+        roofline.update(launches_per_frame=per_frame, sampled_frames=sampled, avg_launch_us=round(1e3 * avg_ms, 2),
+                        algorithmic_gflop_per_launch=round(tot_flops / n_launch / 1e9, 3),
+                        algorithmic_mb_per_launch=round(tot_bytes / n_launch / 1e6, 2))
 
     if rank == 0:
         total_frames = K * world
@@ -169,6 +202,7 @@ def main():
                                    "468x468 BEV, full 4-block DSVT pillar backbone + BEV ResNet + CenterHead + "
                                    "FilterBoxByScore; seeded random weights (dsvt.wts is not shipped)",
                        "frames_per_gpu": K, "parallelism": f"frame-batch dp{world}, one result gather",
+                       "launch": "hip-graph replay per frame" if use_graph else "host launch per op",
                        "caps": dict(points=caps.N, pillars=caps.P, windows_sets=caps.W),
                        "frame0": counts[0]},
             "roofline": roofline,

@@ -242,6 +242,27 @@ class DsvtPipeline:
         o = self._bev(bev)
         return self.filter(*self._decode(o))
 
+    # ---- HIP-graph replay of a whole frame -------------------------------------------------------
+    def capture(self, points, n, warmup=3):
+        """Record forward(points, n) into a HIP graph.  `points` / `n` are the static input buffers:
+        refill them in place (copy_) and call replay().  Every kernel of the frame (the C-ABI plugins
+        enqueue on the capturing stream, device-side counts never visit the host) becomes one graph
+        launch, which removes the ~150 per-op host launches from the frame's critical path."""
+        # warm-up on the CURRENT stream: warming up on a side stream (the usual PyTorch recipe) makes the
+        # second replay fault on ROCm 7.2 ("write access to a read-only page"), also for graphs that hold
+        # nothing but this library's kernels -- see tools/graph_test2.py
+        for _ in range(warmup):
+            self.forward(points, n)
+        torch.cuda.synchronize(self.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.graph_out = self.forward(points, n)
+        return self.graph_out
+
+    def replay(self):
+        self.graph.replay()
+        return self.graph_out
+
     def forward(self, points, n):
         """points [1, max_points, 4] f32 (zero padded), n [1] i32 -> boxes [1,500,9] f32, count [1] i32"""
         st = self.voxel_stage(points, n)
