@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "f16"], default="f16",
                     help="f16: fp16 MFMA operands / fp16 dense head, fp32 accumulate + LayerNorm/softmax/decode "
                          "(BASELINE configs[2]); f32: fp32 everywhere (the mode the 1e-3 box-parity tests run in)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="frames in flight per GPU: independent pipeline instances on separate HIP streams (a single "
+                         "180k-point frame leaves most kernels one wave per SIMD; overlapping two frames fills the gaps)")
     ap.add_argument("--no-graph", action="store_true", help="launch every op from the host instead of replaying a HIP graph")
     ap.add_argument("--event-every", type=int, default=10,
                     help="every N-th timed step runs un-graphed with HIP events around each linear launch (roofline sample)")
@@ -91,9 +94,13 @@ def main():
     caps = pkg.pipeline.Caps()                      # 196608 points / 65536 pillars / 2048 windows+sets
     weights = pkg.synth.make_weights()
     f16 = args.dtype == "f16"
-    pipe = pkg.pipeline.DsvtPipeline(weights, caps=caps, device=dev,
-                                     linear_compute=pkg.plugin.COMPUTE_F16 if f16 else pkg.plugin.COMPUTE_F32,
-                                     head_dtype=torch.float16 if f16 else torch.float32)
+    use_graph = not args.no_graph
+    NS = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
+    pipes = [pkg.pipeline.DsvtPipeline(weights, caps=caps, device=dev,
+                                       linear_compute=pkg.plugin.COMPUTE_F16 if f16 else pkg.plugin.COMPUTE_F32,
+                                       head_dtype=torch.float16 if f16 else torch.float32) for _ in range(NS)]
+    pipe = pipes[0]
 
     # synthetic frames of this rank, resident in HBM before the timed region
     K = args.steps
@@ -104,29 +111,31 @@ def main():
         buf[0, :p.shape[0]] = p
         pool.append((torch.from_numpy(buf).to(dev), torch.tensor([p.shape[0]], dtype=torch.int32, device=dev)))
     results = torch.zeros((K, par.ROW), dtype=torch.float32, device=dev)
-
-    use_graph = not args.no_graph
-    static_pts, static_n = torch.zeros_like(pool[0][0]), torch.zeros_like(pool[0][1])
+    static_in = [(torch.zeros_like(pool[0][0]), torch.zeros_like(pool[0][1])) for _ in range(NS)]
 
     def run_frame(i, row, eager=False):
+        """frame i on pipeline/stream i % NS (must be called with that stream current)"""
+        s = i % NS
         pts, n = pool[i % len(pool)]
         if use_graph and not eager:
-            static_pts.copy_(pts); static_n.copy_(n)          # device-to-device refill of the graph's input buffers
-            boxes, cnt = pipe.replay()
+            static_in[s][0].copy_(pts); static_in[s][1].copy_(n)        # device-to-device refill of the graph's inputs
+            boxes, cnt = pipes[s].replay()
         else:
-            boxes, cnt = pipe.forward(pts, n)
+            boxes, cnt = pipes[s].forward(pts, n)
         par.pack_result(boxes[0], cnt, row)
 
-    scratch = torch.zeros((par.ROW,), dtype=torch.float32, device=dev)
-    for i in range(max(args.warmup, 1)):
-        run_frame(i, scratch, eager=True)
-    torch.cuda.synchronize()
-    if use_graph:
-        static_pts.copy_(pool[0][0]); static_n.copy_(pool[0][1])
-        pipe.capture(static_pts, static_n)
-        for i in range(args.warmup):
-            run_frame(i, scratch)
-        torch.cuda.synchronize()
+    scratch = [torch.zeros((par.ROW,), dtype=torch.float32, device=dev) for _ in range(NS)]
+    for s in range(NS):
+        with torch.cuda.stream(streams[s]):
+            for i in range(max(args.warmup, 1)):
+                run_frame(i * NS + s, scratch[s], eager=True)
+            torch.cuda.synchronize()
+            if use_graph:
+                static_in[s][0].copy_(pool[0][0]); static_in[s][1].copy_(pool[0][1])
+                pipes[s].capture(*static_in[s])
+                for i in range(args.warmup):
+                    run_frame(i * NS + s, scratch[s])
+            torch.cuda.synchronize()
     # device-side counts of each pooled frame (for the algorithmic flop count), read outside the timed region
     counts = []
     for pts, n in pool:
@@ -135,26 +144,34 @@ def main():
     torch.cuda.synchronize()
 
     prof = None if args.no_kernel_events else {"DsvtLinearPlugin": []}
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+    marks = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     par.barrier(); torch.cuda.synchronize()
     sampled = 0
     t0 = time.perf_counter()
-    marks[0].record()
     for i in range(K):
-        # roofline sample: every event_every-th step is launched op by op with HIP events around each
-        # linear launch (events cannot bracket kernels inside a graph replay); it stays inside the timed region
+        # roofline sample: every event_every-th step is launched op by op, alone on the GPU, with HIP events
+        # around each linear launch (events cannot bracket kernels inside a graph replay); it stays inside the
+        # timed region
         ev = prof is not None and (not use_graph or i % args.event_every == args.event_every // 2)
+        if ev and (use_graph or NS > 1):
+            torch.cuda.synchronize()
         pkg.plugin.PROFILE = prof if ev else None
-        run_frame(i, results[i], eager=ev)
+        with torch.cuda.stream(streams[i % NS]):
+            marks[i][0].record()
+            run_frame(i, results[i], eager=ev)
+            marks[i][1].record()
+        if ev and (use_graph or NS > 1):
+            torch.cuda.synchronize()
         sampled += ev
-        marks[i + 1].record()
+    for s in streams:
+        torch.cuda.current_stream().wait_stream(s)
     gathered = par.gather_results(results, K * world, rank, world)          # the one collective of the path
     par.barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     pkg.plugin.PROFILE = None
     dt = par.max_over_ranks(dt, dev)
 
-    frame_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(K)])
+    frame_ms = np.array([marks[i][0].elapsed_time(marks[i][1]) for i in range(K)])
     roofline = None
     if prof is not None and prof["DsvtLinearPlugin"]:
         per_frame = len(prof["DsvtLinearPlugin"]) // max(sampled, 1)
@@ -203,6 +220,7 @@ def main():
                                    "FilterBoxByScore; seeded random weights (dsvt.wts is not shipped)",
                        "frames_per_gpu": K, "parallelism": f"frame-batch dp{world}, one result gather",
                        "launch": "hip-graph replay per frame" if use_graph else "host launch per op",
+                       "frames_in_flight": NS,
                        "caps": dict(points=caps.N, pillars=caps.P, windows_sets=caps.W),
                        "frame0": counts[0]},
             "roofline": roofline,
