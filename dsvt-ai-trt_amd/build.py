@@ -18,6 +18,7 @@ SOURCES = [
     ("partition_ops.hip", ["-ffp-contract=off"]),
     ("linear.hip", []),
     ("attention.hip", []),
+    ("conv.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math",
           "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]

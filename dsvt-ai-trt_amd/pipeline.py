@@ -65,10 +65,12 @@ def fold_linear_bn(w, lin, bn, eps, bias=False):
 
 class DsvtPipeline:
     def __init__(self, weights, caps=None, blocks=4, with_head=True, ln_eps=0.0, head_dtype=torch.float32,
-                 device="cuda:0", zero_fill=False, linear_compute=P.COMPUTE_F32):
+                 device="cuda:0", zero_fill=False, linear_compute=P.COMPUTE_F32, hip_head=None):
         """linear_compute: COMPUTE_F32 = fp32 MFMA everywhere (parity mode, boxes within 1e-3 of the
         fp32 oracle); COMPUTE_F16 = fp16 MFMA operands with fp32 accumulate/epilogues (BASELINE
-        configs[2] "fp16").  head_dtype: precision of the dense BEV glue."""
+        configs[2] "fp16").  head_dtype: precision of the dense BEV stage.  hip_head: run the BEV ResNet +
+        CenterHead on DsvtConv2dPlugin (csrc/conv.hip, fp16) instead of PyTorch/MIOpen; default: on in fp16
+        mode."""
         self.caps = c = caps or Caps()
         self.blocks, self.with_head, self.device = blocks, with_head, torch.device(device)
         self.head_dtype = head_dtype
@@ -124,7 +126,11 @@ class DsvtPipeline:
         if with_head:
             self.map2bev = P.add_map_2_bev_op(c.P, C, GX, GY)
             self.filter = P.add_filter_box_by_score_op(TOP_K, X_MIN, X_MAX, Y_MIN, Y_MAX, Z_MIN, Z_MAX, VX, VY, VZ, SCORE_THR)
-            self._build_dense(w)
+            self.hip_head = (head_dtype == torch.float16 and linear_compute == P.COMPUTE_F16) if hip_head is None else hip_head
+            if self.hip_head:
+                self._build_hip_head(w)
+            else:
+                self._build_dense(w)
 
     # ---- dense glue: BN folded into the convolutions, channels-last ----------
     def _conv_params(self, w, conv, bn):
@@ -163,6 +169,78 @@ class DsvtPipeline:
             o += no
         d["heads1"] = (W2.to(self.device, self.head_dtype).contiguous(memory_format=torch.channels_last),
                        b2.to(self.device, self.head_dtype))
+
+    # ---- BEV ResNet + CenterHead on the HIP convolution ------------------------------
+    def _build_hip_head(self, w):
+        cw, dw = P.conv_weight_rows, P.deconv_weight_rows
+
+        def conv(name_conv, name_bn, H, cin, cout, k, stride, relu, res=False):
+            s, sh = bn_fold(w, name_bn, 1e-3)                                                    # :191,208
+            return P.add_conv2d_op(cw(w[name_conv + ".weight"] * s[:, None, None, None]), sh, H, H, cin, cout, k, stride, k // 2,
+                                   relu=relu, has_residual=res)
+
+        ops = self.hops = {}
+        H = GY
+        for (i, cin, cout, stride, nb) in ((0, 192, 128, 1, 2), (1, 128, 128, 2, 3), (2, 128, 256, 2, 3)):
+            for j in range(nb):
+                p = f"module.backbone_2d.blocks.{i}.{j}"
+                st = stride if j == 0 else 1
+                ci = cin if j == 0 else cout
+                ops[p + ".1"] = conv(p + ".conv1", p + ".bn1", H, ci, cout, 3, st, True)
+                Ho = (H + 2 - 3) // st + 1
+                if j == 0:
+                    ops[p + ".d"] = conv(p + ".downsample_layer.0", p + ".downsample_layer.1", H, ci, cout, 1, st, False)
+                ops[p + ".2"] = conv(p + ".conv2", p + ".bn2", Ho, cout, cout, 3, 1, True, res=True)   # + identity, ReLU (:1165-1166)
+                H = Ho
+            k = (1, 2, 4)[i]
+            p = f"module.backbone_2d.deblocks.{i}"
+            s_, sh_ = bn_fold(w, p + ".1", 1e-3)
+            ops[p] = P.add_conv2d_op(dw(w[p + ".0.weight"] * s_[None, :, None, None]), sh_, H, H, cout, 128, 1, 1, 0,
+                                     pixel_shuffle=k, relu=True, out_channel_stride=384, out_channel_offset=128 * i)
+        ops["shared"] = conv("module.dense_head.shared_conv.0", "module.dense_head.shared_conv.1", GY, 384, 64, 3, 1, True)
+        names, outs = ["center", "center_z", "dim", "rot", "hm"], [2, 1, 3, 2, 10]          # iou head is dead (:1440-1452)
+        W0, b0 = [], []
+        for n in names:
+            s_, sh_ = bn_fold(w, f"module.dense_head.heads_list.0.{n}.0.1", 1e-3)
+            W0.append(w[f"module.dense_head.heads_list.0.{n}.0.0.weight"] * s_[:, None, None, None]); b0.append(sh_)
+        ops["heads0"] = P.add_conv2d_op(cw(np.concatenate(W0, 0)), np.concatenate(b0), GY, GX, 64, 320, 3, 1, 1, relu=True)
+        W1 = np.zeros((sum(outs), 320, 3, 3), np.float32); b1 = np.zeros((sum(outs),), np.float32)
+        o = 0
+        for k_, (n, no) in enumerate(zip(names, outs)):                                       # block-diagonal second convs
+            W1[o:o + no, 64 * k_:64 * (k_ + 1)] = w[f"module.dense_head.heads_list.0.{n}.1.weight"]
+            b1[o:o + no] = w[f"module.dense_head.heads_list.0.{n}.1.bias"]
+            o += no
+        ops["heads1"] = P.add_conv2d_op(cw(W1), b1, GY, GX, 320, 18, 3, 1, 1, out_f32=True)
+        self.cat_bev = torch.zeros((1, GY, GX, 384), dtype=torch.float16, device=self.device)
+
+    def _bev_hip(self, x):
+        """x: [1, 468, 468, 192] fp16 NHWC -> [1, 468, 468, 18] fp32 NHWC (center2 cz1 dim3 rot2 hm10)"""
+        ops = self.hops
+        for (i, nb) in ((0, 2), (1, 3), (2, 3)):
+            for j in range(nb):
+                p = f"module.backbone_2d.blocks.{i}.{j}"
+                y = ops[p + ".1"](x)[0]
+                idn = ops[p + ".d"](x)[0] if j == 0 else x
+                x = ops[p + ".2"](y, idn)[0]
+            ops[f"module.backbone_2d.deblocks.{i}"](x, out=[self.cat_bev])                     # deblock + concat (:1363)
+        sh = ops["shared"](self.cat_bev)[0]
+        return ops["heads1"](ops["heads0"](sh)[0])[0]
+
+    def _decode_nhwc(self, o):
+        """same as _decode for an NHWC [1,H,W,18] head output"""
+        of = o.reshape(-1, 18)
+        hm = torch.sigmoid(of[:, 8:18].t().contiguous())                # [10, H*W]
+        sc1, idx1 = torch.topk(hm, TOP_K, dim=1)
+        sc2, idx2 = torch.topk(sc1.reshape(-1), TOP_K)
+        cls = (idx2 // TOP_K).to(torch.int32)
+        ind = idx1.reshape(-1)[idx2]
+        ys, xs = (ind // GX).to(torch.int32), (ind % GX).to(torch.int32)
+        g = of[ind]                                                     # [K, 18]
+        center = g[:, 0:2].contiguous(); center_z = g[:, 2:3].contiguous()
+        dim = torch.exp(g[:, 3:6]).contiguous()
+        angle = torch.atan(g[:, 7:8] / g[:, 6:7]).contiguous()
+        return (sc2.reshape(1, -1), cls.reshape(1, -1), xs.reshape(1, -1), ys.reshape(1, -1), center.reshape(1, 1, -1, 2),
+                center_z.reshape(1, 1, -1, 1), angle.reshape(1, 1, -1, 1), dim.reshape(1, 1, -1, 3))
 
     def _bev(self, x):
         d = self.dense
@@ -236,6 +314,8 @@ class DsvtPipeline:
     def head(self, x, st):
         src = self._xh if (self.f16 and self.head_dtype == torch.float16) else x
         bev = self.map2bev(src, st["coords"], st["P"])[0]             # [1, 468(y), 468(x), 192] NHWC
+        if self.hip_head:
+            return self.filter(*self._decode_nhwc(self._bev_hip(bev)))
         bev = bev.permute(0, 3, 1, 2)                                 # NCHW view of channels-last memory (:1131-1133)
         if bev.dtype != self.head_dtype:
             bev = bev.to(self.head_dtype)

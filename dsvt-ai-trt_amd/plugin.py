@@ -244,14 +244,17 @@ class Plugin:
             raise RuntimeError(f"{self.plugin_type}.enqueue returned {rc}")
 
     # ---- convenience: allocate outputs/workspace once per input signature, then enqueue ----
-    def __call__(self, *inputs):
+    def __call__(self, *inputs, out=None):
         # Hot path: every buffer of the pipeline is static, so the marshalled argument pack
         # (descriptors + pointer arrays) is built once per distinct set of input pointers and a
         # call is then a single ctypes call into dsvtPluginEnqueue.
+        # out: optional list of caller-owned output tensors (e.g. a shared concat buffer).
         key = tuple(t.data_ptr() for t in inputs)
+        if out is not None:
+            key = key + tuple(t.data_ptr() for t in out)
         pack = self._packs.get(key)
         if pack is None:
-            pack = self._make_pack(inputs, key)
+            pack = self._make_pack(inputs, key, out)
         outs, ind, outd, inp, outp, ws = pack
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         prof = PROFILE.get(self.plugin_type) if PROFILE is not None else None
@@ -267,7 +270,7 @@ class Plugin:
             raise RuntimeError(f"{self.plugin_type}.enqueue returned {rc}")
         return outs
 
-    def _make_pack(self, inputs, key):
+    def _make_pack(self, inputs, key, out=None):
         for t in inputs:
             if not t.is_cuda:
                 raise RuntimeError(f"{self.plugin_type}: inputs must be device tensors (no CPU path exists)")
@@ -289,12 +292,14 @@ class Plugin:
             ent = (outs, ws)
             self._cache[sig] = ent
         outs, ws = ent
+        if out is not None:
+            outs = list(out)
         ind = (PluginTensorDesc * len(inputs))(*[_desc(t.shape, _dt_code(t)) for t in inputs])
         outd = (PluginTensorDesc * len(outs))(*[_desc(t.shape, _dt_code(t)) for t in outs])
         inp = (C.c_void_p * len(inputs))(*[t.data_ptr() for t in inputs])
         outp = (C.c_void_p * len(outs))(*[t.data_ptr() for t in outs])
         pack = (outs, ind, outd, inp, outp, C.c_void_p(ws.data_ptr()))
-        self._keepalive.append(tuple(inputs))      # the cached raw pointers must stay valid
+        self._keepalive.append((tuple(inputs), tuple(outs)))      # the cached raw pointers must stay valid
         self._packs[key] = pack
         return pack
 
@@ -441,3 +446,31 @@ def add_set_attention_op(max_win_num, voxel_num_set, channel_num, num_heads, axi
                                                  channel_num=channel_num, num_heads=num_heads, axis_id=axis_id,
                                                  max_pillars_num=max_pillars_num, io_half=int(bool(io_half))),
                   "set_attention_layer")
+
+
+def conv_weight_rows(w):
+    """torch Conv2d weight [Cout, Cin, KH, KW] -> DsvtConv2dPlugin rows [Cout][KH*KW][Cin]."""
+    w = np.asarray(w, np.float32)
+    return np.ascontiguousarray(w.transpose(0, 2, 3, 1)).reshape(w.shape[0], -1)
+
+
+def deconv_weight_rows(w):
+    """torch ConvTranspose2d weight [Cin, Cout, k, k] with stride == k -> pixel-shuffle rows [(dy*k+dx)*Cout + co][Cin]."""
+    w = np.asarray(w, np.float32)
+    return np.ascontiguousarray(w.transpose(2, 3, 1, 0)).reshape(-1, w.shape[0])
+
+
+def add_conv2d_op(weight_rows, bias, in_height, in_width, in_channels, out_channels, kernel_size=1, stride=1, padding=0,
+                  pixel_shuffle=1, relu=False, has_residual=False, out_channel_stride=None, out_channel_offset=0, out_f32=False):
+    """NHWC fp16 implicit-GEMM convolution with fused bias / residual / ReLU / pixel-shuffle / concat offset
+    (csrc/conv.hip): replaces the reference's addConvolutionNd / addDeconvolutionNd + addScale + ReLU + SUM
+    groups (src/dsvt-ai-trt.cpp:149-246, 1144-1468).  Inputs: x [1,H,W,Cin] fp16 (, residual [1,Ho,Wo,C] fp16)."""
+    fields = dict(in_height=in_height, in_width=in_width, in_channels=in_channels, out_channels=out_channels,
+                  kernel_size=kernel_size, stride=stride, padding=padding, pixel_shuffle=pixel_shuffle, relu=int(bool(relu)),
+                  has_residual=int(bool(has_residual)),
+                  out_channel_stride=out_channels if out_channel_stride is None else out_channel_stride,
+                  out_channel_offset=out_channel_offset, out_f32=int(bool(out_f32)),
+                  weight=np.asarray(weight_rows, np.float32).reshape(-1))
+    if bias is not None:
+        fields["bias"] = np.asarray(bias, np.float32).reshape(-1)
+    return Plugin("DsvtConv2dPlugin", fields, "conv2d_layer")

@@ -1,0 +1,84 @@
+"""DsvtConv2dPlugin (NHWC fp16 implicit-GEMM convolution) against PyTorch's convolution on the same
+fp16-rounded operands.  fp32 accumulation on both sides: differences are summation order + the final
+fp16 rounding of the output (2^-11 relative)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ref(x, w, b, stride, pad, res=None, relu=False):
+    y = F.conv2d(x.float(), w.float(), b, stride, pad)
+    if res is not None:
+        y = y + res.float()
+    return torch.relu(y) if relu else y
+
+
+def nhwc(t):      # NCHW tensor -> contiguous [1,H,W,C]
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("H,W,cin,cout,k,stride,res,relu", [
+    (52, 47, 128, 128, 3, 1, True, True),      # basic block conv2 + identity + ReLU (KC=128)
+    (52, 47, 192, 128, 3, 1, False, True),     # first BEV conv (KC=96)
+    (52, 47, 128, 256, 3, 2, False, True),     # strided, two output-channel chunks
+    (52, 47, 128, 256, 1, 2, False, False),    # 1x1 downsample
+    (30, 33, 384, 64, 3, 1, False, True),      # shared head conv
+    (30, 33, 64, 320, 3, 1, False, True),      # five head stems at once (KC=64, 3 chunks, last one partial)
+])
+def test_conv_matches_torch(pkg, H, W, cin, cout, k, stride, res, relu):
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(H * 1000 + cin + cout)
+    x = (torch.randn(1, cin, H, W, generator=g)).half().to(DEV)
+    w = (torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)).half().to(DEV)
+    b = (torch.randn(cout, generator=g) * 0.1).to(DEV)
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    r = torch.randn(1, cout, Ho, Wo, generator=g).half().to(DEV) if res else None
+    ref = _ref(x, w, b, stride, pad, r, relu)
+    op = P.add_conv2d_op(P.conv_weight_rows(w.float().cpu().numpy()), b.cpu().numpy(), H, W, cin, cout, k, stride, pad,
+                         relu=relu, has_residual=res)
+    args = [nhwc(x)] + ([nhwc(r)] if res else [])
+    o = op(*args)[0]
+    torch.cuda.synchronize()
+    got = o.permute(0, 3, 1, 2).float()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() < 2e-3 * scale
+
+
+def test_conv_f32_output_partial_channels(pkg):
+    """heads' last conv: 320 -> 18 channels (not a multiple of 4/16), fp32 output."""
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(1, 320, 25, 31, generator=g).half().to(DEV)
+    w = (torch.randn(18, 320, 3, 3, generator=g) / 50).half().to(DEV)
+    b = torch.randn(18, generator=g).to(DEV)
+    ref = _ref(x, w, b, 1, 1)
+    op = P.add_conv2d_op(P.conv_weight_rows(w.float().cpu().numpy()), b.cpu().numpy(), 25, 31, 320, 18, 3, 1, 1, out_f32=True)
+    o = op(nhwc(x))[0]
+    assert o.dtype == torch.float32 and tuple(o.shape) == (1, 25, 31, 18)
+    assert (o.permute(0, 3, 1, 2) - ref).abs().max().item() < 1e-3 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("k,cin", [(1, 128), (2, 128), (4, 256)])
+def test_deconv_pixel_shuffle_and_concat(pkg, k, cin):
+    """ConvTranspose2d(kernel == stride) + BN bias + ReLU written into a channel slice of a wider tensor
+    (the reference's deblocks + concat, src/dsvt-ai-trt.cpp:217-246, 1363)."""
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(k)
+    H, W, cout, total, off = 19, 23, 128, 384, 128
+    x = torch.randn(1, cin, H, W, generator=g).half().to(DEV)
+    w = (torch.randn(cin, cout, k, k, generator=g) / np.sqrt(cin)).half().to(DEV)
+    b = (torch.randn(cout, generator=g) * 0.1).to(DEV)
+    ref = torch.relu(F.conv_transpose2d(x.float(), w.float(), b, stride=k))
+    op = P.add_conv2d_op(P.deconv_weight_rows(w.float().cpu().numpy()), b.cpu().numpy(), H, W, cin, cout, 1, 1, 0,
+                         pixel_shuffle=k, relu=True, out_channel_stride=total, out_channel_offset=off)
+    buf = torch.full((1, H * k, W * k, total), 7.0, dtype=torch.float16, device=DEV)
+    op(nhwc(x), out=[buf])
+    torch.cuda.synchronize()
+    got = buf[..., off:off + cout].permute(0, 3, 1, 2).float()
+    assert (got - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+    assert (buf[..., :off] == 7.0).all() and (buf[..., off + cout:] == 7.0).all()     # other slices untouched

@@ -14,8 +14,8 @@ def main():
     buf = np.zeros((1, caps.N, 4), np.float32); buf[0, :p.shape[0]] = p
     pts = torch.from_numpy(buf).to(dev); n = torch.tensor([p.shape[0]], dtype=torch.int32, device=dev)
     ref = None
-    for hd, lc in [(torch.float32, 0), (torch.float32, 1), (torch.float16, 1)]:
-        pipe = pkg.pipeline.DsvtPipeline(w, caps=caps, device=dev, head_dtype=hd, linear_compute=lc)
+    for hd, lc, hh in [(torch.float32, 0, False), (torch.float16, 1, False), (torch.float16, 1, True)]:
+        pipe = pkg.pipeline.DsvtPipeline(w, caps=caps, device=dev, head_dtype=hd, linear_compute=lc, hip_head=hh)
         for _ in range(4):
             out = pipe.forward(pts, n)
         torch.cuda.synchronize()
@@ -37,7 +37,7 @@ def main():
             from tests.parity import match_boxes
             worst, un = match_boxes(b, c, ref[0], ref[1], tol=0.2)
             msg = f" vs fp32 head: count {c} vs {ref[1]}, max|diff| matched {worst:.3e}, unmatched {un}"
-        print(f"head_dtype={hd} linear_compute={lc}: voxel_stage {T[0]:.3f} ms, backbone {T[1]:.3f} ms, head {T[2]:.3f} ms, total {T.sum():.3f} ms{msg}")
+        print(f"head_dtype={hd} linear_compute={lc} hip_head={hh}: voxel_stage {T[0]:.3f} ms, backbone {T[1]:.3f} ms, head {T[2]:.3f} ms, total {T.sum():.3f} ms{msg}")
 
 if __name__ == "__main__":
     main()
