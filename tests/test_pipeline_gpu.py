@@ -78,3 +78,46 @@ def test_pipeline_is_deterministic(pkg, weights):
         # near-tied candidates can swap rows, so rows are matched by centre, not by index
         worst, unmatched = match_boxes(b[0].cpu().numpy(), int(cb[0]), a[0].cpu().numpy(), int(ca[0]))
         assert unmatched == 0 and worst < 1e-4, (worst, unmatched)
+
+
+def _box_errors(got, n_got, exp, n_exp):
+    """per-field max abs error over rows matched by (class, nearest centre within 0.2 m); fraction matched"""
+    got, exp = got[:n_got], exp[:n_exp]
+    used = np.zeros(n_got, bool)
+    errs, matched = [], 0
+    for e in exp:
+        d = np.abs(got[:, :2] - e[:2]).max(1) + (got[:, 7] != e[7]) * 1e3 + used * 1e3
+        j = int(np.argmin(d))
+        if d[j] > 0.2:
+            continue
+        used[j] = True; matched += 1
+        errs.append(np.abs(got[j] - e))
+    errs = np.array(errs)
+    return errs.max(0), matched / max(n_exp, 1)
+
+
+@pytest.mark.parametrize("frame", ["000000", "000003"])
+def test_boxes_f16_mode(pkg, oracle, weights, frame):
+    """BASELINE configs[2] precision ("fp16"): fp16 MFMA operands / fp16 BEV activations, fp32 accumulate,
+    fp32 LayerNorm / softmax / decode -- the mode bench.py times by default.  The reference's own fp16
+    build (TensorRT kFP16, include/params.h:332) is not reproducible, so this mode is judged against the fp32
+    oracle with fp16-sized tolerances (fp16 rounds at 2^-11 = 4.9e-4 relative and the network is ~60
+    roundings deep).  Measured on MI355X, frames 000000 / 000003: centre x,y <= 5.7e-4 m, z <= 1.7e-3 m,
+    size <= 1.9e-3, score <= 4e-4, every oracle box has a partner.  The yaw is atan(sin/cos) of two raw head
+    outputs (src/dsvt-ai-trt.cpp:1668-1669): ill-conditioned when cos ~ 0, so its bound is loose (observed
+    4.5e-2 rad on one box, 6e-3 otherwise)."""
+    from oracle import dense_ref as D
+    caps = pkg.pipeline.Caps.reference()
+    pipe = pkg.pipeline.DsvtPipeline(weights, caps=caps, device=DEV, linear_compute=pkg.plugin.COMPUTE_F16,
+                                     head_dtype=torch.float16)
+    assert pipe.hip_head
+    pts, n = cases.load_frame(frame, caps.N)
+    boxes, cnt = _run(pkg, pipe, pts, n)
+    torch.cuda.synchronize()
+    eb, ec = D.forward(pts, n, weights, D.OracleCfg())
+    err, frac = _box_errors(boxes[0].cpu().numpy(), int(cnt[0]), eb, ec)
+    print("f16 box errors per field", err, "matched", frac, "counts", int(cnt[0]), ec)
+    assert frac >= 0.99
+    assert err[:2].max() < 2e-3 and err[2] < 5e-3 and err[3:6].max() < 5e-3 and err[8] < 2e-3
+    assert err[6] < 1e-1
+    assert abs(int(cnt[0]) - ec) <= 2
