@@ -28,6 +28,7 @@
 #include "plugin_base.h"
 #include "device_utils.h"
 #include "linear.h"
+#include <cstdlib>
 
 namespace dsvt {
 
@@ -265,40 +266,54 @@ __device__ __forceinline__ half8 loadFrag(const void* A, const void* A2, size_t 
     }
 }
 
-template <bool AHALF>
-__global__ void __launch_bounds__(256, 2)
+// MT = 16-row MFMA tiles per wave, NW = waves per workgroup; rows per workgroup = 16 * MT * NW = 128 either way.
+//   <2, 4>: 4 waves x 32 rows, ~245 VGPRs, 2 workgroups/CU = 2 waves/SIMD
+//   <1, 8>: 8 waves x 16 rows, <=128 VGPRs, 2 workgroups/CU = 4 waves/SIMD -- twice the waves to hide the
+//           load -> barrier -> MFMA -> store chain of a 35k-row problem that gives every SIMD ~one tile
+template <bool AHALF, int MT, int NW>
+__global__ void __launch_bounds__(64 * NW, (MT == 1 ? 4 : 2))
 linear_f16_kernel(LinearArgs a, const _Float16* __restrict__ Wh)
 {
     __shared__ __attribute__((aligned(16))) _Float16 sWh[BN * LDW];      // 79,872 B: two workgroups per CU
+    constexpr int NTHR = 64 * NW;
     const int M = rowLimit(a);
     const int m0 = blockIdx.x * BM16;
     if (m0 >= M) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int K = a.K, N = a.N;
-    int row0 = m0 + wave * 32 + r, row1 = row0 + 16;
-    const int rc0 = row0 < M ? row0 : M - 1, rc1 = row1 < M ? row1 : M - 1;     // clamp loads; rows >= M are never stored
+    int row[MT], rc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        row[mt] = m0 + wave * 16 * MT + mt * 16 + r;
+        rc[mt] = row[mt] < M ? row[mt] : M - 1;                          // clamp loads; rows >= M are never stored
+    }
 
     for (int n0 = 0; n0 < N; n0 += BN) {
-        floatx4 acc0[NT], acc1[NT];
+        floatx4 acc[MT][NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { acc0[t] = floatx4{0.f, 0.f, 0.f, 0.f}; acc1[t] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[mt][t] = floatx4{0.f, 0.f, 0.f, 0.f};
         const bool add = n0 < a.add_cols;
         const int ntiles = (N - n0 + 15) / 16 < NT ? (N - n0 + 15) / 16 : NT;
         for (int ks = 0; ks < K; ks += KS) {
             // the activation fragments of the whole slab are requested first, so their HBM latency
             // overlaps the W slab's trip L2 -> VGPR -> LDS
-            half8 f0[NSTEP], f1[NSTEP];
-            const size_t o0 = (size_t)rc0 * K + ks + g * 8, o1 = (size_t)rc1 * K + ks + g * 8;
-            if (add) {
+            half8 f[MT][NSTEP];
 #pragma unroll
-                for (int s = 0; s < NSTEP; ++s) { f0[s] = loadFrag<AHALF, true>(a.A, a.A2, o0 + s * 32); f1[s] = loadFrag<AHALF, true>(a.A, a.A2, o1 + s * 32); }
-            } else {
+            for (int mt = 0; mt < MT; ++mt) {
+                const size_t o = (size_t)rc[mt] * K + ks + g * 8;
+                if (add) {
 #pragma unroll
-                for (int s = 0; s < NSTEP; ++s) { f0[s] = loadFrag<AHALF, false>(a.A, nullptr, o0 + s * 32); f1[s] = loadFrag<AHALF, false>(a.A, nullptr, o1 + s * 32); }
+                    for (int s = 0; s < NSTEP; ++s) f[mt][s] = loadFrag<AHALF, true>(a.A, a.A2, o + s * 32);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < NSTEP; ++s) f[mt][s] = loadFrag<AHALF, false>(a.A, nullptr, o + s * 32);
+                }
             }
             __syncthreads();                                   // previous slab's MFMAs are done with sWh
-            for (int i = tid; i < BN * (KS / 8); i += 256) {
+            for (int i = tid; i < BN * (KS / 8); i += NTHR) {
                 const int n = i / (KS / 8), c = i % (KS / 8);
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
                 if (n0 + n < N) v = *reinterpret_cast<const uint4*>(Wh + (size_t)(n0 + n) * K + ks + c * 8);
@@ -312,22 +327,31 @@ linear_f16_kernel(LinearArgs a, const _Float16* __restrict__ Wh)
                 for (int t = 0; t < NT; ++t) {
                     if (t < ntiles) {
                         const half8 wf = *reinterpret_cast<const half8*>(pw + t * 16 * LDW + s * 32);
-                        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, f0[s], acc0[t], 0, 0, 0);
-                        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, f1[s], acc1[t], 0, 0, 0);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, f[mt][s], acc[mt][t], 0, 0, 0);
                     }
                 }
             }
         }
-        linearEpilogue(acc0, a, n0, row0, g, M, N);
-        linearEpilogue(acc1, a, n0, row1, g, M, N);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) linearEpilogue(acc[mt], a, n0, row[mt], g, M, N);
     }
 }
 
+static int g_f16_variant = -1;     // 0: <2,4>   1: <1,8>
+
 int launchLinearF16(const LinearArgs& a, const _Float16* Wh, hipStream_t stream) {
     if (a.K % KS != 0) return -3;
-    dim3 grid(cdiv(a.max_rows, BM16)), block(256);
-    if (a.a_half) hipLaunchKernelGGL(linear_f16_kernel<true>, grid, block, 0, stream, a, Wh);
-    else hipLaunchKernelGGL(linear_f16_kernel<false>, grid, block, 0, stream, a, Wh);
+    if (g_f16_variant < 0) { const char* e = getenv("DSVT_LINEAR_VARIANT"); g_f16_variant = e ? atoi(e) : 1; }
+    dim3 grid(cdiv(a.max_rows, BM16));
+    if (g_f16_variant == 0) {
+        if (a.a_half) hipLaunchKernelGGL((linear_f16_kernel<true, 2, 4>), grid, dim3(256), 0, stream, a, Wh);
+        else hipLaunchKernelGGL((linear_f16_kernel<false, 2, 4>), grid, dim3(256), 0, stream, a, Wh);
+    } else {
+        if (a.a_half) hipLaunchKernelGGL((linear_f16_kernel<true, 1, 8>), grid, dim3(512), 0, stream, a, Wh);
+        else hipLaunchKernelGGL((linear_f16_kernel<false, 1, 8>), grid, dim3(512), 0, stream, a, Wh);
+    }
     return lastError();
 }
 
