@@ -44,11 +44,13 @@ struct ConvArgs {
     int KH, KW, stride, pad, up, relu;
 };
 
-template <int KC>
-__global__ void __launch_bounds__(256, 2)
+// MT = 16-pixel MFMA tiles per wave, NW = waves per workgroup (128 pixels per workgroup either way)
+template <int KC, int MT, int NW>
+__global__ void __launch_bounds__(64 * NW, (MT == 1 ? 4 : 2))
 conv_f16_kernel(ConvArgs a)
 {
-    constexpr int KSTEPS = KC / 32, LDW = KC + 16, WPT = KC / 16;     // WPT: uint4 weight loads per thread per slab
+    constexpr int NTHR = 64 * NW;
+    constexpr int KSTEPS = KC / 32, LDW = KC + 16, WPT = (CNB * KC / 8 + NTHR - 1) / NTHR;     // WPT: uint4 weight loads per thread per slab
     __shared__ __attribute__((aligned(16))) _Float16 sW[2][CNB * LDW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -64,18 +66,18 @@ conv_f16_kernel(ConvArgs a)
     const int per_xcd = gridDim.x / 8;                    // grid.x is rounded up to a multiple of 8 by the host
     const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (tile * CPX >= npix) return;
-    int py[2], px[2]; bool pv[2];
+    int py[MT], px[MT]; bool pv[MT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        int p = tile * CPX + wave * 32 + mt * 16 + r;
+    for (int mt = 0; mt < MT; ++mt) {
+        int p = tile * CPX + wave * 16 * MT + mt * 16 + r;
         pv[mt] = p < npix;
         p = pv[mt] ? p : npix - 1;
         py[mt] = p / a.Wo; px[mt] = p % a.Wo;
     }
 
-    floatx4 acc[2][CNT];
+    floatx4 acc[MT][CNT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int t = 0; t < CNT; ++t) acc[mt][t] = floatx4{0.f, 0.f, 0.f, 0.f};
 
@@ -84,22 +86,22 @@ conv_f16_kernel(ConvArgs a)
         const _Float16* base = a.wt + (size_t)n0 * Ktot + (size_t)tap * a.Cin + cc * KC;
 #pragma unroll
         for (int j = 0; j < WPT; ++j) {
-            const int i = tid + j * 256, n = i / (KC / 8), c = i % (KC / 8);
+            const int i = tid + j * NTHR, n = i / (KC / 8), c = i % (KC / 8);
             wr[j] = n < nvalid ? *reinterpret_cast<const uint4*>(base + (size_t)n * Ktot + c * 8) : make_uint4(0u, 0u, 0u, 0u);
         }
     };
     auto storeW = [&](int buf, const uint4 (&wr)[WPT]) {
 #pragma unroll
         for (int j = 0; j < WPT; ++j) {
-            const int i = tid + j * 256, n = i / (KC / 8), c = i % (KC / 8);
-            *reinterpret_cast<uint4*>(&sW[buf][n * LDW + c * 8]) = wr[j];
+            const int i = tid + j * NTHR, n = i / (KC / 8), c = i % (KC / 8);
+            if (n < CNB) *reinterpret_cast<uint4*>(&sW[buf][n * LDW + c * 8]) = wr[j];
         }
     };
-    auto loadA = [&](int s, half8 (&af)[2][KSTEPS]) {
+    auto loadA = [&](int s, half8 (&af)[MT][KSTEPS]) {
         const int tap = s / nck, cc = s - tap * nck;
         const int ky = tap / a.KW, kx = tap - ky * a.KW;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             const int yi = py[mt] * a.stride + ky - a.pad, xi = px[mt] * a.stride + kx - a.pad;
             const bool inb = yi >= 0 && yi < a.H && xi >= 0 && xi < a.W;
             const _Float16* src = a.in + ((size_t)(inb ? yi : 0) * a.W + (inb ? xi : 0)) * a.Cin + cc * KC + g * 8;
@@ -113,7 +115,7 @@ conv_f16_kernel(ConvArgs a)
     };
 
     uint4 wr[WPT];
-    half8 cur[2][KSTEPS], nxt[2][KSTEPS];
+    half8 cur[MT][KSTEPS], nxt[MT][KSTEPS];
     loadW(0, wr);
     loadA(0, cur);
     storeW(0, wr);
@@ -129,13 +131,14 @@ conv_f16_kernel(ConvArgs a)
             for (int t = 0; t < CNT; ++t)
                 if (t < ntiles) {
                     const half8 wf = *reinterpret_cast<const half8*>(pw + t * 16 * LDW + ks * 32);
-                    acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, cur[0][ks], acc[0][t], 0, 0, 0);
-                    acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, cur[1][ks], acc[1][t], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, cur[mt][ks], acc[mt][t], 0, 0, 0);
                 }
         if (more) {
             storeW(buf ^ 1, wr);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ++ks) cur[mt][ks] = nxt[mt][ks];
         }
@@ -148,7 +151,7 @@ conv_f16_kernel(ConvArgs a)
     const int cbase = n0 - sub * a.Cout;
     const int Wout = a.Wo * a.up;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         if (!pv[mt]) continue;
         const size_t opix = (size_t)(py[mt] * a.up + dy) * Wout + (px[mt] * a.up + dx);
 #pragma unroll
@@ -189,11 +192,20 @@ conv_f16_kernel(ConvArgs a)
 }
 
 static int launchConv(const ConvArgs& a, int KC, hipStream_t stream) {
-    dim3 grid((unsigned)(cdiv(cdiv(a.Ho * a.Wo, CPX), 8) * 8), (unsigned)cdiv(a.CoutRows, CNB)), block(256);
-    if (KC == 128) hipLaunchKernelGGL(conv_f16_kernel<128>, grid, block, 0, stream, a);
-    else if (KC == 96) hipLaunchKernelGGL(conv_f16_kernel<96>, grid, block, 0, stream, a);
-    else if (KC == 64) hipLaunchKernelGGL(conv_f16_kernel<64>, grid, block, 0, stream, a);
-    else return -3;
+    dim3 grid((unsigned)(cdiv(cdiv(a.Ho * a.Wo, CPX), 8) * 8), (unsigned)cdiv(a.CoutRows, CNB));
+    static int variant = -1;       // 0: 4 waves x 32 pixels   1: 8 waves x 16 pixels (4 waves/SIMD)
+    if (variant < 0) { const char* e = getenv("DSVT_CONV_VARIANT"); variant = e ? atoi(e) : 1; }
+    if (variant == 0) {
+        if (KC == 128) hipLaunchKernelGGL((conv_f16_kernel<128, 2, 4>), grid, dim3(256), 0, stream, a);
+        else if (KC == 96) hipLaunchKernelGGL((conv_f16_kernel<96, 2, 4>), grid, dim3(256), 0, stream, a);
+        else if (KC == 64) hipLaunchKernelGGL((conv_f16_kernel<64, 2, 4>), grid, dim3(256), 0, stream, a);
+        else return -3;
+    } else {
+        if (KC == 128) hipLaunchKernelGGL((conv_f16_kernel<128, 1, 8>), grid, dim3(512), 0, stream, a);
+        else if (KC == 96) hipLaunchKernelGGL((conv_f16_kernel<96, 1, 8>), grid, dim3(512), 0, stream, a);
+        else if (KC == 64) hipLaunchKernelGGL((conv_f16_kernel<64, 1, 8>), grid, dim3(512), 0, stream, a);
+        else return -3;
+    }
     return lastError();
 }
 
