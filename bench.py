@@ -35,6 +35,7 @@ import __graft_entry__ as G  # noqa: E402
 PEAK_F32_MATRIX_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0               # same guide: "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured float4 copy)
 N_POINTS = 180000
+PMC_FILE = "r01_f_pmc_traffic.json"
 FRAME_POOL = 4                      # distinct synthetic clouds cycled through by the steps
 
 
@@ -65,7 +66,7 @@ def cpu_baseline(pkg, weights, caps, points, n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--dtype", choices=["f32", "f16"], default="f16",
@@ -75,7 +76,7 @@ def main():
                     help="frames in flight per GPU: independent pipeline instances on separate HIP streams (a single "
                          "180k-point frame leaves most kernels one wave per SIMD; overlapping two frames fills the gaps)")
     ap.add_argument("--no-graph", action="store_true", help="launch every op from the host instead of replaying a HIP graph")
-    ap.add_argument("--event-every", type=int, default=10,
+    ap.add_argument("--event-every", type=int, default=20,
                     help="every N-th timed step runs un-graphed with HIP events around each linear launch (roofline sample)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline = null)")
@@ -202,6 +203,17 @@ def main():
             roofline = dict(kernel="linear_f32_kernel (DsvtLinearPlugin, v_mfma_f32_16x16x4_f32)", bound="mfma",
                             achieved=round(tflops, 2), peak=PEAK_F32_MATRIX_TFLOPS, unit="TFLOP/s",
                             frac=round(tflops / PEAK_F32_MATRIX_TFLOPS, 4), traffic=None, hbm_gbs=round(gbs, 1))
+        # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
+        # --pmc WRITE_SIZE in separate runs of this script, corrected as MI355X_MICROARCH.md prescribes; counters
+        # cannot be read from inside the process)
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+            key = [k for k in pm if ("linear_f16_kernelILb1ELi1ELi8" in k if f16 else "linear_f32_kernel<true>" in k)]
+            if key:
+                roofline["traffic"] = round(pm[key[0]]["traffic_mb_per_launch"] * 1e6)
+                roofline["traffic_source"] = "profiles/" + PMC_FILE
+        except Exception:
+            pass
         roofline.update(launches_per_frame=per_frame, sampled_frames=sampled, avg_launch_us=round(1e3 * avg_ms, 2),
                         algorithmic_gflop_per_launch=round(tot_flops / n_launch / 1e9, 3),
                         algorithmic_mb_per_launch=round(tot_bytes / n_launch / 1e6, 2))
