@@ -1,0 +1,346 @@
+// mlp.hip -- DsvtEncoderMlpPlugin: everything a DSVT encoder layer does after the attention core,
+// in ONE launch (fp16 MFMA operands, fp32 accumulate / LayerNorm):
+//
+//     s1 = LN1(att Wo^T + bo + x)                       src/dsvt-ai-trt.cpp:448, 669-676
+//     h  = GELU(s1 W1^T + b1)                           :506, gelu.cu:208-209
+//     s2 = LN2(s1 + h W2^T + b2)                        :525, 684-690
+//     x' = LN3(s2 + x)      [ x' = LN4(x' + xb) on the 2nd layer of a block ]   :691-697, 750-756
+//
+// In the reference this is 3 FullyConnected layers, 4-5 ElementWise SUMs, 3-4 LayerNorm plugins (3 kernels
+// each) and a GELU plugin: ~20 launches and ~0.6 GB of traffic per layer.  As three DsvtLinear launches it
+// is ~180 MB; here s1 and h never leave the register file (~100 MB: att16 + x (+ xb) in, x' + x'16 out).
+//
+// How the chaining works.  Each GEMM computes the transposed tile D[n][m] (see linear.hip): afterwards lane
+// (r, g) holds, for activation row m = r, the output columns n = 16t + 4g + i (t = 0..11, i = 0..3).  The next
+// GEMM needs that row as its B operand: 8 k-values per lane and k-step.  The MFMA sums over k, so ANY bijection
+// between (lane group g, element j) and k is fine as long as the weight fragment uses the same one.  Taking
+// k-step s = tiles {2s, 2s+1}:  element j < 4 -> k = 32s + 4g + j,  j >= 4 -> k = 32s + 16 + 4g + (j-4)  makes the
+// B fragment exactly the eight fp32 values the lane already holds (converted to fp16) -- no shuffle, no LDS.
+// The host stores W1 and W2 with their k columns permuted the same way (dsvt::permuteK), so the W fragment is
+// still one contiguous ds_read_b128.
+//
+// Workgroup = 8 waves x 16 rows = 128 rows; weights stream through one 80 KB LDS buffer: first Wo, then four
+// refills of {W1 rows [96q, 96q+96), W2 columns [96q, 96q+96)}: FC1 is produced 96 columns at a time and each
+// piece is consumed at once as a 96-wide K slab of FC2 (live registers: FC2 accumulator 48 + s1 operand 24 +
+// FC1 piece 24 + h piece 12 -- under the 128 that let two workgroups share a CU).
+#include "plugin_base.h"
+#include "device_utils.h"
+
+namespace dsvt {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+constexpr int MC = 192, MF = 384;                 // d_model, FFN width (include/params.h:80-84)
+constexpr int MNT = MC / 16;                      // 12 column tiles
+constexpr int MLDW = MC + 16;                     // LDS row stride (halfs)
+constexpr int MNSTEP = MC / 32;                   // 6 k-steps per 192-wide slab
+constexpr int MROWS = 128, MWAVES = 8;
+
+struct MlpArgs {
+    const _Float16* att; const float* x; const float* xb;        // xb == nullptr: no block-residual LayerNorm
+    const _Float16* Wo; const _Float16* W1; const _Float16* W2;   // Wo natural [192][192]; W1 [384][192], W2 [192][384] k-permuted
+    const float* bo; const float* b1; const float* b2;
+    const float* ln_g; const float* ln_b;                         // [4][192]: norm1, norm2, encoder norm, block residual norm
+    float* out; _Float16* out16;
+    const uint32_t* count; int max_rows; float eps;
+};
+
+__device__ __forceinline__ float mlpGelu(float x) {
+    const float B = 0.7978845608028654f, C = 0.035677408136300125f;
+    const float u = x * (C * x * x + B);
+    return x * (1.0f - __builtin_amdgcn_rcpf(__expf(2.0f * u) + 1.0f));
+}
+__device__ __forceinline__ float rowSum4m(float v) {
+    v += __shfl_xor(v, 16, kWave); v += __shfl_xor(v, 32, kWave);
+    return v;
+}
+// LayerNorm over the 192 values of a row spread as acc[12][4] over 4 lanes
+__device__ __forceinline__ void mlpLayerNorm(floatx4 (&acc)[MNT], const float* gm, const float* bt, int g, float eps) {
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < MNT; ++t) sum += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+    const float mean = rowSum4m(sum) / MC;
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < MNT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float d = acc[t][i] - mean; sq += d * d; }
+    const float inv = 1.0f / sqrtf(rowSum4m(sq) / MC + eps);
+#pragma unroll
+    for (int t = 0; t < MNT; ++t) {
+        const float4 g4 = *reinterpret_cast<const float4*>(gm + t * 16 + 4 * g), b4 = *reinterpret_cast<const float4*>(bt + t * 16 + 4 * g);
+        acc[t][0] = (acc[t][0] - mean) * inv * g4.x + b4.x; acc[t][1] = (acc[t][1] - mean) * inv * g4.y + b4.y;
+        acc[t][2] = (acc[t][2] - mean) * inv * g4.z + b4.z; acc[t][3] = (acc[t][3] - mean) * inv * g4.w + b4.w;
+    }
+}
+// C-layout values of tiles {2s, 2s+1} -> B fragment of k-step s (see header)
+__device__ __forceinline__ void packFrags(const floatx4 (&acc)[MNT], half8 (&f)[MNSTEP]) {
+#pragma unroll
+    for (int s = 0; s < MNSTEP; ++s) {
+        half8 h;
+        h[0] = (_Float16)acc[2 * s][0]; h[1] = (_Float16)acc[2 * s][1]; h[2] = (_Float16)acc[2 * s][2]; h[3] = (_Float16)acc[2 * s][3];
+        h[4] = (_Float16)acc[2 * s + 1][0]; h[5] = (_Float16)acc[2 * s + 1][1]; h[6] = (_Float16)acc[2 * s + 1][2]; h[7] = (_Float16)acc[2 * s + 1][3];
+        f[s] = h;
+    }
+}
+
+constexpr int MQ = 96;                              // FC1 output columns / FC2 K columns handled per LDS refill
+constexpr int MQT = MQ / 16;                        // 6 tiles
+constexpr int MQS = MQ / 32;                        // 3 k-steps
+constexpr int MLDW2 = MQ + 8;                       // W2 quarter-slab row stride (2-way conflicts; 16 would not fit two workgroups per CU)
+
+__global__ void __launch_bounds__(64 * MWAVES, 4)
+encoder_mlp_f16_kernel(MlpArgs a)
+{
+    // 79,872 B: either the whole Wo [192][208], or W1 rows [96][208] followed by W2 columns [192][104]
+    __shared__ __attribute__((aligned(16))) _Float16 sW[MC * MLDW];
+    _Float16* sW1 = sW;
+    _Float16* sW2 = sW + MQ * MLDW;
+    uint32_t cnt = *a.count;
+    const int M = (int)(cnt < (uint32_t)a.max_rows ? cnt : (uint32_t)a.max_rows);
+    const int m0 = blockIdx.x * MROWS;
+    if (m0 >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int row = m0 + wave * 16 + r;
+    const bool valid = row < M;
+    const int rc = valid ? row : M - 1;
+    constexpr int NTHR = 64 * MWAVES;
+
+    // ---- GEMM 1: out-proj, natural k order (the B fragment comes from memory) ---------------------------------
+    half8 fs1[MNSTEP];
+    floatx4 acc3[MNT];
+    {
+        half8 fa[MNSTEP];
+#pragma unroll
+        for (int s = 0; s < MNSTEP; ++s) fa[s] = *reinterpret_cast<const half8*>(a.att + (size_t)rc * MC + s * 32 + g * 8);
+        for (int i = tid; i < MC * (MC / 8); i += NTHR) {
+            const int n = i / (MC / 8), c = i % (MC / 8);
+            *reinterpret_cast<uint4*>(&sW[n * MLDW + c * 8]) = *reinterpret_cast<const uint4*>(a.Wo + (size_t)n * MC + c * 8);
+        }
+        __syncthreads();
+        floatx4 acc[MNT];
+#pragma unroll
+        for (int t = 0; t < MNT; ++t) acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+        const _Float16* pw = &sW[r * MLDW + g * 8];
+#pragma unroll
+        for (int s = 0; s < MNSTEP; ++s)
+#pragma unroll
+            for (int t = 0; t < MNT; ++t) {
+                const half8 wf = *reinterpret_cast<const half8*>(pw + t * 16 * MLDW + s * 32);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, fa[s], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+        for (int t = 0; t < MNT; ++t) {                                 // + bo + x
+            const int col = t * 16 + 4 * g;
+            const float4 b = *reinterpret_cast<const float4*>(a.bo + col);
+            const float4 xv = *reinterpret_cast<const float4*>(a.x + (size_t)rc * MC + col);
+            acc[t][0] += b.x + xv.x; acc[t][1] += b.y + xv.y; acc[t][2] += b.z + xv.z; acc[t][3] += b.w + xv.w;
+        }
+        mlpLayerNorm(acc, a.ln_g, a.ln_b, g, a.eps);                      // s1
+        packFrags(acc, fs1);                                            // s1 as the FC1 operand
+#pragma unroll
+        for (int t = 0; t < MNT; ++t) {                                 // FC2 accumulator starts at s1 + b2 (LN2's residual, fp32)
+            const float4 b = *reinterpret_cast<const float4*>(a.b2 + t * 16 + 4 * g);
+            acc3[t][0] = acc[t][0] + b.x; acc3[t][1] = acc[t][1] + b.y; acc3[t][2] = acc[t][2] + b.z; acc3[t][3] = acc[t][3] + b.w;
+        }
+    }
+
+    // ---- FC1 in four 96-column pieces, each immediately consumed by FC2 as a 96-wide K slab --------------------
+#pragma unroll 1
+    for (int q = 0; q < MF / MQ; ++q) {
+        __syncthreads();                                               // previous slabs are no longer read
+        for (int i = tid; i < MQ * (MC / 8); i += NTHR) {              // W1 rows [96q, 96q+96), all 192 (permuted) k
+            const int n = i / (MC / 8), c = i % (MC / 8);
+            *reinterpret_cast<uint4*>(&sW1[n * MLDW + c * 8]) = *reinterpret_cast<const uint4*>(a.W1 + (size_t)(q * MQ + n) * MC + c * 8);
+        }
+        for (int i = tid; i < MC * (MQ / 8); i += NTHR) {              // W2 (permuted) columns [96q, 96q+96) of all 192 rows
+            const int n = i / (MQ / 8), c = i % (MQ / 8);
+            *reinterpret_cast<uint4*>(&sW2[n * MLDW2 + c * 8]) = *reinterpret_cast<const uint4*>(a.W2 + (size_t)n * MF + q * MQ + c * 8);
+        }
+        __syncthreads();
+        floatx4 acc2[MQT];
+#pragma unroll
+        for (int t = 0; t < MQT; ++t) acc2[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+        {
+            const _Float16* pw = &sW1[r * MLDW + g * 8];
+#pragma unroll
+            for (int s = 0; s < MNSTEP; ++s)
+#pragma unroll
+                for (int t = 0; t < MQT; ++t) {
+                    const half8 wf = *reinterpret_cast<const half8*>(pw + t * 16 * MLDW + s * 32);
+                    acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, fs1[s], acc2[t], 0, 0, 0);
+                }
+        }
+        half8 fh[MQS];
+#pragma unroll
+        for (int sp = 0; sp < MQS; ++sp) {
+            const float4 b0 = *reinterpret_cast<const float4*>(a.b1 + q * MQ + (2 * sp) * 16 + 4 * g);
+            const float4 b1v = *reinterpret_cast<const float4*>(a.b1 + q * MQ + (2 * sp + 1) * 16 + 4 * g);
+            half8 h;
+            h[0] = (_Float16)mlpGelu(acc2[2 * sp][0] + b0.x); h[1] = (_Float16)mlpGelu(acc2[2 * sp][1] + b0.y);
+            h[2] = (_Float16)mlpGelu(acc2[2 * sp][2] + b0.z); h[3] = (_Float16)mlpGelu(acc2[2 * sp][3] + b0.w);
+            h[4] = (_Float16)mlpGelu(acc2[2 * sp + 1][0] + b1v.x); h[5] = (_Float16)mlpGelu(acc2[2 * sp + 1][1] + b1v.y);
+            h[6] = (_Float16)mlpGelu(acc2[2 * sp + 1][2] + b1v.z); h[7] = (_Float16)mlpGelu(acc2[2 * sp + 1][3] + b1v.w);
+            fh[sp] = h;
+        }
+        {
+            const _Float16* pw = &sW2[r * MLDW2 + g * 8];
+#pragma unroll
+            for (int sp = 0; sp < MQS; ++sp)
+#pragma unroll
+                for (int t = 0; t < MNT; ++t) {
+                    const half8 wf = *reinterpret_cast<const half8*>(pw + t * 16 * MLDW2 + sp * 32);
+                    acc3[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, fh[sp], acc3[t], 0, 0, 0);
+                }
+        }
+    }
+    // ---- s2 = LN2(s1 + f + b2) (already summed); x' = LN3(s2 + x); [x' = LN4(x' + xb)] ----------------------
+    mlpLayerNorm(acc3, a.ln_g + MC, a.ln_b + MC, g, a.eps);
+#pragma unroll
+    for (int t = 0; t < MNT; ++t) {
+        const float4 xv = *reinterpret_cast<const float4*>(a.x + (size_t)rc * MC + t * 16 + 4 * g);
+        acc3[t][0] += xv.x; acc3[t][1] += xv.y; acc3[t][2] += xv.z; acc3[t][3] += xv.w;
+    }
+    mlpLayerNorm(acc3, a.ln_g + 2 * MC, a.ln_b + 2 * MC, g, a.eps);
+    if (a.xb) {
+#pragma unroll
+        for (int t = 0; t < MNT; ++t) {
+            const float4 xv = *reinterpret_cast<const float4*>(a.xb + (size_t)rc * MC + t * 16 + 4 * g);
+            acc3[t][0] += xv.x; acc3[t][1] += xv.y; acc3[t][2] += xv.z; acc3[t][3] += xv.w;
+        }
+        mlpLayerNorm(acc3, a.ln_g + 3 * MC, a.ln_b + 3 * MC, g, a.eps);
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int t = 0; t < MNT; ++t) {
+        const int col = t * 16 + 4 * g;
+        *reinterpret_cast<float4*>(a.out + (size_t)row * MC + col) = make_float4(acc3[t][0], acc3[t][1], acc3[t][2], acc3[t][3]);
+        half4 h; h[0] = (_Float16)acc3[t][0]; h[1] = (_Float16)acc3[t][1]; h[2] = (_Float16)acc3[t][2]; h[3] = (_Float16)acc3[t][3];
+        *reinterpret_cast<half4*>(a.out16 + (size_t)row * MC + col) = h;
+    }
+}
+
+// position p = 32s + 8g + j of a permuted weight row holds the column k(p) the chained B fragment carries there
+static inline int permuteK(int p) {
+    const int s = p / 32, q = p % 32, g = q / 8, j = q % 8;
+    return 32 * s + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
+}
+
+class DsvtEncoderMlpPlugin : public Plugin {
+public:
+    int max_rows_, has_block_ln_; float eps_;
+    std::vector<float> wo_, w1_, w2_, bo_, b1_, b2_, lg_, lb_;     // as given (natural order)
+    _Float16 *wo_dev_ = nullptr, *w1_dev_ = nullptr, *w2_dev_ = nullptr;
+    float *bo_dev_ = nullptr, *b1_dev_ = nullptr, *b2_dev_ = nullptr, *lg_dev_ = nullptr, *lb_dev_ = nullptr;
+    bool ok_ = false;
+    DsvtEncoderMlpPlugin(int max_rows, int has_block_ln, float eps, const float* wo, const float* w1, const float* w2,
+                         const float* bo, const float* b1, const float* b2, const float* lg, const float* lb)
+        : max_rows_(max_rows), has_block_ln_(has_block_ln), eps_(eps), wo_(wo, wo + MC * MC), w1_(w1, w1 + MF * MC),
+          w2_(w2, w2 + MC * MF), bo_(bo, bo + MC), b1_(b1, b1 + MF), b2_(b2, b2 + MC),
+          lg_(lg, lg + (3 + has_block_ln) * MC), lb_(lb, lb + (3 + has_block_ln) * MC) {
+        lg_.resize(4 * MC, 1.f); lb_.resize(4 * MC, 0.f);
+        std::vector<_Float16> h(MF * MC);
+        auto upH = [&](const std::vector<float>& src, int rows, int K, bool perm, _Float16** d) {
+            for (int n = 0; n < rows; ++n)
+                for (int p = 0; p < K; ++p) h[(size_t)n * K + p] = (_Float16)src[(size_t)n * K + (perm ? permuteK(p) : p)];
+            return hipMalloc(d, sizeof(_Float16) * rows * K) == hipSuccess &&
+                   hipMemcpy(*d, h.data(), sizeof(_Float16) * rows * K, hipMemcpyHostToDevice) == hipSuccess;
+        };
+        auto upF = [](const std::vector<float>& src, float** d) {
+            return hipMalloc(d, sizeof(float) * src.size()) == hipSuccess &&
+                   hipMemcpy(*d, src.data(), sizeof(float) * src.size(), hipMemcpyHostToDevice) == hipSuccess;
+        };
+        ok_ = upH(wo_, MC, MC, false, &wo_dev_) && upH(w1_, MF, MC, true, &w1_dev_) && upH(w2_, MC, MF, true, &w2_dev_) &&
+              upF(bo_, &bo_dev_) && upF(b1_, &b1_dev_) && upF(b2_, &b2_dev_) && upF(lg_, &lg_dev_) && upF(lb_, &lb_dev_);
+    }
+    ~DsvtEncoderMlpPlugin() override {
+        for (void* p : {(void*)wo_dev_, (void*)w1_dev_, (void*)w2_dev_, (void*)bo_dev_, (void*)b1_dev_, (void*)b2_dev_, (void*)lg_dev_, (void*)lb_dev_})
+            if (p) (void)hipFree(p);
+    }
+    const char* type() const override { return "DsvtEncoderMlpPlugin"; }
+    int nbOutputs() const override { return 2; }
+    int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
+        if (i < 0 || i > 1) return -1;
+        *out = dims3(in[0].d[0], max_rows_, MC); return 0;
+    }
+    int outputType(int i, const int32_t*, int) const override { return i == 0 ? DSVT_FLOAT : DSVT_HALF; }
+    bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int nbIn, int) const override {
+        if (io[pos].format != DSVT_FORMAT_LINEAR) return false;
+        if (pos == 0) return io[pos].type == DSVT_HALF;
+        if (pos == 1) return io[pos].type == DSVT_INT32;
+        if (pos < nbIn) return io[pos].type == DSVT_FLOAT;
+        return io[pos].type == (pos == nbIn ? DSVT_FLOAT : DSVT_HALF);
+    }
+    size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override { return 0; }
+    // inputs: att16 [1,P,192] half, count [1], x [1,P,192] f32 (, xb [1,P,192] f32)   outputs: x' f32, x' f16
+    int enqueue(const DsvtPluginTensorDesc*, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void*,
+                hipStream_t stream) override {
+        if (!ok_) return static_cast<int>(hipErrorOutOfMemory);
+        MlpArgs a{};
+        a.att = static_cast<const _Float16*>(in[0]); a.count = static_cast<const uint32_t*>(in[1]);
+        a.x = static_cast<const float*>(in[2]); a.xb = has_block_ln_ ? static_cast<const float*>(in[3]) : nullptr;
+        a.Wo = wo_dev_; a.W1 = w1_dev_; a.W2 = w2_dev_; a.bo = bo_dev_; a.b1 = b1_dev_; a.b2 = b2_dev_;
+        a.ln_g = lg_dev_; a.ln_b = lb_dev_; a.out = static_cast<float*>(out[0]); a.out16 = static_cast<_Float16*>(out[1]);
+        a.max_rows = max_rows_; a.eps = eps_;
+        if (zeroFill) {
+            DSVT_CHECK(hipMemsetAsync(out[0], 0, sizeof(float) * (size_t)max_rows_ * MC, stream));
+            DSVT_CHECK(hipMemsetAsync(out[1], 0, sizeof(_Float16) * (size_t)max_rows_ * MC, stream));
+        }
+        hipLaunchKernelGGL(encoder_mlp_f16_kernel, dim3(cdiv(max_rows_, MROWS)), dim3(64 * MWAVES), 0, stream, a);
+        return lastError();
+    }
+    size_t nFloats() const { return wo_.size() + w1_.size() + w2_.size() + bo_.size() + b1_.size() + b2_.size() + 2 * (size_t)(3 + has_block_ln_) * MC; }
+    size_t serializationSize() const override { return 2 * sizeof(int) + sizeof(float) + sizeof(float) * nFloats(); }
+    void serialize(void* buf) const override {
+        char* d = static_cast<char*>(buf);
+        wr<int>(d, max_rows_); wr<int>(d, has_block_ln_); wr<float>(d, eps_);
+        auto put = [&](const std::vector<float>& v, size_t n) { memcpy(d, v.data(), sizeof(float) * n); d += sizeof(float) * n; };
+        put(wo_, wo_.size()); put(w1_, w1_.size()); put(w2_, w2_.size()); put(bo_, bo_.size()); put(b1_, b1_.size()); put(b2_, b2_.size());
+        put(lg_, (size_t)(3 + has_block_ln_) * MC); put(lb_, (size_t)(3 + has_block_ln_) * MC);
+    }
+    Plugin* clone() const override {
+        return new DsvtEncoderMlpPlugin(max_rows_, has_block_ln_, eps_, wo_.data(), w1_.data(), w2_.data(), bo_.data(), b1_.data(), b2_.data(),
+                                        lg_.data(), lb_.data());
+    }
+};
+
+static Plugin* mlpCreate(const DsvtPluginFieldCollection* fc) {
+    int max_rows = fieldInt(fc, "max_rows"), hb = fieldInt(fc, "has_block_norm");
+    if (max_rows <= 0 || hb < 0 || hb > 1) return nullptr;
+    struct Need { const char* name; int len; } need[] = {
+        {"out_proj_weight", MC * MC}, {"linear1_weight", MF * MC}, {"linear2_weight", MC * MF}, {"out_proj_bias", MC},
+        {"linear1_bias", MF}, {"linear2_bias", MC}, {"ln_weights", (3 + hb) * MC}, {"ln_bias", (3 + hb) * MC}};
+    const float* p[8];
+    for (int i = 0; i < 8; ++i) {
+        const DsvtPluginField* f = findField(fc, need[i].name);
+        if (!f || !f->data || f->length != need[i].len) return nullptr;
+        p[i] = static_cast<const float*>(f->data);
+    }
+    return new DsvtEncoderMlpPlugin(max_rows, hb, fieldFloat(fc, "ln_eps", 0.f), p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
+}
+static Plugin* mlpDeser(const void* data, size_t len) {
+    if (len < 2 * sizeof(int) + sizeof(float)) return nullptr;
+    const char* d = static_cast<const char*>(data);
+    int max_rows = rd<int>(d), hb = rd<int>(d); float eps = rd<float>(d);
+    if (max_rows <= 0 || hb < 0 || hb > 1) return nullptr;
+    size_t n = (size_t)MC * MC + 2 * (size_t)MF * MC + MC + MF + MC + 2 * (size_t)(3 + hb) * MC;
+    if (len < 2 * sizeof(int) + sizeof(float) + n * sizeof(float)) return nullptr;
+    std::vector<float> all(n); memcpy(all.data(), d, n * sizeof(float));
+    const float* q = all.data();
+    const float* wo = q; q += MC * MC; const float* w1 = q; q += MF * MC; const float* w2 = q; q += MC * MF;
+    const float* bo = q; q += MC; const float* b1 = q; q += MF; const float* b2 = q; q += MC;
+    const float* lg = q; q += (3 + hb) * MC; const float* lb = q;
+    return new DsvtEncoderMlpPlugin(max_rows, hb, eps, wo, w1, w2, bo, b1, b2, lg, lb);
+}
+static Creator g_mlpCreator{"DsvtEncoderMlpPlugin",
+    {{"max_rows", DSVT_FIELD_INT32}, {"has_block_norm", DSVT_FIELD_INT32}, {"ln_eps", DSVT_FIELD_FLOAT32},
+     {"out_proj_weight", DSVT_FIELD_FLOAT32}, {"out_proj_bias", DSVT_FIELD_FLOAT32}, {"linear1_weight", DSVT_FIELD_FLOAT32},
+     {"linear1_bias", DSVT_FIELD_FLOAT32}, {"linear2_weight", DSVT_FIELD_FLOAT32}, {"linear2_bias", DSVT_FIELD_FLOAT32},
+     {"ln_weights", DSVT_FIELD_FLOAT32}, {"ln_bias", DSVT_FIELD_FLOAT32}},
+    mlpCreate, mlpDeser, {}, {}};
+static Registrar g_mlpReg(&g_mlpCreator);
+
+}  // namespace dsvt

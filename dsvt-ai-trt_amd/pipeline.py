@@ -65,7 +65,7 @@ def fold_linear_bn(w, lin, bn, eps, bias=False):
 
 class DsvtPipeline:
     def __init__(self, weights, caps=None, blocks=4, with_head=True, ln_eps=0.0, head_dtype=torch.float32,
-                 device="cuda:0", zero_fill=False, linear_compute=P.COMPUTE_F32, hip_head=None):
+                 device="cuda:0", zero_fill=False, linear_compute=P.COMPUTE_F32, hip_head=None, fused_mlp=None):
         """linear_compute: COMPUTE_F32 = fp32 MFMA everywhere (parity mode, boxes within 1e-3 of the
         fp32 oracle); COMPUTE_F16 = fp16 MFMA operands with fp32 accumulate/epilogues (BASELINE
         configs[2] "fp16").  head_dtype: precision of the dense BEV stage.  hip_head: run the BEV ResNet +
@@ -78,6 +78,7 @@ class DsvtPipeline:
         zf = lambda op: op.set_zero_fill(zero_fill)
         ct = dict(compute_type=linear_compute)
         self.f16 = f16 = linear_compute == P.COMPUTE_F16
+        self.fused_mlp = f16 if fused_mlp is None else (fused_mlp and f16)      # out-proj -> FC1 -> FC2 in one launch (csrc/mlp.hip)
         # fp16 mode: GEMM operands travel as fp16 (x16, pos16, qkv, att, h); the residual stream that feeds the
         # LayerNorms stays fp32 (the LayerNorm epilogues write both copies)
         h_in = dict(input_half=True) if f16 else {}
@@ -112,6 +113,15 @@ class DsvtPipeline:
                 if l == 1:                                # block residual LayerNorm (:750-756)
                     lns2.append((w[f"module.backbone_3d.residual_norm_stage_0.{b}.weight"],
                                  w[f"module.backbone_3d.residual_norm_stage_0.{b}.bias"]))
+                if self.fused_mlp:
+                    self.layers[(b, l)] = dict(
+                        qkv=zf(P.add_linear_op(wi, bi, c.P, add_cols=2 * C, **ct, **h_in, **o16)),
+                        attn=zf(P.add_set_attention_op(c.W, L_SET, C, H, l, c.P, io_half=f16)),
+                        mlp=zf(P.add_encoder_mlp_op(w[lp + ".win_attn.self_attn.out_proj.weight"], w[lp + ".win_attn.self_attn.out_proj.bias"],
+                                                    w[lp + ".win_attn.linear1.weight"], w[lp + ".win_attn.linear1.bias"],
+                                                    w[lp + ".win_attn.linear2.weight"], w[lp + ".win_attn.linear2.bias"],
+                                                    [ln(".win_attn.norm1")] + lns2, c.P, ln_eps=ln_eps)))
+                    continue
                 self.layers[(b, l)] = dict(
                     qkv=zf(P.add_linear_op(wi, bi, c.P, add_cols=2 * C, **ct, **h_in, **o16)),
                     attn=zf(P.add_set_attention_op(c.W, L_SET, C, H, l, c.P, io_half=f16)),
@@ -301,6 +311,11 @@ class DsvtPipeline:
                 L = self.layers[(b, l)]
                 qkv = L["qkv"](xh, Pn, pos)[0]
                 att = L["attn"](qkv, inds, mask, S)[0]
+                if self.fused_mlp:
+                    x, xh = L["mlp"](att, Pn, x, xb) if l == 1 else L["mlp"](att, Pn, x)
+                    if trace is not None:
+                        trace[(b, l)] = x.clone()
+                    continue
                 o = L["out"](att, Pn, x)
                 s1, s1h = o[0], o[-1]
                 h = L["fc1"](s1h, Pn)[0]

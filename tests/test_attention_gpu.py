@@ -144,3 +144,45 @@ def test_linear_f16_mfma(pkg, oracle, K, N, act, nln):
         e16 = host(P.add_linear_op(Wh, b, MR, compute_type=P.COMPUTE_F16, **kw)(dev(Ah[None]), scalar(n), *extra)[0])[0]
         e32 = host(P.add_linear_op(Wh, b, MR, compute_type=P.COMPUTE_F32, **kw)(dev(Ah[None]), scalar(n), *extra)[0])[0]
         assert np.abs(e16[:n] - e32[:n]).max() < 2e-5 * scale
+
+
+@pytest.mark.parametrize("block_ln", [False, True])
+def test_fused_encoder_mlp_equals_linear_chain(pkg, block_ln):
+    """DsvtEncoderMlpPlugin (one launch, activations chained through registers with a permuted-k operand
+    layout) against the same maths as three DsvtLinear launches in fp16 mode."""
+    P = pkg.plugin
+    rng = np.random.default_rng(11 + block_ln)
+    MR, n, C = 8192, 5504, 192
+    w = pkg.synth.make_weights(with_bev=False)
+    lp = "module.backbone_3d.stage_0.2.encoder_list.1"
+    ln = lambda k: (w[lp + k + ".weight"], w[lp + k + ".bias"])
+    lns = [ln(".win_attn.norm1"), ln(".win_attn.norm2"), ln(".norm")]
+    if block_ln:
+        lns.append((w["module.backbone_3d.residual_norm_stage_0.2.weight"], w["module.backbone_3d.residual_norm_stage_0.2.bias"]))
+    att = np.zeros((MR, C), np.float32); att[:n] = rng.standard_normal((n, C))
+    x = np.zeros((MR, C), np.float32); x[:n] = rng.standard_normal((n, C))
+    xb = np.zeros((MR, C), np.float32); xb[:n] = rng.standard_normal((n, C))
+    att_h = dev(att[None]).half(); cnt = scalar(n)
+    f16 = dict(compute_type=P.COMPUTE_F16, input_half=True)
+    out = P.add_linear_op(w[lp + ".win_attn.self_attn.out_proj.weight"], w[lp + ".win_attn.self_attn.out_proj.bias"], MR,
+                          layer_norms=lns[:1], output_mode=P.OUT_BOTH, **f16)
+    fc1 = P.add_linear_op(w[lp + ".win_attn.linear1.weight"], w[lp + ".win_attn.linear1.bias"], MR, activation=P.ACT_GELU,
+                          output_mode=P.OUT_F16, **f16)
+    fc2 = P.add_linear_op(w[lp + ".win_attn.linear2.weight"], w[lp + ".win_attn.linear2.bias"], MR, layer_norms=lns[1:],
+                          output_mode=P.OUT_BOTH, **f16)
+    s1, s1h = out(att_h, cnt, dev(x[None]))
+    h = fc1(s1h, cnt)[0]
+    res = [s1, dev(x[None])] + ([dev(xb[None])] if block_ln else [])
+    ref, ref_h = fc2(h, cnt, *res)
+    mlp = P.add_encoder_mlp_op(w[lp + ".win_attn.self_attn.out_proj.weight"], w[lp + ".win_attn.self_attn.out_proj.bias"],
+                               w[lp + ".win_attn.linear1.weight"], w[lp + ".win_attn.linear1.bias"],
+                               w[lp + ".win_attn.linear2.weight"], w[lp + ".win_attn.linear2.bias"], lns, MR)
+    args = [att_h, cnt, dev(x[None])] + ([dev(xb[None])] if block_ln else [])
+    got, got_h = mlp(*args)
+    torch.cuda.synchronize()
+    g, r_ = host(got)[0], host(ref)[0]
+    # same fp16 roundings of the operands; differences: summation order and the chain keeps s1 (LN2's residual) in fp32
+    assert np.abs(g[:n] - r_[:n]).max() < 3e-3
+    assert np.abs(g[:n] - r_[:n]).mean() < 2e-4
+    assert not g[n:].any()
+    assert np.abs(got_h[0, :n].float().cpu().numpy() - g[:n]).max() < 4e-3       # fp16 copy of the same result
