@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 import __graft_entry__ as G  # noqa: E402
 
 PEAK_F32_MATRIX_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_F16_MATRIX_TFLOPS = 2500.0     # same guide: "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBS = 8000.0               # same guide: "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured float4 copy)
 N_POINTS = 180000
 PMC_FILE = "r01_f_pmc_traffic.json"
@@ -144,7 +145,8 @@ def main():
         counts.append(dict(P=int(st["P"][0]), Nk=int(st["Nk"][0]), S=[int(g[2][0]) for g in st["gss"]]))
     torch.cuda.synchronize()
 
-    prof = None if args.no_kernel_events else {"DsvtLinearPlugin": []}
+    prof = None if args.no_kernel_events else {"DsvtLinearPlugin": [], "DsvtEncoderMlpPlugin": [], "DsvtSetAttentionPlugin": [],
+                                               "DsvtConv2dPlugin": []}
     marks = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     par.barrier(); torch.cuda.synchronize()
     sampled = 0
@@ -173,50 +175,78 @@ def main():
     dt = par.max_over_ranks(dt, dev)
 
     frame_ms = np.array([marks[i][0].elapsed_time(marks[i][1]) for i in range(K)])
-    roofline = None
-    if prof is not None and prof["DsvtLinearPlugin"]:
-        per_frame = len(prof["DsvtLinearPlugin"]) // max(sampled, 1)
-        tot_ms, tot_flops, tot_bytes = 0.0, 0.0, 0.0
-        for j, (e0, e1, pl) in enumerate(prof["DsvtLinearPlugin"]):
-            c = counts[(j // per_frame) % len(pool)]
-            f = pl.fields
-            rows = c[pl.rows_kind]          # "Nk" for the two PFN linears, "P" for everything on voxel rows
-            K_, N_ = f["in_features"], f["out_features"]
-            tot_ms += e0.elapsed_time(e1)
-            tot_flops += 2.0 * rows * K_ * N_
-            # algorithmic HBM bytes: operand rows (+ the added pos rows), one fp32 residual row per LayerNorm
-            # stage, the output row(s), and the weights once
-            esz = 2 if f.get("input_half") else 4
-            out_b = {0: 4, 1: 2, 2: 6}[f.get("output_mode", 0)]
-            tot_bytes += rows * (K_ * esz * (2 if f.get("add_cols") else 1) + 4 * N_ * f.get("num_layer_norms", 0) + out_b * N_) \
-                + K_ * N_ * (2 if f16 else 4)
-        n_launch = len(prof["DsvtLinearPlugin"])
-        avg_ms = tot_ms / n_launch
-        tflops = tot_flops / n_launch / (avg_ms * 1e-3) / 1e12
-        gbs = tot_bytes / n_launch / (avg_ms * 1e-3) / 1e9
-        if f16:
-            # fp16 operands: 2.5 PF of MFMA against ~100 MB per launch -- the kernel is HBM/latency bound
-            roofline = dict(kernel="linear_f16_kernel (DsvtLinearPlugin, v_mfma_f32_16x16x32_f16)", bound="hbm",
-                            achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
-                            traffic=None, mfma_tflops=round(tflops, 2))
-        else:
-            roofline = dict(kernel="linear_f32_kernel (DsvtLinearPlugin, v_mfma_f32_16x16x4_f32)", bound="mfma",
-                            achieved=round(tflops, 2), peak=PEAK_F32_MATRIX_TFLOPS, unit="TFLOP/s",
-                            frac=round(tflops / PEAK_F32_MATRIX_TFLOPS, 4), traffic=None, hbm_gbs=round(gbs, 1))
-        # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
-        # --pmc WRITE_SIZE in separate runs of this script, corrected as MI355X_MICROARCH.md prescribes; counters
-        # cannot be read from inside the process)
+    roofline, roofline_all = None, []
+    if prof is not None and sampled:
+        pm = {}
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
-            key = [k for k in pm if ("linear_f16_kernelILb1ELi1ELi8" in k if f16 else "linear_f32_kernel<true>" in k)]
-            if key:
-                roofline["traffic"] = round(pm[key[0]]["traffic_mb_per_launch"] * 1e6)
-                roofline["traffic_source"] = "profiles/" + PMC_FILE
         except Exception:
             pass
-        roofline.update(launches_per_frame=per_frame, sampled_frames=sampled, avg_launch_us=round(1e3 * avg_ms, 2),
-                        algorithmic_gflop_per_launch=round(tot_flops / n_launch / 1e9, 3),
-                        algorithmic_mb_per_launch=round(tot_bytes / n_launch / 1e6, 2))
+
+        def pmc_traffic(substr):
+            ks = [k for k in pm if substr in k]
+            return round(pm[ks[0]]["traffic_mb_per_launch"] * 1e6) if ks else None
+
+        def work(pl, c):
+            """(flops, algorithmic HBM bytes) of one launch of plugin `pl` on a frame with counts c"""
+            f = pl.fields
+            if pl.plugin_type == "DsvtLinearPlugin":
+                rows = c[pl.rows_kind]          # "Nk" for the two PFN linears, "P" for everything on voxel rows
+                K_, N_ = f["in_features"], f["out_features"]
+                esz = 2 if f.get("input_half") else 4
+                out_b = {0: 4, 1: 2, 2: 6}[f.get("output_mode", 0)]
+                return (2.0 * rows * K_ * N_,
+                        rows * (K_ * esz * (2 if f.get("add_cols") else 1) + 4 * N_ * f.get("num_layer_norms", 0) + out_b * N_)
+                        + K_ * N_ * (2 if f16 else 4))
+            if pl.plugin_type == "DsvtEncoderMlpPlugin":
+                rows = c["P"]                   # att16 + x (+ xb) in, x' fp32 + fp16 out, weights once
+                return (2.0 * rows * (192 * 192 + 2 * 192 * 384),
+                        rows * 192 * (2 + 4 + 4 * f.get("has_block_norm", 0) + 4 + 2) + 2 * (192 * 192 + 2 * 192 * 384))
+            if pl.plugin_type == "DsvtSetAttentionPlugin":
+                S = c["S"][0 if pl.win == 0 else 1]
+                esz = 2 if f.get("io_half") else 4
+                return (4.0 * 36 * 36 * 192 * S, S * 36 * 192 * esz * 3 + c["P"] * 192 * esz)
+            if pl.plugin_type == "DsvtConv2dPlugin":
+                Ho = (f["in_height"] + 2 * f["padding"] - f["kernel_size"]) // f["stride"] + 1
+                up = f.get("pixel_shuffle", 1)
+                taps = f["kernel_size"] ** 2
+                return (2.0 * Ho * Ho * up * up * f["out_channels"] * taps * f["in_channels"],
+                        2 * f["in_height"] ** 2 * f["in_channels"] + (4 if f.get("out_f32") else 2) * Ho * Ho * up * up * f["out_channels"]
+                        + 2 * up * up * f["out_channels"] * taps * f["in_channels"])
+            return (0.0, 0.0)
+
+        meta = {"DsvtLinearPlugin": ("linear_f16_kernel (v_mfma_f32_16x16x32_f16)" if f16 else "linear_f32_kernel (v_mfma_f32_16x16x4_f32)",
+                                     "hbm" if f16 else "mfma", "linear_f16_kernelILb1ELi1ELi8" if f16 else "linear_f32_kernel<true>"),
+                "DsvtEncoderMlpPlugin": ("encoder_mlp_f16_kernel (out-proj+LN -> FC1+GELU -> FC2+LN+LN, v_mfma_f32_16x16x32_f16)", "hbm", "encoder_mlp_f16_kernel"),
+                "DsvtSetAttentionPlugin": ("set_attention_kernel (v_mfma_f32_16x16x4_f32)", "hbm", "set_attention_kernel"),
+                "DsvtConv2dPlugin": ("conv_f16_kernel (implicit GEMM, v_mfma_f32_16x16x32_f16)", "mfma", "conv_f16_kernel<64")}
+        for ptype, lst in prof.items():
+            if not lst:
+                continue
+            per_frame = len(lst) // sampled
+            tot_ms = tot_fl = tot_by = 0.0
+            for j, (e0, e1, pl) in enumerate(lst):
+                fl, by = work(pl, counts[(j // per_frame) % len(pool)])
+                tot_ms += e0.elapsed_time(e1); tot_fl += fl; tot_by += by
+            n_l = len(lst)
+            avg_ms = tot_ms / n_l
+            tfl, gbs = tot_fl / n_l / (avg_ms * 1e-3) / 1e12, tot_by / n_l / (avg_ms * 1e-3) / 1e9
+            kname, bound, pmk = meta[ptype]
+            peak_tf = (PEAK_F32_MATRIX_TFLOPS if (ptype == "DsvtSetAttentionPlugin" or not f16) else PEAK_F16_MATRIX_TFLOPS)
+            r = dict(kernel=kname, bound=bound)
+            if bound == "hbm":
+                r.update(achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4), mfma_tflops=round(tfl, 2))
+            else:
+                r.update(achieved=round(tfl, 2), peak=peak_tf, unit="TFLOP/s", frac=round(tfl / peak_tf, 4), hbm_gbs=round(gbs, 1))
+            r.update(traffic=pmc_traffic(pmk), launches_per_frame=per_frame, sampled_frames=sampled, avg_launch_us=round(1e3 * avg_ms, 2),
+                     ms_per_frame=round(tot_ms / sampled, 3), algorithmic_gflop_per_launch=round(tot_fl / n_l / 1e9, 3),
+                     algorithmic_mb_per_launch=round(tot_by / n_l / 1e6, 2))
+            if r["traffic"] is not None:
+                r["traffic_source"] = "profiles/" + PMC_FILE
+            roofline_all.append((ptype, r))
+        # the headline roofline object = the hot path's (SURVEY 8a) kernel with the largest share of the frame
+        hot = [x for x in roofline_all if x[0] != "DsvtConv2dPlugin"] or roofline_all
+        roofline = max(hot, key=lambda x: x[1]["ms_per_frame"])[1]
 
     if rank == 0:
         total_frames = K * world
@@ -236,6 +266,7 @@ def main():
                        "caps": dict(points=caps.N, pillars=caps.P, windows_sets=caps.W),
                        "frame0": counts[0]},
             "roofline": roofline,
+            "roofline_other_kernels": [r for _, r in roofline_all if r is not roofline],
         }
         if not args.no_cpu_baseline and world == 1:
             p0 = pool[0][0][0].cpu().numpy()

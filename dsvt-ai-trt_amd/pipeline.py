@@ -114,13 +114,14 @@ class DsvtPipeline:
                     lns2.append((w[f"module.backbone_3d.residual_norm_stage_0.{b}.weight"],
                                  w[f"module.backbone_3d.residual_norm_stage_0.{b}.bias"]))
                 if self.fused_mlp:
-                    self.layers[(b, l)] = dict(
+                    self.layers[(b, l)] = L_ = dict(
                         qkv=zf(P.add_linear_op(wi, bi, c.P, add_cols=2 * C, **ct, **h_in, **o16)),
                         attn=zf(P.add_set_attention_op(c.W, L_SET, C, H, l, c.P, io_half=f16)),
                         mlp=zf(P.add_encoder_mlp_op(w[lp + ".win_attn.self_attn.out_proj.weight"], w[lp + ".win_attn.self_attn.out_proj.bias"],
                                                     w[lp + ".win_attn.linear1.weight"], w[lp + ".win_attn.linear1.bias"],
                                                     w[lp + ".win_attn.linear2.weight"], w[lp + ".win_attn.linear2.bias"],
                                                     [ln(".win_attn.norm1")] + lns2, c.P, ln_eps=ln_eps)))
+                    L_["attn"].win = b % 2
                     continue
                 self.layers[(b, l)] = dict(
                     qkv=zf(P.add_linear_op(wi, bi, c.P, add_cols=2 * C, **ct, **h_in, **o16)),
@@ -132,6 +133,7 @@ class DsvtPipeline:
                                            activation=P.ACT_GELU, **ct, **h_in, **o16)),
                     fc2=zf(P.add_linear_op(w[lp + ".win_attn.linear2.weight"], w[lp + ".win_attn.linear2.bias"], c.P,
                                            layer_norms=lns2, ln_eps=ln_eps, **ct, **h_in, **oboth)))
+                self.layers[(b, l)]["attn"].win = b % 2
         self.cat = torch.zeros((1, c.Nk, 192), dtype=torch.float32, device=self.device)
         if with_head:
             self.map2bev = P.add_map_2_bev_op(c.P, C, GX, GY)
