@@ -83,10 +83,15 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline = null)")
     args = ap.parse_args()
 
-    G.build()
+    # one rank builds (the in-tree .so normally travels with the snapshot and this is a no-op); the others wait
+    rank0 = int(os.environ.get("RANK", "0")) == 0
+    if rank0:
+        G.build()
+    par = G._load_file("dsvt_parallel_boot", os.path.join(G.PKG_DIR, "parallel.py"))
+    rank, local_rank, world = par.init()
+    par.barrier()
     pkg = G.load_package()
     par = pkg.parallel
-    rank, local_rank, world = par.init()
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")

@@ -1,0 +1,67 @@
+"""BASELINE configs[0] plumbing on CPU: the reference's host path -- loadData (include/helper.h:28-72),
+save_result + nms_cpu (helper.h:257-283, 470-481) -- as restated in the oracle.  Size-independent properties
+stand in for golden outputs (the reference ships none: data/outputs/ is not in the tree)."""
+import numpy as np
+import pytest
+
+from tests import cases
+
+
+def _boxes(rng, n):
+    b = np.zeros((n, 9), np.float32)
+    b[:, 0:2] = rng.uniform(-40, 40, (n, 2)); b[:, 2] = rng.uniform(-2, 1, n)
+    b[:, 3:6] = rng.uniform(0.5, 5.0, (n, 3)); b[:, 6] = rng.uniform(-1.5, 1.5, n)
+    b[:, 7] = rng.integers(0, 10, n); b[:, 8] = rng.uniform(0.3, 1.0, n)
+    return b
+
+
+def test_load_data_zero_pads_and_counts(oracle):
+    raw = open(f"{cases.GOLDEN}/000000.bin", "rb").read()
+    pts, n = oracle.load_data(raw, 50000)
+    assert n == 34537 == len(raw) // 16 and pts.shape == (50000, 4)
+    assert np.array_equal(pts[:n].tobytes(), raw) and not pts[n:].any()
+    with pytest.raises(ValueError):
+        oracle.load_data(raw, 1000)                 # reference prints and exit(-1)s (helper.h:47-53)
+
+
+def test_box_overlap_known_cases(oracle):
+    a = np.array([0, 0, 0, 2, 4, 1, 0, 0, 0.9], np.float32)      # dim0 -> l = 2, dim1 -> w = 4 (helper.h:472-476): w along x
+    assert abs(oracle.box_overlap(a, a) - 8.0) < 1e-4            # identical boxes: full area w*l
+    b = a.copy(); b[0] = 2.0                                      # shifted by half the x extent (w = 4)
+    assert abs(oracle.box_overlap(a, b) - 4.0) < 1e-3
+    c = a.copy(); c[0] = 10.0
+    assert oracle.box_overlap(a, c) == 0.0                        # disjoint
+    d = a.copy(); d[6] = np.pi / 2                                # rotated by 90 deg around the same centre: 2 x 2 overlap
+    assert abs(oracle.box_overlap(a, d) - 4.0) < 2e-2
+
+
+def test_nms_properties(oracle):
+    rng = np.random.default_rng(0)
+    boxes = _boxes(rng, 500)
+    rows, keep = oracle.nms_cpu(boxes, 500, 0.01)
+    assert 0 < len(keep) < 500 and len(set(keep.tolist())) == len(keep)
+    assert np.all(np.diff(rows[:, 8]) <= 0)                      # kept boxes come out by descending score
+    # rows are x,y,z,l,w,h,rt,id,score with l = dim0, w = dim1 (save_result swaps them into Bndbox and save_txt prints l,w)
+    assert np.allclose(rows[:, 3], boxes[keep, 3]) and np.allclose(rows[:, 4], boxes[keep, 4])
+    # no two survivors overlap above the threshold; every suppressed box overlaps a higher-scored survivor
+    kb = boxes[keep]
+    for i in range(len(kb)):
+        for j in range(i + 1, len(kb)):
+            ov = oracle.box_overlap(kb[i], kb[j])
+            assert ov / max(kb[i, 3] * kb[i, 4] + kb[j, 3] * kb[j, 4] - ov, 1e-8) < 0.01
+    gone = sorted(set(range(500)) - set(keep.tolist()))
+    for g in gone[:60]:
+        hit = False
+        for k in keep:
+            if boxes[k, 8] >= boxes[g, 8]:
+                ov = oracle.box_overlap(boxes[k], boxes[g])
+                hit |= ov / max(boxes[k, 3] * boxes[k, 4] + boxes[g, 3] * boxes[g, 4] - ov, 1e-8) >= 0.01
+        assert hit
+    # idempotence: NMS of the survivors keeps all of them
+    rows2, keep2 = oracle.nms_cpu(kb, len(kb), 0.01)
+    assert len(keep2) == len(keep)
+    # empty and single-box inputs
+    r0, k0 = oracle.nms_cpu(boxes, 0, 0.01)
+    assert len(k0) == 0
+    r1, k1 = oracle.nms_cpu(boxes, 1, 0.01)
+    assert k1.tolist() == [0]
