@@ -19,6 +19,10 @@ struct LinearArgs {
     int row_mult, max_rows, K, N, add_cols, act, n_ln;
     int out_ld;           // row stride of out / out16 in elements (>= N); lets Q/K/V land in one [rows, 3C] buffer
     int a_half;           // A / A2 are fp16 (fp16-MFMA kernel only)
+    // position-embedding prologue (fp16-MFMA kernel only): when pe_xy != nullptr the operand row is not read from A
+    // but computed on the fly, A'[m][k] = relu(pe_xy[m][0] * pe_w0[k] + pe_xy[m][1] * pe_w1[k] + pe_b[k])  -- the first
+    // FC + BN + ReLU of fullyConnectedBnLELU_fullyConnected (src/dsvt-ai-trt.cpp:461-492), K = 2
+    const float* pe_xy; const float* pe_w0; const float* pe_w1; const float* pe_b;
     float eps;
 };
 

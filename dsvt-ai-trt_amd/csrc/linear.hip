@@ -304,7 +304,25 @@ linear_f16_kernel(LinearArgs a, const _Float16* __restrict__ Wh)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const size_t o = (size_t)rc[mt] * K + ks + g * 8;
-                if (add) {
+                if (a.pe_xy) {                   // operand row = ReLU(BN(FC(xy))) computed in registers (K_in = 2)
+                    const float2 xy = *reinterpret_cast<const float2*>(a.pe_xy + (size_t)rc[mt] * 2);
+#pragma unroll
+                    for (int s = 0; s < NSTEP; ++s) {
+                        const int k0 = ks + s * 32 + g * 8;
+                        half8 v;
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const float4 w0 = *reinterpret_cast<const float4*>(a.pe_w0 + k0 + 4 * hh);
+                            const float4 w1 = *reinterpret_cast<const float4*>(a.pe_w1 + k0 + 4 * hh);
+                            const float4 bb = *reinterpret_cast<const float4*>(a.pe_b + k0 + 4 * hh);
+                            v[4 * hh + 0] = (_Float16)fmaxf(fmaf(xy.x, w0.x, fmaf(xy.y, w1.x, bb.x)), 0.f);
+                            v[4 * hh + 1] = (_Float16)fmaxf(fmaf(xy.x, w0.y, fmaf(xy.y, w1.y, bb.y)), 0.f);
+                            v[4 * hh + 2] = (_Float16)fmaxf(fmaf(xy.x, w0.z, fmaf(xy.y, w1.z, bb.z)), 0.f);
+                            v[4 * hh + 3] = (_Float16)fmaxf(fmaf(xy.x, w0.w, fmaf(xy.y, w1.w, bb.w)), 0.f);
+                        }
+                        f[mt][s] = v;
+                    }
+                } else if (add) {
 #pragma unroll
                     for (int s = 0; s < NSTEP; ++s) f[mt][s] = loadFrag<AHALF, true>(a.A, a.A2, o + s * 32);
                 } else {
@@ -370,13 +388,18 @@ struct LinCfg {
 class DsvtLinearPlugin : public Plugin {
 public:
     LinCfg c_;
-    std::vector<float> w_, b_, g_, be_;
-    float *w_dev_ = nullptr, *b_dev_ = nullptr, *g_dev_ = nullptr, *be_dev_ = nullptr;
+    std::vector<float> w_, b_, g_, be_, pe_;       // pe_: [w0 (K) | w1 (K) | b (K)] of the fused K_in = 2 first FC, or empty
+    float *w_dev_ = nullptr, *b_dev_ = nullptr, *g_dev_ = nullptr, *be_dev_ = nullptr, *pe_dev_ = nullptr;
     _Float16* wh_dev_ = nullptr;
     bool ok_ = false;
     bool useF16() const { return c_.compute_type == 1 && c_.K % KS == 0; }
-    DsvtLinearPlugin(const LinCfg& c, const float* w, const float* b, const float* g, const float* be)
+    DsvtLinearPlugin(const LinCfg& c, const float* w, const float* b, const float* g, const float* be,
+                     const float* pe_w = nullptr, const float* pe_b = nullptr)
         : c_(c), w_(w, w + (size_t)c.N * c.K) {
+        if (pe_w && pe_b) {                      // torch Linear(2 -> K).weight is [K][2]
+            pe_.resize(3 * (size_t)c.K);
+            for (int k = 0; k < c.K; ++k) { pe_[k] = pe_w[2 * k]; pe_[c.K + k] = pe_w[2 * k + 1]; pe_[2 * c.K + k] = pe_b[k]; }
+        }
         if (b) b_.assign(b, b + c.N);
         if (c.n_ln) { g_.assign(g, g + (size_t)c.n_ln * c.N); be_.assign(be, be + (size_t)c.n_ln * c.N); }
         auto up = [](const std::vector<float>& h, float** d) {
@@ -384,7 +407,7 @@ public:
             if (hipMalloc(d, sizeof(float) * h.size()) != hipSuccess) return false;
             return hipMemcpy(*d, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice) == hipSuccess;
         };
-        ok_ = up(w_, &w_dev_) && up(b_, &b_dev_) && up(g_, &g_dev_) && up(be_, &be_dev_);
+        ok_ = up(w_, &w_dev_) && up(b_, &b_dev_) && up(g_, &g_dev_) && up(be_, &be_dev_) && up(pe_, &pe_dev_);
         if (ok_ && useF16()) {
             std::vector<_Float16> wh(w_.size());
             for (size_t i = 0; i < w_.size(); ++i) wh[i] = (_Float16)w_[i];
@@ -393,7 +416,7 @@ public:
         }
     }
     ~DsvtLinearPlugin() override {
-        for (float* p : {w_dev_, b_dev_, g_dev_, be_dev_}) if (p) (void)hipFree(p);
+        for (float* p : {w_dev_, b_dev_, g_dev_, be_dev_, pe_dev_}) if (p) (void)hipFree(p);
         if (wh_dev_) (void)hipFree(wh_dev_);
     }
     const char* type() const override { return "DsvtLinearPlugin"; }
@@ -409,6 +432,7 @@ public:
     bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int nbIn, int) const override {
         if (io[pos].format != DSVT_FORMAT_LINEAR) return false;
         if (pos == 1) return io[pos].type == DSVT_INT32;
+        if (pos == 0 && !pe_.empty()) return io[pos].type == DSVT_FLOAT;        // the [rows, 2] xy tensor
         if (pos == 0 || (pos == 2 && c_.add_cols > 0)) return io[pos].type == (c_.input_half ? DSVT_HALF : DSVT_FLOAT);
         if (pos < nbIn) return io[pos].type == DSVT_FLOAT;                      // residuals
         return io[pos].type == outputType(pos - nbIn, nullptr, 0);
@@ -420,6 +444,10 @@ public:
         LinearArgs a{};
         int idx = 0;
         a.A = in[idx++];
+        if (!pe_.empty()) {
+            a.pe_xy = static_cast<const float*>(a.A); a.A = nullptr;
+            a.pe_w0 = pe_dev_; a.pe_w1 = pe_dev_ + c_.K; a.pe_b = pe_dev_ + 2 * (size_t)c_.K;
+        }
         a.count = static_cast<const uint32_t*>(in[idx++]);
         a.A2 = c_.add_cols > 0 ? in[idx++] : nullptr;
         for (int s = 0; s < c_.n_ln; ++s) {
@@ -438,26 +466,33 @@ public:
         return useF16() ? launchLinearF16(a, wh_dev_, stream) : launchLinearF32(a, stream);
     }
     size_t serializationSize() const override {
-        return 11 * sizeof(int) + sizeof(float) + sizeof(float) * (w_.size() + b_.size() + g_.size() + be_.size());
+        return 12 * sizeof(int) + sizeof(float) + sizeof(float) * (w_.size() + b_.size() + g_.size() + be_.size() + pe_.size());
     }
     void serialize(void* buf) const override {
         char* d = static_cast<char*>(buf);
         wr<int>(d, c_.max_rows); wr<int>(d, c_.K); wr<int>(d, c_.N); wr<int>(d, c_.row_mult); wr<int>(d, c_.act); wr<int>(d, c_.add_cols);
         wr<int>(d, c_.n_ln); wr<float>(d, c_.eps); wr<int>(d, b_.empty() ? 0 : 1); wr<int>(d, c_.compute_type);
-        wr<int>(d, c_.input_half); wr<int>(d, c_.output_mode);
-        for (const std::vector<float>* v : {&w_, &b_, &g_, &be_}) { memcpy(d, v->data(), sizeof(float) * v->size()); d += sizeof(float) * v->size(); }
+        wr<int>(d, c_.input_half); wr<int>(d, c_.output_mode); wr<int>(d, pe_.empty() ? 0 : 1);
+        for (const std::vector<float>* v : {&w_, &b_, &g_, &be_, &pe_}) { memcpy(d, v->data(), sizeof(float) * v->size()); d += sizeof(float) * v->size(); }
     }
-    Plugin* clone() const override { return new DsvtLinearPlugin(c_, w_.data(), b_.empty() ? nullptr : b_.data(), g_.data(), be_.data()); }
+    Plugin* clone() const override {
+        DsvtLinearPlugin* p = new DsvtLinearPlugin(c_, w_.data(), b_.empty() ? nullptr : b_.data(), g_.data(), be_.data());
+        if (!pe_.empty()) { p->pe_ = pe_; p->ok_ = p->ok_ && hipMalloc(&p->pe_dev_, sizeof(float) * pe_.size()) == hipSuccess &&
+                            hipMemcpy(p->pe_dev_, pe_.data(), sizeof(float) * pe_.size(), hipMemcpyHostToDevice) == hipSuccess; }
+        return p;
+    }
 };
 
-static Plugin* linNew(const LinCfg& c, const float* w, const float* b, const float* g, const float* be) {
+static Plugin* linNew(const LinCfg& c, const float* w, const float* b, const float* g, const float* be,
+                      const float* pe_w = nullptr, const float* pe_b = nullptr) {
+    if ((pe_w || pe_b) && !(pe_w && pe_b && c.compute_type == 1 && c.K % KS == 0 && c.add_cols == 0 && !c.input_half)) return nullptr;
     if (c.max_rows <= 0 || c.K <= 0 || c.N <= 0 || c.N % 4 != 0 || c.row_mult <= 0 || !w) return nullptr;
     if (c.compute_type < 0 || c.compute_type > 1 || c.output_mode < 0 || c.output_mode > 2) return nullptr;
     if (c.act < 0 || c.act > 2 || c.n_ln < 0 || c.n_ln > 3) return nullptr;
     if (c.n_ln > 0 && (c.N > BN || !g || !be)) return nullptr;             // a LayerNorm row must fit one tile
     if (c.add_cols < 0 || c.add_cols > c.N || (c.add_cols % BN != 0 && c.add_cols != c.N)) return nullptr;
     if (c.input_half && !(c.compute_type == 1 && c.K % KS == 0)) return nullptr;      // fp16 inputs only on the fp16 kernel
-    return new DsvtLinearPlugin(c, w, b, g, be);
+    return new DsvtLinearPlugin(c, w, b, g, be, pe_w, pe_b);
 }
 static Plugin* linCreate(const DsvtPluginFieldCollection* fc) {
     const DsvtPluginField* w = findField(fc, "weight"); const DsvtPluginField* b = findField(fc, "bias");
@@ -470,23 +505,32 @@ static Plugin* linCreate(const DsvtPluginFieldCollection* fc) {
     if (!w || !w->data || c.K <= 0 || c.N <= 0 || w->length != c.K * c.N) return nullptr;
     if (b && b->data && b->length != c.N) return nullptr;
     if (c.n_ln > 0 && (!g || !be || g->length != c.n_ln * c.N || be->length != c.n_ln * c.N)) return nullptr;
+    const DsvtPluginField* pw = findField(fc, "pe_weight"); const DsvtPluginField* pb = findField(fc, "pe_bias");
+    if ((pw && pw->data && pw->length != 2 * c.K) || (pb && pb->data && pb->length != c.K)) return nullptr;
     return linNew(c, static_cast<const float*>(w->data), (b && b->data) ? static_cast<const float*>(b->data) : nullptr,
-                  g ? static_cast<const float*>(g->data) : nullptr, be ? static_cast<const float*>(be->data) : nullptr);
+                  g ? static_cast<const float*>(g->data) : nullptr, be ? static_cast<const float*>(be->data) : nullptr,
+                  (pw && pw->data) ? static_cast<const float*>(pw->data) : nullptr, (pb && pb->data) ? static_cast<const float*>(pb->data) : nullptr);
 }
 static Plugin* linDeser(const void* data, size_t len) {
-    if (len < 11 * sizeof(int) + sizeof(float)) return nullptr;
+    if (len < 12 * sizeof(int) + sizeof(float)) return nullptr;
     const char* d = static_cast<const char*>(data);
     LinCfg c{};
     c.max_rows = rd<int>(d); c.K = rd<int>(d); c.N = rd<int>(d); c.row_mult = rd<int>(d); c.act = rd<int>(d); c.add_cols = rd<int>(d);
     c.n_ln = rd<int>(d); c.eps = rd<float>(d); int has_b = rd<int>(d); c.compute_type = rd<int>(d);
-    c.input_half = rd<int>(d); c.output_mode = rd<int>(d);
+    c.input_half = rd<int>(d); c.output_mode = rd<int>(d); int has_pe = rd<int>(d);
     if (c.K <= 0 || c.N <= 0 || c.n_ln < 0 || c.n_ln > 3) return nullptr;
-    size_t need = (size_t)c.K * c.N + (has_b ? c.N : 0) + 2 * (size_t)c.n_ln * c.N;
-    if (len < 11 * sizeof(int) + sizeof(float) + need * sizeof(float)) return nullptr;
+    size_t need = (size_t)c.K * c.N + (has_b ? c.N : 0) + 2 * (size_t)c.n_ln * c.N + (has_pe ? 3 * (size_t)c.K : 0);
+    if (len < 12 * sizeof(int) + sizeof(float) + need * sizeof(float)) return nullptr;
     std::vector<float> all(need);
     memcpy(all.data(), d, need * sizeof(float));
     const float* w = all.data(); const float* b = has_b ? w + (size_t)c.K * c.N : nullptr;
     const float* g = w + (size_t)c.K * c.N + (has_b ? c.N : 0); const float* be = g + (size_t)c.n_ln * c.N;
+    if (has_pe) {                                  // stored as [w0 | w1 | b]; rebuild the [K][2] weight the constructor expects
+        const float* pe = be + (size_t)c.n_ln * c.N;
+        std::vector<float> pw(2 * (size_t)c.K);
+        for (int k = 0; k < c.K; ++k) { pw[2 * k] = pe[k]; pw[2 * k + 1] = pe[c.K + k]; }
+        return linNew(c, w, b, g, be, pw.data(), pe + 2 * (size_t)c.K);
+    }
     return linNew(c, w, b, g, be);
 }
 static Creator g_linCreator{"DsvtLinearPlugin",
@@ -494,7 +538,8 @@ static Creator g_linCreator{"DsvtLinearPlugin",
      {"row_mult", DSVT_FIELD_INT32}, {"activation", DSVT_FIELD_INT32}, {"add_cols", DSVT_FIELD_INT32},
      {"num_layer_norms", DSVT_FIELD_INT32}, {"ln_eps", DSVT_FIELD_FLOAT32}, {"compute_type", DSVT_FIELD_INT32},
      {"input_half", DSVT_FIELD_INT32}, {"output_mode", DSVT_FIELD_INT32},
-     {"weight", DSVT_FIELD_FLOAT32}, {"bias", DSVT_FIELD_FLOAT32}, {"ln_weights", DSVT_FIELD_FLOAT32}, {"ln_bias", DSVT_FIELD_FLOAT32}},
+     {"weight", DSVT_FIELD_FLOAT32}, {"bias", DSVT_FIELD_FLOAT32}, {"ln_weights", DSVT_FIELD_FLOAT32}, {"ln_bias", DSVT_FIELD_FLOAT32},
+     {"pe_weight", DSVT_FIELD_FLOAT32}, {"pe_bias", DSVT_FIELD_FLOAT32}},
     linCreate, linDeser, {}, {}};
 static Registrar g_linReg(&g_linCreator);
 

@@ -102,8 +102,12 @@ class DsvtPipeline:
             for l in range(2):
                 pre = f"module.backbone_3d.input_layer.posembed_layers.0.{b}.{l}.position_embedding_head"
                 Wa, ba = fold_linear_bn(w, pre + ".0", pre + ".1", 1e-5, bias=True)                 # :461-492
-                self.pe[(b, l)] = (zf(P.add_linear_op(Wa, ba, c.P, activation=P.ACT_RELU, **ct)),
-                                   zf(P.add_linear_op(w[pre + ".3.weight"], w[pre + ".3.bias"], c.P, **ct, **o16)))
+                if f16:      # both FCs of the MLP in one launch: the K_in = 2 one runs in the A prologue
+                    self.pe[(b, l)] = (None, zf(P.add_linear_op(w[pre + ".3.weight"], w[pre + ".3.bias"], c.P, **ct, **o16,
+                                                                 pe_weight=Wa, pe_bias=ba)))
+                else:
+                    self.pe[(b, l)] = (zf(P.add_linear_op(Wa, ba, c.P, activation=P.ACT_RELU, **ct)),
+                                       zf(P.add_linear_op(w[pre + ".3.weight"], w[pre + ".3.bias"], c.P, **ct, **o16)))
                 lp = f"module.backbone_3d.stage_0.{b}.encoder_list.{l}"
                 wi = w[lp + ".win_attn.self_attn.in_proj_weight"].copy()
                 bi = w[lp + ".win_attn.self_attn.in_proj_bias"].copy()
@@ -309,7 +313,8 @@ class DsvtPipeline:
             inds, mask, S = st["gss"][b % 2][0], st["gss"][b % 2][1], st["gss"][b % 2][2]
             for l in range(2):
                 a, fc = self.pe[(b, l)]
-                pos = fc(a(st["wps"][l][5], Pn)[0], Pn)[0]           # pos-embed input = window config l (:603-637)
+                xy = st["wps"][l][5]                                  # pos-embed input = window config l (:603-637)
+                pos = fc(xy, Pn)[0] if a is None else fc(a(xy, Pn)[0], Pn)[0]
                 L = self.layers[(b, l)]
                 qkv = L["qkv"](xh, Pn, pos)[0]
                 att = L["attn"](qkv, inds, mask, S)[0]

@@ -421,7 +421,7 @@ OUT_F32, OUT_F16, OUT_BOTH = 0, 1, 2
 
 
 def add_linear_op(weight, bias, max_rows, row_mult=1, activation=ACT_NONE, add_cols=0, layer_norms=(), ln_eps=0.0,
-                  compute_type=COMPUTE_F32, input_half=False, output_mode=OUT_F32):
+                  compute_type=COMPUTE_F32, input_half=False, output_mode=OUT_F32, pe_weight=None, pe_bias=None):
     """FC with fused prologue/epilogue (csrc/linear.hip), used where the reference calls
     addFullyConnected (src/dsvt-ai-trt.cpp:283,476,490,506,525) + ElementWise/LayerNorm/GELU.
     Inputs: A [1,rows,K], count [1], (A2 if add_cols), then one residual per LayerNorm stage.
@@ -433,6 +433,9 @@ def add_linear_op(weight, bias, max_rows, row_mult=1, activation=ACT_NONE, add_c
                   input_half=int(bool(input_half)), output_mode=output_mode, weight=weight.reshape(-1))
     if bias is not None:
         fields["bias"] = np.asarray(bias, np.float32).reshape(-1)
+    if pe_weight is not None:      # fused K_in = 2 first FC (+BN, ReLU) of the position-embedding MLP: input 0 becomes xy [1,rows,2]
+        fields["pe_weight"] = np.asarray(pe_weight, np.float32).reshape(-1)
+        fields["pe_bias"] = np.asarray(pe_bias, np.float32).reshape(-1)
     if layer_norms:
         fields["ln_weights"] = np.concatenate([np.asarray(g, np.float32).reshape(-1) for g, _ in layer_norms])
         fields["ln_bias"] = np.concatenate([np.asarray(b, np.float32).reshape(-1) for _, b in layer_norms])
