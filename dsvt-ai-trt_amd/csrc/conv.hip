@@ -21,6 +21,7 @@
 #include "plugin_base.h"
 #include "device_utils.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace dsvt {
 
@@ -42,7 +43,44 @@ struct ConvArgs {
     int CoutRows;                                // rows of wt = up*up*Cout
     int Cout;                                    // real output channels
     int KH, KW, stride, pad, up, relu;
+    int wide;                                    // halo kernel: 16-byte epilogue accesses are legal (channel strides / offsets % 8, Cout % 16, fp16 output)
 };
+
+
+// bias / residual / ReLU / store of four consecutive output channels co..co+3 of output pixel opix
+__device__ __forceinline__ void convStore(const ConvArgs& a, floatx4 acc, size_t opix, int co)
+{
+    if (co >= a.Cout) return;
+    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+    const bool full = co + 3 < a.Cout;
+    if (a.bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (co + i < a.Cout) v[i] += a.bias[co + i];
+    }
+    if (a.res && full) {
+        const half4 rv = *reinterpret_cast<const half4*>(a.res + opix * a.res_ld + co);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += (float)rv[i];
+    }
+    if (a.relu) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+    if (a.out_f32) {
+        float* o = static_cast<float*>(a.out) + opix * a.out_ld + a.out_coff + co;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (co + i < a.Cout) o[i] = v[i];
+    } else {
+        _Float16* o = static_cast<_Float16*>(a.out) + opix * a.out_ld + a.out_coff + co;
+        if (full) {
+            half4 h; h[0] = (_Float16)v[0]; h[1] = (_Float16)v[1]; h[2] = (_Float16)v[2]; h[3] = (_Float16)v[3];
+            *reinterpret_cast<half4*>(o) = h;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (co + i < a.Cout) o[i] = (_Float16)v[i];
+        }
+    }
+}
 
 // MT = 16-pixel MFMA tiles per wave, NW = waves per workgroup (128 pixels per workgroup either way)
 template <int KC, int MT, int NW>
@@ -191,6 +229,283 @@ conv_f16_kernel(ConvArgs a)
     }
 }
 
+
+// -------------------------------------------------------------------------------------
+// Halo-tile kernel for the stride-1 layers (every 3x3 / 1x1 convolution of the BEV backbone and the
+// CenterHead except the two stride-2 entries): the re-read factor of the kernel above (each input
+// pixel fetched once per tap, each weight slab once per 128 pixels -- ~1 GB of L2->CU traffic for a
+// 468x468x128 layer, waves parked in s_waitcnt 2/3 of the time) is what bounds it, not MFMA or LDS.
+//
+//   * workgroup = TH rows x 32 columns of output pixels x 128 output channels, TH waves; wave
+//     (pg, cg) owns rows 2pg, 2pg+1 (four 16-pixel MFMA tiles) x 64 channels (four 16-channel
+//     tiles): a 64 x 64 register tile, 16 MFMAs per 8 ds_read_b128.
+//   * the (TH+2) x 34 x 64-channel input halo sits in LDS, 128 B per pixel, 16-byte chunk c of
+//     pixel column hx stored at slot c ^ (hx & 7): the B fragment of tap (ky, kx) is one
+//     conflict-free ds_read_b128 per 16-pixel tile; the row stride (40 pixels) is 0 mod 8 so the
+//     swizzle term depends on the column only.  Each input pixel is fetched ~1.3x, not 9x.
+//   * weights are packed by the host in MFMA-fragment order [k-step][16-channel tile][lane][8 halfs]:
+//     a 64-wide K slab (one tap, one 64-channel chunk) is a linear 16 KB copy into LDS and an A
+//     fragment is a lane-linear ds_read_b128.
+//   * persistent grid (one workgroup per CU): a workgroup walks items = (pixel tile, 128-channel
+//     chunk); the next halo (next 64-channel chunk, or the next item's first) and the next weight
+//     slab are requested before the MFMAs of the current one and written to the other LDS buffer
+//     after them -- one barrier per slab, no exposed prologue between items.
+constexpr int HTW = 32;           // tile width in pixels
+constexpr int HHS = 40;           // LDS halo row stride in pixels (>= HTW + 2, multiple of 8)
+
+// Wide epilogue of one 16-pixel tile x two 16-channel tiles (t0, t0 + 1) of a wave: v_permlane16_swap exchanges
+// the odd 16-lane rows of X with the even rows of Y, after which lane (r, g) holds EIGHT consecutive output
+// channels of pixel r (first channel t0*16 + (g&1)*16 + (g>>1)*8): bias / residual / store are 16-byte accesses
+// and the four lanes of a pixel cover a contiguous 64-byte segment.
+__device__ __forceinline__ void convStoreWide(const ConvArgs& a, floatx4 X, floatx4 Y, bool valid, size_t opix, int co0, int g)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(X[i]), __float_as_uint(Y[i]), false, false);
+        X[i] = __uint_as_float(sw[0]); Y[i] = __uint_as_float(sw[1]);
+    }
+    const int co = co0 + (g & 1) * 16 + (g >> 1) * 8;
+    if (!valid || co >= a.Cout) return;
+    float v[8] = {X[0], X[1], X[2], X[3], Y[0], Y[1], Y[2], Y[3]};
+    if (a.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co), b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    if (a.res) {
+        const half8 rv = *reinterpret_cast<const half8*>(a.res + opix * a.res_ld + co);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += (float)rv[i];
+    }
+    half8 h;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = (_Float16)(a.relu ? fmaxf(v[i], 0.f) : v[i]);
+    *reinterpret_cast<half8*>(static_cast<_Float16*>(a.out) + opix * a.out_ld + a.out_coff + co) = h;
+}
+
+typedef __attribute__((address_space(1))) const void* glds_src_t;
+typedef __attribute__((address_space(3))) void* glds_dst_t;
+
+// end of a K slab: this wave's LDS-DMA requests older than the youngest `keep` have landed, then the workgroup barrier
+// publishes them (LDS-DMA data is ordered for a ds_read only by the issuing wave's vmcnt followed by a barrier)
+template <int KEEP>
+__device__ __forceinline__ void slabBarrier() {
+    if (KEEP == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int TH, int KS>
+__global__ void __launch_bounds__(64 * TH, 1)
+conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __restrict__ zeros, int tilesX, int nitems, int nchunk, int dbg)
+{
+    constexpr int HS = KS == 1 ? 32 : HHS;                          // LDS halo row stride in pixels (multiple of 8)
+    constexpr int HH = TH + KS - 1, HWU = HTW + KS - 1, T = KS * KS, PAD = KS / 2;
+    constexpr int HBYTES = HH * HS * 128, WBYTES = 16384;
+    constexpr int NI = HH * HS / 8;                                 // 1 KB LDS-DMA instructions per halo (8 pixels x 128 B each)
+    constexpr int HPW = (NI + TH - 1) / TH;                         // ... per wave
+    constexpr int WPW = (16 + TH - 1) / TH;                         // 1 KB instructions per wave per 16 KB weight slab
+    static_assert(KS == 1 || HPW <= T, "one halo request per tap");
+    // ONE shared object: halo[2] | wslab[2]  (a second __shared__ object makes hipcc drain the DMA queue before every ds_read)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HBYTES + 2 * WBYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int pg = wave >> 1, cg = wave & 1;
+    const int NCC = a.Cin >> 6, NCT = nchunk * 8;
+
+    // halo requests of this lane: request j of the wave covers LDS pixels 8(wave + j TH) .. +7; lane = (pixel, 16-byte slot)
+    int hpos[HPW];
+#pragma unroll
+    for (int j = 0; j < HPW; ++j) {
+        const int lp = 8 * (wave + j * TH) + (lane >> 3), slot = lane & 7;
+        const int hy = lp / HS, hx = lp - hy * HS;
+        hpos[j] = (hy << 16) | (hx << 4) | (slot ^ (hx & 7));         // 16-byte channel chunk of the pixel stored in this slot
+    }
+    int goff[HPW];                                                    // element offset into the input, or -1: zeros
+    auto setup = [&](int yy, int xx) {
+#pragma unroll
+        for (int j = 0; j < HPW; ++j) {
+            const int hx = (hpos[j] >> 4) & 0xfff;
+            const int gy = yy - PAD + (hpos[j] >> 16), gx = xx - PAD + hx;
+            const bool ok = hx < HWU && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            goff[j] = ok ? (gy * a.W + gx) * a.Cin + (hpos[j] & 15) * 8 : -1;
+        }
+    };
+    auto decode = [&](int it, int& yy, int& xx, int& ch) {
+        ch = it % nchunk; const int t = it / nchunk;
+        yy = (t / tilesX) * TH; xx = (t % tilesX) * HTW;
+    };
+    auto haloRequest = [&](int j, int cc, int hb) {                   // wave-uniform j; returns nothing, one LDS-DMA
+        const _Float16* src = goff[j] >= 0 ? a.in + goff[j] + cc * 64 : zeros;
+        __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + hb * HBYTES + (wave + j * TH) * 1024), 16, 0, 0);
+    };
+    auto weightRequests = [&](int q0, int ch, int wb) {
+#pragma unroll
+        for (int j = 0; j < WPW; ++j) {
+            const int u = wave + j * TH;
+            if (16 % TH == 0 || u < 16) {
+                const _Float16* src = Wp + (((size_t)(q0 + (u >> 3)) * NCT + ch * 8 + (u & 7)) * 64 + lane) * 8;
+                __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + 2 * HBYTES + wb * WBYTES + u * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    int pbase[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) pbase[m] = ((2 * pg + (m >> 1)) * HS + (m & 1) * 16 + r) * 128;
+    int swz[KS];
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) swz[kx] = (g ^ ((r + kx) & 7)) << 4;
+
+    floatx4 acc[4][4];
+    // bias / residual / ReLU / store of a finished item (tile origin ey, ex; 128-channel chunk ech)
+    auto epilogue = [&](int ey, int ex, int ech) {
+        const int n0 = ech * CNB;
+        int ctn = (a.CoutRows - n0 + 15) / 16 - cg * 4;
+        ctn = ctn < 0 ? 0 : ctn > 4 ? 4 : ctn;
+        const int sub = n0 / a.Cout, dy = sub / a.up, dx = sub - dy * a.up, cbase = n0 - sub * a.Cout;
+        const int Wout = a.Wo * a.up;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int oy = ey + 2 * pg + (m >> 1), ox = ex + (m & 1) * 16 + r;
+            const bool valid = oy < a.Ho && ox < a.Wo;
+            const size_t opix = valid ? (size_t)(oy * a.up + dy) * Wout + (ox * a.up + dx) : 0;
+            if (a.wide) {
+#pragma unroll
+                for (int t0 = 0; t0 < 4; t0 += 2)
+                    if (t0 < ctn) convStoreWide(a, acc[t0][m], acc[t0 + 1][m], valid, opix, cbase + cg * 64 + t0 * 16, g);
+            } else if (valid) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    if (ct < ctn) convStore(a, acc[ct][m], opix, cbase + cg * 64 + ct * 16 + 4 * g);
+            }
+        }
+    };
+
+    int item = blockIdx.x;
+    if (item >= nitems) return;
+    int y0, x0, chunk;
+    decode(item, y0, x0, chunk);
+    setup(y0, x0);
+#pragma unroll
+    for (int j = 0; j < HPW; ++j)
+        if (NI % TH == 0 || wave + j * TH < NI) haloRequest(j, 0, 0);
+    weightRequests(0, chunk, 0);
+    slabBarrier<0>();
+    int hb = 0, wb = 0;
+    bool pending = false; int ey = 0, ex = 0, ech = 0;          // finished item whose epilogue has not run yet
+    for (;;) {
+        const int n0 = chunk * CNB;
+        int ctn = (a.CoutRows - n0 + 15) / 16 - cg * 4;           // valid 16-channel tiles of this wave
+        ctn = ctn < 0 ? 0 : ctn > 4 ? 4 : ctn;
+        int nitem = item, ny0 = y0, nx0 = x0, nch = chunk;
+        bool have_next = true;
+        for (int cc = 0; cc < NCC; ++cc) {
+            int ncc = cc + 1;
+            if (ncc == NCC) {
+                ncc = 0; nitem = item + gridDim.x; have_next = nitem < nitems;
+                if (have_next) { decode(nitem, ny0, nx0, nch); setup(ny0, nx0); }
+            }
+            const bool haloNext = have_next && !(dbg & 1);
+#pragma unroll
+            for (int tap = 0; tap < T; ++tap) {
+                const bool lastTap = tap == T - 1;
+                const bool moreW = (!lastTap || have_next) && !(dbg & 2);
+                if (tap == 0 && cc == 0) {
+                    // epilogue of the previous item first: its stores are the oldest requests of this slab and have the
+                    // whole MFMA block to complete
+                    if (pending && !(dbg & 8)) epilogue(ey, ex, ech);
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) acc[ct][m] = floatx4{0.f, 0.f, 0.f, 0.f};
+                }
+                if (moreW) weightRequests(lastTap ? ncc * T * 2 : (cc * T + tap + 1) * 2, lastTap ? nch : chunk, wb ^ 1);
+                // the next halo is requested AFTER this slab's weight requests, one per tap: the slab-end wait (in-order
+                // counter, vmcnt(1)) retires the weights and leaves the halo request in flight across the barrier
+                bool haloInFlight = false;
+                if (KS == 1) {
+                    if (haloNext) {
+#pragma unroll
+                        for (int j = 0; j < HPW; ++j)
+                            if (NI % TH == 0 || wave + j * TH < NI) haloRequest(j, ncc, hb ^ 1);
+                    }
+                } else if (tap < HPW) {
+                    if (haloNext && (NI % TH == 0 || wave + (tap < HPW ? tap : 0) * TH < NI)) {
+                        haloRequest(tap < HPW ? tap : 0, ncc, hb ^ 1);
+                        haloInFlight = !lastTap;
+                    }
+                }
+                const unsigned char* hbp = smem + hb * HBYTES;
+                const unsigned char* wbp = smem + 2 * HBYTES + wb * WBYTES + ((cg * 4 * 64 + lane) << 4);
+                const int ky = tap / KS, kx = tap - ky * KS;
+                const int toff = (ky * HS + kx) * 128;
+                const int sw = swz[kx];
+                auto slab = [&](auto full) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        half8 A[4], B[4];
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct) A[ct] = *reinterpret_cast<const half8*>(wbp + ((ks * 8 + ct) << 10));
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) B[m] = *reinterpret_cast<const half8*>(hbp + pbase[m] + toff + (sw ^ (ks << 6)));
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct)
+                            if (decltype(full)::value || ct < ctn)
+#pragma unroll
+                                for (int m = 0; m < 4; ++m)
+                                    acc[ct][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ct], B[m], acc[ct][m], 0, 0, 0);
+                    }
+                };
+                if (dbg & 4) {} else if (ctn == 4) slab(std::true_type{}); else slab(std::false_type{});
+                if (haloInFlight) slabBarrier<1>(); else slabBarrier<0>();
+                wb ^= 1;
+            }
+            hb ^= 1;
+        }
+        pending = true; ey = y0; ex = x0; ech = chunk;
+        if (!have_next) break;
+        item = nitem; y0 = ny0; x0 = nx0; chunk = nch;
+    }
+    if (!(dbg & 8)) epilogue(ey, ex, ech);
+}
+
+static int numCUs() {
+    static int n = 0;
+    if (!n) { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); n = hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }
+    return n;
+}
+
+// tile height of the halo kernel: the (rounds of items over the CUs) x (tile height) product is the makespan
+static int haloTileRows(const ConvArgs& a) {
+    if (const char* e = getenv("DSVT_CONV_TH")) { const int t = atoi(e); if (t == 4 || t == 8 || t == 10) return t; }
+    const int nchunk = cdiv(a.CoutRows, CNB), cus = numCUs();
+    int best = 8; long bestCost = -1;
+    for (int th : {8, 4}) {          // the 10-row instantiation exceeds 168 VGPRs (10 waves => 3 waves on two SIMDs) and spills
+        const long items = (long)cdiv(a.Ho, th) * cdiv(a.Wo, HTW) * nchunk;
+        long cost = cdiv(items, (long)cus) * th * 16;
+        if (th == 4) cost = cost * 5 / 4;           // one wave per SIMD hides less latency
+        if (bestCost < 0 || cost < bestCost) { best = th; bestCost = cost; }
+    }
+    return best;
+}
+
+static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16* zeros, hipStream_t stream) {
+    const int th = haloTileRows(a);
+    const int tilesX = cdiv(a.Wo, HTW), nchunk = cdiv(a.CoutRows, CNB);
+    const int nitems = cdiv(a.Ho, th) * tilesX * nchunk;
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("DSVT_CONV_DBG"); dbg = e ? atoi(e) : 0; }           // timing ablations only (wrong results)
+    static int gridCap = -1;
+    if (gridCap < 0) { const char* e = getenv("DSVT_CONV_GRID"); gridCap = e ? atoi(e) : 0; }      // test knob: force multi-item workgroups
+    int grid = nitems < numCUs() ? nitems : numCUs();
+    if (gridCap > 0 && grid > gridCap) grid = gridCap;
+#define DSVT_HALO_LAUNCH(TH_, KS_) hipLaunchKernelGGL((conv_halo_kernel<TH_, KS_>), dim3(grid), dim3(64 * TH_), 0, stream, a, Wp, zeros, tilesX, nitems, nchunk, dbg)
+    if (a.KH == 3) { if (th == 10) DSVT_HALO_LAUNCH(10, 3); else if (th == 8) DSVT_HALO_LAUNCH(8, 3); else DSVT_HALO_LAUNCH(4, 3); }
+    else           { if (th == 10) DSVT_HALO_LAUNCH(10, 1); else if (th == 8) DSVT_HALO_LAUNCH(8, 1); else DSVT_HALO_LAUNCH(4, 1); }
+#undef DSVT_HALO_LAUNCH
+    return lastError();
+}
+
 static int launchConv(const ConvArgs& a, int KC, hipStream_t stream) {
     dim3 grid((unsigned)(cdiv(cdiv(a.Ho * a.Wo, CPX), 8) * 8), (unsigned)cdiv(a.CoutRows, CNB));
     static int variant = -1;       // 0: 4 waves x 32 pixels   1: 8 waves x 16 pixels (4 waves/SIMD)
@@ -219,7 +534,14 @@ public:
     ConvCfg c_;
     std::vector<float> w_, b_;           // w_: [up*up*Cout][KH*KW][Cin]
     _Float16* w_dev_ = nullptr; float* b_dev_ = nullptr;
+    _Float16* wp_dev_ = nullptr;         // fragment-packed copy for the halo kernel (stride-1 layers)
+    _Float16* zeros_dev_ = nullptr;      // 256 zero bytes: LDS-DMA source of out-of-image halo pixels
     bool ok_ = false;
+    bool haloEligible() const {
+        static int on = -1;
+        if (on < 0) { const char* e = getenv("DSVT_CONV_HALO"); on = e ? atoi(e) : 1; }
+        return on && c_.stride == 1 && c_.KH == c_.KW && (c_.KH == 1 || c_.KH == 3) && c_.pad == c_.KH / 2 && c_.Cin % 64 == 0;
+    }
     int Ho() const { return (c_.H + 2 * c_.pad - c_.KH) / c_.stride + 1; }
     int Wo() const { return (c_.W + 2 * c_.pad - c_.KW) / c_.stride + 1; }
     int rows() const { return c_.up * c_.up * c_.Cout; }
@@ -240,8 +562,29 @@ public:
               hipMemcpy(w_dev_, wh.data(), sizeof(_Float16) * nw, hipMemcpyHostToDevice) == hipSuccess;
         if (ok_ && b) ok_ = hipMalloc(&b_dev_, sizeof(float) * c.Cout) == hipSuccess &&
                             hipMemcpy(b_dev_, b_.data(), sizeof(float) * c.Cout, hipMemcpyHostToDevice) == hipSuccess;
+        if (ok_ && haloEligible()) {
+            // [k-step q = (cc * taps + tap) * 2 + ks][16-channel tile ct][lane (r, g)][8] <- W[ct*16 + r][tap][cc*64 + ks*32 + g*8 + j]
+            const int T = c.KH * c.KW, NCC = c.Cin / 64, NCT = cdiv(rows(), CNB) * 8, R = rows();
+            std::vector<_Float16> wp((size_t)NCC * T * 2 * NCT * 512, (_Float16)0.f);
+            for (int cc = 0; cc < NCC; ++cc)
+                for (int tap = 0; tap < T; ++tap)
+                    for (int ks = 0; ks < 2; ++ks)
+                        for (int ct = 0; ct < NCT; ++ct)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int n = ct * 16 + (lane & 15);
+                                if (n >= R) continue;
+                                const size_t dst = ((((size_t)(cc * T + tap) * 2 + ks) * NCT + ct) * 64 + lane) * 8;
+                                const size_t src = ((size_t)n * T + tap) * c.Cin + cc * 64 + ks * 32 + (lane >> 4) * 8;
+                                for (int j = 0; j < 8; ++j) wp[dst + j] = wh[src + j];
+                            }
+            ok_ = hipMalloc(&wp_dev_, sizeof(_Float16) * wp.size()) == hipSuccess &&
+                  hipMemcpy(wp_dev_, wp.data(), sizeof(_Float16) * wp.size(), hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMalloc(&zeros_dev_, 256) == hipSuccess && hipMemset(zeros_dev_, 0, 256) == hipSuccess;
+        }
     }
-    ~DsvtConv2dPlugin() override { if (w_dev_) (void)hipFree(w_dev_); if (b_dev_) (void)hipFree(b_dev_); }
+    ~DsvtConv2dPlugin() override {
+        if (w_dev_) (void)hipFree(w_dev_); if (b_dev_) (void)hipFree(b_dev_); if (wp_dev_) (void)hipFree(wp_dev_); if (zeros_dev_) (void)hipFree(zeros_dev_);
+    }
     const char* type() const override { return "DsvtConv2dPlugin"; }
     int nbOutputs() const override { return 1; }
     int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
@@ -265,6 +608,8 @@ public:
         a.out = out[0]; a.out_ld = c_.out_ld; a.out_coff = c_.out_coff; a.out_f32 = c_.out_f32;
         a.Ho = Ho(); a.Wo = Wo(); a.CoutRows = rows(); a.Cout = c_.Cout;
         a.KH = c_.KH; a.KW = c_.KW; a.stride = c_.stride; a.pad = c_.pad; a.up = c_.up; a.relu = c_.relu;
+        a.wide = !c_.out_f32 && c_.Cout % 16 == 0 && c_.out_ld % 8 == 0 && c_.out_coff % 8 == 0 && (!c_.has_res || a.res_ld % 8 == 0);
+        if (wp_dev_) return launchConvHalo(a, wp_dev_, zeros_dev_, stream);
         return launchConv(a, KC(), stream);
     }
     size_t serializationSize() const override { return 14 * sizeof(int) + sizeof(int) + sizeof(float) * (w_.size() + b_.size()); }

@@ -186,3 +186,32 @@ def test_fused_encoder_mlp_equals_linear_chain(pkg, block_ln):
     assert np.abs(g[:n] - r_[:n]).mean() < 2e-4
     assert not g[n:].any()
     assert np.abs(got_h[0, :n].float().cpu().numpy() - g[:n]).max() < 4e-3       # fp16 copy of the same result
+
+
+def test_linear_posembed_prologue_equals_two_launches(pkg):
+    """pe_weight / pe_bias: the K_in = 2 FC + BN + ReLU of the position-embedding MLP (src/dsvt-ai-trt.cpp:461-492)
+    evaluated in the operand prologue of the second FC == the two-launch chain with an fp16 intermediate."""
+    P = pkg.plugin
+    rng = np.random.default_rng(5)
+    MR, n, C = 8192, 5504, 192
+    xy = np.zeros((MR, 2), np.float32); xy[:n] = rng.uniform(-6, 6, (n, 2))
+    Wa = (rng.standard_normal((C, 2)) * 0.5).astype(np.float32); ba = (rng.standard_normal(C) * 0.2).astype(np.float32)
+    Wb = (rng.standard_normal((C, C)) / np.sqrt(C)).astype(np.float32); bb = (rng.standard_normal(C) * 0.1).astype(np.float32)
+    cnt = scalar(n)
+    h = P.add_linear_op(Wa, ba, MR, activation=P.ACT_RELU)(dev(xy[None]), cnt)[0]       # fp32 kernel (K = 2)
+    ref = host(P.add_linear_op(Wb, bb, MR, compute_type=P.COMPUTE_F16)(h, cnt)[0])[0]
+    fused = P.add_linear_op(Wb, bb, MR, compute_type=P.COMPUTE_F16, pe_weight=Wa, pe_bias=ba)
+    got = host(fused(dev(xy[None]), cnt)[0])[0]
+    scale = np.abs(ref[:n]).max()
+    # the hidden row is rounded to fp16 in both; fma contraction of the K = 2 dot product may move it by one fp16 ulp
+    assert np.abs(got[:n] - ref[:n]).max() < 2e-3 * scale
+    assert np.abs(got[:n] - ref[:n]).mean() < 1e-4 * scale
+    assert not got[n:].any()
+    # serialise -> deserialise -> same bytes and same result
+    blob = fused.serialize()
+    again = P.Plugin.deserialize("DsvtLinearPlugin", blob)
+    assert again.serialize() == blob
+    assert np.array_equal(host(again(dev(xy[None]), cnt)[0])[0], got)
+    # the prologue exists only in the fp16 kernel: the fp32 compute type refuses the fields
+    with pytest.raises(Exception):
+        P.add_linear_op(Wb, bb, MR, compute_type=P.COMPUTE_F32, pe_weight=Wa, pe_bias=ba)

@@ -82,3 +82,27 @@ def test_deconv_pixel_shuffle_and_concat(pkg, k, cin):
     got = buf[..., off:off + cout].permute(0, 3, 1, 2).float()
     assert (got - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
     assert (buf[..., :off] == 7.0).all() and (buf[..., off + cout:] == 7.0).all()     # other slices untouched
+
+
+@pytest.mark.parametrize("H,W,cin,cout,k,res", [
+    (468, 468, 128, 128, 3, True),      # 885 (8-row) / 705 (10-row) tiles over 256 CUs: every workgroup walks several items
+    (234, 234, 64, 320, 3, False),      # three 128-channel chunks per tile, the last one half full
+    (117, 117, 256, 256, 1, False),     # 1x1: no halo, one slab per 64-channel chunk
+])
+def test_conv_halo_kernel_full_size(pkg, H, W, cin, cout, k, res):
+    """The persistent halo-tile kernel at the BEV sizes (multi-item workgroups, ragged right / bottom tiles)."""
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(H + cin + cout + k)
+    x = torch.randn(1, cin, H, W, generator=g).half().to(DEV)
+    w = (torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)).half().to(DEV)
+    b = (torch.randn(cout, generator=g) * 0.1).to(DEV)
+    r = torch.randn(1, cout, H, W, generator=g).half().to(DEV) if res else None
+    ref = _ref(x, w, b, 1, k // 2, r, True)
+    op = P.add_conv2d_op(P.conv_weight_rows(w.float().cpu().numpy()), b.cpu().numpy(), H, W, cin, cout, k, 1, k // 2,
+                         relu=True, has_residual=res)
+    args = [nhwc(x)] + ([nhwc(r)] if res else [])
+    got = op(*args)[0].permute(0, 3, 1, 2).float()
+    torch.cuda.synchronize()
+    assert (got - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+    again = op(*args)[0].permute(0, 3, 1, 2).float()
+    assert torch.equal(got, again)
