@@ -287,30 +287,44 @@ typedef __attribute__((address_space(3))) void* glds_dst_t;
 
 // end of a K slab: this wave's LDS-DMA requests older than the youngest `keep` have landed, then the workgroup barrier
 // publishes them (LDS-DMA data is ordered for a ds_read only by the issuing wave's vmcnt followed by a barrier)
-template <int KEEP>
-__device__ __forceinline__ void slabBarrier() {
-    if (KEEP == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+__device__ __forceinline__ void slabBarrier(int keep) {
+    switch (keep) {          // wave-uniform
+        case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
 
-template <int TH, int KS>
+// CTW = 16-channel tiles per workgroup: 8 (128 output channels; wave (pg, cg) = 64 pixels x 64 channels) or 4 / 2
+// (layers with <= 64 / <= 32 output channels: both waves of a row pair use the same channel tiles and split the four
+// pixel tiles; a 16 KB weight slab then holds 2 / 4 taps, so the barrier cadence stays at 16 fragment rows)
+template <int TH, int KS, int CTW>
 __global__ void __launch_bounds__(64 * TH, 1)
 conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __restrict__ zeros, int tilesX, int nitems, int nchunk, int dbg)
 {
+    constexpr bool NARROW = CTW < 8;
     constexpr int HS = KS == 1 ? 32 : HHS;                          // LDS halo row stride in pixels (multiple of 8)
     constexpr int HH = TH + KS - 1, HWU = HTW + KS - 1, T = KS * KS, PAD = KS / 2;
+    constexpr int TPS = (8 / CTW) < T ? (8 / CTW) : T;              // taps per weight slab
+    constexpr int NG = (T + TPS - 1) / TPS;                         // slabs per 64-channel phase
+    constexpr int WROWS = TPS * 2 * CTW;                            // 1 KB fragment rows per slab (16, or 8 for a narrow 1x1)
+    constexpr int CTP = CTW < 4 ? CTW : 4;                          // channel tiles per wave
+    constexpr int NM = NARROW ? 2 : 4;                              // 16-pixel tiles per wave
     constexpr int HBYTES = HH * HS * 128, WBYTES = 16384;
     constexpr int NI = HH * HS / 8;                                 // 1 KB LDS-DMA instructions per halo (8 pixels x 128 B each)
     constexpr int HPW = (NI + TH - 1) / TH;                         // ... per wave
-    constexpr int WPW = (16 + TH - 1) / TH;                         // 1 KB instructions per wave per 16 KB weight slab
+    constexpr int WPW = (WROWS + TH - 1) / TH;                      // weight rows per wave per slab
     static_assert(KS == 1 || HPW <= T, "one halo request per tap");
     // ONE shared object: halo[2] | wslab[2]  (a second __shared__ object makes hipcc drain the DMA queue before every ds_read)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HBYTES + 2 * WBYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
     const int pg = wave >> 1, cg = wave & 1;
-    const int NCC = a.Cin >> 6, NCT = nchunk * 8;
+    const int NCC = a.Cin >> 6, NCT = NARROW ? CTW : nchunk * 8;
+    const int m0 = NARROW ? 2 * cg : 0, cgc = NARROW ? 0 : cg;       // first pixel tile / channel group of this wave
 
     // halo requests of this lane: request j of the wave covers LDS pixels 8(wave + j TH) .. +7; lane = (pixel, 16-byte slot)
     int hpos[HPW];
@@ -334,49 +348,51 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         ch = it % nchunk; const int t = it / nchunk;
         yy = (t / tilesX) * TH; xx = (t % tilesX) * HTW;
     };
-    auto haloRequest = [&](int j, int cc, int hb) {                   // wave-uniform j; returns nothing, one LDS-DMA
+    auto haloRequest = [&](int j, int cc, int hb) {                   // wave-uniform j: one LDS-DMA of 1 KB
         const _Float16* src = goff[j] >= 0 ? a.in + goff[j] + cc * 64 : zeros;
         __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + hb * HBYTES + (wave + j * TH) * 1024), 16, 0, 0);
     };
-    auto weightRequests = [&](int q0, int ch, int wb) {
+    auto weightRequests = [&](int q0, int ch, int wb) {               // slab starting at k-step q0 (= 2 (cc T + tap))
 #pragma unroll
         for (int j = 0; j < WPW; ++j) {
             const int u = wave + j * TH;
-            if (16 % TH == 0 || u < 16) {
-                const _Float16* src = Wp + (((size_t)(q0 + (u >> 3)) * NCT + ch * 8 + (u & 7)) * 64 + lane) * 8;
-                __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + 2 * HBYTES + wb * WBYTES + u * 1024), 16, 0, 0);
+            if (WROWS % TH == 0 || u < WROWS) {
+                const size_t row = NARROW ? (size_t)q0 * CTW + u : (size_t)(q0 + (u >> 3)) * NCT + ch * 8 + (u & 7);
+                __builtin_amdgcn_global_load_lds((glds_src_t)(Wp + (row * 64 + lane) * 8), (glds_dst_t)(smem + 2 * HBYTES + wb * WBYTES + u * 1024), 16, 0, 0);
             }
         }
     };
 
-    int pbase[4];
+    int pbase[NM];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) pbase[m] = ((2 * pg + (m >> 1)) * HS + (m & 1) * 16 + r) * 128;
+    for (int m = 0; m < NM; ++m) pbase[m] = ((2 * pg + ((m0 + m) >> 1)) * HS + ((m0 + m) & 1) * 16 + r) * 128;
     int swz[KS];
 #pragma unroll
     for (int kx = 0; kx < KS; ++kx) swz[kx] = (g ^ ((r + kx) & 7)) << 4;
 
-    floatx4 acc[4][4];
+    floatx4 acc[CTP][NM];
+    auto tilesOf = [&](int ch) {                                      // valid 16-channel tiles of this wave in chunk ch
+        int n = (a.CoutRows - ch * CNB + 15) / 16 - cgc * 4;
+        return n < 0 ? 0 : n > CTP ? CTP : n;
+    };
     // bias / residual / ReLU / store of a finished item (tile origin ey, ex; 128-channel chunk ech)
     auto epilogue = [&](int ey, int ex, int ech) {
-        const int n0 = ech * CNB;
-        int ctn = (a.CoutRows - n0 + 15) / 16 - cg * 4;
-        ctn = ctn < 0 ? 0 : ctn > 4 ? 4 : ctn;
+        const int n0 = ech * CNB, ctn = tilesOf(ech);
         const int sub = n0 / a.Cout, dy = sub / a.up, dx = sub - dy * a.up, cbase = n0 - sub * a.Cout;
         const int Wout = a.Wo * a.up;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int oy = ey + 2 * pg + (m >> 1), ox = ex + (m & 1) * 16 + r;
+        for (int m = 0; m < NM; ++m) {
+            const int oy = ey + 2 * pg + ((m0 + m) >> 1), ox = ex + ((m0 + m) & 1) * 16 + r;
             const bool valid = oy < a.Ho && ox < a.Wo;
             const size_t opix = valid ? (size_t)(oy * a.up + dy) * Wout + (ox * a.up + dx) : 0;
             if (a.wide) {
 #pragma unroll
-                for (int t0 = 0; t0 < 4; t0 += 2)
-                    if (t0 < ctn) convStoreWide(a, acc[t0][m], acc[t0 + 1][m], valid, opix, cbase + cg * 64 + t0 * 16, g);
+                for (int t0 = 0; t0 + 1 < CTP; t0 += 2)
+                    if (t0 < ctn) convStoreWide(a, acc[t0][m], acc[t0 + 1][m], valid, opix, cbase + cgc * 64 + t0 * 16, g);
             } else if (valid) {
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-                    if (ct < ctn) convStore(a, acc[ct][m], opix, cbase + cg * 64 + ct * 16 + 4 * g);
+                for (int ct = 0; ct < CTP; ++ct)
+                    if (ct < ctn) convStore(a, acc[ct][m], opix, cbase + cgc * 64 + ct * 16 + 4 * g);
             }
         }
     };
@@ -390,13 +406,11 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     for (int j = 0; j < HPW; ++j)
         if (NI % TH == 0 || wave + j * TH < NI) haloRequest(j, 0, 0);
     weightRequests(0, chunk, 0);
-    slabBarrier<0>();
+    slabBarrier(0);
     int hb = 0, wb = 0;
     bool pending = false; int ey = 0, ex = 0, ech = 0;          // finished item whose epilogue has not run yet
     for (;;) {
-        const int n0 = chunk * CNB;
-        int ctn = (a.CoutRows - n0 + 15) / 16 - cg * 4;           // valid 16-channel tiles of this wave
-        ctn = ctn < 0 ? 0 : ctn > 4 ? 4 : ctn;
+        const int ctn = tilesOf(chunk);
         int nitem = item, ny0 = y0, nx0 = x0, nch = chunk;
         bool have_next = true;
         for (int cc = 0; cc < NCC; ++cc) {
@@ -406,23 +420,28 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                 if (have_next) { decode(nitem, ny0, nx0, nch); setup(ny0, nx0); }
             }
             const bool haloNext = have_next && !(dbg & 1);
+            int nreq = 0;                                        // halo requests issued after the current slab's weight requests
 #pragma unroll
             for (int tap = 0; tap < T; ++tap) {
-                const bool lastTap = tap == T - 1;
-                const bool moreW = (!lastTap || have_next) && !(dbg & 2);
-                if (tap == 0 && cc == 0) {
-                    // epilogue of the previous item first: its stores are the oldest requests of this slab and have the
-                    // whole MFMA block to complete
-                    if (pending && !(dbg & 8)) epilogue(ey, ex, ech);
+                constexpr int dummy = 0; (void)dummy;
+                const int tl = tap % TPS, grp = tap / TPS;
+                const bool lastTap = tap == T - 1, endOfSlab = tl == TPS - 1 || lastTap, lastGroup = grp == NG - 1;
+                if (tl == 0) {
+                    if (tap == 0 && cc == 0) {
+                        // epilogue of the previous item first: its stores are the oldest requests of this slab and have the
+                        // whole MFMA block to complete
+                        if (pending && !(dbg & 8)) epilogue(ey, ex, ech);
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct)
+                        for (int ct = 0; ct < CTP; ++ct)
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) acc[ct][m] = floatx4{0.f, 0.f, 0.f, 0.f};
+                            for (int m = 0; m < NM; ++m) acc[ct][m] = floatx4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    if ((!lastGroup || have_next) && !(dbg & 2))
+                        weightRequests(lastGroup ? ncc * T * 2 : (cc * T + (grp + 1) * TPS) * 2, lastGroup ? nch : chunk, wb ^ 1);
+                    nreq = 0;
                 }
-                if (moreW) weightRequests(lastTap ? ncc * T * 2 : (cc * T + tap + 1) * 2, lastTap ? nch : chunk, wb ^ 1);
                 // the next halo is requested AFTER this slab's weight requests, one per tap: the slab-end wait (in-order
-                // counter, vmcnt(1)) retires the weights and leaves the halo request in flight across the barrier
-                bool haloInFlight = false;
+                // counter, vmcnt(nreq)) retires the weights and leaves the halo requests in flight across the barrier
                 if (KS == 1) {
                     if (haloNext) {
 #pragma unroll
@@ -432,33 +451,38 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                 } else if (tap < HPW) {
                     if (haloNext && (NI % TH == 0 || wave + (tap < HPW ? tap : 0) * TH < NI)) {
                         haloRequest(tap < HPW ? tap : 0, ncc, hb ^ 1);
-                        haloInFlight = !lastTap;
+                        ++nreq;
                     }
                 }
                 const unsigned char* hbp = smem + hb * HBYTES;
-                const unsigned char* wbp = smem + 2 * HBYTES + wb * WBYTES + ((cg * 4 * 64 + lane) << 4);
+                const unsigned char* wbp = smem + 2 * HBYTES + wb * WBYTES + (lane << 4);
                 const int ky = tap / KS, kx = tap - ky * KS;
                 const int toff = (ky * HS + kx) * 128;
                 const int sw = swz[kx];
                 auto slab = [&](auto full) {
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        half8 A[4], B[4];
+                        half8 A[CTP], B[NM];
 #pragma unroll
-                        for (int ct = 0; ct < 4; ++ct) A[ct] = *reinterpret_cast<const half8*>(wbp + ((ks * 8 + ct) << 10));
+                        for (int ct = 0; ct < CTP; ++ct) {
+                            const int row = NARROW ? (tl * 2 + ks) * CTW + ct : ks * 8 + ct;
+                            A[ct] = *reinterpret_cast<const half8*>(wbp + ((row + (NARROW ? 0 : cgc * 4)) << 10));
+                        }
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) B[m] = *reinterpret_cast<const half8*>(hbp + pbase[m] + toff + (sw ^ (ks << 6)));
+                        for (int m = 0; m < NM; ++m) B[m] = *reinterpret_cast<const half8*>(hbp + pbase[m] + toff + (sw ^ (ks << 6)));
 #pragma unroll
-                        for (int ct = 0; ct < 4; ++ct)
+                        for (int ct = 0; ct < CTP; ++ct)
                             if (decltype(full)::value || ct < ctn)
 #pragma unroll
-                                for (int m = 0; m < 4; ++m)
+                                for (int m = 0; m < NM; ++m)
                                     acc[ct][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ct], B[m], acc[ct][m], 0, 0, 0);
                     }
                 };
-                if (dbg & 4) {} else if (ctn == 4) slab(std::true_type{}); else slab(std::false_type{});
-                if (haloInFlight) slabBarrier<1>(); else slabBarrier<0>();
-                wb ^= 1;
+                if (dbg & 4) {} else if (ctn == CTP) slab(std::true_type{}); else slab(std::false_type{});
+                if (endOfSlab) {
+                    slabBarrier(lastTap ? 0 : nreq);             // the phase's last barrier also publishes the next halo
+                    wb ^= 1;
+                }
             }
             hb ^= 1;
         }
@@ -469,6 +493,9 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     if (!(dbg & 8)) epilogue(ey, ex, ech);
 }
 
+// 16-channel tiles per workgroup of the halo kernel (and of its packed weights)
+static int haloChannelTiles(int coutRows) { return coutRows <= 32 ? 2 : coutRows <= 64 ? 4 : 8; }
+
 static int numCUs() {
     static int n = 0;
     if (!n) { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); n = hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }
@@ -477,7 +504,7 @@ static int numCUs() {
 
 // tile height of the halo kernel: the (rounds of items over the CUs) x (tile height) product is the makespan
 static int haloTileRows(const ConvArgs& a) {
-    if (const char* e = getenv("DSVT_CONV_TH")) { const int t = atoi(e); if (t == 4 || t == 8 || t == 10) return t; }
+    if (const char* e = getenv("DSVT_CONV_TH")) { const int t = atoi(e); if (t == 4 || t == 8) return t; }
     const int nchunk = cdiv(a.CoutRows, CNB), cus = numCUs();
     int best = 8; long bestCost = -1;
     for (int th : {8, 4}) {          // the 10-row instantiation exceeds 168 VGPRs (10 waves => 3 waves on two SIMDs) and spills
@@ -499,9 +526,12 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
     if (gridCap < 0) { const char* e = getenv("DSVT_CONV_GRID"); gridCap = e ? atoi(e) : 0; }      // test knob: force multi-item workgroups
     int grid = nitems < numCUs() ? nitems : numCUs();
     if (gridCap > 0 && grid > gridCap) grid = gridCap;
-#define DSVT_HALO_LAUNCH(TH_, KS_) hipLaunchKernelGGL((conv_halo_kernel<TH_, KS_>), dim3(grid), dim3(64 * TH_), 0, stream, a, Wp, zeros, tilesX, nitems, nchunk, dbg)
-    if (a.KH == 3) { if (th == 10) DSVT_HALO_LAUNCH(10, 3); else if (th == 8) DSVT_HALO_LAUNCH(8, 3); else DSVT_HALO_LAUNCH(4, 3); }
-    else           { if (th == 10) DSVT_HALO_LAUNCH(10, 1); else if (th == 8) DSVT_HALO_LAUNCH(8, 1); else DSVT_HALO_LAUNCH(4, 1); }
+#define DSVT_HALO_LAUNCH(TH_, KS_, CTW_) hipLaunchKernelGGL((conv_halo_kernel<TH_, KS_, CTW_>), dim3(grid), dim3(64 * TH_), 0, stream, a, Wp, zeros, tilesX, nitems, nchunk, dbg)
+#define DSVT_HALO_TH(KS_, CTW_) do { if (th == 8) DSVT_HALO_LAUNCH(8, KS_, CTW_); else DSVT_HALO_LAUNCH(4, KS_, CTW_); } while (0)
+    const int ctw = haloChannelTiles(a.CoutRows);
+    if (a.KH == 3) { if (ctw == 8) DSVT_HALO_TH(3, 8); else if (ctw == 4) DSVT_HALO_TH(3, 4); else DSVT_HALO_TH(3, 2); }
+    else           { if (ctw == 8) DSVT_HALO_TH(1, 8); else if (ctw == 4) DSVT_HALO_TH(1, 4); else DSVT_HALO_TH(1, 2); }
+#undef DSVT_HALO_TH
 #undef DSVT_HALO_LAUNCH
     return lastError();
 }
@@ -563,9 +593,11 @@ public:
         if (ok_ && b) ok_ = hipMalloc(&b_dev_, sizeof(float) * c.Cout) == hipSuccess &&
                             hipMemcpy(b_dev_, b_.data(), sizeof(float) * c.Cout, hipMemcpyHostToDevice) == hipSuccess;
         if (ok_ && haloEligible()) {
-            // [k-step q = (cc * taps + tap) * 2 + ks][16-channel tile ct][lane (r, g)][8] <- W[ct*16 + r][tap][cc*64 + ks*32 + g*8 + j]
-            const int T = c.KH * c.KW, NCC = c.Cin / 64, NCT = cdiv(rows(), CNB) * 8, R = rows();
-            std::vector<_Float16> wp((size_t)NCC * T * 2 * NCT * 512, (_Float16)0.f);
+            // [k-step q = (cc * taps + tap) * 2 + ks][16-channel tile ct][lane (r, g)][8] <- W[ct*16 + r][tap][cc*64 + ks*32 + g*8 + j];
+            // one 16 KB slab of zero padding at the end: the last slab of a narrow layer is requested whole
+            const int T = c.KH * c.KW, NCC = c.Cin / 64, R = rows(), ctw = haloChannelTiles(R);
+            const int NCT = ctw < 8 ? ctw : cdiv(R, CNB) * 8;
+            std::vector<_Float16> wp((size_t)NCC * T * 2 * NCT * 512 + 8192, (_Float16)0.f);
             for (int cc = 0; cc < NCC; ++cc)
                 for (int tap = 0; tap < T; ++tap)
                     for (int ks = 0; ks < 2; ++ks)
