@@ -20,6 +20,7 @@ SOURCES = [
     ("attention.hip", []),
     ("conv.hip", []),
     ("mlp.hip", []),
+    ("decode.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math",
           "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]

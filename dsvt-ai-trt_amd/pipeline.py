@@ -228,6 +228,7 @@ class DsvtPipeline:
             o += no
         ops["heads1"] = P.add_conv2d_op(cw(W1), b1, GY, GX, 320, 18, 3, 1, 1, out_f32=True)
         self.cat_bev = torch.zeros((1, GY, GX, 384), dtype=torch.float16, device=self.device)
+        self.topk = P.add_center_head_topk_op(GY, GX, 18, 10, TOP_K)      # decode on the device
 
     def _bev_hip(self, x):
         """x: [1, 468, 468, 192] fp16 NHWC -> [1, 468, 468, 18] fp32 NHWC (center2 cz1 dim3 rot2 hm10)"""
@@ -337,7 +338,7 @@ class DsvtPipeline:
         src = self._xh if (self.f16 and self.head_dtype == torch.float16) else x
         bev = self.map2bev(src, st["coords"], st["P"])[0]             # [1, 468(y), 468(x), 192] NHWC
         if self.hip_head:
-            return self.filter(*self._decode_nhwc(self._bev_hip(bev)))
+            return self.filter(*self.topk(self._bev_hip(bev)))
         bev = bev.permute(0, 3, 1, 2)                                 # NCHW view of channels-last memory (:1131-1133)
         if bev.dtype != self.head_dtype:
             bev = bev.to(self.head_dtype)

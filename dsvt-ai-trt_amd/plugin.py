@@ -386,6 +386,16 @@ def add_gelu_op(max_pillars_num, channel_num):
     return Plugin("GeluPlugin", dict(max_pillars_num=max_pillars_num, channel_num=channel_num), "gelu_layer")
 
 
+def add_center_head_topk_op(feature_height, feature_width, channel_num=18, class_num=10, max_top_k=500,
+                            center_offset=0, center_z_offset=2, dim_offset=3, rot_offset=6, hm_offset=8):
+    """CenterHead decode (src/dsvt-ai-trt.cpp:1479-1669: sigmoid, two-stage TopK, gathers, exp, atan) on the device.
+    Input: head tensor [1,H,W,C] fp32 channels-last.  Outputs: the eight inputs of FilterBoxByScorePlugin."""
+    return Plugin("CenterHeadTopKPlugin", dict(feature_height=feature_height, feature_width=feature_width, channel_num=channel_num,
+                                               class_num=class_num, max_top_k=max_top_k, center_offset=center_offset,
+                                               center_z_offset=center_z_offset, dim_offset=dim_offset, rot_offset=rot_offset,
+                                               hm_offset=hm_offset), "center_head_topk_layer")
+
+
 def add_filter_box_by_score_op(max_top_k, min_x_range, max_x_range, min_y_range, max_y_range, min_z_range,
                                max_z_range, voxel_x_size, voxel_y_size, voxel_z_size, score_threshold):
     """plugin_helper.h:607-678.  Inputs: scores, classes, xs, ys, center, center_z, angle, dim."""

@@ -317,3 +317,62 @@ def test_filter_box_by_score(pkg, oracle):
         assert int(host(o2[1])[0]) == c2 and np.array_equal(host(o2[0])[0], e2)
         if expect is not None:
             assert c2 == expect
+
+
+def _torch_decode(o, W, K):
+    """the TensorRT layer sequence of src/dsvt-ai-trt.cpp:1479-1669 in torch (two-stage TopK on sigmoid scores)"""
+    of = o.reshape(-1, 18)
+    hm = torch.sigmoid(of[:, 8:18].t().contiguous())
+    k1 = min(K, hm.shape[1])
+    sc1, idx1 = torch.topk(hm, k1, dim=1)
+    sc2, idx2 = torch.topk(sc1.reshape(-1), K)
+    cls = idx2 // k1
+    ind = idx1.reshape(-1)[idx2]
+    g = of[ind]
+    return dict(score=sc2, cls=cls, xs=ind % W, ys=ind // W, center=g[:, 0:2], z=g[:, 2], dim=torch.exp(g[:, 3:6]),
+                angle=torch.atan(g[:, 7] / g[:, 6]))
+
+
+@pytest.mark.parametrize("H,W,K", [(468, 468, 500), (37, 53, 500), (8, 8, 500), (5, 7, 500)])
+def test_center_head_topk_matches_two_stage_topk(pkg, H, W, K):
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(H * W)
+    o = torch.randn(1, H, W, 18, generator=g)
+    o[..., 8:18] = o[..., 8:18] * 0.6 - 1.8                  # heat-map logits like the synthetic head's
+    o = o.to("cuda:0")
+    op = P.add_center_head_topk_op(H, W, 18, 10, K)
+    sc, cls, xs, ys, center, cz, ang, dim = op(o)
+    torch.cuda.synchronize()
+    n = min(K, H * W * 10)
+    ref = _torch_decode(o, W, n)
+    assert torch.all(sc[0, :-1] >= sc[0, 1:])                # descending
+    assert (sc[0, :n] - ref["score"]).abs().max().item() < 1e-6
+    # random logits: no ties among the winners => the same (class, cell) sequence
+    assert torch.equal(cls[0, :n].long(), ref["cls"]) and torch.equal(xs[0, :n].long(), ref["xs"]) and torch.equal(ys[0, :n].long(), ref["ys"])
+    assert torch.equal(center[0, 0, :n], ref["center"]) and torch.equal(cz[0, 0, :n, 0], ref["z"])
+    assert (dim[0, 0, :n] - ref["dim"]).abs().max().item() < 1e-5 * ref["dim"].abs().max().item()
+    assert (ang[0, 0, :n, 0] - ref["angle"]).abs().max().item() < 1e-6
+    if n < K:
+        assert not sc[0, n:].any()
+    sc2 = op(o)[0]
+    assert torch.equal(sc, sc2)                              # reproducible
+
+
+def test_center_head_topk_degenerate_heat_map(pkg):
+    """all logits equal except a few: the threshold bin holds > 65536 elements (two-level refinement + truncation);
+    the distinct large ones must come first, the rest are ties at the common score, in ascending index order."""
+    P = pkg.plugin
+    H = W = 200
+    o = torch.zeros(1, H, W, 18)
+    o[..., 8:18] = -2.0
+    flat = o.reshape(-1, 18)
+    picks = [(7, 3, 1.5), (39999, 9, 0.7), (123, 0, 0.2)]     # (cell, class, logit)
+    for cell, c, v in picks:
+        flat[cell, 8 + c] = v
+    o = o.to("cuda:0")
+    sc, cls, xs, ys = P.add_center_head_topk_op(H, W, 18, 10, 500)(o)[:4]
+    torch.cuda.synchronize()
+    exp = torch.sigmoid(torch.tensor([1.5, 0.7, 0.2, -2.0]))
+    assert (sc[0, :3].cpu() - exp[:3]).abs().max() < 1e-6 and (sc[0, 3:].cpu() - exp[3]).abs().max() < 1e-6
+    assert cls[0, :3].tolist() == [3, 9, 0]
+    assert (ys[0, :3] * W + xs[0, :3]).tolist() == [7, 39999, 123]
