@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--event-every", type=int, default=20,
                     help="every N-th timed step runs un-graphed with HIP events around each linear launch (roofline sample)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-nms", action="store_true", help="stop at FilterBoxByScore (the reference engine's output) instead of the final boxes")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline = null)")
     args = ap.parse_args()
 
@@ -106,7 +107,8 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
     pipes = [pkg.pipeline.DsvtPipeline(weights, caps=caps, device=dev,
                                        linear_compute=pkg.plugin.COMPUTE_F16 if f16 else pkg.plugin.COMPUTE_F32,
-                                       head_dtype=torch.float16 if f16 else torch.float32) for _ in range(NS)]
+                                       head_dtype=torch.float16 if f16 else torch.float32, device_nms=not args.no_nms)
+             for _ in range(NS)]
     pipe = pipes[0]
 
     # synthetic frames of this rank, resident in HBM before the timed region

@@ -21,6 +21,7 @@ SOURCES = [
     ("conv.hip", []),
     ("mlp.hip", []),
     ("decode.hip", []),
+    ("nms.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math",
           "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]

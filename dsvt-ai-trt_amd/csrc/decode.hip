@@ -155,10 +155,13 @@ topk_decode(const float* __restrict__ head, TopKParams p, const uint32_t* __rest
         }
     }
     __syncthreads();
-    // bitonic sort, descending, 4096 entries, 1024 threads x 2 compare-exchanges per step
-    for (int k = 2; k <= TK_SORT; k <<= 1)
+    // bitonic sort, descending, of the smallest power of two >= the number of candidates (the rest of sk is zero = lowest)
+    uint32_t tot = (Ma + Me <= TK_SORT) ? Ma + Me : (nsel < TK_SORT ? nsel : TK_SORT);
+    int NS = 512;
+    while (NS < (int)tot) NS <<= 1;
+    for (int k = 2; k <= NS; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int q = t; q < TK_SORT / 2; q += 1024) {
+            for (int q = t; q < NS / 2; q += 1024) {
                 const int lo = ((q & ~(j - 1)) << 1) | (q & (j - 1)), hi = lo | j;
                 const bool desc = (lo & k) == 0;
                 const unsigned long long a = sk[lo], b = sk[hi];

@@ -1,0 +1,297 @@
+// nms.hip -- RotatedNmsPlugin: the reference's host-side rotated BEV NMS on the device.
+//
+// SURVEY.md section 8(f)-2, second half.  The reference copies FilterBoxByScorePlugin's rows to the
+// host and runs nms_cpu (include/helper.h:257-283) on them: sort by score, then greedily keep a box
+// and drop every later box whose rotated-rectangle IoU with it is >= NMS_THRESH (0.01, class
+// agnostic; params.h:334).  box_overlap (helper.h:166-255) clips the two rectangles by collecting
+// edge intersections + contained corners, ordering them by atan2 around their centroid and summing
+// the fan triangles.  The arithmetic below is that code line by line in fp32 (cos / sin / atan2 in
+// double like the host's, the file is built with -ffp-contract=off); the only shortcut is that a pair
+// whose centres are farther apart than the two half diagonals (+ margin) skips it, which is exactly the
+// case where the reference finds no intersection point and no contained corner and returns 0.
+//
+//   nms_sort   one workgroup: stable order of the n <= 512 rows by descending score (bitonic, LDS)
+//   nms_mask   one wave per (row j, 64-row word): bit i = IoU(i, j) >= thresh for i < j (ballot) -- the transposed mask
+//   nms_scan   mask in LDS; one wave sweeps 64 rows at a time (suppression by earlier blocks is a parallel test
+//              against their kept sets, the walk inside a block is register-only), then the kept rows are
+//              written in score order
+// Outputs: rows [1, max_boxes, 9] (the input row of every kept box, i.e. x, y, z, l, w, h, rt, id,
+// score as helper.h:452-460 prints them), keep_idx [1, max_boxes] (input row numbers), count [1].
+#include "plugin_base.h"
+#include "device_utils.h"
+
+namespace dsvt {
+
+static bool f32Lin(const DsvtPluginTensorDesc& t) { return t.type == DSVT_FLOAT && t.format == DSVT_FORMAT_LINEAR; }
+static bool i32Lin(const DsvtPluginTensorDesc& t) { return t.type == DSVT_INT32 && t.format == DSVT_FORMAT_LINEAR; }
+
+constexpr int NMS_MAX = 512, NMS_WORDS = NMS_MAX / 64;
+constexpr float kThresHold = 1e-8f;                                  // helper.h:26
+
+struct Bnd { float x, y, z, w, l, h, rt; int id; float score; };     // helper.h:93-106
+struct F2 { float x, y; };
+
+__device__ __forceinline__ Bnd rowToBox(const float* o) {            // src/dsvt-ai-trt.cpp:1940-1950: dim0 -> l, dim1 -> w
+    return Bnd{o[0], o[1], o[2], o[4], o[3], o[5], o[6], (int)o[7], o[8]};
+}
+__device__ __forceinline__ float crossf(F2 p1, F2 p2, F2 p0) { return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y); }   // :109-111
+
+__device__ __forceinline__ bool checkBox2d(const Bnd& box, F2 p) {   // :113-123
+    const float MARGIN = 1e-2f;
+    const float angle_cos = (float)cos((double)-box.rt), angle_sin = (float)sin((double)-box.rt);
+    const float rot_x = (p.x - box.x) * angle_cos + (p.y - box.y) * (-angle_sin);
+    const float rot_y = (p.x - box.x) * angle_sin + (p.y - box.y) * angle_cos;
+    return fabsf(rot_x) < box.w / 2 + MARGIN && fabsf(rot_y) < box.l / 2 + MARGIN;
+}
+
+__device__ __forceinline__ bool intersection(F2 p1, F2 p0, F2 q1, F2 q0, F2& ans) {   // :125-156
+    if (!(fminf(p0.x, p1.x) <= fmaxf(q0.x, q1.x) && fminf(q0.x, q1.x) <= fmaxf(p0.x, p1.x) &&
+          fminf(p0.y, p1.y) <= fmaxf(q0.y, q1.y) && fminf(q0.y, q1.y) <= fmaxf(p0.y, p1.y)))
+        return false;
+    const float s1 = crossf(q0, p1, p0), s2 = crossf(p1, q1, p0), s3 = crossf(p0, q1, q0), s4 = crossf(q1, p1, q0);
+    if (!(s1 * s2 > 0 && s3 * s4 > 0)) return false;
+    const float s5 = crossf(q1, p1, p0);
+    if (fabsf(s5 - s1) > kThresHold) {
+        ans.x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+        ans.y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+    } else {
+        const float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+        const float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+        const float D = a0 * b1 - a1 * b0;
+        ans.x = (b0 * c1 - b1 * c0) / D;
+        ans.y = (a1 * c0 - a0 * c1) / D;
+    }
+    return true;
+}
+
+__device__ __forceinline__ void rotateAround(F2 c, float ac, float as, F2& p) {       // :158-163
+    const float nx = (p.x - c.x) * ac + (p.y - c.y) * (-as) + c.x;
+    const float ny = (p.x - c.x) * as + (p.y - c.y) * ac + c.y;
+    p.x = nx; p.y = ny;
+}
+
+__device__ float boxOverlap(const Bnd& a, const Bnd& b) {            // :166-255
+    const float a_dx = a.w / 2, b_dx = b.w / 2, a_dy = a.l / 2, b_dy = b.l / 2;
+    F2 ac[5], bc[5], cp[24], pc = {0.f, 0.f};          // the host's cross_points[16] cannot hold the 16 + 8 worst case either
+    const F2 ca = {a.x, a.y}, cb = {b.x, b.y};
+    int cnt = 0;
+    ac[0] = F2{a.x - a_dx, a.y - a_dy}; ac[1] = F2{a.x + a_dx, a.y - a_dy}; ac[2] = F2{a.x + a_dx, a.y + a_dy}; ac[3] = F2{a.x - a_dx, a.y + a_dy};
+    bc[0] = F2{b.x - b_dx, b.y - b_dy}; bc[1] = F2{b.x + b_dx, b.y - b_dy}; bc[2] = F2{b.x + b_dx, b.y + b_dy}; bc[3] = F2{b.x - b_dx, b.y + b_dy};
+    const float a_cos = (float)cos((double)a.rt), a_sin = (float)sin((double)a.rt);
+    const float b_cos = (float)cos((double)b.rt), b_sin = (float)sin((double)b.rt);
+    for (int k = 0; k < 4; ++k) { rotateAround(ca, a_cos, a_sin, ac[k]); rotateAround(cb, b_cos, b_sin, bc[k]); }
+    ac[4] = ac[0]; bc[4] = bc[0];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            if (intersection(ac[i + 1], ac[i], bc[j + 1], bc[j], cp[cnt])) { pc.x += cp[cnt].x; pc.y += cp[cnt].y; ++cnt; }
+    for (int k = 0; k < 4; ++k) {
+        if (checkBox2d(a, bc[k])) { pc.x += bc[k].x; pc.y += bc[k].y; cp[cnt++] = bc[k]; }
+        if (checkBox2d(b, ac[k])) { pc.x += ac[k].x; pc.y += ac[k].y; cp[cnt++] = ac[k]; }
+    }
+    if (cnt == 0) return 0.f;                                        // reference: 0/0 centroid, empty fan, area 0
+    pc.x /= cnt; pc.y /= cnt;
+    double ang[24];                                                  // the host recomputes atan2 inside every comparison; same values
+    for (int i = 0; i < cnt; ++i) ang[i] = atan2((double)(cp[i].y - pc.y), (double)(cp[i].x - pc.x));
+    for (int j = 0; j < cnt - 1; ++j)
+        for (int i = 0; i < cnt - j - 1; ++i)
+            if (ang[i] > ang[i + 1]) {
+                const F2 t = cp[i]; cp[i] = cp[i + 1]; cp[i + 1] = t;
+                const double ta = ang[i]; ang[i] = ang[i + 1]; ang[i + 1] = ta;
+            }
+    float area = 0.f;
+    for (int k = 0; k < cnt - 1; ++k) {
+        const F2 u = {cp[k].x - cp[0].x, cp[k].y - cp[0].y}, v = {cp[k + 1].x - cp[0].x, cp[k + 1].y - cp[0].y};
+        area += (u.x * v.y - u.y * v.x);
+    }
+    return (float)(fabs((double)area) / 2.0);
+}
+
+// ---- kernels -------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512)
+nms_sort(const float* __restrict__ rows, const uint32_t* __restrict__ count, int max_boxes, uint32_t* __restrict__ order)
+{
+    __shared__ unsigned long long sk[NMS_MAX];       // (score key << 32) | ~row : descending = score desc, row asc (stable)
+    const int t = threadIdx.x;
+    int n = (int)*count; if (n > max_boxes) n = max_boxes;
+    unsigned long long e = 0ull;
+    if (t < n) {
+        const uint32_t u = __float_as_uint(rows[(size_t)t * 9 + 8]);
+        const uint32_t key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        e = ((unsigned long long)key << 32) | (uint32_t)~(uint32_t)t;
+    }
+    sk[t] = e;
+    __syncthreads();
+    for (int k = 2; k <= NMS_MAX; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (t < NMS_MAX / 2) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                const bool desc = (lo & k) == 0;
+                const unsigned long long a = sk[lo], b = sk[hi];
+                if ((a < b) == desc && a != b) { sk[lo] = b; sk[hi] = a; }
+            }
+            __syncthreads();
+        }
+    if (t < n) order[t] = ~(uint32_t)sk[t];
+}
+
+// word (j, wi) of the TRANSPOSED suppression matrix: bit b = "sorted row i = 64 wi + b (i < j) suppresses sorted row j"
+__global__ void __launch_bounds__(64)
+nms_mask(const float* __restrict__ rows, const uint32_t* __restrict__ count, const uint32_t* __restrict__ order, int max_boxes,
+         float thresh, unsigned long long* __restrict__ maskT)
+{
+    int n = (int)*count; if (n > max_boxes) n = max_boxes;
+    const int j = blockIdx.x, wi = blockIdx.y, lane = threadIdx.x, i = wi * 64 + lane;
+    if (j >= n) return;
+    bool sup = false;
+    if (i < j) {
+        const Bnd bi = rowToBox(rows + (size_t)order[i] * 9), bj = rowToBox(rows + (size_t)order[j] * 9);
+        // centres farther apart than both half diagonals + the containment margin: no intersection point, no contained corner
+        const float dx = bi.x - bj.x, dy = bi.y - bj.y;
+        const float ri = 0.5f * sqrtf(bi.w * bi.w + bi.l * bi.l), rj = 0.5f * sqrtf(bj.w * bj.w + bj.l * bj.l);
+        const float reach = ri + rj + 0.1f;
+        if (dx * dx + dy * dy <= reach * reach) {
+            const float sa = bi.w * bi.l, sb = bj.w * bj.l;                        // helper.h:272-275 (i is the kept box, j the later one)
+            const float so = boxOverlap(bi, bj);
+            const float iou = so / fmaxf(sa + sb - so, kThresHold);
+            sup = iou >= thresh;
+        }
+    }
+    const unsigned long long word = __ballot(sup);
+    if (lane == 0) maskT[(size_t)j * NMS_WORDS + wi] = word;
+}
+
+__global__ void __launch_bounds__(512)
+nms_scan(const float* __restrict__ rows, const uint32_t* __restrict__ count, const uint32_t* __restrict__ order,
+         const unsigned long long* __restrict__ maskT, int max_boxes, float* __restrict__ out_rows, int32_t* __restrict__ keep_idx,
+         uint32_t* __restrict__ out_count, bool zero_fill)
+{
+    __shared__ unsigned long long sm[NMS_MAX * NMS_WORDS];
+    __shared__ unsigned long long keptw[NMS_WORDS];
+    __shared__ uint32_t kept[NMS_MAX];
+    const int t = threadIdx.x, lane = t & 63;
+    int n = (int)*count; if (n > max_boxes) n = max_boxes;
+    {                                                // all loads of the mask in flight at once (8 per thread)
+        unsigned long long v[NMS_WORDS];
+#pragma unroll
+        for (int u = 0; u < NMS_WORDS; ++u) { const int e = t + u * 512; v[u] = e < n * NMS_WORDS ? maskT[e] : 0ull; }
+#pragma unroll
+        for (int u = 0; u < NMS_WORDS; ++u) sm[t + u * 512] = v[u];
+    }
+    __syncthreads();
+    if (t < 64) {
+        // Greedy sweep (helper.h:260-281), 64 sorted rows at a time, one wave.  Lane = row j of the block.  Whether an
+        // EARLIER block suppresses j is a parallel test of j's transposed mask words against the kept sets of those blocks;
+        // inside the block the walk is serial but register-only: row j is kept unless suppressed from outside or by a
+        // row kept earlier in this block (its own word of the block, fetched with v_readlane).
+        unsigned long long ks[NMS_WORDS];            // kept set, wave-uniform
+#pragma unroll
+        for (int w = 0; w < NMS_WORDS; ++w) ks[w] = 0ull;
+#pragma unroll
+        for (int w = 0; w < NMS_WORDS; ++w) {
+            const int base = w * 64;
+            if (base < n) {
+                const int nb = n - base < 64 ? n - base : 64;
+                const int j = base + lane;
+                unsigned long long pre = 0ull;
+#pragma unroll
+                for (int wi = 0; wi < NMS_WORDS; ++wi)
+                    if (wi < w) pre |= sm[j * NMS_WORDS + wi] & ks[wi];
+                const unsigned long long own = lane < nb ? sm[j * NMS_WORDS + w] : 0ull;
+                const unsigned long long outside = __ballot(pre != 0ull || lane >= nb);
+                const uint32_t olo = (uint32_t)own, ohi = (uint32_t)(own >> 32);
+                uint32_t klo = 0, khi = 0;
+                const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)outside), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(outside >> 32));
+                for (int b = 0; b < 32; ++b) {
+                    const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)olo, b);
+                    if (!((xlo >> b) & 1u) && !(mlo & klo)) klo |= 1u << b;
+                }
+                for (int b = 0; b < 32; ++b) {
+                    const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)olo, b + 32), mhi = (uint32_t)__builtin_amdgcn_readlane((int)ohi, b + 32);
+                    if (!((xhi >> b) & 1u) && !(mlo & klo) && !(mhi & khi)) khi |= 1u << b;
+                }
+                ks[w] = ((unsigned long long)khi << 32) | klo;
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < NMS_WORDS; ++w) if (lane == 0) keptw[w] = ks[w];
+    }
+    __syncthreads();
+    // kept sorted rows -> compact list, in order (rank = number of kept rows before it)
+    int nk = 0;
+#pragma unroll
+    for (int w = 0; w < NMS_WORDS; ++w) nk += __popcll(keptw[w]);
+    if (t < n && ((keptw[t >> 6] >> (t & 63)) & 1ull)) {
+        int rank = __popcll(keptw[t >> 6] & ((1ull << (t & 63)) - 1ull));
+        for (int w = 0; w < (t >> 6); ++w) rank += __popcll(keptw[w]);
+        kept[rank] = order[t];                       // input row number
+    }
+    __syncthreads();
+    constexpr int PER = (NMS_MAX * 9 + 511) / 512;
+    float v[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {                  // independent loads first, stores after
+        const int e = t + u * 512, k = e / 9, c = e - k * 9;
+        v[u] = (e < max_boxes * 9 && k < nk) ? rows[(size_t)kept[k] * 9 + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = t + u * 512;
+        if (e < max_boxes * 9 && (e / 9 < nk || zero_fill)) out_rows[e] = v[u];
+    }
+    if (t < max_boxes && (t < nk || zero_fill)) keep_idx[t] = t < nk ? (int32_t)kept[t] : 0;
+    if (t == 0) *out_count = (uint32_t)nk;
+}
+
+// ---- plugin ----------------------------------------------------------------------------------
+class RotatedNmsPlugin : public Plugin {
+public:
+    int max_boxes_; float thresh_;
+    RotatedNmsPlugin(int m, float t) : max_boxes_(m), thresh_(t) {}
+    const char* type() const override { return "RotatedNmsPlugin"; }
+    int nbOutputs() const override { return 3; }
+    int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
+        if (i == 0) { *out = dims3(in[0].d[0], max_boxes_, 9); return 0; }
+        if (i == 1) { *out = dims2(in[0].d[0], max_boxes_); return 0; }
+        if (i == 2) { *out = dims1(in[0].d[0]); return 0; }
+        return -1;
+    }
+    int outputType(int i, const int32_t*, int) const override { return i == 0 ? DSVT_FLOAT : DSVT_INT32; }
+    bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int, int) const override {
+        if (pos == 0 || pos == 2) return f32Lin(io[pos]);
+        return pos >= 0 && pos <= 4 && i32Lin(io[pos]);
+    }
+    size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override {
+        return alignUp(sizeof(uint32_t) * NMS_MAX) + alignUp(sizeof(unsigned long long) * NMS_MAX * NMS_WORDS);
+    }
+    int enqueue(const DsvtPluginTensorDesc* inDesc, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void* ws,
+                hipStream_t stream) override {
+        if (inDesc && inDesc[0].dims.nbDims > 0 && inDesc[0].dims.d[0] != 1) return -2;
+        WsCarver c(ws);
+        uint32_t* order = c.take<uint32_t>(NMS_MAX);
+        unsigned long long* mask = c.take<unsigned long long>((size_t)NMS_MAX * NMS_WORDS);
+        const float* rows = static_cast<const float*>(in[0]);
+        const uint32_t* count = static_cast<const uint32_t*>(in[1]);
+        hipLaunchKernelGGL(nms_sort, dim3(1), dim3(512), 0, stream, rows, count, max_boxes_, order);
+        hipLaunchKernelGGL(nms_mask, dim3(max_boxes_, cdiv(max_boxes_, 64)), dim3(64), 0, stream, rows, count, order, max_boxes_, thresh_, mask);
+        hipLaunchKernelGGL(nms_scan, dim3(1), dim3(512), 0, stream, rows, count, order, mask, max_boxes_, static_cast<float*>(out[0]),
+                           static_cast<int32_t*>(out[1]), static_cast<uint32_t*>(out[2]), zeroFill);
+        return lastError();
+    }
+    size_t serializationSize() const override { return sizeof(int) + sizeof(float); }
+    void serialize(void* b) const override { char* d = static_cast<char*>(b); wr<int>(d, max_boxes_); wr<float>(d, thresh_); }
+    Plugin* clone() const override { return new RotatedNmsPlugin(max_boxes_, thresh_); }
+};
+static Plugin* nmsCreate(const DsvtPluginFieldCollection* fc) {
+    const int m = fieldInt(fc, "max_boxes"); const float t = fieldFloat(fc, "nms_thresh", 0.01f);
+    return (m > 0 && m <= NMS_MAX) ? new RotatedNmsPlugin(m, t) : nullptr;
+}
+static Plugin* nmsDeser(const void* data, size_t len) {
+    if (len < sizeof(int) + sizeof(float)) return nullptr;
+    const char* d = static_cast<const char*>(data);
+    const int m = rd<int>(d); const float t = rd<float>(d);
+    return (m > 0 && m <= NMS_MAX) ? new RotatedNmsPlugin(m, t) : nullptr;
+}
+static Creator g_nmsCreator{"RotatedNmsPlugin", {{"max_boxes", DSVT_FIELD_INT32}, {"nms_thresh", DSVT_FIELD_FLOAT32}}, nmsCreate, nmsDeser, {}, {}};
+static Registrar g_nmsReg(&g_nmsCreator);
+
+}  // namespace dsvt

@@ -31,6 +31,7 @@ GX, GY, GZ = 468, 468, 1
 WINS = [((12, 12, 1), (0, 0, 0)), ((24, 24, 1), (6, 6, 0))]      # include/params.h:47-66
 L_SET, C, H, C_FFN = 36, 192, 8, 384                              # params.h:70,73,80-84
 TOP_K, SCORE_THR = 500, 0.3                                       # params.h:327-328
+NMS_THRESH = 0.01                                                 # params.h:334
 
 
 class Caps:
@@ -65,12 +66,14 @@ def fold_linear_bn(w, lin, bn, eps, bias=False):
 
 class DsvtPipeline:
     def __init__(self, weights, caps=None, blocks=4, with_head=True, ln_eps=0.0, head_dtype=torch.float32,
-                 device="cuda:0", zero_fill=False, linear_compute=P.COMPUTE_F32, hip_head=None, fused_mlp=None):
+                 device="cuda:0", zero_fill=False, linear_compute=P.COMPUTE_F32, hip_head=None, fused_mlp=None,
+                 device_nms=False):
         """linear_compute: COMPUTE_F32 = fp32 MFMA everywhere (parity mode, boxes within 1e-3 of the
         fp32 oracle); COMPUTE_F16 = fp16 MFMA operands with fp32 accumulate/epilogues (BASELINE
         configs[2] "fp16").  head_dtype: precision of the dense BEV stage.  hip_head: run the BEV ResNet +
         CenterHead on DsvtConv2dPlugin (csrc/conv.hip, fp16) instead of PyTorch/MIOpen; default: on in fp16
-        mode."""
+        mode.  device_nms: append RotatedNmsPlugin (the reference's host nms_cpu, include/helper.h:257-283) so that
+        forward() returns the final boxes instead of FilterBoxByScore's rows."""
         self.caps = c = caps or Caps()
         self.blocks, self.with_head, self.device = blocks, with_head, torch.device(device)
         self.head_dtype = head_dtype
@@ -142,6 +145,7 @@ class DsvtPipeline:
         if with_head:
             self.map2bev = P.add_map_2_bev_op(c.P, C, GX, GY)
             self.filter = P.add_filter_box_by_score_op(TOP_K, X_MIN, X_MAX, Y_MIN, Y_MAX, Z_MIN, Z_MAX, VX, VY, VZ, SCORE_THR)
+            self.nms = P.add_rotated_nms_op(TOP_K, NMS_THRESH) if device_nms else None
             self.hip_head = (head_dtype == torch.float16 and linear_compute == P.COMPUTE_F16) if hip_head is None else hip_head
             if self.hip_head:
                 self._build_hip_head(w)
@@ -338,12 +342,18 @@ class DsvtPipeline:
         src = self._xh if (self.f16 and self.head_dtype == torch.float16) else x
         bev = self.map2bev(src, st["coords"], st["P"])[0]             # [1, 468(y), 468(x), 192] NHWC
         if self.hip_head:
-            return self.filter(*self.topk(self._bev_hip(bev)))
+            return self._post(self.filter(*self.topk(self._bev_hip(bev))))
         bev = bev.permute(0, 3, 1, 2)                                 # NCHW view of channels-last memory (:1131-1133)
         if bev.dtype != self.head_dtype:
             bev = bev.to(self.head_dtype)
         o = self._bev(bev)
-        return self.filter(*self._decode(o))
+        return self._post(self.filter(*self._decode(o)))
+
+    def _post(self, fb):
+        if self.nms is None:
+            return fb
+        rows, _, cnt = self.nms(*fb)
+        return rows, cnt
 
     # ---- HIP-graph replay of a whole frame -------------------------------------------------------
     def capture(self, points, n, warmup=3):

@@ -396,6 +396,12 @@ def add_center_head_topk_op(feature_height, feature_width, channel_num=18, class
                                                hm_offset=hm_offset), "center_head_topk_layer")
 
 
+def add_rotated_nms_op(max_boxes=500, nms_thresh=0.01):
+    """nms_cpu (include/helper.h:257-283) on the device.  Inputs: FilterBoxByScorePlugin's rows [1,K,9] and count [1].
+    Outputs: kept rows [1,K,9] in score order, their input row numbers [1,K], count [1]."""
+    return Plugin("RotatedNmsPlugin", dict(max_boxes=int(max_boxes), nms_thresh=float(nms_thresh)), "rotated_nms_layer")
+
+
 def add_filter_box_by_score_op(max_top_k, min_x_range, max_x_range, min_y_range, max_y_range, min_z_range,
                                max_z_range, voxel_x_size, voxel_y_size, voxel_z_size, score_threshold):
     """plugin_helper.h:607-678.  Inputs: scores, classes, xs, ys, center, center_z, angle, dim."""

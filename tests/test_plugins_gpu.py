@@ -376,3 +376,34 @@ def test_center_head_topk_degenerate_heat_map(pkg):
     assert (sc[0, :3].cpu() - exp[:3]).abs().max() < 1e-6 and (sc[0, 3:].cpu() - exp[3]).abs().max() < 1e-6
     assert cls[0, :3].tolist() == [3, 9, 0]
     assert (ys[0, :3] * W + xs[0, :3]).tolist() == [7, 39999, 123]
+
+
+def _nms_boxes(rng, n, spread):
+    """n FilterBoxByScore-layout rows (x, y, z, dim0 = l, dim1 = w, dim2 = h, angle, class, score), clustered so many overlap"""
+    b = np.zeros((500, 9), np.float32)
+    b[:n, 0:2] = rng.uniform(-spread, spread, (n, 2)); b[:n, 2] = rng.uniform(-2, 2, n)
+    b[:n, 3] = rng.uniform(0.5, 6.0, n); b[:n, 4] = rng.uniform(0.5, 2.5, n); b[:n, 5] = rng.uniform(1, 3, n)
+    b[:n, 6] = rng.uniform(-1.57, 1.57, n); b[:n, 7] = rng.integers(0, 10, n)
+    b[:n, 8] = np.sort(rng.uniform(0.3, 1.0, n).astype(np.float32))[::-1]
+    return b
+
+
+@pytest.mark.parametrize("n,spread,seed", [(500, 40.0, 0), (500, 8.0, 1), (137, 15.0, 2), (1, 5.0, 3), (0, 5.0, 4)])
+def test_rotated_nms_matches_host_nms(pkg, oracle, n, spread, seed):
+    """RotatedNmsPlugin == nms_cpu (include/helper.h:257-283, restated in the oracle): same kept rows, same order."""
+    P = pkg.plugin
+    rng = np.random.default_rng(seed)
+    b = _nms_boxes(rng, n, spread)
+    if n > 10:                                       # unsorted input with a score tie: the plugin sorts (stable) itself
+        perm = rng.permutation(n); b[:n] = b[perm]
+        b[5, 8] = b[9, 8]
+    rows, keep = oracle.nms_cpu(b, n, 0.01)
+    out, idx, cnt = P.add_rotated_nms_op(500, 0.01)(dev(b[None]), scalar(n))
+    torch.cuda.synchronize()
+    k = int(cnt.cpu()[0])
+    assert k == len(keep)
+    assert np.array_equal(host(idx)[0, :k], keep)
+    assert np.array_equal(host(out)[0, :k], rows)
+    assert not host(out)[0, k:].any()
+    if n == 500:
+        assert 1 < k < n                             # the case does exercise suppression
