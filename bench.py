@@ -36,7 +36,7 @@ PEAK_F32_MATRIX_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Pe
 PEAK_F16_MATRIX_TFLOPS = 2500.0     # same guide: "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBS = 8000.0               # same guide: "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured float4 copy)
 N_POINTS = 180000
-PMC_FILE = "r01_f_pmc_traffic.json"
+PMC_FILE = "r01_h_pmc_traffic.json"
 FRAME_POOL = 4                      # distinct synthetic clouds cycled through by the steps
 
 
@@ -226,7 +226,7 @@ def main():
                                      "hbm" if f16 else "mfma", "linear_f16_kernelILb1ELi1ELi8" if f16 else "linear_f32_kernel<true>"),
                 "DsvtEncoderMlpPlugin": ("encoder_mlp_f16_kernel (out-proj+LN -> FC1+GELU -> FC2+LN+LN, v_mfma_f32_16x16x32_f16)", "hbm", "encoder_mlp_f16_kernel"),
                 "DsvtSetAttentionPlugin": ("set_attention_kernel (v_mfma_f32_16x16x4_f32)", "hbm", "set_attention_kernel"),
-                "DsvtConv2dPlugin": ("conv_f16_kernel (implicit GEMM, v_mfma_f32_16x16x32_f16)", "mfma", "conv_f16_kernel<64")}
+                "DsvtConv2dPlugin": ("conv_halo_kernel / conv_f16_kernel (implicit GEMM, v_mfma_f32_16x16x32_f16)", "mfma", "conv_halo_kernelILi8ELi3ELi8")}
         for ptype, lst in prof.items():
             if not lst:
                 continue
@@ -265,8 +265,8 @@ def main():
             "ms_per_step": round(1e3 * dt / K, 4), "p50_ms": round(float(np.median(frame_ms)), 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2]: lidar_like({args.points}, seed) Waymo-shaped cloud, 0.32 m pillars, "
-                                   "468x468 BEV, full 4-block DSVT pillar backbone + BEV ResNet + CenterHead + "
-                                   "FilterBoxByScore; seeded random weights (dsvt.wts is not shipped)",
+                                   "468x468 BEV, full 4-block DSVT pillar backbone + BEV ResNet + CenterHead + top-K decode + "
+                                   "FilterBoxByScore" + ("" if args.no_nms else " + rotated NMS (final boxes)") + "; seeded random weights (dsvt.wts is not shipped)",
                        "frames_per_gpu": K, "parallelism": f"frame-batch dp{world}, one result gather",
                        "launch": "hip-graph replay per frame" if use_graph else "host launch per op",
                        "frames_in_flight": NS,

@@ -33,6 +33,15 @@
  *   DsvtLinearPlugin          FC (+prologue/epilogue) used where the reference calls
  *                             addFullyConnected (src/dsvt-ai-trt.cpp:283,476,490,506,525)
  *   DsvtSetAttentionPlugin    GetValueByIndex + MHA core + MapSetFeature2Voxel in one
+ *   DsvtEncoderMlpPlugin      out-proj + LayerNorm -> FC1 + GELU -> FC2 + LayerNorms of one encoder
+ *                             layer in one launch (src/dsvt-ai-trt.cpp:669-756)
+ *   DsvtConv2dPlugin          convBnLELU / convBn / deconvBnLELU / conv_with_bias of the BEV
+ *                             backbone and CenterHead (src/dsvt-ai-trt.cpp:149-246, 1144-1468)
+ *   CenterHeadTopKPlugin      the decode the reference builds from TensorRT layers: sigmoid,
+ *                             two-stage TopK, gathers, exp, atan (src/dsvt-ai-trt.cpp:1479-1669);
+ *                             its outputs are FilterBoxByScorePlugin's inputs
+ *   RotatedNmsPlugin          nms_cpu / box_overlap of the host post-processing
+ *                             (include/helper.h:166-283) on the device
  *
  * Differences from the reference that a caller can observe are listed in
  * INTEGRATION.md (deterministic canonical ordering instead of atomic arrival
