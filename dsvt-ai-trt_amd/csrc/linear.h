@@ -24,6 +24,7 @@ struct LinearArgs {
     // FC + BN + ReLU of fullyConnectedBnLELU_fullyConnected (src/dsvt-ai-trt.cpp:461-492), K = 2
     const float* pe_xy; const float* pe_w0; const float* pe_w1; const float* pe_b;
     float eps;
+    unsigned long long* trace;    // debugging: per-workgroup phase timestamps (s_memtime) of the streamed kernel, or nullptr
 };
 
 // y = epilogue(A' W^T + b) on v_mfma_f32_16x16x4_f32 (fp32 A only); returns 0 or a hipError_t

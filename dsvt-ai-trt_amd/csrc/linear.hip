@@ -28,7 +28,10 @@
 #include "plugin_base.h"
 #include "device_utils.h"
 #include "linear.h"
+#include <cstdio>
 #include <cstdlib>
+#include <type_traits>
+#include <vector>
 
 namespace dsvt {
 
@@ -55,6 +58,7 @@ __device__ __forceinline__ float rowSum4(float v) {
 
 // Epilogue shared by both kernels.  `acc[t]` = output columns n0 + 16t + 4g .. +3 of activation
 // row `row` (one row per lane, g = lane >> 4).
+template <bool WITH_LN = true>
 __device__ __forceinline__ void linearEpilogue(floatx4 (&acc)[NT], const LinearArgs& a, int n0, int row, int g, int M, int N)
 {
     const bool valid = row < M;
@@ -75,7 +79,7 @@ __device__ __forceinline__ void linearEpilogue(floatx4 (&acc)[NT], const LinearA
             }
         }
     }
-    for (int s = 0; s < a.n_ln; ++s) {       // y = LayerNorm_s(y + res_s); N <= BN (checked on the host), n0 == 0
+    for (int s = 0; WITH_LN && s < a.n_ln; ++s) {       // y = LayerNorm_s(y + res_s); N <= BN (checked on the host), n0 == 0
         const float* res = a.res[s];
         float sum = 0.f;
 #pragma unroll
@@ -357,11 +361,180 @@ linear_f16_kernel(LinearArgs a, const _Float16* __restrict__ Wh)
     }
 }
 
-static int g_f16_variant = -1;     // 0: <2,4>   1: <1,8>
+
+// -------------------------------------------------------------------------------------
+// fp16 MFMA, weights streamed by LDS-DMA (K = 192, N a multiple of 192: every fp16 launch of the frame pipeline)
+// -------------------------------------------------------------------------------------
+// What bounds linear_f16_kernel above is not HBM or MFMA: a 35k-row problem gives every workgroup ONE 128-row tile,
+// and that tile walks load W slab -> ds_write -> barrier -> MFMA -> next slab with every load exposed (SQ_WAIT_ANY
+// = 73 % of wave cycles, MFMA busy 6 %).  Here the host packs W in MFMA-fragment order -- stage = 96 columns x 192 k =
+// 36 rows of 1 KB, row (k-step ks, tile t) = [lane (r, g)][8 halfs] <- W[96 s + 16 t + r][32 ks + 8 g + j] -- so a stage
+// is a linear 36 KB image: it is copied by global_load_lds (no staging registers, no ds_write) into a two-slot ring one
+// stage ahead of the MFMAs, an A fragment is a lane-linear (conflict-free) ds_read_b128, and the only waits are one
+// s_waitcnt + raw s_barrier.
+constexpr int SROWS = 36, SBYTES = SROWS * 1024;
+
+typedef __attribute__((address_space(1))) const void* glds_src_t;
+typedef __attribute__((address_space(3))) void* glds_dst_t;
+
+__device__ __forceinline__ void stageBarrier() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// AMODE 0: fp32 A, 1: fp16 A, 2: position-embedding prologue (A' computed from xy).  blockIdx.y = 192-column chunk
+// (one workgroup = 128 rows x 192 columns = two stages; the QKV launch is a 270 x 3 grid whose chunks re-read their
+// rows from L2): no store is ever in flight while a stage is awaited -- stores share the in-order vmcnt queue with the
+// DMA, and a store's acknowledgement takes microseconds when every workgroup writes at once.
+template <int AMODE, int MT, int NW>
+__global__ void __launch_bounds__(64 * NW, (MT == 1 ? 4 : 2))
+linear_f16_stream_kernel(LinearArgs a, const _Float16* __restrict__ Wp)
+{
+    // two stage slots (+ 3 KB: position-embedding parameters w0 | w1 | b, 192 floats each, fetched by the same DMA queue)
+    __shared__ __attribute__((aligned(16))) unsigned char ring[2 * SBYTES + (AMODE == 2 ? 3072 : 0)];      // <= 76,800 B: two workgroups per CU
+    const unsigned long long t_start = a.trace ? clock64() : 0ull;
+    const int M = rowLimit(a);
+    const int m0 = blockIdx.x * BM16;
+    if (m0 >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    auto mark = [&](int i) { if (a.trace && tid == 0) a.trace[wg * 8 + i] = clock64(); };
+    if (a.trace && tid == 0) a.trace[wg * 8] = t_start;
+    mark(1);
+    const int N = a.N, n0 = blockIdx.y * BN;
+    auto request = [&](int s) {                      // s = 0, 1: the two 96-column stages of this chunk
+#pragma unroll
+        for (int j = 0; j < (SROWS + NW - 1) / NW; ++j) {
+            const int row = wave + j * NW;
+            if (SROWS % NW == 0 || row < SROWS)
+                __builtin_amdgcn_global_load_lds((glds_src_t)(Wp + ((size_t)(2 * blockIdx.y + s) * SROWS + row) * 512 + lane * 8),
+                                                 (glds_dst_t)(ring + s * SBYTES + row * 1024), 16, 0, 0);
+        }
+    };
+    request(0);
+    if (AMODE == 2 && wave < 3) {                    // pe_w0 | pe_w1 | pe_b, 768 B each: one 1 KB request per array
+        const float* src = (wave == 0 ? a.pe_w0 : wave == 1 ? a.pe_w1 : a.pe_b) + (lane < 48 ? lane * 4 : 0);
+        __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(ring + 2 * SBYTES + wave * 1024), 16, 0, 0);
+    }
+    request(1);
+    int row[MT], rc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        row[mt] = m0 + wave * 16 * MT + mt * 16 + r;
+        rc[mt] = row[mt] < M ? row[mt] : M - 1;                          // clamp loads; rows >= M are never stored
+    }
+    // B-operand fragments of the whole K = 192 row (A + A2 for the chunks below add_cols)
+    half8 f[MT][NSTEP];
+    float2 xy[MT];
+    if (AMODE == 2) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xy[mt] = *reinterpret_cast<const float2*>(a.pe_xy + (size_t)rc[mt] * 2);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) asm volatile("" :: "v"(xy[mt].x), "v"(xy[mt].y));
+    } else {
+        const bool withA2 = n0 < a.add_cols;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const size_t o = (size_t)rc[mt] * KS + g * 8;
+            if (withA2) {
+#pragma unroll
+                for (int s = 0; s < NSTEP; ++s) f[mt][s] = loadFrag<AMODE == 1, true>(a.A, a.A2, o + s * 32);
+            } else {
+#pragma unroll
+                for (int s = 0; s < NSTEP; ++s) f[mt][s] = loadFrag<AMODE == 1, false>(a.A, nullptr, o + s * 32);
+            }
+        }
+        // make hipcc place its wait for these ordinary loads HERE (with an LDS-DMA in flight it waits vmcnt(0) at the first
+        // use of an ordinarily loaded register): both stages and the rows are then awaited together, once
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) asm volatile("" :: "v"(f[mt][s]));
+    }
+    mark(2);
+    stageBarrier();                                  // both stages (and the row fragments) have landed
+    mark(3);
+    if (AMODE == 2) {                                // operand row = ReLU(BN(FC(xy))), K_in = 2, parameters from LDS
+        const float* pw0 = reinterpret_cast<const float*>(ring + 2 * SBYTES), *pw1 = pw0 + 256, *pb = pw0 + 512;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                const int k0 = s * 32 + g * 8;
+                half8 v;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const float4 w0 = *reinterpret_cast<const float4*>(pw0 + k0 + 4 * hh);
+                    const float4 w1 = *reinterpret_cast<const float4*>(pw1 + k0 + 4 * hh);
+                    const float4 bb = *reinterpret_cast<const float4*>(pb + k0 + 4 * hh);
+                    v[4 * hh + 0] = (_Float16)fmaxf(fmaf(xy[mt].x, w0.x, fmaf(xy[mt].y, w1.x, bb.x)), 0.f);
+                    v[4 * hh + 1] = (_Float16)fmaxf(fmaf(xy[mt].x, w0.y, fmaf(xy[mt].y, w1.y, bb.y)), 0.f);
+                    v[4 * hh + 2] = (_Float16)fmaxf(fmaf(xy[mt].x, w0.z, fmaf(xy[mt].y, w1.z, bb.z)), 0.f);
+                    v[4 * hh + 3] = (_Float16)fmaxf(fmaf(xy[mt].x, w0.w, fmaf(xy[mt].y, w1.w, bb.w)), 0.f);
+                }
+                f[mt][s] = v;
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    floatx4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[mt][t] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* slot = ring + lane * 16;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int ks = 0; ks < NSTEP; ++ks)
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const half8 wf = *reinterpret_cast<const half8*>(slot + h * SBYTES + (ks * 6 + t) * 1024);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][6 * h + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, f[mt][ks], acc[mt][6 * h + t], 0, 0, 0);
+                if (t == 5) __builtin_amdgcn_sched_barrier(0);     // bound the hoisting of fragment reads (register budget)
+            }
+    mark(6);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) linearEpilogue<true>(acc[mt], a, n0, row[mt], g, M, N);
+    if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); mark(7); }
+}
+
+int launchLinearF16Stream(const LinearArgs& a, const _Float16* Wp, hipStream_t stream) {
+    if (a.K != KS || a.N % BN != 0 || (a.N > BN && a.n_ln > 0)) return -3;
+    dim3 grid(cdiv(a.max_rows, BM16), a.N / BN);
+    const int amode = a.pe_xy ? 2 : a.a_half ? 1 : 0;
+    static int mt2 = -1;           // DSVT_STREAM_MT=2: 4 waves x 32 rows (<= 256 VGPRs); default 8 waves x 16 rows (<= 128 VGPRs, 4 waves/SIMD):
+    if (mt2 < 0) { const char* e = getenv("DSVT_STREAM_MT"); mt2 = e ? atoi(e) : 1; }      // 1.5 % faster with two frames in flight, slower alone
+    const bool wide = mt2 == 2;
+#define DSVT_LS(AM) do { if (wide) hipLaunchKernelGGL((linear_f16_stream_kernel<AM, 2, 4>), grid, dim3(256), 0, stream, a, Wp); \
+                         else hipLaunchKernelGGL((linear_f16_stream_kernel<AM, 1, 8>), grid, dim3(512), 0, stream, a, Wp); } while (0)
+    if (amode == 2) DSVT_LS(2); else if (amode == 1) DSVT_LS(1); else DSVT_LS(0);
+#undef DSVT_LS
+    return lastError();
+}
+
+// fragment-ordered stage image of W [N][192] (N a multiple of 96)
+static std::vector<_Float16> packStages(const float* W, int N) {
+    std::vector<_Float16> out((size_t)N * KS);
+    for (int s = 0; s < N / 96; ++s)
+        for (int ks = 0; ks < NSTEP; ++ks)
+            for (int t = 0; t < 6; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j)
+                        out[(((size_t)s * SROWS + ks * 6 + t) * 64 + lane) * 8 + j] =
+                            (_Float16)W[(size_t)(96 * s + 16 * t + (lane & 15)) * KS + 32 * ks + 8 * (lane >> 4) + j];
+    return out;
+}
+
+static int g_f16_variant = -1;     // 0: <2,4>   1: <1,8>   2 (default): weights streamed by LDS-DMA where the shape allows
 
 int launchLinearF16(const LinearArgs& a, const _Float16* Wh, hipStream_t stream) {
     if (a.K % KS != 0) return -3;
-    if (g_f16_variant < 0) { const char* e = getenv("DSVT_LINEAR_VARIANT"); g_f16_variant = e ? atoi(e) : 1; }
+    if (g_f16_variant < 0) { const char* e = getenv("DSVT_LINEAR_VARIANT"); g_f16_variant = e ? atoi(e) : 1; if (g_f16_variant == 2) g_f16_variant = 1; }
     dim3 grid(cdiv(a.max_rows, BM16));
     if (g_f16_variant == 0) {
         if (a.a_half) hipLaunchKernelGGL((linear_f16_kernel<true, 2, 4>), grid, dim3(256), 0, stream, a, Wh);
@@ -391,7 +564,13 @@ public:
     std::vector<float> w_, b_, g_, be_, pe_;       // pe_: [w0 (K) | w1 (K) | b (K)] of the fused K_in = 2 first FC, or empty
     float *w_dev_ = nullptr, *b_dev_ = nullptr, *g_dev_ = nullptr, *be_dev_ = nullptr, *pe_dev_ = nullptr;
     _Float16* wh_dev_ = nullptr;
+    _Float16* wp_dev_ = nullptr;      // fragment-ordered stage image for the LDS-DMA kernel (K = 192, N % 192 == 0)
     bool ok_ = false;
+    bool useStream() const {
+        static int v = -1;
+        if (v < 0) { const char* e = getenv("DSVT_LINEAR_VARIANT"); v = e ? atoi(e) : 2; }
+        return v == 2 && useF16() && c_.K == KS && c_.N % BN == 0;
+    }
     bool useF16() const { return c_.compute_type == 1 && c_.K % KS == 0; }
     DsvtLinearPlugin(const LinCfg& c, const float* w, const float* b, const float* g, const float* be,
                      const float* pe_w = nullptr, const float* pe_b = nullptr)
@@ -414,10 +593,16 @@ public:
             ok_ = hipMalloc(&wh_dev_, sizeof(_Float16) * wh.size()) == hipSuccess &&
                   hipMemcpy(wh_dev_, wh.data(), sizeof(_Float16) * wh.size(), hipMemcpyHostToDevice) == hipSuccess;
         }
+        if (ok_ && useStream()) {
+            const std::vector<_Float16> wp = packStages(w_.data(), c_.N);
+            ok_ = hipMalloc(&wp_dev_, sizeof(_Float16) * wp.size()) == hipSuccess &&
+                  hipMemcpy(wp_dev_, wp.data(), sizeof(_Float16) * wp.size(), hipMemcpyHostToDevice) == hipSuccess;
+        }
     }
     ~DsvtLinearPlugin() override {
         for (float* p : {w_dev_, b_dev_, g_dev_, be_dev_, pe_dev_}) if (p) (void)hipFree(p);
         if (wh_dev_) (void)hipFree(wh_dev_);
+        if (wp_dev_) (void)hipFree(wp_dev_);
     }
     const char* type() const override { return "DsvtLinearPlugin"; }
     int nbOutputs() const override { return c_.output_mode == OUT_BOTH ? 2 : 1; }
@@ -462,6 +647,20 @@ public:
         if (zeroFill) {
             if (a.out) DSVT_CHECK(hipMemsetAsync(a.out, 0, sizeof(float) * (size_t)c_.max_rows * c_.N, stream));
             if (a.out16) DSVT_CHECK(hipMemsetAsync(a.out16, 0, sizeof(_Float16) * (size_t)c_.max_rows * c_.N, stream));
+        }
+        if (wp_dev_) {
+            static unsigned long long* tr = nullptr; static int tron = -1;
+            if (tron < 0) { tron = getenv("DSVT_LINEAR_TRACE") ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 8 * 4096); }
+            a.trace = tr;
+            const int rc = launchLinearF16Stream(a, wp_dev_, stream);
+            if (tron) {
+                (void)hipStreamSynchronize(stream);
+                fprintf(stderr, "[linear trace N=%d pe=%d] wg0:", c_.N, (int)!pe_.empty());
+                for (int i = 1; i < 8; ++i) fprintf(stderr, " %lld", (long long)(tr[i] - tr[0]));
+                fprintf(stderr, " | wg200:"); for (int i = 1; i < 8; ++i) fprintf(stderr, " %lld", (long long)(tr[200 * 8 + i] - tr[200 * 8]));
+                fprintf(stderr, " | start skew wg200-wg0 %lld\n", (long long)(tr[200 * 8] - tr[0]));
+            }
+            return rc;
         }
         return useF16() ? launchLinearF16(a, wh_dev_, stream) : launchLinearF32(a, stream);
     }

@@ -11,14 +11,16 @@ rocprofv3 --pmc TA_BUSY_avr TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum GR
 cd $R
 python - "$O" "$PAT" <<'PY'
 import csv, sys, collections, statistics, glob
-O, pat = sys.argv[1:3]
-for p in ("p1", "p2", "p3"):
-    agg = collections.defaultdict(list)
-    for f in glob.glob(f"{O}/{p}/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            if pat in r["Kernel_Name"]:
-                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in agg.items():
-        print(f"{p} {k:32s} n={len(v):3d} median={statistics.median(v):16.1f}")
-    if not agg: print(p, "no rows; log tail:", open(f"{O}/{p}.log").read()[-600:])
+O, pats = sys.argv[1:3]
+for pat in pats.split(","):              # several kernel-name substrings, comma separated
+    print("==", pat)
+    for p in ("p1", "p2", "p3"):
+        agg = collections.defaultdict(list)
+        for f in glob.glob(f"{O}/{p}/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if pat in r["Kernel_Name"]:
+                    agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            print(f"{p} {k:32s} n={len(v):3d} median={statistics.median(v):16.1f}")
+        if not agg: print(p, "no rows; log tail:", open(f"{O}/{p}.log").read()[-300:])
 PY
