@@ -25,6 +25,8 @@
 // FC1 piece 24 + h piece 12 -- under the 128 that let two workgroups share a CU).
 #include "plugin_base.h"
 #include "device_utils.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace dsvt {
 
@@ -223,6 +225,278 @@ encoder_mlp_f16_kernel(MlpArgs a)
     }
 }
 
+
+// -------------------------------------------------------------------------------------
+// Same arithmetic, weights streamed by LDS-DMA (default).  The kernel above is one 128-row tile per workgroup walking
+// nine exposed "load slab -> ds_write -> barrier -> MFMA" steps (SQ_WAIT_ANY = 70 % of wave cycles, MFMA busy 6 %).
+// Here the host packs the three matrices as TEN stages of 36 fragment rows (1 KB each, MFMA A-operand order):
+//   stages 0,1    Wo columns [96h, 96h+96) x 192 k               row (ks, t)  <- Wo[96h + 16t + r][32ks + 8g + j]
+//   stage 2+2q    W1 rows [96q, 96q+96) x 192 permuted k         row (ks, t)  <- W1p[96q + 16t + r][32ks + 8g + j]
+//   stage 3+2q    W2 (all 192 rows) x permuted k [96q, 96q+96)   row (sp, t)  <- W2p[16t + r][96q + 32sp + 8g + j]
+// and a workgroup copies stage s+1 into the other half of a two-slot ring with global_load_lds while the MFMAs of
+// stage s run; one s_waitcnt + raw s_barrier per stage.  Biases and LayerNorm-1 parameters the stream phase needs
+// come through the same DMA queue into LDS (an ordinary global load with a DMA in flight makes hipcc wait vmcnt(0));
+// x is loaded in the prologue straight into the out-proj accumulator (acc = x, + bo after the barrier) and re-read for
+// LayerNorm 3 once nothing is in flight; no store is issued before the last stage has landed.
+constexpr int MS_ROWS = 36, MS_BYTES = MS_ROWS * 1024, MS_STAGES = 10;
+constexpr int MP_FLOATS = 1280;                    // bo | ln1_g | ln1_b | b1 (384) | b2 | pad  -> five 1 KB DMA rows
+constexpr int MP_BO = 0, MP_G1 = 192, MP_B1LN = 384, MP_B1 = 576, MP_B2 = 960;
+
+typedef __attribute__((address_space(1))) const void* mlp_gsrc_t;
+typedef __attribute__((address_space(3))) void* mlp_ldst_t;
+
+struct MlpStreamArgs {
+    const _Float16* att; const float* x; const float* xb;
+    const _Float16* Wp;                              // MS_STAGES x 36 x 512 halfs
+    const float* params;                             // MP_FLOATS
+    const float* ln_g; const float* ln_b;            // [4][192]
+    float* out; _Float16* out16;
+    const uint32_t* count; int max_rows; float eps;
+    unsigned long long* trace;                       // debugging: per-workgroup phase timestamps, or nullptr
+    int dbg;                                         // timing ablations (wrong results): 1 no LN1, 2 no GELU, 4 no final LNs, 8 no stores, 16 no MFMA
+};
+
+__device__ __forceinline__ void mlpStageBarrier() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// LayerNorm with gamma / beta in LDS
+__device__ __forceinline__ void mlpLayerNormLds(floatx4 (&acc)[MNT], const float* gm, const float* bt, int g, float eps) {
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < MNT; ++t) sum += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+    const float mean = rowSum4m(sum) / MC;
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < MNT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float d = acc[t][i] - mean; sq += d * d; }
+    const float inv = 1.0f / sqrtf(rowSum4m(sq) / MC + eps);
+#pragma unroll
+    for (int t = 0; t < MNT; ++t) {
+        const float4 g4 = *reinterpret_cast<const float4*>(gm + t * 16 + 4 * g), b4 = *reinterpret_cast<const float4*>(bt + t * 16 + 4 * g);
+        acc[t][0] = (acc[t][0] - mean) * inv * g4.x + b4.x; acc[t][1] = (acc[t][1] - mean) * inv * g4.y + b4.y;
+        acc[t][2] = (acc[t][2] - mean) * inv * g4.z + b4.z; acc[t][3] = (acc[t][3] - mean) * inv * g4.w + b4.w;
+    }
+}
+
+// MT 16-row tiles per wave, NW waves: 128 rows per workgroup either way.  <1, 8> needs 4 waves/SIMD (<= 128 VGPRs, spills);
+// <2, 4> runs at 2 waves/SIMD with 256 VGPRs and halves the LDS reads per MFMA.
+// PQ = FC1 columns per piece: 64 => fifteen 24-row stages (24 KB).  A stage's MFMAs (0.2-0.35 us) are much shorter than a
+// DMA round trip (~2 us), so the ring has THREE slots and stage s+2 is requested when stage s starts: the end-of-stage wait
+// is a counted vmcnt that retires stage s+1 and leaves s+2 in flight.
+template <int MT, int NW, int PQ>
+__global__ void __launch_bounds__(64 * NW, (MT == 1 ? 4 : 2))
+encoder_mlp_stream_kernel(MlpStreamArgs a)
+{
+    constexpr int PQT = PQ / 16, PQS = PQ / 32, SR = 6 * PQT, SB = SR * 1024, NWO = MC / PQ, NPIECE = MF / PQ;
+    constexpr int NST = NWO + 2 * NPIECE, NRW = SR / NW;
+    static_assert(12 * PQS == SR && SR % NW == 0 && (NRW == 3 || NRW == 6), "uniform request count per wave");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * SB + MP_FLOATS * 4];     // 78,848 B: two workgroups per CU
+    const uint32_t cnt = *a.count;
+    const int M = (int)(cnt < (uint32_t)a.max_rows ? cnt : (uint32_t)a.max_rows);
+    const int m0 = blockIdx.x * MROWS;
+    if (m0 >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    int row[MT], rc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        row[mt] = m0 + wave * 16 * MT + mt * 16 + r;
+        rc[mt] = row[mt] < M ? row[mt] : M - 1;
+    }
+    const float* prm = reinterpret_cast<const float*>(lds + 3 * SB);
+    int nmark = 0;
+    auto mark = [&]() { if (a.trace && tid == 0 && nmark < 32) a.trace[blockIdx.x * 32 + nmark] = clock64(); ++nmark; };
+    mark();
+    auto request = [&](int s) {
+#pragma unroll
+        for (int j = 0; j < (SR + NW - 1) / NW; ++j) {
+            const int rw = wave + j * NW;
+            if (SR % NW == 0 || rw < SR)
+                __builtin_amdgcn_global_load_lds((mlp_gsrc_t)(a.Wp + ((size_t)s * SR + rw) * 512 + lane * 8),
+                                                 (mlp_ldst_t)(lds + (s % 3) * SB + rw * 1024), 16, 0, 0);
+        }
+    };
+    // end of stage st: stage st+1 has landed (the younger requests of stage st+2 stay in flight), then the barrier
+    auto stageEnd = [&](int st) {
+        if (st + 2 < NST) {
+            if (NRW == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    request(0);
+#pragma unroll
+    for (int j = 0; j < (MP_FLOATS / 256 + NW - 1) / NW; ++j) {
+        const int pr = wave + j * NW;
+        if (pr < MP_FLOATS / 256)
+            __builtin_amdgcn_global_load_lds((mlp_gsrc_t)(a.params + pr * 256 + lane * 4), (mlp_ldst_t)(lds + 3 * SB + pr * 1024), 16, 0, 0);
+    }
+
+    request(1);
+    // ---- prologue: the att row as the out-proj B operand, x straight into the out-proj accumulator -----------------
+    half8 fa[MT][MNSTEP];
+    floatx4 acc[MT][MNT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int s = 0; s < MNSTEP; ++s) fa[mt][s] = *reinterpret_cast<const half8*>(a.att + (size_t)rc[mt] * MC + s * 32 + g * 8);
+#pragma unroll
+        for (int t = 0; t < MNT; ++t) {
+            const float4 xv = *reinterpret_cast<const float4*>(a.x + (size_t)rc[mt] * MC + t * 16 + 4 * g);
+            acc[mt][t] = floatx4{xv.x, xv.y, xv.z, xv.w};
+        }
+    }
+    // hipcc's own wait for these ordinary loads belongs here, not behind the next stage's request (see linear.hip)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int s = 0; s < MNSTEP; ++s) asm volatile("" :: "v"(fa[mt][s]));
+#pragma unroll
+        for (int t = 0; t < MNT; ++t) asm volatile("" :: "v"(acc[mt][t]));
+    }
+    mark();
+    mlpStageBarrier();                               // stages 0, 1 + parameters landed
+    mark();
+#pragma unroll
+    for (int t = 0; t < MNT; ++t) {
+        const float4 b = *reinterpret_cast<const float4*>(prm + MP_BO + t * 16 + 4 * g);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { acc[mt][t][0] += b.x; acc[mt][t][1] += b.y; acc[mt][t][2] += b.z; acc[mt][t][3] += b.w; }
+    }
+    const unsigned char* lbase = lds + lane * 16;
+
+    // ---- stages 0 .. NWO-1: out-proj, PQ columns per stage ---------------------------------------------------------------
+#pragma unroll
+    for (int h = 0; h < NWO; ++h) {
+        request(h + 2);                              // (stages NWO, NWO+1 are the first W1 piece / W2 slab)
+        const unsigned char* sl = lbase + (h % 3) * SB;
+#pragma unroll
+        for (int ks = 0; ks < MNSTEP; ++ks) {
+#pragma unroll
+            for (int t = 0; t < PQT; ++t) {
+                const half8 wf = *reinterpret_cast<const half8*>(sl + (ks * PQT + t) * 1024);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][h * PQT + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, fa[mt][ks], acc[mt][h * PQT + t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mark();
+        if (h + 1 < NWO) stageEnd(h);
+    }
+    half8 fs1[MT][MNSTEP];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        if (!(a.dbg & 1)) mlpLayerNormLds(acc[mt], prm + MP_G1, prm + MP_B1LN, g, a.eps);         // s1 = LN1(att Wo^T + bo + x)
+        packFrags(acc[mt], fs1[mt]);                                            // s1 as the FC1 operand
+    }
+#pragma unroll
+    for (int t = 0; t < MNT; ++t) {                                     // the FC2 accumulator starts at s1 + b2 (LN2's residual, fp32)
+        const float4 b = *reinterpret_cast<const float4*>(prm + MP_B2 + t * 16 + 4 * g);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { acc[mt][t][0] += b.x; acc[mt][t][1] += b.y; acc[mt][t][2] += b.z; acc[mt][t][3] += b.w; }
+    }
+    mark();
+    stageEnd(NWO - 1);                               // first W1 piece landed
+    mark();
+
+    // ---- FC1 in four 96-column pieces, each consumed at once as a 96-wide K slab of FC2 -------------------------------
+    // W1 piece q = stage NWO + 2q, W2 slab q = stage NWO + 2q + 1
+#pragma unroll 1
+    for (int q = 0; q < NPIECE; ++q) {
+        const int stA = NWO + 2 * q, stB = stA + 1;
+        if (stA + 2 < NST) request(stA + 2);         // next W1 piece
+        const unsigned char* slotA = lbase + (stA % 3) * SB;
+        floatx4 acc2[MT][PQT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < PQT; ++t) acc2[mt][t] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < MNSTEP; ++ks) {
+#pragma unroll
+            for (int t = 0; t < PQT; ++t) {
+                const half8 wf = *reinterpret_cast<const half8*>(slotA + (ks * PQT + t) * 1024);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc2[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, fs1[mt][ks], acc2[mt][t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        half8 fh[MT][PQS];
+#pragma unroll
+        for (int sp = 0; sp < PQS; ++sp) {
+            const float4 b0 = *reinterpret_cast<const float4*>(prm + MP_B1 + q * PQ + (2 * sp) * 16 + 4 * g);
+            const float4 b1v = *reinterpret_cast<const float4*>(prm + MP_B1 + q * PQ + (2 * sp + 1) * 16 + 4 * g);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                half8 h;
+                if (a.dbg & 2) {
+                    h[0] = (_Float16)acc2[mt][2 * sp][0]; h[1] = (_Float16)acc2[mt][2 * sp][1]; h[2] = (_Float16)acc2[mt][2 * sp][2]; h[3] = (_Float16)acc2[mt][2 * sp][3];
+                    h[4] = (_Float16)acc2[mt][2 * sp + 1][0]; h[5] = (_Float16)acc2[mt][2 * sp + 1][1]; h[6] = (_Float16)acc2[mt][2 * sp + 1][2]; h[7] = (_Float16)acc2[mt][2 * sp + 1][3];
+                } else {
+                h[0] = (_Float16)mlpGelu(acc2[mt][2 * sp][0] + b0.x); h[1] = (_Float16)mlpGelu(acc2[mt][2 * sp][1] + b0.y);
+                h[2] = (_Float16)mlpGelu(acc2[mt][2 * sp][2] + b0.z); h[3] = (_Float16)mlpGelu(acc2[mt][2 * sp][3] + b0.w);
+                h[4] = (_Float16)mlpGelu(acc2[mt][2 * sp + 1][0] + b1v.x); h[5] = (_Float16)mlpGelu(acc2[mt][2 * sp + 1][1] + b1v.y);
+                h[6] = (_Float16)mlpGelu(acc2[mt][2 * sp + 1][2] + b1v.z); h[7] = (_Float16)mlpGelu(acc2[mt][2 * sp + 1][3] + b1v.w);
+                }
+                fh[mt][sp] = h;
+            }
+        }
+        mark();
+        stageEnd(stA);                               // W2 slab landed; everyone is done with the W1 piece
+        if (stB + 2 < NST) request(stB + 2);         // next W2 slab
+        const unsigned char* slotB = lbase + (stB % 3) * SB;
+#pragma unroll
+        for (int sp = 0; sp < PQS; ++sp) {
+#pragma unroll
+            for (int t = 0; t < MNT; ++t) {
+                const half8 wf = *reinterpret_cast<const half8*>(slotB + (sp * 12 + t) * 1024);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, fh[mt][sp], acc[mt][t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mark();
+        if (stB + 1 < NST) stageEnd(stB);            // next W1 piece landed; everyone is done with the W2 slab
+    }
+    mark();
+    // ---- s2 = LN2(s1 + f + b2) (already summed); x' = LN3(s2 + x); [x' = LN4(x' + xb)]: nothing in flight any more ------
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        if (!(a.dbg & 4)) {
+        mlpLayerNorm(acc[mt], a.ln_g + MC, a.ln_b + MC, g, a.eps);
+#pragma unroll
+        for (int t = 0; t < MNT; ++t) {
+            const float4 xv = *reinterpret_cast<const float4*>(a.x + (size_t)rc[mt] * MC + t * 16 + 4 * g);
+            acc[mt][t][0] += xv.x; acc[mt][t][1] += xv.y; acc[mt][t][2] += xv.z; acc[mt][t][3] += xv.w;
+        }
+        mlpLayerNorm(acc[mt], a.ln_g + 2 * MC, a.ln_b + 2 * MC, g, a.eps);
+        }
+        if (a.xb) {
+#pragma unroll
+            for (int t = 0; t < MNT; ++t) {
+                const float4 xv = *reinterpret_cast<const float4*>(a.xb + (size_t)rc[mt] * MC + t * 16 + 4 * g);
+                acc[mt][t][0] += xv.x; acc[mt][t][1] += xv.y; acc[mt][t][2] += xv.z; acc[mt][t][3] += xv.w;
+            }
+            mlpLayerNorm(acc[mt], a.ln_g + 3 * MC, a.ln_b + 3 * MC, g, a.eps);
+        }
+        if (row[mt] < M && !(a.dbg & 8)) {
+#pragma unroll
+            for (int t = 0; t < MNT; ++t) {
+                const int col = t * 16 + 4 * g;
+                *reinterpret_cast<float4*>(a.out + (size_t)row[mt] * MC + col) = make_float4(acc[mt][t][0], acc[mt][t][1], acc[mt][t][2], acc[mt][t][3]);
+                half4 h; h[0] = (_Float16)acc[mt][t][0]; h[1] = (_Float16)acc[mt][t][1]; h[2] = (_Float16)acc[mt][t][2]; h[3] = (_Float16)acc[mt][t][3];
+                *reinterpret_cast<half4*>(a.out16 + (size_t)row[mt] * MC + col) = h;
+            }
+        }
+    }
+    if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); mark(); }
+}
+
 // position p = 32s + 8g + j of a permuted weight row holds the column k(p) the chained B fragment carries there
 static inline int permuteK(int p) {
     const int s = p / 32, q = p % 32, g = q / 8, j = q % 8;
@@ -235,6 +509,8 @@ public:
     std::vector<float> wo_, w1_, w2_, bo_, b1_, b2_, lg_, lb_;     // as given (natural order)
     _Float16 *wo_dev_ = nullptr, *w1_dev_ = nullptr, *w2_dev_ = nullptr;
     float *bo_dev_ = nullptr, *b1_dev_ = nullptr, *b2_dev_ = nullptr, *lg_dev_ = nullptr, *lb_dev_ = nullptr;
+    _Float16* wp_dev_ = nullptr; float* prm_dev_ = nullptr;       // stage image + LDS parameter block of the streamed kernel
+    int pq_ = 64;                                                 // FC1 columns per piece of that image
     bool ok_ = false;
     DsvtEncoderMlpPlugin(int max_rows, int has_block_ln, float eps, const float* wo, const float* w1, const float* w2,
                          const float* bo, const float* b1, const float* b2, const float* lg, const float* lb)
@@ -255,9 +531,35 @@ public:
         };
         ok_ = upH(wo_, MC, MC, false, &wo_dev_) && upH(w1_, MF, MC, true, &w1_dev_) && upH(w2_, MC, MF, true, &w2_dev_) &&
               upF(bo_, &bo_dev_) && upF(b1_, &b1_dev_) && upF(b2_, &b2_dev_) && upF(lg_, &lg_dev_) && upF(lb_, &lb_dev_);
+        if (!ok_) return;
+        // stage image (see encoder_mlp_stream_kernel), for pq_ FC1 columns per piece
+        const int PQ = pq_, PQT = PQ / 16, PQS = PQ / 32, SR = 6 * PQT, NWO = MC / PQ, NPIECE = MF / PQ;
+        std::vector<_Float16> wp((size_t)(NWO + 2 * NPIECE) * SR * 512);
+        auto put = [&](int stage, int rowi, int lane, int j, float v) { wp[(((size_t)stage * SR + rowi) * 64 + lane) * 8 + j] = (_Float16)v; };
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const int r = lane & 15, g = lane >> 4;
+                for (int h = 0; h < NWO; ++h)
+                    for (int ks = 0; ks < 6; ++ks)
+                        for (int t = 0; t < PQT; ++t)
+                            put(h, ks * PQT + t, lane, j, wo_[(size_t)(PQ * h + 16 * t + r) * MC + 32 * ks + 8 * g + j]);
+                for (int q = 0; q < NPIECE; ++q) {
+                    for (int ks = 0; ks < 6; ++ks)
+                        for (int t = 0; t < PQT; ++t)
+                            put(NWO + 2 * q, ks * PQT + t, lane, j, w1_[(size_t)(PQ * q + 16 * t + r) * MC + permuteK(32 * ks + 8 * g + j)]);
+                    for (int sp = 0; sp < PQS; ++sp)
+                        for (int t = 0; t < 12; ++t)
+                            put(NWO + 2 * q + 1, sp * 12 + t, lane, j, w2_[(size_t)(16 * t + r) * MF + permuteK(PQ * q + 32 * sp + 8 * g + j)]);
+                }
+            }
+        std::vector<float> prm(MP_FLOATS, 0.f);
+        for (int i = 0; i < MC; ++i) { prm[MP_BO + i] = bo_[i]; prm[MP_G1 + i] = lg_[i]; prm[MP_B1LN + i] = lb_[i]; prm[MP_B2 + i] = b2_[i]; }
+        for (int i = 0; i < MF; ++i) prm[MP_B1 + i] = b1_[i];
+        ok_ = hipMalloc(&wp_dev_, sizeof(_Float16) * wp.size()) == hipSuccess &&
+              hipMemcpy(wp_dev_, wp.data(), sizeof(_Float16) * wp.size(), hipMemcpyHostToDevice) == hipSuccess && upF(prm, &prm_dev_);
     }
     ~DsvtEncoderMlpPlugin() override {
-        for (void* p : {(void*)wo_dev_, (void*)w1_dev_, (void*)w2_dev_, (void*)bo_dev_, (void*)b1_dev_, (void*)b2_dev_, (void*)lg_dev_, (void*)lb_dev_})
+        for (void* p : {(void*)wo_dev_, (void*)w1_dev_, (void*)w2_dev_, (void*)bo_dev_, (void*)b1_dev_, (void*)b2_dev_, (void*)lg_dev_, (void*)lb_dev_, (void*)wp_dev_, (void*)prm_dev_})
             if (p) (void)hipFree(p);
     }
     const char* type() const override { return "DsvtEncoderMlpPlugin"; }
@@ -289,7 +591,27 @@ public:
             DSVT_CHECK(hipMemsetAsync(out[0], 0, sizeof(float) * (size_t)max_rows_ * MC, stream));
             DSVT_CHECK(hipMemsetAsync(out[1], 0, sizeof(_Float16) * (size_t)max_rows_ * MC, stream));
         }
-        hipLaunchKernelGGL(encoder_mlp_f16_kernel, dim3(cdiv(max_rows_, MROWS)), dim3(64 * MWAVES), 0, stream, a);
+        static int variant = -1;       // DSVT_MLP_VARIANT=0: register-staged weights; 1 (default): LDS-DMA stream, 4 waves x 32 rows; 2: 8 waves x 16 rows
+        if (variant < 0) { const char* e = getenv("DSVT_MLP_VARIANT"); variant = e ? atoi(e) : 1; }
+        if (variant == 0) {
+            hipLaunchKernelGGL(encoder_mlp_f16_kernel, dim3(cdiv(max_rows_, MROWS)), dim3(64 * MWAVES), 0, stream, a);
+        } else {
+            MlpStreamArgs b{};
+            b.att = a.att; b.x = a.x; b.xb = a.xb; b.Wp = wp_dev_; b.params = prm_dev_; b.ln_g = lg_dev_; b.ln_b = lb_dev_;
+            b.out = a.out; b.out16 = a.out16; b.count = a.count; b.max_rows = max_rows_; b.eps = eps_;
+            const dim3 grid(cdiv(max_rows_, MROWS));
+            static unsigned long long* tr = nullptr; static int tron = -1;
+            if (tron < 0) { tron = getenv("DSVT_MLP_TRACE") ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 32 * 1024); }
+            b.trace = tr;
+            static int dbg = -1; if (dbg < 0) { const char* e = getenv("DSVT_MLP_DBG"); dbg = e ? atoi(e) : 0; }
+            b.dbg = dbg;
+            if (variant == 2) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, 64>), grid, dim3(512), 0, stream, b);
+            else hipLaunchKernelGGL((encoder_mlp_stream_kernel<2, 4, 64>), grid, dim3(256), 0, stream, b);
+            if (tron) {
+                (void)hipStreamSynchronize(stream);
+                for (int w : {0, 200}) { fprintf(stderr, "[mlp trace wg%d]", w); for (int i = 1; i < 32; ++i) fprintf(stderr, " %lld", (long long)(tr[w * 32 + i] - tr[w * 32])); fprintf(stderr, "\n"); }
+            }
+        }
         return lastError();
     }
     size_t nFloats() const { return wo_.size() + w1_.size() + w2_.size() + bo_.size() + b1_.size() + b2_.size() + 2 * (size_t)(3 + has_block_ln_) * MC; }
