@@ -23,6 +23,7 @@
 #include "plugin_base.h"
 #include "device_utils.h"
 #include "linear.h"
+#include <cstdlib>
 
 namespace dsvt {
 
@@ -190,9 +191,156 @@ set_attention_kernel(AttnArgs a)
         }
 }
 
+
+// -------------------------------------------------------------------------------------
+// fp16 I/O on v_mfma_f32_16x16x32_f16.  The fp32 kernel above spends 35 % of its cycles in the matrix pipe
+// (126 v_mfma_f32_16x16x4_f32 per head at 32 cycles each); with fp16 operands one K = 32 step covers the padded
+// head dim (24 -> 32) of Q K^T and 32 keys of P V: 21 MFMAs of 16 cycles per head.
+//   * Q, K rows are staged as fp16 (row stride 208 B = 13 x 16 B: conflict-free ds_read_b128 over 16 rows); lane
+//     group g = 3 of a fragment is the zero padding d = 24..31.
+//   * S^T accumulators (lane group g <-> keys 16t + 4g + i) become the A operand of P V after a conversion to fp16:
+//     k-step 0 = tiles t = 0, 1, k-step 1 = tile t = 2 + zeros.  The MFMA sums over k, so V only has to be read with
+//     the same (g, j) <-> key map: V is staged TRANSPOSED ([channel][key], 64 keys, pad zeroed) and a B fragment is two
+//     8-byte reads (keys 4g..4g+3 of tile t).
+//   * scores, softmax and the output accumulation stay fp32.
+typedef _Float16 ahalf8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ahalf4 __attribute__((ext_vector_type(4)));
+constexpr int AQL = 104;      // halfs per staged Q / K row
+constexpr int AVL = 72;       // halfs per staged V^T row (64 keys + 8)
+
+__global__ void __launch_bounds__(256)
+set_attention_f16_kernel(AttnArgs a)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 sQ[AL * AQL];
+    __shared__ __attribute__((aligned(16))) _Float16 sK[AL * AQL];
+    __shared__ __attribute__((aligned(16))) _Float16 sVt[AHB * ADH * AVL];
+    __shared__ uint32_t sRow[AL];
+    __shared__ float sMask[AHB][AL];
+
+    const int nhb = a.H / AHB;
+    const int set = blockIdx.x / nhb, hq = blockIdx.x % nhb;
+    uint32_t S = *a.set_num; if (S > (uint32_t)a.max_sets) S = a.max_sets;
+    if ((uint32_t)set >= S) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+
+    if (tid < AL) sRow[tid] = a.inds ? a.inds[(size_t)set * AL + tid] : (uint32_t)(set * AL + tid);
+    if (tid < AHB * AL) {
+        int h = tid / AL, k = tid % AL;
+        sMask[h][k] = a.mask[(size_t)set * a.mask_set_stride + (size_t)(hq * AHB + h) * a.mask_head_stride + k];
+    }
+    for (int i = tid; i < AHB * ADH * AVL / 2; i += 256) reinterpret_cast<uint32_t*>(sVt)[i] = 0u;     // padded keys must be finite
+    __syncthreads();
+    // ---- stage the 36 gathered rows: Q, K as rows, V transposed -------------------------------------
+    for (int i = tid; i < AL * 3 * 12; i += 256) {
+        const int slot = i / 36, rem = i % 36, seg = rem / 12, c8 = (rem % 12) * 8;
+        const _Float16* src = static_cast<const _Float16*>(a.qkv) + (size_t)sRow[slot] * a.qkv_ld + seg * a.C + hq * (AHB * ADH) + c8;
+        const ahalf8 v = *reinterpret_cast<const ahalf8*>(src);
+        if (seg == 0) *reinterpret_cast<ahalf8*>(&sQ[slot * AQL + c8]) = v;
+        else if (seg == 1) *reinterpret_cast<ahalf8*>(&sK[slot * AQL + c8]) = v;
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sVt[(c8 + j) * AVL + slot] = v[j];
+        }
+    }
+    __syncthreads();
+
+    const int hoff = wave * ADH;
+    const ahalf8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // ---- S^T[key][query] = sum_d K[key][d] Q[query][d] ----------------------------------------------
+    floatx4 sc[3][3];
+    {
+        ahalf8 kf[3], qf[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            int row = 16 * t + r; row = row < AL ? row : AL - 1;          // rows >= 36 are padding: clamp, mask later
+            kf[t] = g < 3 ? *reinterpret_cast<const ahalf8*>(&sK[row * AQL + hoff + g * 8]) : zero8;
+            qf[t] = g < 3 ? *reinterpret_cast<const ahalf8*>(&sQ[row * AQL + hoff + g * 8]) : zero8;
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                sc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t], qf[u], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    // ---- softmax over keys for each query column (lane holds keys 16t + 4g + i, query 16u + r) ----
+    float mk[3][4];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { int key = 16 * t + 4 * g + i; mk[t][i] = key < AL ? sMask[wave][key] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int key = 16 * t + 4 * g + i;
+                float v = key < AL ? sc[t][u][i] + mk[t][i] : -INFINITY;
+                sc[t][u][i] = v; mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, kWave)); mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int key = 16 * t + 4 * g + i;
+                float e = key < AL ? expf(sc[t][u][i] - mx) : 0.f;
+                sc[t][u][i] = e; sum += e;
+            }
+        sum += __shfl_xor(sum, 16, kWave); sum += __shfl_xor(sum, 32, kWave);
+        float inv = 1.0f / sum;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sc[t][u][i] *= inv;
+    }
+    // ---- O[query][d] = sum_key P[query][key] V[key][d] -------------------------------------------------
+    ahalf8 vb[2][2];                     // [channel tile][k-step]
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const bool dv = 16 * dt + r < ADH;
+        const _Float16* pv = &sVt[(hoff + (dv ? 16 * dt + r : 0)) * AVL + 4 * g];
+        const ahalf4 v0 = *reinterpret_cast<const ahalf4*>(pv), v1 = *reinterpret_cast<const ahalf4*>(pv + 16), v2 = *reinterpret_cast<const ahalf4*>(pv + 32);
+        ahalf8 b0 = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        ahalf8 b1 = {v2[0], v2[1], v2[2], v2[3], 0, 0, 0, 0};
+        vb[dt][0] = dv ? b0 : zero8; vb[dt][1] = dv ? b1 : zero8;
+    }
+    floatx4 oc[3][2];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        ahalf8 p0, p1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { p0[i] = (_Float16)sc[0][u][i]; p0[4 + i] = (_Float16)sc[1][u][i]; p1[i] = (_Float16)sc[2][u][i]; p1[4 + i] = (_Float16)0.f; }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            oc[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p0, vb[dt][0], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            oc[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p1, vb[dt][1], oc[u][dt], 0, 0, 0);
+        }
+    }
+    // ---- write back: lane holds queries 16u + 4g + i, channels 16dt + r -------------------------
+    const int h = hq * AHB + wave;
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int q = 16 * u + 4 * g + i;
+            if (q >= AL) continue;
+            if (a.inds && sMask[wave][q] < 0.f) continue;      // duplicate slot: the first occurrence writes the identical row
+            _Float16* dst = static_cast<_Float16*>(a.out) + (size_t)sRow[q] * a.out_ld + h * ADH;
+            dst[r] = (_Float16)oc[u][0][i];
+            if (16 + r < ADH) dst[16 + r] = (_Float16)oc[u][1][i];
+        }
+}
+
 static int launchAttention(const AttnArgs& a, bool io16, hipStream_t stream) {
     dim3 grid((unsigned)(a.max_sets * (a.H / AHB))), block(256);
-    if (io16) hipLaunchKernelGGL(set_attention_kernel<true>, grid, block, 0, stream, a);
+    static int f16mma = -1;        // DSVT_ATTN_F32MMA=1: fp16 I/O on the fp32 matrix instructions (the previous kernel)
+    if (f16mma < 0) { const char* e = getenv("DSVT_ATTN_F32MMA"); f16mma = (e && atoi(e)) ? 0 : 1; }
+    if (io16 && f16mma) hipLaunchKernelGGL(set_attention_f16_kernel, grid, block, 0, stream, a);
+    else if (io16) hipLaunchKernelGGL(set_attention_kernel<true>, grid, block, 0, stream, a);
     else hipLaunchKernelGGL(set_attention_kernel<false>, grid, block, 0, stream, a);
     return lastError();
 }
