@@ -20,6 +20,7 @@ SOURCES = [
     ("attention.hip", []),
     ("conv.hip", []),
     ("mlp.hip", []),
+    ("pfn.hip", []),
     ("decode.hip", []),
     ("nms.hip", ["-ffp-contract=off"]),
 ]
