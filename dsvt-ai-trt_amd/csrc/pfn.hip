@@ -1,23 +1,21 @@
 // pfn.hip -- DsvtPillarFeatureNetPlugin: the two PFN layers + both scatter-max reductions of the voxel feature
-// encoder in two launches that never write a per-point activation.
+// encoder in ONE launch that never writes a per-point activation.
 //
 // Reference wiring (src/dsvt-ai-trt.cpp:565-589): x0 = ReLU(BN(FC0(f))) [Nk,96] -> TorchScatterMax -> concat
 // [x0 | max_pillar(x0)] [Nk,192] -> x1 = ReLU(BN(FC1(cat))) [Nk,192] -> TorchScatterMax -> pillar features [P,192].
-// As separate launches that is ~1 GB of traffic per 180k-point frame (six kernels, 0.33 ms).  Two facts remove it:
-//   * FC1 is linear in the two halves of its input:  FC1(cat) = W1a x0 + W1b max_pillar(x0) + b1, and the second
-//     term is per PILLAR.  With t_p = W1b m_p + b1 (an ordinary [P,96] x [96,192] linear, DsvtLinearPlugin),
-//     x1(point) = ReLU(W1a x0(point) + t_pillar(point)).
-//   * x0 costs 10 MACs per output: cheaper to recompute than to store.
-// So:  pass 0:  m_p = max over the pillar's points of x0                      -> [P, 96]
-//      (linear: t = W1b' m + b1')                                             -> [P,192]
-//      pass 1:  vfeat_p = max over the pillar's points of ReLU(W1a' x0 + t_p) -> [P,192] (fp32 and an fp16 copy)
-// BatchNorm is folded into the weights by the caller.  The compact point ids of a pillar are consecutive
-// (Points2Features' canonical order: pillar-major, then slot), so a workgroup that owns 32 consecutive pillars owns
-// a contiguous range of point rows: no pillar straddles workgroups, the per-pillar maxima live in an LDS table
-// (ds_max_u32 on the bit pattern: values are >= 0 after the ReLU), and nothing is atomic in global memory.
-//
-// Arithmetic: layer 0 on v_mfma_f32_16x16x4_f32 (fp32: the inputs are raw metric coordinates), layer 1 on
-// v_mfma_f32_16x16x32_f16 with the layer-0 tile chained through registers (k-permuted W1a, see mlp.hip); maxima fp32.
+// As separate launches that is ~1 GB of traffic per 180k-point frame (six kernels, 0.33 ms).  Three facts remove it:
+//   * FC1 is linear in the two halves of its input:  FC1(cat) = W1a x0 + W1b m_p + b1 with m_p = max_pillar(x0);
+//     the second term is per PILLAR;
+//   * ReLU and "+ constant" are monotone, so  max_points ReLU(W1a x0 + t_p) = ReLU(max_points(W1a x0) + t_p):
+//     both per-point maxima, m_p and U_p = max_points(W1a x0), come out of ONE pass over the points;
+//   * x0 is consumed from registers (the layer-0 tile is the B operand of layer 1, see mlp.hip).
+// A workgroup owns 16 consecutive pillars; the compact point ids of a pillar are consecutive (Points2Features' canonical
+// order: pillar-major, then slot), so it owns a contiguous range of point rows and no pillar straddles workgroups:
+// the maxima live in LDS tables (ds_max_u32 on order-preserving keys), nothing is atomic in global memory.  After the
+// point loop the workgroup computes t = W1b m (16 x 96 x 192 on the matrix cores, W1b fragments straight from L2) and
+// writes  vfeat_p = ReLU(U_p + t_p + b1)  as fp32 and fp16.
+// Arithmetic: layer 0 on v_mfma_f32_16x16x4_f32 (fp32: the inputs are raw metric coordinates), both halves of layer 1 on
+// v_mfma_f32_16x16x32_f16 (operands rounded to fp16, fp32 accumulate); maxima, bias, ReLU in fp32.
 #include "plugin_base.h"
 #include "device_utils.h"
 #include <cstdlib>
@@ -29,7 +27,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 constexpr int PF_IN = 10, PF_C0 = 96, PF_C1 = 192;
-constexpr int PF_PB = 32;              // pillars per workgroup
+constexpr int PF_PB = 16;              // pillars per workgroup (= one MFMA row tile of the per-pillar GEMM)
 constexpr int PF_NW = 4;               // waves per workgroup: 64 point rows per iteration
 
 struct PfnArgs {
@@ -38,36 +36,41 @@ struct PfnArgs {
     const uint32_t* pcnt;              // [P]
     const uint32_t* pillar_num; int max_pillars;
     const float* w0; const float* b0;  // [96][12] (k padded with zeros), [96]
-    const _Float16* w1a;               // layer 1: fragment-ordered [3 k-steps][12 tiles][64 lanes][8] (k-permuted); nullptr in pass 0
-    const float* t;                    // [P,192] per-pillar term of layer 1 (pass 1)
-    float* out; _Float16* out16;       // pass 0: m [P,96] (out16 unused); pass 1: vfeat [P,192] + fp16 copy
+    const _Float16* w1a;               // fragment-ordered [3 k-steps][12 tiles][64 lanes][8], k-permuted (chained operand)
+    const _Float16* w1b;               // fragment-ordered [3 k-steps][12 tiles][64 lanes][8], natural k
+    const float* b1;                   // [192]
+    float* out; _Float16* out16;       // vfeat [P,192] + fp16 copy
 };
 
-template <bool LAYER1>
+__device__ __forceinline__ uint32_t pfnKey(float f) {            // larger float <=> larger key; every key > 0
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float pfnUnkey(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
 __global__ void __launch_bounds__(64 * PF_NW)
 pfn_kernel(PfnArgs a)
 {
-    constexpr int NC = LAYER1 ? PF_C1 : PF_C0, NT = NC / 16;
-    __shared__ uint32_t sMax[PF_PB * NC];                              // 24 KB / 12 KB
+    __shared__ uint32_t sM[PF_PB * PF_C0];                             // max_pillar(x0): bit patterns (x0 >= 0)          6 KB
+    __shared__ uint32_t sU[PF_PB * PF_C1];                             // max_pillar(W1a x0): order-preserving keys         12 KB
     __shared__ uint32_t sStart[PF_PB + 1];
-    __shared__ __attribute__((aligned(16))) _Float16 sW1[LAYER1 ? 3 * 12 * 512 : 8];     // 36 KB
+    __shared__ __attribute__((aligned(16))) _Float16 sW1[3 * 12 * 512];                                                // 36 KB
     uint32_t P = *a.pillar_num; if (P > (uint32_t)a.max_pillars) P = a.max_pillars;
     const uint32_t pb0 = blockIdx.x * PF_PB;
     if (pb0 >= P) return;
     const int npil = P - pb0 < (uint32_t)PF_PB ? (int)(P - pb0) : PF_PB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
 
-    for (int i = tid; i < PF_PB * NC; i += 64 * PF_NW) sMax[i] = 0u;
+    for (int i = tid; i < PF_PB * PF_C0; i += 64 * PF_NW) sM[i] = 0u;
+    for (int i = tid; i < PF_PB * PF_C1; i += 64 * PF_NW) sU[i] = 0u;
     if (tid <= npil) {
         // first row of pillar pb0 + tid; the sentinel entry is one past the last pillar's rows
         const uint32_t p = pb0 + (tid < npil ? tid : npil - 1);
         const uint32_t s = a.pidx[(size_t)p * a.T];
         sStart[tid] = tid < npil ? s : s + a.pcnt[p];
     }
-    if (LAYER1) {
-        for (int i = tid; i < 3 * 12 * 64; i += 64 * PF_NW)
-            *reinterpret_cast<uint4*>(&sW1[i * 8]) = *reinterpret_cast<const uint4*>(a.w1a + (size_t)i * 8);
-    }
+    for (int i = tid; i < 3 * 12 * 64; i += 64 * PF_NW)
+        *reinterpret_cast<uint4*>(&sW1[i * 8]) = *reinterpret_cast<const uint4*>(a.w1a + (size_t)i * 8);
     // layer-0 weights as MFMA A fragments: lane (r, g) holds W0[16t + r][4ks + g]
     float w0f[6][3], b0f[6][4];
 #pragma unroll
@@ -80,18 +83,23 @@ pfn_kernel(PfnArgs a)
     __syncthreads();
     const uint32_t row0 = sStart[0], rowEnd = sStart[npil];
 
-    for (uint32_t base = row0; base < rowEnd; base += 16 * PF_NW) {
+    // B fragment of layer 0: lane (r, g) holds f[row][4ks + g]; the next iteration's values are requested one iteration ahead
+    auto loadFeat = [&](uint32_t base, float (&fb)[3]) {
         const uint32_t row = base + 16 * wave + r;
-        const bool valid = row < rowEnd;
-        // pillar of this row: the last j with sStart[j] <= row
-        int j = 0;
-#pragma unroll
-        for (int step = 16; step > 0; step >>= 1) { const int c = j + step; if (c < npil && sStart[c] <= row) j = c; }
-        // ---- layer 0: x0^T tile = W0 f^T; B fragment: lane (r, g) holds f[row][4ks + g] ---------------------------
-        const float* fr = a.feat + (size_t)(valid ? row : row0) * PF_IN;
-        float fb[3];
+        const float* fr = a.feat + (size_t)(row < rowEnd ? row : row0) * PF_IN;
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) { const int k = 4 * ks + g; fb[ks] = k < PF_IN ? fr[k] : 0.f; }
+    };
+    float fb[3], fnext[3];
+    loadFeat(row0, fb);
+    for (uint32_t base = row0; base < rowEnd; base += 16 * PF_NW) {
+        if (base + 16 * PF_NW < rowEnd) loadFeat(base + 16 * PF_NW, fnext);
+        const uint32_t row = base + 16 * wave + r;
+        const bool valid = row < rowEnd;
+        int j = 0;                                   // pillar of this row: the last j with sStart[j] <= row
+#pragma unroll
+        for (int step = PF_PB / 2; step > 0; step >>= 1) { const int c = j + step; if (c < npil && sStart[c] <= row) j = c; }
+        // ---- layer 0: x0^T tile = ReLU(W0 f^T + b0) --------------------------------------------------------------------
         floatx4 x0[6];
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
@@ -101,48 +109,67 @@ pfn_kernel(PfnArgs a)
 #pragma unroll
             for (int i = 0; i < 4; ++i) x0[t][i] = fmaxf(x0[t][i], 0.f);                 // ReLU (:144)
         }
-        if (!LAYER1) {
+        if (valid) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) atomicMax(&sM[j * PF_C0 + 16 * t + 4 * g + i], __float_as_uint(x0[t][i]) & 0x7fffffffu);      // (-0 -> +0)
+        }
+        // ---- per-point half of layer 1: u^T = W1a x0^T; the layer-0 tile is the B operand (k-step s = tiles 2s, 2s+1) -----
+        half8 f1[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            half8 h;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { h[i] = (_Float16)x0[2 * s][i]; h[4 + i] = (_Float16)x0[2 * s + 1][i]; }
+            f1[s] = h;
+        }
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(&sW1[((s * 12 + t) * 64 + lane) * 8]), f1[s], acc, 0, 0, 0);
             if (valid) {
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) atomicMax(&sMax[j * NC + 16 * t + 4 * g + i], __float_as_uint(x0[t][i]) & 0x7fffffffu);      // (-0 -> +0)
-            }
-        } else {
-            // ---- layer 1: x1^T = W1a x0^T (+ t_pillar); the layer-0 tile is the B operand (k-step s = tiles 2s, 2s+1) ---
-            half8 f1[3];
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                half8 h;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { h[i] = (_Float16)x0[2 * s][i]; h[4 + i] = (_Float16)x0[2 * s + 1][i]; }
-                f1[s] = h;
-            }
-            const float* tr = a.t + (size_t)(pb0 + j) * PF_C1;
-#pragma unroll
-            for (int t = 0; t < 12; ++t) {
-                const float4 tv = *reinterpret_cast<const float4*>(tr + 16 * t + 4 * g);
-                floatx4 acc = {tv.x, tv.y, tv.z, tv.w};
-#pragma unroll
-                for (int s = 0; s < 3; ++s)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(&sW1[((s * 12 + t) * 64 + lane) * 8]), f1[s], acc, 0, 0, 0);
-                if (valid) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) atomicMax(&sMax[j * NC + 16 * t + 4 * g + i], __float_as_uint(fmaxf(acc[i], 0.f)) & 0x7fffffffu);
-                }
+                for (int i = 0; i < 4; ++i) atomicMax(&sU[j * PF_C1 + 16 * t + 4 * g + i], pfnKey(acc[i]));
             }
         }
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) fb[ks] = fnext[ks];
     }
     __syncthreads();
-    // ---- the 32 pillar rows of this workgroup ----------------------------------------------------------------------
-    for (int i = tid; i < npil * (NC / 4); i += 64 * PF_NW) {
-        const int pj = i / (NC / 4), c4 = (i % (NC / 4)) * 4;
-        const uint4 v = *reinterpret_cast<const uint4*>(&sMax[pj * NC + c4]);
-        const float4 f = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-        *reinterpret_cast<float4*>(a.out + (size_t)(pb0 + pj) * NC + c4) = f;
-        if (LAYER1 && a.out16) {
-            half4 h; h[0] = (_Float16)f.x; h[1] = (_Float16)f.y; h[2] = (_Float16)f.z; h[3] = (_Float16)f.w;
-            *reinterpret_cast<half4*>(a.out16 + (size_t)(pb0 + pj) * NC + c4) = h;
+    // ---- per-pillar half: t^T = W1b m^T (16 pillars x 96 -> 192); wave w owns column tiles 3w .. 3w+2 ---------------------
+    half8 mf[3];                                     // B fragment: lane (r, g) holds m[pillar r][32s + 8g + j]
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const uint4 lo = *reinterpret_cast<const uint4*>(&sM[r * PF_C0 + 32 * s + 8 * g]);
+        const uint4 hi = *reinterpret_cast<const uint4*>(&sM[r * PF_C0 + 32 * s + 8 * g + 4]);
+        half8 h;
+        h[0] = (_Float16)__uint_as_float(lo.x); h[1] = (_Float16)__uint_as_float(lo.y); h[2] = (_Float16)__uint_as_float(lo.z); h[3] = (_Float16)__uint_as_float(lo.w);
+        h[4] = (_Float16)__uint_as_float(hi.x); h[5] = (_Float16)__uint_as_float(hi.y); h[6] = (_Float16)__uint_as_float(hi.z); h[7] = (_Float16)__uint_as_float(hi.w);
+        mf[s] = h;
+    }
+    const bool pv = r < npil;
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) {
+        const int t = 3 * wave + tt;
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(a.w1b + ((size_t)(s * 12 + t) * 64 + lane) * 8), mf[s], acc, 0, 0, 0);
+        if (pv) {                                    // lane (r, g): pillar r, columns 16t + 4g + i
+            const int col = 16 * t + 4 * g;
+            const float4 b = *reinterpret_cast<const float4*>(a.b1 + col);
+            const uint4 u = *reinterpret_cast<const uint4*>(&sU[r * PF_C1 + col]);
+            float4 v;
+            v.x = fmaxf(pfnUnkey(u.x) + acc[0] + b.x, 0.f); v.y = fmaxf(pfnUnkey(u.y) + acc[1] + b.y, 0.f);
+            v.z = fmaxf(pfnUnkey(u.z) + acc[2] + b.z, 0.f); v.w = fmaxf(pfnUnkey(u.w) + acc[3] + b.w, 0.f);
+            *reinterpret_cast<float4*>(a.out + (size_t)(pb0 + r) * PF_C1 + col) = v;
+            if (a.out16) {
+                half4 h; h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+                *reinterpret_cast<half4*>(a.out16 + (size_t)(pb0 + r) * PF_C1 + col) = h;
+            }
         }
     }
 }
@@ -152,46 +179,45 @@ static inline int pfnPermuteK(int p) {       // see mlp.hip: position p of a per
     return 32 * s + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
 }
 
-// fields: max_pillars_num, layer (0 | 1), weight (layer 0: [96][10]; layer 1: W1a = [192][96], the x0 half of the folded FC1),
-// bias (layer 0: [96]).  Inputs: feat [1,Nk,10] f32, pidx [1,P,T] i32, pcnt [1,P,1] i32, pillar_num [1] (, t [1,P,192] f32 for layer 1).
-// Outputs: layer 0: m [1,P,96] f32; layer 1: vfeat [1,P,192] f32 + fp16 copy.
+// fields: max_pillars_num, weight0 [96][10], bias0 [96], weight1 [192][192] (the folded FC1: columns 0..95 act on x0, 96..191 on
+// max_pillar(x0)), bias1 [192].  Inputs: feat [1,Nk,10] f32, pidx [1,P,T] i32, pcnt [1,P,1] i32, pillar_num [1].
+// Outputs: pillar features [1,P,192] f32 + fp16 copy.
 class DsvtPillarFeatureNetPlugin : public Plugin {
 public:
-    int max_pillars_, layer_;
-    std::vector<float> w_, b_;
-    float* w0_dev_ = nullptr; float* b0_dev_ = nullptr; _Float16* w1_dev_ = nullptr;
-    // layer 1 re-computes layer 0, so it carries both weight sets
-    std::vector<float> w0_, b0_;
+    int max_pillars_;
+    std::vector<float> w0_, b0_, w1_, b1_;
+    float *w0_dev_ = nullptr, *b0_dev_ = nullptr, *b1_dev_ = nullptr; _Float16 *w1a_dev_ = nullptr, *w1b_dev_ = nullptr;
     bool ok_ = false;
-    DsvtPillarFeatureNetPlugin(int mp, int layer, const float* w0, const float* b0, const float* w1a)
-        : max_pillars_(mp), layer_(layer), w0_(w0, w0 + PF_C0 * PF_IN), b0_(b0, b0 + PF_C0) {
-        if (layer) w_.assign(w1a, w1a + (size_t)PF_C1 * PF_C0);
+    DsvtPillarFeatureNetPlugin(int mp, const float* w0, const float* b0, const float* w1, const float* b1)
+        : max_pillars_(mp), w0_(w0, w0 + PF_C0 * PF_IN), b0_(b0, b0 + PF_C0), w1_(w1, w1 + (size_t)PF_C1 * PF_C1), b1_(b1, b1 + PF_C1) {
         std::vector<float> w0p((size_t)PF_C0 * 12, 0.f);
         for (int n = 0; n < PF_C0; ++n) for (int k = 0; k < PF_IN; ++k) w0p[n * 12 + k] = w0_[n * PF_IN + k];
-        ok_ = hipMalloc(&w0_dev_, sizeof(float) * w0p.size()) == hipSuccess &&
-              hipMemcpy(w0_dev_, w0p.data(), sizeof(float) * w0p.size(), hipMemcpyHostToDevice) == hipSuccess &&
-              hipMalloc(&b0_dev_, sizeof(float) * PF_C0) == hipSuccess &&
-              hipMemcpy(b0_dev_, b0_.data(), sizeof(float) * PF_C0, hipMemcpyHostToDevice) == hipSuccess;
-        if (ok_ && layer) {
-            std::vector<_Float16> wp((size_t)3 * 12 * 512);
-            for (int s = 0; s < 3; ++s)
-                for (int t = 0; t < 12; ++t)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 8; ++j)
-                            wp[(((size_t)s * 12 + t) * 64 + lane) * 8 + j] =
-                                (_Float16)w_[(size_t)(16 * t + (lane & 15)) * PF_C0 + pfnPermuteK(32 * s + 8 * (lane >> 4) + j)];
-            ok_ = hipMalloc(&w1_dev_, sizeof(_Float16) * wp.size()) == hipSuccess &&
-                  hipMemcpy(w1_dev_, wp.data(), sizeof(_Float16) * wp.size(), hipMemcpyHostToDevice) == hipSuccess;
-        }
+        std::vector<_Float16> wa((size_t)3 * 12 * 512), wb((size_t)3 * 12 * 512);
+        for (int s = 0; s < 3; ++s)
+            for (int t = 0; t < 12; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const size_t d = (((size_t)s * 12 + t) * 64 + lane) * 8 + j;
+                        const int n = 16 * t + (lane & 15), p = 32 * s + 8 * (lane >> 4) + j;
+                        wa[d] = (_Float16)w1_[(size_t)n * PF_C1 + pfnPermuteK(p)];           // x0 half, chained (k-permuted) operand
+                        wb[d] = (_Float16)w1_[(size_t)n * PF_C1 + PF_C0 + p];                // max half, natural k
+                    }
+        auto upF = [](const std::vector<float>& h, float** d) {
+            return hipMalloc(d, sizeof(float) * h.size()) == hipSuccess && hipMemcpy(*d, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice) == hipSuccess;
+        };
+        auto upH = [](const std::vector<_Float16>& h, _Float16** d) {
+            return hipMalloc(d, sizeof(_Float16) * h.size()) == hipSuccess && hipMemcpy(*d, h.data(), sizeof(_Float16) * h.size(), hipMemcpyHostToDevice) == hipSuccess;
+        };
+        ok_ = upF(w0p, &w0_dev_) && upF(b0_, &b0_dev_) && upF(b1_, &b1_dev_) && upH(wa, &w1a_dev_) && upH(wb, &w1b_dev_);
     }
     ~DsvtPillarFeatureNetPlugin() override {
-        if (w0_dev_) (void)hipFree(w0_dev_); if (b0_dev_) (void)hipFree(b0_dev_); if (w1_dev_) (void)hipFree(w1_dev_);
+        for (void* p : {(void*)w0_dev_, (void*)b0_dev_, (void*)b1_dev_, (void*)w1a_dev_, (void*)w1b_dev_}) if (p) (void)hipFree(p);
     }
     const char* type() const override { return "DsvtPillarFeatureNetPlugin"; }
-    int nbOutputs() const override { return layer_ ? 2 : 1; }
+    int nbOutputs() const override { return 2; }
     int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
-        if (i < 0 || i >= nbOutputs()) return -1;
-        *out = dims3(in[0].d[0], max_pillars_, layer_ ? PF_C1 : PF_C0); return 0;
+        if (i < 0 || i > 1) return -1;
+        *out = dims3(in[0].d[0], max_pillars_, PF_C1); return 0;
     }
     int outputType(int i, const int32_t*, int) const override { return i == 0 ? DSVT_FLOAT : DSVT_HALF; }
     bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int nbIn, int) const override {
@@ -208,48 +234,48 @@ public:
         a.feat = static_cast<const float*>(in[0]); a.pidx = static_cast<const uint32_t*>(in[1]);
         a.T = inDesc ? inDesc[1].dims.d[inDesc[1].dims.nbDims - 1] : 48;
         a.pcnt = static_cast<const uint32_t*>(in[2]); a.pillar_num = static_cast<const uint32_t*>(in[3]); a.max_pillars = max_pillars_;
-        a.w0 = w0_dev_; a.b0 = b0_dev_; a.w1a = w1_dev_; a.t = layer_ ? static_cast<const float*>(in[4]) : nullptr;
-        a.out = static_cast<float*>(out[0]); a.out16 = layer_ ? static_cast<_Float16*>(out[1]) : nullptr;
-        const int NC = layer_ ? PF_C1 : PF_C0;
+        a.w0 = w0_dev_; a.b0 = b0_dev_; a.w1a = w1a_dev_; a.w1b = w1b_dev_; a.b1 = b1_dev_;
+        a.out = static_cast<float*>(out[0]); a.out16 = static_cast<_Float16*>(out[1]);
         if (zeroFill) {
-            DSVT_CHECK(hipMemsetAsync(out[0], 0, sizeof(float) * (size_t)max_pillars_ * NC, stream));
-            if (layer_) DSVT_CHECK(hipMemsetAsync(out[1], 0, sizeof(_Float16) * (size_t)max_pillars_ * NC, stream));
+            DSVT_CHECK(hipMemsetAsync(out[0], 0, sizeof(float) * (size_t)max_pillars_ * PF_C1, stream));
+            DSVT_CHECK(hipMemsetAsync(out[1], 0, sizeof(_Float16) * (size_t)max_pillars_ * PF_C1, stream));
         }
-        const dim3 grid(cdiv(max_pillars_, PF_PB));
-        if (layer_) hipLaunchKernelGGL(pfn_kernel<true>, grid, dim3(64 * PF_NW), 0, stream, a);
-        else hipLaunchKernelGGL(pfn_kernel<false>, grid, dim3(64 * PF_NW), 0, stream, a);
+        hipLaunchKernelGGL(pfn_kernel, dim3(cdiv(max_pillars_, PF_PB)), dim3(64 * PF_NW), 0, stream, a);
         return lastError();
     }
-    size_t serializationSize() const override { return 2 * sizeof(int) + sizeof(float) * (w0_.size() + b0_.size() + w_.size()); }
+    size_t nFloats() const { return w0_.size() + b0_.size() + w1_.size() + b1_.size(); }
+    size_t serializationSize() const override { return sizeof(int) + sizeof(float) * nFloats(); }
     void serialize(void* buf) const override {
         char* d = static_cast<char*>(buf);
-        wr<int>(d, max_pillars_); wr<int>(d, layer_);
-        for (const std::vector<float>* v : {&w0_, &b0_, &w_}) { memcpy(d, v->data(), sizeof(float) * v->size()); d += sizeof(float) * v->size(); }
+        wr<int>(d, max_pillars_);
+        for (const std::vector<float>* v : {&w0_, &b0_, &w1_, &b1_}) { memcpy(d, v->data(), sizeof(float) * v->size()); d += sizeof(float) * v->size(); }
     }
-    Plugin* clone() const override { return new DsvtPillarFeatureNetPlugin(max_pillars_, layer_, w0_.data(), b0_.data(), w_.empty() ? nullptr : w_.data()); }
+    Plugin* clone() const override { return new DsvtPillarFeatureNetPlugin(max_pillars_, w0_.data(), b0_.data(), w1_.data(), b1_.data()); }
 };
 static Plugin* pfnCreate(const DsvtPluginFieldCollection* fc) {
-    const int mp = fieldInt(fc, "max_pillars_num"), layer = fieldInt(fc, "layer");
-    const DsvtPluginField* w0 = findField(fc, "weight0"); const DsvtPluginField* b0 = findField(fc, "bias0");
-    const DsvtPluginField* w1 = findField(fc, "weight1");
-    if (mp <= 0 || layer < 0 || layer > 1 || !w0 || !w0->data || w0->length != PF_C0 * PF_IN || !b0 || !b0->data || b0->length != PF_C0) return nullptr;
-    if (layer && (!w1 || !w1->data || w1->length != PF_C1 * PF_C0)) return nullptr;
-    return new DsvtPillarFeatureNetPlugin(mp, layer, static_cast<const float*>(w0->data), static_cast<const float*>(b0->data),
-                                          layer ? static_cast<const float*>(w1->data) : nullptr);
+    const int mp = fieldInt(fc, "max_pillars_num");
+    struct Need { const char* name; int len; } need[] = {{"weight0", PF_C0 * PF_IN}, {"bias0", PF_C0}, {"weight1", PF_C1 * PF_C1}, {"bias1", PF_C1}};
+    const float* p[4];
+    for (int i = 0; i < 4; ++i) {
+        const DsvtPluginField* f = findField(fc, need[i].name);
+        if (!f || !f->data || f->length != need[i].len) return nullptr;
+        p[i] = static_cast<const float*>(f->data);
+    }
+    return mp > 0 ? new DsvtPillarFeatureNetPlugin(mp, p[0], p[1], p[2], p[3]) : nullptr;
 }
 static Plugin* pfnDeser(const void* data, size_t len) {
-    if (len < 2 * sizeof(int)) return nullptr;
+    if (len < sizeof(int)) return nullptr;
     const char* d = static_cast<const char*>(data);
-    const int mp = rd<int>(d), layer = rd<int>(d);
-    if (mp <= 0 || layer < 0 || layer > 1) return nullptr;
-    const size_t n = (size_t)PF_C0 * PF_IN + PF_C0 + (layer ? (size_t)PF_C1 * PF_C0 : 0);
-    if (len < 2 * sizeof(int) + n * sizeof(float)) return nullptr;
+    const int mp = rd<int>(d);
+    const size_t n = (size_t)PF_C0 * PF_IN + PF_C0 + (size_t)PF_C1 * PF_C1 + PF_C1;
+    if (mp <= 0 || len < sizeof(int) + n * sizeof(float)) return nullptr;
     std::vector<float> all(n); memcpy(all.data(), d, n * sizeof(float));
-    return new DsvtPillarFeatureNetPlugin(mp, layer, all.data(), all.data() + PF_C0 * PF_IN, layer ? all.data() + PF_C0 * PF_IN + PF_C0 : nullptr);
+    const float* q = all.data();
+    return new DsvtPillarFeatureNetPlugin(mp, q, q + PF_C0 * PF_IN, q + PF_C0 * PF_IN + PF_C0, q + PF_C0 * PF_IN + PF_C0 + (size_t)PF_C1 * PF_C1);
 }
 static Creator g_pfnCreator{"DsvtPillarFeatureNetPlugin",
-    {{"max_pillars_num", DSVT_FIELD_INT32}, {"layer", DSVT_FIELD_INT32}, {"weight0", DSVT_FIELD_FLOAT32}, {"bias0", DSVT_FIELD_FLOAT32},
-     {"weight1", DSVT_FIELD_FLOAT32}},
+    {{"max_pillars_num", DSVT_FIELD_INT32}, {"weight0", DSVT_FIELD_FLOAT32}, {"bias0", DSVT_FIELD_FLOAT32}, {"weight1", DSVT_FIELD_FLOAT32},
+     {"bias1", DSVT_FIELD_FLOAT32}},
     pfnCreate, pfnDeser, {}, {}};
 static Registrar g_pfnReg(&g_pfnCreator);
 

@@ -95,12 +95,10 @@ class DsvtPipeline:
         self.pfn0 = zf(P.add_linear_op(W0, b0, c.Nk, activation=P.ACT_RELU, **ct))
         self.pfn1 = zf(P.add_linear_op(W1, b1, c.Nk, activation=P.ACT_RELU, **ct))
         self.pfn0.rows_kind = self.pfn1.rows_kind = "Nk"      # rows = kept points, not pillars (bench flop count)
-        # fp16 mode: the whole voxel feature encoder without per-point activations (csrc/pfn.hip): FC1(cat) = W1a x0 + W1b max(x0) + b1
+        # fp16 mode: the whole voxel feature encoder in one launch, no per-point activation in memory (csrc/pfn.hip)
         self.fused_pfn = f16
         if self.fused_pfn:
-            self.pfnA = zf(P.add_pillar_feature_net_op(c.P, 0, W0, b0))
-            self.pfnT = zf(P.add_linear_op(np.ascontiguousarray(W1[:, 96:]), b1, c.P))          # fp32, K = 96: per-pillar term
-            self.pfnB = zf(P.add_pillar_feature_net_op(c.P, 1, W0, b0, np.ascontiguousarray(W1[:, :96])))
+            self.pfn = zf(P.add_pillar_feature_net_op(c.P, W0, b0, W1, b1))
         self.smax0 = zf(P.add_torch_scatter_max(c.Nk, c.P, 96))
         self.smax1 = zf(P.add_torch_scatter_max(c.Nk, c.P, 192))
         self.wp = [zf(P.add_window_partition(c.W, c.Vw, GX, GY, GZ, *win, *shift)) for win, shift in WINS]
@@ -307,8 +305,7 @@ class DsvtPipeline:
     def voxel_stage(self, points, n):
         feat, pidx, coords, pcnt, Pn, Nk = self.voxelizer(points, n)
         if self.fused_pfn:
-            m = self.pfnA(feat, pidx, pcnt, Pn)[0]
-            vfeat, vfeat16 = self.pfnB(feat, pidx, pcnt, Pn, self.pfnT(m, Pn)[0])
+            vfeat, vfeat16 = self.pfn(feat, pidx, pcnt, Pn)
             wps = [op(coords, Pn) for op in self.wp]
             gss = [op(wp[0], wp[1], wp[2], wp[3]) for op, wp in zip(self.gs, wps)]
             return dict(feat=feat, pidx=pidx, coords=coords, pcnt=pcnt, P=Pn, Nk=Nk, vfeat=vfeat, vfeat16=vfeat16, wps=wps, gss=gss)

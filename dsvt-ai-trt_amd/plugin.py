@@ -396,15 +396,14 @@ def add_center_head_topk_op(feature_height, feature_width, channel_num=18, class
                                                hm_offset=hm_offset), "center_head_topk_layer")
 
 
-def add_pillar_feature_net_op(max_pillars_num, layer, weight0, bias0, weight1=None):
-    """Both PFN layers + scatter-max reductions without per-point activations (csrc/pfn.hip).  BatchNorm folded by the caller.
-    layer 0: (feat, pidx, pcnt, pillar_num) -> max_pillar(x0) [1,P,96];  layer 1: (..., t [1,P,192]) -> pillar features
-    [1,P,192] fp32 + fp16, where t = W1[:, 96:] max_pillar(x0) + b1 and weight1 = W1[:, :96]."""
-    f = dict(max_pillars_num=int(max_pillars_num), layer=int(layer), weight0=np.asarray(weight0, np.float32).reshape(-1),
-             bias0=np.asarray(bias0, np.float32).reshape(-1))
-    if layer:
-        f["weight1"] = np.ascontiguousarray(np.asarray(weight1, np.float32)).reshape(-1)
-    return Plugin("DsvtPillarFeatureNetPlugin", f, "pillar_feature_net_layer")
+def add_pillar_feature_net_op(max_pillars_num, weight0, bias0, weight1, bias1):
+    """Both PFN layers + both scatter-max reductions in one launch, no per-point activation in memory (csrc/pfn.hip).
+    BatchNorm folded by the caller: weight0 [96,10], weight1 [192,192] (columns 0..95 act on x0, 96..191 on its pillar max).
+    Inputs: feat [1,Nk,10], pidx [1,P,T], pcnt [1,P,1], pillar_num [1].  Outputs: pillar features [1,P,192] fp32 + fp16."""
+    return Plugin("DsvtPillarFeatureNetPlugin", dict(
+        max_pillars_num=int(max_pillars_num), weight0=np.asarray(weight0, np.float32).reshape(-1),
+        bias0=np.asarray(bias0, np.float32).reshape(-1), weight1=np.ascontiguousarray(np.asarray(weight1, np.float32)).reshape(-1),
+        bias1=np.asarray(bias1, np.float32).reshape(-1)), "pillar_feature_net_layer")
 
 
 def add_rotated_nms_op(max_boxes=500, nms_thresh=0.01):
