@@ -10,14 +10,14 @@
 //     both per-point maxima, m_p and U_p = max_points(W1a x0), come out of ONE pass over the points;
 //   * x0 is consumed from registers (the layer-0 tile is the B operand of layer 1, see mlp.hip).
 // A workgroup owns 16 consecutive pillars; the compact point ids of a pillar are consecutive (Points2Features' canonical
-// order: pillar-major, then slot), so it owns a contiguous range of point rows and no pillar straddles workgroups:
-// the maxima live in LDS tables (ds_max_u32 on order-preserving keys), nothing is atomic in global memory.  After the
-// point loop the workgroup computes t = W1b m (16 x 96 x 192 on the matrix cores, W1b fragments straight from L2) and
+// order: pillar-major, then slot) and every 16-point MFMA tile belongs to one pillar, so the maxima are plain register
+// reductions: nothing is atomic, in LDS or in global memory.  After the point pass the workgroup computes t = W1b m (16 x 96 x 192 on the matrix cores, W1b fragments straight from L2) and
 // writes  vfeat_p = ReLU(U_p + t_p + b1)  as fp32 and fp16.
 // Arithmetic: layer 0 on v_mfma_f32_16x16x4_f32 (fp32: the inputs are raw metric coordinates), both halves of layer 1 on
 // v_mfma_f32_16x16x32_f16 (operands rounded to fp16, fp32 accumulate); maxima, bias, ReLU in fp32.
 #include "plugin_base.h"
 #include "device_utils.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace dsvt {
@@ -28,7 +28,7 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 constexpr int PF_IN = 10, PF_C0 = 96, PF_C1 = 192;
 constexpr int PF_PB = 16;              // pillars per workgroup (= one MFMA row tile of the per-pillar GEMM)
-constexpr int PF_NW = 4;               // waves per workgroup: 64 point rows per iteration
+constexpr int PF_NW = 4;               // waves per workgroup (four pillars of a group each; 8 waves measured 12 % slower)
 
 struct PfnArgs {
     const float* feat;                 // [Nk, 10]
@@ -40,6 +40,8 @@ struct PfnArgs {
     const _Float16* w1b;               // fragment-ordered [3 k-steps][12 tiles][64 lanes][8], natural k
     const float* b1;                   // [192]
     float* out; _Float16* out16;       // vfeat [P,192] + fp16 copy
+    unsigned long long* trace;         // debugging: phase timestamps of workgroup 0
+    int dbg;                           // timing ablations (wrong results): 1 no m atomics, 2 no U atomics, 4 no layer-1 MFMA, 8 no epilogue
 };
 
 __device__ __forceinline__ uint32_t pfnKey(float f) {            // larger float <=> larger key; every key > 0
@@ -48,27 +50,29 @@ __device__ __forceinline__ uint32_t pfnKey(float f) {            // larger float
 }
 __device__ __forceinline__ float pfnUnkey(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
+// max over the four 16-lane groups (lanes l, l ^ 16, l ^ 32, l ^ 48) on the VALU: v_permlane16_swap / v_permlane32_swap with both
+// operands equal broadcast the even / odd rows (lower / upper half) into two registers
+__device__ __forceinline__ float maxOverLaneGroups(float v) {
+    const uint32_t u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float w = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const uint32_t x = __float_as_uint(w);
+    const auto b = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 __global__ void __launch_bounds__(64 * PF_NW)
 pfn_kernel(PfnArgs a)
 {
-    __shared__ uint32_t sM[PF_PB * PF_C0];                             // max_pillar(x0): bit patterns (x0 >= 0)          6 KB
-    __shared__ uint32_t sU[PF_PB * PF_C1];                             // max_pillar(W1a x0): order-preserving keys         12 KB
+    __shared__ uint32_t sM[PF_PB * PF_C0];                             // max_pillar(x0), float bits                      6 KB
+    __shared__ uint32_t sU[PF_PB * PF_C1];                             // max_pillar(W1a x0), float bits                 12 KB
     __shared__ uint32_t sStart[PF_PB + 1];
     __shared__ __attribute__((aligned(16))) _Float16 sW1[3 * 12 * 512];                                                // 36 KB
     uint32_t P = *a.pillar_num; if (P > (uint32_t)a.max_pillars) P = a.max_pillars;
-    const uint32_t pb0 = blockIdx.x * PF_PB;
-    if (pb0 >= P) return;
-    const int npil = P - pb0 < (uint32_t)PF_PB ? (int)(P - pb0) : PF_PB;
+    const uint32_t ngroups = (P + PF_PB - 1) / PF_PB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
-
-    for (int i = tid; i < PF_PB * PF_C0; i += 64 * PF_NW) sM[i] = 0u;
-    for (int i = tid; i < PF_PB * PF_C1; i += 64 * PF_NW) sU[i] = 0u;
-    if (tid <= npil) {
-        // first row of pillar pb0 + tid; the sentinel entry is one past the last pillar's rows
-        const uint32_t p = pb0 + (tid < npil ? tid : npil - 1);
-        const uint32_t s = a.pidx[(size_t)p * a.T];
-        sStart[tid] = tid < npil ? s : s + a.pcnt[p];
-    }
+    if (blockIdx.x >= ngroups) return;
+    // persistent workgroup: W1a (36 KB) and the layer-0 fragments are loaded once, groups of 16 pillars round-robin
     for (int i = tid; i < 3 * 12 * 64; i += 64 * PF_NW)
         *reinterpret_cast<uint4*>(&sW1[i * 8]) = *reinterpret_cast<const uint4*>(a.w1a + (size_t)i * 8);
     // layer-0 weights as MFMA A fragments: lane (r, g) holds W0[16t + r][4ks + g]
@@ -80,66 +84,116 @@ pfn_kernel(PfnArgs a)
         const float4 b = *reinterpret_cast<const float4*>(a.b0 + 16 * t + 4 * g);
         b0f[t][0] = b.x; b0f[t][1] = b.y; b0f[t][2] = b.z; b0f[t][3] = b.w;
     }
-    __syncthreads();
-    const uint32_t row0 = sStart[0], rowEnd = sStart[npil];
+    int nmark = 0;
+    auto mark = [&]() { if (a.trace && blockIdx.x == 0 && tid == 0 && nmark < 32) a.trace[nmark] = clock64(); ++nmark; };
+    mark();
+  for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    __syncthreads();                                 // everyone is done with the previous group's tables
+    mark();
+    const uint32_t pb0 = grp * PF_PB;
+    const int npil = P - pb0 < (uint32_t)PF_PB ? (int)(P - pb0) : PF_PB;
 
-    // B fragment of layer 0: lane (r, g) holds f[row][4ks + g]; the next iteration's values are requested one iteration ahead
-    auto loadFeat = [&](uint32_t base, float (&fb)[3]) {
-        const uint32_t row = base + 16 * wave + r;
-        const float* fr = a.feat + (size_t)(row < rowEnd ? row : row0) * PF_IN;
+    for (int i = tid; i < PF_PB * PF_C0; i += 64 * PF_NW) sM[i] = 0u;
+    for (int i = tid; i < PF_PB * PF_C1; i += 64 * PF_NW) sU[i] = 0u;
+    if (tid <= npil) {
+        // first row of pillar pb0 + tid; the sentinel entry is one past the last pillar's rows
+        const uint32_t p = pb0 + (tid < npil ? tid : npil - 1);
+        const uint32_t s = a.pidx[(size_t)p * a.T];
+        sStart[tid] = tid < npil ? s : s + a.pcnt[p];
+    }
+    __syncthreads();
+    // ---- point pass: one pillar at a time per wave, 16 points per MFMA tile (a short tile is padded with copies of the
+    // pillar's first point: duplicates do not change a maximum).  Every tile belongs to ONE pillar, so the pillar maxima are
+    // plain reductions -- ds_max atomics from 16 lanes that share a pillar serialise at ~100 cycles per instruction --
+    //   x0^T tile  = W0 (A) x f (B)      transposed layout, lane = point: the k-permuted B... operand of layer 1 (see mlp.hip)
+    //   x0   tile  = f (A) x W0 (B)      lane (r', g') = column r', points 4g'..4g'+3: max over points = 3 in-register max + 2 shuffles
+    //   u    tile  = x0 (A) x W1a (B)    same layout; the chained fragment works as the A operand just as well
+    float b0c[6];
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) { const int k = 4 * ks + g; fb[ks] = k < PF_IN ? fr[k] : 0.f; }
+    for (int t = 0; t < 6; ++t) b0c[t] = a.b0[16 * t + r];
+    mark();
+    // flat walk over this wave's (pillar, tile) pairs; the next tile's point rows are requested before the current tile's MFMAs
+    auto loadTile = [&](uint32_t base, uint32_t s0, uint32_t e0, float (&fbv)[3]) {
+        const uint32_t row = base + r;
+        const float* fr = a.feat + (size_t)(row < e0 ? row : s0) * PF_IN;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) { const int k = 4 * ks + g; fbv[ks] = k < PF_IN ? fr[k] : 0.f; }
     };
+    int pl = wave;
+    bool have = pl < npil;
+    uint32_t s0 = 0, e0 = 0, base = 0;
     float fb[3], fnext[3];
-    loadFeat(row0, fb);
-    for (uint32_t base = row0; base < rowEnd; base += 16 * PF_NW) {
-        if (base + 16 * PF_NW < rowEnd) loadFeat(base + 16 * PF_NW, fnext);
-        const uint32_t row = base + 16 * wave + r;
-        const bool valid = row < rowEnd;
-        int j = 0;                                   // pillar of this row: the last j with sStart[j] <= row
+    if (have) { s0 = sStart[pl]; e0 = sStart[pl + 1]; base = s0; loadTile(base, s0, e0, fnext); }
+    float mx0[6], mxu[12];
 #pragma unroll
-        for (int step = PF_PB / 2; step > 0; step >>= 1) { const int c = j + step; if (c < npil && sStart[c] <= row) j = c; }
-        // ---- layer 0: x0^T tile = ReLU(W0 f^T + b0) --------------------------------------------------------------------
+    for (int t = 0; t < 6; ++t) mx0[t] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 12; ++t) mxu[t] = -INFINITY;
+    while (have) {
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) fb[ks] = fnext[ks];
+        // the tile after this one
+        const bool lastOfPillar = base + 16 >= e0;
+        int npl = pl; uint32_t ns0 = s0, ne0 = e0, nbase = base + 16;
+        if (lastOfPillar) { npl = pl + PF_NW; if (npl < npil) { ns0 = sStart[npl]; ne0 = sStart[npl + 1]; nbase = ns0; } }
+        const bool haveNext = npl < npil;
+        if (haveNext) loadTile(nbase, ns0, ne0, fnext);
+
         floatx4 x0[6];
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
             x0[t] = floatx4{b0f[t][0], b0f[t][1], b0f[t][2], b0f[t][3]};
+            floatx4 d0 = {b0c[t], b0c[t], b0c[t], b0c[t]};
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) x0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0f[t][ks], fb[ks], x0[t], 0, 0, 0);
+            for (int ks = 0; ks < 3; ++ks) {
+                x0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0f[t][ks], fb[ks], x0[t], 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[ks], w0f[t][ks], d0, 0, 0, 0);
+            }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) x0[t][i] = fmaxf(x0[t][i], 0.f);                 // ReLU (:144)
+            for (int i = 0; i < 4; ++i) x0[t][i] = fmaxf(x0[t][i], 0.f);             // ReLU (:144)
+            mx0[t] = fmaxf(mx0[t], fmaxf(fmaxf(d0[0], d0[1]), fmaxf(d0[2], d0[3])));  // max(ReLU(.)) = max(0, max(.))
         }
-        if (valid) {
+        if (!(a.dbg & 4)) {
+            half8 f1[3];
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int s = 0; s < 3; ++s) {
+                half8 h;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) atomicMax(&sM[j * PF_C0 + 16 * t + 4 * g + i], __float_as_uint(x0[t][i]) & 0x7fffffffu);      // (-0 -> +0)
-        }
-        // ---- per-point half of layer 1: u^T = W1a x0^T; the layer-0 tile is the B operand (k-step s = tiles 2s, 2s+1) -----
-        half8 f1[3];
+                for (int i = 0; i < 4; ++i) { h[i] = (_Float16)x0[2 * s][i]; h[4 + i] = (_Float16)x0[2 * s + 1][i]; }
+                f1[s] = h;
+            }
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            half8 h;
+            for (int t = 0; t < 12; ++t) {
+                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { h[i] = (_Float16)x0[2 * s][i]; h[4 + i] = (_Float16)x0[2 * s + 1][i]; }
-            f1[s] = h;
-        }
-#pragma unroll
-        for (int t = 0; t < 12; ++t) {
-            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 3; ++s)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(&sW1[((s * 12 + t) * 64 + lane) * 8]), f1[s], acc, 0, 0, 0);
-            if (valid) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) atomicMax(&sU[j * PF_C1 + 16 * t + 4 * g + i], pfnKey(acc[i]));
+                for (int s = 0; s < 3; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1[s], *reinterpret_cast<const half8*>(&sW1[((s * 12 + t) * 64 + lane) * 8]), acc, 0, 0, 0);
+                mxu[t] = fmaxf(mxu[t], fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
             }
         }
+        if (lastOfPillar) {
+            // across the four lane groups (points 4g'..4g'+3), then lane group 0 owns column 16t + r
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) fb[ks] = fnext[ks];
+            for (int t = 0; t < 6; ++t) mx0[t] = maxOverLaneGroups(mx0[t]);
+#pragma unroll
+            for (int t = 0; t < 12; ++t) mxu[t] = maxOverLaneGroups(mxu[t]);
+            if (g == 0) {
+#pragma unroll
+                for (int t = 0; t < 6; ++t) sM[pl * PF_C0 + 16 * t + r] = __float_as_uint(mx0[t]);
+#pragma unroll
+                for (int t = 0; t < 12; ++t) sU[pl * PF_C1 + 16 * t + r] = __float_as_uint(mxu[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 6; ++t) mx0[t] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 12; ++t) mxu[t] = -INFINITY;
+        }
+        pl = npl; s0 = ns0; e0 = ne0; base = nbase; have = haveNext;
     }
+    mark();
     __syncthreads();
-    // ---- per-pillar half: t^T = W1b m^T (16 pillars x 96 -> 192); wave w owns column tiles 3w .. 3w+2 ---------------------
+    mark();
+    // ---- per-pillar half: t^T = W1b m^T (16 pillars x 96 -> 192); wave w owns column tiles w, w + 8 ----------------------------
     half8 mf[3];                                     // B fragment: lane (r, g) holds m[pillar r][32s + 8g + j]
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -150,10 +204,11 @@ pfn_kernel(PfnArgs a)
         h[4] = (_Float16)__uint_as_float(hi.x); h[5] = (_Float16)__uint_as_float(hi.y); h[6] = (_Float16)__uint_as_float(hi.z); h[7] = (_Float16)__uint_as_float(hi.w);
         mf[s] = h;
     }
-    const bool pv = r < npil;
+    const bool pv = r < npil && !(a.dbg & 8);
 #pragma unroll
-    for (int tt = 0; tt < 3; ++tt) {
-        const int t = 3 * wave + tt;
+    for (int tt = 0; tt < (12 + PF_NW - 1) / PF_NW; ++tt) {
+        const int t = wave + tt * PF_NW;
+        if (t >= 12) break;
         floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 3; ++s)
@@ -163,8 +218,8 @@ pfn_kernel(PfnArgs a)
             const float4 b = *reinterpret_cast<const float4*>(a.b1 + col);
             const uint4 u = *reinterpret_cast<const uint4*>(&sU[r * PF_C1 + col]);
             float4 v;
-            v.x = fmaxf(pfnUnkey(u.x) + acc[0] + b.x, 0.f); v.y = fmaxf(pfnUnkey(u.y) + acc[1] + b.y, 0.f);
-            v.z = fmaxf(pfnUnkey(u.z) + acc[2] + b.z, 0.f); v.w = fmaxf(pfnUnkey(u.w) + acc[3] + b.w, 0.f);
+            v.x = fmaxf(__uint_as_float(u.x) + acc[0] + b.x, 0.f); v.y = fmaxf(__uint_as_float(u.y) + acc[1] + b.y, 0.f);
+            v.z = fmaxf(__uint_as_float(u.z) + acc[2] + b.z, 0.f); v.w = fmaxf(__uint_as_float(u.w) + acc[3] + b.w, 0.f);
             *reinterpret_cast<float4*>(a.out + (size_t)(pb0 + r) * PF_C1 + col) = v;
             if (a.out16) {
                 half4 h; h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
@@ -172,6 +227,13 @@ pfn_kernel(PfnArgs a)
             }
         }
     }
+  }
+}
+
+static int pfnCUs() {
+    static int n = 0;
+    if (!n) { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); n = hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }
+    return n;
 }
 
 static inline int pfnPermuteK(int p) {       // see mlp.hip: position p of a permuted weight row holds column k(p)
@@ -231,6 +293,11 @@ public:
                 hipStream_t stream) override {
         if (!ok_) return static_cast<int>(hipErrorOutOfMemory);
         PfnArgs a{};
+        static unsigned long long* tr = nullptr; static int tron = -1;
+        if (tron < 0) { tron = getenv("DSVT_PFN_TRACE") ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 64); }
+        a.trace = tr;
+        static int dbg = -1; if (dbg < 0) { const char* e = getenv("DSVT_PFN_DBG"); dbg = e ? atoi(e) : 0; }
+        a.dbg = dbg;
         a.feat = static_cast<const float*>(in[0]); a.pidx = static_cast<const uint32_t*>(in[1]);
         a.T = inDesc ? inDesc[1].dims.d[inDesc[1].dims.nbDims - 1] : 48;
         a.pcnt = static_cast<const uint32_t*>(in[2]); a.pillar_num = static_cast<const uint32_t*>(in[3]); a.max_pillars = max_pillars_;
@@ -240,7 +307,9 @@ public:
             DSVT_CHECK(hipMemsetAsync(out[0], 0, sizeof(float) * (size_t)max_pillars_ * PF_C1, stream));
             DSVT_CHECK(hipMemsetAsync(out[1], 0, sizeof(_Float16) * (size_t)max_pillars_ * PF_C1, stream));
         }
-        hipLaunchKernelGGL(pfn_kernel, dim3(cdiv(max_pillars_, PF_PB)), dim3(64 * PF_NW), 0, stream, a);
+        int grid = 2 * pfnCUs(); if (grid > cdiv(max_pillars_, PF_PB)) grid = cdiv(max_pillars_, PF_PB);       // two resident workgroups per CU (54 KB of LDS each)
+        hipLaunchKernelGGL(pfn_kernel, dim3(grid), dim3(64 * PF_NW), 0, stream, a);
+        if (tron) { (void)hipStreamSynchronize(stream); fprintf(stderr, "[pfn trace wg0]"); for (int i = 1; i < 24; ++i) fprintf(stderr, " %lld", (long long)(tr[i] - tr[0])); fprintf(stderr, "\n"); }
         return lastError();
     }
     size_t nFloats() const { return w0_.size() + b0_.size() + w1_.size() + b1_.size(); }
