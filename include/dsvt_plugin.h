@@ -35,6 +35,8 @@
  *   DsvtSetAttentionPlugin    GetValueByIndex + MHA core + MapSetFeature2Voxel in one
  *   DsvtEncoderMlpPlugin      out-proj + LayerNorm -> FC1 + GELU -> FC2 + LayerNorms of one encoder
  *                             layer in one launch (src/dsvt-ai-trt.cpp:669-756)
+ *   DsvtPillarFeatureNetPlugin  both PFN layers + both TorchScatterMax reductions in one launch
+ *                             (src/dsvt-ai-trt.cpp:565-589)
  *   DsvtConv2dPlugin          convBnLELU / convBn / deconvBnLELU / conv_with_bias of the BEV
  *                             backbone and CenterHead (src/dsvt-ai-trt.cpp:149-246, 1144-1468)
  *   CenterHeadTopKPlugin      the decode the reference builds from TensorRT layers: sigmoid,
