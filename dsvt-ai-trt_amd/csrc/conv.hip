@@ -302,7 +302,10 @@ __device__ __forceinline__ void slabBarrier(int keep) {
 // CTW = 16-channel tiles per workgroup: 8 (128 output channels; wave (pg, cg) = 64 pixels x 64 channels) or 4 / 2
 // (layers with <= 64 / <= 32 output channels: both waves of a row pair use the same channel tiles and split the four
 // pixel tiles; a 16 KB weight slab then holds 2 / 4 taps, so the barrier cadence stays at 16 fragment rows)
-template <int TH, int KS, int CTW>
+// HB = halo buffers: 2 = the next halo streams in behind the weight slabs (one workgroup per CU);  1 = the halo is reloaded
+// between phases (exposed, but the LDS footprint lets TWO 4-wave workgroups share a CU: their barriers and their
+// LDS-read / MFMA phases are no longer in lockstep)
+template <int TH, int KS, int CTW, int HB>
 __global__ void __launch_bounds__(64 * TH, 1)
 conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __restrict__ zeros, int tilesX, int nitems, int nchunk, int dbg)
 {
@@ -320,7 +323,7 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     constexpr int WPW = (WROWS + TH - 1) / TH;                      // weight rows per wave per slab
     static_assert(KS == 1 || HPW <= T, "one halo request per tap");
     // ONE shared object: halo[2] | wslab[2]  (a second __shared__ object makes hipcc drain the DMA queue before every ds_read)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HBYTES + 2 * WBYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[HB * HBYTES + 2 * WBYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
     const int pg = wave >> 1, cg = wave & 1;
     const int NCC = a.Cin >> 6, NCT = NARROW ? CTW : nchunk * 8;
@@ -358,7 +361,7 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
             const int u = wave + j * TH;
             if (WROWS % TH == 0 || u < WROWS) {
                 const size_t row = NARROW ? (size_t)q0 * CTW + u : (size_t)(q0 + (u >> 3)) * NCT + ch * 8 + (u & 7);
-                __builtin_amdgcn_global_load_lds((glds_src_t)(Wp + (row * 64 + lane) * 8), (glds_dst_t)(smem + 2 * HBYTES + wb * WBYTES + u * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glds_src_t)(Wp + (row * 64 + lane) * 8), (glds_dst_t)(smem + HB * HBYTES + wb * WBYTES + u * 1024), 16, 0, 0);
             }
         }
     };
@@ -442,7 +445,8 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                 }
                 // the next halo is requested AFTER this slab's weight requests, one per tap: the slab-end wait (in-order
                 // counter, vmcnt(nreq)) retires the weights and leaves the halo requests in flight across the barrier
-                if (KS == 1) {
+                if (HB == 1) {
+                } else if (KS == 1) {
                     if (haloNext) {
 #pragma unroll
                         for (int j = 0; j < HPW; ++j)
@@ -455,7 +459,7 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                     }
                 }
                 const unsigned char* hbp = smem + hb * HBYTES;
-                const unsigned char* wbp = smem + 2 * HBYTES + wb * WBYTES + (lane << 4);
+                const unsigned char* wbp = smem + HB * HBYTES + wb * WBYTES + (lane << 4);
                 const int ky = tap / KS, kx = tap - ky * KS;
                 const int toff = (ky * HS + kx) * 128;
                 const int sw = swz[kx];
@@ -483,8 +487,14 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                     slabBarrier(lastTap ? 0 : nreq);             // the phase's last barrier also publishes the next halo
                     wb ^= 1;
                 }
+                if (HB == 1 && lastTap && haloNext) {            // everyone is done with the halo: reload it in place
+#pragma unroll
+                    for (int j = 0; j < HPW; ++j)
+                        if (NI % TH == 0 || wave + j * TH < NI) haloRequest(j, ncc, 0);
+                    slabBarrier(0);
+                }
             }
-            hb ^= 1;
+            if (HB == 2) hb ^= 1;
         }
         pending = true; ey = y0; ex = x0; ech = chunk;
         if (!have_next) break;
@@ -517,17 +527,23 @@ static int haloTileRows(const ConvArgs& a) {
 }
 
 static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16* zeros, hipStream_t stream) {
-    const int th = haloTileRows(a);
+    int th = haloTileRows(a);
+    // measured on the 468x468 layers: 64-channel outputs (both waves of a row pair share the channel tiles) run 11 % faster as
+    // two decoupled 4-row workgroups per CU; 128-channel outputs 34 % slower (twice the weight traffic)
+    if (!getenv("DSVT_CONV_TH") && haloChannelTiles(a.CoutRows) == 4) th = 4;
     const int tilesX = cdiv(a.Wo, HTW), nchunk = cdiv(a.CoutRows, CNB);
     const int nitems = cdiv(a.Ho, th) * tilesX * nchunk;
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("DSVT_CONV_DBG"); dbg = e ? atoi(e) : 0; }           // timing ablations only (wrong results)
     static int gridCap = -1;
     if (gridCap < 0) { const char* e = getenv("DSVT_CONV_GRID"); gridCap = e ? atoi(e) : 0; }      // test knob: force multi-item workgroups
-    int grid = nitems < numCUs() ? nitems : numCUs();
+    static int hb1 = -1;           // 4-row tiles run as two single-halo-buffer workgroups per CU (DSVT_CONV_HB1=0: one double-buffered)
+    if (hb1 < 0) { const char* e = getenv("DSVT_CONV_HB1"); hb1 = e ? atoi(e) : 1; }
+    const int slots = (th == 4 && hb1) ? 2 * numCUs() : numCUs();
+    int grid = nitems < slots ? nitems : slots;
     if (gridCap > 0 && grid > gridCap) grid = gridCap;
-#define DSVT_HALO_LAUNCH(TH_, KS_, CTW_) hipLaunchKernelGGL((conv_halo_kernel<TH_, KS_, CTW_>), dim3(grid), dim3(64 * TH_), 0, stream, a, Wp, zeros, tilesX, nitems, nchunk, dbg)
-#define DSVT_HALO_TH(KS_, CTW_) do { if (th == 8) DSVT_HALO_LAUNCH(8, KS_, CTW_); else DSVT_HALO_LAUNCH(4, KS_, CTW_); } while (0)
+#define DSVT_HALO_LAUNCH(TH_, KS_, CTW_, HB_) hipLaunchKernelGGL((conv_halo_kernel<TH_, KS_, CTW_, HB_>), dim3(grid), dim3(64 * TH_), 0, stream, a, Wp, zeros, tilesX, nitems, nchunk, dbg)
+#define DSVT_HALO_TH(KS_, CTW_) do { if (th == 8) DSVT_HALO_LAUNCH(8, KS_, CTW_, 2); else if (hb1) DSVT_HALO_LAUNCH(4, KS_, CTW_, 1); else DSVT_HALO_LAUNCH(4, KS_, CTW_, 2); } while (0)
     const int ctw = haloChannelTiles(a.CoutRows);
     if (a.KH == 3) { if (ctw == 8) DSVT_HALO_TH(3, 8); else if (ctw == 4) DSVT_HALO_TH(3, 4); else DSVT_HALO_TH(3, 2); }
     else           { if (ctw == 8) DSVT_HALO_TH(1, 8); else if (ctw == 4) DSVT_HALO_TH(1, 4); else DSVT_HALO_TH(1, 2); }
