@@ -293,7 +293,15 @@ __device__ __forceinline__ void slabBarrier(int keep) {
         case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory"); break;
         case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
         case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); break;
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -322,8 +330,11 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     constexpr int HPW = (NI + TH - 1) / TH;                         // ... per wave
     constexpr int WPW = (WROWS + TH - 1) / TH;                      // weight rows per wave per slab
     static_assert(KS == 1 || HPW <= T, "one halo request per tap");
+    // weight slabs in flight: NWB = 3 (slab s+2 requested when slab s starts, counted vmcnt at the slab end) is implemented and
+    // measured 8 % SLOWER than one slab of lead on the 468x468 layers (117.7 vs 108.6 us): the slab-end wait is not what stalls
+    constexpr int NWB = 2, LEAD = NWB - 1;
     // ONE shared object: halo[2] | wslab[2]  (a second __shared__ object makes hipcc drain the DMA queue before every ds_read)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[HB * HBYTES + 2 * WBYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[HB * HBYTES + NWB * WBYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
     const int pg = wave >> 1, cg = wave & 1;
     const int NCC = a.Cin >> 6, NCT = NARROW ? CTW : nchunk * 8;
@@ -409,8 +420,11 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     for (int j = 0; j < HPW; ++j)
         if (NI % TH == 0 || wave + j * TH < NI) haloRequest(j, 0, 0);
     weightRequests(0, chunk, 0);
+    if (LEAD == 2) weightRequests(TPS * 2, chunk, 1);           // (NG >= 3 for the 3x3 variants: the second slab is in the same phase)
     slabBarrier(0);
     int hb = 0, wb = 0;
+    const int wcnt = (WROWS - wave + TH - 1) / TH;              // weight requests this wave issues per slab
+    int nreqPrev = 0;                                           // halo requests issued during the previous slab
     bool pending = false; int ey = 0, ex = 0, ech = 0;          // finished item whose epilogue has not run yet
     for (;;) {
         const int ctn = tilesOf(chunk);
@@ -424,6 +438,7 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
             }
             const bool haloNext = have_next && !(dbg & 1);
             int nreq = 0;                                        // halo requests issued after the current slab's weight requests
+            bool wIssued = false;
 #pragma unroll
             for (int tap = 0; tap < T; ++tap) {
                 constexpr int dummy = 0; (void)dummy;
@@ -439,8 +454,12 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
 #pragma unroll
                             for (int m = 0; m < NM; ++m) acc[ct][m] = floatx4{0.f, 0.f, 0.f, 0.f};
                     }
-                    if ((!lastGroup || have_next) && !(dbg & 2))
-                        weightRequests(lastGroup ? ncc * T * 2 : (cc * T + (grp + 1) * TPS) * 2, lastGroup ? nch : chunk, wb ^ 1);
+                    // the slab LEAD ahead: (cc, grp + LEAD) or, past the end of this phase, (ncc, grp + LEAD - NG) of the next one
+                    wIssued = false;
+                    if (!(dbg & 2)) {
+                        if (grp + LEAD < NG) { weightRequests((cc * T + (grp + LEAD) * TPS) * 2, chunk, (wb + LEAD) % NWB); wIssued = true; }
+                        else if (have_next) { weightRequests((ncc * T + (grp + LEAD - NG) * TPS) * 2, nch, (wb + LEAD) % NWB); wIssued = true; }
+                    }
                     nreq = 0;
                 }
                 // the next halo is requested AFTER this slab's weight requests, one per tap: the slab-end wait (in-order
@@ -484,8 +503,16 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                 };
                 if (dbg & 4) {} else if (ctn == CTP) slab(std::true_type{}); else slab(std::false_type{});
                 if (endOfSlab) {
-                    slabBarrier(lastTap ? 0 : nreq);             // the phase's last barrier also publishes the next halo
-                    wb ^= 1;
+                    // in issue order the queue holds: [W of the next slab] [halo reqs of the previous slab] [W issued at this slab's
+                    // start] [halo reqs of this slab].  LEAD 1: retire everything but this slab's halo requests.  LEAD 2: retire the
+                    // next slab's weights, i.e. leave the three younger groups in flight.  The last slab of a phase also publishes
+                    // the next halo: its youngest request is at least two taps old by then, so only weights may stay in flight.
+                    int keep;
+                    if (LEAD == 1) keep = lastTap ? 0 : nreq;
+                    else keep = (lastTap ? 0 : nreq + nreqPrev) + (wIssued ? wcnt : 0);
+                    slabBarrier(keep);
+                    nreqPrev = nreq;
+                    wb = (wb + 1) % NWB;
                 }
                 if (HB == 1 && lastTap && haloNext) {            // everyone is done with the halo: reload it in place
 #pragma unroll
