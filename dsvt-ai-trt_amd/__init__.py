@@ -12,3 +12,4 @@ from . import plugin          # noqa: F401  (loads libdsvt_hip.so or raises)
 from . import synth           # noqa: F401
 from . import pipeline        # noqa: F401
 from . import parallel        # noqa: F401
+from . import hostio          # noqa: F401

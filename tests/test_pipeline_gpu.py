@@ -121,3 +121,28 @@ def test_boxes_f16_mode(pkg, oracle, weights, frame):
     assert err[:2].max() < 2e-3 and err[2] < 5e-3 and err[3:6].max() < 5e-3 and err[8] < 2e-3
     assert err[6] < 1e-1
     assert abs(int(cnt[0]) - ec) <= 2
+
+
+def test_frame_uploader_feeds_the_pipeline(pkg):
+    """hostio.FrameUploader moves n x 16 bytes (not the zero-padded cap) from pinned memory; the plugins bound every loop by
+    the device-side count, so stale rows beyond n from an earlier, larger frame must not matter."""
+    P = pkg.plugin
+    c = cases.caps("ref")
+    up = pkg.hostio.FrameUploader(c["N"], depth=1)
+    vox = P.add_voxel_generator(c["N"], c["Nk"], c["P"], 4, 10, 48, -74.88, 74.88, -74.88, 74.88, -5.0, 3.0, 0.32, 0.32, 8.0, 468, 468, 1)
+    big, nb = pkg.hostio.load_bin(f"{cases.GOLDEN}/000000.bin", c["N"])
+    small, ns = pkg.hostio.load_bin(f"{cases.GOLDEN}/000004.bin", c["N"])
+    assert nb != ns
+    outs = {}
+    for name, (pts, n) in (("big", (big, nb)), ("small", (small, ns)), ("big2", (big, nb))):
+        d, dn = up.upload(pts, n)
+        outs[name] = [t.clone() for t in vox(d, dn)]
+    torch.cuda.synchronize()
+    for a, b in zip(outs["big"], outs["big2"]):
+        assert torch.equal(a, b)
+    # the same frame through a freshly zero-padded buffer
+    pad, n = cases.load_frame("000004", c["N"])
+    ref = vox(torch.from_numpy(pad[None]).to("cuda:0"), torch.tensor([n], dtype=torch.int32, device="cuda:0"))
+    torch.cuda.synchronize()
+    for a, b in zip(outs["small"], ref):
+        assert torch.equal(a, b)
