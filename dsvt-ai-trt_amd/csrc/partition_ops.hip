@@ -44,12 +44,27 @@ wp_count(const uint4* __restrict__ coords, const uint32_t* __restrict__ voxel_nu
          uint32_t* __restrict__ win_cnt, uint32_t* __restrict__ vox_win, uint32_t* __restrict__ vox_slot)
 {
     uint32_t n = *voxel_num; if (n > (uint32_t)max_pillars) n = max_pillars;
-    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n) return;
-    uint32_t win, ix, iy, iz;
-    winOf(coords[v], p, win, ix, iy, iz);
-    vox_win[v] = win;
-    vox_slot[v] = win == kNoneU ? 0u : atomicAdd(&win_cnt[win], 1u);     // count only; order fixed in wp_fill
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t win = kNoneU, ix, iy, iz;
+    if (v < n) { winOf(coords[v], p, win, ix, iy, iz); vox_win[v] = win; }
+    // Pillars are sorted by y * GX + x, so consecutive lanes mostly fall into the same window (12 / 24 cells wide): one atomic
+    // per RUN of equal windows instead of one per voxel (same-address atomics serialise in L2).  Slots only have to be unique
+    // inside a window; their order is fixed in wp_fill.
+    const uint32_t prev = __shfl_up(win, 1, kWave);
+    const bool head = lane == 0 || prev != win;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long below = heads & ((2ull << lane) - 1ull);            // run heads at or before this lane
+    const int leader = 63 - __builtin_clzll(below);
+    uint32_t base = 0;
+    if (head && win != kNoneU) {
+        // run length: up to the next head
+        const unsigned long long nxt = heads & ~((2ull << lane) - 1ull);
+        const int len = (nxt ? __builtin_ctzll(nxt) : 64) - lane;
+        base = atomicAdd(&win_cnt[win], (uint32_t)len);
+    }
+    base = __shfl(base, leader, kWave);
+    if (v < n) vox_slot[v] = win == kNoneU ? 0u : base + (uint32_t)(lane - leader);
 }
 
 // single workgroup: scan the dense window grid
