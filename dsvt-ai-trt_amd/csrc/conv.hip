@@ -581,19 +581,10 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
 
 static int launchConv(const ConvArgs& a, int KC, hipStream_t stream) {
     dim3 grid((unsigned)(cdiv(cdiv(a.Ho * a.Wo, CPX), 8) * 8), (unsigned)cdiv(a.CoutRows, CNB));
-    static int variant = -1;       // 0: 4 waves x 32 pixels   1: 8 waves x 16 pixels (4 waves/SIMD)
-    if (variant < 0) { const char* e = getenv("DSVT_CONV_VARIANT"); variant = e ? atoi(e) : 1; }
-    if (variant == 0) {
-        if (KC == 128) hipLaunchKernelGGL((conv_f16_kernel<128, 2, 4>), grid, dim3(256), 0, stream, a);
-        else if (KC == 96) hipLaunchKernelGGL((conv_f16_kernel<96, 2, 4>), grid, dim3(256), 0, stream, a);
-        else if (KC == 64) hipLaunchKernelGGL((conv_f16_kernel<64, 2, 4>), grid, dim3(256), 0, stream, a);
-        else return -3;
-    } else {
-        if (KC == 128) hipLaunchKernelGGL((conv_f16_kernel<128, 1, 8>), grid, dim3(512), 0, stream, a);
-        else if (KC == 96) hipLaunchKernelGGL((conv_f16_kernel<96, 1, 8>), grid, dim3(512), 0, stream, a);
-        else if (KC == 64) hipLaunchKernelGGL((conv_f16_kernel<64, 1, 8>), grid, dim3(512), 0, stream, a);
-        else return -3;
-    }
+    if (KC == 128) hipLaunchKernelGGL((conv_f16_kernel<128, 1, 8>), grid, dim3(512), 0, stream, a);
+    else if (KC == 96) hipLaunchKernelGGL((conv_f16_kernel<96, 1, 8>), grid, dim3(512), 0, stream, a);
+    else if (KC == 64) hipLaunchKernelGGL((conv_f16_kernel<64, 1, 8>), grid, dim3(512), 0, stream, a);
+    else return -3;
     return lastError();
 }
 

@@ -19,10 +19,9 @@
 // The host stores W1 and W2 with their k columns permuted the same way (dsvt::permuteK), so the W fragment is
 // still one contiguous ds_read_b128.
 //
-// Workgroup = 8 waves x 16 rows = 128 rows; weights stream through one 80 KB LDS buffer: first Wo, then four
-// refills of {W1 rows [96q, 96q+96), W2 columns [96q, 96q+96)}: FC1 is produced 96 columns at a time and each
-// piece is consumed at once as a 96-wide K slab of FC2 (live registers: FC2 accumulator 48 + s1 operand 24 +
-// FC1 piece 24 + h piece 12 -- under the 128 that let two workgroups share a CU).
+// Workgroup = 128 rows (4 waves x 32).  FC1 is produced 64 columns at a time and each piece is consumed at once as a
+// 64-wide K slab of FC2, so neither s1 nor h ever leaves the register file; the weights arrive as fifteen 24 KB stages
+// (see encoder_mlp_stream_kernel below).
 #include "plugin_base.h"
 #include "device_utils.h"
 #include <cstdio>
@@ -36,18 +35,8 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 constexpr int MC = 192, MF = 384;                 // d_model, FFN width (include/params.h:80-84)
 constexpr int MNT = MC / 16;                      // 12 column tiles
-constexpr int MLDW = MC + 16;                     // LDS row stride (halfs)
 constexpr int MNSTEP = MC / 32;                   // 6 k-steps per 192-wide slab
-constexpr int MROWS = 128, MWAVES = 8;
-
-struct MlpArgs {
-    const _Float16* att; const float* x; const float* xb;        // xb == nullptr: no block-residual LayerNorm
-    const _Float16* Wo; const _Float16* W1; const _Float16* W2;   // Wo natural [192][192]; W1 [384][192], W2 [192][384] k-permuted
-    const float* bo; const float* b1; const float* b2;
-    const float* ln_g; const float* ln_b;                         // [4][192]: norm1, norm2, encoder norm, block residual norm
-    float* out; _Float16* out16;
-    const uint32_t* count; int max_rows; float eps;
-};
+constexpr int MROWS = 128;
 
 __device__ __forceinline__ float mlpGelu(float x) {
     const float B = 0.7978845608028654f, C = 0.035677408136300125f;
@@ -88,148 +77,10 @@ __device__ __forceinline__ void packFrags(const floatx4 (&acc)[MNT], half8 (&f)[
     }
 }
 
-constexpr int MQ = 96;                              // FC1 output columns / FC2 K columns handled per LDS refill
-constexpr int MQT = MQ / 16;                        // 6 tiles
-constexpr int MQS = MQ / 32;                        // 3 k-steps
-constexpr int MLDW2 = MQ + 8;                       // W2 quarter-slab row stride (2-way conflicts; 16 would not fit two workgroups per CU)
-
-__global__ void __launch_bounds__(64 * MWAVES, 4)
-encoder_mlp_f16_kernel(MlpArgs a)
-{
-    // 79,872 B: either the whole Wo [192][208], or W1 rows [96][208] followed by W2 columns [192][104]
-    __shared__ __attribute__((aligned(16))) _Float16 sW[MC * MLDW];
-    _Float16* sW1 = sW;
-    _Float16* sW2 = sW + MQ * MLDW;
-    uint32_t cnt = *a.count;
-    const int M = (int)(cnt < (uint32_t)a.max_rows ? cnt : (uint32_t)a.max_rows);
-    const int m0 = blockIdx.x * MROWS;
-    if (m0 >= M) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, g = lane >> 4;
-    const int row = m0 + wave * 16 + r;
-    const bool valid = row < M;
-    const int rc = valid ? row : M - 1;
-    constexpr int NTHR = 64 * MWAVES;
-
-    // ---- GEMM 1: out-proj, natural k order (the B fragment comes from memory) ---------------------------------
-    half8 fs1[MNSTEP];
-    floatx4 acc3[MNT];
-    {
-        half8 fa[MNSTEP];
-#pragma unroll
-        for (int s = 0; s < MNSTEP; ++s) fa[s] = *reinterpret_cast<const half8*>(a.att + (size_t)rc * MC + s * 32 + g * 8);
-        for (int i = tid; i < MC * (MC / 8); i += NTHR) {
-            const int n = i / (MC / 8), c = i % (MC / 8);
-            *reinterpret_cast<uint4*>(&sW[n * MLDW + c * 8]) = *reinterpret_cast<const uint4*>(a.Wo + (size_t)n * MC + c * 8);
-        }
-        __syncthreads();
-        floatx4 acc[MNT];
-#pragma unroll
-        for (int t = 0; t < MNT; ++t) acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
-        const _Float16* pw = &sW[r * MLDW + g * 8];
-#pragma unroll
-        for (int s = 0; s < MNSTEP; ++s)
-#pragma unroll
-            for (int t = 0; t < MNT; ++t) {
-                const half8 wf = *reinterpret_cast<const half8*>(pw + t * 16 * MLDW + s * 32);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, fa[s], acc[t], 0, 0, 0);
-            }
-#pragma unroll
-        for (int t = 0; t < MNT; ++t) {                                 // + bo + x
-            const int col = t * 16 + 4 * g;
-            const float4 b = *reinterpret_cast<const float4*>(a.bo + col);
-            const float4 xv = *reinterpret_cast<const float4*>(a.x + (size_t)rc * MC + col);
-            acc[t][0] += b.x + xv.x; acc[t][1] += b.y + xv.y; acc[t][2] += b.z + xv.z; acc[t][3] += b.w + xv.w;
-        }
-        mlpLayerNorm(acc, a.ln_g, a.ln_b, g, a.eps);                      // s1
-        packFrags(acc, fs1);                                            // s1 as the FC1 operand
-#pragma unroll
-        for (int t = 0; t < MNT; ++t) {                                 // FC2 accumulator starts at s1 + b2 (LN2's residual, fp32)
-            const float4 b = *reinterpret_cast<const float4*>(a.b2 + t * 16 + 4 * g);
-            acc3[t][0] = acc[t][0] + b.x; acc3[t][1] = acc[t][1] + b.y; acc3[t][2] = acc[t][2] + b.z; acc3[t][3] = acc[t][3] + b.w;
-        }
-    }
-
-    // ---- FC1 in four 96-column pieces, each immediately consumed by FC2 as a 96-wide K slab --------------------
-#pragma unroll 1
-    for (int q = 0; q < MF / MQ; ++q) {
-        __syncthreads();                                               // previous slabs are no longer read
-        for (int i = tid; i < MQ * (MC / 8); i += NTHR) {              // W1 rows [96q, 96q+96), all 192 (permuted) k
-            const int n = i / (MC / 8), c = i % (MC / 8);
-            *reinterpret_cast<uint4*>(&sW1[n * MLDW + c * 8]) = *reinterpret_cast<const uint4*>(a.W1 + (size_t)(q * MQ + n) * MC + c * 8);
-        }
-        for (int i = tid; i < MC * (MQ / 8); i += NTHR) {              // W2 (permuted) columns [96q, 96q+96) of all 192 rows
-            const int n = i / (MQ / 8), c = i % (MQ / 8);
-            *reinterpret_cast<uint4*>(&sW2[n * MLDW2 + c * 8]) = *reinterpret_cast<const uint4*>(a.W2 + (size_t)n * MF + q * MQ + c * 8);
-        }
-        __syncthreads();
-        floatx4 acc2[MQT];
-#pragma unroll
-        for (int t = 0; t < MQT; ++t) acc2[t] = floatx4{0.f, 0.f, 0.f, 0.f};
-        {
-            const _Float16* pw = &sW1[r * MLDW + g * 8];
-#pragma unroll
-            for (int s = 0; s < MNSTEP; ++s)
-#pragma unroll
-                for (int t = 0; t < MQT; ++t) {
-                    const half8 wf = *reinterpret_cast<const half8*>(pw + t * 16 * MLDW + s * 32);
-                    acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, fs1[s], acc2[t], 0, 0, 0);
-                }
-        }
-        half8 fh[MQS];
-#pragma unroll
-        for (int sp = 0; sp < MQS; ++sp) {
-            const float4 b0 = *reinterpret_cast<const float4*>(a.b1 + q * MQ + (2 * sp) * 16 + 4 * g);
-            const float4 b1v = *reinterpret_cast<const float4*>(a.b1 + q * MQ + (2 * sp + 1) * 16 + 4 * g);
-            half8 h;
-            h[0] = (_Float16)mlpGelu(acc2[2 * sp][0] + b0.x); h[1] = (_Float16)mlpGelu(acc2[2 * sp][1] + b0.y);
-            h[2] = (_Float16)mlpGelu(acc2[2 * sp][2] + b0.z); h[3] = (_Float16)mlpGelu(acc2[2 * sp][3] + b0.w);
-            h[4] = (_Float16)mlpGelu(acc2[2 * sp + 1][0] + b1v.x); h[5] = (_Float16)mlpGelu(acc2[2 * sp + 1][1] + b1v.y);
-            h[6] = (_Float16)mlpGelu(acc2[2 * sp + 1][2] + b1v.z); h[7] = (_Float16)mlpGelu(acc2[2 * sp + 1][3] + b1v.w);
-            fh[sp] = h;
-        }
-        {
-            const _Float16* pw = &sW2[r * MLDW2 + g * 8];
-#pragma unroll
-            for (int sp = 0; sp < MQS; ++sp)
-#pragma unroll
-                for (int t = 0; t < MNT; ++t) {
-                    const half8 wf = *reinterpret_cast<const half8*>(pw + t * 16 * MLDW2 + sp * 32);
-                    acc3[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, fh[sp], acc3[t], 0, 0, 0);
-                }
-        }
-    }
-    // ---- s2 = LN2(s1 + f + b2) (already summed); x' = LN3(s2 + x); [x' = LN4(x' + xb)] ----------------------
-    mlpLayerNorm(acc3, a.ln_g + MC, a.ln_b + MC, g, a.eps);
-#pragma unroll
-    for (int t = 0; t < MNT; ++t) {
-        const float4 xv = *reinterpret_cast<const float4*>(a.x + (size_t)rc * MC + t * 16 + 4 * g);
-        acc3[t][0] += xv.x; acc3[t][1] += xv.y; acc3[t][2] += xv.z; acc3[t][3] += xv.w;
-    }
-    mlpLayerNorm(acc3, a.ln_g + 2 * MC, a.ln_b + 2 * MC, g, a.eps);
-    if (a.xb) {
-#pragma unroll
-        for (int t = 0; t < MNT; ++t) {
-            const float4 xv = *reinterpret_cast<const float4*>(a.xb + (size_t)rc * MC + t * 16 + 4 * g);
-            acc3[t][0] += xv.x; acc3[t][1] += xv.y; acc3[t][2] += xv.z; acc3[t][3] += xv.w;
-        }
-        mlpLayerNorm(acc3, a.ln_g + 3 * MC, a.ln_b + 3 * MC, g, a.eps);
-    }
-    if (!valid) return;
-#pragma unroll
-    for (int t = 0; t < MNT; ++t) {
-        const int col = t * 16 + 4 * g;
-        *reinterpret_cast<float4*>(a.out + (size_t)row * MC + col) = make_float4(acc3[t][0], acc3[t][1], acc3[t][2], acc3[t][3]);
-        half4 h; h[0] = (_Float16)acc3[t][0]; h[1] = (_Float16)acc3[t][1]; h[2] = (_Float16)acc3[t][2]; h[3] = (_Float16)acc3[t][3];
-        *reinterpret_cast<half4*>(a.out16 + (size_t)row * MC + col) = h;
-    }
-}
-
-
 // -------------------------------------------------------------------------------------
-// Same arithmetic, weights streamed by LDS-DMA (default).  The kernel above is one 128-row tile per workgroup walking
-// nine exposed "load slab -> ds_write -> barrier -> MFMA" steps (SQ_WAIT_ANY = 70 % of wave cycles, MFMA busy 6 %).
-// Here the host packs the three matrices as TEN stages of 36 fragment rows (1 KB each, MFMA A-operand order):
+// Weights streamed by LDS-DMA.  (The first version of this kernel staged each weight slab through registers: one 128-row
+// tile per workgroup walking nine exposed "load slab -> ds_write -> barrier -> MFMA" steps, SQ_WAIT_ANY = 70 % of wave
+// cycles, MFMA busy 6 %, 87 us.)  The host packs the three matrices as TEN stages of 36 fragment rows (1 KB each, MFMA A-operand order):
 //   stages 0,1    Wo columns [96h, 96h+96) x 192 k               row (ks, t)  <- Wo[96h + 16t + r][32ks + 8g + j]
 //   stage 2+2q    W1 rows [96q, 96q+96) x 192 permuted k         row (ks, t)  <- W1p[96q + 16t + r][32ks + 8g + j]
 //   stage 3+2q    W2 (all 192 rows) x permuted k [96q, 96q+96)   row (sp, t)  <- W2p[16t + r][96q + 32sp + 8g + j]
@@ -238,7 +89,6 @@ encoder_mlp_f16_kernel(MlpArgs a)
 // come through the same DMA queue into LDS (an ordinary global load with a DMA in flight makes hipcc wait vmcnt(0));
 // x is loaded in the prologue straight into the out-proj accumulator (acc = x, + bo after the barrier) and re-read for
 // LayerNorm 3 once nothing is in flight; no store is issued before the last stage has landed.
-constexpr int MS_ROWS = 36, MS_BYTES = MS_ROWS * 1024, MS_STAGES = 10;
 constexpr int MP_FLOATS = 1280;                    // bo | ln1_g | ln1_b | b1 (384) | b2 | pad  -> five 1 KB DMA rows
 constexpr int MP_BO = 0, MP_G1 = 192, MP_B1LN = 384, MP_B1 = 576, MP_B2 = 960;
 
@@ -507,8 +357,7 @@ class DsvtEncoderMlpPlugin : public Plugin {
 public:
     int max_rows_, has_block_ln_; float eps_;
     std::vector<float> wo_, w1_, w2_, bo_, b1_, b2_, lg_, lb_;     // as given (natural order)
-    _Float16 *wo_dev_ = nullptr, *w1_dev_ = nullptr, *w2_dev_ = nullptr;
-    float *bo_dev_ = nullptr, *b1_dev_ = nullptr, *b2_dev_ = nullptr, *lg_dev_ = nullptr, *lb_dev_ = nullptr;
+    float *lg_dev_ = nullptr, *lb_dev_ = nullptr;
     _Float16* wp_dev_ = nullptr; float* prm_dev_ = nullptr;       // stage image + LDS parameter block of the streamed kernel
     int pq_ = 64;                                                 // FC1 columns per piece of that image
     bool ok_ = false;
@@ -518,19 +367,11 @@ public:
           w2_(w2, w2 + MC * MF), bo_(bo, bo + MC), b1_(b1, b1 + MF), b2_(b2, b2 + MC),
           lg_(lg, lg + (3 + has_block_ln) * MC), lb_(lb, lb + (3 + has_block_ln) * MC) {
         lg_.resize(4 * MC, 1.f); lb_.resize(4 * MC, 0.f);
-        std::vector<_Float16> h(MF * MC);
-        auto upH = [&](const std::vector<float>& src, int rows, int K, bool perm, _Float16** d) {
-            for (int n = 0; n < rows; ++n)
-                for (int p = 0; p < K; ++p) h[(size_t)n * K + p] = (_Float16)src[(size_t)n * K + (perm ? permuteK(p) : p)];
-            return hipMalloc(d, sizeof(_Float16) * rows * K) == hipSuccess &&
-                   hipMemcpy(*d, h.data(), sizeof(_Float16) * rows * K, hipMemcpyHostToDevice) == hipSuccess;
-        };
         auto upF = [](const std::vector<float>& src, float** d) {
             return hipMalloc(d, sizeof(float) * src.size()) == hipSuccess &&
                    hipMemcpy(*d, src.data(), sizeof(float) * src.size(), hipMemcpyHostToDevice) == hipSuccess;
         };
-        ok_ = upH(wo_, MC, MC, false, &wo_dev_) && upH(w1_, MF, MC, true, &w1_dev_) && upH(w2_, MC, MF, true, &w2_dev_) &&
-              upF(bo_, &bo_dev_) && upF(b1_, &b1_dev_) && upF(b2_, &b2_dev_) && upF(lg_, &lg_dev_) && upF(lb_, &lb_dev_);
+        ok_ = upF(lg_, &lg_dev_) && upF(lb_, &lb_dev_);
         if (!ok_) return;
         // stage image (see encoder_mlp_stream_kernel), for pq_ FC1 columns per piece
         const int PQ = pq_, PQT = PQ / 16, PQS = PQ / 32, SR = 6 * PQT, NWO = MC / PQ, NPIECE = MF / PQ;
@@ -559,7 +400,7 @@ public:
               hipMemcpy(wp_dev_, wp.data(), sizeof(_Float16) * wp.size(), hipMemcpyHostToDevice) == hipSuccess && upF(prm, &prm_dev_);
     }
     ~DsvtEncoderMlpPlugin() override {
-        for (void* p : {(void*)wo_dev_, (void*)w1_dev_, (void*)w2_dev_, (void*)bo_dev_, (void*)b1_dev_, (void*)b2_dev_, (void*)lg_dev_, (void*)lb_dev_, (void*)wp_dev_, (void*)prm_dev_})
+        for (void* p : {(void*)lg_dev_, (void*)lb_dev_, (void*)wp_dev_, (void*)prm_dev_})
             if (p) (void)hipFree(p);
     }
     const char* type() const override { return "DsvtEncoderMlpPlugin"; }
@@ -581,36 +422,28 @@ public:
     int enqueue(const DsvtPluginTensorDesc*, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void*,
                 hipStream_t stream) override {
         if (!ok_) return static_cast<int>(hipErrorOutOfMemory);
-        MlpArgs a{};
-        a.att = static_cast<const _Float16*>(in[0]); a.count = static_cast<const uint32_t*>(in[1]);
-        a.x = static_cast<const float*>(in[2]); a.xb = has_block_ln_ ? static_cast<const float*>(in[3]) : nullptr;
-        a.Wo = wo_dev_; a.W1 = w1_dev_; a.W2 = w2_dev_; a.bo = bo_dev_; a.b1 = b1_dev_; a.b2 = b2_dev_;
-        a.ln_g = lg_dev_; a.ln_b = lb_dev_; a.out = static_cast<float*>(out[0]); a.out16 = static_cast<_Float16*>(out[1]);
-        a.max_rows = max_rows_; a.eps = eps_;
+        MlpStreamArgs b{};
+        b.att = static_cast<const _Float16*>(in[0]); b.count = static_cast<const uint32_t*>(in[1]);
+        b.x = static_cast<const float*>(in[2]); b.xb = has_block_ln_ ? static_cast<const float*>(in[3]) : nullptr;
+        b.Wp = wp_dev_; b.params = prm_dev_; b.ln_g = lg_dev_; b.ln_b = lb_dev_;
+        b.out = static_cast<float*>(out[0]); b.out16 = static_cast<_Float16*>(out[1]); b.max_rows = max_rows_; b.eps = eps_;
         if (zeroFill) {
             DSVT_CHECK(hipMemsetAsync(out[0], 0, sizeof(float) * (size_t)max_rows_ * MC, stream));
             DSVT_CHECK(hipMemsetAsync(out[1], 0, sizeof(_Float16) * (size_t)max_rows_ * MC, stream));
         }
-        static int variant = -1;       // DSVT_MLP_VARIANT=0: register-staged weights; 1 (default): LDS-DMA stream, 4 waves x 32 rows; 2: 8 waves x 16 rows
+        static int variant = -1;       // DSVT_MLP_VARIANT=2: 8 waves x 16 rows (<= 128 VGPRs, spills); default 4 waves x 32 rows
         if (variant < 0) { const char* e = getenv("DSVT_MLP_VARIANT"); variant = e ? atoi(e) : 1; }
-        if (variant == 0) {
-            hipLaunchKernelGGL(encoder_mlp_f16_kernel, dim3(cdiv(max_rows_, MROWS)), dim3(64 * MWAVES), 0, stream, a);
-        } else {
-            MlpStreamArgs b{};
-            b.att = a.att; b.x = a.x; b.xb = a.xb; b.Wp = wp_dev_; b.params = prm_dev_; b.ln_g = lg_dev_; b.ln_b = lb_dev_;
-            b.out = a.out; b.out16 = a.out16; b.count = a.count; b.max_rows = max_rows_; b.eps = eps_;
-            const dim3 grid(cdiv(max_rows_, MROWS));
-            static unsigned long long* tr = nullptr; static int tron = -1;
-            if (tron < 0) { tron = getenv("DSVT_MLP_TRACE") ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 32 * 1024); }
-            b.trace = tr;
-            static int dbg = -1; if (dbg < 0) { const char* e = getenv("DSVT_MLP_DBG"); dbg = e ? atoi(e) : 0; }
-            b.dbg = dbg;
-            if (variant == 2) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, 64>), grid, dim3(512), 0, stream, b);
-            else hipLaunchKernelGGL((encoder_mlp_stream_kernel<2, 4, 64>), grid, dim3(256), 0, stream, b);
-            if (tron) {
-                (void)hipStreamSynchronize(stream);
-                for (int w : {0, 200}) { fprintf(stderr, "[mlp trace wg%d]", w); for (int i = 1; i < 32; ++i) fprintf(stderr, " %lld", (long long)(tr[w * 32 + i] - tr[w * 32])); fprintf(stderr, "\n"); }
-            }
+        const dim3 grid(cdiv(max_rows_, MROWS));
+        static unsigned long long* tr = nullptr; static int tron = -1;         // tools/trace_mlp.py
+        if (tron < 0) { tron = getenv("DSVT_MLP_TRACE") ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 32 * 1024); }
+        b.trace = tr;
+        static int dbg = -1; if (dbg < 0) { const char* e = getenv("DSVT_MLP_DBG"); dbg = e ? atoi(e) : 0; }
+        b.dbg = dbg;
+        if (variant == 2) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, 64>), grid, dim3(512), 0, stream, b);
+        else hipLaunchKernelGGL((encoder_mlp_stream_kernel<2, 4, 64>), grid, dim3(256), 0, stream, b);
+        if (tron) {
+            (void)hipStreamSynchronize(stream);
+            for (int w : {0, 200}) { fprintf(stderr, "[mlp trace wg%d]", w); for (int i = 1; i < 32; ++i) fprintf(stderr, " %lld", (long long)(tr[w * 32 + i] - tr[w * 32])); fprintf(stderr, "\n"); }
         }
         return lastError();
     }
