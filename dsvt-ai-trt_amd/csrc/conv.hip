@@ -539,25 +539,16 @@ static int numCUs() {
     return n;
 }
 
-// tile height of the halo kernel: the (rounds of items over the CUs) x (tile height) product is the makespan
-static int haloTileRows(const ConvArgs& a) {
+// tile height of the halo kernel.  Alone on the GPU the 64-channel and the 117x117 layers run 5-10 % faster as 4-row tiles (two
+// decoupled workgroups per CU / all CUs busy); with two frames in flight -- the bench default -- 8-row tiles everywhere are
+// 4 % faster end to end (415 vs 400 frames/s): a layer that leaves CUs or LDS unused leaves them to the other frame's kernels.
+static int haloTileRows(const ConvArgs&) {
     if (const char* e = getenv("DSVT_CONV_TH")) { const int t = atoi(e); if (t == 4 || t == 8) return t; }
-    const int nchunk = cdiv(a.CoutRows, CNB), cus = numCUs();
-    int best = 8; long bestCost = -1;
-    for (int th : {8, 4}) {          // the 10-row instantiation exceeds 168 VGPRs (10 waves => 3 waves on two SIMDs) and spills
-        const long items = (long)cdiv(a.Ho, th) * cdiv(a.Wo, HTW) * nchunk;
-        long cost = cdiv(items, (long)cus) * th * 16;
-        if (th == 4) cost = cost * 5 / 4;           // one wave per SIMD hides less latency
-        if (bestCost < 0 || cost < bestCost) { best = th; bestCost = cost; }
-    }
-    return best;
+    return 8;
 }
 
 static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16* zeros, hipStream_t stream) {
-    int th = haloTileRows(a);
-    // measured on the 468x468 layers: 64-channel outputs (both waves of a row pair share the channel tiles) run 11 % faster as
-    // two decoupled 4-row workgroups per CU; 128-channel outputs 34 % slower (twice the weight traffic)
-    if (!getenv("DSVT_CONV_TH") && haloChannelTiles(a.CoutRows) == 4) th = 4;
+    const int th = haloTileRows(a);
     const int tilesX = cdiv(a.Wo, HTW), nchunk = cdiv(a.CoutRows, CNB);
     const int nitems = cdiv(a.Ho, th) * tilesX * nchunk;
     static int dbg = -1;
