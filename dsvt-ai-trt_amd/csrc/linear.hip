@@ -387,8 +387,7 @@ __device__ __forceinline__ void stageBarrier() {
 // rows from L2): no store is ever in flight while a stage is awaited -- stores share the in-order vmcnt queue with the
 // DMA, and a store's acknowledgement takes microseconds when every workgroup writes at once.
 template <int AMODE, int MT, int NW>
-__global__ void __launch_bounds__(64 * NW, (MT == 1 ? 4 : 2))
-linear_f16_stream_kernel(LinearArgs a, const _Float16* __restrict__ Wp)
+__device__ __forceinline__ void linearStreamBody(const LinearArgs a, const _Float16* __restrict__ Wp)
 {
     // two stage slots (+ 3 KB: position-embedding parameters w0 | w1 | b, 192 floats each, fetched by the same DMA queue)
     __shared__ __attribute__((aligned(16))) unsigned char ring[2 * SBYTES + (AMODE == 2 ? 3072 : 0)];      // <= 76,800 B: two workgroups per CU
@@ -500,6 +499,39 @@ linear_f16_stream_kernel(LinearArgs a, const _Float16* __restrict__ Wp)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) linearEpilogue<true>(acc[mt], a, n0, row[mt], g, M, N);
     if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); mark(7); }
+}
+
+template <int AMODE, int MT, int NW>
+__global__ void __launch_bounds__(64 * NW, (MT == 1 ? 4 : 2))
+linear_f16_stream_kernel(LinearArgs a, const _Float16* __restrict__ Wp)
+{
+    linearStreamBody<AMODE, MT, NW>(a, Wp);
+}
+
+// The eight position-embedding MLPs of a frame (one per encoder layer: src/dsvt-ai-trt.cpp:603-637 builds them per block
+// and per layer) depend only on the window coordinates, not on the features: one launch, blockIdx.z = layer, instead of
+// eight 270-workgroup launches spread between the attention layers.
+struct PosEmbedLayer {
+    const float* xy; const float* pe_w0; const float* pe_w1; const float* pe_b;     // first FC (K_in = 2, BN folded) + ReLU
+    const _Float16* Wp; const float* bias;                                           // second FC (fragment-ordered), bias
+    _Float16* out16;
+};
+constexpr int kMaxPosLayers = 8;
+struct PosEmbedBatch { PosEmbedLayer layer[kMaxPosLayers]; };
+
+__global__ void __launch_bounds__(512, 4)
+posembed_batched_kernel(LinearArgs a, PosEmbedBatch b)
+{
+    // (a dynamic index into a by-value kernel argument would be copied to scratch; constant indices are scalar kernarg loads)
+    const float* xy = b.layer[0].xy; const float* w0 = b.layer[0].pe_w0; const float* w1 = b.layer[0].pe_w1; const float* pb = b.layer[0].pe_b;
+    const _Float16* Wp = b.layer[0].Wp; const float* bias = b.layer[0].bias; _Float16* out16 = b.layer[0].out16;
+#pragma unroll
+    for (int i = 1; i < kMaxPosLayers; ++i)
+        if ((int)blockIdx.z == i) { xy = b.layer[i].xy; w0 = b.layer[i].pe_w0; w1 = b.layer[i].pe_w1; pb = b.layer[i].pe_b; Wp = b.layer[i].Wp; bias = b.layer[i].bias; out16 = b.layer[i].out16; }
+    LinearArgs la{};
+    la.count = a.count; la.row_mult = 1; la.max_rows = a.max_rows; la.K = KS; la.N = KS; la.out_ld = KS; la.act = ACT_NONE;
+    la.pe_xy = xy; la.pe_w0 = w0; la.pe_w1 = w1; la.pe_b = pb; la.bias = bias; la.out16 = out16;
+    linearStreamBody<2, 1, 8>(la, Wp);
 }
 
 int launchLinearF16Stream(const LinearArgs& a, const _Float16* Wp, hipStream_t stream) {
@@ -732,5 +764,103 @@ static Creator g_linCreator{"DsvtLinearPlugin",
      {"pe_weight", DSVT_FIELD_FLOAT32}, {"pe_bias", DSVT_FIELD_FLOAT32}},
     linCreate, linDeser, {}, {}};
 static Registrar g_linReg(&g_linCreator);
+
+// -------------------------------------------------------------------------------------
+// DsvtPosEmbedPlugin: all position-embedding MLPs of a frame in one launch.
+// fields: max_rows, num_layers, layer_input (int[num_layers]: which xy input each layer reads), pe_weight [L][192][2], pe_bias [L][192],
+//         weight [L][192][192], bias [L][192].  Inputs: count [1], then the xy tensors [1,rows,2] f32.  Outputs: L tensors [1,rows,192] fp16.
+class DsvtPosEmbedPlugin : public Plugin {
+public:
+    int max_rows_, L_;
+    std::vector<int> src_;
+    std::vector<float> pw_, pb_, w_, b_;
+    float* pe_dev_ = nullptr; float* b_dev_ = nullptr; _Float16* wp_dev_ = nullptr;
+    bool ok_ = false;
+    DsvtPosEmbedPlugin(int max_rows, int L, const int* src, const float* pw, const float* pb, const float* w, const float* b)
+        : max_rows_(max_rows), L_(L), src_(src, src + L), pw_(pw, pw + (size_t)L * KS * 2), pb_(pb, pb + (size_t)L * KS),
+          w_(w, w + (size_t)L * KS * KS), b_(b, b + (size_t)L * KS) {
+        std::vector<float> pe((size_t)L * 3 * KS);               // per layer: w0 | w1 | b
+        for (int l = 0; l < L; ++l)
+            for (int k = 0; k < KS; ++k) {
+                pe[(size_t)l * 3 * KS + k] = pw_[((size_t)l * KS + k) * 2]; pe[(size_t)l * 3 * KS + KS + k] = pw_[((size_t)l * KS + k) * 2 + 1];
+                pe[(size_t)l * 3 * KS + 2 * KS + k] = pb_[(size_t)l * KS + k];
+            }
+        std::vector<_Float16> wp;
+        for (int l = 0; l < L; ++l) { const std::vector<_Float16> one = packStages(w_.data() + (size_t)l * KS * KS, KS); wp.insert(wp.end(), one.begin(), one.end()); }
+        ok_ = hipMalloc(&pe_dev_, sizeof(float) * pe.size()) == hipSuccess && hipMemcpy(pe_dev_, pe.data(), sizeof(float) * pe.size(), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMalloc(&b_dev_, sizeof(float) * b_.size()) == hipSuccess && hipMemcpy(b_dev_, b_.data(), sizeof(float) * b_.size(), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMalloc(&wp_dev_, sizeof(_Float16) * wp.size()) == hipSuccess && hipMemcpy(wp_dev_, wp.data(), sizeof(_Float16) * wp.size(), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    ~DsvtPosEmbedPlugin() override { if (pe_dev_) (void)hipFree(pe_dev_); if (b_dev_) (void)hipFree(b_dev_); if (wp_dev_) (void)hipFree(wp_dev_); }
+    int nInputs() const { int m = 0; for (int v : src_) m = v > m ? v : m; return m + 2; }
+    const char* type() const override { return "DsvtPosEmbedPlugin"; }
+    int nbOutputs() const override { return L_; }
+    int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
+        if (i < 0 || i >= L_) return -1;
+        *out = dims3(in[1].d[0], max_rows_, KS); return 0;
+    }
+    int outputType(int, const int32_t*, int) const override { return DSVT_HALF; }
+    bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int nbIn, int) const override {
+        if (io[pos].format != DSVT_FORMAT_LINEAR) return false;
+        if (pos == 0) return io[pos].type == DSVT_INT32;
+        return io[pos].type == (pos < nbIn ? DSVT_FLOAT : DSVT_HALF);
+    }
+    size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override { return 0; }
+    int enqueue(const DsvtPluginTensorDesc*, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void*, hipStream_t stream) override {
+        if (!ok_) return static_cast<int>(hipErrorOutOfMemory);
+        LinearArgs a{};
+        a.count = static_cast<const uint32_t*>(in[0]);
+        a.row_mult = 1; a.max_rows = max_rows_; a.K = KS; a.N = KS; a.out_ld = KS; a.act = ACT_NONE;
+        PosEmbedBatch b{};
+        for (int l = 0; l < L_; ++l) {
+            PosEmbedLayer& Y = b.layer[l];
+            Y.xy = static_cast<const float*>(in[1 + src_[l]]);
+            Y.pe_w0 = pe_dev_ + (size_t)l * 3 * KS; Y.pe_w1 = Y.pe_w0 + KS; Y.pe_b = Y.pe_w0 + 2 * KS;
+            Y.Wp = wp_dev_ + (size_t)l * KS * KS; Y.bias = b_dev_ + (size_t)l * KS; Y.out16 = static_cast<_Float16*>(out[l]);
+            if (zeroFill) DSVT_CHECK(hipMemsetAsync(out[l], 0, sizeof(_Float16) * (size_t)max_rows_ * KS, stream));
+        }
+        hipLaunchKernelGGL(posembed_batched_kernel, dim3(cdiv(max_rows_, BM16), 1, L_), dim3(512), 0, stream, a, b);
+        return lastError();
+    }
+    size_t serializationSize() const override { return (2 + L_) * sizeof(int) + sizeof(float) * (pw_.size() + pb_.size() + w_.size() + b_.size()); }
+    void serialize(void* buf) const override {
+        char* d = static_cast<char*>(buf);
+        wr<int>(d, max_rows_); wr<int>(d, L_);
+        for (int v : src_) wr<int>(d, v);
+        for (const std::vector<float>* v : {&pw_, &pb_, &w_, &b_}) { memcpy(d, v->data(), sizeof(float) * v->size()); d += sizeof(float) * v->size(); }
+    }
+    Plugin* clone() const override { return new DsvtPosEmbedPlugin(max_rows_, L_, src_.data(), pw_.data(), pb_.data(), w_.data(), b_.data()); }
+};
+static Plugin* peNew(int max_rows, int L, const int* src, const float* pw, const float* pb, const float* w, const float* b) {
+    if (max_rows <= 0 || L <= 0 || L > kMaxPosLayers) return nullptr;
+    for (int l = 0; l < L; ++l) if (src[l] < 0 || src[l] > 7) return nullptr;
+    return new DsvtPosEmbedPlugin(max_rows, L, src, pw, pb, w, b);
+}
+static Plugin* peCreate(const DsvtPluginFieldCollection* fc) {
+    const int max_rows = fieldInt(fc, "max_rows"), L = fieldInt(fc, "num_layers");
+    const DsvtPluginField* src = findField(fc, "layer_input"); const DsvtPluginField* pw = findField(fc, "pe_weight");
+    const DsvtPluginField* pb = findField(fc, "pe_bias"); const DsvtPluginField* w = findField(fc, "weight"); const DsvtPluginField* b = findField(fc, "bias");
+    if (L <= 0 || !src || !src->data || src->length != L || !pw || !pw->data || pw->length != L * KS * 2 || !pb || !pb->data || pb->length != L * KS ||
+        !w || !w->data || w->length != L * KS * KS || !b || !b->data || b->length != L * KS) return nullptr;
+    return peNew(max_rows, L, static_cast<const int*>(src->data), static_cast<const float*>(pw->data), static_cast<const float*>(pb->data),
+                 static_cast<const float*>(w->data), static_cast<const float*>(b->data));
+}
+static Plugin* peDeser(const void* data, size_t len) {
+    if (len < 2 * sizeof(int)) return nullptr;
+    const char* d = static_cast<const char*>(data);
+    const int max_rows = rd<int>(d), L = rd<int>(d);
+    if (max_rows <= 0 || L <= 0 || L > kMaxPosLayers) return nullptr;
+    const size_t nf = (size_t)L * (KS * 2 + KS + KS * KS + KS);
+    if (len < (2 + L) * sizeof(int) + nf * sizeof(float)) return nullptr;
+    std::vector<int> src(L); for (int l = 0; l < L; ++l) src[l] = rd<int>(d);
+    std::vector<float> all(nf); memcpy(all.data(), d, nf * sizeof(float));
+    const float* q = all.data();
+    return peNew(max_rows, L, src.data(), q, q + (size_t)L * KS * 2, q + (size_t)L * KS * 3, q + (size_t)L * KS * 3 + (size_t)L * KS * KS);
+}
+static Creator g_peCreator{"DsvtPosEmbedPlugin",
+    {{"max_rows", DSVT_FIELD_INT32}, {"num_layers", DSVT_FIELD_INT32}, {"layer_input", DSVT_FIELD_INT32}, {"pe_weight", DSVT_FIELD_FLOAT32},
+     {"pe_bias", DSVT_FIELD_FLOAT32}, {"weight", DSVT_FIELD_FLOAT32}, {"bias", DSVT_FIELD_FLOAT32}},
+    peCreate, peDeser, {}, {}};
+static Registrar g_peReg(&g_peCreator);
 
 }  // namespace dsvt

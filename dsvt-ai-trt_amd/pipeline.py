@@ -145,6 +145,16 @@ class DsvtPipeline:
                     fc2=zf(P.add_linear_op(w[lp + ".win_attn.linear2.weight"], w[lp + ".win_attn.linear2.bias"], c.P,
                                            layer_norms=lns2, ln_eps=ln_eps, **ct, **h_in, **oboth)))
                 self.layers[(b, l)]["attn"].win = b % 2
+        self.pe_all = None
+        if f16:      # the position embeddings depend only on the window coordinates: all layers in one launch, before the backbone
+            keys = [(b, l) for b in range(blocks) for l in range(2)]
+            pes = []
+            for (b, l) in keys:
+                pre = f"module.backbone_3d.input_layer.posembed_layers.0.{b}.{l}.position_embedding_head"
+                Wa, ba = fold_linear_bn(w, pre + ".0", pre + ".1", 1e-5, bias=True)
+                pes.append((Wa, ba, w[pre + ".3.weight"], w[pre + ".3.bias"]))
+            self.pe_all = zf(P.add_pos_embed_op(c.P, [l for (_, l) in keys], [p_[0] for p_ in pes], [p_[1] for p_ in pes],
+                                                [p_[2] for p_ in pes], [p_[3] for p_ in pes]))
         self.cat = torch.zeros((1, c.Nk, 192), dtype=torch.float32, device=self.device)
         if with_head:
             self.map2bev = P.add_map_2_bev_op(c.P, C, GX, GY)
@@ -321,6 +331,7 @@ class DsvtPipeline:
     def backbone(self, st, trace=None):
         Pn = st["P"]
         x = st["vfeat"]
+        pos_all = self.pe_all(Pn, st["wps"][0][5], st["wps"][1][5]) if self.pe_all is not None else None
         xh = st.get("vfeat16") if self.f16 else x           # GEMM-operand copy of the residual stream
         if xh is None:
             xh = x.to(torch.float16)
@@ -330,7 +341,10 @@ class DsvtPipeline:
             for l in range(2):
                 a, fc = self.pe[(b, l)]
                 xy = st["wps"][l][5]                                  # pos-embed input = window config l (:603-637)
-                pos = fc(xy, Pn)[0] if a is None else fc(a(xy, Pn)[0], Pn)[0]
+                if pos_all is not None:
+                    pos = pos_all[2 * b + l]
+                else:
+                    pos = fc(xy, Pn)[0] if a is None else fc(a(xy, Pn)[0], Pn)[0]
                 L = self.layers[(b, l)]
                 qkv = L["qkv"](xh, Pn, pos)[0]
                 att = L["attn"](qkv, inds, mask, S)[0]

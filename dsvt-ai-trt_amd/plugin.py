@@ -396,6 +396,17 @@ def add_center_head_topk_op(feature_height, feature_width, channel_num=18, class
                                                hm_offset=hm_offset), "center_head_topk_layer")
 
 
+def add_pos_embed_op(max_rows, layer_input, pe_weights, pe_biases, weights, biases):
+    """All position-embedding MLPs of a frame (FC(2->192)+BN+ReLU -> FC(192->192), src/dsvt-ai-trt.cpp:461-492, one per encoder layer)
+    in one launch.  layer_input[l] selects which xy input layer l reads.  Inputs: count [1], xy tensors [1,rows,2] f32.
+    Outputs: one [1,rows,192] fp16 tensor per layer.  BatchNorm folded into pe_weights / pe_biases by the caller."""
+    L = len(layer_input)
+    f32 = lambda xs: np.ascontiguousarray(np.stack([np.asarray(x, np.float32) for x in xs])).reshape(-1)
+    return Plugin("DsvtPosEmbedPlugin", dict(max_rows=int(max_rows), num_layers=L, layer_input=[int(v) for v in layer_input],
+                                             pe_weight=f32(pe_weights), pe_bias=f32(pe_biases), weight=f32(weights), bias=f32(biases)),
+                  "pos_embed_layer")
+
+
 def add_pillar_feature_net_op(max_pillars_num, weight0, bias0, weight1, bias1):
     """Both PFN layers + both scatter-max reductions in one launch, no per-point activation in memory (csrc/pfn.hip).
     BatchNorm folded by the caller: weight0 [96,10], weight1 [192,192] (columns 0..95 act on x0, 96..191 on its pillar max).

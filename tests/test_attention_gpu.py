@@ -215,3 +215,28 @@ def test_linear_posembed_prologue_equals_two_launches(pkg):
     # the prologue exists only in the fp16 kernel: the fp32 compute type refuses the fields
     with pytest.raises(Exception):
         P.add_linear_op(Wb, bb, MR, compute_type=P.COMPUTE_F32, pe_weight=Wa, pe_bias=ba)
+
+
+def test_batched_pos_embed_equals_per_layer_launches(pkg):
+    """DsvtPosEmbedPlugin (all layers, one launch, blockIdx.z = layer) == one DsvtLinearPlugin launch per layer with the
+    position-embedding prologue: same kernel body, so bit-identical."""
+    P = pkg.plugin
+    rng = np.random.default_rng(9)
+    MR, n, C, L = 8192, 5504, 192, 4
+    xys = [np.zeros((MR, 2), np.float32) for _ in range(2)]
+    for x in xys:
+        x[:n] = rng.uniform(-12, 12, (n, 2))
+    Wa = [(rng.standard_normal((C, 2)) * 0.5).astype(np.float32) for _ in range(L)]
+    ba = [(rng.standard_normal(C) * 0.2).astype(np.float32) for _ in range(L)]
+    Wb = [(rng.standard_normal((C, C)) / np.sqrt(C)).astype(np.float32) for _ in range(L)]
+    bb = [(rng.standard_normal(C) * 0.1).astype(np.float32) for _ in range(L)]
+    src = [0, 1, 0, 1]
+    cnt = scalar(n)
+    dx = [dev(x[None]) for x in xys]
+    outs = P.add_pos_embed_op(MR, src, Wa, ba, Wb, bb)(cnt, *dx)
+    torch.cuda.synchronize()
+    assert len(outs) == L
+    for l in range(L):
+        ref = P.add_linear_op(Wb[l], bb[l], MR, compute_type=P.COMPUTE_F16, output_mode=P.OUT_F16, pe_weight=Wa[l], pe_bias=ba[l])(dx[src[l]], cnt)[0]
+        assert torch.equal(outs[l], ref)
+        assert not outs[l][0, n:].any()
