@@ -36,7 +36,7 @@ PEAK_F32_MATRIX_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Pe
 PEAK_F16_MATRIX_TFLOPS = 2500.0     # same guide: "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBS = 8000.0               # same guide: "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured float4 copy)
 N_POINTS = 180000
-PMC_FILE = "r01_i_pmc_traffic.json"
+PMC_FILE = "r01_j_pmc_traffic.json"
 FRAME_POOL = 4                      # distinct synthetic clouds cycled through by the steps
 
 
@@ -163,7 +163,7 @@ def main():
     torch.cuda.synchronize()
 
     prof = None if args.no_kernel_events else {"DsvtLinearPlugin": [], "DsvtEncoderMlpPlugin": [], "DsvtSetAttentionPlugin": [],
-                                               "DsvtConv2dPlugin": [], "DsvtPillarFeatureNetPlugin": []}
+                                               "DsvtConv2dPlugin": [], "DsvtPillarFeatureNetPlugin": [], "DsvtPosEmbedPlugin": []}
     marks = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     par.barrier(); torch.cuda.synchronize()
     sampled = 0
@@ -223,6 +223,9 @@ def main():
                 S = c["S"][0 if pl.win == 0 else 1]
                 esz = 2 if f.get("io_half") else 4
                 return (4.0 * 36 * 36 * 192 * S, S * 36 * 192 * esz * 3 + c["P"] * 192 * esz)
+            if pl.plugin_type == "DsvtPosEmbedPlugin":
+                L = f["num_layers"]
+                return (2.0 * L * c["P"] * (2 * 192 + 192 * 192), c["P"] * 16 + L * (c["P"] * 192 * 2 + 2 * 192 * 192))
             if pl.plugin_type == "DsvtPillarFeatureNetPlugin":
                 return (2.0 * c["Nk"] * (10 * 96 + 96 * 192) + 2.0 * c["P"] * 96 * 192, c["Nk"] * 40 + c["P"] * 192 * 6)
             if pl.plugin_type == "DsvtConv2dPlugin":
@@ -239,6 +242,7 @@ def main():
                 "DsvtEncoderMlpPlugin": ("encoder_mlp_stream_kernel (out-proj+LN -> FC1+GELU -> FC2+LN+LN, v_mfma_f32_16x16x32_f16, weights by LDS-DMA)", "hbm", "encoder_mlp_stream_kernel"),
                 "DsvtSetAttentionPlugin": ("set_attention_f16_kernel (v_mfma_f32_16x16x32_f16)" if f16 else "set_attention_kernel (v_mfma_f32_16x16x4_f32)", "hbm",
                                            "set_attention_f16_kernel" if f16 else "set_attention_kernel"),
+                "DsvtPosEmbedPlugin": ("posembed_batched_kernel (8 position-embedding MLPs, v_mfma_f32_16x16x32_f16)", "hbm", "posembed_batched_kernel"),
                 "DsvtPillarFeatureNetPlugin": ("pfn_kernel (both PFN layers + scatter-max, v_mfma_f32_16x16x4_f32 + 16x16x32_f16)", "mfma", "pfn_kernel"),
                 "DsvtConv2dPlugin": ("conv_halo_kernel / conv_f16_kernel (implicit GEMM, v_mfma_f32_16x16x32_f16)", "mfma", "conv_halo_kernelILi8ELi3ELi8")}
         for ptype, lst in prof.items():

@@ -35,6 +35,7 @@
  *   DsvtSetAttentionPlugin    GetValueByIndex + MHA core + MapSetFeature2Voxel in one
  *   DsvtEncoderMlpPlugin      out-proj + LayerNorm -> FC1 + GELU -> FC2 + LayerNorms of one encoder
  *                             layer in one launch (src/dsvt-ai-trt.cpp:669-756)
+ *   DsvtPosEmbedPlugin        all position-embedding MLPs of a frame in one launch (src/dsvt-ai-trt.cpp:461-492)
  *   DsvtPillarFeatureNetPlugin  both PFN layers + both TorchScatterMax reductions in one launch
  *                             (src/dsvt-ai-trt.cpp:565-589)
  *   DsvtConv2dPlugin          convBnLELU / convBn / deconvBnLELU / conv_with_bias of the BEV
