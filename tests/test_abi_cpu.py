@@ -125,3 +125,17 @@ def test_wts_roundtrip(pkg, tmp_path):
     s = pkg.synth.split_in_proj(pkg.synth.make_weights(with_bev=False))
     k = "module.backbone_3d.stage_0.0.encoder_list.0.win_attn.self_attn.in_proj_weight"
     assert s[k + ".query"].shape == (192, 192) and np.array_equal(s[k + ".value"], s[k][384:])
+
+
+def test_plain_c_client_compiles_links_and_runs(pkg, tmp_path):
+    """include/dsvt_plugin.h is valid C (gcc -std=c99 -Wall -Werror) and a C program can drive the creator side of the ABI
+    exactly like include/plugin_helper.h:253-310 drives TensorRT's registry (tests/c_client/abi_client.c)."""
+    import subprocess
+    libdir = os.path.join(ROOT, "dsvt-ai-trt_amd")
+    exe = str(tmp_path / "abi_client")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_client", "abi_client.c"), "-o", exe,
+                           "-L", libdir, "-l:libdsvt_hip.so", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "abi_client ok" in out.stdout and "gfx950" in out.stdout

@@ -146,3 +146,34 @@ def test_frame_uploader_feeds_the_pipeline(pkg):
     torch.cuda.synchronize()
     for a, b in zip(outs["small"], ref):
         assert torch.equal(a, b)
+
+
+def test_full_size_frame_properties(pkg):
+    """BASELINE configs[2] size (180k-point Waymo-shaped cloud, fp16 mode, frame ends at the final boxes): properties that do
+    not need the CPU oracle (10 s per frame) -- reproducibility, ordering / range of the boxes, NMS idempotence, empty input."""
+    P = pkg.plugin
+    caps = pkg.pipeline.Caps()
+    w = pkg.synth.make_weights()
+    pipe = pkg.pipeline.DsvtPipeline(w, caps=caps, linear_compute=P.COMPUTE_F16, head_dtype=torch.float16, device_nms=True)
+    p = pkg.synth.lidar_like(180000, seed=3)
+    buf = np.zeros((1, caps.N, 4), np.float32); buf[0, :p.shape[0]] = p
+    pts = torch.from_numpy(buf).to("cuda:0"); n = torch.tensor([p.shape[0]], dtype=torch.int32, device="cuda:0")
+    rows, cnt = [t.clone() for t in pipe.forward(pts, n)]
+    rows2, cnt2 = [t.clone() for t in pipe.forward(pts, n)]
+    torch.cuda.synchronize()
+    assert torch.equal(rows, rows2) and torch.equal(cnt, cnt2)                  # bit-reproducible, atomics included
+    k = int(cnt.cpu()[0])
+    r = rows[0, :k].cpu().numpy()
+    assert 0 < k <= 500 and not rows[0, k:].any()
+    assert np.all(r[:-1, 8] >= r[1:, 8]) and r[:, 8].min() >= 0.3 and r[:, 8].max() <= 1.0     # score order, threshold (params.h:328)
+    assert np.all((r[:, 0] >= -74.88) & (r[:, 0] < 74.88) & (r[:, 1] >= -74.88) & (r[:, 1] < 74.88))
+    assert np.all((r[:, 7] >= 0) & (r[:, 7] < 10) & (r[:, 7] == np.round(r[:, 7])))
+    assert np.all(r[:, 3:6] > 0)                                                                # exp(dim)
+    # NMS of an NMS result keeps everything, in the same order
+    again, idx, c2 = P.add_rotated_nms_op(500, 0.01)(rows, cnt)
+    torch.cuda.synchronize()
+    assert int(c2.cpu()[0]) == k and torch.equal(again[0, :k], rows[0, :k]) and idx[0, :k].cpu().tolist() == list(range(k))
+    # empty cloud
+    rows0, cnt0 = pipe.forward(pts, torch.zeros_like(n))
+    torch.cuda.synchronize()
+    assert int(cnt0.cpu()[0]) == 0 and not rows0.any()
