@@ -13,3 +13,4 @@ from . import synth           # noqa: F401
 from . import pipeline        # noqa: F401
 from . import parallel        # noqa: F401
 from . import hostio          # noqa: F401
+from . import detect          # noqa: F401

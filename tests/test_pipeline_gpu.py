@@ -177,3 +177,34 @@ def test_full_size_frame_properties(pkg):
     rows0, cnt0 = pipe.forward(pts, torch.zeros_like(n))
     torch.cuda.synchronize()
     assert int(cnt0.cpu()[0]) == 0 and not rows0.any()
+
+
+def test_detect_directory_writes_reference_txt(pkg, weights, tmp_path):
+    """detect.run_directory = the reference's `-d` loop (src/dsvt-ai-trt.cpp:1876-1960): every .bin of the directory -> one .txt
+    in save_txt's layout, holding the boxes the pipeline (device top-K + FilterBoxByScore + rotated NMS) returns for that frame."""
+    import subprocess, sys, os
+    out = tmp_path / "outputs"
+    done = pkg.detect.run_directory(cases.GOLDEN, str(out), weights, caps=pkg.pipeline.Caps.reference(), fp16=False, log=lambda *_: None)
+    assert [d[0] for d in done] == ["000000", "000003", "000004"]
+    c = pkg.pipeline.Caps.reference()
+    pipe = pkg.pipeline.DsvtPipeline(weights, caps=c, device_nms=True)
+    for name, kept, ms in done:
+        sec, rows = pkg.detect.read_txt(str(out / f"{name}.txt"))
+        assert rows.shape == (kept, 9) and abs(sec - ms) < 1e-3
+        pts, n = cases.load_frame(name, c.N)
+        r, cnt = pipe.forward(torch.from_numpy(pts[None]).to("cuda:0"), torch.tensor([n], dtype=torch.int32, device="cuda:0"))
+        k = int(cnt[0])
+        assert k == kept
+        exp = r.reshape(-1, 9)[:k].cpu().numpy()
+        assert np.abs(rows - exp).max() < 2e-6 * max(1.0, np.abs(exp).max())        # text carries 6 decimals
+        assert np.array_equal(rows[:, 7], exp[:, 7])
+    # the command-line wrapper: same files
+    out2 = tmp_path / "cli"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, os.path.join(root, "tools", "detect.py"), "--data", cases.GOLDEN, "--out", str(out2), "--fp32", "--ref-caps"],
+                   check=True, timeout=600, capture_output=True)
+    for name, _, _ in done:
+        _, a = pkg.detect.read_txt(str(out / f"{name}.txt"))
+        _, b = pkg.detect.read_txt(str(out2 / f"{name}.txt"))
+        # (another process: the fp32 dense stage runs on MIOpen, whose algorithm choice may differ in the last bits)
+        assert a.shape == b.shape and np.abs(a - b).max() < 1e-4 and np.array_equal(a[:, 7], b[:, 7])
