@@ -530,6 +530,142 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     if (!(dbg & 8)) epilogue(ey, ex, ech);
 }
 
+// -------------------------------------------------------------------------------------
+// The 468x468 layers with 128-channel output chunks: 16 rows x 32 pixels x 128 channels per workgroup, wave w = rows 2w, 2w+1
+// x ALL 128 channels (128 accumulator registers).  Against the 8-row kernel above this halves, per MFMA, the LDS-DMA pieces
+// a wave issues (each costs 60-180 cycles of issue among MFMAs), the workgroup barriers, and cuts the fragment reads from 16
+// to 12 per 32 MFMAs.  To keep two halo buffers in LDS the K loop walks 32-channel phases: a halo pixel is 64 B (four 16-byte
+// chunks, chunk c of halo column hx in slot c ^ ((hx >> 1) & 2): conflict-free ds_read_b128 for all three kx), one
+// (phase, tap) step is ONE k-step of the packed weights (8 fragment rows), a 16 KB weight slab = two steps = 64 MFMAs per
+// wave per barrier.  Phases run continuously across taps and items: the halo of phase p+1 (or of the next item's phase 0)
+// is requested during the first three slabs of phase p, the weights of slab s+1 when slab s starts; one vmcnt(0) + barrier
+// per slab.  The slab loop is NOT unrolled (a fully unrolled body of 1152 MFMAs makes hipcc spill the accumulators).
+constexpr int WT_ROWS = 16, WT_HH = WT_ROWS + 2, WT_HS = 40;
+constexpr int WT_HBYTES = WT_HH * WT_HS * 64;                     // 46,080 B: one 32-channel phase of the halo
+constexpr int WT_NPC = WT_HBYTES / 1024;                          // 45 LDS-DMA pieces (16 pixels each)
+constexpr int WT_WBYTES = 16384;
+
+__global__ void __launch_bounds__(512, 1)
+conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __restrict__ zeros, int tilesX, int nitems, int nchunk)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WT_HBYTES + 2 * WT_WBYTES];      // halo[2] | wslab[2] = 124,928 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int NP = a.Cin >> 5;                                    // 32-channel phases (even: Cin % 64 == 0)
+    const int NSLAB = (NP * 9) >> 1;                              // two (phase, tap) steps per slab
+    const int NCT = nchunk * 8;
+
+    auto decode = [&](int it, int& yy, int& xx, int& ch) {
+        ch = it % nchunk; const int t = it / nchunk;
+        yy = (t / tilesX) * WT_ROWS; xx = (t % tilesX) * HTW;
+    };
+    // piece pc of the halo of phase ph at tile origin (yy, xx) -> buffer hb
+    auto haloRequest = [&](int pc, int yy, int xx, int ph, int hb) {
+        const int lp = pc * 16 + (lane >> 2), hy = lp / WT_HS, hx = lp - hy * WT_HS;
+        const int chunk = (lane & 3) ^ ((hx >> 1) & 2);
+        const int gy = yy - 1 + hy, gx = xx - 1 + hx;
+        const bool ok = hx < HTW + 2 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const _Float16* src = ok ? a.in + (size_t)(gy * a.W + gx) * a.Cin + ph * 32 + chunk * 8 : zeros;
+        __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + hb * WT_HBYTES + pc * 1024), 16, 0, 0);
+    };
+    // the 16 fragment rows of slab sl (steps 2 sl, 2 sl + 1) of chunk ch -> buffer wb
+    auto weightRequests = [&](int sl, int ch, int wb) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int u = wave + 8 * j, step = 2 * sl + j, ph = step / 9, tap = step - 9 * ph;     // u >> 3 == j
+            const size_t row = (size_t)(2 * ((ph >> 1) * 9 + tap) + (ph & 1)) * NCT + ch * 8 + wave;
+            __builtin_amdgcn_global_load_lds((glds_src_t)(Wp + (row * 64 + lane) * 8), (glds_dst_t)(smem + 2 * WT_HBYTES + wb * WT_WBYTES + u * 1024), 16, 0, 0);
+        }
+    };
+
+    int item = blockIdx.x;
+    if (item >= nitems) return;
+    int y0, x0, chunk;
+    decode(item, y0, x0, chunk);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        if (wave + 8 * i < WT_NPC) haloRequest(wave + 8 * i, y0, x0, 0, 0);
+    weightRequests(0, chunk, 0);
+    slabBarrier(0);
+
+    const int pb = ((2 * wave) * WT_HS + r) * 64;                 // this lane's pixel of pixel tile 0, tap (0, 0)
+    const int aoff = lane << 4;
+    int wb = 0;
+    floatx4 acc[8][4];
+    for (;;) {
+        int nitem = item + gridDim.x, ny0 = 0, nx0 = 0, nch = 0;
+        const bool have_next = nitem < nitems;
+        if (have_next) decode(nitem, ny0, nx0, nch);
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[ct][m] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int s = 0; s < NSLAB; ++s) {
+            if (s + 1 < NSLAB) weightRequests(s + 1, chunk, wb ^ 1);
+            else if (have_next) weightRequests(0, nch, wb ^ 1);
+            const int p = (2 * s) / 9, j = (2 * s - 9 * p) >> 1;
+            if (j < 3) {                                          // the buffer of phase p + 1 is free since phase p - 1 ended
+                const bool inItem = p + 1 < NP;
+                if (inItem || have_next) {
+                    const int yy = inItem ? y0 : ny0, xx = inItem ? x0 : nx0, ph = inItem ? p + 1 : 0;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int pc = wave + 8 * (2 * j + i);
+                        if (pc < WT_NPC) haloRequest(pc, yy, xx, ph, (p + 1) & 1);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int step = 2 * s + u, ph = step / 9, tap = step - 9 * ph, ky = tap / 3, kx = tap - 3 * ky;
+                const unsigned char* hbp = smem + (ph & 1) * WT_HBYTES + (ky * WT_HS + kx) * 64 + pb + ((g ^ (((r + kx) >> 1) & 2)) << 4);
+                const unsigned char* wbp = smem + 2 * WT_HBYTES + wb * WT_WBYTES + u * 8192 + aoff;
+                half8 B[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) B[m] = *reinterpret_cast<const half8*>(hbp + ((m >> 1) * WT_HS + (m & 1) * 16) * 64);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    half8 A[4];
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) A[ct] = *reinterpret_cast<const half8*>(wbp + (h * 4 + ct) * 1024);
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+                            acc[h * 4 + ct][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ct], B[m], acc[h * 4 + ct][m], 0, 0, 0);
+                }
+            }
+            slabBarrier(0);
+            wb ^= 1;
+        }
+        // bias / residual / ReLU / store
+        {
+            const int n0 = chunk * CNB;
+            int ctn = (a.CoutRows - n0 + 15) / 16; ctn = ctn > 8 ? 8 : ctn;
+            const int sub = n0 / a.Cout, dy = sub / a.up, dx = sub - dy * a.up, cbase = n0 - sub * a.Cout;
+            const int Wout = a.Wo * a.up;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int oy = y0 + 2 * wave + (m >> 1), ox = x0 + (m & 1) * 16 + r;
+                const bool valid = oy < a.Ho && ox < a.Wo;
+                const size_t opix = valid ? (size_t)(oy * a.up + dy) * Wout + (ox * a.up + dx) : 0;
+                if (a.wide) {
+#pragma unroll
+                    for (int t0 = 0; t0 < 8; t0 += 2)
+                        if (t0 < ctn) convStoreWide(a, acc[t0][m], acc[t0 + 1][m], valid, opix, cbase + t0 * 16, g);
+                } else if (valid) {
+#pragma unroll
+                    for (int ct = 0; ct < 8; ++ct)
+                        if (ct < ctn) convStore(a, acc[ct][m], opix, cbase + ct * 16 + 4 * g);
+                }
+            }
+        }
+        if (!have_next) break;
+        // (the epilogue's loads and stores retire at the first slab end of the next item: nothing else is in flight)
+        item = nitem; y0 = ny0; x0 = nx0; chunk = nch;
+    }
+}
+
 // 16-channel tiles per workgroup of the halo kernel (and of its packed weights)
 static int haloChannelTiles(int coutRows) { return coutRows <= 32 ? 2 : coutRows <= 64 ? 4 : 8; }
 
@@ -550,6 +686,14 @@ static int haloTileRows(const ConvArgs&) {
 static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16* zeros, hipStream_t stream) {
     const int th = haloTileRows(a);
     const int tilesX = cdiv(a.Wo, HTW), nchunk = cdiv(a.CoutRows, CNB);
+    static int wideOn = -1;        // DSVT_CONV_WIDE=0: every layer on the 8-row kernel
+    if (wideOn < 0) { const char* e = getenv("DSVT_CONV_WIDE"); wideOn = e ? atoi(e) : 1; }
+    const int nwide = cdiv(a.Ho, WT_ROWS) * tilesX * nchunk;
+    if (wideOn && a.KH == 3 && haloChannelTiles(a.CoutRows) == 8 && nwide >= numCUs()) {      // fewer items than CUs: 8-row tiles
+        const int grid = nwide < numCUs() ? nwide : numCUs();
+        hipLaunchKernelGGL(conv_wide_kernel, dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk);
+        return lastError();
+    }
     const int nitems = cdiv(a.Ho, th) * tilesX * nchunk;
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("DSVT_CONV_DBG"); dbg = e ? atoi(e) : 0; }           // timing ablations only (wrong results)

@@ -88,6 +88,9 @@ def test_deconv_pixel_shuffle_and_concat(pkg, k, cin):
     (468, 468, 128, 128, 3, True),      # 885 (8-row) / 705 (10-row) tiles over 256 CUs: every workgroup walks several items
     (234, 234, 64, 320, 3, False),      # three 128-channel chunks per tile, the last one half full
     (117, 117, 256, 256, 1, False),     # 1x1: no halo, one slab per 64-channel chunk
+    (468, 468, 192, 128, 3, False),     # first BEV conv on the 16-row kernel: six 32-channel phases, 27 slabs
+    (468, 468, 64, 384, 3, False),      # head stems on the 16-row kernel: two phases, three chunks, 1350 items
+    (250, 200, 128, 128, 3, True),      # 16-row kernel with ragged bottom / right tiles, grid = item count
 ])
 def test_conv_halo_kernel_full_size(pkg, H, W, cin, cout, k, res):
     """The persistent halo-tile kernel at the BEV sizes (multi-item workgroups, ragged right / bottom tiles)."""
