@@ -545,14 +545,20 @@ constexpr int WT_HBYTES = WT_HH * WT_HS * 64;                     // 46,080 B: o
 constexpr int WT_NPC = WT_HBYTES / 1024;                          // 45 LDS-DMA pieces (16 pixels each)
 constexpr int WT_WBYTES = 16384;
 
+// CT = 16-channel tiles per workgroup (8: 128-channel chunks; 4 / 2: layers with <= 64 / <= 32 output channels, whose weight
+// slab holds SPS = 4 steps: with nine-step phases and two halo buffers a slab cannot span more than four steps).
+template <int CT>
 __global__ void __launch_bounds__(512, 1)
 conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __restrict__ zeros, int tilesX, int nitems, int nchunk)
 {
+    constexpr int SPS = CT == 8 ? 2 : 4;                          // (phase, tap) steps per weight slab
+    constexpr int PPS = SPS == 2 ? 2 : 6;                         // halo pieces a wave requests per slab
+    constexpr int CH = CT > 4 ? 4 : CT;                           // A fragments read per batch
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WT_HBYTES + 2 * WT_WBYTES];      // halo[2] | wslab[2] = 124,928 B
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
     const int NP = a.Cin >> 5;                                    // 32-channel phases (even: Cin % 64 == 0)
-    const int NSLAB = (NP * 9) >> 1;                              // two (phase, tap) steps per slab
-    const int NCT = nchunk * 8;
+    const int NSTEP = NP * 9, NSLAB = (NSTEP + SPS - 1) / SPS;    // (CT < 8: the last slab may be partial; the packed weights end in a zero slab)
+    const int NCT = CT == 8 ? nchunk * 8 : CT;
 
     auto decode = [&](int it, int& yy, int& xx, int& ch) {
         ch = it % nchunk; const int t = it / nchunk;
@@ -567,12 +573,12 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         const _Float16* src = ok ? a.in + (size_t)(gy * a.W + gx) * a.Cin + ph * 32 + chunk * 8 : zeros;
         __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + hb * WT_HBYTES + pc * 1024), 16, 0, 0);
     };
-    // the 16 fragment rows of slab sl (steps 2 sl, 2 sl + 1) of chunk ch -> buffer wb
+    // the 16 fragment rows of slab sl (steps SPS sl ...) of chunk ch -> buffer wb
     auto weightRequests = [&](int sl, int ch, int wb) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int u = wave + 8 * j, step = 2 * sl + j, ph = step / 9, tap = step - 9 * ph;     // u >> 3 == j
-            const size_t row = (size_t)(2 * ((ph >> 1) * 9 + tap) + (ph & 1)) * NCT + ch * 8 + wave;
+            const int u = wave + 8 * j, step = SPS * sl + u / CT, ph = step / 9, tap = step - 9 * ph;
+            const size_t row = (size_t)(2 * ((ph >> 1) * 9 + tap) + (ph & 1)) * NCT + ch * 8 + u % CT;
             __builtin_amdgcn_global_load_lds((glds_src_t)(Wp + (row * 64 + lane) * 8), (glds_dst_t)(smem + 2 * WT_HBYTES + wb * WT_WBYTES + u * 1024), 16, 0, 0);
         }
     };
@@ -590,49 +596,53 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     const int pb = ((2 * wave) * WT_HS + r) * 64;                 // this lane's pixel of pixel tile 0, tap (0, 0)
     const int aoff = lane << 4;
     int wb = 0;
-    floatx4 acc[8][4];
+    floatx4 acc[CT][4];
     for (;;) {
         int nitem = item + gridDim.x, ny0 = 0, nx0 = 0, nch = 0;
         const bool have_next = nitem < nitems;
         if (have_next) decode(nitem, ny0, nx0, nch);
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int m = 0; m < 4; ++m) acc[ct][m] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int s = 0; s < NSLAB; ++s) {
             if (s + 1 < NSLAB) weightRequests(s + 1, chunk, wb ^ 1);
             else if (have_next) weightRequests(0, nch, wb ^ 1);
-            const int p = (2 * s) / 9, j = (2 * s - 9 * p) >> 1;
-            if (j < 3) {                                          // the buffer of phase p + 1 is free since phase p - 1 ended
-                const bool inItem = p + 1 < NP;
-                if (inItem || have_next) {
-                    const int yy = inItem ? y0 : ny0, xx = inItem ? x0 : nx0, ph = inItem ? p + 1 : 0;
+            // halo of phase P (the phase after the one this slab starts in): its buffer is free once phase P - 2 has ended, i.e.
+            // from slab s0 = ceil(9 (P - 1) / SPS) on, and the first slab that touches phase P is floor(9 P / SPS) > s0 + 6 / PPS - 1
+            {
+                const int P = (SPS * s) / 9 + 1, k = s - (9 * (P - 1) + SPS - 1) / SPS;
+                const bool inItem = P < NP;
+                if (k * PPS < 6 && (inItem || have_next)) {
+                    const int yy = inItem ? y0 : ny0, xx = inItem ? x0 : nx0, ph = inItem ? P : 0;
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int pc = wave + 8 * (2 * j + i);
-                        if (pc < WT_NPC) haloRequest(pc, yy, xx, ph, (p + 1) & 1);
+                    for (int i = 0; i < PPS; ++i) {
+                        const int pc = wave + 8 * (k * PPS + i);
+                        if (pc < WT_NPC) haloRequest(pc, yy, xx, ph, P & 1);
                     }
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int step = 2 * s + u, ph = step / 9, tap = step - 9 * ph, ky = tap / 3, kx = tap - 3 * ky;
-                const unsigned char* hbp = smem + (ph & 1) * WT_HBYTES + (ky * WT_HS + kx) * 64 + pb + ((g ^ (((r + kx) >> 1) & 2)) << 4);
-                const unsigned char* wbp = smem + 2 * WT_HBYTES + wb * WT_WBYTES + u * 8192 + aoff;
-                half8 B[4];
+            for (int u = 0; u < SPS; ++u) {
+                const int step = SPS * s + u, ph = step / 9, tap = step - 9 * ph, ky = tap / 3, kx = tap - 3 * ky;
+                if (CT == 8 || step < NSTEP) {
+                    const unsigned char* hbp = smem + (ph & 1) * WT_HBYTES + (ky * WT_HS + kx) * 64 + pb + ((g ^ (((r + kx) >> 1) & 2)) << 4);
+                    const unsigned char* wbp = smem + 2 * WT_HBYTES + wb * WT_WBYTES + u * CT * 1024 + aoff;
+                    half8 B[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) B[m] = *reinterpret_cast<const half8*>(hbp + ((m >> 1) * WT_HS + (m & 1) * 16) * 64);
+                    for (int m = 0; m < 4; ++m) B[m] = *reinterpret_cast<const half8*>(hbp + ((m >> 1) * WT_HS + (m & 1) * 16) * 64);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    half8 A[4];
+                    for (int c0 = 0; c0 < CT; c0 += CH) {
+                        half8 A[CH];
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) A[ct] = *reinterpret_cast<const half8*>(wbp + (h * 4 + ct) * 1024);
+                        for (int ct = 0; ct < CH; ++ct) A[ct] = *reinterpret_cast<const half8*>(wbp + (c0 + ct) * 1024);
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct)
+                        for (int ct = 0; ct < CH; ++ct)
 #pragma unroll
-                        for (int m = 0; m < 4; ++m)
-                            acc[h * 4 + ct][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ct], B[m], acc[h * 4 + ct][m], 0, 0, 0);
+                            for (int m = 0; m < 4; ++m)
+                                acc[c0 + ct][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ct], B[m], acc[c0 + ct][m], 0, 0, 0);
+                    }
                 }
             }
             slabBarrier(0);
@@ -641,7 +651,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         // bias / residual / ReLU / store
         {
             const int n0 = chunk * CNB;
-            int ctn = (a.CoutRows - n0 + 15) / 16; ctn = ctn > 8 ? 8 : ctn;
+            int ctn = (a.CoutRows - n0 + 15) / 16; ctn = ctn > CT ? CT : ctn;
             const int sub = n0 / a.Cout, dy = sub / a.up, dx = sub - dy * a.up, cbase = n0 - sub * a.Cout;
             const int Wout = a.Wo * a.up;
 #pragma unroll
@@ -651,11 +661,11 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                 const size_t opix = valid ? (size_t)(oy * a.up + dy) * Wout + (ox * a.up + dx) : 0;
                 if (a.wide) {
 #pragma unroll
-                    for (int t0 = 0; t0 < 8; t0 += 2)
+                    for (int t0 = 0; t0 < CT; t0 += 2)
                         if (t0 < ctn) convStoreWide(a, acc[t0][m], acc[t0 + 1][m], valid, opix, cbase + t0 * 16, g);
                 } else if (valid) {
 #pragma unroll
-                    for (int ct = 0; ct < 8; ++ct)
+                    for (int ct = 0; ct < CT; ++ct)
                         if (ct < ctn) convStore(a, acc[ct][m], opix, cbase + ct * 16 + 4 * g);
                 }
             }
@@ -689,9 +699,13 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
     static int wideOn = -1;        // DSVT_CONV_WIDE=0: every layer on the 8-row kernel
     if (wideOn < 0) { const char* e = getenv("DSVT_CONV_WIDE"); wideOn = e ? atoi(e) : 1; }
     const int nwide = cdiv(a.Ho, WT_ROWS) * tilesX * nchunk;
-    if (wideOn && a.KH == 3 && haloChannelTiles(a.CoutRows) == 8 && nwide >= numCUs()) {      // fewer items than CUs: 8-row tiles
-        const int grid = nwide < numCUs() ? nwide : numCUs();
-        hipLaunchKernelGGL(conv_wide_kernel, dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk);
+    // (fewer items than CUs: 8-row tiles.  Two channel tiles: 32 MFMAs per slab cannot hide the halo stream, 86.7 vs 85.6 us
+    // on the 320 -> 18 head layer, so those stay on the 8-row kernel)
+    const int ctWide = haloChannelTiles(a.CoutRows);
+    if (wideOn && a.KH == 3 && nwide >= numCUs() && ctWide >= 4) {
+        const int grid = numCUs();
+        if (ctWide == 8) hipLaunchKernelGGL(conv_wide_kernel<8>, dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk);
+        else hipLaunchKernelGGL(conv_wide_kernel<4>, dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk);
         return lastError();
     }
     const int nitems = cdiv(a.Ho, th) * tilesX * nchunk;

@@ -91,6 +91,8 @@ def test_deconv_pixel_shuffle_and_concat(pkg, k, cin):
     (468, 468, 192, 128, 3, False),     # first BEV conv on the 16-row kernel: six 32-channel phases, 27 slabs
     (468, 468, 64, 384, 3, False),      # head stems on the 16-row kernel: two phases, three chunks, 1350 items
     (250, 200, 128, 128, 3, True),      # 16-row kernel with ragged bottom / right tiles, grid = item count
+    (468, 468, 384, 64, 3, False),      # shared head conv: four channel tiles, four steps per weight slab, 27 slabs
+    (468, 468, 320, 18, 3, False),      # head outputs: two channel tiles (18 of 32 channels real), 90 steps = 22.5 slabs
 ])
 def test_conv_halo_kernel_full_size(pkg, H, W, cin, cout, k, res):
     """The persistent halo-tile kernel at the BEV sizes (multi-item workgroups, ragged right / bottom tiles)."""
@@ -102,7 +104,7 @@ def test_conv_halo_kernel_full_size(pkg, H, W, cin, cout, k, res):
     r = torch.randn(1, cout, H, W, generator=g).half().to(DEV) if res else None
     ref = _ref(x, w, b, 1, k // 2, r, True)
     op = P.add_conv2d_op(P.conv_weight_rows(w.float().cpu().numpy()), b.cpu().numpy(), H, W, cin, cout, k, 1, k // 2,
-                         relu=True, has_residual=res)
+                         relu=True, has_residual=res, out_f32=cout % 4 != 0)      # fp16 rows need 8-byte alignment
     args = [nhwc(x)] + ([nhwc(r)] if res else [])
     got = op(*args)[0].permute(0, 3, 1, 2).float()
     torch.cuda.synchronize()
