@@ -540,25 +540,36 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
 // wave per barrier.  Phases run continuously across taps and items: the halo of phase p+1 (or of the next item's phase 0)
 // is requested during the first three slabs of phase p, the weights of slab s+1 when slab s starts; one vmcnt(0) + barrier
 // per slab.  The slab loop is NOT unrolled (a fully unrolled body of 1152 MFMAs makes hipcc spill the accumulators).
-constexpr int WT_ROWS = 16, WT_HH = WT_ROWS + 2, WT_HS = 40;
-constexpr int WT_HBYTES = WT_HH * WT_HS * 64;                     // 46,080 B: one 32-channel phase of the halo
-constexpr int WT_NPC = WT_HBYTES / 1024;                          // 45 LDS-DMA pieces (16 pixels each)
-constexpr int WT_WBYTES = 16384;
+// CT = 16-channel tiles per workgroup (8: 128-channel chunks; 4: 64-channel chunks, whose weight slab holds SPS = 4 steps:
+// with nine-step phases and two halo buffers a slab cannot span more than four steps).
+// NW = waves = half the tile rows.  <8, 8, 40> and <4, 8, 40> serve the 468x468 layers; <4, 4, 36> (8 rows x 32 pixels x 64
+// channels, 4 waves, 78 KB of LDS: two independent workgroups per CU) serves the 234x234 and 117x117 layers, which have
+// too few 16-row x 128-channel items for 256 CUs (117x117x256: 240 items of four waves instead of 120 of eight).
+// HS = halo row stride in pixels (>= 34; HS * 64 B is a multiple of 256 B, so the bank pattern is that of one row).
+template <int CT, int NW, int HS>
+struct WideCfg {
+    static constexpr int ROWS = 2 * NW, HH = ROWS + 2;
+    static constexpr int NPC = (HH * HS * 64 + 1023) / 1024;       // LDS-DMA pieces (16 pixels each) per halo phase
+    static constexpr int HBYTES = NPC * 1024, WBYTES = 16384;
+    static constexpr int PPW = (NPC + NW - 1) / NW;                // pieces per wave per phase
+    static constexpr int RPW = 16 / NW;                            // weight rows per wave per slab
+};
 
-// CT = 16-channel tiles per workgroup (8: 128-channel chunks; 4 / 2: layers with <= 64 / <= 32 output channels, whose weight
-// slab holds SPS = 4 steps: with nine-step phases and two halo buffers a slab cannot span more than four steps).
-template <int CT>
-__global__ void __launch_bounds__(512, 1)
+template <int CT, int NW, int HS>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1)
 conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __restrict__ zeros, int tilesX, int nitems, int nchunk)
 {
+    using C = WideCfg<CT, NW, HS>;
+    constexpr int WT_HS = HS, WT_HBYTES = C::HBYTES, WT_WBYTES = C::WBYTES, WT_NPC = C::NPC, WT_ROWS = C::ROWS, PPW = C::PPW;
     constexpr int SPS = CT == 8 ? 2 : 4;                          // (phase, tap) steps per weight slab
-    constexpr int PPS = SPS == 2 ? 2 : 6;                         // halo pieces a wave requests per slab
+    constexpr int PPS = SPS == 2 ? (PPW + 2) / 3 : PPW;           // halo pieces a wave requests per slab
+    constexpr int NRS = (PPW + PPS - 1) / PPS;                    // ... over this many slabs
     constexpr int CH = CT > 4 ? 4 : CT;                           // A fragments read per batch
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WT_HBYTES + 2 * WT_WBYTES];      // halo[2] | wslab[2] = 124,928 B
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WT_HBYTES + 2 * WT_WBYTES];      // halo[2] | wslab[2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
     const int NP = a.Cin >> 5;                                    // 32-channel phases (even: Cin % 64 == 0)
-    const int NSTEP = NP * 9, NSLAB = (NSTEP + SPS - 1) / SPS;    // (CT < 8: the last slab may be partial; the packed weights end in a zero slab)
-    const int NCT = CT == 8 ? nchunk * 8 : CT;
+    const int NSTEP = NP * 9, NSLAB = (NSTEP + SPS - 1) / SPS;    // (SPS = 4: the last slab may be partial; the packed weights end in a zero slab)
+    const int NCT = a.CoutRows <= 64 ? 4 : (a.CoutRows + 127) / 128 * 8;      // 16-channel tiles per k-step of the packed weights
 
     auto decode = [&](int it, int& yy, int& xx, int& ch) {
         ch = it % nchunk; const int t = it / nchunk;
@@ -569,16 +580,16 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         const int lp = pc * 16 + (lane >> 2), hy = lp / WT_HS, hx = lp - hy * WT_HS;
         const int chunk = (lane & 3) ^ ((hx >> 1) & 2);
         const int gy = yy - 1 + hy, gx = xx - 1 + hx;
-        const bool ok = hx < HTW + 2 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const bool ok = hx < HTW + 2 && hy < C::HH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         const _Float16* src = ok ? a.in + (size_t)(gy * a.W + gx) * a.Cin + ph * 32 + chunk * 8 : zeros;
         __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + hb * WT_HBYTES + pc * 1024), 16, 0, 0);
     };
     // the 16 fragment rows of slab sl (steps SPS sl ...) of chunk ch -> buffer wb
     auto weightRequests = [&](int sl, int ch, int wb) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int u = wave + 8 * j, step = SPS * sl + u / CT, ph = step / 9, tap = step - 9 * ph;
-            const size_t row = (size_t)(2 * ((ph >> 1) * 9 + tap) + (ph & 1)) * NCT + ch * 8 + u % CT;
+        for (int j = 0; j < C::RPW; ++j) {
+            const int u = wave + NW * j, step = SPS * sl + u / CT, ph = step / 9, tap = step - 9 * ph;
+            const size_t row = (size_t)(2 * ((ph >> 1) * 9 + tap) + (ph & 1)) * NCT + ch * CT + u % CT;
             __builtin_amdgcn_global_load_lds((glds_src_t)(Wp + (row * 64 + lane) * 8), (glds_dst_t)(smem + 2 * WT_HBYTES + wb * WT_WBYTES + u * 1024), 16, 0, 0);
         }
     };
@@ -588,8 +599,8 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     int y0, x0, chunk;
     decode(item, y0, x0, chunk);
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-        if (wave + 8 * i < WT_NPC) haloRequest(wave + 8 * i, y0, x0, 0, 0);
+    for (int i = 0; i < PPW; ++i)
+        if (wave + NW * i < WT_NPC) haloRequest(wave + NW * i, y0, x0, 0, 0);
     weightRequests(0, chunk, 0);
     slabBarrier(0);
 
@@ -610,23 +621,23 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
             if (s + 1 < NSLAB) weightRequests(s + 1, chunk, wb ^ 1);
             else if (have_next) weightRequests(0, nch, wb ^ 1);
             // halo of phase P (the phase after the one this slab starts in): its buffer is free once phase P - 2 has ended, i.e.
-            // from slab s0 = ceil(9 (P - 1) / SPS) on, and the first slab that touches phase P is floor(9 P / SPS) > s0 + 6 / PPS - 1
+            // from slab s0 = ceil(9 (P - 1) / SPS) on, and the first slab that touches phase P is floor(9 P / SPS) > s0 + NRS - 1
             {
                 const int P = (SPS * s) / 9 + 1, k = s - (9 * (P - 1) + SPS - 1) / SPS;
                 const bool inItem = P < NP;
-                if (k * PPS < 6 && (inItem || have_next)) {
+                if (k < NRS && (inItem || have_next)) {
                     const int yy = inItem ? y0 : ny0, xx = inItem ? x0 : nx0, ph = inItem ? P : 0;
 #pragma unroll
                     for (int i = 0; i < PPS; ++i) {
-                        const int pc = wave + 8 * (k * PPS + i);
-                        if (pc < WT_NPC) haloRequest(pc, yy, xx, ph, P & 1);
+                        const int pc = wave + NW * (k * PPS + i);
+                        if (k * PPS + i < PPW && pc < WT_NPC) haloRequest(pc, yy, xx, ph, P & 1);
                     }
                 }
             }
 #pragma unroll
             for (int u = 0; u < SPS; ++u) {
                 const int step = SPS * s + u, ph = step / 9, tap = step - 9 * ph, ky = tap / 3, kx = tap - 3 * ky;
-                if (CT == 8 || step < NSTEP) {
+                if (SPS == 2 || step < NSTEP) {
                     const unsigned char* hbp = smem + (ph & 1) * WT_HBYTES + (ky * WT_HS + kx) * 64 + pb + ((g ^ (((r + kx) >> 1) & 2)) << 4);
                     const unsigned char* wbp = smem + 2 * WT_HBYTES + wb * WT_WBYTES + u * CT * 1024 + aoff;
                     half8 B[4];
@@ -650,7 +661,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         }
         // bias / residual / ReLU / store
         {
-            const int n0 = chunk * CNB;
+            const int n0 = chunk * CT * 16;
             int ctn = (a.CoutRows - n0 + 15) / 16; ctn = ctn > CT ? CT : ctn;
             const int sub = n0 / a.Cout, dy = sub / a.up, dx = sub - dy * a.up, cbase = n0 - sub * a.Cout;
             const int Wout = a.Wo * a.up;
@@ -698,15 +709,23 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
     const int tilesX = cdiv(a.Wo, HTW), nchunk = cdiv(a.CoutRows, CNB);
     static int wideOn = -1;        // DSVT_CONV_WIDE=0: every layer on the 8-row kernel
     if (wideOn < 0) { const char* e = getenv("DSVT_CONV_WIDE"); wideOn = e ? atoi(e) : 1; }
-    const int nwide = cdiv(a.Ho, WT_ROWS) * tilesX * nchunk;
-    // (fewer items than CUs: 8-row tiles.  Two channel tiles: 32 MFMAs per slab cannot hide the halo stream, 86.7 vs 85.6 us
-    // on the 320 -> 18 head layer, so those stay on the 8-row kernel)
+    const int nwide = cdiv(a.Ho, 16) * tilesX * nchunk;
+    // 16-row tiles when they fill the CUs, else 8-row x 64-channel tiles on four waves (two workgroups per CU).  (Two channel
+    // tiles: 32 MFMAs per slab cannot hide the halo stream, 86.7 vs 85.6 us on the 320 -> 18 head layer: the 8-row kernel below.)
     const int ctWide = haloChannelTiles(a.CoutRows);
-    if (wideOn && a.KH == 3 && nwide >= numCUs() && ctWide >= 4) {
-        const int grid = numCUs();
-        if (ctWide == 8) hipLaunchKernelGGL(conv_wide_kernel<8>, dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk);
-        else hipLaunchKernelGGL(conv_wide_kernel<4>, dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk);
-        return lastError();
+    if (wideOn && a.KH == 3 && ctWide >= 4) {
+        if (nwide >= numCUs()) {
+            const int grid = numCUs();
+            if (ctWide == 8) hipLaunchKernelGGL((conv_wide_kernel<8, 8, 40>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk);
+            else hipLaunchKernelGGL((conv_wide_kernel<4, 8, 40>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk);
+            return lastError();
+        }
+        if (wideOn != 2) {
+            const int nch64 = cdiv(a.CoutRows, 64), nsmall = cdiv(a.Ho, 8) * tilesX * nch64;
+            const int grid = nsmall < 2 * numCUs() ? nsmall : 2 * numCUs();
+            hipLaunchKernelGGL((conv_wide_kernel<4, 4, 36>), dim3(grid), dim3(256), 0, stream, a, Wp, zeros, tilesX, nsmall, nch64);
+            return lastError();
+        }
     }
     const int nitems = cdiv(a.Ho, th) * tilesX * nchunk;
     static int dbg = -1;

@@ -92,6 +92,8 @@ def test_deconv_pixel_shuffle_and_concat(pkg, k, cin):
     (468, 468, 64, 384, 3, False),      # head stems on the 16-row kernel: two phases, three chunks, 1350 items
     (250, 200, 128, 128, 3, True),      # 16-row kernel with ragged bottom / right tiles, grid = item count
     (468, 468, 384, 64, 3, False),      # shared head conv: four channel tiles, four steps per weight slab, 27 slabs
+    (234, 234, 128, 128, 3, True),      # 8-row x 64-channel tiles on four waves: 480 items, two workgroups per CU
+    (117, 117, 256, 256, 3, True),      # ... 240 items, eight phases
     (468, 468, 320, 18, 3, False),      # head outputs: two channel tiles (18 of 32 channels real), 90 steps = 22.5 slabs
 ])
 def test_conv_halo_kernel_full_size(pkg, H, W, cin, cout, k, res):
