@@ -546,22 +546,22 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
 // channels, 4 waves, 78 KB of LDS: two independent workgroups per CU) serves the 234x234 and 117x117 layers, which have
 // too few 16-row x 128-channel items for 256 CUs (117x117x256: 240 items of four waves instead of 120 of eight).
 // HS = halo row stride in pixels (>= 34; HS * 64 B is a multiple of 256 B, so the bank pattern is that of one row).
-template <int CT, int NW, int HS>
+template <int CT, int NW, int HS, int SPS>
 struct WideCfg {
     static constexpr int ROWS = 2 * NW, HH = ROWS + 2;
     static constexpr int NPC = (HH * HS * 64 + 1023) / 1024;       // LDS-DMA pieces (16 pixels each) per halo phase
-    static constexpr int HBYTES = NPC * 1024, WBYTES = 16384;
+    static constexpr int HBYTES = NPC * 1024, WBYTES = SPS * CT * 1024;
     static constexpr int PPW = (NPC + NW - 1) / NW;                // pieces per wave per phase
-    static constexpr int RPW = 16 / NW;                            // weight rows per wave per slab
+    static constexpr int RPW = SPS * CT / NW;                       // weight rows per wave per slab
 };
 
-template <int CT, int NW, int HS>
+template <int CT, int NW, int HS, int SPS = (CT == 8 ? 2 : 4)>
 __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1)
 conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __restrict__ zeros, int tilesX, int nitems, int nchunk)
 {
-    using C = WideCfg<CT, NW, HS>;
+    using C = WideCfg<CT, NW, HS, SPS>;
+    static_assert(SPS == 2 || SPS == 4, "nine-step phases and two halo buffers: a slab spans at most four steps");
     constexpr int WT_HS = HS, WT_HBYTES = C::HBYTES, WT_WBYTES = C::WBYTES, WT_NPC = C::NPC, WT_ROWS = C::ROWS, PPW = C::PPW;
-    constexpr int SPS = CT == 8 ? 2 : 4;                          // (phase, tap) steps per weight slab
     constexpr int PPS = SPS == 2 ? (PPW + 2) / 3 : PPW;           // halo pieces a wave requests per slab
     constexpr int NRS = (PPW + PPS - 1) / PPS;                    // ... over this many slabs
     constexpr int CH = CT > 4 ? 4 : CT;                           // A fragments read per batch
@@ -634,26 +634,40 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                     }
                 }
             }
-#pragma unroll
-            for (int u = 0; u < SPS; ++u) {
-                const int step = SPS * s + u, ph = step / 9, tap = step - 9 * ph, ky = tap / 3, kx = tap - 3 * ky;
-                if (SPS == 2 || step < NSTEP) {
+            // fragments are double buffered by hand: the reads of batch b + 1 (CH channel tiles x 4 pixel tiles = 4 CH MFMAs) are
+            // issued BEFORE the MFMAs of batch b (left to itself hipcc emits read, s_waitcnt lgkmcnt(0), 8 MFMAs, read, ...)
+            {
+                constexpr int BPS = CT / CH, NB = SPS * BPS;          // batches per step / per slab
+                half8 Bf[2][4], Af[2][CH];
+                auto loadB = [&](int u, half8 (&B)[4]) {
+                    const int step = SPS * s + u, ph = step / 9, tap = step - 9 * ph, ky = tap / 3, kx = tap - 3 * ky;
                     const unsigned char* hbp = smem + (ph & 1) * WT_HBYTES + (ky * WT_HS + kx) * 64 + pb + ((g ^ (((r + kx) >> 1) & 2)) << 4);
-                    const unsigned char* wbp = smem + 2 * WT_HBYTES + wb * WT_WBYTES + u * CT * 1024 + aoff;
-                    half8 B[4];
 #pragma unroll
                     for (int m = 0; m < 4; ++m) B[m] = *reinterpret_cast<const half8*>(hbp + ((m >> 1) * WT_HS + (m & 1) * 16) * 64);
+                };
+                auto loadA = [&](int u, int c0, half8 (&A)[CH]) {
+                    const unsigned char* wbp = smem + 2 * WT_HBYTES + wb * WT_WBYTES + (u * CT + c0) * 1024 + aoff;
 #pragma unroll
-                    for (int c0 = 0; c0 < CT; c0 += CH) {
-                        half8 A[CH];
+                    for (int ct = 0; ct < CH; ++ct) A[ct] = *reinterpret_cast<const half8*>(wbp + ct * 1024);
+                };
+                loadB(0, Bf[0]); loadA(0, 0, Af[0]);
 #pragma unroll
-                        for (int ct = 0; ct < CH; ++ct) A[ct] = *reinterpret_cast<const half8*>(wbp + (c0 + ct) * 1024);
+                for (int b = 0; b < NB; ++b) {
+                    const int u = b / BPS, c0 = (b % BPS) * CH;
+                    if (b + 1 < NB) {
+                        const int un = (b + 1) / BPS, cn = ((b + 1) % BPS) * CH;
+                        if (cn == 0) loadB(un, Bf[un & 1]);
+                        loadA(un, cn, Af[(b + 1) & 1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (SPS == 2 || SPS * s + u < NSTEP) {
 #pragma unroll
                         for (int ct = 0; ct < CH; ++ct)
 #pragma unroll
                             for (int m = 0; m < 4; ++m)
-                                acc[c0 + ct][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ct], B[m], acc[c0 + ct][m], 0, 0, 0);
+                                acc[c0 + ct][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[b & 1][ct], Bf[u & 1][m], acc[c0 + ct][m], 0, 0, 0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             slabBarrier(0);
@@ -799,7 +813,7 @@ public:
             // one 16 KB slab of zero padding at the end: the last slab of a narrow layer is requested whole
             const int T = c.KH * c.KW, NCC = c.Cin / 64, R = rows(), ctw = haloChannelTiles(R);
             const int NCT = ctw < 8 ? ctw : cdiv(R, CNB) * 8;
-            std::vector<_Float16> wp((size_t)NCC * T * 2 * NCT * 512 + 8192, (_Float16)0.f);
+            std::vector<_Float16> wp((size_t)NCC * T * 2 * NCT * 512 + (size_t)(NCT > 4 ? 4 * NCT : 16) * 512, (_Float16)0.f);   // (a partial four-step slab: two k-steps)
             for (int cc = 0; cc < NCC; ++cc)
                 for (int tap = 0; tap < T; ++tap)
                     for (int ks = 0; ks < 2; ++ks)
