@@ -557,7 +557,7 @@ struct WideCfg {
 
 template <int CT, int NW, int HS, int SPS = (CT == 8 ? 2 : 4)>
 __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1)
-conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __restrict__ zeros, int tilesX, int nitems, int nchunk)
+conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __restrict__ zeros, int tilesX, int nitems, int nchunk, int dbg)
 {
     using C = WideCfg<CT, NW, HS, SPS>;
     static_assert(SPS == 2 || SPS == 4, "nine-step phases and two halo buffers: a slab spans at most four steps");
@@ -565,7 +565,8 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     constexpr int PPS = SPS == 2 ? (PPW + 2) / 3 : PPW;           // halo pieces a wave requests per slab
     constexpr int NRS = (PPW + PPS - 1) / PPS;                    // ... over this many slabs
     constexpr int CH = CT > 4 ? 4 : CT;                           // A fragments read per batch
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WT_HBYTES + 2 * WT_WBYTES];      // halo[2] | wslab[2]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WT_HBYTES + 2 * WT_WBYTES + 1024];      // halo[2] | wslab[2] | bias
+    constexpr int BIAS_OFF = 2 * WT_HBYTES + 2 * WT_WBYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
     const int NP = a.Cin >> 5;                                    // 32-channel phases (even: Cin % 64 == 0)
     const int NSTEP = NP * 9, NSLAB = (NSTEP + SPS - 1) / SPS;    // (SPS = 4: the last slab may be partial; the packed weights end in a zero slab)
@@ -594,10 +595,21 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         }
     };
 
+    // the chunk's bias (CT * 16 floats) travels as one more LDS-DMA piece and the accumulators start from it: the epilogue of a
+    // layer without a residual then holds no load at all (a load issued after a store is awaited with vmcnt(0): gfx950 counts
+    // loads and stores in one counter and hipcc cannot count across the two kinds)
+    const bool biasInit = a.wide && a.bias != nullptr;
+    auto biasRequest = [&](int ch) {
+        const int n0 = ch * CT * 16, sub = n0 / a.Cout, co = n0 - sub * a.Cout + lane * 4;
+        const void* src = (biasInit && lane < CT * 4 && co + 3 < a.Cout) ? static_cast<const void*>(a.bias + co) : static_cast<const void*>(zeros);
+        __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + BIAS_OFF), 16, 0, 0);
+    };
+
     int item = blockIdx.x;
     if (item >= nitems) return;
     int y0, x0, chunk;
     decode(item, y0, x0, chunk);
+    if (wave == 0) biasRequest(chunk);
 #pragma unroll
     for (int i = 0; i < PPW; ++i)
         if (wave + NW * i < WT_NPC) haloRequest(wave + NW * i, y0, x0, 0, 0);
@@ -613,19 +625,22 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         const bool have_next = nitem < nitems;
         if (have_next) decode(nitem, ny0, nx0, nch);
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+        for (int ct = 0; ct < CT; ++ct) {
+            const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + BIAS_OFF + (ct * 16 + 4 * g) * 4);      // zeros without a bias
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[ct][m] = floatx4{0.f, 0.f, 0.f, 0.f};
+            for (int m = 0; m < 4; ++m) acc[ct][m] = b4;
+        }
 #pragma unroll 1
         for (int s = 0; s < NSLAB; ++s) {
-            if (s + 1 < NSLAB) weightRequests(s + 1, chunk, wb ^ 1);
-            else if (have_next) weightRequests(0, nch, wb ^ 1);
+            if (dbg & 2) {}                                       // (dbg: timing ablation)
+            else if (s + 1 < NSLAB) weightRequests(s + 1, chunk, wb ^ 1);
+            else if (have_next) { weightRequests(0, nch, wb ^ 1); if (wave == 0) biasRequest(nch); }
             // halo of phase P (the phase after the one this slab starts in): its buffer is free once phase P - 2 has ended, i.e.
             // from slab s0 = ceil(9 (P - 1) / SPS) on, and the first slab that touches phase P is floor(9 P / SPS) > s0 + NRS - 1
             {
                 const int P = (SPS * s) / 9 + 1, k = s - (9 * (P - 1) + SPS - 1) / SPS;
                 const bool inItem = P < NP;
-                if (k < NRS && (inItem || have_next)) {
+                if (k < NRS && (inItem || have_next) && !(dbg & 1)) {
                     const int yy = inItem ? y0 : ny0, xx = inItem ? x0 : nx0, ph = inItem ? P : 0;
 #pragma unroll
                     for (int i = 0; i < PPS; ++i) {
@@ -673,22 +688,50 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
             slabBarrier(0);
             wb ^= 1;
         }
-        // bias / residual / ReLU / store
-        {
+        // residual / ReLU / store (the bias is in the accumulators)
+        if (!(dbg & 8)) {
             const int n0 = chunk * CT * 16;
             int ctn = (a.CoutRows - n0 + 15) / 16; ctn = ctn > CT ? CT : ctn;
             const int sub = n0 / a.Cout, dy = sub / a.up, dx = sub - dy * a.up, cbase = n0 - sub * a.Cout;
             const int Wout = a.Wo * a.up;
+            if (a.wide) {
+                constexpr int TP = CT / 2, NBLK = 4 * TP;             // blocks b = (pixel tile m, channel-tile pair tp)
+                const int cg8 = (g & 1) * 16 + (g >> 1) * 8;
+                bool valid[4]; size_t opix[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int oy = y0 + 2 * wave + (m >> 1), ox = x0 + (m & 1) * 16 + r;
-                const bool valid = oy < a.Ho && ox < a.Wo;
-                const size_t opix = valid ? (size_t)(oy * a.up + dy) * Wout + (ox * a.up + dx) : 0;
-                if (a.wide) {
+                for (int m = 0; m < 4; ++m) {
+                    const int oy = y0 + 2 * wave + (m >> 1), ox = x0 + (m & 1) * 16 + r;
+                    valid[m] = oy < a.Ho && ox < a.Wo;
+                    opix[m] = valid[m] ? (size_t)(oy * a.up + dy) * Wout + (ox * a.up + dx) : 0;
+                }
 #pragma unroll
-                    for (int t0 = 0; t0 < CT; t0 += 2)
-                        if (t0 < ctn) convStoreWide(a, acc[t0][m], acc[t0 + 1][m], valid, opix, cbase + t0 * 16, g);
-                } else if (valid) {
+                for (int b = 0; b < NBLK; ++b) {
+                    const int m = b / TP, tp = b % TP, co = cbase + tp * 32 + cg8;
+                    if (2 * tp >= ctn) continue;
+                    floatx4 X = acc[2 * tp][m], Y = acc[2 * tp + 1][m];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(X[i]), __float_as_uint(Y[i]), false, false);
+                        X[i] = __uint_as_float(sw[0]); Y[i] = __uint_as_float(sw[1]);
+                    }
+                    if (!valid[m] || co >= a.Cout) continue;
+                    float v[8] = {X[0], X[1], X[2], X[3], Y[0], Y[1], Y[2], Y[3]};
+                    if (a.res) {
+                        const half8 rv = *reinterpret_cast<const half8*>(a.res + opix[m] * a.res_ld + co);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] += (float)rv[i];
+                    }
+                    half8 h;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) h[i] = (_Float16)(a.relu ? fmaxf(v[i], 0.f) : v[i]);
+                    *reinterpret_cast<half8*>(static_cast<_Float16*>(a.out) + opix[m] * a.out_ld + a.out_coff + co) = h;
+                }
+            } else {                                                  // (not a layer of this network)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int oy = y0 + 2 * wave + (m >> 1), ox = x0 + (m & 1) * 16 + r;
+                    if (!(oy < a.Ho && ox < a.Wo)) continue;
+                    const size_t opix = (size_t)(oy * a.up + dy) * Wout + (ox * a.up + dx);
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
                         if (ct < ctn) convStore(a, acc[ct][m], opix, cbase + ct * 16 + 4 * g);
@@ -727,17 +770,19 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
     // 16-row tiles when they fill the CUs, else 8-row x 64-channel tiles on four waves (two workgroups per CU).  (Two channel
     // tiles: 32 MFMAs per slab cannot hide the halo stream, 86.7 vs 85.6 us on the 320 -> 18 head layer: the 8-row kernel below.)
     const int ctWide = haloChannelTiles(a.CoutRows);
+    static int dbgW = -1;
+    if (dbgW < 0) { const char* e = getenv("DSVT_CONV_DBG"); dbgW = e ? atoi(e) : 0; }          // timing ablations only (wrong results)
     if (wideOn && a.KH == 3 && ctWide >= 4) {
-        if (nwide >= numCUs()) {
+        if (nwide >= numCUs() && wideOn != 4) {
             const int grid = numCUs();
-            if (ctWide == 8) hipLaunchKernelGGL((conv_wide_kernel<8, 8, 40>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk);
-            else hipLaunchKernelGGL((conv_wide_kernel<4, 8, 40>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk);
+            if (ctWide == 8) hipLaunchKernelGGL((conv_wide_kernel<8, 8, 40>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk, dbgW);
+            else hipLaunchKernelGGL((conv_wide_kernel<4, 8, 40>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk, dbgW);
             return lastError();
         }
         if (wideOn != 2) {
             const int nch64 = cdiv(a.CoutRows, 64), nsmall = cdiv(a.Ho, 8) * tilesX * nch64;
             const int grid = nsmall < 2 * numCUs() ? nsmall : 2 * numCUs();
-            hipLaunchKernelGGL((conv_wide_kernel<4, 4, 36>), dim3(grid), dim3(256), 0, stream, a, Wp, zeros, tilesX, nsmall, nch64);
+            hipLaunchKernelGGL((conv_wide_kernel<4, 4, 36>), dim3(grid), dim3(256), 0, stream, a, Wp, zeros, tilesX, nsmall, nch64, dbgW);
             return lastError();
         }
     }
