@@ -257,6 +257,7 @@ constexpr int HHS = 40;           // LDS halo row stride in pixels (>= HTW + 2, 
 // the odd 16-lane rows of X with the even rows of Y, after which lane (r, g) holds EIGHT consecutive output
 // channels of pixel r (first channel t0*16 + (g&1)*16 + (g>>1)*8): bias / residual / store are 16-byte accesses
 // and the four lanes of a pixel cover a contiguous 64-byte segment.
+template <bool WITH_BIAS = true>
 __device__ __forceinline__ void convStoreWide(const ConvArgs& a, floatx4 X, floatx4 Y, bool valid, size_t opix, int co0, int g)
 {
 #pragma unroll
@@ -267,7 +268,7 @@ __device__ __forceinline__ void convStoreWide(const ConvArgs& a, floatx4 X, floa
     const int co = co0 + (g & 1) * 16 + (g >> 1) * 8;
     if (!valid || co >= a.Cout) return;
     float v[8] = {X[0], X[1], X[2], X[3], Y[0], Y[1], Y[2], Y[3]};
-    if (a.bias) {
+    if (WITH_BIAS && a.bias) {
         const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co), b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
         v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
     }
@@ -334,7 +335,8 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     // measured 8 % SLOWER than one slab of lead on the 468x468 layers (117.7 vs 108.6 us): the slab-end wait is not what stalls
     constexpr int NWB = 2, LEAD = NWB - 1;
     // ONE shared object: halo[2] | wslab[2]  (a second __shared__ object makes hipcc drain the DMA queue before every ds_read)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[HB * HBYTES + NWB * WBYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[HB * HBYTES + NWB * WBYTES + 1024];      // ... | bias of the item's chunk
+    constexpr int BIAS_OFF = HB * HBYTES + NWB * WBYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
     const int pg = wave >> 1, cg = wave & 1;
     const int NCC = a.Cin >> 6, NCT = NARROW ? CTW : nchunk * 8;
@@ -402,7 +404,7 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
             if (a.wide) {
 #pragma unroll
                 for (int t0 = 0; t0 + 1 < CTP; t0 += 2)
-                    if (t0 < ctn) convStoreWide(a, acc[t0][m], acc[t0 + 1][m], valid, opix, cbase + cgc * 64 + t0 * 16, g);
+                    if (t0 < ctn) convStoreWide<false>(a, acc[t0][m], acc[t0 + 1][m], valid, opix, cbase + cgc * 64 + t0 * 16, g);
             } else if (valid) {
 #pragma unroll
                 for (int ct = 0; ct < CTP; ++ct)
@@ -411,11 +413,21 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         }
     };
 
+    // the bias of a chunk (<= 128 floats) is one more LDS-DMA piece and the accumulators start from it: the wide epilogue then has
+    // no load between its stores (a load after a store is awaited with vmcnt(0), i.e. behind the store's write acknowledgement)
+    const bool biasInit = a.wide && a.bias != nullptr;
+    auto biasRequest = [&](int ch) {
+        const int n0 = ch * CNB, sub = n0 / a.Cout, co = n0 - sub * a.Cout + lane * 4;
+        const void* src = (biasInit && lane < 32 && co + 3 < a.Cout) ? static_cast<const void*>(a.bias + co) : static_cast<const void*>(zeros);
+        __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + BIAS_OFF), 16, 0, 0);
+    };
+
     int item = blockIdx.x;
     if (item >= nitems) return;
     int y0, x0, chunk;
     decode(item, y0, x0, chunk);
     setup(y0, x0);
+    if (wave == 0) biasRequest(chunk);
 #pragma unroll
     for (int j = 0; j < HPW; ++j)
         if (NI % TH == 0 || wave + j * TH < NI) haloRequest(j, 0, 0);
@@ -450,15 +462,20 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                         // whole MFMA block to complete
                         if (pending && !(dbg & 8)) epilogue(ey, ex, ech);
 #pragma unroll
-                        for (int ct = 0; ct < CTP; ++ct)
+                        for (int ct = 0; ct < CTP; ++ct) {
+                            const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + BIAS_OFF + (cgc * 64 + ct * 16 + 4 * g) * 4);      // zeros without a bias
 #pragma unroll
-                            for (int m = 0; m < NM; ++m) acc[ct][m] = floatx4{0.f, 0.f, 0.f, 0.f};
+                            for (int m = 0; m < NM; ++m) acc[ct][m] = b4;
+                        }
                     }
                     // the slab LEAD ahead: (cc, grp + LEAD) or, past the end of this phase, (ncc, grp + LEAD - NG) of the next one
                     wIssued = false;
                     if (!(dbg & 2)) {
                         if (grp + LEAD < NG) { weightRequests((cc * T + (grp + LEAD) * TPS) * 2, chunk, (wb + LEAD) % NWB); wIssued = true; }
-                        else if (have_next) { weightRequests((ncc * T + (grp + LEAD - NG) * TPS) * 2, nch, (wb + LEAD) % NWB); wIssued = true; }
+                        else if (have_next) {
+                            weightRequests((ncc * T + (grp + LEAD - NG) * TPS) * 2, nch, (wb + LEAD) % NWB); wIssued = true;
+                            if (ncc == 0 && grp + LEAD == NG && wave == 0) biasRequest(nch);      // first slab of the next item: its bias too
+                        }
                     }
                     nreq = 0;
                 }
