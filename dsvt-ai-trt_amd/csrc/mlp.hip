@@ -260,6 +260,17 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
     for (int q = 0; q < NPIECE; ++q) {
         const int stA = NWO + 2 * q, stB = stA + 1;
         if (stA + 2 < NST) request(stA + 2);         // next W1 piece
+        else {
+            // last piece: nothing left to stream, so the parameters of the final LayerNorms (ln_g | ln_b, 4 x 192 floats each) take
+            // the slot stage NST-3 has just left: the epilogue then reads them with ds_read, and its only global loads are x / xb
+#pragma unroll
+            for (int j = 0; j < (6 + NW - 1) / NW; ++j) {
+                const int pr = wave + j * NW;
+                if (pr < 6)
+                    __builtin_amdgcn_global_load_lds((mlp_gsrc_t)((pr < 3 ? a.ln_g + pr * 256 : a.ln_b + (pr - 3) * 256) + lane * 4),
+                                                     (mlp_ldst_t)(lds + (NST % 3) * SB + pr * 1024), 16, 0, 0);
+            }
+        }
         const unsigned char* slotA = lbase + (stA % 3) * SB;
         floatx4 acc2[MT][PQT];
 #pragma unroll
@@ -315,32 +326,45 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
     }
     mark();
     // ---- s2 = LN2(s1 + f + b2) (already summed); x' = LN3(s2 + x); [x' = LN4(x' + xb)]: nothing in flight any more ------
+    const float* lnL = reinterpret_cast<const float*>(lds + (NST % 3) * SB);        // ln_g [4][192] | ln_b [4][192]
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+        int rcl = rc[mt];
+        asm volatile("" : "+v"(rcl));                // (row addresses re-formed here, not carried through the streaming loop in spilled registers)
         if (!(a.dbg & 4)) {
-        mlpLayerNorm(acc[mt], a.ln_g + MC, a.ln_b + MC, g, a.eps);
+        mlpLayerNormLds(acc[mt], lnL + MC, lnL + 4 * MC + MC, g, a.eps);
 #pragma unroll
         for (int t = 0; t < MNT; ++t) {
-            const float4 xv = *reinterpret_cast<const float4*>(a.x + (size_t)rc[mt] * MC + t * 16 + 4 * g);
+            const float4 xv = *reinterpret_cast<const float4*>(a.x + (size_t)rcl * MC + t * 16 + 4 * g);
             acc[mt][t][0] += xv.x; acc[mt][t][1] += xv.y; acc[mt][t][2] += xv.z; acc[mt][t][3] += xv.w;
         }
-        mlpLayerNorm(acc[mt], a.ln_g + 2 * MC, a.ln_b + 2 * MC, g, a.eps);
+        mlpLayerNormLds(acc[mt], lnL + 2 * MC, lnL + 4 * MC + 2 * MC, g, a.eps);
         }
+        __builtin_amdgcn_sched_barrier(0);           // (x and xb rows of a tile together: 96 registers of loads)
         if (a.xb) {
 #pragma unroll
             for (int t = 0; t < MNT; ++t) {
-                const float4 xv = *reinterpret_cast<const float4*>(a.xb + (size_t)rc[mt] * MC + t * 16 + 4 * g);
+                const float4 xv = *reinterpret_cast<const float4*>(a.xb + (size_t)rcl * MC + t * 16 + 4 * g);
                 acc[mt][t][0] += xv.x; acc[mt][t][1] += xv.y; acc[mt][t][2] += xv.z; acc[mt][t][3] += xv.w;
             }
-            mlpLayerNorm(acc[mt], a.ln_g + 3 * MC, a.ln_b + 3 * MC, g, a.eps);
+            mlpLayerNormLds(acc[mt], lnL + 3 * MC, lnL + 4 * MC + 3 * MC, g, a.eps);
         }
-        if (row[mt] < M && !(a.dbg & 8)) {
+        __builtin_amdgcn_sched_barrier(0);           // (keeps the second tile's loads from being hoisted over the first tile's arithmetic: spills)
+    }
+    // every load of the epilogue (LayerNorm parameters, x, xb of BOTH row tiles) is issued before the first store: gfx950 counts
+    // loads and stores in one vmcnt, so a load after a store is awaited behind that store's write acknowledgement
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int rw = row[mt];
+        asm volatile("" : "+v"(rw));                 // (the store addresses are formed here, not kept alive through the streaming loop)
+        if (rw < M && !(a.dbg & 8)) {
 #pragma unroll
             for (int t = 0; t < MNT; ++t) {
                 const int col = t * 16 + 4 * g;
-                *reinterpret_cast<float4*>(a.out + (size_t)row[mt] * MC + col) = make_float4(acc[mt][t][0], acc[mt][t][1], acc[mt][t][2], acc[mt][t][3]);
+                *reinterpret_cast<float4*>(a.out + (size_t)rw * MC + col) = make_float4(acc[mt][t][0], acc[mt][t][1], acc[mt][t][2], acc[mt][t][3]);
                 half4 h; h[0] = (_Float16)acc[mt][t][0]; h[1] = (_Float16)acc[mt][t][1]; h[2] = (_Float16)acc[mt][t][2]; h[3] = (_Float16)acc[mt][t][3];
-                *reinterpret_cast<half4*>(a.out16 + (size_t)row[mt] * MC + col) = h;
+                *reinterpret_cast<half4*>(a.out16 + (size_t)rw * MC + col) = h;
             }
         }
     }
