@@ -48,12 +48,13 @@ struct ConvArgs {
 
 
 // bias / residual / ReLU / store of four consecutive output channels co..co+3 of output pixel opix
+template <bool WITH_BIAS = true>
 __device__ __forceinline__ void convStore(const ConvArgs& a, floatx4 acc, size_t opix, int co)
 {
     if (co >= a.Cout) return;
     float v[4] = {acc[0], acc[1], acc[2], acc[3]};
     const bool full = co + 3 < a.Cout;
-    if (a.bias) {
+    if (WITH_BIAS && a.bias) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) if (co + i < a.Cout) v[i] += a.bias[co + i];
     }
@@ -408,17 +409,17 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
             } else if (valid) {
 #pragma unroll
                 for (int ct = 0; ct < CTP; ++ct)
-                    if (ct < ctn) convStore(a, acc[ct][m], opix, cbase + cgc * 64 + ct * 16 + 4 * g);
+                    if (ct < ctn) convStore<false>(a, acc[ct][m], opix, cbase + cgc * 64 + ct * 16 + 4 * g);
             }
         }
     };
 
     // the bias of a chunk (<= 128 floats) is one more LDS-DMA piece and the accumulators start from it: the wide epilogue then has
     // no load between its stores (a load after a store is awaited with vmcnt(0), i.e. behind the store's write acknowledgement)
-    const bool biasInit = a.wide && a.bias != nullptr;
+    const bool biasInit = a.bias != nullptr;                       // (the plugin pads the bias array with zeros to a whole float4)
     auto biasRequest = [&](int ch) {
         const int n0 = ch * CNB, sub = n0 / a.Cout, co = n0 - sub * a.Cout + lane * 4;
-        const void* src = (biasInit && lane < 32 && co + 3 < a.Cout) ? static_cast<const void*>(a.bias + co) : static_cast<const void*>(zeros);
+        const void* src = (biasInit && lane < 32 && co < a.Cout) ? static_cast<const void*>(a.bias + co) : static_cast<const void*>(zeros);
         __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + BIAS_OFF), 16, 0, 0);
     };
 
@@ -615,10 +616,10 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     // the chunk's bias (CT * 16 floats) travels as one more LDS-DMA piece and the accumulators start from it: the epilogue of a
     // layer without a residual then holds no load at all (a load issued after a store is awaited with vmcnt(0): gfx950 counts
     // loads and stores in one counter and hipcc cannot count across the two kinds)
-    const bool biasInit = a.wide && a.bias != nullptr;
+    const bool biasInit = a.bias != nullptr;                       // (the plugin pads the bias array with zeros to a whole float4)
     auto biasRequest = [&](int ch) {
         const int n0 = ch * CT * 16, sub = n0 / a.Cout, co = n0 - sub * a.Cout + lane * 4;
-        const void* src = (biasInit && lane < CT * 4 && co + 3 < a.Cout) ? static_cast<const void*>(a.bias + co) : static_cast<const void*>(zeros);
+        const void* src = (biasInit && lane < CT * 4 && co < a.Cout) ? static_cast<const void*>(a.bias + co) : static_cast<const void*>(zeros);
         __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + BIAS_OFF), 16, 0, 0);
     };
 
@@ -751,7 +752,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                     const size_t opix = (size_t)(oy * a.up + dy) * Wout + (ox * a.up + dx);
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
-                        if (ct < ctn) convStore(a, acc[ct][m], opix, cbase + ct * 16 + 4 * g);
+                        if (ct < ctn) convStore<false>(a, acc[ct][m], opix, cbase + ct * 16 + 4 * g);
                 }
             }
         }
@@ -868,8 +869,11 @@ public:
         for (size_t i = 0; i < nw; ++i) wh[i] = (_Float16)w_[i];
         ok_ = hipMalloc(&w_dev_, sizeof(_Float16) * nw) == hipSuccess &&
               hipMemcpy(w_dev_, wh.data(), sizeof(_Float16) * nw, hipMemcpyHostToDevice) == hipSuccess;
-        if (ok_ && b) ok_ = hipMalloc(&b_dev_, sizeof(float) * c.Cout) == hipSuccess &&
-                            hipMemcpy(b_dev_, b_.data(), sizeof(float) * c.Cout, hipMemcpyHostToDevice) == hipSuccess;
+        if (ok_ && b) {                      // zero padded to whole float4s: the halo kernels fetch the bias as 16-byte LDS-DMA lanes
+            const size_t nb = ((size_t)c.Cout + 3) / 4 * 4;
+            ok_ = hipMalloc(&b_dev_, sizeof(float) * nb) == hipSuccess && hipMemset(b_dev_, 0, sizeof(float) * nb) == hipSuccess &&
+                  hipMemcpy(b_dev_, b_.data(), sizeof(float) * c.Cout, hipMemcpyHostToDevice) == hipSuccess;
+        }
         if (ok_ && haloEligible()) {
             // [k-step q = (cc * taps + tap) * 2 + ks][16-channel tile ct][lane (r, g)][8] <- W[ct*16 + r][tap][cc*64 + ks*32 + g*8 + j];
             // one 16 KB slab of zero padding at the end: the last slab of a narrow layer is requested whole
