@@ -37,6 +37,8 @@ constexpr int MC = 192, MF = 384;                 // d_model, FFN width (include
 constexpr int MNT = MC / 16;                      // 12 column tiles
 constexpr int MNSTEP = MC / 32;                   // 6 k-steps per 192-wide slab
 constexpr int MROWS = 128;
+constexpr int MLP_SMALL_MAX = 8192;        // rows beyond one tile per CU that are cut into small workgroups
+constexpr int MLP_SW = 1;                  // waves of a small workgroup, 32 rows each (two waves: 53.6 vs 50.1 us at 34.5k rows)
 
 __device__ __forceinline__ float mlpGelu(float x) {
     const float B = 0.7978845608028654f, C = 0.035677408136300125f;
@@ -103,6 +105,7 @@ struct MlpStreamArgs {
     float* out; _Float16* out16;
     const uint32_t* count; int max_rows; float eps;
     unsigned long long* trace;                       // debugging: per-workgroup phase timestamps, or nullptr
+    int ncu;                                         // CUs of the device (tile plan, see the kernel)
     int dbg;                                         // timing ablations (wrong results): 1 no LN1, 2 no GELU, 4 no final LNs, 8 no stores, 16 no MFMA
 };
 
@@ -146,9 +149,21 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * SB + MP_FLOATS * 4];     // 78,848 B: two workgroups per CU
     const uint32_t cnt = *a.count;
     const int M = (int)(cnt < (uint32_t)a.max_rows ? cnt : (uint32_t)a.max_rows);
-    const int m0 = blockIdx.x * MROWS;
-    if (m0 >= M) return;
+    // Tile plan.  One 128-row workgroup per CU takes 41-45 us whatever the count; a CU that hosts two takes 58-62 us (measured,
+    // tools/mlp_rows.py), so 269 tiles on 256 CUs cost as much as 512.  When the rows just overflow one tile per CU, the overflow
+    // (<= MLP_SMALL_MAX rows) is cut into 32-row workgroups of ONE wave (the other waves exit): they stream the same weights but
+    // share a CU with a full workgroup at a fraction of its LDS / MFMA load.
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = (M + MROWS - 1) / MROWS, over = M - a.ncu * MROWS;
+    const bool plan = MT == 2 && T > a.ncu && over <= MLP_SMALL_MAX && !(a.dbg & 32);
+    const int FULL = plan ? a.ncu : T;
+    const bool small = (int)blockIdx.x >= FULL;
+    int m0 = blockIdx.x * MROWS;
+    if (small) {
+        m0 = FULL * MROWS + ((int)blockIdx.x - FULL) * 32 * MLP_SW;
+        if (wave >= MLP_SW) return;
+    }
+    if (m0 >= M) return;
     const int r = lane & 15, g = lane >> 4;
     int row[MT], rc[MT];
 #pragma unroll
@@ -161,6 +176,15 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
     auto mark = [&]() { if (a.trace && tid == 0 && nmark < 32) a.trace[blockIdx.x * 32 + nmark] = clock64(); ++nmark; };
     mark();
     auto request = [&](int s) {
+        if (small) {                                 // (MLP_SW waves share the SR rows)
+#pragma unroll
+            for (int j = 0; j < SR / MLP_SW; ++j) {
+                const int rw = wave + j * MLP_SW;
+                __builtin_amdgcn_global_load_lds((mlp_gsrc_t)(a.Wp + ((size_t)s * SR + rw) * 512 + lane * 8),
+                                                 (mlp_ldst_t)(lds + (s % 3) * SB + rw * 1024), 16, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < (SR + NW - 1) / NW; ++j) {
             const int rw = wave + j * NW;
@@ -172,7 +196,9 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
     // end of stage st: stage st+1 has landed (the younger requests of stage st+2 stay in flight), then the barrier
     auto stageEnd = [&](int st) {
         if (st + 2 < NST) {
-            if (NRW == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+            static_assert(SR == 24 && (MLP_SW == 1 || MLP_SW == 2), "a small workgroup's wave counts SR / MLP_SW requests per stage");
+            if (small) { if (MLP_SW == 1) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); }
+            else if (NRW == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
@@ -180,9 +206,10 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
         asm volatile("" ::: "memory");
     };
     request(0);
+    const int nwa = small ? MLP_SW : NW;             // waves that share the parameter pieces
 #pragma unroll
-    for (int j = 0; j < (MP_FLOATS / 256 + NW - 1) / NW; ++j) {
-        const int pr = wave + j * NW;
+    for (int j = 0; j < MP_FLOATS / 256; ++j) {
+        const int pr = wave + j * nwa;
         if (pr < MP_FLOATS / 256)
             __builtin_amdgcn_global_load_lds((mlp_gsrc_t)(a.params + pr * 256 + lane * 4), (mlp_ldst_t)(lds + 3 * SB + pr * 1024), 16, 0, 0);
     }
@@ -264,8 +291,8 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
             // last piece: nothing left to stream, so the parameters of the final LayerNorms (ln_g | ln_b, 4 x 192 floats each) take
             // the slot stage NST-3 has just left: the epilogue then reads them with ds_read, and its only global loads are x / xb
 #pragma unroll
-            for (int j = 0; j < (6 + NW - 1) / NW; ++j) {
-                const int pr = wave + j * NW;
+            for (int j = 0; j < 6; ++j) {
+                const int pr = wave + j * nwa;
                 if (pr < 6)
                     __builtin_amdgcn_global_load_lds((mlp_gsrc_t)((pr < 3 ? a.ln_g + pr * 256 : a.ln_b + (pr - 3) * 256) + lane * 4),
                                                      (mlp_ldst_t)(lds + (NST % 3) * SB + pr * 1024), 16, 0, 0);
@@ -457,7 +484,13 @@ public:
         }
         static int variant = -1;       // DSVT_MLP_VARIANT=2: 8 waves x 16 rows (<= 128 VGPRs, spills); default 4 waves x 32 rows
         if (variant < 0) { const char* e = getenv("DSVT_MLP_VARIANT"); variant = e ? atoi(e) : 1; }
-        const dim3 grid(cdiv(max_rows_, MROWS));
+        static int ncu = 0;
+        if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }
+        b.ncu = ncu;
+        const int over = max_rows_ - ncu * MROWS;
+        const int gsmall = over > 0 ? ncu + cdiv(over < MLP_SMALL_MAX ? over : MLP_SMALL_MAX, 32 * MLP_SW) : 0;
+        const int gfull = cdiv(max_rows_, MROWS);
+        const dim3 grid(gfull > gsmall ? gfull : gsmall);
         static unsigned long long* tr = nullptr; static int tron = -1;         // tools/trace_mlp.py
         if (tron < 0) { tron = getenv("DSVT_MLP_TRACE") ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 32 * 1024); }
         b.trace = tr;
