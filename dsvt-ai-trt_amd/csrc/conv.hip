@@ -802,6 +802,13 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
     static int dbgW = -1;
     if (dbgW < 0) { const char* e = getenv("DSVT_CONV_DBG"); dbgW = e ? atoi(e) : 0; }          // timing ablations only (wrong results)
     if (wideOn && a.KH == 3 && ctWide >= 4) {
+        // short K (the 64 -> 320 head stems: 9 slabs per item, the epilogue weighs as much as the MFMAs): 8-row x 128-channel tiles on
+        // four waves, two independent workgroups per CU, 2655 items: 116-122 vs 130 us (no gain on the K >= 1152 layers)
+        if (ctWide == 8 && (a.Cin <= 64 || wideOn == 6)) {
+            const int n8 = cdiv(a.Ho, 8) * tilesX * nchunk, grid = n8 < 2 * numCUs() ? n8 : 2 * numCUs();
+            hipLaunchKernelGGL((conv_wide_kernel<8, 4, 36, 2, 2>), dim3(grid), dim3(256), 0, stream, a, Wp, zeros, tilesX, n8, nchunk, dbgW);
+            return lastError();
+        }
         if (nwide >= numCUs() && wideOn != 4) {
             const int grid = numCUs();
             // (a third weight slab -- requests two slabs ahead -- measured 80.2 vs 82.6 us on the 128-channel layers, nothing elsewhere)

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libdsvt_hip.so")
+_SO = os.environ.get("DSVT_HIP_LIB") or os.path.join(_HERE, "libdsvt_hip.so")      # (DSVT_HIP_LIB: A/B runs against another build)
 
 FIELD_INT32, FIELD_FLOAT32 = 3, 5
 DT_FLOAT, DT_HALF, DT_INT32 = 0, 1, 3
