@@ -36,7 +36,7 @@ PEAK_F32_MATRIX_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Pe
 PEAK_F16_MATRIX_TFLOPS = 2500.0     # same guide: "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBS = 8000.0               # same guide: "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured float4 copy)
 N_POINTS = 180000
-PMC_FILE = "r01_j_pmc_traffic.json"
+PMC_FILE = "r01_m_pmc_traffic.json"
 FRAME_POOL = 4                      # distinct synthetic clouds cycled through by the steps
 
 
@@ -244,7 +244,7 @@ def main():
                                            "set_attention_f16_kernel" if f16 else "set_attention_kernel"),
                 "DsvtPosEmbedPlugin": ("posembed_batched_kernel (8 position-embedding MLPs, v_mfma_f32_16x16x32_f16)", "hbm", "posembed_batched_kernel"),
                 "DsvtPillarFeatureNetPlugin": ("pfn_kernel (both PFN layers + scatter-max, v_mfma_f32_16x16x4_f32 + 16x16x32_f16)", "mfma", "pfn_kernel"),
-                "DsvtConv2dPlugin": ("conv_halo_kernel / conv_f16_kernel (implicit GEMM, v_mfma_f32_16x16x32_f16)", "mfma", "conv_halo_kernelILi8ELi3ELi8")}
+                "DsvtConv2dPlugin": ("conv_wide_kernel / conv_halo_kernel / conv_f16_kernel (implicit GEMM, v_mfma_f32_16x16x32_f16)", "mfma", "conv_wide_kernelILi8ELi8")}
         for ptype, lst in prof.items():
             if not lst:
                 continue
