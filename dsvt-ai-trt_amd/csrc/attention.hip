@@ -229,12 +229,13 @@ set_attention_f16_kernel(AttnArgs a)
         int h = tid / AL, k = tid % AL;
         sMask[h][k] = a.mask[(size_t)set * a.mask_set_stride + (size_t)(hq * AHB + h) * a.mask_head_stride + k];
     }
-    for (int i = tid; i < AHB * ADH * AVL / 2; i += 256) reinterpret_cast<uint32_t*>(sVt)[i] = 0u;     // padded keys must be finite
-    __syncthreads();
     // ---- stage the 36 gathered rows: Q, K as rows, V transposed -------------------------------------
+    // (every thread reads its slot's row index itself: no LDS round trip + barrier between the index and the row loads; the
+    // key columns 36..63 of sVt stay unwritten -- their B fragments are zeroed in registers below)
     for (int i = tid; i < AL * 3 * 12; i += 256) {
         const int slot = i / 36, rem = i % 36, seg = rem / 12, c8 = (rem % 12) * 8;
-        const _Float16* src = static_cast<const _Float16*>(a.qkv) + (size_t)sRow[slot] * a.qkv_ld + seg * a.C + hq * (AHB * ADH) + c8;
+        const uint32_t rowi = a.inds ? a.inds[(size_t)set * AL + slot] : (uint32_t)(set * AL + slot);
+        const _Float16* src = static_cast<const _Float16*>(a.qkv) + (size_t)rowi * a.qkv_ld + seg * a.C + hq * (AHB * ADH) + c8;
         const ahalf8 v = *reinterpret_cast<const ahalf8*>(src);
         if (seg == 0) *reinterpret_cast<ahalf8*>(&sQ[slot * AQL + c8]) = v;
         else if (seg == 1) *reinterpret_cast<ahalf8*>(&sK[slot * AQL + c8]) = v;
@@ -306,7 +307,7 @@ set_attention_f16_kernel(AttnArgs a)
         const ahalf4 v0 = *reinterpret_cast<const ahalf4*>(pv), v1 = *reinterpret_cast<const ahalf4*>(pv + 16), v2 = *reinterpret_cast<const ahalf4*>(pv + 32);
         ahalf8 b0 = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         ahalf8 b1 = {v2[0], v2[1], v2[2], v2[3], 0, 0, 0, 0};
-        vb[dt][0] = dv ? b0 : zero8; vb[dt][1] = dv ? b1 : zero8;
+        vb[dt][0] = dv ? b0 : zero8; vb[dt][1] = (dv && g == 0) ? b1 : zero8;      // keys 32 + 4g + i: only g = 0 is real (and staged)
     }
     floatx4 oc[3][2];
 #pragma unroll
@@ -315,24 +316,28 @@ set_attention_f16_kernel(AttnArgs a)
 #pragma unroll
         for (int i = 0; i < 4; ++i) { p0[i] = (_Float16)sc[0][u][i]; p0[4 + i] = (_Float16)sc[1][u][i]; p1[i] = (_Float16)sc[2][u][i]; p1[4 + i] = (_Float16)0.f; }
 #pragma unroll
+        // O^T = V^T P^T (V^T as the A operand): the lane of query r then holds FOUR consecutive channels 16 dt + 4 g + i, an
+        // 8-byte store, instead of one channel of four queries (24 two-byte stores per lane)
         for (int dt = 0; dt < 2; ++dt) {
-            oc[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p0, vb[dt][0], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            oc[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p1, vb[dt][1], oc[u][dt], 0, 0, 0);
+            oc[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[dt][0], p0, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            oc[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[dt][1], p1, oc[u][dt], 0, 0, 0);
         }
     }
-    // ---- write back: lane holds queries 16u + 4g + i, channels 16dt + r -------------------------
+    // ---- write back: lane holds query 16u + r, channels 16dt + 4g + i -------------------------
     const int h = hq * AHB + wave;
 #pragma unroll
-    for (int u = 0; u < 3; ++u)
+    for (int u = 0; u < 3; ++u) {
+        const int q = 16 * u + r;
+        if (q >= AL) continue;
+        if (a.inds && sMask[wave][q] < 0.f) continue;      // duplicate slot: the first occurrence writes the identical row
+        _Float16* dst = static_cast<_Float16*>(a.out) + (size_t)sRow[q] * a.out_ld + h * ADH + 4 * g;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int q = 16 * u + 4 * g + i;
-            if (q >= AL) continue;
-            if (a.inds && sMask[wave][q] < 0.f) continue;      // duplicate slot: the first occurrence writes the identical row
-            _Float16* dst = static_cast<_Float16*>(a.out) + (size_t)sRow[q] * a.out_ld + h * ADH;
-            dst[r] = (_Float16)oc[u][0][i];
-            if (16 + r < ADH) dst[16 + r] = (_Float16)oc[u][1][i];
+        for (int dt = 0; dt < 2; ++dt) {
+            if (16 * dt + 4 * g >= ADH) continue;
+            ahalf4 o4 = {(_Float16)oc[u][dt][0], (_Float16)oc[u][dt][1], (_Float16)oc[u][dt][2], (_Float16)oc[u][dt][3]};
+            *reinterpret_cast<ahalf4*>(dst + 16 * dt) = o4;
         }
+    }
 }
 
 static int launchAttention(const AttnArgs& a, bool io16, hipStream_t stream) {
