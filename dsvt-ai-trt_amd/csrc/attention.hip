@@ -206,14 +206,15 @@ set_attention_kernel(AttnArgs a)
 typedef _Float16 ahalf8 __attribute__((ext_vector_type(8)));
 typedef _Float16 ahalf4 __attribute__((ext_vector_type(4)));
 constexpr int AQL = 104;      // halfs per staged Q / K row
-constexpr int AVL = 72;       // halfs per staged V^T row (64 keys + 8)
+constexpr int AVL = 40;       // halfs per staged V^T row (36 keys + 4: 80-byte rows, conflict-free 8-byte fragment reads; the reads of
+                              // keys >= 40 -- lane groups g >= 2 of the third key tile -- run into the next row and are discarded)
 
 __global__ void __launch_bounds__(256)
 set_attention_f16_kernel(AttnArgs a)
 {
     __shared__ __attribute__((aligned(16))) _Float16 sQ[AL * AQL];
     __shared__ __attribute__((aligned(16))) _Float16 sK[AL * AQL];
-    __shared__ __attribute__((aligned(16))) _Float16 sVt[AHB * ADH * AVL];
+    __shared__ __attribute__((aligned(16))) _Float16 sVt[AHB * ADH * AVL + 16];      // 23.4 KB in all: seven workgroups per CU
     __shared__ uint32_t sRow[AL];
     __shared__ float sMask[AHB][AL];
 
