@@ -114,6 +114,31 @@ __device__ __forceinline__ void linearEpilogue(floatx4 (&acc)[NT], const LinearA
             }
         }
     }
+    // wide stores: v_permlane16_swap exchanges the odd 16-lane rows of tile t with the even rows of tile t + 1, after which the lane of
+    // row r holds EIGHT consecutive columns n0 + 16 t + 16 (g & 1) + 8 (g >> 1): 16-byte fp16 / 2 x 16-byte fp32 stores, half as many
+    if ((N & 15) == 0 && (a.out_ld & 7) == 0 && !(NT & 1)) {
+#pragma unroll
+        for (int t = 0; t < NT; t += 2) {
+            floatx4 X = acc[t], Y = acc[t + 1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(X[i]), __float_as_uint(Y[i]), false, false);
+                X[i] = __uint_as_float(sw[0]); Y[i] = __uint_as_float(sw[1]);
+            }
+            const int col = n0 + t * 16 + (g & 1) * 16 + (g >> 1) * 8;
+            if (!valid || col >= N) continue;
+            if (a.out) {
+                float* o = a.out + (size_t)row * a.out_ld + col;
+                *reinterpret_cast<float4*>(o) = make_float4(X[0], X[1], X[2], X[3]);
+                *reinterpret_cast<float4*>(o + 4) = make_float4(Y[0], Y[1], Y[2], Y[3]);
+            }
+            if (a.out16) {
+                half8 h = {(_Float16)X[0], (_Float16)X[1], (_Float16)X[2], (_Float16)X[3], (_Float16)Y[0], (_Float16)Y[1], (_Float16)Y[2], (_Float16)Y[3]};
+                *reinterpret_cast<half8*>(a.out16 + (size_t)row * a.out_ld + col) = h;
+            }
+        }
+        return;
+    }
     if (!valid) return;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
