@@ -385,13 +385,22 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
     for (int mt = 0; mt < MT; ++mt) {
         int rw = row[mt];
         asm volatile("" : "+v"(rw));                 // (the store addresses are formed here, not kept alive through the streaming loop)
-        if (rw < M && !(a.dbg & 8)) {
+        // wide stores (see linearEpilogue): after v_permlane16_swap of tiles t, t + 1 the lane of row r holds 8 consecutive columns
 #pragma unroll
-            for (int t = 0; t < MNT; ++t) {
-                const int col = t * 16 + 4 * g;
-                *reinterpret_cast<float4*>(a.out + (size_t)rw * MC + col) = make_float4(acc[mt][t][0], acc[mt][t][1], acc[mt][t][2], acc[mt][t][3]);
-                half4 h; h[0] = (_Float16)acc[mt][t][0]; h[1] = (_Float16)acc[mt][t][1]; h[2] = (_Float16)acc[mt][t][2]; h[3] = (_Float16)acc[mt][t][3];
-                *reinterpret_cast<half4*>(a.out16 + (size_t)rw * MC + col) = h;
+        for (int t = 0; t < MNT; t += 2) {
+            floatx4 X = acc[mt][t], Y = acc[mt][t + 1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(X[i]), __float_as_uint(Y[i]), false, false);
+                X[i] = __uint_as_float(sw[0]); Y[i] = __uint_as_float(sw[1]);
+            }
+            if (rw < M && !(a.dbg & 8)) {
+                const int col = t * 16 + (g & 1) * 16 + (g >> 1) * 8;
+                float* o = a.out + (size_t)rw * MC + col;
+                *reinterpret_cast<float4*>(o) = make_float4(X[0], X[1], X[2], X[3]);
+                *reinterpret_cast<float4*>(o + 4) = make_float4(Y[0], Y[1], Y[2], Y[3]);
+                half8 h = {(_Float16)X[0], (_Float16)X[1], (_Float16)X[2], (_Float16)X[3], (_Float16)Y[0], (_Float16)Y[1], (_Float16)Y[2], (_Float16)Y[3]};
+                *reinterpret_cast<half8*>(a.out16 + (size_t)rw * MC + col) = h;
             }
         }
     }
