@@ -213,7 +213,8 @@ def main():
                 esz = 2 if f.get("input_half") else 4
                 out_b = {0: 4, 1: 2, 2: 6}[f.get("output_mode", 0)]
                 return (2.0 * rows * K_ * N_,
-                        rows * (K_ * esz * (2 if f.get("add_cols") else 1) + 4 * N_ * f.get("num_layer_norms", 0) + out_b * N_)
+                        rows * (K_ * esz * (2 if (f.get("add_cols") and not f.get("add_gather_width")) else 1) + 12 * bool(f.get("add_gather_width"))
+                                + 4 * N_ * f.get("num_layer_norms", 0) + out_b * N_)
                         + K_ * N_ * (2 if f16 else 4))
             if pl.plugin_type == "DsvtEncoderMlpPlugin":
                 rows = c["P"]                   # att16 + x (+ xb) in, x' fp32 + fp16 out, weights once

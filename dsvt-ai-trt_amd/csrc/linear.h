@@ -23,6 +23,9 @@ struct LinearArgs {
     // but computed on the fly, A'[m][k] = relu(pe_xy[m][0] * pe_w0[k] + pe_xy[m][1] * pe_w1[k] + pe_b[k])  -- the first
     // FC + BN + ReLU of fullyConnectedBnLELU_fullyConnected (src/dsvt-ai-trt.cpp:461-492), K = 2
     const float* pe_xy; const float* pe_w0; const float* pe_w1; const float* pe_b;
+    // gathered A2 (streamed fp16 kernel only): when a2_c2d != nullptr row m adds A2 row c2d[m][1] * a2_wx + c2d[m][2] (the window
+    // cell of voxel m, WindowPartition output 4) instead of A2 row m: A2 is then a per-layer TABLE of position embeddings
+    const int32_t* a2_c2d; int a2_wx;
     float eps;
     unsigned long long* trace;    // debugging: per-workgroup phase timestamps (s_memtime) of the streamed kernel, or nullptr
 };

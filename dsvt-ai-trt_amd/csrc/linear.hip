@@ -278,16 +278,20 @@ __device__ __forceinline__ half8 toHalf8(float4 x, float4 y) {
 
 // B-operand fragment (8 consecutive k of one activation row) straight from global memory
 template <bool AHALF, bool ADD>
-__device__ __forceinline__ half8 loadFrag(const void* A, const void* A2, size_t off) {
+__device__ __forceinline__ half8 loadFrag(const void* A, const void* A2, size_t off, size_t off2);
+template <bool AHALF, bool ADD>
+__device__ __forceinline__ half8 loadFrag(const void* A, const void* A2, size_t off) { return loadFrag<AHALF, ADD>(A, A2, off, off); }
+template <bool AHALF, bool ADD>
+__device__ __forceinline__ half8 loadFrag(const void* A, const void* A2, size_t off, size_t off2) {
     if (AHALF) {
         half8 v = *reinterpret_cast<const half8*>(static_cast<const _Float16*>(A) + off);
-        if (ADD) v += *reinterpret_cast<const half8*>(static_cast<const _Float16*>(A2) + off);
+        if (ADD) v += *reinterpret_cast<const half8*>(static_cast<const _Float16*>(A2) + off2);
         return v;
     } else {
         const float* p = static_cast<const float*>(A) + off;
         float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
         if (ADD) {
-            const float* q = static_cast<const float*>(A2) + off;
+            const float* q = static_cast<const float*>(A2) + off2;
             const float4 u = *reinterpret_cast<const float4*>(q), w = *reinterpret_cast<const float4*>(q + 4);
             x.x += u.x; x.y += u.y; x.z += u.z; x.w += u.w; y.x += w.x; y.y += w.y; y.z += w.z; y.w += w.w;
         }
@@ -462,8 +466,13 @@ __device__ __forceinline__ void linearStreamBody(const LinearArgs a, const _Floa
         for (int mt = 0; mt < MT; ++mt) {
             const size_t o = (size_t)rc[mt] * KS + g * 8;
             if (withA2) {
+                size_t o2 = o;
+                if (a.a2_c2d) {                          // table row = window cell of this voxel
+                    const int32_t* c = a.a2_c2d + (size_t)rc[mt] * 3;
+                    o2 = (size_t)(c[1] * a.a2_wx + c[2]) * KS + g * 8;
+                }
 #pragma unroll
-                for (int s = 0; s < NSTEP; ++s) f[mt][s] = loadFrag<AMODE == 1, true>(a.A, a.A2, o + s * 32);
+                for (int s = 0; s < NSTEP; ++s) f[mt][s] = loadFrag<AMODE == 1, true>(a.A, a.A2, o + s * 32, o2 + s * 32);
             } else {
 #pragma unroll
                 for (int s = 0; s < NSTEP; ++s) f[mt][s] = loadFrag<AMODE == 1, false>(a.A, nullptr, o + s * 32);
@@ -604,6 +613,7 @@ struct LinCfg {
     int compute_type;      // 0: fp32 MFMA (exact fp32 products)   1: fp16 MFMA operands, fp32 accumulate
     int input_half;        // A / A2 tensors are fp16 (needs compute_type 1)
     int output_mode;       // OUT_F32: one fp32 output; OUT_F16: one fp16 output; OUT_BOTH: fp32 + fp16 copy
+    int a2_gather_wx;      // > 0: input 2 is a [cells, K] table and input 3 the [rows, 3] window coordinates (z, y, x); row m adds table row y * wx + x
 };
 
 class DsvtLinearPlugin : public Plugin {
@@ -667,6 +677,7 @@ public:
         if (pos == 1) return io[pos].type == DSVT_INT32;
         if (pos == 0 && !pe_.empty()) return io[pos].type == DSVT_FLOAT;        // the [rows, 2] xy tensor
         if (pos == 0 || (pos == 2 && c_.add_cols > 0)) return io[pos].type == (c_.input_half ? DSVT_HALF : DSVT_FLOAT);
+        if (pos == 3 && c_.a2_gather_wx > 0) return io[pos].type == DSVT_INT32;
         if (pos < nbIn) return io[pos].type == DSVT_FLOAT;                      // residuals
         return io[pos].type == outputType(pos - nbIn, nullptr, 0);
     }
@@ -683,6 +694,7 @@ public:
         }
         a.count = static_cast<const uint32_t*>(in[idx++]);
         a.A2 = c_.add_cols > 0 ? in[idx++] : nullptr;
+        if (c_.a2_gather_wx > 0) { a.a2_c2d = static_cast<const int32_t*>(in[idx++]); a.a2_wx = c_.a2_gather_wx; }
         for (int s = 0; s < c_.n_ln; ++s) {
             a.res[s] = static_cast<const float*>(in[idx++]);
             a.gamma[s] = g_dev_ + (size_t)s * c_.N; a.beta[s] = be_dev_ + (size_t)s * c_.N;
@@ -696,6 +708,7 @@ public:
             if (a.out) DSVT_CHECK(hipMemsetAsync(a.out, 0, sizeof(float) * (size_t)c_.max_rows * c_.N, stream));
             if (a.out16) DSVT_CHECK(hipMemsetAsync(a.out16, 0, sizeof(_Float16) * (size_t)c_.max_rows * c_.N, stream));
         }
+        if (c_.a2_gather_wx > 0 && !wp_dev_) return -4;           // the table gather lives in the streamed kernel only
         if (wp_dev_) {
             static unsigned long long* tr = nullptr; static int tron = -1;
             if (tron < 0) { tron = getenv("DSVT_LINEAR_TRACE") ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 8 * 4096); }
@@ -713,13 +726,13 @@ public:
         return useF16() ? launchLinearF16(a, wh_dev_, stream) : launchLinearF32(a, stream);
     }
     size_t serializationSize() const override {
-        return 12 * sizeof(int) + sizeof(float) + sizeof(float) * (w_.size() + b_.size() + g_.size() + be_.size() + pe_.size());
+        return 13 * sizeof(int) + sizeof(float) + sizeof(float) * (w_.size() + b_.size() + g_.size() + be_.size() + pe_.size());
     }
     void serialize(void* buf) const override {
         char* d = static_cast<char*>(buf);
         wr<int>(d, c_.max_rows); wr<int>(d, c_.K); wr<int>(d, c_.N); wr<int>(d, c_.row_mult); wr<int>(d, c_.act); wr<int>(d, c_.add_cols);
         wr<int>(d, c_.n_ln); wr<float>(d, c_.eps); wr<int>(d, b_.empty() ? 0 : 1); wr<int>(d, c_.compute_type);
-        wr<int>(d, c_.input_half); wr<int>(d, c_.output_mode); wr<int>(d, pe_.empty() ? 0 : 1);
+        wr<int>(d, c_.input_half); wr<int>(d, c_.output_mode); wr<int>(d, pe_.empty() ? 0 : 1); wr<int>(d, c_.a2_gather_wx);
         for (const std::vector<float>* v : {&w_, &b_, &g_, &be_, &pe_}) { memcpy(d, v->data(), sizeof(float) * v->size()); d += sizeof(float) * v->size(); }
     }
     Plugin* clone() const override {
@@ -739,6 +752,7 @@ static Plugin* linNew(const LinCfg& c, const float* w, const float* b, const flo
     if (c.n_ln > 0 && (c.N > BN || !g || !be)) return nullptr;             // a LayerNorm row must fit one tile
     if (c.add_cols < 0 || c.add_cols > c.N || (c.add_cols % BN != 0 && c.add_cols != c.N)) return nullptr;
     if (c.input_half && !(c.compute_type == 1 && c.K % KS == 0)) return nullptr;      // fp16 inputs only on the fp16 kernel
+    if (c.a2_gather_wx < 0 || (c.a2_gather_wx > 0 && !(c.add_cols > 0 && c.input_half && c.K == KS))) return nullptr;   // table gather: streamed fp16 kernel
     return new DsvtLinearPlugin(c, w, b, g, be, pe_w, pe_b);
 }
 static Plugin* linCreate(const DsvtPluginFieldCollection* fc) {
@@ -749,6 +763,7 @@ static Plugin* linCreate(const DsvtPluginFieldCollection* fc) {
     c.row_mult = fieldInt(fc, "row_mult", 1); c.act = fieldInt(fc, "activation"); c.add_cols = fieldInt(fc, "add_cols");
     c.n_ln = fieldInt(fc, "num_layer_norms"); c.eps = fieldFloat(fc, "ln_eps", 0.f); c.compute_type = fieldInt(fc, "compute_type", 0);
     c.input_half = fieldInt(fc, "input_half", 0); c.output_mode = fieldInt(fc, "output_mode", 0);
+    c.a2_gather_wx = fieldInt(fc, "add_gather_width", 0);
     if (!w || !w->data || c.K <= 0 || c.N <= 0 || w->length != c.K * c.N) return nullptr;
     if (b && b->data && b->length != c.N) return nullptr;
     if (c.n_ln > 0 && (!g || !be || g->length != c.n_ln * c.N || be->length != c.n_ln * c.N)) return nullptr;
@@ -759,15 +774,15 @@ static Plugin* linCreate(const DsvtPluginFieldCollection* fc) {
                   (pw && pw->data) ? static_cast<const float*>(pw->data) : nullptr, (pb && pb->data) ? static_cast<const float*>(pb->data) : nullptr);
 }
 static Plugin* linDeser(const void* data, size_t len) {
-    if (len < 12 * sizeof(int) + sizeof(float)) return nullptr;
+    if (len < 13 * sizeof(int) + sizeof(float)) return nullptr;
     const char* d = static_cast<const char*>(data);
     LinCfg c{};
     c.max_rows = rd<int>(d); c.K = rd<int>(d); c.N = rd<int>(d); c.row_mult = rd<int>(d); c.act = rd<int>(d); c.add_cols = rd<int>(d);
     c.n_ln = rd<int>(d); c.eps = rd<float>(d); int has_b = rd<int>(d); c.compute_type = rd<int>(d);
-    c.input_half = rd<int>(d); c.output_mode = rd<int>(d); int has_pe = rd<int>(d);
+    c.input_half = rd<int>(d); c.output_mode = rd<int>(d); int has_pe = rd<int>(d); c.a2_gather_wx = rd<int>(d);
     if (c.K <= 0 || c.N <= 0 || c.n_ln < 0 || c.n_ln > 3) return nullptr;
     size_t need = (size_t)c.K * c.N + (has_b ? c.N : 0) + 2 * (size_t)c.n_ln * c.N + (has_pe ? 3 * (size_t)c.K : 0);
-    if (len < 12 * sizeof(int) + sizeof(float) + need * sizeof(float)) return nullptr;
+    if (len < 13 * sizeof(int) + sizeof(float) + need * sizeof(float)) return nullptr;
     std::vector<float> all(need);
     memcpy(all.data(), d, need * sizeof(float));
     const float* w = all.data(); const float* b = has_b ? w + (size_t)c.K * c.N : nullptr;
@@ -784,7 +799,7 @@ static Creator g_linCreator{"DsvtLinearPlugin",
     {{"max_rows", DSVT_FIELD_INT32}, {"in_features", DSVT_FIELD_INT32}, {"out_features", DSVT_FIELD_INT32},
      {"row_mult", DSVT_FIELD_INT32}, {"activation", DSVT_FIELD_INT32}, {"add_cols", DSVT_FIELD_INT32},
      {"num_layer_norms", DSVT_FIELD_INT32}, {"ln_eps", DSVT_FIELD_FLOAT32}, {"compute_type", DSVT_FIELD_INT32},
-     {"input_half", DSVT_FIELD_INT32}, {"output_mode", DSVT_FIELD_INT32},
+     {"input_half", DSVT_FIELD_INT32}, {"output_mode", DSVT_FIELD_INT32}, {"add_gather_width", DSVT_FIELD_INT32},
      {"weight", DSVT_FIELD_FLOAT32}, {"bias", DSVT_FIELD_FLOAT32}, {"ln_weights", DSVT_FIELD_FLOAT32}, {"ln_bias", DSVT_FIELD_FLOAT32},
      {"pe_weight", DSVT_FIELD_FLOAT32}, {"pe_bias", DSVT_FIELD_FLOAT32}},
     linCreate, linDeser, {}, {}};

@@ -67,7 +67,7 @@ def fold_linear_bn(w, lin, bn, eps, bias=False):
 class DsvtPipeline:
     def __init__(self, weights, caps=None, blocks=4, with_head=True, ln_eps=0.0, head_dtype=torch.float32,
                  device="cuda:0", zero_fill=False, linear_compute=P.COMPUTE_F32, hip_head=None, fused_mlp=None,
-                 device_nms=False):
+                 device_nms=False, pos_table=None):
         """linear_compute: COMPUTE_F32 = fp32 MFMA everywhere (parity mode, boxes within 1e-3 of the
         fp32 oracle); COMPUTE_F16 = fp16 MFMA operands with fp32 accumulate/epilogues (BASELINE
         configs[2] "fp16").  head_dtype: precision of the dense BEV stage.  hip_head: run the BEV ResNet +
@@ -81,6 +81,9 @@ class DsvtPipeline:
         zf = lambda op: op.set_zero_fill(zero_fill)
         ct = dict(compute_type=linear_compute)
         self.f16 = f16 = linear_compute == P.COMPUTE_F16
+        # fp16 mode: the position embedding of a voxel depends only on its cell inside the window (144 / 576 cells), so each layer's
+        # embedding is a TABLE computed once at construction; the QKV linear adds table row y * wx + x in its A prologue
+        self.pos_table = f16 if pos_table is None else (pos_table and f16)
         self.fused_mlp = f16 if fused_mlp is None else (fused_mlp and f16)      # out-proj -> FC1 -> FC2 in one launch (csrc/mlp.hip)
         # fp16 mode: GEMM operands travel as fp16 (x16, pos16, qkv, att, h); the residual stream that feeds the
         # LayerNorms stays fp32 (the LayerNorm epilogues write both copies)
@@ -126,7 +129,8 @@ class DsvtPipeline:
                                  w[f"module.backbone_3d.residual_norm_stage_0.{b}.bias"]))
                 if self.fused_mlp:
                     self.layers[(b, l)] = L_ = dict(
-                        qkv=zf(P.add_linear_op(wi, bi, c.P, add_cols=2 * C, **ct, **h_in, **o16)),
+                        qkv=zf(P.add_linear_op(wi, bi, c.P, add_cols=2 * C, **ct, **h_in, **o16,
+                                               add_gather_width=WINS[l][0][0] if self.pos_table else 0)),
                         attn=zf(P.add_set_attention_op(c.W, L_SET, C, H, l, c.P, io_half=f16)),
                         mlp=zf(P.add_encoder_mlp_op(w[lp + ".win_attn.self_attn.out_proj.weight"], w[lp + ".win_attn.self_attn.out_proj.bias"],
                                                     w[lp + ".win_attn.linear1.weight"], w[lp + ".win_attn.linear1.bias"],
@@ -155,6 +159,23 @@ class DsvtPipeline:
                 pes.append((Wa, ba, w[pre + ".3.weight"], w[pre + ".3.bias"]))
             self.pe_all = zf(P.add_pos_embed_op(c.P, [l for (_, l) in keys], [p_[0] for p_ in pes], [p_[1] for p_ in pes],
                                                 [p_[2] for p_ in pes], [p_[3] for p_ in pes]))
+            self.pos_tables = None
+            if self.pos_table and self.fused_mlp:
+                # one launch of the same kernel over the cell grids of the two window shapes: table[(b, l)][y * wx + x] = MLP(x - wx/2, y - wy/2)
+                ncell = max(w_[0][0] * w_[0][1] for w_ in WINS)
+                tab = P.add_pos_embed_op(ncell, [l for (_, l) in keys], [p_[0] for p_ in pes], [p_[1] for p_ in pes],
+                                         [p_[2] for p_ in pes], [p_[3] for p_ in pes])
+                grids = []
+                for (wx, wy, _), _s in WINS:
+                    g = torch.zeros((1, ncell, 2), dtype=torch.float32)
+                    yy, xx = torch.meshgrid(torch.arange(wy), torch.arange(wx), indexing="ij")
+                    g[0, :wx * wy, 0] = xx.reshape(-1).float() - wx / 2
+                    g[0, :wx * wy, 1] = yy.reshape(-1).float() - wy / 2
+                    grids.append(g.to(self.device))
+                outs = tab(torch.tensor([ncell], dtype=torch.int32, device=self.device), *grids)
+                torch.cuda.synchronize(self.device)
+                self.pos_tables = {k: outs[i].clone() for i, k in enumerate(keys)}
+                self.pe_all = None
         self.cat = torch.zeros((1, c.Nk, 192), dtype=torch.float32, device=self.device)
         if with_head:
             self.map2bev = P.add_map_2_bev_op(c.P, C, GX, GY)
@@ -331,6 +352,7 @@ class DsvtPipeline:
     def backbone(self, st, trace=None):
         Pn = st["P"]
         x = st["vfeat"]
+        tables = getattr(self, "pos_tables", None)
         pos_all = self.pe_all(Pn, st["wps"][0][5], st["wps"][1][5]) if self.pe_all is not None else None
         xh = st.get("vfeat16") if self.f16 else x           # GEMM-operand copy of the residual stream
         if xh is None:
@@ -341,11 +363,20 @@ class DsvtPipeline:
             for l in range(2):
                 a, fc = self.pe[(b, l)]
                 xy = st["wps"][l][5]                                  # pos-embed input = window config l (:603-637)
-                if pos_all is not None:
+                if tables is not None:
+                    pos = None
+                elif pos_all is not None:
                     pos = pos_all[2 * b + l]
                 else:
                     pos = fc(xy, Pn)[0] if a is None else fc(a(xy, Pn)[0], Pn)[0]
                 L = self.layers[(b, l)]
+                if tables is not None:
+                    qkv = L["qkv"](xh, Pn, tables[(b, l)], st["wps"][l][4])[0]
+                    att = L["attn"](qkv, inds, mask, S)[0]
+                    x, xh = L["mlp"](att, Pn, x, xb) if l == 1 else L["mlp"](att, Pn, x)
+                    if trace is not None:
+                        trace[(b, l)] = x.clone()
+                    continue
                 qkv = L["qkv"](xh, Pn, pos)[0]
                 att = L["attn"](qkv, inds, mask, S)[0]
                 if self.fused_mlp:

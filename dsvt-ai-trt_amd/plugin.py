@@ -458,16 +458,18 @@ OUT_F32, OUT_F16, OUT_BOTH = 0, 1, 2
 
 
 def add_linear_op(weight, bias, max_rows, row_mult=1, activation=ACT_NONE, add_cols=0, layer_norms=(), ln_eps=0.0,
-                  compute_type=COMPUTE_F32, input_half=False, output_mode=OUT_F32, pe_weight=None, pe_bias=None):
+                  compute_type=COMPUTE_F32, input_half=False, output_mode=OUT_F32, pe_weight=None, pe_bias=None, add_gather_width=0):
     """FC with fused prologue/epilogue (csrc/linear.hip), used where the reference calls
     addFullyConnected (src/dsvt-ai-trt.cpp:283,476,490,506,525) + ElementWise/LayerNorm/GELU.
     Inputs: A [1,rows,K], count [1], (A2 if add_cols), then one residual per LayerNorm stage.
-    layer_norms: sequence of (gamma, beta)."""
+    layer_norms: sequence of (gamma, beta).
+    add_gather_width = wx > 0: A2 is a [1, cells, K] table and one more input follows it, the [1, rows, 3] window coordinates
+    (z, y, x) of WindowPartition (output 4); row m adds table row y * wx + x."""
     weight = np.asarray(weight, np.float32)
     N, K = weight.shape
     fields = dict(max_rows=max_rows, in_features=K, out_features=N, row_mult=row_mult, activation=activation,
                   add_cols=add_cols, num_layer_norms=len(layer_norms), ln_eps=float(ln_eps), compute_type=compute_type,
-                  input_half=int(bool(input_half)), output_mode=output_mode, weight=weight.reshape(-1))
+                  input_half=int(bool(input_half)), output_mode=output_mode, add_gather_width=int(add_gather_width), weight=weight.reshape(-1))
     if bias is not None:
         fields["bias"] = np.asarray(bias, np.float32).reshape(-1)
     if pe_weight is not None:      # fused K_in = 2 first FC (+BN, ReLU) of the position-embedding MLP: input 0 becomes xy [1,rows,2]

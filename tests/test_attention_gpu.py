@@ -240,3 +240,29 @@ def test_batched_pos_embed_equals_per_layer_launches(pkg):
         ref = P.add_linear_op(Wb[l], bb[l], MR, compute_type=P.COMPUTE_F16, output_mode=P.OUT_F16, pe_weight=Wa[l], pe_bias=ba[l])(dx[src[l]], cnt)[0]
         assert torch.equal(outs[l], ref)
         assert not outs[l][0, n:].any()
+
+
+def test_qkv_position_table_gather(pkg):
+    """QKV linear with add_gather_width: q = k = (x + table[y * wx + x_cell]) W^T, bit-identical to the same op fed the gathered
+    position rows as a full [rows, K] tensor (the table is what the position-embedding MLP yields on the window's cell grid)."""
+    DEV = "cuda:0"
+    P = pkg.plugin
+    rng = np.random.default_rng(5)
+    MR, n, C, wx, wy = 4096, 3000, 192, 24, 24
+    x = torch.from_numpy(rng.standard_normal((1, MR, C)).astype(np.float32)).half().to(DEV)
+    table = torch.from_numpy(rng.standard_normal((1, wx * wy, C)).astype(np.float32)).half().to(DEV)
+    c2d = np.zeros((1, MR, 3), np.int32)
+    c2d[0, :, 1] = rng.integers(0, wy, MR); c2d[0, :, 2] = rng.integers(0, wx, MR)
+    cell = c2d[0, :, 1] * wx + c2d[0, :, 2]
+    pos = table[0][torch.from_numpy(cell).to(DEV).long()][None].contiguous()
+    W = (rng.standard_normal((3 * C, C)) / np.sqrt(C)).astype(np.float32); b = (rng.standard_normal(3 * C) * 0.1).astype(np.float32)
+    kw = dict(add_cols=2 * C, compute_type=P.COMPUTE_F16, input_half=True, output_mode=P.OUT_F16)
+    cnt = torch.tensor([n], dtype=torch.int32, device=DEV)
+    ref = P.add_linear_op(W, b, MR, **kw)(x, cnt, pos)[0]
+    op = P.add_linear_op(W, b, MR, add_gather_width=wx, **kw)
+    got = op(x, cnt, table, torch.from_numpy(c2d).to(DEV))[0]
+    torch.cuda.synchronize()
+    assert torch.equal(got[0, :n], ref[0, :n])
+    again = P.Plugin.deserialize("DsvtLinearPlugin", op.serialize())(x, cnt, table, torch.from_numpy(c2d).to(DEV))[0]
+    torch.cuda.synchronize()
+    assert torch.equal(again[0, :n], ref[0, :n])
