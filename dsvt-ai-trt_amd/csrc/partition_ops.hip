@@ -129,11 +129,51 @@ wp_fill(const uint4* __restrict__ coords, WPParams p, const uint32_t* __restrict
     const uint32_t r = blockIdx.x;
     if (r >= *win_num) return;
     const uint32_t w = rank2win[r], n = win_cnt[w], seg = win_seg[w];
-    int m = 1; while ((uint32_t)m < n) m <<= 1;
-    for (int i = threadIdx.x; i < m; i += blockDim.x) lds[i] = (uint32_t)i < n ? sorted_vox[seg + i] : kNoneU;
-    __syncthreads();
-    bitonicSortLds(lds, m);
     const uint32_t Vw = p.max_voxel_num_per_win;
+    // Voxel ids ascend with the cell key y * GX + x (Points2Features' canonical order), so inside a window of a one-level grid
+    // "ascending voxel id" IS the row-major order of the in-window cells: the rank of a voxel is the number of occupied cells
+    // before its own -- an occupancy bitmap + popcount instead of a bitonic sort (55 barrier passes for a 24 x 24 window)
+    const uint32_t vol = (uint32_t)(p.wx * p.wy);
+    int m = 1; while ((uint32_t)m < n) m <<= 1;
+    bool sorted = false;
+    if (p.wz == 1 && p.sz == 1 && vol <= 1024u && n <= vol) {
+        // (that holds for Points2Features' output; a caller may hand over pillars in any order, so the result is checked and the
+        // sort below remains the fallback)
+        __shared__ unsigned long long bits[17];
+        uint32_t* ord = lds + m;                                  // second half of the dynamic LDS (2 x capacity)
+        if (threadIdx.x < 17) bits[threadIdx.x] = 0ull;
+        __syncthreads();
+        for (uint32_t s = threadIdx.x; s < n; s += blockDim.x) {
+            const uint32_t v = sorted_vox[seg + s];
+            uint32_t win, ix, iy, iz;
+            winOf(coords[v], p, win, ix, iy, iz);
+            const uint32_t cell = iy * (uint32_t)p.wx + ix;
+            atomicOr(&bits[cell >> 6], 1ull << (cell & 63));
+            lds[s] = v;
+        }
+        __syncthreads();
+        for (uint32_t s0 = threadIdx.x; s0 < n; s0 += blockDim.x) {
+            const uint32_t v = lds[s0];
+            uint32_t win, ix, iy, iz;
+            winOf(coords[v], p, win, ix, iy, iz);
+            const uint32_t cell = iy * (uint32_t)p.wx + ix;
+            uint32_t s = (uint32_t)__popcll(bits[cell >> 6] & ((1ull << (cell & 63)) - 1ull));
+            for (uint32_t q = 0; q < (cell >> 6); ++q) s += (uint32_t)__popcll(bits[q]);
+            ord[s] = v;
+        }
+        __syncthreads();
+        int bad = 0;
+        for (uint32_t i = threadIdx.x; i + 1 < n; i += blockDim.x) bad |= ord[i] >= ord[i + 1];
+        sorted = !__syncthreads_or(bad);
+        if (sorted)
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lds[i] = ord[i];
+        __syncthreads();
+    }
+    if (!sorted) {
+        for (int i = threadIdx.x; i < m; i += blockDim.x) lds[i] = (uint32_t)i < n ? sorted_vox[seg + i] : kNoneU;
+        __syncthreads();
+        bitonicSortLds(lds, m);
+    }
     for (uint32_t s = threadIdx.x; s < n; s += blockDim.x) {
         uint32_t v = lds[s], win, ix, iy, iz;
         winOf(coords[v], p, win, ix, iy, iz);
@@ -208,7 +248,7 @@ public:
         hipLaunchKernelGGL(wp_scan, dim3(1), dim3(1024), 0, stream, win_cnt, dense(), p_, win_seg, rank2win, vcnt, win_num, zeroFill);
         hipLaunchKernelGGL(wp_scatter, dim3(cdiv(mp, 256)), dim3(256), 0, stream, voxel_num, mp, vox_win, vox_slot, win_seg, sorted_vox);
         int vol = p_.wx * p_.wy * p_.wz, cap = 1; while (cap < vol) cap <<= 1;
-        hipLaunchKernelGGL(wp_fill, dim3(p_.max_win_num), dim3(256), sizeof(uint32_t) * cap, stream, coords, p_, win_num, rank2win,
+        hipLaunchKernelGGL(wp_fill, dim3(p_.max_win_num), dim3(256), sizeof(uint32_t) * cap * 2, stream, coords, p_, win_num, rank2win,
                            win_cnt, win_seg, sorted_vox, gidx, cinw, c2d, xy);
         return lastError();
     }
