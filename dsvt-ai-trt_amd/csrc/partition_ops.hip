@@ -7,8 +7,10 @@
 // iterative quicksort on 4.6 kB of local memory (getSet.cu:293-324, <=406 threads active on
 // the whole GPU).  Here nothing depends on arrival order:
 //   * windows are numbered by an exclusive scan over the dense window grid (ascending
-//     window linear id); a window's voxels are ordered by voxel id with a workgroup bitonic
-//     sort in LDS (= the serial arrival order of the reference);
+//     window linear id); a window's voxels are ordered by voxel id (= the serial arrival order
+//     of the reference): for pillars that arrive in cell order that is the row-major order of
+//     the in-window cells, i.e. rank = popcount of an occupancy bitmap; otherwise a workgroup
+//     bitonic sort in LDS;
 //   * the two per-window sorts use the fact that the in-window keys are unique and smaller
 //     than the window volume: each voxel is dropped into an LDS table at its key and the
 //     table is compacted with a workgroup scan -- no comparison sort at all;
