@@ -162,16 +162,13 @@ p2f_scatter(const uint32_t* __restrict__ n_ptr, int max_points, const uint32_t* 
     sorted_idx[cell_seg[cell] + pt_slot[i]] = i;
 }
 
-// one wavefront per pillar
-__global__ void __launch_bounds__(256)
-p2f_pillar(const float4* __restrict__ pts, P2FParams p, const uint32_t* __restrict__ pillar_num,
+// one wavefront, one pillar (any point count)
+__device__ __forceinline__ void p2fPillarWave(uint32_t pid, const float4* __restrict__ pts, const P2FParams& p,
            const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ pil_seg,
            const uint32_t* __restrict__ pil_full, const uint32_t* __restrict__ pil_ptoff,
-           float* __restrict__ feat, uint32_t* __restrict__ pidx)
+           float* __restrict__ feat, uint32_t* __restrict__ pidx, uint32_t* sel_lds)
 {
     const int lane = laneId();
-    const uint32_t pid = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
-    if (pid >= *pillar_num) return;
     const uint32_t T = p.max_num_points_per_voxel;
     const uint32_t seg = pil_seg[pid], nfull = pil_full[pid], ptoff = pil_ptoff[pid];
     const uint32_t kept = nfull < T ? nfull : T;
@@ -184,8 +181,35 @@ p2f_pillar(const float4* __restrict__ pts, P2FParams p, const uint32_t* __restri
         for (uint32_t j = 0; j < nfull; ++j) rank += (__shfl(mine, (int)j, kWave) < mine) ? 1u : 0u;
         if (lane >= (int)nfull) rank = lane;              // idle lanes push onto themselves
         sel = (uint32_t)__builtin_amdgcn_ds_permute((int)(rank * 4), (int)mine);
+    } else if (nfull <= 256u) {
+        // 65 .. 256 points (a few hundred cells next to the sensor): rank every id against all the others with wave shuffles and
+        // drop it at its rank through LDS.  (The selection loop below costs `kept` dependent global-load rounds, ~50 us per cell:
+        // it set the duration of the whole kernel.)
+        uint32_t vals[4], rk[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t idx = (uint32_t)lane + 64u * e;
+            vals[e] = idx < nfull ? sorted_idx[seg + idx] : kNone;
+            rk[e] = 0;
+        }
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+            if (64u * e2 >= nfull) break;
+            const int cnt = (int)(nfull - 64u * e2 < 64u ? nfull - 64u * e2 : 64u);
+            for (int j = 0; j < cnt; ++j) {
+                const uint32_t o = __shfl(vals[e2], j, kWave);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rk[e] += o < vals[e] ? 1u : 0u;
+            }
+        }
+        uint32_t* sm = sel_lds + (threadIdx.x / kWave) * kWave;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (vals[e] != kNone && rk[e] < (uint32_t)kWave) sm[rk[e]] = vals[e];
+        __builtin_amdgcn_wave_barrier();
+        if (lane < (int)kept) sel = sm[lane];
     } else {
-        // over-full cell (more than 64 points): select the `kept` smallest ids one by one
+        // more than 256 points in one cell: select the `kept` smallest ids one by one
         uint32_t last = 0; bool first = true;
         for (uint32_t s = 0; s < kept; ++s) {
             uint32_t m = kNone;
@@ -225,6 +249,70 @@ p2f_pillar(const float4* __restrict__ pts, P2FParams p, const uint32_t* __restri
         f[4] = q.x - cx; f[5] = q.y - cy; f[6] = q.z - cz;                                     // :859-861
         f[7] = fx; f[8] = fy; f[9] = fz;                                                       // :854-856
     }
+}
+
+
+// the arithmetic of one point row (reference lines as in p2fPillarWave)
+__device__ __forceinline__ void p2fWriteFeat(float* f, const float4 q, float cx, float cy, float cz, const P2FParams& p) {
+    int index_x = (int)floorf((q.x - p.min_x) / p.vx);                                     // :844-846
+    int index_y = (int)floorf((q.y - p.min_y) / p.vy);
+    int index_z = (int)floorf((q.z - p.min_z) / p.vz);
+    float fx = (float)((double)q.x - ((index_x + 0.5) * (double)p.vx + (double)p.min_x));    // :849-851 (double bracket)
+    float fy = (float)((double)q.y - ((index_y + 0.5) * (double)p.vy + (double)p.min_y));
+    float fz = (float)((double)q.z - ((index_z + 0.5) * (double)p.vz + (double)p.min_z));
+    f[0] = q.x; f[1] = q.y; f[2] = q.z; f[3] = q.w;                                        // :838-841
+    f[4] = q.x - cx; f[5] = q.y - cy; f[6] = q.z - cz;                                     // :859-861
+    f[7] = fx; f[8] = fy; f[9] = fz;                                                       // :854-856
+}
+
+// A wavefront owns FOUR consecutive pillars.  Pillars hold 4.8 points on average, so when all four have <= 16 points (the
+// common case) each takes a 16-lane group: same ranking, same sequential fp32 sums, a quarter of the wavefronts.  A pillar
+// with more points gets the whole wavefront first.
+__global__ void __launch_bounds__(256)
+p2f_pillar(const float4* __restrict__ pts, P2FParams p, const uint32_t* __restrict__ pillar_num,
+           const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ pil_seg,
+           const uint32_t* __restrict__ pil_full, const uint32_t* __restrict__ pil_ptoff,
+           float* __restrict__ feat, uint32_t* __restrict__ pidx)
+{
+    __shared__ uint32_t sel_lds[256];
+    const int lane = laneId(), sub = lane >> 4, sl = lane & 15;
+    const uint32_t P = *pillar_num;
+    // (pillars gw, gw + Q, gw + 2Q, gw + 3Q: dense cells come in runs of neighbours, a wavefront should not get four of them)
+    const uint32_t Q = (P + 3u) / 4u, gw = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    if (gw >= Q) return;
+    const uint32_t pid = gw + (uint32_t)sub * Q;
+    const bool have = pid < P;
+    const uint32_t nfull = have ? pil_full[pid] : 0u;
+    // pillars with more than 16 points: the whole wavefront, one after the other (every lane still here)
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t nk = __shfl(nfull, 16 * k, kWave);
+        if (nk > 16u) p2fPillarWave(gw + (uint32_t)k * Q, pts, p, sorted_idx, pil_seg, pil_full, pil_ptoff, feat, pidx, sel_lds);
+    }
+    // loop bound of the group loops: the largest small pillar of this wavefront (wave-uniform)
+    int nmax = 0;
+    for (int k = 0; k < 4; ++k) { const int nk = (int)__shfl(nfull, 16 * k, kWave); if (nk <= 16 && nk > nmax) nmax = nk; }
+    nmax = __builtin_amdgcn_readfirstlane(nmax);
+    if (!have || nfull > 16u) return;                                           // (whole 16-lane groups: the group shuffles below stay inside live groups)
+    const uint32_t T = p.max_num_points_per_voxel;
+    const uint32_t seg = pil_seg[pid], ptoff = pil_ptoff[pid];
+    const uint32_t kept = nfull < T ? nfull : T;
+    // lane s (< kept) of the group ends up holding the point id with the s-th smallest index in the cell
+    const uint32_t mine = sl < (int)nfull ? sorted_idx[seg + sl] : kNone;
+    uint32_t rank = 0;
+    for (int j = 0; j < nmax; ++j) rank += (__shfl(mine, j, 16) < mine) ? 1u : 0u;
+    if (sl >= (int)nfull) rank = (uint32_t)sl;                                  // idle lanes push onto themselves
+    const uint32_t sel = (uint32_t)__builtin_amdgcn_ds_permute((int)(((uint32_t)(sub << 4) + rank) * 4), (int)mine);
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sl < (int)kept) q = pts[sel];
+    float cx = 0.f, cy = 0.f, cz = 0.f;                                         // sequential fp32 sum in slot order (:813-824)
+    for (int s_ = 0; s_ < nmax; ++s_) {
+        const float vx = __shfl(q.x, s_, 16), vy = __shfl(q.y, s_, 16), vz = __shfl(q.z, s_, 16);
+        if (s_ < (int)kept) { cx += vx; cy += vy; cz += vz; }
+    }
+    const int ni = (int)kept;
+    cx = cx / ni; cy = cy / ni; cz = cz / ni;
+    for (uint32_t e = (uint32_t)sl; e < T; e += 16u) pidx[(size_t)pid * T + e] = e < kept ? ptoff + e : 0u;   // :829-830
+    if (sl < (int)kept) p2fWriteFeat(feat + (size_t)(ptoff + sl) * p.feature_num, q, cx, cy, cz, p);
 }
 
 class Points2FeaturesPlugin : public Plugin {
@@ -297,7 +385,7 @@ public:
                            pil_seg, pil_full, pil_ptoff, coords, pcnt, pillar_num, point_num);
         hipLaunchKernelGGL(p2f_scatter, dim3(cdiv(p_.max_points_num, 256)), dim3(256), 0, stream, n_ptr, p_.max_points_num,
                            pt_cell, pt_slot, cell_seg, sorted_idx);
-        hipLaunchKernelGGL(p2f_pillar, dim3(cdiv(p_.max_pillars_num, 4)), dim3(256), 0, stream, pts, p_, pillar_num,
+        hipLaunchKernelGGL(p2f_pillar, dim3(cdiv(p_.max_pillars_num, 16)), dim3(256), 0, stream, pts, p_, pillar_num,
                            sorted_idx, pil_seg, pil_full, pil_ptoff, feat, pidx);
         return lastError();
     }
