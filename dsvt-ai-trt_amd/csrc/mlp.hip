@@ -140,28 +140,45 @@ __device__ __forceinline__ void mlpLayerNormLds(floatx4 (&acc)[MNT], const float
 // DMA round trip (~2 us), so the ring has THREE slots and stage s+2 is requested when stage s starts: the end-of-stage wait
 // is a counted vmcnt that retires stage s+1 and leaves s+2 in flight.
 template <int MT, int NW, int PQ>
-__global__ void __launch_bounds__(64 * NW, (MT == 1 ? 4 : 2))
+__global__ void __launch_bounds__(64 * NW, (MT == 1 ? 3 : 2))
 encoder_mlp_stream_kernel(MlpStreamArgs a)
 {
     constexpr int PQT = PQ / 16, PQS = PQ / 32, SR = 6 * PQT, SB = SR * 1024, NWO = MC / PQ, NPIECE = MF / PQ;
     constexpr int NST = NWO + 2 * NPIECE, NRW = SR / NW;
-    static_assert(12 * PQS == SR && SR % NW == 0 && (NRW == 3 || NRW == 6), "uniform request count per wave");
+    constexpr bool ELASTIC = MT == 1 && NW == 10;   // 8 .. 10 waves of 16 rows are live, chosen from the row count (see below)
+    static_assert(12 * PQS == SR && (ELASTIC || (SR % NW == 0 && (NRW == 3 || NRW == 6))), "uniform request count per wave");
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * SB + MP_FLOATS * 4];     // 78,848 B: two workgroups per CU
     const uint32_t cnt = *a.count;
     const int M = (int)(cnt < (uint32_t)a.max_rows ? cnt : (uint32_t)a.max_rows);
-    // Tile plan.  One 128-row workgroup per CU takes 41-45 us whatever the count; a CU that hosts two takes 58-62 us (measured,
-    // tools/mlp_rows.py), so 269 tiles on 256 CUs cost as much as 512.  When the rows just overflow one tile per CU, the overflow
-    // (<= MLP_SMALL_MAX rows) is cut into 32-row workgroups of ONE wave (the other waves exit): they stream the same weights but
-    // share a CU with a full workgroup at a fraction of its LDS / MFMA load.
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int T = (M + MROWS - 1) / MROWS, over = M - a.ncu * MROWS;
-    const bool plan = MT == 2 && T > a.ncu && over <= MLP_SMALL_MAX && !(a.dbg & 32);
-    const int FULL = plan ? a.ncu : T;
-    const bool small = (int)blockIdx.x >= FULL;
-    int m0 = blockIdx.x * MROWS;
-    if (small) {
-        m0 = FULL * MROWS + ((int)blockIdx.x - FULL) * 32 * MLP_SW;
-        if (wave >= MLP_SW) return;
+    // Tile plan.  One workgroup per CU takes 41-45 us whatever the row count; a CU that hosts two 128-row workgroups takes 58-62 us
+    // (measured, tools/mlp_rows.py), so 269 tiles on 256 CUs cost as much as 512.
+    //  * <2, 4> (four waves x 32 rows): when the rows just overflow one tile per CU, the overflow (<= MLP_SMALL_MAX rows) is cut into
+    //    32-row workgroups of ONE wave (the other waves exit): they stream the same weights but share a CU with a full workgroup
+    //    at a fraction of its LDS / MFMA load.
+    //  * <1, 10> (elastic): the block has ten waves of 16 rows and 8, 9 or 10 of them are live, so that ncu workgroups cover the
+    //    rows (16 x 9 x 256 = 36,864 >= 34,483); the others exit at once.  Two waves per SIMD (168 VGPRs) overlap one wave's GELU /
+    //    LayerNorm / waits with the other's MFMAs.  Beyond 160 rows per CU: eight live waves, workgroups in rounds.
+    int nwa = NW;                                    // live waves of this workgroup
+    int m0;
+    bool small = false;
+    if (ELASTIC) {
+        int need = (M + 16 * a.ncu - 1) / (16 * a.ncu);
+        nwa = need <= 8 ? 8 : need <= NW ? need : 8;
+        if (a.dbg & 32) nwa = 8;
+        if (wave >= nwa) return;
+        m0 = blockIdx.x * 16 * nwa;
+    } else {
+        const int T = (M + MROWS - 1) / MROWS, over = M - a.ncu * MROWS;
+        const bool plan = T > a.ncu && over <= MLP_SMALL_MAX && !(a.dbg & 32);
+        const int FULL = plan ? a.ncu : T;
+        small = (int)blockIdx.x >= FULL;
+        m0 = blockIdx.x * MROWS;
+        if (small) {
+            m0 = FULL * MROWS + ((int)blockIdx.x - FULL) * 16 * MT * MLP_SW;
+            if (wave >= MLP_SW) return;
+            nwa = MLP_SW;
+        }
     }
     if (m0 >= M) return;
     const int r = lane & 15, g = lane >> 4;
@@ -171,6 +188,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
         row[mt] = m0 + wave * 16 * MT + mt * 16 + r;
         rc[mt] = row[mt] < M ? row[mt] : M - 1;
     }
+    const int nreq = (SR - wave + nwa - 1) / nwa;    // weight rows this wave requests per stage (elastic: 3 or 2)
     const float* prm = reinterpret_cast<const float*>(lds + 3 * SB);
     int nmark = 0;
     auto mark = [&]() { if (a.trace && tid == 0 && nmark < 32) a.trace[blockIdx.x * 32 + nmark] = clock64(); ++nmark; };
@@ -182,6 +200,16 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
                 const int rw = wave + j * MLP_SW;
                 __builtin_amdgcn_global_load_lds((mlp_gsrc_t)(a.Wp + ((size_t)s * SR + rw) * 512 + lane * 8),
                                                  (mlp_ldst_t)(lds + (s % 3) * SB + rw * 1024), 16, 0, 0);
+            }
+            return;
+        }
+        if (ELASTIC) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int rw = wave + j * nwa;
+                if (rw < SR)
+                    __builtin_amdgcn_global_load_lds((mlp_gsrc_t)(a.Wp + ((size_t)s * SR + rw) * 512 + lane * 8),
+                                                     (mlp_ldst_t)(lds + (s % 3) * SB + rw * 1024), 16, 0, 0);
             }
             return;
         }
@@ -198,6 +226,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
         if (st + 2 < NST) {
             static_assert(SR == 24 && (MLP_SW == 1 || MLP_SW == 2), "a small workgroup's wave counts SR / MLP_SW requests per stage");
             if (small) { if (MLP_SW == 1) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); }
+            else if (ELASTIC) { if (nreq == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); }
             else if (NRW == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -206,7 +235,6 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
         asm volatile("" ::: "memory");
     };
     request(0);
-    const int nwa = small ? MLP_SW : NW;             // waves that share the parameter pieces
 #pragma unroll
     for (int j = 0; j < MP_FLOATS / 256; ++j) {
         const int pr = wave + j * nwa;
@@ -491,21 +519,23 @@ public:
             DSVT_CHECK(hipMemsetAsync(out[0], 0, sizeof(float) * (size_t)max_rows_ * MC, stream));
             DSVT_CHECK(hipMemsetAsync(out[1], 0, sizeof(_Float16) * (size_t)max_rows_ * MC, stream));
         }
-        static int variant = -1;       // DSVT_MLP_VARIANT=2: 8 waves x 16 rows (<= 128 VGPRs, spills); default 4 waves x 32 rows
-        if (variant < 0) { const char* e = getenv("DSVT_MLP_VARIANT"); variant = e ? atoi(e) : 1; }
         static int ncu = 0;
         if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }
         b.ncu = ncu;
         const int over = max_rows_ - ncu * MROWS;
-        const int gsmall = over > 0 ? ncu + cdiv(over < MLP_SMALL_MAX ? over : MLP_SMALL_MAX, 32 * MLP_SW) : 0;
-        const int gfull = cdiv(max_rows_, MROWS);
+        static int variant = -1;       // DSVT_MLP_VARIANT=1: <2,4> four waves x 32 rows + small overflow workgroups; 2: <1,8>; default 3: <1,10> elastic
+        if (variant < 0) { const char* e = getenv("DSVT_MLP_VARIANT"); variant = e ? atoi(e) : 3; }
+        const int srows = 16 * (variant == 2 ? 1 : 2) * MLP_SW;                 // rows of a small workgroup
+        const int gsmall = over > 0 ? ncu + cdiv(over < MLP_SMALL_MAX ? over : MLP_SMALL_MAX, srows) : 0;
+        const int gfull = cdiv(max_rows_, MROWS);                               // (covers the elastic variant too: >= 128 rows per workgroup)
         const dim3 grid(gfull > gsmall ? gfull : gsmall);
         static unsigned long long* tr = nullptr; static int tron = -1;         // tools/trace_mlp.py
         if (tron < 0) { tron = getenv("DSVT_MLP_TRACE") ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 32 * 1024); }
         b.trace = tr;
         static int dbg = -1; if (dbg < 0) { const char* e = getenv("DSVT_MLP_DBG"); dbg = e ? atoi(e) : 0; }
         b.dbg = dbg;
-        if (variant == 2) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, 64>), grid, dim3(512), 0, stream, b);
+        if (variant == 3) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 10, 64>), grid, dim3(640), 0, stream, b);
+        else if (variant == 2) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, 64>), grid, dim3(512), 0, stream, b);
         else hipLaunchKernelGGL((encoder_mlp_stream_kernel<2, 4, 64>), grid, dim3(256), 0, stream, b);
         if (tron) {
             (void)hipStreamSynchronize(stream);
