@@ -818,6 +818,13 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
         }
         if (wideOn != 2) {
             const int nch64 = cdiv(a.CoutRows, 64), nsmall = cdiv(a.Ho, 8) * tilesX * nch64;
+            // 16-row x 64-channel items on eight waves when they nearly fill the CUs (234x234x128: 240 items, one per CU, 40 LDS-DMA
+            // pieces per wave and item instead of 59)
+            const int n16 = cdiv(a.Ho, 16) * tilesX * nch64;
+            if (n16 * 10 >= numCUs() * 9 && n16 <= numCUs() && wideOn != 7) {
+                hipLaunchKernelGGL((conv_wide_kernel<4, 8, 40, 4, 2>), dim3(n16), dim3(512), 0, stream, a, Wp, zeros, tilesX, n16, nch64, dbgW);
+                return lastError();
+            }
             const int grid = nsmall < 2 * numCUs() ? nsmall : 2 * numCUs();
             hipLaunchKernelGGL((conv_wide_kernel<4, 4, 36, 4, 2>), dim3(grid), dim3(256), 0, stream, a, Wp, zeros, tilesX, nsmall, nch64, dbgW);
             return lastError();
