@@ -233,17 +233,24 @@ set_attention_f16_kernel(AttnArgs a)
     // ---- stage the 36 gathered rows: Q, K as rows, V transposed -------------------------------------
     // (every thread reads its slot's row index itself: no LDS round trip + barrier between the index and the row loads; the
     // key columns 36..63 of sVt stay unwritten -- their B fragments are zeroed in registers below)
-    for (int i = tid; i < AL * 3 * 12; i += 256) {
-        const int slot = i / 36, rem = i % 36, seg = rem / 12, c8 = (rem % 12) * 8;
+    // Q, K: item = (slot, Q | K, 8-channel chunk): consecutive lanes write consecutive 16-byte pieces of a row
+    for (int i = tid; i < AL * 2 * 12; i += 256) {
+        const int slot = i / 24, rem = i % 24, seg = rem / 12, c8 = (rem % 12) * 8;
         const uint32_t rowi = a.inds ? a.inds[(size_t)set * AL + slot] : (uint32_t)(set * AL + slot);
         const _Float16* src = static_cast<const _Float16*>(a.qkv) + (size_t)rowi * a.qkv_ld + seg * a.C + hq * (AHB * ADH) + c8;
         const ahalf8 v = *reinterpret_cast<const ahalf8*>(src);
-        if (seg == 0) *reinterpret_cast<ahalf8*>(&sQ[slot * AQL + c8]) = v;
-        else if (seg == 1) *reinterpret_cast<ahalf8*>(&sK[slot * AQL + c8]) = v;
-        else {
+        *reinterpret_cast<ahalf8*>(&(seg == 0 ? sQ : sK)[slot * AQL + c8]) = v;
+    }
+    // V transposed: item = (8-channel chunk, slot) with the SLOT fastest, so the eight 2-byte writes of a wave instruction land on
+    // consecutive keys of one channel row (the chunk-fastest order hit two LDS banks with twelve lanes: SQ_LDS_BANK_CONFLICT was
+    // 74 % of the kernel's LDS cycles)
+    for (int i = tid; i < 12 * AL; i += 256) {
+        const int c8 = (i / AL) * 8, slot = i % AL;
+        const uint32_t rowi = a.inds ? a.inds[(size_t)set * AL + slot] : (uint32_t)(set * AL + slot);
+        const _Float16* src = static_cast<const _Float16*>(a.qkv) + (size_t)rowi * a.qkv_ld + 2 * a.C + hq * (AHB * ADH) + c8;
+        const ahalf8 v = *reinterpret_cast<const ahalf8*>(src);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sVt[(c8 + j) * AVL + slot] = v[j];
-        }
+        for (int j = 0; j < 8; ++j) sVt[(c8 + j) * AVL + slot] = v[j];
     }
     __syncthreads();
 
