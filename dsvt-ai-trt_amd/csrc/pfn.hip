@@ -64,8 +64,11 @@ __device__ __forceinline__ float maxOverLaneGroups(float v) {
 __global__ void __launch_bounds__(64 * PF_NW)
 pfn_kernel(PfnArgs a)
 {
-    __shared__ uint32_t sM[PF_PB * PF_C0];                             // max_pillar(x0), float bits                      6 KB
-    __shared__ uint32_t sU[PF_PB * PF_C1];                             // max_pillar(W1a x0), float bits                 12 KB
+    // (row strides 100 / 196 dwords: with 96 / 192 the sixteen pillar rows of a 16-byte read fall on two / one bank group,
+    // SQ_LDS_BANK_CONFLICT was 40 % of the kernel's LDS cycles)
+    constexpr int SM_LD = PF_C0 + 4, SU_LD = PF_C1 + 4;
+    __shared__ __attribute__((aligned(16))) uint32_t sM[PF_PB * SM_LD];   // max_pillar(x0), float bits                      6 KB
+    __shared__ __attribute__((aligned(16))) uint32_t sU[PF_PB * SU_LD];   // max_pillar(W1a x0), float bits                 12 KB
     __shared__ uint32_t sStart[PF_PB + 1];
     __shared__ __attribute__((aligned(16))) _Float16 sW1[3 * 12 * 512];                                                // 36 KB
     uint32_t P = *a.pillar_num; if (P > (uint32_t)a.max_pillars) P = a.max_pillars;
@@ -93,8 +96,8 @@ pfn_kernel(PfnArgs a)
     const uint32_t pb0 = grp * PF_PB;
     const int npil = P - pb0 < (uint32_t)PF_PB ? (int)(P - pb0) : PF_PB;
 
-    for (int i = tid; i < PF_PB * PF_C0; i += 64 * PF_NW) sM[i] = 0u;
-    for (int i = tid; i < PF_PB * PF_C1; i += 64 * PF_NW) sU[i] = 0u;
+    for (int i = tid; i < PF_PB * SM_LD; i += 64 * PF_NW) sM[i] = 0u;
+    for (int i = tid; i < PF_PB * SU_LD; i += 64 * PF_NW) sU[i] = 0u;
     if (tid <= npil) {
         // first row of pillar pb0 + tid; the sentinel entry is one past the last pillar's rows
         const uint32_t p = pb0 + (tid < npil ? tid : npil - 1);
@@ -179,9 +182,9 @@ pfn_kernel(PfnArgs a)
             for (int t = 0; t < 12; ++t) mxu[t] = maxOverLaneGroups(mxu[t]);
             if (g == 0) {
 #pragma unroll
-                for (int t = 0; t < 6; ++t) sM[pl * PF_C0 + 16 * t + r] = __float_as_uint(mx0[t]);
+                for (int t = 0; t < 6; ++t) sM[pl * SM_LD + 16 * t + r] = __float_as_uint(mx0[t]);
 #pragma unroll
-                for (int t = 0; t < 12; ++t) sU[pl * PF_C1 + 16 * t + r] = __float_as_uint(mxu[t]);
+                for (int t = 0; t < 12; ++t) sU[pl * SU_LD + 16 * t + r] = __float_as_uint(mxu[t]);
             }
 #pragma unroll
             for (int t = 0; t < 6; ++t) mx0[t] = 0.f;
@@ -197,8 +200,8 @@ pfn_kernel(PfnArgs a)
     half8 mf[3];                                     // B fragment: lane (r, g) holds m[pillar r][32s + 8g + j]
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-        const uint4 lo = *reinterpret_cast<const uint4*>(&sM[r * PF_C0 + 32 * s + 8 * g]);
-        const uint4 hi = *reinterpret_cast<const uint4*>(&sM[r * PF_C0 + 32 * s + 8 * g + 4]);
+        const uint4 lo = *reinterpret_cast<const uint4*>(&sM[r * SM_LD + 32 * s + 8 * g]);
+        const uint4 hi = *reinterpret_cast<const uint4*>(&sM[r * SM_LD + 32 * s + 8 * g + 4]);
         half8 h;
         h[0] = (_Float16)__uint_as_float(lo.x); h[1] = (_Float16)__uint_as_float(lo.y); h[2] = (_Float16)__uint_as_float(lo.z); h[3] = (_Float16)__uint_as_float(lo.w);
         h[4] = (_Float16)__uint_as_float(hi.x); h[5] = (_Float16)__uint_as_float(hi.y); h[6] = (_Float16)__uint_as_float(hi.z); h[7] = (_Float16)__uint_as_float(hi.w);
@@ -216,7 +219,7 @@ pfn_kernel(PfnArgs a)
         if (pv) {                                    // lane (r, g): pillar r, columns 16t + 4g + i
             const int col = 16 * t + 4 * g;
             const float4 b = *reinterpret_cast<const float4*>(a.b1 + col);
-            const uint4 u = *reinterpret_cast<const uint4*>(&sU[r * PF_C1 + col]);
+            const uint4 u = *reinterpret_cast<const uint4*>(&sU[r * SU_LD + col]);
             float4 v;
             v.x = fmaxf(__uint_as_float(u.x) + acc[0] + b.x, 0.f); v.y = fmaxf(__uint_as_float(u.y) + acc[1] + b.y, 0.f);
             v.z = fmaxf(__uint_as_float(u.z) + acc[2] + b.z, 0.f); v.w = fmaxf(__uint_as_float(u.w) + acc[3] + b.w, 0.f);
