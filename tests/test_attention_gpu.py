@@ -146,13 +146,16 @@ def test_linear_f16_mfma(pkg, oracle, K, N, act, nln):
         assert np.abs(e16[:n] - e32[:n]).max() < 2e-5 * scale
 
 
-@pytest.mark.parametrize("block_ln", [False, True])
-def test_fused_encoder_mlp_equals_linear_chain(pkg, block_ln):
+@pytest.mark.parametrize("block_ln,MR,n", [(False, 8192, 5504), (True, 8192, 5504),
+                                             (True, 65536, 34483),      # nine live waves per workgroup (one workgroup per CU)
+                                             (False, 65536, 39000),     # ten
+                                             (False, 65536, 50000)])    # beyond 160 rows per CU: eight-wave workgroups in rounds
+def test_fused_encoder_mlp_equals_linear_chain(pkg, block_ln, MR, n):
     """DsvtEncoderMlpPlugin (one launch, activations chained through registers with a permuted-k operand
     layout) against the same maths as three DsvtLinear launches in fp16 mode."""
     P = pkg.plugin
     rng = np.random.default_rng(11 + block_ln)
-    MR, n, C = 8192, 5504, 192
+    C = 192
     w = pkg.synth.make_weights(with_bev=False)
     lp = "module.backbone_3d.stage_0.2.encoder_list.1"
     ln = lambda k: (w[lp + k + ".weight"], w[lp + k + ".bias"])
