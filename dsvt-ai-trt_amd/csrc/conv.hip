@@ -189,6 +189,21 @@ conv_f16_kernel(ConvArgs a)
     const int dy = sub / a.up, dx = sub - dy * a.up;
     const int cbase = n0 - sub * a.Cout;
     const int Wout = a.Wo * a.up;
+    // the bias of every tile first (loads only): a load issued after a store is awaited behind the store's acknowledgement
+    if (a.bias) {
+#pragma unroll
+        for (int t = 0; t < CNT; ++t) {
+            const int co = cbase + t * 16 + 4 * g;
+            if (t >= ntiles || co >= a.Cout) continue;
+            float b4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b4[i] = co + i < a.Cout ? a.bias[co + i] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[mt][t][i] += b4[i];
+        }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         if (!pv[mt]) continue;
@@ -199,10 +214,6 @@ conv_f16_kernel(ConvArgs a)
             if (t >= ntiles || co >= a.Cout) continue;
             float v[4] = {acc[mt][t][0], acc[mt][t][1], acc[mt][t][2], acc[mt][t][3]};
             const bool full = co + 3 < a.Cout;
-            if (a.bias) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) if (co + i < a.Cout) v[i] += a.bias[co + i];
-            }
             if (a.res && full) {
                 const half4 rv = *reinterpret_cast<const half4*>(a.res + opix * a.res_ld + co);
 #pragma unroll
