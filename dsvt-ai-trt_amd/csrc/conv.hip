@@ -204,6 +204,32 @@ conv_f16_kernel(ConvArgs a)
                 for (int i = 0; i < 4; ++i) acc[mt][t][i] += b4[i];
         }
     }
+    if (a.wide && !a.res) {
+        // wide stores (see the halo kernels): v_permlane16_swap of tiles t, t + 1 leaves eight consecutive channels per lane
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const size_t opix = pv[mt] ? (size_t)(py[mt] * a.up + dy) * Wout + (px[mt] * a.up + dx) : 0;
+#pragma unroll
+            for (int t = 0; t < CNT; t += 2) {
+                floatx4 X = acc[mt][t], Y = acc[mt][t + 1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(X[i]), __float_as_uint(Y[i]), false, false);
+                    X[i] = __uint_as_float(sw[0]); Y[i] = __uint_as_float(sw[1]);
+                }
+                const int co = cbase + t * 16 + (g & 1) * 16 + (g >> 1) * 8;
+                if (!pv[mt] || t >= ntiles || co >= a.Cout) continue;
+                half8 h;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    h[i] = (_Float16)(a.relu ? fmaxf(X[i], 0.f) : X[i]);
+                    h[4 + i] = (_Float16)(a.relu ? fmaxf(Y[i], 0.f) : Y[i]);
+                }
+                *reinterpret_cast<half8*>(static_cast<_Float16*>(a.out) + opix * a.out_ld + a.out_coff + co) = h;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         if (!pv[mt]) continue;
