@@ -238,8 +238,8 @@ def main():
                         + 2 * up * up * f["out_channels"] * taps * f["in_channels"])
             return (0.0, 0.0)
 
-        meta = {"DsvtLinearPlugin": ("linear_f16_stream_kernel (v_mfma_f32_16x16x32_f16, weights by LDS-DMA)" if f16 else "linear_f32_kernel (v_mfma_f32_16x16x4_f32)",
-                                     "hbm" if f16 else "mfma", "linear_f16_stream_kernelILi1ELi1ELi8" if f16 else "linear_f32_kernel<true>"),
+        meta = {"DsvtLinearPlugin": ("linear_f16_rows_kernel (QKV: all column chunks of a row tile per workgroup, v_mfma_f32_16x16x32_f16, weights by LDS-DMA)" if f16 else "linear_f32_kernel (v_mfma_f32_16x16x4_f32)",
+                                     "hbm" if f16 else "mfma", "linear_f16_rows_kernel" if f16 else "linear_f32_kernel<true>"),
                 "DsvtEncoderMlpPlugin": ("encoder_mlp_stream_kernel (out-proj+LN -> FC1+GELU -> FC2+LN+LN, v_mfma_f32_16x16x32_f16, weights by LDS-DMA)", "hbm", "encoder_mlp_stream_kernel"),
                 "DsvtSetAttentionPlugin": ("set_attention_f16_kernel (v_mfma_f32_16x16x32_f16)" if f16 else "set_attention_kernel (v_mfma_f32_16x16x4_f32)", "hbm",
                                            "set_attention_f16_kernel" if f16 else "set_attention_kernel"),

@@ -568,8 +568,151 @@ posembed_batched_kernel(LinearArgs a, PosEmbedBatch b)
     linearStreamBody<2, 1, 8>(la, Wp);
 }
 
+// -------------------------------------------------------------------------------------
+// All column chunks of a row tile in ONE workgroup (QKV: N = 576 = three 192-column chunks; fp16 A, fp16 output, bias only).
+// The one-chunk-per-workgroup grid above reads the activation rows once per chunk and runs 810 workgroups in 1.58 rounds of
+// two per CU; here a workgroup loads its rows once, keeps FOUR 36 KB weight stages in LDS (chunk c + 1 streams in while chunk
+// c computes) and stores chunk c while chunk c + 1 computes.  The stores of a chunk are YOUNGER than the LDS-DMA requests the
+// next chunk waits for, so the wait is a counted vmcnt that leaves exactly those stores in flight (one in-order counter, see
+// DESIGN.md "one counter").  Rows per workgroup are elastic like the encoder MLP's: 8, 9 or 10 live waves of 16 rows so that one
+// workgroup per CU covers the rows.
+constexpr int RW_NW = 10;             // waves of the block (live: 8 .. 10)
+__global__ void __launch_bounds__(64 * RW_NW, 3)
+linear_f16_rows_kernel(LinearArgs a, const _Float16* __restrict__ Wp, int ncu)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char ring[4 * SBYTES + 4096];   // four weight stages + the bias (<= 1024 floats): one workgroup per CU
+    const int M = rowLimit(a);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int need = (M + 16 * ncu - 1) / (16 * ncu);
+    const int nwa = need <= 8 ? 8 : need <= RW_NW ? need : 8;        // beyond 160 rows per CU: eight-wave workgroups in rounds
+    if (wave >= nwa) return;
+    const int m0 = blockIdx.x * 16 * nwa;
+    if (m0 >= M) return;
+    const int NCH = a.N / BN;                                        // column chunks (two stages each)
+    const int nreq = (SROWS - wave + nwa - 1) / nwa;                 // fragment rows this wave requests per stage (3 .. 5)
+    auto request = [&](int st) {                                     // stage st (= 2 chunk + half) -> slot st % 4
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int row = wave + j * nwa;
+            if (row < SROWS)
+                __builtin_amdgcn_global_load_lds((glds_src_t)(Wp + ((size_t)st * SROWS + row) * 512 + lane * 8),
+                                                 (glds_dst_t)(ring + (st & 3) * SBYTES + row * 1024), 16, 0, 0);
+        }
+    };
+    auto waitKeep = [&](int keep) {                                  // wave-uniform; then the workgroup barrier
+        switch (keep) {
+            case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); break;
+            case 14: asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory"); break;
+            case 16: asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // the bias comes by LDS-DMA as well and is read back with inline-asm ds_read: an ordinary global load in the chunk loop would be
+    // awaited with vmcnt(0) (behind the previous chunk's stores), and so would a compiler-visible ds_read of memory an LDS-DMA
+    // may be writing
+    if (wave < 4) {
+        const int f0 = wave * 256 + lane * 4;
+        const float* src = a.bias ? a.bias + (f0 + 3 < a.N ? f0 : 0) : reinterpret_cast<const float*>(Wp);       // (unused lanes: any valid address)
+        __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(ring + 4 * SBYTES + wave * 1024), 16, 0, 0);
+    }
+    const uint32_t bias_lds = (uint32_t)(uintptr_t)(glds_dst_t)(ring + 4 * SBYTES);
+    request(0); request(1);
+    if (NCH > 1) { request(2); request(3); }
+    const int row = m0 + wave * 16 + r, rc = row < M ? row : M - 1;
+    const bool waveValid = m0 + wave * 16 < M;                       // (else this wave issues no store)
+    const int nst = waveValid ? 6 : 0;                               // wide stores of one chunk per wave
+    // operand fragments: x (+ A2 row, gathered through the window cell when a2_c2d is set) for the chunks below add_cols, x alone above
+    half8 fx[NSTEP], fp[NSTEP];
+    {
+        const size_t o = (size_t)rc * KS + g * 8;
+        size_t o2 = o;
+        if (a.a2_c2d) { const int32_t* c = a.a2_c2d + (size_t)rc * 3; o2 = (size_t)(c[1] * a.a2_wx + c[2]) * KS + g * 8; }
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) fx[s] = *reinterpret_cast<const half8*>(static_cast<const _Float16*>(a.A) + o + s * 32);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s)
+            fp[s] = a.add_cols > 0 ? *reinterpret_cast<const half8*>(static_cast<const _Float16*>(a.A2) + o2 + s * 32) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) { asm volatile("" :: "v"(fx[s])); asm volatile("" :: "v"(fp[s])); }     // hipcc's wait for the row loads: here, once
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) fp[s] += fx[s];
+    }
+    // stages 0, 1 landed (2, 3 may stay in flight: they are younger)
+    waitKeep(NCH > 1 ? 2 * nreq : 0);
+    const unsigned char* slot = ring + lane * 16;
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        const bool add = c * BN < a.add_cols;
+        floatx4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned char* sp = slot + ((2 * c + h) & 3) * SBYTES;
+#pragma unroll
+            for (int ks = 0; ks < NSTEP; ++ks) {
+                const half8 f = add ? fp[ks] : fx[ks];
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+                    acc[6 * h + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(sp + (ks * 6 + t) * 1024), f, acc[6 * h + t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // everyone is done with the two slots of chunk c: the stages of chunk c + 2 may overwrite them
+        const bool more = c + 2 < NCH;
+        if (c + 1 < NCH) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+            if (more) { request(2 * c + 4); request(2 * c + 5); }
+        }
+        // bias + wide fp16 stores of chunk c (issued AFTER the requests above: they stay the youngest entries of the counter)
+        {
+            const int n0 = c * BN;
+#pragma unroll
+            for (int t = 0; t < NT; t += 2) {
+                floatx4 X = acc[t], Y = acc[t + 1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(X[i]), __float_as_uint(Y[i]), false, false);
+                    X[i] = __uint_as_float(sw[0]); Y[i] = __uint_as_float(sw[1]);
+                }
+                if (a.bias) {                                // the lane's eight columns after the swap are contiguous: two 16-byte LDS reads
+                    const uint32_t ad = bias_lds + (uint32_t)(n0 + t * 16 + (g & 1) * 16 + (g >> 1) * 8) * 4u;
+                    floatx4 b0, b1;
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b0), "=&v"(b1) : "v"(ad));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { X[i] += b0[i]; Y[i] += b1[i]; }
+                }
+                if (row < M) {
+                    half8 hv = {(_Float16)X[0], (_Float16)X[1], (_Float16)X[2], (_Float16)X[3], (_Float16)Y[0], (_Float16)Y[1], (_Float16)Y[2], (_Float16)Y[3]};
+                    *reinterpret_cast<half8*>(a.out16 + (size_t)row * a.out_ld + n0 + t * 16 + (g & 1) * 16 + (g >> 1) * 8) = hv;
+                }
+            }
+        }
+        // the stages of chunk c + 1 have landed: everything older than [requests of chunk c + 2] [stores of chunk c] is retired
+        if (c + 1 < NCH) waitKeep((more ? 2 * nreq : 0) + nst);
+    }
+}
+
+int launchLinearF16Rows(const LinearArgs& a, const _Float16* Wp, hipStream_t stream) {
+    static int ncu = 0;
+    if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }
+    hipLaunchKernelGGL(linear_f16_rows_kernel, dim3(cdiv(a.max_rows, 128)), dim3(64 * RW_NW), 0, stream, a, Wp, ncu);
+    return lastError();
+}
+
 int launchLinearF16Stream(const LinearArgs& a, const _Float16* Wp, hipStream_t stream) {
     if (a.K != KS || a.N % BN != 0 || (a.N > BN && a.n_ln > 0)) return -3;
+    static int rowsOn = -1;        // DSVT_LINEAR_ROWS=0: one column chunk per workgroup for every layer
+    if (rowsOn < 0) { const char* e = getenv("DSVT_LINEAR_ROWS"); rowsOn = e ? atoi(e) : 1; }
+    if (rowsOn && a.N > BN && a.a_half && !a.pe_xy && a.out16 && !a.out && a.act == ACT_NONE && a.n_ln == 0 && a.row_mult == 1 &&
+        (a.add_cols % BN) == 0 && a.N <= 1024 && !a.trace)
+        return launchLinearF16Rows(a, Wp, stream);
     dim3 grid(cdiv(a.max_rows, BM16), a.N / BN);
     const int amode = a.pe_xy ? 2 : a.a_half ? 1 : 0;
     static int mt2 = -1;           // DSVT_STREAM_MT=2: 4 waves x 32 rows (<= 256 VGPRs); default 8 waves x 16 rows (<= 128 VGPRs, 4 waves/SIMD):
