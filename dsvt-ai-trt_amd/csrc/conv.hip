@@ -601,9 +601,9 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
 // channels, 4 waves, 78 KB of LDS: two independent workgroups per CU) serves the 234x234 and 117x117 layers, which have
 // too few 16-row x 128-channel items for 256 CUs (117x117x256: 240 items of four waves instead of 120 of eight).
 // HS = halo row stride in pixels (>= 34; HS * 64 B is a multiple of 256 B, so the bank pattern is that of one row).
-template <int CT, int NW, int HS, int SPS>
+template <int CT, int NW, int HS, int SPS, int RW>
 struct WideCfg {
-    static constexpr int ROWS = 2 * NW, HH = ROWS + 2;
+    static constexpr int ROWS = RW * NW, HH = ROWS + 2;
     static constexpr int NPC = (HH * HS * 64 + 1023) / 1024;       // LDS-DMA pieces (16 pixels each) per halo phase
     static constexpr int HBYTES = NPC * 1024, WBYTES = SPS * CT * 1024;
     static constexpr int PPW = (NPC + NW - 1) / NW;                // pieces per wave per phase
@@ -612,11 +612,14 @@ struct WideCfg {
 
 // NWB = weight slabs in LDS: 3 = the slab TWO ahead is requested when a slab starts and the slab-end wait leaves those requests
 // in flight (one slab of MFMAs, 0.5-1 us, is shorter than an L2 -> LDS round trip under load); 2 where LDS must hold two workgroups.
-template <int CT, int NW, int HS, int SPS = (CT == 8 ? 2 : 4), int NWB = 3>
-__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1)
+// RW = tile rows per wave: 2 (64 pixels, four pixel tiles) or 1 (32 pixels, two pixel tiles: twice the waves on the same tile --
+// for the small layers, where one wave per SIMD cannot hide its own LDS-DMA issue and wait time)
+template <int CT, int NW, int HS, int SPS = (CT == 8 ? 2 : 4), int NWB = 3, int RW = 2>
+__global__ void __launch_bounds__(64 * NW, (NW * (RW == 1 ? 1 : 2) <= 8 && (NW == 4 || RW == 1)) ? 2 : 1)
 conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __restrict__ zeros, int tilesX, int nitems, int nchunk, int dbg)
 {
-    using C = WideCfg<CT, NW, HS, SPS>;
+    using C = WideCfg<CT, NW, HS, SPS, RW>;
+    constexpr int NM = 2 * RW;                                    // 16-pixel tiles per wave
     static_assert(SPS == 2 || SPS == 4, "nine-step phases and two halo buffers: a slab spans at most four steps");
     constexpr int WT_HS = HS, WT_HBYTES = C::HBYTES, WT_WBYTES = C::WBYTES, WT_NPC = C::NPC, WT_ROWS = C::ROWS, PPW = C::PPW;
     constexpr int PPS = SPS == 2 ? (PPW + 2) / 3 : PPW;           // halo pieces a wave requests per slab
@@ -675,10 +678,10 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     slabBarrier(0);
     if (LEAD == 2) weightRequests(1, chunk, 1);                   // (NSLAB >= 5; retired by the first slab-end wait)
 
-    const int pb = ((2 * wave) * WT_HS + r) * 64;                 // this lane's pixel of pixel tile 0, tap (0, 0)
+    const int pb = ((RW * wave) * WT_HS + r) * 64;                // this lane's pixel of pixel tile 0, tap (0, 0)
     const int aoff = lane << 4;
     int wb = 0;
-    floatx4 acc[CT][4];
+    floatx4 acc[CT][NM];
     for (;;) {
         int nitem = item + gridDim.x, ny0 = 0, nx0 = 0, nch = 0;
         const bool have_next = nitem < nitems;
@@ -687,7 +690,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         for (int ct = 0; ct < CT; ++ct) {
             const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + BIAS_OFF + (ct * 16 + 4 * g) * 4);      // zeros without a bias
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[ct][m] = b4;
+            for (int m = 0; m < NM; ++m) acc[ct][m] = b4;
         }
 #pragma unroll 1
         for (int s = 0; s < NSLAB; ++s) {
@@ -719,12 +722,12 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
             // issued BEFORE the MFMAs of batch b (left to itself hipcc emits read, s_waitcnt lgkmcnt(0), 8 MFMAs, read, ...)
             {
                 constexpr int BPS = CT / CH, NB = SPS * BPS;          // batches per step / per slab
-                half8 Bf[2][4], Af[2][CH];
-                auto loadB = [&](int u, half8 (&B)[4]) {
+                half8 Bf[2][NM], Af[2][CH];
+                auto loadB = [&](int u, half8 (&B)[NM]) {
                     const int step = SPS * s + u, ph = step / 9, tap = step - 9 * ph, ky = tap / 3, kx = tap - 3 * ky;
                     const unsigned char* hbp = smem + (ph & 1) * WT_HBYTES + (ky * WT_HS + kx) * 64 + pb + ((g ^ (((r + kx) >> 1) & 2)) << 4);
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) B[m] = *reinterpret_cast<const half8*>(hbp + ((m >> 1) * WT_HS + (m & 1) * 16) * 64);
+                    for (int m = 0; m < NM; ++m) B[m] = *reinterpret_cast<const half8*>(hbp + ((m >> 1) * WT_HS + (m & 1) * 16) * 64);
                 };
                 auto loadA = [&](int u, int c0, half8 (&A)[CH]) {
                     const unsigned char* wbp = smem + 2 * WT_HBYTES + wb * WT_WBYTES + (u * CT + c0) * 1024 + aoff;
@@ -745,7 +748,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
 #pragma unroll
                         for (int ct = 0; ct < CH; ++ct)
 #pragma unroll
-                            for (int m = 0; m < 4; ++m)
+                            for (int m = 0; m < NM; ++m)
                                 acc[c0 + ct][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[b & 1][ct], Bf[u & 1][m], acc[c0 + ct][m], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -761,12 +764,12 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
             const int sub = n0 / a.Cout, dy = sub / a.up, dx = sub - dy * a.up, cbase = n0 - sub * a.Cout;
             const int Wout = a.Wo * a.up;
             if (a.wide) {
-                constexpr int TP = CT / 2, NBLK = 4 * TP;             // blocks b = (pixel tile m, channel-tile pair tp)
+                constexpr int TP = CT / 2, NBLK = NM * TP;            // blocks b = (pixel tile m, channel-tile pair tp)
                 const int cg8 = (g & 1) * 16 + (g >> 1) * 8;
-                bool valid[4]; size_t opix[4];
+                bool valid[NM]; size_t opix[NM];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int oy = y0 + 2 * wave + (m >> 1), ox = x0 + (m & 1) * 16 + r;
+                for (int m = 0; m < NM; ++m) {
+                    const int oy = y0 + RW * wave + (m >> 1), ox = x0 + (m & 1) * 16 + r;
                     valid[m] = oy < a.Ho && ox < a.Wo;
                     opix[m] = valid[m] ? (size_t)(oy * a.up + dy) * Wout + (ox * a.up + dx) : 0;
                 }
@@ -794,8 +797,8 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                 }
             } else {                                                  // (not a layer of this network)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int oy = y0 + 2 * wave + (m >> 1), ox = x0 + (m & 1) * 16 + r;
+                for (int m = 0; m < NM; ++m) {
+                    const int oy = y0 + RW * wave + (m >> 1), ox = x0 + (m & 1) * 16 + r;
                     if (!(oy < a.Ho && ox < a.Wo)) continue;
                     const size_t opix = (size_t)(oy * a.up + dy) * Wout + (ox * a.up + dx);
 #pragma unroll
@@ -858,12 +861,15 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
             // 16-row x 64-channel items on eight waves when they nearly fill the CUs (234x234x128: 240 items, one per CU, 40 LDS-DMA
             // pieces per wave and item instead of 59)
             const int n16 = cdiv(a.Ho, 16) * tilesX * nch64;
-            if (n16 * 10 >= numCUs() * 9 && n16 <= numCUs() && wideOn != 7) {
+            if (n16 * 10 >= numCUs() * 9 && n16 <= numCUs() && wideOn != 7 && wideOn != 10) {
                 hipLaunchKernelGGL((conv_wide_kernel<4, 8, 40, 4, 2>), dim3(n16), dim3(512), 0, stream, a, Wp, zeros, tilesX, n16, nch64, dbgW);
                 return lastError();
             }
             const int grid = nsmall < 2 * numCUs() ? nsmall : 2 * numCUs();
-            hipLaunchKernelGGL((conv_wide_kernel<4, 4, 36, 4, 2>), dim3(grid), dim3(256), 0, stream, a, Wp, zeros, tilesX, nsmall, nch64, dbgW);
+            // 8 rows x 32 pixels x 64 channels: eight waves of ONE row each (117x117x256: 31.4 us; four waves of two rows: 35.6 us --
+            // one wave per SIMD cannot hide its own LDS-DMA issue and wait time)
+            if (wideOn == 9) hipLaunchKernelGGL((conv_wide_kernel<4, 4, 36, 4, 2>), dim3(grid), dim3(256), 0, stream, a, Wp, zeros, tilesX, nsmall, nch64, dbgW);
+            else hipLaunchKernelGGL((conv_wide_kernel<4, 8, 36, 4, 2, 1>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nsmall, nch64, dbgW);
             return lastError();
         }
     }
