@@ -233,25 +233,47 @@ set_attention_f16_kernel(AttnArgs a)
     // ---- stage the 36 gathered rows: Q, K as rows, V transposed -------------------------------------
     // (every thread reads its slot's row index itself: no LDS round trip + barrier between the index and the row loads; the
     // key columns 36..63 of sVt stay unwritten -- their B fragments are zeroed in registers below)
-    // Q, K: item = (slot, Q | K, 8-channel chunk): consecutive lanes write consecutive 16-byte pieces of a row
-    for (int i = tid; i < AL * 2 * 12; i += 256) {
-        const int slot = i / 24, rem = i % 24, seg = rem / 12, c8 = (rem % 12) * 8;
-        const uint32_t rowi = a.inds ? a.inds[(size_t)set * AL + slot] : (uint32_t)(set * AL + slot);
-        const _Float16* src = static_cast<const _Float16*>(a.qkv) + (size_t)rowi * a.qkv_ld + seg * a.C + hq * (AHB * ADH) + c8;
-        const ahalf8 v = *reinterpret_cast<const ahalf8*>(src);
-        *reinterpret_cast<ahalf8*>(&(seg == 0 ? sQ : sK)[slot * AQL + c8]) = v;
-    }
+    // All row indices first, then all rows, then the LDS writes: left as loops hipcc keeps "load index, wait, load row, wait, write"
+    // per item -- ten dependent memory round trips per thread instead of two.
+    // Q, K: item = (slot, Q | K, 8-channel chunk): consecutive lanes write consecutive 16-byte pieces of a row.
     // V transposed: item = (8-channel chunk, slot) with the SLOT fastest, so the eight 2-byte writes of a wave instruction land on
     // consecutive keys of one channel row (the chunk-fastest order hit two LDS banks with twelve lanes: SQ_LDS_BANK_CONFLICT was
     // 74 % of the kernel's LDS cycles)
-    for (int i = tid; i < 12 * AL; i += 256) {
-        const int c8 = (i / AL) * 8, slot = i % AL;
-        const uint32_t rowi = a.inds ? a.inds[(size_t)set * AL + slot] : (uint32_t)(set * AL + slot);
-        const _Float16* src = static_cast<const _Float16*>(a.qkv) + (size_t)rowi * a.qkv_ld + 2 * a.C + hq * (AHB * ADH) + c8;
-        const ahalf8 v = *reinterpret_cast<const ahalf8*>(src);
+    constexpr int NQK = (AL * 2 * 12 + 255) / 256, NV = (12 * AL + 255) / 256, NIT = NQK + NV;
+    int slotOf[NIT], segOf[NIT], c8Of[NIT]; bool live[NIT];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sVt[(c8 + j) * AVL + slot] = v[j];
+    for (int k = 0; k < NQK; ++k) {
+        const int i = tid + 256 * k; live[k] = i < AL * 2 * 12;
+        const int ii = live[k] ? i : 0, rem = ii % 24;
+        slotOf[k] = ii / 24; segOf[k] = rem / 12; c8Of[k] = (rem % 12) * 8;
     }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = tid + 256 * k; live[NQK + k] = i < 12 * AL;
+        const int ii = live[NQK + k] ? i : 0;
+        slotOf[NQK + k] = ii % AL; segOf[NQK + k] = 2; c8Of[NQK + k] = (ii / AL) * 8;
+    }
+    uint32_t rowOf[NIT];
+    if (a.inds) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) rowOf[k] = a.inds[(size_t)set * AL + slotOf[k]];
+    } else {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) rowOf[k] = (uint32_t)(set * AL + slotOf[k]);
+    }
+    ahalf8 val[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k)
+        val[k] = *reinterpret_cast<const ahalf8*>(static_cast<const _Float16*>(a.qkv) + (size_t)rowOf[k] * a.qkv_ld + segOf[k] * a.C + hq * (AHB * ADH) + c8Of[k]);
+#pragma unroll
+    for (int k = 0; k < NQK; ++k)
+        if (live[k]) *reinterpret_cast<ahalf8*>(&(segOf[k] == 0 ? sQ : sK)[slotOf[k] * AQL + c8Of[k]]) = val[k];
+#pragma unroll
+    for (int k = NQK; k < NIT; ++k)
+        if (live[k]) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sVt[(c8Of[k] + j) * AVL + slotOf[k]] = val[k][j];
+        }
     __syncthreads();
 
     const int hoff = wave * ADH;
