@@ -225,11 +225,10 @@ set_attention_f16_kernel(AttnArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
 
-    if (tid < AL) sRow[tid] = a.inds ? a.inds[(size_t)set * AL + tid] : (uint32_t)(set * AL + tid);
-    if (tid < AHB * AL) {
-        int h = tid / AL, k = tid % AL;
-        sMask[h][k] = a.mask[(size_t)set * a.mask_set_stride + (size_t)(hq * AHB + h) * a.mask_head_stride + k];
-    }
+    // (the row-index / mask values the epilogue needs are loaded here and written to LDS after the staging loads are in flight)
+    uint32_t myRow = (uint32_t)(set * AL + (tid < AL ? tid : 0)); float myMask = 0.f;
+    if (a.inds && tid < AL) myRow = a.inds[(size_t)set * AL + tid];
+    if (tid < AHB * AL) myMask = a.mask[(size_t)set * a.mask_set_stride + (size_t)(hq * AHB + tid / AL) * a.mask_head_stride + tid % AL];
     // ---- stage the 36 gathered rows: Q, K as rows, V transposed -------------------------------------
     // (every thread reads its slot's row index itself: no LDS round trip + barrier between the index and the row loads; the
     // key columns 36..63 of sVt stay unwritten -- their B fragments are zeroed in registers below)
@@ -265,6 +264,8 @@ set_attention_f16_kernel(AttnArgs a)
 #pragma unroll
     for (int k = 0; k < NIT; ++k)
         val[k] = *reinterpret_cast<const ahalf8*>(static_cast<const _Float16*>(a.qkv) + (size_t)rowOf[k] * a.qkv_ld + segOf[k] * a.C + hq * (AHB * ADH) + c8Of[k]);
+    if (tid < AL) sRow[tid] = myRow;
+    if (tid < AHB * AL) sMask[tid / AL][tid % AL] = myMask;
 #pragma unroll
     for (int k = 0; k < NQK; ++k)
         if (live[k]) *reinterpret_cast<ahalf8*>(&(segOf[k] == 0 ? sQ : sK)[slotOf[k] * AQL + c8Of[k]]) = val[k];
