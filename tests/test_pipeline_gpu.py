@@ -208,3 +208,24 @@ def test_detect_directory_writes_reference_txt(pkg, weights, tmp_path):
         _, b = pkg.detect.read_txt(str(out2 / f"{name}.txt"))
         # (another process: the fp32 dense stage runs on MIOpen, whose algorithm choice may differ in the last bits)
         assert a.shape == b.shape and np.abs(a - b).max() < 1e-4 and np.array_equal(a[:, 7], b[:, 7])
+
+
+@pytest.mark.parametrize("n_pts", [0, 1, 37])
+def test_degenerate_frames_run_through_the_fp16_pipeline(pkg, weights, n_pts):
+    """Empty / one-point / few-point frames: every kernel of the fp16 frame (elastic row tiles, set attention with zero or
+    one set, convolutions over an empty BEV map, top-K / NMS on bias-only logits) returns, twice the same, with finite rows."""
+    P = pkg.plugin
+    c = pkg.pipeline.Caps.reference()
+    pipe = pkg.pipeline.DsvtPipeline(weights, caps=c, linear_compute=P.COMPUTE_F16, head_dtype=torch.float16, device_nms=True)
+    pts = np.zeros((1, c.N, 4), np.float32)
+    if n_pts:
+        pts[0, :n_pts] = pkg.synth.lidar_like(max(n_pts, 8), 3)[:n_pts]
+    outs = []
+    for _ in range(2):
+        rows, cnt = pipe.forward(torch.from_numpy(pts).to(DEV), torch.tensor([n_pts], dtype=torch.int32, device=DEV))
+        torch.cuda.synchronize()
+        outs.append((rows.clone(), int(cnt[0])))
+    assert outs[0][1] == outs[1][1] and 0 <= outs[0][1] <= 500
+    k = outs[0][1]
+    assert torch.equal(outs[0][0].reshape(-1, 9)[:k], outs[1][0].reshape(-1, 9)[:k])
+    assert torch.isfinite(outs[0][0].reshape(-1, 9)[:k]).all()
