@@ -269,3 +269,24 @@ def test_qkv_position_table_gather(pkg):
     again = P.Plugin.deserialize("DsvtLinearPlugin", op.serialize())(x, cnt, table, torch.from_numpy(c2d).to(DEV))[0]
     torch.cuda.synchronize()
     assert torch.equal(again[0, :n], ref[0, :n])
+
+
+@pytest.mark.parametrize("MR,n", [(65536, 34483), (65536, 39000), (65536, 50000), (8192, 100)])
+def test_qkv_rows_kernel_row_regimes(pkg, MR, n):
+    """The whole-row QKV kernel picks 8, 9 or 10 live waves of 16 rows from the device-side count (one workgroup per CU), and runs
+    eight-wave workgroups in rounds beyond 160 rows per CU: every regime against an fp32 torch product of the same fp16 operands."""
+    P = pkg.plugin
+    DEV = "cuda:0"
+    g = torch.Generator(device="cpu").manual_seed(MR + n)
+    C = 192
+    x = torch.randn((1, MR, C), generator=g).half().to(DEV)
+    pos = (torch.randn((1, MR, C), generator=g) * 0.5).half().to(DEV)
+    W = (torch.randn((3 * C, C), generator=g) / np.sqrt(C)); b = torch.randn(3 * C, generator=g) * 0.1
+    op = P.add_linear_op(W.numpy(), b.numpy(), MR, add_cols=2 * C, compute_type=P.COMPUTE_F16, input_half=True, output_mode=P.OUT_F16)
+    got = op(x, torch.tensor([n], dtype=torch.int32, device=DEV), pos)[0]
+    torch.cuda.synchronize()
+    Wd = W.half().float().to(DEV); xs = (x[0, :n] + pos[0, :n]).float(); xv = x[0, :n].float()
+    ref = torch.cat([xs @ Wd[:2 * C].T, xv @ Wd[2 * C:].T], 1) + b.to(DEV)
+    err = (got[0, :n].float() - ref).abs().max().item()
+    assert err < 2e-2 * ref.abs().max().item()
+    assert not got[0, n:].any()
