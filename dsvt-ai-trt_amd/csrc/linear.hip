@@ -45,9 +45,11 @@ __device__ __forceinline__ float geluFast(float x) {
     // tanh-GELU of the reference (gelu.cu:208-209) in fp32:  (0.5 + 0.5 tanh(u)) x  with
     // tanh(u) = 1 - 2 / (exp(2u) + 1)  =>  x * (1 - 1 / (exp(2u) + 1)).  exp overflow gives 1/inf = 0 -> x,
     // underflow gives 1/1 -> 0: both limits are the right ones.
-    const float B = 0.7978845608028654f, C = 0.035677408136300125f;
-    const float u = x * (C * x * x + B);
-    return x * (1.0f - __builtin_amdgcn_rcpf(__expf(2.0f * u) + 1.0f));
+    // 0.5 (1 + tanh u) = 1 / (1 + exp(-2u)),  u = x (B + C x^2):  seven VALU operations (the constants carry the -2 log2(e) of
+    // the exp2); exp2 -> inf gives 1/inf = 0 -> -0 for very negative x, exp2 -> 0 gives x: both limits are the right ones
+    const float Bn = -2.0f * 1.4426950408889634f * 0.7978845608028654f, Cn = -2.0f * 1.4426950408889634f * 0.035677408136300125f;
+    const float z = x * __builtin_fmaf(Cn, x * x, Bn);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
 }
 
 // sum over the 4 lane groups that share an activation row (lanes differing in bits 4..5)

@@ -41,9 +41,11 @@ constexpr int MLP_SMALL_MAX = 8192;        // rows beyond one tile per CU that a
 constexpr int MLP_SW = 1;                  // waves of a small workgroup, 32 rows each (two waves: 53.6 vs 50.1 us at 34.5k rows)
 
 __device__ __forceinline__ float mlpGelu(float x) {
-    const float B = 0.7978845608028654f, C = 0.035677408136300125f;
-    const float u = x * (C * x * x + B);
-    return x * (1.0f - __builtin_amdgcn_rcpf(__expf(2.0f * u) + 1.0f));
+    // 0.5 (1 + tanh u) = 1 / (1 + exp(-2u)),  u = x (B + C x^2):  seven VALU operations (the constants carry the -2 log2(e) of
+    // the exp2); exp2 -> inf gives 1/inf = 0 -> -0 for very negative x, exp2 -> 0 gives x: both limits are the right ones
+    const float Bn = -2.0f * 1.4426950408889634f * 0.7978845608028654f, Cn = -2.0f * 1.4426950408889634f * 0.035677408136300125f;
+    const float z = x * __builtin_fmaf(Cn, x * x, Bn);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
 }
 __device__ __forceinline__ float rowSum4m(float v) {
     v += __shfl_xor(v, 16, kWave); v += __shfl_xor(v, 32, kWave);
