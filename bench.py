@@ -15,8 +15,14 @@ Extra objects in the line:
   roofline      the dominant hand-written kernel (the MFMA linear kernel): algorithmic flops per
                 launch / average launch duration, measured with HIP events around every launch
                 during the timed steps, against the dense fp32-matrix peak of gfx950.
-  cpu_baseline  the CPU oracle (oracle/, a port of the reference's arithmetic) run on the host
-                cores of the same box on one frame of the same workload.
+  cpu_baseline  SURVEY 8(d): the reference's HOST path -- loadData + save_result + nms_cpu (include/helper.h:28-72,
+                257-283, 470-481; restated in oracle/dsvt_oracle.c) -- timed single-threaded (the reference is) on the
+                host cores of the same box, fed the FilterBoxByScore rows the GPU produced for the same frames; plus a
+                frame-parallel variant (one frame per thread, 32 frames), the CPU voxelize + partition restatement and the
+                whole network on the CPU oracle as extra keys.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks itself
+(torch.distributed.run, one process per GPU) and fails if fewer than N GPUs are visible.
 """
 import argparse
 import json
@@ -40,28 +46,94 @@ PMC_FILE = "r01_u_pmc_traffic.json"
 FRAME_POOL = 4                      # distinct synthetic clouds cycled through by the steps
 
 
-def cpu_baseline(pkg, weights, caps, points, n):
-    """The oracle (port of the reference arithmetic) on the host cores, one frame of the workload."""
-    from oracle import oracle as O, dense_ref as D
+def cpu_model():
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(caps, frames, n_parallel_frames=32, whole_network=None):
+    """SURVEY 8(d).  frames: [(points [n,4] float32 numpy, FilterBoxByScore rows [500,9] float32 numpy from the GPU, count)].
+    value = frames/s of the reference's host path, ONE thread: loadData (read the .bin, size check, zero-pad to the cap) +
+    save_result + nms_cpu on the GPU's own rows."""
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    O.lib()
+    tmp = tempfile.mkdtemp(prefix="dsvt_bench_")
+    paths = []
+    for i, (pts, _, _) in enumerate(frames):
+        paths.append(os.path.join(tmp, f"{i:06d}.bin"))
+        pts.astype(np.float32).tofile(paths[-1])
+
+    def host_path(i):
+        with open(paths[i % len(frames)], "rb") as fh:
+            raw = fh.read()
+        O.load_data(raw, caps.N)                                        # helper.h:28-72 + the zero-padded copy (:1909)
+        _, rows, cnt = frames[i % len(frames)]
+        return len(O.nms_cpu(rows, cnt, 0.01)[1])                         # save_result + nms_cpu (helper.h:257-283, 470-481)
+
+    host_path(0)
+    reps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 3.0 or reps < len(frames):
+        kept = host_path(reps); reps += 1
+    t_1 = (time.perf_counter() - t0) / reps
+    cores = os.cpu_count() or 1
+    nthr = min(cores, n_parallel_frames)
+    with ThreadPoolExecutor(nthr) as ex:                                # ctypes releases the GIL inside the C restatement
+        list(ex.map(host_path, range(nthr)))
+        t0 = time.perf_counter()
+        rounds = 0
+        while time.perf_counter() - t0 < 3.0:
+            list(ex.map(host_path, range(n_parallel_frames))); rounds += 1
+        t_par = (time.perf_counter() - t0) / (rounds * n_parallel_frames)
+    # context: the CPU restatement of the voxelizer + both partitions, one core
+    from oracle import dense_ref as D
     cfg = D.OracleCfg(max_points=caps.N, max_points_filter=caps.Nk, max_pillars=caps.P, max_win=caps.W,
-                      max_vox_per_win=caps.Vw)
+                      max_vox_per_win=caps.Vw, max_sets=caps.S)
+    pts0 = np.zeros((caps.N, 4), np.float32); n0 = frames[0][0].shape[0]; pts0[:n0] = frames[0][0]
     t0 = time.perf_counter()
-    vox = O.points2features(points, n, cfg.p2f)
+    vox = O.points2features(pts0, n0, cfg.p2f)
     for wc, gc in zip(cfg.wp, cfg.gs):
         wp = O.window_partition(vox["coords"], vox["P"], wc)
         O.get_set(wp["gidx"], wp["cinw"], wp["vcnt"], wp["W"], gc)
     t_pre = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    boxes, cnt = D.forward(points, n, weights, cfg)
-    t_frame = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    O.nms_cpu(boxes, cnt, 0.01)                       # include/helper.h:257-283, NMS_THRESH params.h:334
-    t_nms = time.perf_counter() - t0
-    return dict(value=round(1.0 / (t_frame + t_nms), 4), unit="frames/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"1 frame lidar_like({N_POINTS},0): whole network fp32 on the CPU oracle + host NMS "
-                       f"(dense layers on {torch.get_num_threads()} torch threads, plugin restatement on 1 core)",
-                frame_ms=round(1e3 * t_frame, 1), preprocess_voxelize_partition_ms_1core=round(1e3 * t_pre, 2),
-                nms_ms_1core=round(1e3 * t_nms, 3), boxes=int(cnt))
+    out = dict(value=round(1.0 / t_1, 2), unit="frames/s", cores=1, kind="port", cpu_model=cpu_model(), host_cores=cores,
+               sample=f"reference host path (loadData of a {frames[0][0].shape[0]}-point .bin zero-padded to {caps.N} + save_result + "
+                      f"nms_cpu on the {frames[0][2]} FilterBoxByScore rows the GPU produced), {reps} frames, 1 thread",
+               ms_per_frame=round(1e3 * t_1, 3), nms_kept=int(kept),
+               frame_parallel=dict(value=round(1.0 / t_par, 1), unit="frames/s", threads=nthr, frames=n_parallel_frames,
+                                   note="same host path, one frame per thread"),
+               preprocess_voxelize_partition_ms_1core=round(1e3 * t_pre, 2))
+    if whole_network is not None:
+        weights, = whole_network
+        t0 = time.perf_counter()
+        boxes, cnt = D.forward(pts0, n0, weights, cfg)
+        t_frame = time.perf_counter() - t0
+        out["whole_network_port"] = dict(value=round(1.0 / t_frame, 4), unit="frames/s", frame_ms=round(1e3 * t_frame, 1),
+                                         note=f"the whole network in fp32 on the CPU oracle, dense layers on {torch.get_num_threads()} "
+                                              "torch threads, plugin restatement on 1 core", boxes=int(cnt))
+    for p_ in paths:
+        os.remove(p_)
+    os.rmdir(tmp)
+    return out
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside torchrun: launch the N ranks (one process per GPU) and relay rank 0's JSON line"""
+    import socket
+    import subprocess
+    if not torch.cuda.is_available() or torch.cuda.device_count() < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {torch.cuda.device_count() if torch.cuda.is_available() else 0} GPU(s) visible")
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -83,20 +155,28 @@ def main():
     ap.add_argument("--host-input", action="store_true", help="frames start in pinned host memory and are uploaded (n x 16 B) inside the timed region: the PCIe-inclusive rate quoted in DESIGN.md, never the headline value")
     ap.add_argument("--no-nms", action="store_true", help="stop at FilterBoxByScore (the reference engine's output) instead of the final boxes")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline = null)")
+    ap.add_argument("--rccl-single", action="store_true", help="N = 1 only: create a communicator of size 1 so that the result gather "
+                                                               "really goes through RCCL (SURVEY 8e: exercising the collective on one device)")
+    ap.add_argument("--whole-network-cpu", action="store_true", help="cpu_baseline also runs the whole network on the CPU oracle (~10 s)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
 
     # one rank builds (the in-tree .so normally travels with the snapshot and this is a no-op); the others wait
     rank0 = int(os.environ.get("RANK", "0")) == 0
     if rank0:
         G.build()
     par = G._load_file("dsvt_parallel_boot", os.path.join(G.PKG_DIR, "parallel.py"))
-    rank, local_rank, world = par.init()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: n_gpus would not be the ranks that ran")
+    if torch.cuda.device_count() < int(os.environ.get("LOCAL_RANK", "0")) + 1:
+        raise SystemExit(f"bench.py: rank {os.environ.get('RANK')} has no GPU (only {torch.cuda.device_count()} visible)")
+    rank, local_rank, world = par.init(single_rank_group=args.rccl_single)
     par.barrier()
     pkg = G.load_package()
     par = pkg.parallel
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -155,6 +235,21 @@ def main():
                 for i in range(args.warmup):
                     run_frame(i * NS + s, scratch[s])
             torch.cuda.synchronize()
+    # the graph replay does the frame's work: one replay against one eager (op-by-op) run of the same frame, bit for bit
+    # (every kernel is deterministic), outside the timed region
+    replay_equals_eager = None
+    if use_graph:
+        replay_equals_eager = True
+        for s in range(NS):
+            with torch.cuda.stream(streams[s]):
+                pts, n = pool[(s + 1) % len(pool)]
+                eb, ec = [t.clone() for t in pipes[s].forward(pts, n)]
+                static_in[s][0].copy_(pts); static_in[s][1].copy_(n)
+                gb, gc = pipes[s].replay()
+                torch.cuda.synchronize()
+                replay_equals_eager = replay_equals_eager and bool(torch.equal(eb, gb)) and bool(torch.equal(ec, gc)) and int(ec[0]) > 0
+        if not replay_equals_eager:
+            raise SystemExit("bench.py: the HIP-graph replay of a frame differs from its eager run")
     # device-side counts of each pooled frame (for the algorithmic flop count), read outside the timed region
     counts = []
     for pts, n in pool:
@@ -185,7 +280,7 @@ def main():
         sampled += ev
     for s in streams:
         torch.cuda.current_stream().wait_stream(s)
-    gathered = par.gather_results(results, K * world, rank, world)          # the one collective of the path
+    gathered = par.gather_results(results, K * world, rank, world, force_collective=args.rccl_single)          # the one collective of the path
     par.barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     pkg.plugin.PROFILE = None
@@ -287,16 +382,29 @@ def main():
                                    "468x468 BEV, full 4-block DSVT pillar backbone + BEV ResNet + CenterHead + top-K decode + "
                                    "FilterBoxByScore" + ("" if args.no_nms else " + rotated NMS (final boxes)") + "; seeded random weights (dsvt.wts is not shipped)",
                        "frames_per_gpu": K, "parallelism": f"frame-batch dp{world}, one result gather",
+                       "frames": f"{min(FRAME_POOL, max(K, 1))} distinct clouds per rank, seeds rank * {FRAME_POOL} + i, cycled (BASELINE configs[3]: "
+                                 f"32 frames lidar_like(180000, 0..31), 4 per GPU on 8 GPUs)",
+                       "result_gather": ("rccl gather" if world > 1 else "rccl gather (communicator of size 1)" if args.rccl_single
+                                         else "none (single process)"),
+                       "graph_replay_equals_eager": replay_equals_eager,
                        "launch": "hip-graph replay per frame" if use_graph else "host launch per op",
                        "frames_in_flight": NS,
-                       "caps": dict(points=caps.N, pillars=caps.P, windows_sets=caps.W),
+                       "caps": dict(points=caps.N, pillars=caps.P, windows=caps.W, sets=caps.S, overflow_free=caps.overflow_free()),
                        "frame0": counts[0]},
             "roofline": roofline,
             "roofline_other_kernels": [r for _, r in roofline_all if r is not roofline],
         }
         if not args.no_cpu_baseline and world == 1:
-            p0 = pool[0][0][0].cpu().numpy()
-            line["cpu_baseline"] = cpu_baseline(pkg, weights, caps, p0, int(pool[0][1][0]))
+            # the FilterBoxByScore rows of the pooled frames as the GPU produced them (the reference's D2H payload)
+            frames = []
+            nms_op, pipe.nms = pipe.nms, None
+            for pts, n in pool:
+                fb = pipe.forward(pts, n)
+                torch.cuda.synchronize()
+                k = int(n[0])
+                frames.append((pts[0, :k].cpu().numpy(), fb[0][0].cpu().numpy().copy(), int(fb[1][0])))
+            pipe.nms = nms_op
+            line["cpu_baseline"] = cpu_baseline(caps, frames, whole_network=(weights,) if args.whole_network_cpu else None)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))

@@ -25,6 +25,12 @@ static DsvtPlugin* wrap(Plugin* p, const char* layerName) {
     return new DsvtPlugin{p};
 }
 
+// Nothing may unwind through the C boundary: every entry point that allocates or runs plugin code is wrapped, and a C++ exception
+// (std::bad_alloc from a weight copy, ...) becomes the entry point's failure value.
+#define DSVT_GUARD(fail, ...) try { __VA_ARGS__ } catch (...) { return fail; }
+constexpr int32_t kErrNullArg = -1;      // enqueue & co.: a required pointer was NULL
+constexpr int32_t kErrException = -3;    // a C++ exception was caught at the boundary
+
 extern "C" {
 
 int32_t dsvtGetNbPluginTypes(void) { return static_cast<int32_t>(registry().size()); }
@@ -34,63 +40,84 @@ const char* dsvtGetPluginTypeName(int32_t i) {
 }
 
 const DsvtPluginFieldCollection* dsvtGetFieldNames(const char* type, const char* version) {
-    Creator* c = findCreator(type, version);
-    if (!c) return nullptr;
-    if (c->fieldStore.empty()) {
-        for (const FieldDef& f : c->fields) c->fieldStore.push_back(DsvtPluginField{f.name, nullptr, f.type, 1});
-        c->fc.nbFields = static_cast<int32_t>(c->fieldStore.size());
-        c->fc.fields = c->fieldStore.data();
-    }
-    return &c->fc;
+    DSVT_GUARD(nullptr,
+        Creator* c = findCreator(type, version);
+        if (!c) return nullptr;
+        if (c->fieldStore.empty()) {
+            for (const FieldDef& f : c->fields) c->fieldStore.push_back(DsvtPluginField{f.name, nullptr, f.type, 1});
+            c->fc.nbFields = static_cast<int32_t>(c->fieldStore.size());
+            c->fc.fields = c->fieldStore.data();
+        }
+        return &c->fc;)
 }
 
 DsvtPlugin* dsvtCreatePlugin(const char* type, const char* version, const char* layerName,
                              const DsvtPluginFieldCollection* fc) {
-    Creator* c = findCreator(type, version);
-    return c ? wrap(c->create(fc), layerName) : nullptr;
+    DSVT_GUARD(nullptr,
+        Creator* c = findCreator(type, version);
+        if (!c || !fc || fc->nbFields < 0 || (fc->nbFields > 0 && !fc->fields)) return nullptr;
+        fieldError() = false;
+        Plugin* p = c->create(fc);
+        if (p && fieldError()) { delete p; p = nullptr; }      // an array field shorter than what the creator reads
+        return wrap(p, layerName);)
 }
 
 DsvtPlugin* dsvtDeserializePlugin(const char* type, const char* version, const char* layerName,
                                   const void* data, size_t len) {
-    Creator* c = findCreator(type, version);
-    return (c && data) ? wrap(c->deserialize(data, len), layerName) : nullptr;
+    DSVT_GUARD(nullptr,
+        Creator* c = findCreator(type, version);
+        return (c && data) ? wrap(c->deserialize(data, len), layerName) : nullptr;)
 }
 
-const char* dsvtPluginGetType(const DsvtPlugin* p) { return p->impl->type(); }
+const char* dsvtPluginGetType(const DsvtPlugin* p) { return p ? p->impl->type() : nullptr; }
 const char* dsvtPluginGetVersion(const DsvtPlugin*) { return DSVT_PLUGIN_VERSION; }
-int32_t dsvtPluginGetNbOutputs(const DsvtPlugin* p) { return p->impl->nbOutputs(); }
+int32_t dsvtPluginGetNbOutputs(const DsvtPlugin* p) { return p ? p->impl->nbOutputs() : kErrNullArg; }
 
 int32_t dsvtPluginGetOutputDimensions(const DsvtPlugin* p, int32_t idx, const DsvtDims* in, int32_t nbIn, DsvtDims* out) {
-    return p->impl->outputDims(idx, in, nbIn, out);
+    if (!p || !out || (nbIn > 0 && !in)) return kErrNullArg;
+    DSVT_GUARD(kErrException, return p->impl->outputDims(idx, in, nbIn, out);)
 }
 int32_t dsvtPluginGetOutputDataType(const DsvtPlugin* p, int32_t idx, const int32_t* inTypes, int32_t nbIn) {
-    return p->impl->outputType(idx, inTypes, nbIn);
+    if (!p || (nbIn > 0 && !inTypes)) return kErrNullArg;
+    DSVT_GUARD(kErrException, return p->impl->outputType(idx, inTypes, nbIn);)
 }
 int32_t dsvtPluginSupportsFormatCombination(const DsvtPlugin* p, int32_t pos, const DsvtPluginTensorDesc* io,
                                             int32_t nbIn, int32_t nbOut) {
-    return p->impl->supportsFormat(pos, io, nbIn, nbOut) ? 1 : 0;
+    if (!p || !io || pos < 0 || pos >= nbIn + nbOut) return 0;
+    DSVT_GUARD(0, return p->impl->supportsFormat(pos, io, nbIn, nbOut) ? 1 : 0;)
 }
 size_t dsvtPluginGetWorkspaceSize(const DsvtPlugin* p, const DsvtPluginTensorDesc* in, int32_t nbIn,
                                   const DsvtPluginTensorDesc* out, int32_t nbOut) {
-    return p->impl->workspaceSize(in, nbIn, out, nbOut);
+    if (!p) return 0;
+    DSVT_GUARD(0, return p->impl->workspaceSize(in, nbIn, out, nbOut);)
 }
 int32_t dsvtPluginEnqueue(DsvtPlugin* p, const DsvtPluginTensorDesc* inDesc, const DsvtPluginTensorDesc* outDesc,
                           const void* const* inputs, void* const* outputs, void* ws, dsvtStream_t stream) {
-    return p->impl->enqueue(inDesc, outDesc, inputs, outputs, ws, reinterpret_cast<hipStream_t>(stream));
+    if (!p || !inputs || !outputs) return kErrNullArg;
+    DSVT_GUARD(kErrException, return p->impl->enqueue(inDesc, outDesc, inputs, outputs, ws, reinterpret_cast<hipStream_t>(stream));)
 }
-size_t dsvtPluginGetSerializationSize(const DsvtPlugin* p) { return p->impl->serializationSize(); }
-void dsvtPluginSerialize(const DsvtPlugin* p, void* buf) { p->impl->serialize(buf); }
+size_t dsvtPluginGetSerializationSize(const DsvtPlugin* p) {
+    if (!p) return 0;
+    DSVT_GUARD(0, return p->impl->serializationSize();)
+}
+void dsvtPluginSerialize(const DsvtPlugin* p, void* buf) {
+    if (!p || !buf) return;
+    try { p->impl->serialize(buf); } catch (...) {}
+}
 DsvtPlugin* dsvtPluginClone(const DsvtPlugin* p) {
-    Plugin* c = p->impl->clone();
-    c->zeroFill = p->impl->zeroFill;
-    return wrap(c, p->impl->layerName.c_str());
+    if (!p) return nullptr;
+    DSVT_GUARD(nullptr,
+        Plugin* c = p->impl->clone();
+        if (!c) return nullptr;
+        c->zeroFill = p->impl->zeroFill;
+        return wrap(c, p->impl->layerName.c_str());)
 }
 void dsvtPluginDestroy(DsvtPlugin* p) {
     if (!p) return;
-    delete p->impl;
+    try { delete p->impl; } catch (...) {}
     delete p;
 }
-void dsvtPluginSetZeroFill(DsvtPlugin* p, int32_t enable) { p->impl->zeroFill = enable != 0; }
+void dsvtPluginSetZeroFill(DsvtPlugin* p, int32_t enable) { if (p) p->impl->zeroFill = enable != 0; }
 const char* dsvtGetBuildInfo(void) { return "libdsvt_hip gfx950 (CDNA4) hand-written HIP, built " __DATE__; }
 
 }  // extern "C"

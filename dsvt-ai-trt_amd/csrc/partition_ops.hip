@@ -295,7 +295,9 @@ static Registrar g_wpReg(&g_wpCreator);
 // =====================================================================================
 // GetSet
 // =====================================================================================
-struct GSParams { int max_win_num, max_voxel_num_per_win, voxel_num_set, wx, wy, wz, num_heads; };
+// max_set_num: capacity of the SET dimension of the outputs.  The reference sizes it with MAX_WIN_NUM too (getSet.cu:147,242); a frame has up
+// to ceil(P / 36) + W sets, so the pipeline sizes it separately (non-reference field "max_set_num", default = max_win_num).
+struct GSParams { int max_win_num, max_voxel_num_per_win, voxel_num_set, wx, wy, wz, num_heads, max_set_num; };
 
 __device__ __forceinline__ uint32_t setsOf(uint32_t n, uint32_t L) { return (uint32_t)(int)ceilf((float)n / (float)(int)L); }   // getSet.cu:335
 
@@ -316,7 +318,7 @@ gs_scan(const uint32_t* __restrict__ vcnt, const uint32_t* __restrict__ win_num,
         uint32_t base = blockExclusiveScan<1024>(ns, smem, &tot) + carry; carry += tot;
         if (w < W) {
             // capacity guard the reference lacks (:337): the set list stops at the first window that does not fit
-            bool ok = base + ns <= (uint32_t)p.max_win_num;
+            bool ok = base + ns <= (uint32_t)p.max_set_num;
             set_base[w] = ok ? base : kNoneU;
             if (ok && ns) atomicMax(&smax, base + ns);
         }
@@ -338,7 +340,7 @@ gs_sets(const uint32_t* __restrict__ gidx, const uint32_t* __restrict__ cinw, co
     if (w >= W) return;
     const uint32_t base = set_base[w];
     if (base == kNoneU) return;
-    const uint32_t Vw = p.max_voxel_num_per_win, L = p.voxel_num_set, MW = p.max_win_num;
+    const uint32_t Vw = p.max_voxel_num_per_win, L = p.voxel_num_set, MW = p.max_set_num;
     const uint32_t n = vcnt[w] < Vw ? vcnt[w] : Vw;
     const uint32_t vol = (uint32_t)(p.wx * p.wy * p.wz);
     uint32_t* ty = lds;             // [vol]  key_y -> voxel id
@@ -400,9 +402,9 @@ public:
     int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
         int b = in[0].d[0];
         switch (i) {
-            case 0: case 1: *out = dims4(b, 2, p_.max_win_num, p_.voxel_num_set); return 0;
+            case 0: case 1: *out = dims4(b, 2, p_.max_set_num, p_.voxel_num_set); return 0;
             case 2: *out = dims1(b); return 0;
-            case 3: case 4: *out = dims4(b, p_.max_win_num, p_.num_heads, p_.voxel_num_set); return 0;
+            case 3: case 4: *out = dims4(b, p_.max_set_num, p_.num_heads, p_.voxel_num_set); return 0;
         }
         return -1;
     }
@@ -427,7 +429,7 @@ public:
         float* m1 = static_cast<float*>(out[4]);
         uint32_t* set_base = static_cast<uint32_t*>(workspace);
         if (zeroFill) {                                                                // getSet.cu:681-686
-            size_t e = (size_t)2 * p_.max_win_num * p_.voxel_num_set, eh = (size_t)p_.max_win_num * p_.num_heads * p_.voxel_num_set;
+            size_t e = (size_t)2 * p_.max_set_num * p_.voxel_num_set, eh = (size_t)p_.max_set_num * p_.num_heads * p_.voxel_num_set;
             DSVT_CHECK(hipMemsetAsync(inds, 0, sizeof(uint32_t) * e, stream));
             DSVT_CHECK(hipMemsetAsync(mask, 0, sizeof(float) * e, stream));
             DSVT_CHECK(hipMemsetAsync(m0, 0, sizeof(float) * eh, stream));
@@ -438,16 +440,20 @@ public:
         hipLaunchKernelGGL(gs_sets, dim3(p_.max_win_num), dim3(256), lds, stream, gidx, cinw, vcnt, win_num, set_base, p_, inds, mask, m0, m1);
         return lastError();
     }
-    size_t serializationSize() const override { return 6 * sizeof(int); }
-    void serialize(void* b) const override {                                           // getSet.cu:749-758
+    // the reference's six ints (getSet.cu:749-758); a seventh only when the set capacity differs from the window capacity
+    bool ownSetCap() const { return p_.max_set_num != p_.max_win_num; }
+    size_t serializationSize() const override { return (ownSetCap() ? 7 : 6) * sizeof(int); }
+    void serialize(void* b) const override {
         char* d = static_cast<char*>(b);
         wr<int>(d, p_.voxel_num_set); wr<int>(d, p_.max_win_num); wr<int>(d, p_.max_voxel_num_per_win);
         wr<int>(d, p_.wx); wr<int>(d, p_.wy); wr<int>(d, p_.wz);
+        if (ownSetCap()) wr<int>(d, p_.max_set_num);
     }
     Plugin* clone() const override { return new GetSetPlugin(p_); }
 };
 static Plugin* gsNew(GSParams p) {
     p.num_heads = 8;                                                                   // NUM_HEADS, include/params.h:73
+    if (p.max_set_num <= 0) p.max_set_num = p.max_win_num;
     if (p.max_win_num <= 0 || p.max_voxel_num_per_win <= 0 || p.voxel_num_set <= 0 || p.wx <= 0 || p.wy <= 0 || p.wz <= 0) return nullptr;
     size_t lds = sizeof(uint32_t) * (2 * (size_t)p.wx * p.wy * p.wz + 2 * (size_t)p.max_voxel_num_per_win);
     if (lds > 150 * 1024) return nullptr;
@@ -458,6 +464,7 @@ static Plugin* gsCreate(const DsvtPluginFieldCollection* fc) {
     p.max_win_num = fieldInt(fc, "max_win_num"); p.max_voxel_num_per_win = fieldInt(fc, "max_voxel_num_per_win");
     p.voxel_num_set = fieldInt(fc, "voxel_num_set"); fieldInts(fc, "win_shape", w, 3);
     p.wx = w[0]; p.wy = w[1]; p.wz = w[2];
+    p.max_set_num = fieldInt(fc, "max_set_num", 0);
     return gsNew(p);
 }
 static Plugin* gsDeser(const void* data, size_t len) {
@@ -465,6 +472,7 @@ static Plugin* gsDeser(const void* data, size_t len) {
     const char* d = static_cast<const char*>(data); GSParams p{};
     p.voxel_num_set = rd<int>(d); p.max_win_num = rd<int>(d); p.max_voxel_num_per_win = rd<int>(d);
     p.wx = rd<int>(d); p.wy = rd<int>(d); p.wz = rd<int>(d);
+    if (len >= 7 * sizeof(int)) p.max_set_num = rd<int>(d);
     return gsNew(p);
 }
 static Creator g_gsCreator{"GetSetPlugin",

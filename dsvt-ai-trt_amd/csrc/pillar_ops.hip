@@ -334,10 +334,9 @@ static Plugin* lnCreate(const DsvtPluginFieldCollection* fc) {
     // createPlugin reads "eps" (:558) and its factory only forwards names the creator
     // advertises (plugin_helper.h:527) -- so eps never arrives and stays 0.  Same here:
     // "pes" is advertised, "eps" is honoured if a caller does pass it.
-    const DsvtPluginField* w = findField(fc, "weights"); const DsvtPluginField* b = findField(fc, "bias");
-    return lnNew(fieldInt(fc, "max_pillars_num"), fieldInt(fc, "channel_num"), fieldInt(fc, "weights_size"),
-                 fieldFloat(fc, "eps", 0.0f), w ? static_cast<const float*>(w->data) : nullptr,
-                 b ? static_cast<const float*>(b->data) : nullptr);
+    const int ws = fieldInt(fc, "weights_size");
+    return lnNew(fieldInt(fc, "max_pillars_num"), fieldInt(fc, "channel_num"), ws,
+                 fieldFloat(fc, "eps", 0.0f), fieldFloatArray(fc, "weights", ws), fieldFloatArray(fc, "bias", ws));
 }
 static Plugin* lnDeser(const void* data, size_t len) {
     if (len < 3 * sizeof(int) + sizeof(float)) return nullptr;

@@ -76,13 +76,32 @@ inline float fieldFloat(const DsvtPluginFieldCollection* fc, const char* name, f
     const DsvtPluginField* f = findField(fc, name);
     return (f && f->data) ? static_cast<const float*>(f->data)[0] : def;
 }
+// Array fields.  The reference's factories pass length = 1 even for arrays (include/plugin_helper.h:92-104) and its creators read
+// a fixed number of elements, so length <= 1 means "unspecified" here too; a caller that DOES state a length states the truth, and a
+// field shorter than what the creator reads is an error (fieldError() makes dsvtCreatePlugin return NULL instead of reading past it).
+inline bool& fieldError() { static thread_local bool e = false; return e; }
+inline bool fieldHolds(const DsvtPluginField* f, long n) {
+    if (f && f->data && f->length > 1 && f->length < n) { fieldError() = true; return false; }
+    return f && f->data;
+}
 inline void fieldInts(const DsvtPluginFieldCollection* fc, const char* name, int* out, int n) {
     const DsvtPluginField* f = findField(fc, name);
-    for (int i = 0; i < n; ++i) out[i] = (f && f->data) ? static_cast<const int*>(f->data)[i] : 0;
+    const bool ok = fieldHolds(f, n);
+    for (int i = 0; i < n; ++i) out[i] = ok ? static_cast<const int*>(f->data)[i] : 0;
 }
 inline void fieldFloats(const DsvtPluginFieldCollection* fc, const char* name, float* out, int n) {
     const DsvtPluginField* f = findField(fc, name);
-    for (int i = 0; i < n; ++i) out[i] = (f && f->data) ? static_cast<const float*>(f->data)[i] : 0.f;
+    const bool ok = fieldHolds(f, n);
+    for (int i = 0; i < n; ++i) out[i] = ok ? static_cast<const float*>(f->data)[i] : 0.f;
+}
+// pointer to an n-element float / int array field, or nullptr (absent, or shorter than n)
+inline const float* fieldFloatArray(const DsvtPluginFieldCollection* fc, const char* name, long n) {
+    const DsvtPluginField* f = findField(fc, name);
+    return fieldHolds(f, n) ? static_cast<const float*>(f->data) : nullptr;
+}
+inline const int* fieldIntArray(const DsvtPluginFieldCollection* fc, const char* name, long n) {
+    const DsvtPluginField* f = findField(fc, name);
+    return fieldHolds(f, n) ? static_cast<const int*>(f->data) : nullptr;
 }
 
 // writeToBuffer / readFromBuffer, as in e.g. plugins/src/getSet.cu:45-59

@@ -71,7 +71,7 @@ def run_directory(data_dir, out_dir, weights, caps=None, fp16=True, device="cuda
 
 def load_weights(wts=None, seed=1234, log=print):
     if wts:
-        return synth.read_wts(wts)
+        return synth.shape_weights(synth.read_wts(wts))      # the file holds flat tensors; the pipeline needs shapes
     log(f"no --wts given: seeded synthetic weights (seed {seed}); the boxes are meaningless but the path is the real one")
     return synth.make_weights(seed)
 

@@ -20,12 +20,15 @@ def env_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def init(backend=None):
+def init(backend=None, single_rank_group=False):
     """Join the job described by RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  No-op for a
-    single process."""
+    single process unless single_rank_group: then a communicator of size 1 is created so that the
+    result gather really goes through the collective library (RCCL on a GPU box) -- how the
+    collective is exercised when only one GPU is visible."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -50,11 +53,12 @@ def unpack_result(row):
     return row[:ROW - 1].reshape(500, 9), int(round(float(row[ROW - 1])))
 
 
-def gather_results(local, n_frames, rank, world, dst=0):
+def gather_results(local, n_frames, rank, world, dst=0, force_collective=False):
     """local: [frames_of_this_rank, ROW].  Returns on `dst` a [n_frames, ROW] tensor in global frame
     order (None elsewhere).  One gather for the whole batch; ranks may own a different number of
-    frames, so rows are padded to the maximum."""
-    if world == 1:
+    frames, so rows are padded to the maximum.  A single process skips the collective unless
+    force_collective (needs init(single_rank_group=True))."""
+    if world == 1 and not (force_collective and dist.is_initialized()):
         return local
     per = (n_frames + world - 1) // world
     pad = torch.zeros((per, ROW), dtype=local.dtype, device=local.device)

@@ -38,12 +38,29 @@ class Caps:
     """Runtime replacement of the reference's compile-time caps (include/params.h:24-27,68-69)."""
 
     def __init__(self, max_points=196608, max_points_filter=196608, max_pillars=65536, max_win=2048,
-                 max_vox_per_win=576):
+                 max_vox_per_win=576, max_sets=None):
+        """max_sets: capacity of the set dimension (GetSet / attention).  The reference sizes it with MAX_WIN_NUM
+        (plugins/src/getSet.cu:147,242); a frame holds sum_w ceil(n_w / 36) <= ceil(P / 36) + W sets, so the default is that bound
+        (rounded up to 1024): with it, and max_win >= the number of window cells of the grid, GetSet can never truncate."""
         self.N, self.Nk, self.P, self.W, self.Vw = max_points, max_points_filter, max_pillars, max_win, max_vox_per_win
+        if max_sets is None:
+            max_sets = -(-(-(-max_pillars // L_SET) + min(max_win, self.max_windows_of_grid())) // 1024) * 1024
+        self.S = max_sets
+
+    @staticmethod
+    def max_windows_of_grid():
+        """window cells of the densest configuration: nwx * nwy with nw = int(ceil(G / w) + 1) on INTEGER G / w (windowPartition.cu:425-427)"""
+        return max((int(math.ceil(GX // wx) + 1)) * (int(math.ceil(GY // wy) + 1)) for (wx, wy, _), _s in WINS)
+
+    def overflow_free(self):
+        """True when no frame that fits max_pillars can overflow the window or set capacity (nothing is silently dropped)"""
+        nw = self.max_windows_of_grid()
+        return self.W >= nw and self.S >= -(-self.P // L_SET) + nw and self.Vw >= max(wx * wy * wz for (wx, wy, wz), _s in WINS)
 
     @classmethod
     def reference(cls):
-        return cls(50000, 30000, 10000, 800, 576)
+        """include/params.h:24-27,68-69: the set capacity is MAX_WIN_NUM there"""
+        return cls(50000, 30000, 10000, 800, 576, max_sets=800)
 
 
 def bn_fold(w, prefix, eps):
@@ -105,7 +122,7 @@ class DsvtPipeline:
         self.smax0 = zf(P.add_torch_scatter_max(c.Nk, c.P, 96))
         self.smax1 = zf(P.add_torch_scatter_max(c.Nk, c.P, 192))
         self.wp = [zf(P.add_window_partition(c.W, c.Vw, GX, GY, GZ, *win, *shift)) for win, shift in WINS]
-        self.gs = [zf(P.add_get_set_op(c.W, c.Vw, L_SET, *win)) for win, _ in WINS]
+        self.gs = [zf(P.add_get_set_op(c.W, c.Vw, L_SET, *win, max_set_num=c.S)) for win, _ in WINS]
         self.pe, self.layers, self.res_ln = {}, {}, {}
         scale = np.float32(math.sqrt(C / H))
         for b in range(blocks):
@@ -131,7 +148,7 @@ class DsvtPipeline:
                     self.layers[(b, l)] = L_ = dict(
                         qkv=zf(P.add_linear_op(wi, bi, c.P, add_cols=2 * C, **ct, **h_in, **o16,
                                                add_gather_width=WINS[l][0][0] if self.pos_table else 0)),
-                        attn=zf(P.add_set_attention_op(c.W, L_SET, C, H, l, c.P, io_half=f16)),
+                        attn=zf(P.add_set_attention_op(c.S, L_SET, C, H, l, c.P, io_half=f16)),
                         mlp=zf(P.add_encoder_mlp_op(w[lp + ".win_attn.self_attn.out_proj.weight"], w[lp + ".win_attn.self_attn.out_proj.bias"],
                                                     w[lp + ".win_attn.linear1.weight"], w[lp + ".win_attn.linear1.bias"],
                                                     w[lp + ".win_attn.linear2.weight"], w[lp + ".win_attn.linear2.bias"],
@@ -140,7 +157,7 @@ class DsvtPipeline:
                     continue
                 self.layers[(b, l)] = dict(
                     qkv=zf(P.add_linear_op(wi, bi, c.P, add_cols=2 * C, **ct, **h_in, **o16)),
-                    attn=zf(P.add_set_attention_op(c.W, L_SET, C, H, l, c.P, io_half=f16)),
+                    attn=zf(P.add_set_attention_op(c.S, L_SET, C, H, l, c.P, io_half=f16)),
                     out=zf(P.add_linear_op(w[lp + ".win_attn.self_attn.out_proj.weight"],
                                            w[lp + ".win_attn.self_attn.out_proj.bias"], c.P,
                                            layer_norms=[ln(".win_attn.norm1")], ln_eps=ln_eps, **ct, **h_in, **oboth)),

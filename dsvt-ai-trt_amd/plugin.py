@@ -344,11 +344,14 @@ def add_window_partition(max_win_num, max_voxel_num_per_win, sparse_shape_x, spa
         "window_partition_layer")
 
 
-def add_get_set_op(max_win_num, max_voxel_num_per_win, voxel_num_set, win_shape_x, win_shape_y, win_shape_z):
-    """plugin_helper.h:253-314.  Inputs: gidx, cinw, vcnt, win_num."""
-    return Plugin("GetSetPlugin", dict(max_win_num=max_win_num, max_voxel_num_per_win=max_voxel_num_per_win,
-                                       voxel_num_set=voxel_num_set,
-                                       win_shape=[win_shape_x, win_shape_y, win_shape_z]), "get_set_layer")
+def add_get_set_op(max_win_num, max_voxel_num_per_win, voxel_num_set, win_shape_x, win_shape_y, win_shape_z, max_set_num=None):
+    """plugin_helper.h:253-314.  Inputs: gidx, cinw, vcnt, win_num.
+    max_set_num (not in the reference, whose set dimension is MAX_WIN_NUM too): capacity of the set dimension of the outputs."""
+    f = dict(max_win_num=max_win_num, max_voxel_num_per_win=max_voxel_num_per_win, voxel_num_set=voxel_num_set,
+             win_shape=[win_shape_x, win_shape_y, win_shape_z])
+    if max_set_num is not None and max_set_num != max_win_num:
+        f["max_set_num"] = int(max_set_num)
+    return Plugin("GetSetPlugin", f, "get_set_layer")
 
 
 def add_get_value_by_index_op(max_win_num, voxel_num_set, channel_num, axis_id):

@@ -161,11 +161,32 @@ def write_wts(path, weights):
         f.write(f"{len(weights)}\n")
         for k, v in weights.items():
             flat = np.asarray(v, np.float32).reshape(-1)
-            f.write(f"{k} {flat.size}")
-            be = flat.astype(">f4").tobytes()
-            for i in range(flat.size):
-                f.write(" " + be[4 * i:4 * i + 4].hex())
-            f.write("\n")
+            hx = flat.astype(">f4").tobytes().hex()
+            f.write(f"{k} {flat.size} " + " ".join(hx[i:i + 8] for i in range(0, len(hx), 8)) + "\n")
+
+
+def weight_shapes(blocks=4):
+    """name -> shape of every tensor the pipeline consumes (the wiring of src/dsvt-ai-trt.cpp:577-1468)"""
+    return {k: v.shape for k, v in make_weights(0, blocks).items()}
+
+
+def shape_weights(flat, blocks=4):
+    """`.wts` tensors are flat (the file carries element counts only, tools/gen_wts.py:93-99; the reference hands them to TensorRT
+    layers whose dimensions come from include/params.h).  Gives every tensor the pipeline consumes its shape, drops the
+    state_dict entries it does not use (num_batches_tracked, the dead iou head's statistics, ...) and refuses a file whose
+    element counts do not fit the architecture."""
+    out, missing = {}, []
+    for name, shape in weight_shapes(blocks).items():
+        if name not in flat:
+            missing.append(name)
+            continue
+        a = np.asarray(flat[name], np.float32)
+        if a.size != int(np.prod(shape)):
+            raise ValueError(f"{name}: {a.size} elements in the file, the architecture needs {shape}")
+        out[name] = a.reshape(shape)
+    if missing:
+        raise KeyError(f"{len(missing)} tensors missing from the weight file, e.g. {missing[:3]}")
+    return out
 
 
 def read_wts(path):

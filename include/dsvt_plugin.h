@@ -124,7 +124,9 @@ const char* dsvtGetPluginTypeName(int32_t index);
 const DsvtPluginFieldCollection* dsvtGetFieldNames(const char* pluginType, const char* pluginVersion);
 
 /* IPluginCreator::createPlugin(name, fc), e.g. plugins/src/points2Features.cu:1113-1195.
- * Returns NULL on unknown type/version or invalid fields. */
+ * Returns NULL on unknown type/version, NULL fc, or invalid fields -- including an array field
+ * whose stated length (> 1) is shorter than the number of elements the creator reads; length
+ * <= 1 is taken as "unspecified" because the reference's factories pass 1 for every field. */
 DsvtPlugin* dsvtCreatePlugin(const char* pluginType, const char* pluginVersion, const char* layerName,
                              const DsvtPluginFieldCollection* fc);
 
@@ -161,7 +163,10 @@ size_t dsvtPluginGetWorkspaceSize(const DsvtPlugin* p, const DsvtPluginTensorDes
  * Points2FeaturesPlugin::enqueue plugins/src/points2Features.cu:896-990.
  * All pointers are device pointers owned by the caller; work is issued asynchronously on
  * `stream`; no host synchronisation happens inside.  Returns 0 on success; a HIP launch
- * error returns its hipError_t value (the reference abort()s instead). */
+ * error returns its hipError_t value (> 0; the reference abort()s instead); -1 = a required
+ * pointer (plugin, inputs, outputs) is NULL; -2 = unsupported tensor shape (batch != 1, like
+ * the reference, whose kernels ignore the batch dimension: points2Features.cu:678,900); -3 = a
+ * C++ exception was caught at the boundary (nothing ever unwinds into the caller). */
 int32_t dsvtPluginEnqueue(DsvtPlugin* p, const DsvtPluginTensorDesc* inputDesc, const DsvtPluginTensorDesc* outputDesc,
                           const void* const* inputs, void* const* outputs, void* workspace, dsvtStream_t stream);
 

@@ -79,7 +79,7 @@ class OracleCfg:
     """Runtime caps (the reference's params.h macros) for one pipeline instance."""
 
     def __init__(self, max_points=50000, max_points_filter=30000, max_pillars=10000, max_win=800,
-                 max_vox_per_win=576, top_k=500, score_threshold=0.3, ln_eps=0.0, blocks=4):
+                 max_vox_per_win=576, top_k=500, score_threshold=0.3, ln_eps=0.0, blocks=4, max_sets=None):
         self.p2f = dict(max_points_num=max_points, max_points_num_voxel_filter=max_points_filter,
                         max_pillars_num=max_pillars, point_feature_num=4, feature_num=10,
                         max_num_points_per_voxel=48,
@@ -91,7 +91,8 @@ class OracleCfg:
                    dict(max_win_num=max_win, max_voxel_num_per_win=max_vox_per_win,
                         sparse_shape=[468, 468, 1], win_shape=[24, 24, 1], shift_list=[6, 6, 0],
                         max_pillars_num=max_pillars)]
-        self.gs = [dict(max_win_num=max_win, max_voxel_num_per_win=max_vox_per_win, voxel_num_set=36,
+        # the reference sizes the set dimension with MAX_WIN_NUM (getSet.cu:147,242); max_sets only enlarges that dimension
+        self.gs = [dict(max_win_num=max_sets or max_win, max_voxel_num_per_win=max_vox_per_win, voxel_num_set=36,
                         win_shape=c["win_shape"]) for c in self.wp]
         self.fb = dict(max_top_k=top_k, point_cloud_range=[-74.88, 74.88, -74.88, 74.88, -5.0, 3.0],
                        voxel_size=[0.32, 0.32, 8.0], score_threshold=score_threshold)

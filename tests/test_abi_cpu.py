@@ -106,6 +106,49 @@ def test_output_dimensions_and_types(pkg):
         P.add_voxel_generator(50000, 30000, 10000, 4, 10, 100, -1, 1, -1, 1, -1, 1, 0.1, 0.1, 1, 20, 20, 1)   # > 64 points per pillar unsupported
 
 
+def test_null_arguments_and_short_fields_are_rejected(pkg):
+    """C boundary hygiene: NULL handles / pointer arrays give an error code instead of a crash; an array field that states a length
+    shorter than what the creator reads makes createPlugin return NULL (length 1 = "unspecified", the reference's own habit,
+    include/plugin_helper.h:92-104, is still accepted)."""
+    P = pkg.plugin
+    L = P.LIB
+    assert L.dsvtPluginEnqueue(None, None, None, None, None, None, None) == -1
+    assert L.dsvtPluginGetNbOutputs(None) == -1
+    assert L.dsvtPluginGetSerializationSize(None) == 0
+    assert not L.dsvtPluginClone(None)
+    assert not L.dsvtCreatePlugin(b"GeluPlugin", b"1", b"x", None)
+    L.dsvtPluginDestroy(None); L.dsvtPluginSerialize(None, None); L.dsvtPluginSetZeroFill(None, 1)
+    op = P.add_gelu_op(16, 8)
+    assert L.dsvtPluginEnqueue(op._h, None, None, None, None, None, None) == -1
+    out = P.Dims()
+    assert L.dsvtPluginGetOutputDimensions(op._h, 0, None, 1, ctypes.byref(out)) == -1
+
+    def create(ptype, fields):
+        keep, fl = [], []
+        for name, arr, length in fields:
+            arr = np.ascontiguousarray(arr); keep.append(arr)
+            fl.append(P.PluginField(name.encode(), arr.ctypes.data, P.FIELD_INT32 if arr.dtype == np.int32 else P.FIELD_FLOAT32, length))
+        fc = P.PluginFieldCollection(len(fl), (P.PluginField * len(fl))(*fl))
+        h = L.dsvtCreatePlugin(ptype.encode(), b"1", b"t", ctypes.byref(fc))
+        if h:
+            L.dsvtPluginDestroy(ctypes.c_void_p(h))
+        return bool(h)
+
+    i = lambda *v: np.asarray(v, np.int32)
+    f = lambda *v: np.asarray(v, np.float32)
+    fb = lambda rng_len: [("max_top_k", i(500), 1), ("point_cloud_range", f(-74.88, 74.88, -74.88, 74.88, -5.0, 3.0), rng_len),
+                          ("voxel_size", f(0.32, 0.32, 8.0), 3), ("score_threshold", f(0.3), 1)]
+    assert create("FilterBoxByScorePlugin", fb(6))
+    assert create("FilterBoxByScorePlugin", fb(1))            # the reference's factories say 1 for every field
+    assert not create("FilterBoxByScorePlugin", fb(3))        # states 3 floats, the creator reads 6
+    wp = lambda n: [("max_win_num", i(800), 1), ("max_voxel_num_per_win", i(576), 1), ("sparse_shape", i(468, 468, 1), 3),
+                    ("win_shape", i(12, 12, 1), n), ("shift_list", i(0, 0, 0), 3)]
+    assert create("WindowPartitionPlugin", wp(3)) and not create("WindowPartitionPlugin", wp(2))
+    ln = lambda n: [("max_pillars_num", i(100), 1), ("channel_num", i(192), 1), ("weights_size", i(192), 1),
+                    ("weights", np.ones(192, np.float32), n), ("bias", np.zeros(192, np.float32), 192)]
+    assert create("LayerNormPlugin", ln(192)) and not create("LayerNormPlugin", ln(64))
+
+
 def test_no_cpu_path(pkg):
     """The product path refuses host tensors instead of silently computing somewhere else."""
     import torch

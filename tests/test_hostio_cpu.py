@@ -28,3 +28,25 @@ def test_save_txt_format(pkg, tmp_path):
     assert lines[2].split(",  ")[7] == "9" and lines[2].endswith("0.300001")
     assert lines[3] == "" and len(lines) == 4
     assert pkg.hostio.format_results(np.zeros((0, 9), np.float32), 1.0) == "1.000000\n"
+
+
+def test_wts_file_to_shaped_weights(pkg, tmp_path):
+    """detect.load_weights: a .wts file (flat tensors, tools/gen_wts.py:86-99) -> the shaped dict DsvtPipeline consumes; extra
+    state_dict keys are dropped, a tensor of the wrong size is refused."""
+    w = pkg.synth.make_weights(blocks=1)
+    extra = dict(w)
+    extra["module.vfe.pfn_layers.0.norm.num_batches_tracked"] = np.zeros(1, np.float32)
+    path = str(tmp_path / "dsvt.wts")
+    pkg.synth.write_wts(path, extra)
+    flat = pkg.synth.read_wts(path)
+    assert all(v.ndim == 1 for v in flat.values())
+    got = pkg.synth.shape_weights(flat, blocks=1)
+    assert set(got) == set(w)
+    for k in w:
+        assert got[k].shape == w[k].shape and np.array_equal(got[k], w[k])
+    bad = dict(flat); bad["module.vfe.pfn_layers.0.linear.weight"] = bad["module.vfe.pfn_layers.0.linear.weight"][:-1]
+    with pytest.raises(ValueError):
+        pkg.synth.shape_weights(bad, blocks=1)
+    del bad["module.vfe.pfn_layers.0.linear.weight"]
+    with pytest.raises(KeyError):
+        pkg.synth.shape_weights(bad, blocks=1)

@@ -64,6 +64,39 @@ def test_gather_world2_gloo(n_frames):
     assert res == {0: True, 1: True}
 
 
+def _single_rank_worker(backend, port, q):
+    """world size 1, a real communicator: the gather goes through the collective library (gloo here, RCCL in
+    tests/test_parallel_gpu.py) instead of the single-process shortcut"""
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("par", os.path.join(ROOT, "dsvt-ai-trt_amd", "parallel.py"))
+    par = importlib.util.module_from_spec(spec); spec.loader.exec_module(par)
+    r, _, w = par.init(backend=backend, single_rank_group=True)
+    dev = torch.device("cuda:0" if backend == "nccl" else "cpu")
+    ok = torch.distributed.is_initialized() and torch.distributed.get_backend() == backend and (r, w) == (0, 1)
+    local = torch.stack([_fake_frame(par, f) for f in range(3)]).to(dev)
+    par.barrier()
+    out = par.gather_results(local, 3, r, w, force_collective=True)
+    ok = ok and out is not local and torch.equal(out.cpu(), local.cpu())
+    ok = ok and par.max_over_ranks(2.5, dev) == 2.5
+    q.put((0, bool(ok)))
+    torch.distributed.destroy_process_group()
+
+
+def run_single_rank(backend):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_single_rank_worker, args=(backend, _free_port(), q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and res == (0, True)
+
+
+def test_gather_single_rank_group_gloo():
+    run_single_rank("gloo")
+
+
 def test_shard_frames_partition():
     import importlib.util
     spec = importlib.util.spec_from_file_location("par", os.path.join(ROOT, "dsvt-ai-trt_amd", "parallel.py"))

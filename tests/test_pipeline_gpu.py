@@ -20,6 +20,23 @@ def weights(pkg):
     return pkg.synth.make_weights()
 
 
+def _frame_and_caps(pkg, frame):
+    """a reference frame under the reference caps, or `lidar_like(N, 0)` (frame = "lidar<N>") under the Waymo-sized caps"""
+    if frame.startswith("lidar"):
+        caps = pkg.pipeline.Caps()
+        pts, n = cases.pad_points(pkg.synth.lidar_like(int(frame[5:]), 0), caps.N)
+    else:
+        caps = pkg.pipeline.Caps.reference()
+        pts, n = cases.load_frame(frame, caps.N)
+    return caps, pts, n
+
+
+def _oracle_cfg(caps):
+    from oracle import dense_ref as D
+    return D.OracleCfg(max_points=caps.N, max_points_filter=caps.Nk, max_pillars=caps.P, max_win=caps.W, max_vox_per_win=caps.Vw,
+                       max_sets=caps.S)
+
+
 def test_backbone_features_frame000000(pkg, oracle, weights):
     """config 2 shape of test (voxelize + partition + DSVT blocks, fp32) on the reference frame:
     per-layer voxel features against the oracle."""
@@ -46,16 +63,17 @@ def test_backbone_features_frame000000(pkg, oracle, weights):
     assert np.abs(x[0, :Pn].cpu().numpy() - ox[:Pn]).max() < 2e-4
 
 
-@pytest.mark.parametrize("frame", ["000000", "000004"])
+@pytest.mark.parametrize("frame", ["000000", "000004", "lidar180000"])
 def test_boxes_reference_frames(pkg, oracle, weights, frame):
+    """fp32 mode of the HIP path against the oracle at the north-star tolerance, on reference frames and on the bench frame
+    (BASELINE configs[2] size: 180k points, 34.5k pillars, 1714 / 1158 sets)."""
     from oracle import dense_ref as D
-    caps = pkg.pipeline.Caps.reference()
+    caps, pts, n = _frame_and_caps(pkg, frame)
     pipe = pkg.pipeline.DsvtPipeline(weights, caps=caps, device=DEV)
-    pts, n = cases.load_frame(frame, caps.N)
     boxes, cnt = _run(pkg, pipe, pts, n)
     torch.cuda.synchronize()
-    eb, ec = D.forward(pts, n, weights, D.OracleCfg())
-    assert 0 < ec < 500                       # the score threshold actually filters
+    eb, ec = D.forward(pts, n, weights, _oracle_cfg(caps))
+    assert 0 < ec <= 500 and (ec < 500 or frame.startswith("lidar"))      # the score threshold actually filters the reference frames
     worst, unmatched = match_boxes(boxes[0].cpu().numpy(), int(cnt[0]), eb, ec)
     assert unmatched == 0 and worst < 1e-3, (worst, unmatched)     # north-star tolerance: 1e-3 fp32
 
@@ -96,30 +114,37 @@ def _box_errors(got, n_got, exp, n_exp):
     return errs.max(0), matched / max(n_exp, 1)
 
 
-@pytest.mark.parametrize("frame", ["000000", "000003"])
+# Bounds of the fp16 frame against the fp32 oracle: centre x,y / z / size / score, yaw.  The north-star 1e-3 is met by the fp32 mode
+# (test_boxes_reference_frames, 1e-5 measured).  For fp16 OPERANDS it is out of reach, and not because of one tensor:
+# profiles/r02_f16_error_attribution.txt swaps stages between the two modes and shows that ONE fp16 rounding site -- the weights of the
+# last convolution alone, or its input alone, or the pillar feature net alone -- already moves z / size by 3.5e-4 .. 5.5e-4 (2^-12 mean
+# relative operand error x O(1) outputs, max over 500 boxes; size = exp(d) multiplies it by the box size), and the ~60 sites of the frame
+# add in quadrature to what is measured here: 180k-point frame xy 7.3e-4, z 2.0e-3, size 4.0e-3, score 5.8e-4; reference frames
+# xy 5.7e-4, z 1.7e-3, size 1.9e-3, score 4e-4.  The bounds are those figures x 1.5.
+F16_TOL = dict(xy=1.2e-3, z=3e-3, size=6e-3, score=1e-3, yaw=1e-1)
+
+
+@pytest.mark.parametrize("frame", ["000000", "000003", "000004", "lidar180000"])
 def test_boxes_f16_mode(pkg, oracle, weights, frame):
     """BASELINE configs[2] precision ("fp16"): fp16 MFMA operands / fp16 BEV activations, fp32 accumulate,
-    fp32 LayerNorm / softmax / decode -- the mode bench.py times by default.  The reference's own fp16
-    build (TensorRT kFP16, include/params.h:332) is not reproducible, so this mode is judged against the fp32
-    oracle with fp16-sized tolerances (fp16 rounds at 2^-11 = 4.9e-4 relative and the network is ~60
-    roundings deep).  Measured on MI355X, frames 000000 / 000003: centre x,y <= 5.7e-4 m, z <= 1.7e-3 m,
-    size <= 1.9e-3, score <= 4e-4, every oracle box has a partner.  The yaw is atan(sin/cos) of two raw head
-    outputs (src/dsvt-ai-trt.cpp:1668-1669): ill-conditioned when cos ~ 0, so its bound is loose (observed
-    4.5e-2 rad on one box, 6e-3 otherwise)."""
+    fp32 LayerNorm / softmax / decode -- the mode bench.py times by default, on the three distinct reference frames and on the
+    bench frame itself (lidar_like(180000, 0)).  The reference's own fp16 build (TensorRT kFP16, include/params.h:332) is not
+    reproducible, so this mode is judged against the fp32 oracle with the fp16-sized bounds F16_TOL derived above.  The yaw is atan(sin/cos) of two
+    raw head outputs (src/dsvt-ai-trt.cpp:1668-1669): ill-conditioned when cos ~ 0, so its bound is loose."""
     from oracle import dense_ref as D
-    caps = pkg.pipeline.Caps.reference()
+    caps, pts, n = _frame_and_caps(pkg, frame)
     pipe = pkg.pipeline.DsvtPipeline(weights, caps=caps, device=DEV, linear_compute=pkg.plugin.COMPUTE_F16,
                                      head_dtype=torch.float16)
     assert pipe.hip_head
-    pts, n = cases.load_frame(frame, caps.N)
     boxes, cnt = _run(pkg, pipe, pts, n)
     torch.cuda.synchronize()
-    eb, ec = D.forward(pts, n, weights, D.OracleCfg())
+    eb, ec = D.forward(pts, n, weights, _oracle_cfg(caps))
     err, frac = _box_errors(boxes[0].cpu().numpy(), int(cnt[0]), eb, ec)
-    print("f16 box errors per field", err, "matched", frac, "counts", int(cnt[0]), ec)
+    print("f16 box errors per field", frame, err, "matched", frac, "counts", int(cnt[0]), ec)
     assert frac >= 0.99
-    assert err[:2].max() < 2e-3 and err[2] < 5e-3 and err[3:6].max() < 5e-3 and err[8] < 2e-3
-    assert err[6] < 1e-1
+    t = F16_TOL
+    assert err[:2].max() < t["xy"] and err[2] < t["z"] and err[3:6].max() < t["size"] and err[8] < t["score"], err
+    assert err[6] < t["yaw"]
     assert abs(int(cnt[0]) - ec) <= 2
 
 
@@ -229,3 +254,18 @@ def test_degenerate_frames_run_through_the_fp16_pipeline(pkg, weights, n_pts):
     k = outs[0][1]
     assert torch.equal(outs[0][0].reshape(-1, 9)[:k], outs[1][0].reshape(-1, 9)[:k])
     assert torch.isfinite(outs[0][0].reshape(-1, 9)[:k]).all()
+
+
+def test_weights_from_a_wts_file_give_the_same_boxes(pkg, weights, tmp_path):
+    """tools/detect.py --wts: the .wts reader returns flat tensors (like the reference's loadWeights, include/helper.h:328-366);
+    detect.load_weights shapes them.  Same boxes, bit for bit, as the in-memory weights."""
+    path = str(tmp_path / "dsvt.wts")
+    pkg.synth.write_wts(path, weights)
+    w2 = pkg.detect.load_weights(path, log=lambda *_: None)
+    caps = pkg.pipeline.Caps.reference()
+    pts, n = cases.load_frame("000003", caps.N)
+    kw = dict(caps=caps, device=DEV, linear_compute=pkg.plugin.COMPUTE_F16, head_dtype=torch.float16, device_nms=True)
+    a = [t.clone() for t in _run(pkg, pkg.pipeline.DsvtPipeline(weights, **kw), pts, n)]
+    b = [t.clone() for t in _run(pkg, pkg.pipeline.DsvtPipeline(w2, **kw), pts, n)]
+    torch.cuda.synchronize()
+    assert int(a[1][0]) > 0 and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
