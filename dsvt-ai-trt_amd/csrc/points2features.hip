@@ -6,14 +6,17 @@
 // every frame) with racy atomic slot order.  Here
 //   1. p2f_count     one coalesced float4 read per point, range filter, cell key, one atomic
 //                    per in-range point on a 0.9 MB cell histogram (order-independent counts);
-//   2. p2f_tile_sums / p2f_scan_top / p2f_apply   exclusive scan over the cells gives, in
-//                    ascending cell-key order, pillar ids, point-segment offsets and the
-//                    compact point offsets (no atomics => deterministic pillar order);
+//   2. p2f_scan      ONE single-pass exclusive scan over the cells (decoupled look-back between 1024-cell tiles, tile
+//                    order by ticket) gives, in ascending cell-key order, pillar ids, point-segment offsets and the
+//                    compact point offsets (deterministic pillar order), the pillar records and the two counts;
 //   3. p2f_scatter   point ids land in their cell's segment (arbitrary order inside it);
 //   4. p2f_pillar    one wavefront per pillar ranks the segment by point id (= input order),
 //                    keeps the first T, sums the cluster mean sequentially in slot order like
 //                    the reference, and writes the 10-d features / point-id rows.
 // Canonical order: pillars ascending by y*GX+x, points in input order, first T.
+// grid_size z > 1 (BASELINE configs[4], a 3-D voxel grid; NOT in the reference, whose voxel z index is forced to 0,
+// points2Features.cu:689-690,755): the cell key gains the z index computed like x and y (the reference computes it the same way for
+// the centre offset, :846), key = (z*GY + y)*GX + x, voxels ascending by that key, coords = (0, z, y, x).
 //
 // Compiled with -ffp-contract=off: cell indices and features follow the reference's
 // expression order exactly (fp32 subtract, IEEE divide, floorf; the centre offset in double).
@@ -51,7 +54,11 @@ p2f_count(const float4* __restrict__ pts, const uint32_t* __restrict__ n_ptr, P2
         // (:689-690) the linear index then aliases the first cell of the next row.  Only an
         // index past the last cell (undefined behaviour in the reference) is dropped.
         uint32_t c = (uint32_t)(iy * p.gx + ix);
-        if (c < (uint32_t)(p.gx * p.gy)) {
+        if (p.gz > 1) {                                           // 3-D grid (not in the reference): same floorf rule for z
+            int iz = (int)floorf((q.z - p.min_z) / p.vz);
+            c = (uint32_t)((iz * p.gy + iy) * p.gx + ix);
+        }
+        if (c < (uint32_t)(p.gx * p.gy * p.gz)) {
             cell = c;
             slot = atomicAdd(&cell_cnt[cell], 1u);                // count only; order fixed later
         }
@@ -64,89 +71,104 @@ __device__ __forceinline__ void cellTriple(uint32_t c, uint32_t T, uint32_t& occ
     occ = c > 0 ? 1u : 0u; full = c; kept = c < T ? c : T;        // :746-748
 }
 
-// per-tile sums of (occupied, full count, kept count)
-__global__ void __launch_bounds__(256)
-p2f_tile_sums(const uint32_t* __restrict__ cell_cnt, int ncell, uint32_t T, uint32_t* __restrict__ tile_sums, int ntiles)
-{
-    __shared__ uint32_t red[3][4];
-    int base = blockIdx.x * kTile + threadIdx.x * 4;
-    uint32_t so = 0, sf = 0, sk = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int c = base + j;
-        if (c < ncell) { uint32_t o, f, k; cellTriple(cell_cnt[c], T, o, f, k); so += o; sf += f; sk += k; }
-    }
-    so = waveSum(so); sf = waveSum(sf); sk = waveSum(sk);
-    int w = threadIdx.x / kWave;
-    if (laneId() == 0) { red[0][w] = so; red[1][w] = sf; red[2][w] = sk; }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        uint32_t s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
-        tile_sums[threadIdx.x * ntiles + blockIdx.x] = s;
-    }
+// ---- single-pass scan over the cells ------------------------------------------------------------------------------
+// Three running sums travel together: occupied cells (-> pillar id), full point counts (-> segment offset) and kept point
+// counts (-> compact point offset).  A tile publishes one 64-bit word: flag (2 bits: 1 = aggregate of this tile, 2 = inclusive
+// prefix up to and including it) | occupied (20) | full (21) | kept (21); validP2F bounds max_points_num so that they fit.
+// Tiles take their index from a ticket counter, so a tile only ever waits for tiles that are already running.
+constexpr uint64_t kFlagAgg = 1ull << 62, kFlagInc = 2ull << 62;
+__device__ __forceinline__ uint64_t packState(uint64_t flag, uint32_t o, uint32_t f, uint32_t k) {
+    return flag | ((uint64_t)o << 42) | ((uint64_t)f << 21) | (uint64_t)k;
+}
+__device__ __forceinline__ void unpackState(uint64_t w, uint32_t& o, uint32_t& f, uint32_t& k) {
+    o = (uint32_t)((w >> 42) & 0xfffffu); f = (uint32_t)((w >> 21) & 0x1fffffu); k = (uint32_t)(w & 0x1fffffu);
 }
 
-// single workgroup: exclusive scan of the tile sums (3 rows), zero the device-side counts
-__global__ void __launch_bounds__(1024)
-p2f_scan_top(uint32_t* __restrict__ tile_sums, int ntiles, uint32_t* __restrict__ pillar_num, uint32_t* __restrict__ point_num)
-{
-    __shared__ uint32_t smem[1024 / kWave + 1];
-    for (int r = 0; r < 3; ++r) {
-        uint32_t carry = 0;
-        for (int b = 0; b < ntiles; b += 1024) {
-            int i = b + threadIdx.x;
-            uint32_t v = i < ntiles ? tile_sums[r * ntiles + i] : 0, tot;
-            uint32_t ex = blockExclusiveScan<1024>(v, smem, &tot);
-            if (i < ntiles) tile_sums[r * ntiles + i] = carry + ex;
-            carry += tot;
-        }
-    }
-    if (threadIdx.x == 0) { *pillar_num = 0; *point_num = 0; }
-}
-
-// per tile: finish the scan; emit per-cell segment offsets and per-pillar records
+// scan_state: [0] ticket counter (as uint64), [1 + t] state of tile t -- zeroed by the same memset as cell_cnt
 __global__ void __launch_bounds__(256)
-p2f_apply(const uint32_t* __restrict__ cell_cnt, int ncell, P2FParams p, const uint32_t* __restrict__ tile_pref, int ntiles,
-          uint32_t* __restrict__ cell_seg, uint32_t* __restrict__ pil_seg, uint32_t* __restrict__ pil_full,
-          uint32_t* __restrict__ pil_ptoff, uint32_t* __restrict__ coords, uint32_t* __restrict__ pcnt,
-          uint32_t* __restrict__ pillar_num, uint32_t* __restrict__ point_num)
+p2f_scan(const uint32_t* __restrict__ cell_cnt, int ncell, P2FParams p, uint64_t* __restrict__ scan_state, int ntiles,
+         uint32_t* __restrict__ cell_seg, uint32_t* __restrict__ pil_seg, uint32_t* __restrict__ pil_full,
+         uint32_t* __restrict__ pil_ptoff, uint32_t* __restrict__ coords, uint32_t* __restrict__ pcnt,
+         uint32_t* __restrict__ pillar_num, uint32_t* __restrict__ point_num)
 {
     __shared__ uint32_t smem[256 / kWave + 1];
+    __shared__ uint32_t s_tile, s_pref[3];
     const uint32_t T = p.max_num_points_per_voxel;
-    int base = blockIdx.x * kTile + threadIdx.x * 4;
+    if (threadIdx.x == 0) s_tile = (uint32_t)atomicAdd(reinterpret_cast<unsigned long long*>(scan_state), 1ull);
+    __syncthreads();
+    const int tile = (int)s_tile;
+    uint64_t* state = scan_state + 1;
+    const int base = tile * kTile + threadIdx.x * 4;
     uint32_t c[4], o[4], f[4], k[4], so = 0, sf = 0, sk = 0;
+    if (base + 3 < ncell) {
+        const uint4 v = *reinterpret_cast<const uint4*>(cell_cnt + base);
+        c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        c[j] = (base + j) < ncell ? cell_cnt[base + j] : 0;
-        cellTriple(c[j], T, o[j], f[j], k[j]);
-        so += o[j]; sf += f[j]; sk += k[j];
+        for (int j = 0; j < 4; ++j) c[j] = (base + j) < ncell ? cell_cnt[base + j] : 0;
     }
-    uint32_t tot;
-    uint32_t eo = blockExclusiveScan<256>(so, smem, &tot) + tile_pref[0 * ntiles + blockIdx.x];
-    uint32_t ef = blockExclusiveScan<256>(sf, smem, &tot) + tile_pref[1 * ntiles + blockIdx.x];
-    uint32_t ek = blockExclusiveScan<256>(sk, smem, &tot) + tile_pref[2 * ntiles + blockIdx.x];
-    uint32_t maxP = 0, maxN = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { cellTriple(c[j], T, o[j], f[j], k[j]); so += o[j]; sf += f[j]; sk += k[j]; }
+    uint32_t to, tf, tk;
+    uint32_t eo = blockExclusiveScan<256>(so, smem, &to);
+    uint32_t ef = blockExclusiveScan<256>(sf, smem, &tf);
+    uint32_t ek = blockExclusiveScan<256>(sk, smem, &tk);
+    // ---- decoupled look-back (wave 0): prefix of all earlier tiles --------------------------------------------------
+    if (threadIdx.x < kWave) {
+        const int lane = threadIdx.x;
+        if (lane == 0)
+            __hip_atomic_store(&state[tile], packState(tile == 0 ? kFlagInc : kFlagAgg, to, tf, tk), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t po = 0, pf = 0, pk = 0;
+        int back = tile - 1;
+        while (back >= 0) {
+            const int t = back - lane;
+            uint64_t w;
+            // every lane polls its predecessor until it has published something
+            do { w = t >= 0 ? __hip_atomic_load(&state[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : kFlagInc; } while (__any((w >> 62) == 0));
+            // nearest predecessor holding an inclusive prefix: lanes below it contribute aggregates, it contributes the prefix
+            const uint64_t inc = __ballot((w >> 62) == 2);
+            const int first = __ffsll((long long)inc) - 1;                    // >= 0 when any (lanes with t < 0 count as "inclusive 0")
+            uint32_t a, b_, d; unpackState(w, a, b_, d);
+            const bool take = first < 0 || lane <= first;
+            if (t < 0 || !take) { a = 0; b_ = 0; d = 0; }
+            po += waveSum(a); pf += waveSum(b_); pk += waveSum(d);
+            if (first >= 0) break;
+            back -= kWave;
+        }
+        if (lane == 0) {
+            s_pref[0] = po; s_pref[1] = pf; s_pref[2] = pk;
+            if (tile > 0)
+                __hip_atomic_store(&state[tile], packState(kFlagInc, po + to, pf + tf, pk + tk), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    eo += s_pref[0]; ef += s_pref[1]; ek += s_pref[2];
+    // ---- per-cell segment offsets, per-pillar records ---------------------------------------------------------------
+    const uint32_t maxP = (uint32_t)p.max_pillars_num, maxN = (uint32_t)p.max_points_num_voxel_filter;
+    const uint32_t gxy = (uint32_t)(p.gx * p.gy);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        int cell = base + j;
+        const int cell = base + j;
         if (cell < ncell) {
             cell_seg[cell] = ef;
             if (o[j]) {
-                // capacity guard the reference lacks: the pillar list is truncated at the first
-                // pillar that overflows max_pillars_num or max_points_num_voxel_filter
-                bool valid = eo < (uint32_t)p.max_pillars_num && ek + k[j] <= (uint32_t)p.max_points_num_voxel_filter;
+                // capacity guard the reference lacks: the pillar list is truncated at the first pillar that overflows
+                // max_pillars_num or max_points_num_voxel_filter (ek + k is monotonic, so the valid pillars form a prefix)
+                const bool valid = eo < maxP && ek + k[j] <= maxN;
                 if (valid) {
                     pil_seg[eo] = ef; pil_full[eo] = f[j]; pil_ptoff[eo] = ek;
                     pcnt[eo] = k[j];                                              // :753
-                    reinterpret_cast<uint4*>(coords)[eo] = make_uint4(0u, 0u, (uint32_t)(cell / p.gx), (uint32_t)(cell % p.gx));  // :755-756
-                    maxP = eo + 1; maxN = ek + k[j];
+                    const uint32_t cz = (uint32_t)cell / gxy, cyx = (uint32_t)cell % gxy;
+                    reinterpret_cast<uint4*>(coords)[eo] = make_uint4(0u, cz, cyx / (uint32_t)p.gx, cyx % (uint32_t)p.gx);       // :755-756 (z = 0 there)
+                } else if (eo == 0 || (eo - 1 < maxP && ek <= maxN)) {
+                    *pillar_num = eo; *point_num = ek;                              // the FIRST pillar that does not fit: P and Nk are its offsets
                 }
             }
         }
         eo += o[j]; ef += f[j]; ek += k[j];
     }
-    // valid pillars form a prefix, so max(pid+1) / max(ptoff+kept) over them are P and Nk
-    if (maxP) { atomicMax(pillar_num, maxP); atomicMax(point_num, maxN); }
+    // nothing overflowed: the last tile knows the totals
+    if (tile == ntiles - 1 && threadIdx.x == 255 && eo <= maxP && ek <= maxN) { *pillar_num = eo; *point_num = ek; }
 }
 
 __global__ void __launch_bounds__(256)
@@ -338,13 +360,15 @@ public:
         if (pos == 0 || pos == 2) return io[pos].type == DSVT_FLOAT;
         return pos >= 1 && pos <= 7 && io[pos].type == DSVT_INT32;
     }
-    int ncell() const { return p_.gx * p_.gy; }
+    int ncell() const { return p_.gx * p_.gy * p_.gz; }
+    // cell histogram followed by the scan's ticket + tile states (one memset covers both); 16-byte aligned rows
+    size_t cntWords() const { return ((size_t)ncell() + 3) / 4 * 4; }
+    size_t headBytes() const { return sizeof(uint32_t) * cntWords() + sizeof(uint64_t) * (1 + (size_t)ntiles()); }
     int ntiles() const { return cdiv(ncell(), kTile); }
     size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override {
         size_t s = 0;
-        s += 2 * alignUp(sizeof(uint32_t) * ncell());                 // cell_cnt, cell_seg
+        s += alignUp(headBytes()) + alignUp(sizeof(uint32_t) * ncell());   // cell_cnt + scan state, cell_seg
         s += 3 * alignUp(sizeof(uint32_t) * p_.max_points_num);       // pt_cell, pt_slot, sorted_idx
-        s += alignUp(sizeof(uint32_t) * 3 * ntiles());                // tile sums
         s += 3 * alignUp(sizeof(uint32_t) * p_.max_pillars_num);      // pil_seg, pil_full, pil_ptoff
         return s;                                                     // ~4.6 MB at 180k caps (reference: 176.8 MB, :262-277)
     }
@@ -360,17 +384,18 @@ public:
         uint32_t* pillar_num = static_cast<uint32_t*>(outputs[4]);
         uint32_t* point_num = static_cast<uint32_t*>(outputs[5]);
         WsCarver ws(workspace);
-        uint32_t* cell_cnt = ws.take<uint32_t>(ncell());
+        char* head = ws.take<char>(headBytes());
+        uint32_t* cell_cnt = reinterpret_cast<uint32_t*>(head);
+        uint64_t* scan_state = reinterpret_cast<uint64_t*>(head + sizeof(uint32_t) * cntWords());
         uint32_t* cell_seg = ws.take<uint32_t>(ncell());
         uint32_t* pt_cell = ws.take<uint32_t>(p_.max_points_num);
         uint32_t* pt_slot = ws.take<uint32_t>(p_.max_points_num);
         uint32_t* sorted_idx = ws.take<uint32_t>(p_.max_points_num);
-        uint32_t* tile_sums = ws.take<uint32_t>(3 * ntiles());
         uint32_t* pil_seg = ws.take<uint32_t>(p_.max_pillars_num);
         uint32_t* pil_full = ws.take<uint32_t>(p_.max_pillars_num);
         uint32_t* pil_ptoff = ws.take<uint32_t>(p_.max_pillars_num);
 
-        DSVT_CHECK(hipMemsetAsync(cell_cnt, 0, sizeof(uint32_t) * ncell(), stream));
+        DSVT_CHECK(hipMemsetAsync(head, 0, headBytes(), stream));
         if (zeroFill) {   // reference zero-fills every output each call (:928-937)
             DSVT_CHECK(hipMemsetAsync(feat, 0, sizeof(float) * (size_t)p_.max_points_num_voxel_filter * p_.feature_num, stream));
             DSVT_CHECK(hipMemsetAsync(pidx, 0, sizeof(uint32_t) * (size_t)p_.max_pillars_num * p_.max_num_points_per_voxel, stream));
@@ -379,9 +404,7 @@ public:
         }
         const int nt = ntiles();
         hipLaunchKernelGGL(p2f_count, dim3(cdiv(p_.max_points_num, 256)), dim3(256), 0, stream, pts, n_ptr, p_, cell_cnt, pt_cell, pt_slot);
-        hipLaunchKernelGGL(p2f_tile_sums, dim3(nt), dim3(256), 0, stream, cell_cnt, ncell(), (uint32_t)p_.max_num_points_per_voxel, tile_sums, nt);
-        hipLaunchKernelGGL(p2f_scan_top, dim3(1), dim3(1024), 0, stream, tile_sums, nt, pillar_num, point_num);
-        hipLaunchKernelGGL(p2f_apply, dim3(nt), dim3(256), 0, stream, cell_cnt, ncell(), p_, tile_sums, nt, cell_seg,
+        hipLaunchKernelGGL(p2f_scan, dim3(nt), dim3(256), 0, stream, cell_cnt, ncell(), p_, scan_state, nt, cell_seg,
                            pil_seg, pil_full, pil_ptoff, coords, pcnt, pillar_num, point_num);
         hipLaunchKernelGGL(p2f_scatter, dim3(cdiv(p_.max_points_num, 256)), dim3(256), 0, stream, n_ptr, p_.max_points_num,
                            pt_cell, pt_slot, cell_seg, sorted_idx);
@@ -405,7 +428,8 @@ static bool validP2F(const P2FParams& p) {
     return p.max_points_num > 0 && p.max_points_num_voxel_filter > 0 && p.max_pillars_num > 0 &&
            p.point_feature_num == 4 && p.feature_num == 10 &&
            p.max_num_points_per_voxel > 0 && p.max_num_points_per_voxel <= kWave &&
-           p.gx > 0 && p.gy > 0 && p.vx > 0 && p.vy > 0 && p.vz > 0;
+           p.gx > 0 && p.gy > 0 && p.gz > 0 && (long)p.gx * p.gy * p.gz < (1l << 30) && p.vx > 0 && p.vy > 0 && p.vz > 0 &&
+           p.max_points_num < (1 << 20);                      // the scan packs (occupied, full, kept) sums into 20 + 21 + 21 bits
 }
 
 static Plugin* p2fCreate(const DsvtPluginFieldCollection* fc) {                                    // :1113-1195

@@ -68,7 +68,10 @@ ORC_API int orc_points2features(const orc_p2f_cfg* c, const float* points, uint3
                                 uint32_t* pillar_num, uint32_t* point_num)
 {
     const int T = c->max_num_points_per_voxel;
-    const int ncell = c->gx * c->gy;
+    /* gz > 1 is NOT the reference (its voxel z index is forced to 0, :689-690,755): it is the one generalisation BASELINE
+     * configs[4] needs -- the z index computed exactly like x and y (and like the reference's own index_z of :846), the cell key
+     * (z*gy + y)*gx + x and coords (0, z, y, x).  With gz == 1 every line below is the reference's. */
+    const int ncell = c->gx * c->gy * (c->gz > 1 ? c->gz : 1);
     const int F = c->feature_num;
     uint32_t* mask = (uint32_t*)calloc((size_t)ncell, sizeof(uint32_t));
     uint32_t* cell_of = (uint32_t*)malloc((size_t)(n_points ? n_points : 1) * sizeof(uint32_t));
@@ -87,6 +90,10 @@ ORC_API int orc_points2features(const orc_p2f_cfg* c, const float* points, uint3
         int ix = (int)floorf((x - c->min_x) / c->vx);                      /* :687 */
         int iy = (int)floorf((y - c->min_y) / c->vy);                      /* :688 */
         uint32_t cell = (uint32_t)(iy * c->gx + ix);                       /* :689-690 */
+        if (c->gz > 1) {
+            int iz = (int)floorf((z - c->min_z) / c->vz);
+            cell = (uint32_t)((iz * c->gy + iy) * c->gx + ix);
+        }
         if (cell >= (uint32_t)ncell) continue;   /* out-of-bounds write in the reference (ix==gx on the last row) */
         uint32_t slot = mask[cell]++;                                      /* :697 */
         if (slot >= (uint32_t)T) continue;                                 /* :699 */
@@ -107,8 +114,8 @@ ORC_API int orc_points2features(const orc_p2f_cfg* c, const float* points, uint3
             Nk + cnt > (uint32_t)c->max_points_num_voxel_filter) break;
         cell_pid[cell] = P;
         pcnt[P] = cnt;                                                     /* :753 */
-        coords[P * 4 + 0] = 0; coords[P * 4 + 1] = 0;
-        coords[P * 4 + 2] = (uint32_t)(cell / c->gx);
+        coords[P * 4 + 0] = 0; coords[P * 4 + 1] = (uint32_t)(cell / (c->gx * c->gy));     /* 0 when gz == 1 */
+        coords[P * 4 + 2] = (uint32_t)((cell % (c->gx * c->gy)) / c->gx);
         coords[P * 4 + 3] = (uint32_t)(cell % c->gx);                      /* :755-756 */
         pt_off[P] = Nk;
         Nk += cnt; P++;

@@ -162,6 +162,51 @@ def test_partition_chain(pkg, oracle, frame, capname, n_pts):
                 assert O.set_fingerprint(inds[0][a], mask[0][a], int(S[0]), host(coords_d)[0], 468) == fp[a]
 
 
+def test_config4_300k_cloud_3d_voxel_grid(pkg, oracle):
+    """BASELINE configs[4] (stress of set partition / scatter): lidar_like(300000, 0) on a 3-D voxel grid -- GZ = 32, voxel z 0.25 m,
+    one 12 x 12 x 32 window shape, up to 4608 voxels per window.  The reference has no voxel path (its z index is forced to 0,
+    points2Features.cu:689-690,755); the voxelizer is generalised by one rule (z index by the same floorf as x, y; key =
+    (z*GY + y)*GX + x), restated identically in the oracle, and WindowPartition / GetSet carry z generically
+    (windowPartition.cu:294-301,354; getSet.cu:386,461), so everything below is bit-exact against the oracle."""
+    P, O = pkg.plugin, oracle
+    c = dict(N=327680, Nk=327680, P=262144, W=2048, Vw=4608)
+    grid, vox_size, win = [468, 468, 32], [0.32, 0.32, 0.25], [12, 12, 32]
+    pts, n = cases.pad_points(pkg.synth.lidar_like(300000, 0), c["N"])
+    cfg = dict(cases.p2f_cfg(c), voxel_size=vox_size, grid_size=grid)
+    ref = O.points2features(pts, n, cfg)
+    assert ref["P"] == 81090 and ref["coords"][:ref["P"], 1].max() > 8                  # 1.8x the 45067 pillars of this cloud, z really varies
+    op = P.add_voxel_generator(c["N"], c["Nk"], c["P"], 4, 10, 48, -74.88, 74.88, -74.88, 74.88, -5.0, 3.0, *vox_size, *grid)
+    outs = op(dev(pts[None]), scalar(n))
+    torch.cuda.synchronize()
+    check_voxelizer(outs, ref)
+    key = lambda co: (co[:, 1].astype(np.int64) * 468 + co[:, 2]) * 468 + co[:, 3]
+    kk = key(ref["coords"][:ref["P"]])
+    assert np.all(np.diff(kk) > 0)                                                       # voxels ascending by (z, y, x) key
+    # independent numpy count of occupied voxels
+    p_ = pts[:n]
+    m = (p_[:, 0] >= -74.88) & (p_[:, 0] < 74.88) & (p_[:, 1] >= -74.88) & (p_[:, 1] < 74.88) & (p_[:, 2] >= -5) & (p_[:, 2] < 3)
+    f32 = np.float32
+    ix = np.floor((p_[m, 0] - f32(-74.88)) / f32(0.32)).astype(np.int64); iy = np.floor((p_[m, 1] - f32(-74.88)) / f32(0.32)).astype(np.int64)
+    iz = np.floor((p_[m, 2] - f32(-5.0)) / f32(0.25)).astype(np.int64)
+    assert len(np.unique((iz * 468 + iy) * 468 + ix)) == ref["P"]
+    # partition: one window shape, both sort axes
+    wcfg = dict(max_win_num=c["W"], max_voxel_num_per_win=c["Vw"], sparse_shape=grid, win_shape=win, shift_list=[0, 0, 0], max_pillars_num=c["P"])
+    S_cap = 10240
+    rw = O.window_partition(ref["coords"], ref["P"], wcfg)
+    rg = O.get_set(rw["gidx"], rw["cinw"], rw["vcnt"], rw["W"], dict(max_win_num=S_cap, max_voxel_num_per_win=c["Vw"], voxel_num_set=36, win_shape=win))
+    assert rw["vcnt"].max() > 576 and rg["S"] > 2048                                     # beyond the pillar configuration's caps
+    wpo = P.add_window_partition(c["W"], c["Vw"], *grid, *win, 0, 0, 0)(outs[2], outs[4])
+    gso = P.add_get_set_op(c["W"], c["Vw"], 36, *win, max_set_num=S_cap)(wpo[0], wpo[1], wpo[2], wpo[3])
+    torch.cuda.synchronize()
+    gidx, cinw, vcnt, W, c2d, xy = [host(o) for o in wpo]
+    assert int(W[0]) == rw["W"] and np.array_equal(vcnt[0], rw["vcnt"]) and np.array_equal(gidx[0], rw["gidx"])
+    assert np.array_equal(cinw[0], rw["cinw"]) and np.array_equal(c2d[0], rw["c2d"]) and np.array_equal(xy[0], rw["xy"])
+    inds, mask, S, m0, m1 = [host(o) for o in gso]
+    assert int(S[0]) == rg["S"] and np.array_equal(inds[0], rg["inds"]) and np.array_equal(mask[0], rg["mask"])
+    covered = np.unique(inds[0][0, :rg["S"]])
+    assert len(covered) == ref["P"]                                                      # every voxel sits in exactly the sets of its window
+
+
 def test_partition_generic_inputs(pkg, oracle):
     """GetSet / WindowPartition must not rely on canonical pillar order: shuffled coords, window
     and set capacity overflow, 3-D windows (config 5 style)."""
