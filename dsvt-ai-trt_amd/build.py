@@ -68,7 +68,22 @@ def build(force=False, verbose=False):
     if force or procs or _stale(OUT, objs):
         cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
         subprocess.check_call(cmd)
+    build_host(force)
     return OUT
+
+
+HOST_SRC = os.path.join(HERE, "host", "dsvt_detect.cpp")
+HOST_EXE = os.path.join(HERE, "dsvt_detect")
+
+
+def build_host(force=False):
+    """The C++ host executable (the reference's `dsvt-ai-trt -d`, src/dsvt-ai-trt.cpp:1771-1970) above the C ABI: only
+    include/dsvt_plugin.h + the HIP runtime.  -ffp-contract=off: its fp32 weight folding must round like numpy's."""
+    hdr = os.path.join(HERE, "..", "include", "dsvt_plugin.h")
+    if force or _stale(HOST_EXE, [HOST_SRC, hdr, OUT]):
+        subprocess.check_call([hipcc(), "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-I", os.path.join(HERE, "..", "include"),
+                               HOST_SRC, "-o", HOST_EXE, "-L", HERE, "-l:libdsvt_hip.so", "-Wl,-rpath,$ORIGIN"])
+    return HOST_EXE
 
 
 if __name__ == "__main__":

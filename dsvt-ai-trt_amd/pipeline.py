@@ -84,7 +84,7 @@ def fold_linear_bn(w, lin, bn, eps, bias=False):
 class DsvtPipeline:
     def __init__(self, weights, caps=None, blocks=4, with_head=True, ln_eps=0.0, head_dtype=torch.float32,
                  device="cuda:0", zero_fill=False, linear_compute=P.COMPUTE_F32, hip_head=None, fused_mlp=None,
-                 device_nms=False, pos_table=None):
+                 device_nms=False, pos_table=None, fork_partition=None):
         """linear_compute: COMPUTE_F32 = fp32 MFMA everywhere (parity mode, boxes within 1e-3 of the
         fp32 oracle); COMPUTE_F16 = fp16 MFMA operands with fp32 accumulate/epilogues (BASELINE
         configs[2] "fp16").  head_dtype: precision of the dense BEV stage.  hip_head: run the BEV ResNet +
@@ -93,6 +93,12 @@ class DsvtPipeline:
         forward() returns the final boxes instead of FilterBoxByScore's rows."""
         self.caps = c = caps or Caps()
         self.blocks, self.with_head, self.device = blocks, with_head, torch.device(device)
+        # fork_partition: WindowPartition / GetSet (12 tiny launches that only need the pillar coordinates) run on a side stream
+        # while the pillar feature net runs on the frame's stream; inside a HIP-graph capture this becomes two parallel branches.
+        # Measured (profiles/README.md, r02_c): no gain with one frame in flight (434 vs 437 frames/s) and the graph with branches
+        # loses the overlap between two frames in flight (435 vs 518 frames/s), so it is off by default.
+        self.fork_partition = bool(fork_partition)
+        self.side = torch.cuda.Stream(self.device) if self.fork_partition else None
         self.head_dtype = head_dtype
         w = weights
         zf = lambda op: op.set_zero_fill(zero_fill)
@@ -353,9 +359,20 @@ class DsvtPipeline:
     def voxel_stage(self, points, n):
         feat, pidx, coords, pcnt, Pn, Nk = self.voxelizer(points, n)
         if self.fused_pfn:
-            vfeat, vfeat16 = self.pfn(feat, pidx, pcnt, Pn)
-            wps = [op(coords, Pn) for op in self.wp]
-            gss = [op(wp[0], wp[1], wp[2], wp[3]) for op, wp in zip(self.gs, wps)]
+            if self.fork_partition:
+                main = torch.cuda.current_stream(self.device)
+                fork = torch.cuda.Event(); fork.record(main)
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(fork)
+                    wps = [op(coords, Pn) for op in self.wp]
+                    gss = [op(wp[0], wp[1], wp[2], wp[3]) for op, wp in zip(self.gs, wps)]
+                    join = torch.cuda.Event(); join.record(self.side)
+                vfeat, vfeat16 = self.pfn(feat, pidx, pcnt, Pn)
+                main.wait_event(join)
+            else:
+                vfeat, vfeat16 = self.pfn(feat, pidx, pcnt, Pn)
+                wps = [op(coords, Pn) for op in self.wp]
+                gss = [op(wp[0], wp[1], wp[2], wp[3]) for op, wp in zip(self.gs, wps)]
             return dict(feat=feat, pidx=pidx, coords=coords, pcnt=pcnt, P=Pn, Nk=Nk, vfeat=vfeat, vfeat16=vfeat16, wps=wps, gss=gss)
         x0 = self.pfn0(feat, Nk)[0]                                                                 # :577
         mp0, _ = self.smax0(x0, pidx, pcnt, Pn)                                                     # :579

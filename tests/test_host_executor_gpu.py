@@ -1,0 +1,83 @@
+"""The C++ host executable above the C ABI (dsvt-ai-trt_amd/host/dsvt_detect.cpp: loadWeights + createEngine order + the `-d` loop of
+src/dsvt-ai-trt.cpp:532-1970, using only include/dsvt_plugin.h and the HIP runtime) against the Python host (pipeline.py) on the
+same weights and frames: the boxes must be the same BITS -- both hosts fold BatchNorm / re-lay out weights in fp32 in the same
+order and call the same plugins -- and the .txt files the same text as hostio.save_txt's."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "dsvt-ai-trt_amd", "dsvt_detect")
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def wts_file(pkg, tmp_path_factory):
+    path = str(tmp_path_factory.mktemp("wts") / "dsvt.wts")
+    pkg.synth.write_wts(path, pkg.synth.make_weights())
+    return path
+
+
+def _read_rows(path):
+    raw = open(path, "rb").read()
+    k = int(np.frombuffer(raw[:4], np.int32)[0])
+    return k, np.frombuffer(raw[4:], np.float32).reshape(k, 9)
+
+
+def _python_boxes(pkg, caps, pts, n):
+    pipe = pkg.pipeline.DsvtPipeline(pkg.synth.make_weights(), caps=caps, device=DEV, linear_compute=pkg.plugin.COMPUTE_F16,
+                                     head_dtype=torch.float16, device_nms=True)
+    rows, cnt = pipe.forward(torch.from_numpy(pts[None]).to(DEV), torch.tensor([n], dtype=torch.int32, device=DEV))
+    torch.cuda.synchronize()
+    k = int(cnt[0])
+    return k, rows[0, :k].cpu().numpy()
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_cpp_host_equals_python_host_on_reference_frames(pkg, wts_file, tmp_path, graph):
+    assert os.path.exists(EXE), "dsvt_detect was not built (__graft_entry__.build())"
+    out = tmp_path / "out"; out.mkdir()
+    cmd = [EXE, "--wts", wts_file, "--data", cases.GOLDEN, "--out", str(out), "--ref-caps", "--dump-raw"] + ([] if graph else ["--no-graph"])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    caps = pkg.pipeline.Caps.reference()
+    for name in ("000000", "000003", "000004"):
+        pts, n = cases.load_frame(name, caps.N)
+        k, rows = _python_boxes(pkg, caps, pts, n)
+        kc, rc = _read_rows(str(out / f"{name}.rows"))
+        assert kc == k and k > 0
+        assert np.array_equal(rc.view(np.uint32), rows.view(np.uint32)), float(np.abs(rc - rows).max())      # bit for bit
+        # the text file is save_txt's (include/helper.h:441-481): same lines as the Python writer, apart from the time on line 1
+        txt = open(out / f"{name}.txt").read().splitlines()
+        assert txt[1:] == pkg.hostio.format_results(rows, 0.0).splitlines()[1:]
+        assert float(txt[0]) > 0
+
+
+def test_cpp_host_on_the_bench_frame(pkg, wts_file, tmp_path):
+    """BASELINE configs[2] size through the C++ host: lidar_like(180000, 0) written as a .bin, default (Waymo-sized) caps"""
+    data = tmp_path / "data"; data.mkdir(); out = tmp_path / "out"; out.mkdir()
+    p = pkg.synth.lidar_like(180000, 0)
+    p.tofile(data / "000000.bin")
+    r = subprocess.run([EXE, "--wts", wts_file, "--data", str(data), "--out", str(out), "--dump-raw", "--repeat", "20"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    caps = pkg.pipeline.Caps()
+    pts, n = cases.pad_points(p, caps.N)
+    k, rows = _python_boxes(pkg, caps, pts, n)
+    kc, rc = _read_rows(str(out / "000000.rows"))
+    assert kc == k and np.array_equal(rc.view(np.uint32), rows.view(np.uint32))
+    ms = float(open(out / "000000.txt").readline())
+    print("dsvt_detect, 180k-point frame, upload + graph launch + download:", ms, "ms")
+    assert ms < 20.0
+
+
+def test_cpp_host_fails_loudly(wts_file, tmp_path):
+    r = subprocess.run([EXE, "--wts", wts_file, "--data", str(tmp_path), "--out", str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no .bin frames" in r.stderr
+    r = subprocess.run([EXE, "--wts", str(tmp_path / "missing.wts"), "--data", cases.GOLDEN, "--out", str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "cannot open" in r.stderr
