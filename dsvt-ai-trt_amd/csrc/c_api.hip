@@ -17,12 +17,12 @@ static Creator* findCreator(const char* type, const char* version) {
 
 using namespace dsvt;
 
-struct DsvtPlugin { Plugin* impl; };
+struct DsvtPlugin { Plugin* impl; int nbInputs = -1; };      // nbInputs: recorded by dsvtPluginConfigurePlugin
 
 static DsvtPlugin* wrap(Plugin* p, const char* layerName) {
     if (!p) return nullptr;
     if (layerName) p->layerName = layerName;
-    return new DsvtPlugin{p};
+    DsvtPlugin* w = new DsvtPlugin; w->impl = p; return w;
 }
 
 // Nothing may unwind through the C boundary: every entry point that allocates or runs plugin code is wrapped, and a C++ exception
@@ -91,10 +91,51 @@ size_t dsvtPluginGetWorkspaceSize(const DsvtPlugin* p, const DsvtPluginTensorDes
     if (!p) return 0;
     DSVT_GUARD(0, return p->impl->workspaceSize(in, nbIn, out, nbOut);)
 }
+// The batch dimension.  The reference carries it in every tensor shape but its kernels index with the scalar counts of frame 0
+// (points2Features.cu:678,900,919), so only batch 1 works there.  Here a batch of B frames is B consecutive batch-1
+// enqueues on the same stream: every tensor whose leading dimension is B is a stack of per-frame slabs (the layout the reference's
+// own output shapes describe), tensors with another leading dimension (shared tables) are passed to every frame, the workspace is
+// reused (same stream => serialised).  Needs the tensor descriptors, like TensorRT always supplies them.
+static size_t slabBytes(const DsvtPluginTensorDesc& d) {
+    size_t n = d.type == DSVT_HALF ? 2 : (d.type == DSVT_INT8 || d.type == DSVT_BOOL) ? 1 : 4;
+    for (int k = 1; k < d.dims.nbDims; ++k) n *= (size_t)d.dims.d[k];
+    return n;
+}
+static int32_t enqueueBatched(Plugin* impl, int B, int nIn, const DsvtPluginTensorDesc* inDesc, const DsvtPluginTensorDesc* outDesc,
+                              const void* const* inputs, void* const* outputs, void* ws, hipStream_t stream) {
+    const int nOut = impl->nbOutputs();
+    std::vector<DsvtPluginTensorDesc> id(inDesc, inDesc + nIn), od(outDesc, outDesc + nOut);
+    std::vector<const void*> ip(nIn); std::vector<void*> op(nOut);
+    for (int k = 0; k < nIn; ++k) if (id[k].dims.d[0] == B) id[k].dims.d[0] = 1;
+    for (int k = 0; k < nOut; ++k) if (od[k].dims.d[0] == B) od[k].dims.d[0] = 1;
+    for (int b = 0; b < B; ++b) {
+        for (int k = 0; k < nIn; ++k)
+            ip[k] = inDesc[k].dims.d[0] == B ? static_cast<const char*>(inputs[k]) + (size_t)b * slabBytes(inDesc[k]) : inputs[k];
+        for (int k = 0; k < nOut; ++k)
+            op[k] = outDesc[k].dims.d[0] == B ? static_cast<char*>(outputs[k]) + (size_t)b * slabBytes(outDesc[k]) : outputs[k];
+        const int32_t rc = impl->enqueue(id.data(), od.data(), ip.data(), op.data(), ws, stream);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
 int32_t dsvtPluginEnqueue(DsvtPlugin* p, const DsvtPluginTensorDesc* inDesc, const DsvtPluginTensorDesc* outDesc,
                           const void* const* inputs, void* const* outputs, void* ws, dsvtStream_t stream) {
     if (!p || !inputs || !outputs) return kErrNullArg;
-    DSVT_GUARD(kErrException, return p->impl->enqueue(inDesc, outDesc, inputs, outputs, ws, reinterpret_cast<hipStream_t>(stream));)
+    DSVT_GUARD(kErrException,
+        const int B = (inDesc && outDesc && inDesc[0].dims.nbDims >= 1) ? inDesc[0].dims.d[0] : 1;
+        if (B > 1) {
+            // enqueue's signature (like TensorRT's) does not carry the number of inputs: configurePlugin delivers it beforehand
+            if (p->nbInputs < 1) return -2;
+            return enqueueBatched(p->impl, B, p->nbInputs, inDesc, outDesc, inputs, outputs, ws, reinterpret_cast<hipStream_t>(stream));
+        }
+        return p->impl->enqueue(inDesc, outDesc, inputs, outputs, ws, reinterpret_cast<hipStream_t>(stream));)
+}
+int32_t dsvtPluginConfigurePlugin(DsvtPlugin* p, const DsvtPluginTensorDesc* in, int32_t nbIn, const DsvtPluginTensorDesc* out, int32_t nbOut) {
+    if (!p || nbIn < 1 || !in || (nbOut > 0 && !out)) return kErrNullArg;
+    if (nbOut != p->impl->nbOutputs()) return -2;
+    p->nbInputs = nbIn;
+    return 0;
 }
 size_t dsvtPluginGetSerializationSize(const DsvtPlugin* p) {
     if (!p) return 0;
@@ -110,7 +151,9 @@ DsvtPlugin* dsvtPluginClone(const DsvtPlugin* p) {
         Plugin* c = p->impl->clone();
         if (!c) return nullptr;
         c->zeroFill = p->impl->zeroFill;
-        return wrap(c, p->impl->layerName.c_str());)
+        DsvtPlugin* w = wrap(c, p->impl->layerName.c_str());
+        w->nbInputs = p->nbInputs;
+        return w;)
 }
 void dsvtPluginDestroy(DsvtPlugin* p) {
     if (!p) return;

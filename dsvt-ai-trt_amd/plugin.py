@@ -72,6 +72,8 @@ def _load():
     lib.dsvtPluginEnqueue.restype = C.c_int32
     lib.dsvtPluginEnqueue.argtypes = [C.c_void_p, C.POINTER(PluginTensorDesc), C.POINTER(PluginTensorDesc),
                                       C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]
+    lib.dsvtPluginConfigurePlugin.restype = C.c_int32
+    lib.dsvtPluginConfigurePlugin.argtypes = [C.c_void_p, C.POINTER(PluginTensorDesc), C.c_int32, C.POINTER(PluginTensorDesc), C.c_int32]
     lib.dsvtPluginGetSerializationSize.restype = C.c_size_t
     lib.dsvtPluginGetSerializationSize.argtypes = [C.c_void_p]
     lib.dsvtPluginSerialize.argtypes = [C.c_void_p, C.c_void_p]
@@ -94,7 +96,7 @@ EXPORTED_SYMBOLS = [
     "dsvtGetNbPluginTypes", "dsvtGetPluginTypeName", "dsvtGetFieldNames", "dsvtCreatePlugin",
     "dsvtDeserializePlugin", "dsvtPluginGetType", "dsvtPluginGetVersion", "dsvtPluginGetNbOutputs",
     "dsvtPluginGetOutputDimensions", "dsvtPluginGetOutputDataType", "dsvtPluginSupportsFormatCombination",
-    "dsvtPluginGetWorkspaceSize", "dsvtPluginEnqueue", "dsvtPluginGetSerializationSize",
+    "dsvtPluginGetWorkspaceSize", "dsvtPluginConfigurePlugin", "dsvtPluginEnqueue", "dsvtPluginGetSerializationSize",
     "dsvtPluginSerialize", "dsvtPluginClone", "dsvtPluginDestroy", "dsvtPluginSetZeroFill", "dsvtGetBuildInfo",
 ]
 
@@ -298,6 +300,8 @@ class Plugin:
         outd = (PluginTensorDesc * len(outs))(*[_desc(t.shape, _dt_code(t)) for t in outs])
         inp = (C.c_void_p * len(inputs))(*[t.data_ptr() for t in inputs])
         outp = (C.c_void_p * len(outs))(*[t.data_ptr() for t in outs])
+        if LIB.dsvtPluginConfigurePlugin(self._h, ind, len(inputs), outd, len(outs)) != 0:          # configurePlugin(in, nbInputs, out, nbOutputs)
+            raise RuntimeError(f"{self.plugin_type}.configurePlugin failed")
         pack = (outs, ind, outd, inp, outp, C.c_void_p(ws.data_ptr()))
         self._keepalive.append((tuple(inputs), tuple(outs)))      # the cached raw pointers must stay valid
         self._packs[key] = pack

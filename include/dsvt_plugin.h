@@ -159,6 +159,12 @@ int32_t dsvtPluginSupportsFormatCombination(const DsvtPlugin* p, int32_t pos, co
 size_t dsvtPluginGetWorkspaceSize(const DsvtPlugin* p, const DsvtPluginTensorDesc* inputs, int32_t nbInputs,
                                   const DsvtPluginTensorDesc* outputs, int32_t nbOutputs);
 
+/* configurePlugin(in, nbInputs, out, nbOutputs), e.g. Points2FeaturesPlugin::configurePlugin plugins/src/points2Features.cu:257-260
+ * (an empty body there).  Here it records nbInputs, which enqueue's signature does not carry and a batched enqueue needs (below).
+ * Returns 0; -1 on NULL arguments; -2 if nbOutputs is not the plugin's. */
+int32_t dsvtPluginConfigurePlugin(DsvtPlugin* p, const DsvtPluginTensorDesc* inputs, int32_t nbInputs,
+                                  const DsvtPluginTensorDesc* outputs, int32_t nbOutputs);
+
 /* enqueue(inputDesc, outputDesc, inputs, outputs, workspace, stream), e.g.
  * Points2FeaturesPlugin::enqueue plugins/src/points2Features.cu:896-990.
  * All pointers are device pointers owned by the caller; work is issued asynchronously on
@@ -166,7 +172,10 @@ size_t dsvtPluginGetWorkspaceSize(const DsvtPlugin* p, const DsvtPluginTensorDes
  * error returns its hipError_t value (> 0; the reference abort()s instead); -1 = a required
  * pointer (plugin, inputs, outputs) is NULL; -2 = unsupported tensor shape (batch != 1, like
  * the reference, whose kernels ignore the batch dimension: points2Features.cu:678,900); -3 = a
- * C++ exception was caught at the boundary (nothing ever unwinds into the caller). */
+ * C++ exception was caught at the boundary (nothing ever unwinds into the caller).
+ * Batch: when inputDesc[0].dims.d[0] = B > 1 (needs a prior dsvtPluginConfigurePlugin, else -2) the call is B batch-1 enqueues on
+ * `stream`: tensors whose leading dimension is B are stacks of per-frame slabs -- the layout the reference's output shapes describe,
+ * although its kernels only ever process frame 0 (points2Features.cu:678,900,919) -- other tensors are shared by all frames. */
 int32_t dsvtPluginEnqueue(DsvtPlugin* p, const DsvtPluginTensorDesc* inputDesc, const DsvtPluginTensorDesc* outputDesc,
                           const void* const* inputs, void* const* outputs, void* workspace, dsvtStream_t stream);
 

@@ -149,6 +149,19 @@ def test_null_arguments_and_short_fields_are_rejected(pkg):
     assert create("LayerNormPlugin", ln(192)) and not create("LayerNormPlugin", ln(64))
 
 
+def test_configure_plugin_protocol(pkg):
+    """configurePlugin (points2Features.cu:257-260) records nbInputs for batched enqueues; wrong output count is refused"""
+    P = pkg.plugin
+    L = P.LIB
+    op = P.add_gelu_op(16, 8)
+    ind = (P.PluginTensorDesc * 2)(P._desc((2, 16, 8), P.DT_FLOAT), P._desc((2,), P.DT_INT32))
+    outd = (P.PluginTensorDesc * 1)(P._desc((2, 16, 8), P.DT_FLOAT))
+    assert L.dsvtPluginConfigurePlugin(op._h, ind, 2, outd, 1) == 0
+    assert L.dsvtPluginConfigurePlugin(op._h, ind, 2, outd, 3) == -2
+    assert L.dsvtPluginConfigurePlugin(None, ind, 2, outd, 1) == -1
+    assert L.dsvtPluginConfigurePlugin(op._h, None, 2, outd, 1) == -1
+
+
 def test_no_cpu_path(pkg):
     """The product path refuses host tensors instead of silently computing somewhere else."""
     import torch

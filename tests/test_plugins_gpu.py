@@ -484,3 +484,49 @@ def test_fused_pillar_feature_net_equals_plugin_chain(pkg, oracle):
     again = P.Plugin.deserialize("DsvtPillarFeatureNetPlugin", fused.serialize())
     assert np.array_equal(host(again(feat, pidx, pcnt, Pn)[0])[0], v_)
     assert np.abs(v16[0, :np_].float().cpu().numpy() - v_[:np_]).max() < 1e-3 * scale
+
+
+def test_batch_of_frames_through_the_ops(pkg, oracle):
+    """The batch dimension the reference carries but cannot use (points2Features.cu:678,900,919: scalar counts of frame 0): a batch
+    of B frames = B per-frame slabs in every tensor, per-frame device-side counts.  Batch 2 through the voxelizer, the fused pillar
+    feature net, WindowPartition, GetSet, the QKV linear (shared position table), the set attention and the encoder MLP must equal the
+    two frames run one by one, bit for bit; and an un-configured plugin refuses a batched enqueue (-2)."""
+    P = pkg.plugin
+    c = cases.caps("ref")
+    w = pkg.synth.make_weights(with_bev=False)
+    frames = [cases.load_frame(f, c["N"]) for f in ("000000", "000004")]
+    W0, b0 = pkg.pipeline.fold_linear_bn(w, "module.vfe.pfn_layers.0.linear", "module.vfe.pfn_layers.0.norm", 1e-5)
+    W1, b1 = pkg.pipeline.fold_linear_bn(w, "module.vfe.pfn_layers.1.linear", "module.vfe.pfn_layers.1.norm", 1e-5)
+    lp = "module.backbone_3d.stage_0.0.encoder_list.0"
+    ln = lambda k: (w[lp + k + ".weight"], w[lp + k + ".bias"])
+    rng = np.random.default_rng(0)
+    table = dev(rng.standard_normal((1, 144, 192)).astype(np.float32)).half()
+
+    def chain(pts, n):
+        """pts [B, N, 4], n [B] -> list of output tensors (fresh ops every call: output buffers are per op instance)"""
+        vox = make_voxelizer(P, c)(pts, n)
+        feat, pidx, coords, pcnt, Pn, Nk = vox
+        v, v16 = P.add_pillar_feature_net_op(c["P"], W0, b0, W1, b1)(feat, pidx, pcnt, Pn)
+        wpo = P.add_window_partition(c["W"], c["Vw"], 468, 468, 1, 12, 12, 1, 0, 0, 0)(coords, Pn)
+        gso = P.add_get_set_op(c["W"], c["Vw"], 36, 12, 12, 1)(wpo[0], wpo[1], wpo[2], wpo[3])
+        qkv = P.add_linear_op(w[lp + ".win_attn.self_attn.in_proj_weight"], w[lp + ".win_attn.self_attn.in_proj_bias"], c["P"], add_cols=384,
+                              compute_type=P.COMPUTE_F16, input_half=True, output_mode=P.OUT_F16, add_gather_width=12)(v16, Pn, table, wpo[4])[0]
+        att = P.add_set_attention_op(c["W"], 36, 192, 8, 0, c["P"], io_half=True)(qkv, gso[0], gso[1], gso[2])[0]
+        x1, x1h = P.add_encoder_mlp_op(w[lp + ".win_attn.self_attn.out_proj.weight"], w[lp + ".win_attn.self_attn.out_proj.bias"],
+                                       w[lp + ".win_attn.linear1.weight"], w[lp + ".win_attn.linear1.bias"], w[lp + ".win_attn.linear2.weight"],
+                                       w[lp + ".win_attn.linear2.bias"], [ln(".win_attn.norm1"), ln(".win_attn.norm2"), ln(".norm")], c["P"])(att, Pn, v)
+        torch.cuda.synchronize()
+        return list(vox) + [v, v16] + list(wpo) + list(gso) + [qkv, att, x1, x1h]
+
+    both = chain(dev(np.stack([f[0] for f in frames])), torch.tensor([f[1] for f in frames], dtype=torch.int32, device=DEV))
+    assert both[0].shape[0] == 2 and both[4].shape == (2,)
+    for b, (pts, n) in enumerate(frames):
+        one = chain(dev(pts[None]), scalar(n))
+        for k, (t2, t1) in enumerate(zip(both, one)):
+            assert t2.shape[1:] == t1.shape[1:] and torch.equal(t2[b], t1[0]), (b, k)
+    assert int(both[4][0]) == 5504 and int(both[4][1]) == 5211           # per-frame pillar counts (SURVEY 8c)
+    # enqueue without configurePlugin: the number of inputs is unknown, a batch is refused
+    raw = P.add_gelu_op(16, 8)
+    x = torch.zeros((2, 16, 8), device=DEV); cnt = torch.tensor([3, 4], dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError, match="-2"):
+        raw.enqueue([x, cnt], [torch.zeros_like(x)])
