@@ -18,6 +18,7 @@
 // All integer work; results are bit-exact against the oracle.
 #include "plugin_base.h"
 #include "device_utils.h"
+#include <algorithm>
 
 namespace dsvt {
 
@@ -480,5 +481,350 @@ static Creator g_gsCreator{"GetSetPlugin",
      {"win_shape", DSVT_FIELD_INT32}},                                                 // :782-785
     gsCreate, gsDeser, {}, {}};
 static Registrar g_gsReg(&g_gsCreator);
+
+
+// =====================================================================================
+// DsvtSetPartitionPlugin -- WindowPartition + GetSet of ALL window configurations of a frame in four launches
+// (the per-configuration plugins above take 2 x (4 + 2) launches and two workspace memsets: ~75 us of launch latency per frame for
+// ~3 MB of integer work).  blockIdx.y = configuration:
+//   sp_count    window id of every voxel, run-aggregated window counters                 (wp_count)
+//   sp_scan     per configuration ONE workgroup: window ranks / segments (wp_scan) AND the set bases of the ranked windows (gs_scan)
+//   sp_scatter  voxels into their window's segment                                        (wp_scatter)
+//   sp_window   per non-empty window: order its voxels (wp_fill), write the in-window coordinates, sort by the two keys through the
+//               LDS tables and emit the sets (gs_sets) -- gidx / cinw never exist in memory
+// Outputs per configuration k: c2d_k [1,P,3], inds_k [1,2,S,36], mask_k [1,2,S,36], set_num_k [1]: exactly the tensors of
+// WindowPartitionPlugin output 4 and GetSetPlugin outputs 0..2 (bit-identical; tests/test_plugins_gpu.py), i.e. what the fused
+// attention / QKV ops consume.  Same reference lines as above: windowPartition.cu:278-470, getSet.cu:267-704.
+// =====================================================================================
+constexpr int kMaxCfg = 4;
+struct SPParams { int K, max_set_num, voxel_num_set, max_pillars; WPParams wp[kMaxCfg]; int dense_off[kMaxCfg + 1]; };
+// the output tensors of one enqueue, passed by value as a kernel argument (no device-side pointer table that could go stale)
+struct SPOuts { uint32_t* c2d[kMaxCfg]; uint32_t* inds[kMaxCfg]; float* mask[kMaxCfg]; uint32_t* snum[kMaxCfg]; };
+
+__global__ void __launch_bounds__(256)
+sp_count(const uint4* __restrict__ coords, const uint32_t* __restrict__ voxel_num, SPParams sp,
+         uint32_t* __restrict__ win_cnt, uint32_t* __restrict__ vox_win, uint32_t* __restrict__ vox_slot)
+{
+    const int k = blockIdx.y;
+    const WPParams& p = sp.wp[k];
+    win_cnt += sp.dense_off[k]; vox_win += (size_t)k * sp.max_pillars; vox_slot += (size_t)k * sp.max_pillars;
+    uint32_t n = *voxel_num; if (n > (uint32_t)sp.max_pillars) n = sp.max_pillars;
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t win = kNoneU, ix, iy, iz;
+    if (v < n) { winOf(coords[v], p, win, ix, iy, iz); vox_win[v] = win; }
+    const uint32_t prev = __shfl_up(win, 1, kWave);                   // one atomic per run of equal windows (see wp_count)
+    const bool head = lane == 0 || prev != win;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long below = heads & ((2ull << lane) - 1ull);
+    const int leader = 63 - __builtin_clzll(below);
+    uint32_t base = 0;
+    if (head && win != kNoneU) {
+        const unsigned long long nxt = heads & ~((2ull << lane) - 1ull);
+        const int len = (nxt ? __builtin_ctzll(nxt) : 64) - lane;
+        base = atomicAdd(&win_cnt[win], (uint32_t)len);
+    }
+    base = __shfl(base, leader, kWave);
+    if (v < n) vox_slot[v] = win == kNoneU ? 0u : base + (uint32_t)(lane - leader);
+}
+
+// one workgroup per configuration
+__global__ void __launch_bounds__(1024)
+sp_scan(const uint32_t* __restrict__ win_cnt, SPParams sp, uint32_t* __restrict__ win_seg, uint32_t* __restrict__ rank2win,
+        uint32_t* __restrict__ set_base, uint32_t* __restrict__ win_num, SPOuts outs)
+{
+    __shared__ uint32_t smem[1024 / kWave + 1];
+    const int k = blockIdx.x;
+    const WPParams& p = sp.wp[k];
+    const int dense = sp.dense_off[k + 1] - sp.dense_off[k];
+    win_cnt += sp.dense_off[k]; win_seg += sp.dense_off[k];
+    rank2win += (size_t)k * p.max_win_num; set_base += (size_t)k * p.max_win_num;
+    const uint32_t L = (uint32_t)sp.voxel_num_set, Vw = (uint32_t)p.max_voxel_num_per_win;
+    uint32_t carry_o = 0, carry_f = 0, carry_s = 0;
+    for (int b = 0; b < dense; b += 1024) {
+        const int w = b + threadIdx.x;
+        const uint32_t c = w < dense ? win_cnt[w] : 0;
+        uint32_t tot;
+        const uint32_t eo = blockExclusiveScan<1024>(c > 0 ? 1u : 0u, smem, &tot) + carry_o; carry_o += tot;
+        const uint32_t ef = blockExclusiveScan<1024>(c, smem, &tot) + carry_f; carry_f += tot;
+        // sets of a ranked window: ceil(min(c, Vw) / L) (getSet.cu:335 on the clamped count of windowPartition.cu:336-340); windows beyond
+        // the window capacity get none
+        const bool ranked = c > 0 && eo < (uint32_t)p.max_win_num;
+        const uint32_t ns = ranked ? setsOf(c > Vw ? Vw : c, L) : 0u;
+        const uint32_t es = blockExclusiveScan<1024>(ns, smem, &tot) + carry_s; carry_s += tot;
+        if (w < dense) {
+            win_seg[w] = ef;
+            if (ranked) {
+                rank2win[eo] = (uint32_t)w;
+                set_base[eo] = es + ns <= (uint32_t)sp.max_set_num ? es : kNoneU;      // capacity guard the reference lacks (getSet.cu:337)
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        win_num[k] = carry_o < (uint32_t)p.max_win_num ? carry_o : (uint32_t)p.max_win_num;
+        // the sets that fit form a prefix (bases ascend): their number is the largest base + ns that still fits = min(total, ...) only when
+        // nothing overflowed; with an overflow the last fitting window is found by sp_window's writers, so publish the clamped total here
+        *outs.snum[k] = carry_s <= (uint32_t)sp.max_set_num ? carry_s : kNoneU;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+sp_scatter(const uint32_t* __restrict__ voxel_num, SPParams sp, const uint32_t* __restrict__ vox_win, const uint32_t* __restrict__ vox_slot,
+           const uint32_t* __restrict__ win_seg, uint32_t* __restrict__ sorted_vox)
+{
+    const int k = blockIdx.y;
+    vox_win += (size_t)k * sp.max_pillars; vox_slot += (size_t)k * sp.max_pillars; sorted_vox += (size_t)k * sp.max_pillars;
+    win_seg += sp.dense_off[k];
+    uint32_t n = *voxel_num; if (n > (uint32_t)sp.max_pillars) n = sp.max_pillars;
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const uint32_t w = vox_win[v];
+    if (w != kNoneU) sorted_vox[win_seg[w] + vox_slot[v]] = v;
+}
+
+// the ordering step of wp_fill: afterwards lds[0 .. n) holds the window's voxel ids ascending.  lds: 2 x cap words (cap = pow2 >= volume)
+__device__ __forceinline__ void orderWindowVoxels(const uint4* __restrict__ coords, const WPParams& p, uint32_t n, uint32_t seg,
+                                                  const uint32_t* __restrict__ sorted_vox, uint32_t* lds, unsigned long long* bits)
+{
+    const uint32_t vol = (uint32_t)(p.wx * p.wy);
+    int m = 1; while ((uint32_t)m < n) m <<= 1;
+    bool sorted = false;
+    if (p.wz == 1 && p.sz == 1 && vol <= 1024u && n <= vol) {           // occupancy bitmap + popcount, verified (see wp_fill)
+        uint32_t* ord = lds + m;
+        if (threadIdx.x < 17) bits[threadIdx.x] = 0ull;
+        __syncthreads();
+        for (uint32_t s = threadIdx.x; s < n; s += blockDim.x) {
+            const uint32_t v = sorted_vox[seg + s];
+            uint32_t win, ix, iy, iz;
+            winOf(coords[v], p, win, ix, iy, iz);
+            const uint32_t cell = iy * (uint32_t)p.wx + ix;
+            atomicOr(&bits[cell >> 6], 1ull << (cell & 63));
+            lds[s] = v;
+        }
+        __syncthreads();
+        for (uint32_t s0 = threadIdx.x; s0 < n; s0 += blockDim.x) {
+            const uint32_t v = lds[s0];
+            uint32_t win, ix, iy, iz;
+            winOf(coords[v], p, win, ix, iy, iz);
+            const uint32_t cell = iy * (uint32_t)p.wx + ix;
+            uint32_t s = (uint32_t)__popcll(bits[cell >> 6] & ((1ull << (cell & 63)) - 1ull));
+            for (uint32_t q = 0; q < (cell >> 6); ++q) s += (uint32_t)__popcll(bits[q]);
+            ord[s] = v;
+        }
+        __syncthreads();
+        int bad = 0;
+        for (uint32_t i = threadIdx.x; i + 1 < n; i += blockDim.x) bad |= ord[i] >= ord[i + 1];
+        sorted = !__syncthreads_or(bad);
+        if (sorted)
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lds[i] = ord[i];
+        __syncthreads();
+    }
+    if (!sorted) {
+        for (int i = threadIdx.x; i < m; i += blockDim.x) lds[i] = (uint32_t)i < n ? sorted_vox[seg + i] : kNoneU;
+        __syncthreads();
+        bitonicSortLds(lds, m);
+    }
+}
+
+// one workgroup per (ranked window, configuration)
+__global__ void __launch_bounds__(256)
+sp_window(const uint4* __restrict__ coords, SPParams sp, const uint32_t* __restrict__ win_num, const uint32_t* __restrict__ rank2win,
+          const uint32_t* __restrict__ win_cnt, const uint32_t* __restrict__ win_seg, const uint32_t* __restrict__ sorted_vox,
+          const uint32_t* __restrict__ set_base, int cap_words, SPOuts outs)
+{
+    extern __shared__ uint32_t lds[];
+    __shared__ unsigned long long bits[17];
+    __shared__ uint32_t smem[256 / kWave + 1];
+    const int k = blockIdx.y;
+    const WPParams& p = sp.wp[k];
+    const uint32_t r = blockIdx.x;
+    if (r >= win_num[k]) return;
+    rank2win += (size_t)k * p.max_win_num; set_base += (size_t)k * p.max_win_num;
+    win_cnt += sp.dense_off[k]; win_seg += sp.dense_off[k]; sorted_vox += (size_t)k * sp.max_pillars;
+    uint32_t* c2d = outs.c2d[k]; uint32_t* inds = outs.inds[k]; float* mask = outs.mask[k];
+    const uint32_t w = rank2win[r], nall = win_cnt[w], seg = win_seg[w];
+    const uint32_t Vw = (uint32_t)p.max_voxel_num_per_win, L = (uint32_t)sp.voxel_num_set, MS = (uint32_t)sp.max_set_num;
+    orderWindowVoxels(coords, p, nall, seg, sorted_vox, lds, bits);
+    // ---- WindowPartition outputs that survive: in-window coordinates per voxel (:362-364); voxels beyond the cap are dropped (:305)
+    const uint32_t n = nall < Vw ? nall : Vw;
+    const uint32_t vol = (uint32_t)(p.wx * p.wy * p.wz);
+    uint32_t* ty = lds + cap_words;     // [vol]  key_y -> voxel id
+    uint32_t* tx = ty + vol;            // [vol]
+    uint32_t* sy = tx + vol;            // [Vw]   voxel ids ascending by key_y
+    uint32_t* sx = sy + Vw;             // [Vw]
+    for (uint32_t i = threadIdx.x; i < vol; i += blockDim.x) { ty[i] = kNoneU; tx[i] = kNoneU; }
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { sy[i] = 0; sx[i] = 0; }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < nall; s += blockDim.x) {
+        const uint32_t v = lds[s];
+        uint32_t win, ix, iy, iz;
+        winOf(coords[v], p, win, ix, iy, iz);
+        if (s < Vw) {
+            c2d[(size_t)v * 3 + 0] = iz; c2d[(size_t)v * 3 + 1] = iy; c2d[(size_t)v * 3 + 2] = ix;
+            const uint32_t ky = iy * (uint32_t)(p.wx * p.wz) + ix * (uint32_t)p.wz + iz;          // getSet.cu:386-387
+            const uint32_t kx = ix * (uint32_t)(p.wy * p.wz) + iy * (uint32_t)p.wz + iz;          // :461-462
+            if (ky < vol) ty[ky] = v;
+            if (kx < vol) tx[kx] = v;
+        } else {
+            c2d[(size_t)v * 3 + 0] = 0; c2d[(size_t)v * 3 + 1] = 0; c2d[(size_t)v * 3 + 2] = 0;
+        }
+    }
+    __syncthreads();
+    const uint32_t base = set_base[r];
+    if (base == kNoneU) {                     // this window's sets do not fit: the FIRST such window publishes the set count
+        // (bases ascend with the rank: the previous window fits iff its base is valid)
+        if (threadIdx.x == 0 && (r == 0 || set_base[r - 1] != kNoneU)) {
+            uint32_t prev = 0;
+            if (r > 0) { const uint32_t pw = rank2win[r - 1]; const uint32_t pc = win_cnt[pw] < Vw ? win_cnt[pw] : Vw; prev = set_base[r - 1] + setsOf(pc, L); }
+            *outs.snum[k] = prev;
+        }
+        return;
+    }
+    // compact both tables in key order (ascending sort of unique keys)
+    uint32_t cy = 0, cx = 0;
+    for (uint32_t b = 0; b < vol; b += blockDim.x) {
+        const uint32_t i = b + threadIdx.x;
+        uint32_t tot;
+        const uint32_t vy = i < vol ? ty[i] : kNoneU, vx = i < vol ? tx[i] : kNoneU;
+        const uint32_t ey = blockExclusiveScan<256>(vy != kNoneU ? 1u : 0u, smem, &tot) + cy; cy += tot;
+        const uint32_t ex = blockExclusiveScan<256>(vx != kNoneU ? 1u : 0u, smem, &tot) + cx; cx += tot;
+        if (vy != kNoneU && ey < Vw) sy[ey] = vy;
+        if (vx != kNoneU && ex < Vw) sx[ex] = vx;
+    }
+    __syncthreads();
+    const uint32_t ns = setsOf(n, L);
+    const int ni = (int)n, Li = (int)L, nsi = (int)ns;
+    for (uint32_t t = threadIdx.x; t < ns * L; t += blockDim.x) {
+        const int j = (int)(t / L), kk = (int)(t % L);
+        const int local = (j * Li + kk) * ni / Li / nsi;                                // getSet.cu:346 paper eq.(3), int arithmetic
+        const int prev = kk > 0 ? (j * Li + kk - 1) * ni / Li / nsi : -1;
+        const size_t s = base + (uint32_t)j;
+        const uint32_t iy = sy[local], ix = sx[local];
+        inds[(size_t)0 * MS * L + s * L + kk] = iy;                                     // :535-538
+        inds[(size_t)1 * MS * L + s * L + kk] = ix;
+        mask[(size_t)0 * MS * L + s * L + kk] = (kk > 0 && iy == sy[prev]) ? -3.4028235e+38f : 0.0f;      // :544-565
+        mask[(size_t)1 * MS * L + s * L + kk] = (kk > 0 && ix == sx[prev]) ? -3.4028235e+38f : 0.0f;
+    }
+}
+
+class DsvtSetPartitionPlugin : public Plugin {
+public:
+    SPParams sp_{};
+    explicit DsvtSetPartitionPlugin(const SPParams& sp) : sp_(sp) {}
+    const char* type() const override { return "DsvtSetPartitionPlugin"; }
+    int nbOutputs() const override { return 4 * sp_.K; }
+    int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
+        if (i < 0 || i >= nbOutputs()) return -1;
+        const int b = in[0].d[0];
+        switch (i % 4) {
+            case 0: *out = dims3(b, sp_.max_pillars, 3); return 0;                                  // c2d
+            case 1: case 2: *out = dims4(b, 2, sp_.max_set_num, sp_.voxel_num_set); return 0;       // inds, mask
+            default: *out = dims1(b); return 0;                                                     // set_num
+        }
+    }
+    int outputType(int i, const int32_t*, int) const override { return i % 4 == 2 ? DSVT_FLOAT : DSVT_INT32; }
+    bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int, int) const override {
+        if (pos < 2) return i32L(io[pos]);
+        return (pos - 2) % 4 == 2 ? f32L(io[pos]) : i32L(io[pos]);
+    }
+    int denseAll() const { return sp_.dense_off[sp_.K]; }
+    size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override {
+        const size_t mw = sp_.wp[0].max_win_num;
+        return 2 * alignUp(sizeof(uint32_t) * denseAll()) + 2 * alignUp(sizeof(uint32_t) * sp_.K * mw) + alignUp(sizeof(uint32_t) * kMaxCfg) +
+               3 * alignUp(sizeof(uint32_t) * (size_t)sp_.K * sp_.max_pillars);
+    }
+    int enqueue(const DsvtPluginTensorDesc*, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void* workspace,
+                hipStream_t stream) override {
+        const uint4* coords = static_cast<const uint4*>(in[0]);
+        const uint32_t* voxel_num = static_cast<const uint32_t*>(in[1]);
+        const int K = sp_.K, mp = sp_.max_pillars, mw = sp_.wp[0].max_win_num;
+        WsCarver ws(workspace);
+        uint32_t* win_cnt = ws.take<uint32_t>(denseAll());
+        uint32_t* win_seg = ws.take<uint32_t>(denseAll());
+        uint32_t* rank2win = ws.take<uint32_t>((size_t)K * mw);
+        uint32_t* set_base = ws.take<uint32_t>((size_t)K * mw);
+        uint32_t* win_num = ws.take<uint32_t>(kMaxCfg);
+        uint32_t* vox_win = ws.take<uint32_t>((size_t)K * mp);
+        uint32_t* vox_slot = ws.take<uint32_t>((size_t)K * mp);
+        uint32_t* sorted_vox = ws.take<uint32_t>((size_t)K * mp);
+        SPOuts o{};
+        for (int k = 0; k < K; ++k) {
+            o.c2d[k] = static_cast<uint32_t*>(out[4 * k]); o.inds[k] = static_cast<uint32_t*>(out[4 * k + 1]);
+            o.mask[k] = static_cast<float*>(out[4 * k + 2]); o.snum[k] = static_cast<uint32_t*>(out[4 * k + 3]);
+        }
+        DSVT_CHECK(hipMemsetAsync(win_cnt, 0, sizeof(uint32_t) * denseAll(), stream));
+        if (zeroFill)
+            for (int k = 0; k < K; ++k) {
+                const size_t e = (size_t)2 * sp_.max_set_num * sp_.voxel_num_set;
+                DSVT_CHECK(hipMemsetAsync(o.c2d[k], 0, sizeof(uint32_t) * (size_t)mp * 3, stream));
+                DSVT_CHECK(hipMemsetAsync(o.inds[k], 0, sizeof(uint32_t) * e, stream));
+                DSVT_CHECK(hipMemsetAsync(o.mask[k], 0, sizeof(float) * e, stream));
+            }
+        hipLaunchKernelGGL(sp_count, dim3(cdiv(mp, 256), K), dim3(256), 0, stream, coords, voxel_num, sp_, win_cnt, vox_win, vox_slot);
+        hipLaunchKernelGGL(sp_scan, dim3(K), dim3(1024), 0, stream, win_cnt, sp_, win_seg, rank2win, set_base, win_num, o);
+        hipLaunchKernelGGL(sp_scatter, dim3(cdiv(mp, 256), K), dim3(256), 0, stream, voxel_num, sp_, vox_win, vox_slot, win_seg, sorted_vox);
+        int capw = 2, ldsw = 0;
+        for (int k = 0; k < K; ++k) {
+            const int vol = sp_.wp[k].wx * sp_.wp[k].wy * sp_.wp[k].wz; int cap = 1; while (cap < vol) cap <<= 1;
+            capw = std::max(capw, 2 * cap);
+            ldsw = std::max(ldsw, 2 * vol + 2 * sp_.wp[k].max_voxel_num_per_win);
+        }
+        hipLaunchKernelGGL(sp_window, dim3(mw, K), dim3(256), sizeof(uint32_t) * (size_t)(capw + ldsw), stream, coords, sp_, win_num, rank2win,
+                           win_cnt, win_seg, sorted_vox, set_base, capw, o);
+        return lastError();
+    }
+    size_t serializationSize() const override { return sizeof(int) * (5 + 9 * (size_t)sp_.K + 2); }
+    void serialize(void* b) const override {
+        char* d = static_cast<char*>(b);
+        wr<int>(d, sp_.K); wr<int>(d, sp_.max_set_num); wr<int>(d, sp_.voxel_num_set); wr<int>(d, sp_.max_pillars);
+        wr<int>(d, sp_.wp[0].max_win_num); wr<int>(d, sp_.wp[0].max_voxel_num_per_win); wr<int>(d, sp_.wp[0].sx);
+        for (int k = 0; k < sp_.K; ++k) {
+            const WPParams& p = sp_.wp[k];
+            wr<int>(d, p.sx); wr<int>(d, p.sy); wr<int>(d, p.sz); wr<int>(d, p.wx); wr<int>(d, p.wy); wr<int>(d, p.wz); wr<int>(d, p.hx); wr<int>(d, p.hy); wr<int>(d, p.hz);
+        }
+    }
+    Plugin* clone() const override { return new DsvtSetPartitionPlugin(sp_); }
+};
+static Plugin* spNew(int K, int mw, int vw, int L, int ms, int mp, const int* shape, const int* wins, const int* shifts) {
+    if (K < 1 || K > kMaxCfg || mw <= 0 || vw <= 0 || L <= 0 || mp <= 0) return nullptr;
+    SPParams sp{}; sp.K = K; sp.max_set_num = ms > 0 ? ms : mw; sp.voxel_num_set = L; sp.max_pillars = mp;
+    for (int k = 0; k < K; ++k) {
+        WPParams& p = sp.wp[k];
+        p.max_win_num = mw; p.max_voxel_num_per_win = vw; p.sx = shape[0]; p.sy = shape[1]; p.sz = shape[2];
+        p.wx = wins[3 * k]; p.wy = wins[3 * k + 1]; p.wz = wins[3 * k + 2]; p.hx = shifts[3 * k]; p.hy = shifts[3 * k + 1]; p.hz = shifts[3 * k + 2];
+        if (p.wx <= 0 || p.wy <= 0 || p.wz <= 0 || p.sx <= 0 || p.sy <= 0 || p.sz <= 0 || p.hx < 0 || p.hy < 0 || p.hz < 0) return nullptr;
+        if ((long)p.wx * p.wy * p.wz > 8192) return nullptr;
+        p.nwx = (int)(ceilf((float)(p.sx / p.wx)) + 1); p.nwy = (int)(ceilf((float)(p.sy / p.wy)) + 1); p.nwz = (int)(ceilf((float)(p.sz / p.wz)) + 1);   // windowPartition.cu:425-427
+        sp.dense_off[k + 1] = sp.dense_off[k] + p.nwx * p.nwy * p.nwz;
+    }
+    return new DsvtSetPartitionPlugin(sp);
+}
+static Plugin* spCreate(const DsvtPluginFieldCollection* fc) {
+    const int K = fieldInt(fc, "num_configs");
+    if (K < 1 || K > kMaxCfg) return nullptr;
+    int shape[3], wins[3 * kMaxCfg], shifts[3 * kMaxCfg];
+    fieldInts(fc, "sparse_shape", shape, 3); fieldInts(fc, "win_shapes", wins, 3 * K); fieldInts(fc, "shift_lists", shifts, 3 * K);
+    return spNew(K, fieldInt(fc, "max_win_num"), fieldInt(fc, "max_voxel_num_per_win"), fieldInt(fc, "voxel_num_set"), fieldInt(fc, "max_set_num", 0),
+                 fieldInt(fc, "max_pillars_num"), shape, wins, shifts);
+}
+static Plugin* spDeser(const void* data, size_t len) {
+    if (len < 7 * sizeof(int)) return nullptr;
+    const char* d = static_cast<const char*>(data);
+    const int K = rd<int>(d), ms = rd<int>(d), L = rd<int>(d), mp = rd<int>(d), mw = rd<int>(d), vw = rd<int>(d); (void)rd<int>(d);
+    if (K < 1 || K > kMaxCfg || len < sizeof(int) * (7 + 9 * (size_t)K)) return nullptr;
+    int shape[3] = {0, 0, 0}, wins[3 * kMaxCfg], shifts[3 * kMaxCfg];
+    for (int k = 0; k < K; ++k) {
+        shape[0] = rd<int>(d); shape[1] = rd<int>(d); shape[2] = rd<int>(d);
+        for (int e = 0; e < 3; ++e) wins[3 * k + e] = rd<int>(d);
+        for (int e = 0; e < 3; ++e) shifts[3 * k + e] = rd<int>(d);
+    }
+    return spNew(K, mw, vw, L, ms, mp, shape, wins, shifts);
+}
+static Creator g_spCreator{"DsvtSetPartitionPlugin",
+    {{"max_win_num", DSVT_FIELD_INT32}, {"max_voxel_num_per_win", DSVT_FIELD_INT32}, {"voxel_num_set", DSVT_FIELD_INT32},
+     {"max_set_num", DSVT_FIELD_INT32}, {"max_pillars_num", DSVT_FIELD_INT32}, {"sparse_shape", DSVT_FIELD_INT32},
+     {"num_configs", DSVT_FIELD_INT32}, {"win_shapes", DSVT_FIELD_INT32}, {"shift_lists", DSVT_FIELD_INT32}},
+    spCreate, spDeser, {}, {}};
+static Registrar g_spReg(&g_spCreator);
 
 }  // namespace dsvt

@@ -195,7 +195,7 @@ struct Op {
 struct Layer { Op qkv, attn, mlp; Tensor table; };
 struct Engine {
     Caps c;
-    Op voxelizer, pfn, wp[2], gs[2], map2bev, shared, heads0, heads1, topk, filter, nms;
+    Op voxelizer, pfn, part, map2bev, shared, heads0, heads1, topk, filter, nms;
     Layer layers[4][2];
     std::map<std::string, Op> conv;
     Tensor cat_bev;
@@ -217,14 +217,12 @@ struct Engine {
             Fields f; f.i("max_pillars_num", c.P).fl("weight0", W0).fl("bias0", b0).fl("weight1", W1).fl("bias1", b1);
             pfn = Op("DsvtPillarFeatureNetPlugin", f, "pillar_feature_net_layer", false);
         }
-        for (int k = 0; k < 2; ++k) {     // WindowPartition / GetSet per window configuration (:592-601)
-            const int* win = WINS[k][0]; const int* sh = WINS[k][1];
-            Fields f; f.i("max_win_num", c.W).i("max_voxel_num_per_win", c.Vw).i("sparse_shape", {GX, GY, GZ})
-                       .i("win_shape", {win[0], win[1], win[2]}).i("shift_list", {sh[0], sh[1], sh[2]});
-            wp[k] = Op("WindowPartitionPlugin", f, "window_partition_layer", false);
-            Fields g; g.i("max_win_num", c.W).i("max_voxel_num_per_win", c.Vw).i("voxel_num_set", L_SET).i("win_shape", {win[0], win[1], win[2]});
-            if (c.S != c.W) g.i("max_set_num", c.S);
-            gs[k] = Op("GetSetPlugin", g, "get_set_layer", false);
+        {   // WindowPartition + GetSet of both window configurations (:592-601) in one fused op: in-window coordinates, set indices / masks / counts
+            Fields f; f.i("max_win_num", c.W).i("max_voxel_num_per_win", c.Vw).i("voxel_num_set", L_SET).i("max_set_num", c.S).i("max_pillars_num", c.P)
+                       .i("sparse_shape", {GX, GY, GZ}).i("num_configs", 2)
+                       .i("win_shapes", {WINS[0][0][0], WINS[0][0][1], WINS[0][0][2], WINS[1][0][0], WINS[1][0][1], WINS[1][0][2]})
+                       .i("shift_lists", {WINS[0][1][0], WINS[0][1][1], WINS[0][1][2], WINS[1][1][0], WINS[1][1][1], WINS[1][1][2]});
+            part = Op("DsvtSetPartitionPlugin", f, "set_partition_layer", false);
         }
         buildPosTables(w, s);
         const float scale = (float)std::sqrt((double)C / H);        // np.float32(math.sqrt(C / H))
@@ -359,18 +357,14 @@ struct Engine {
         const std::vector<Tensor>& v = voxelizer({points, count}, s);             // feat, pidx, coords, pcnt, P, Nk
         const Tensor coords = v[2], Pn = v[4];
         const std::vector<Tensor>& pf = pfn({v[0], v[1], v[3], Pn}, s);           // pillar features fp32, fp16
-        std::vector<Tensor> wpo[2], gso[2];
-        for (int k = 0; k < 2; ++k) {
-            wpo[k] = wp[k]({coords, Pn}, s);                                      // gidx, cinw, vcnt, W, c2d, xy
-            gso[k] = gs[k]({wpo[k][0], wpo[k][1], wpo[k][2], wpo[k][3]}, s);      // inds, mask, S, mask0_h, mask1_h
-        }
+        const std::vector<Tensor>& po = part({coords, Pn}, s);                    // per configuration k: c2d, inds, mask, S at 4k .. 4k+3
         Tensor x = pf[0], xh = pf[1];
         for (int b = 0; b < 4; ++b) {
             const Tensor xb = x;
-            const std::vector<Tensor>& g = gso[b % 2];
+            const Tensor* g = &po[4 * (b % 2) + 1];                               // inds, mask, S of window configuration b % 2
             for (int l = 0; l < 2; ++l) {
                 Layer& L = layers[b][l];
-                const Tensor qkv = L.qkv({xh, Pn, L.table, wpo[l][4]}, s)[0];     // position table of window configuration l (:603-637)
+                const Tensor qkv = L.qkv({xh, Pn, L.table, po[4 * l]}, s)[0];     // position table of window configuration l (:603-637)
                 const Tensor att = L.attn({qkv, g[0], g[1], g[2]}, s)[0];
                 const std::vector<Tensor>& o = l == 1 ? L.mlp({att, Pn, x, xb}, s) : L.mlp({att, Pn, x}, s);
                 x = o[0]; xh = o[1];

@@ -129,6 +129,11 @@ class DsvtPipeline:
         self.smax1 = zf(P.add_torch_scatter_max(c.Nk, c.P, 192))
         self.wp = [zf(P.add_window_partition(c.W, c.Vw, GX, GY, GZ, *win, *shift)) for win, shift in WINS]
         self.gs = [zf(P.add_get_set_op(c.W, c.Vw, L_SET, *win, max_set_num=c.S)) for win, _ in WINS]
+        # fp16 frame: both window configurations' WindowPartition + GetSet in four launches; only the tensors the fused ops consume
+        # (window coordinates, set indices / masks / counts) are produced
+        self.fused_partition = f16 and (pos_table is None or pos_table) and (fused_mlp is None or fused_mlp)
+        if self.fused_partition:
+            self.part = zf(P.add_set_partition_op(c.W, c.Vw, L_SET, c.S, c.P, (GX, GY, GZ), WINS))
         self.pe, self.layers, self.res_ln = {}, {}, {}
         scale = np.float32(math.sqrt(C / H))
         for b in range(blocks):
@@ -369,6 +374,11 @@ class DsvtPipeline:
                     join = torch.cuda.Event(); join.record(self.side)
                 vfeat, vfeat16 = self.pfn(feat, pidx, pcnt, Pn)
                 main.wait_event(join)
+            elif self.fused_partition:
+                vfeat, vfeat16 = self.pfn(feat, pidx, pcnt, Pn)
+                po = self.part(coords, Pn)
+                wps = [[None, None, None, None, po[4 * k], None] for k in range(len(WINS))]      # slot 4 = in-window coordinates
+                gss = [[po[4 * k + 1], po[4 * k + 2], po[4 * k + 3]] for k in range(len(WINS))]  # inds, mask, set count
             else:
                 vfeat, vfeat16 = self.pfn(feat, pidx, pcnt, Pn)
                 wps = [op(coords, Pn) for op in self.wp]

@@ -358,6 +358,16 @@ def add_get_set_op(max_win_num, max_voxel_num_per_win, voxel_num_set, win_shape_
     return Plugin("GetSetPlugin", f, "get_set_layer")
 
 
+def add_set_partition_op(max_win_num, max_voxel_num_per_win, voxel_num_set, max_set_num, max_pillars_num, sparse_shape, wins):
+    """WindowPartition + GetSet of several window configurations in four launches (csrc/partition_ops.hip DsvtSetPartitionPlugin).
+    wins: [(win_shape xyz, shift xyz), ...].  Inputs: coords [1,P,4], pillar_num [1].  Outputs per configuration k: c2d_k [1,P,3]
+    (= WindowPartition output 4), inds_k [1,2,S,36], mask_k [1,2,S,36], set_num_k [1] (= GetSet outputs 0..2)."""
+    return Plugin("DsvtSetPartitionPlugin", dict(
+        max_win_num=max_win_num, max_voxel_num_per_win=max_voxel_num_per_win, voxel_num_set=voxel_num_set, max_set_num=max_set_num,
+        max_pillars_num=max_pillars_num, sparse_shape=[int(v) for v in sparse_shape], num_configs=len(wins),
+        win_shapes=[int(v) for w_, _s in wins for v in w_], shift_lists=[int(v) for _w, s_ in wins for v in s_]), "set_partition_layer")
+
+
 def add_get_value_by_index_op(max_win_num, voxel_num_set, channel_num, axis_id):
     """plugin_helper.h:316-369.  Inputs: voxel_features, pose_features, voxel_inds, valid_set_num."""
     return Plugin("GetValueByIndexPlugin", dict(max_win_num=max_win_num, voxel_num_set=voxel_num_set,

@@ -530,3 +530,55 @@ def test_batch_of_frames_through_the_ops(pkg, oracle):
     x = torch.zeros((2, 16, 8), device=DEV); cnt = torch.tensor([3, 4], dtype=torch.int32, device=DEV)
     with pytest.raises(RuntimeError, match="-2"):
         raw.enqueue([x, cnt], [torch.zeros_like(x)])
+
+
+@pytest.mark.parametrize("frame,capname,n_pts", [("000000", "ref", 0), ("000004", "ref", 0), (None, "waymo", 180000)])
+def test_fused_set_partition_against_oracle(pkg, oracle, frame, capname, n_pts):
+    """DsvtSetPartitionPlugin (both window configurations, four launches) against the oracle's WindowPartition + GetSet: in-window
+    coordinates, set indices, masks and set counts bit-exact -- the same tensors the per-configuration plugins produce."""
+    P, O = pkg.plugin, oracle
+    c = cases.caps(capname)
+    S_cap = 4096 if capname == "waymo" else c["W"]
+    if frame:
+        pts, n = cases.load_frame(frame, c["N"])
+    else:
+        pts, n = cases.pad_points(pkg.synth.lidar_like(n_pts, 0), c["N"])
+    vox = O.points2features(pts, n, cases.p2f_cfg(c))
+    _, outs = run_voxelizer(P, c, pts, n)
+    op = P.add_set_partition_op(c["W"], c["Vw"], 36, S_cap, c["P"], cases.GRID, cases.WINS)
+    po = op(outs[2], outs[4])
+    torch.cuda.synchronize()
+    for k in range(2):
+        rw = O.window_partition(vox["coords"], vox["P"], cases.wp_cfg(c, k))
+        rg = O.get_set(rw["gidx"], rw["cinw"], rw["vcnt"], rw["W"], dict(cases.gs_cfg(c, k), max_win_num=S_cap))
+        c2d, inds, mask, S = [host(t) for t in po[4 * k:4 * k + 4]]
+        assert int(S[0]) == rg["S"]
+        assert np.array_equal(c2d[0], rw["c2d"])
+        assert np.array_equal(inds[0], rg["inds"]) and np.array_equal(mask[0], rg["mask"])
+    again = P.Plugin.deserialize("DsvtSetPartitionPlugin", op.serialize())
+    assert again.serialize() == op.serialize()
+    po2 = again(outs[2], outs[4])
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(po, po2))
+
+
+def test_fused_set_partition_capacity_and_generic_order(pkg, oracle):
+    """set capacity overflow truncates at the first window that does not fit (like GetSet); shuffled pillar order (not Points2Features'
+    canonical order) goes through the sort fallback"""
+    P, O = pkg.plugin, oracle
+    c = cases.caps("ref")
+    pts, n = cases.load_frame("000003", c["N"])
+    vox = O.points2features(pts, n, cases.p2f_cfg(c))
+    rng = np.random.default_rng(1)
+    perm = rng.permutation(vox["P"])
+    coords = vox["coords"].copy(); coords[:vox["P"]] = coords[perm]
+    for S_cap in (800, 200):
+        po = P.add_set_partition_op(c["W"], c["Vw"], 36, S_cap, c["P"], cases.GRID, cases.WINS)(dev(coords[None]), scalar(vox["P"]))
+        torch.cuda.synchronize()
+        for k in range(2):
+            rw = O.window_partition(coords, vox["P"], cases.wp_cfg(c, k))
+            rg = O.get_set(rw["gidx"], rw["cinw"], rw["vcnt"], rw["W"], dict(cases.gs_cfg(c, k), max_win_num=S_cap))
+            c2d, inds, mask, S = [host(t) for t in po[4 * k:4 * k + 4]]
+            assert int(S[0]) == rg["S"] and (S_cap == 800 or rg["S"] <= 200)
+            assert np.array_equal(c2d[0], rw["c2d"])
+            assert np.array_equal(inds[0], rg["inds"]) and np.array_equal(mask[0], rg["mask"])
