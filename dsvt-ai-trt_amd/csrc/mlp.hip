@@ -141,15 +141,20 @@ __device__ __forceinline__ void mlpLayerNormLds(floatx4 (&acc)[MNT], const float
 // PQ = FC1 columns per piece: 64 => fifteen 24-row stages (24 KB).  A stage's MFMAs (0.2-0.35 us) are much shorter than a
 // DMA round trip (~2 us), so the ring has THREE slots and stage s+2 is requested when stage s starts: the end-of-stage wait
 // is a counted vmcnt that retires stage s+1 and leaves s+2 in flight.
-template <int MT, int NW, int PQ>
+// RS = slots of the weight ring, D = RS - 1 = prefetch distance in stages.  With three slots a stage costs max(its MFMAs, half a DMA
+// round trip) ~ 1 us: fifteen stages = 15 us of a 44 us launch were DMA latency.  The elastic variant runs ONE workgroup per CU anyway,
+// so it takes six slots (147 KB): stage s + 5 is requested when stage s starts and the counted wait at the end of stage s leaves four
+// stages in flight.
+template <int MT, int NW, int PQ, int RS>
 __global__ void __launch_bounds__(64 * NW, (MT == 1 ? 3 : 2))
 encoder_mlp_stream_kernel(MlpStreamArgs a)
 {
     constexpr int PQT = PQ / 16, PQS = PQ / 32, SR = 6 * PQT, SB = SR * 1024, NWO = MC / PQ, NPIECE = MF / PQ;
-    constexpr int NST = NWO + 2 * NPIECE, NRW = SR / NW;
+    constexpr int NST = NWO + 2 * NPIECE, NRW = SR / NW, D = RS - 1;
+    constexpr int LNP = 8 * MC * 4;                 // ln_g [4][192] | ln_b [4][192] of the final LayerNorms: six 1 KB DMA rows
     constexpr bool ELASTIC = MT == 1 && NW == 10;   // 8 .. 10 waves of 16 rows are live, chosen from the row count (see below)
     static_assert(12 * PQS == SR && (ELASTIC || (SR % NW == 0 && (NRW == 3 || NRW == 6))), "uniform request count per wave");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * SB + MP_FLOATS * 4];     // 78,848 B: two workgroups per CU
+    __shared__ __attribute__((aligned(16))) unsigned char lds[RS * SB + MP_FLOATS * 4 + LNP];     // RS = 3: 84,992 B; RS = 6: 158,720 B (one workgroup per CU)
     const uint32_t cnt = *a.count;
     const int M = (int)(cnt < (uint32_t)a.max_rows ? cnt : (uint32_t)a.max_rows);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -191,7 +196,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
         rc[mt] = row[mt] < M ? row[mt] : M - 1;
     }
     const int nreq = (SR - wave + nwa - 1) / nwa;    // weight rows this wave requests per stage (elastic: 3 or 2)
-    const float* prm = reinterpret_cast<const float*>(lds + 3 * SB);
+    const float* prm = reinterpret_cast<const float*>(lds + RS * SB);
     int nmark = 0;
     auto mark = [&]() { if (a.trace && tid == 0 && nmark < 32) a.trace[blockIdx.x * 32 + nmark] = clock64(); ++nmark; };
     mark();
@@ -201,7 +206,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
             for (int j = 0; j < SR / MLP_SW; ++j) {
                 const int rw = wave + j * MLP_SW;
                 __builtin_amdgcn_global_load_lds((mlp_gsrc_t)(a.Wp + ((size_t)s * SR + rw) * 512 + lane * 8),
-                                                 (mlp_ldst_t)(lds + (s % 3) * SB + rw * 1024), 16, 0, 0);
+                                                 (mlp_ldst_t)(lds + (s % RS) * SB + rw * 1024), 16, 0, 0);
             }
             return;
         }
@@ -211,7 +216,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
                 const int rw = wave + j * nwa;
                 if (rw < SR)
                     __builtin_amdgcn_global_load_lds((mlp_gsrc_t)(a.Wp + ((size_t)s * SR + rw) * 512 + lane * 8),
-                                                     (mlp_ldst_t)(lds + (s % 3) * SB + rw * 1024), 16, 0, 0);
+                                                     (mlp_ldst_t)(lds + (s % RS) * SB + rw * 1024), 16, 0, 0);
             }
             return;
         }
@@ -220,18 +225,26 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
             const int rw = wave + j * NW;
             if (SR % NW == 0 || rw < SR)
                 __builtin_amdgcn_global_load_lds((mlp_gsrc_t)(a.Wp + ((size_t)s * SR + rw) * 512 + lane * 8),
-                                                 (mlp_ldst_t)(lds + (s % 3) * SB + rw * 1024), 16, 0, 0);
+                                                 (mlp_ldst_t)(lds + (s % RS) * SB + rw * 1024), 16, 0, 0);
         }
     };
-    // end of stage st: stage st+1 has landed (the younger requests of stage st+2 stay in flight), then the barrier
+    // end of stage st: stage st + 1 has landed, the younger requests (stages st + 2 .. st + D, as far as they exist) stay in flight;
+    // then the barrier.  Each wave counts its own requests: `per` per stage.
+    const int per = small ? SR / MLP_SW : ELASTIC ? nreq : NRW;
     auto stageEnd = [&](int st) {
-        if (st + 2 < NST) {
-            static_assert(SR == 24 && (MLP_SW == 1 || MLP_SW == 2), "a small workgroup's wave counts SR / MLP_SW requests per stage");
-            if (small) { if (MLP_SW == 1) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); }
-            else if (ELASTIC) { if (nreq == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); }
-            else if (NRW == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const int ahead = NST - 2 - st;              // stages younger than st + 1 that exist
+        const int keep = (ahead < D - 1 ? (ahead > 0 ? ahead : 0) : D - 1) * per;
+        switch (keep) {
+            case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); break;
+            case 24: asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;      // (waiting for more than needed is always correct)
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -241,10 +254,19 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
     for (int j = 0; j < MP_FLOATS / 256; ++j) {
         const int pr = wave + j * nwa;
         if (pr < MP_FLOATS / 256)
-            __builtin_amdgcn_global_load_lds((mlp_gsrc_t)(a.params + pr * 256 + lane * 4), (mlp_ldst_t)(lds + 3 * SB + pr * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((mlp_gsrc_t)(a.params + pr * 256 + lane * 4), (mlp_ldst_t)(lds + RS * SB + pr * 1024), 16, 0, 0);
     }
-
-    request(1);
+    // the parameters of the final LayerNorms (ln_g | ln_b, 4 x 192 floats each): their own LDS rows, so that the epilogue's only global
+    // loads are x / xb
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int pr = wave + j * nwa;
+        if (pr < 6)
+            __builtin_amdgcn_global_load_lds((mlp_gsrc_t)((pr < 3 ? a.ln_g + pr * 256 : a.ln_b + (pr - 3) * 256) + lane * 4),
+                                             (mlp_ldst_t)(lds + RS * SB + MP_FLOATS * 4 + pr * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int d = 1; d < D; ++d) request(d);
     // ---- prologue: the att row as the out-proj B operand, x straight into the out-proj accumulator -----------------
     half8 fa[MT][MNSTEP];
     floatx4 acc[MT][MNT];
@@ -267,7 +289,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
         for (int t = 0; t < MNT; ++t) asm volatile("" :: "v"(acc[mt][t]));
     }
     mark();
-    mlpStageBarrier();                               // stages 0, 1 + parameters landed
+    mlpStageBarrier();                               // stages 0 .. D-1 + parameters landed
     mark();
 #pragma unroll
     for (int t = 0; t < MNT; ++t) {
@@ -280,8 +302,8 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
     // ---- stages 0 .. NWO-1: out-proj, PQ columns per stage ---------------------------------------------------------------
 #pragma unroll
     for (int h = 0; h < NWO; ++h) {
-        request(h + 2);                              // (stages NWO, NWO+1 are the first W1 piece / W2 slab)
-        const unsigned char* sl = lbase + (h % 3) * SB;
+        request(h + D);                              // (NWO + D <= NST: the stages beyond the out-proj are W1 pieces / W2 slabs)
+        const unsigned char* sl = lbase + (h % RS) * SB;
 #pragma unroll
         for (int ks = 0; ks < MNSTEP; ++ks) {
 #pragma unroll
@@ -316,19 +338,8 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
 #pragma unroll 1
     for (int q = 0; q < NPIECE; ++q) {
         const int stA = NWO + 2 * q, stB = stA + 1;
-        if (stA + 2 < NST) request(stA + 2);         // next W1 piece
-        else {
-            // last piece: nothing left to stream, so the parameters of the final LayerNorms (ln_g | ln_b, 4 x 192 floats each) take
-            // the slot stage NST-3 has just left: the epilogue then reads them with ds_read, and its only global loads are x / xb
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int pr = wave + j * nwa;
-                if (pr < 6)
-                    __builtin_amdgcn_global_load_lds((mlp_gsrc_t)((pr < 3 ? a.ln_g + pr * 256 : a.ln_b + (pr - 3) * 256) + lane * 4),
-                                                     (mlp_ldst_t)(lds + (NST % 3) * SB + pr * 1024), 16, 0, 0);
-            }
-        }
-        const unsigned char* slotA = lbase + (stA % 3) * SB;
+        if (stA + D < NST) request(stA + D);
+        const unsigned char* slotA = lbase + (stA % RS) * SB;
         floatx4 acc2[MT][PQT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -366,8 +377,8 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
         }
         mark();
         stageEnd(stA);                               // W2 slab landed; everyone is done with the W1 piece
-        if (stB + 2 < NST) request(stB + 2);         // next W2 slab
-        const unsigned char* slotB = lbase + (stB % 3) * SB;
+        if (stB + D < NST) request(stB + D);
+        const unsigned char* slotB = lbase + (stB % RS) * SB;
 #pragma unroll
         for (int sp = 0; sp < PQS; ++sp) {
 #pragma unroll
@@ -383,7 +394,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
     }
     mark();
     // ---- s2 = LN2(s1 + f + b2) (already summed); x' = LN3(s2 + x); [x' = LN4(x' + xb)]: nothing in flight any more ------
-    const float* lnL = reinterpret_cast<const float*>(lds + (NST % 3) * SB);        // ln_g [4][192] | ln_b [4][192]
+    const float* lnL = reinterpret_cast<const float*>(lds + RS * SB + MP_FLOATS * 4);        // ln_g [4][192] | ln_b [4][192]
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         int rcl = rc[mt];
@@ -536,9 +547,12 @@ public:
         b.trace = tr;
         static int dbg = -1; if (dbg < 0) { const char* e = getenv("DSVT_MLP_DBG"); dbg = e ? atoi(e) : 0; }
         b.dbg = dbg;
-        if (variant == 3) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 10, 64>), grid, dim3(640), 0, stream, b);
-        else if (variant == 2) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, 64>), grid, dim3(512), 0, stream, b);
-        else hipLaunchKernelGGL((encoder_mlp_stream_kernel<2, 4, 64>), grid, dim3(256), 0, stream, b);
+        static int ring = -1;          // DSVT_MLP_RING=3: the three-slot ring (two workgroups per CU) for the elastic variant too
+        if (ring < 0) { const char* e = getenv("DSVT_MLP_RING"); ring = e ? atoi(e) : 6; }
+        if (variant == 3 && ring == 6) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 10, 64, 6>), grid, dim3(640), 0, stream, b);
+        else if (variant == 3) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 10, 64, 3>), grid, dim3(640), 0, stream, b);
+        else if (variant == 2) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, 64, 3>), grid, dim3(512), 0, stream, b);
+        else hipLaunchKernelGGL((encoder_mlp_stream_kernel<2, 4, 64, 3>), grid, dim3(256), 0, stream, b);
         if (tron) {
             (void)hipStreamSynchronize(stream);
             for (int w : {0, 200}) { fprintf(stderr, "[mlp trace wg%d]", w); for (int i = 1; i < 32; ++i) fprintf(stderr, " %lld", (long long)(tr[w * 32 + i] - tr[w * 32])); fprintf(stderr, "\n"); }
