@@ -36,9 +36,17 @@ __device__ __forceinline__ Bnd rowToBox(const float* o) {            // src/dsvt
 }
 __device__ __forceinline__ float crossf(F2 p1, F2 p2, F2 p0) { return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y); }   // :109-111
 
-__device__ __forceinline__ bool checkBox2d(const Bnd& box, F2 p) {   // :113-123
+// The four trigonometric values box_overlap / check_box2d derive from a box's yaw (helper.h:115-116, 190-193: cos / sin of rt and of
+// -rt, in double like the host, narrowed to float).  They depend on the box alone, so they are computed once per box (nms_sort) instead
+// of once per PAIR (the host does the latter); the values, and with them every IoU, are the same bits.
+struct Trig { float c, s, cn, sn; };                                  // cos(rt), sin(rt), cos(-rt), sin(-rt)
+__device__ __forceinline__ Trig boxTrig(float rt) {
+    return Trig{(float)cos((double)rt), (float)sin((double)rt), (float)cos((double)-rt), (float)sin((double)-rt)};
+}
+
+__device__ __forceinline__ bool checkBox2d(const Bnd& box, const Trig& tg, F2 p) {   // :113-123
     const float MARGIN = 1e-2f;
-    const float angle_cos = (float)cos((double)-box.rt), angle_sin = (float)sin((double)-box.rt);
+    const float angle_cos = tg.cn, angle_sin = tg.sn;
     const float rot_x = (p.x - box.x) * angle_cos + (p.y - box.y) * (-angle_sin);
     const float rot_y = (p.x - box.x) * angle_sin + (p.y - box.y) * angle_cos;
     return fabsf(rot_x) < box.w / 2 + MARGIN && fabsf(rot_y) < box.l / 2 + MARGIN;
@@ -70,23 +78,22 @@ __device__ __forceinline__ void rotateAround(F2 c, float ac, float as, F2& p) { 
     p.x = nx; p.y = ny;
 }
 
-__device__ float boxOverlap(const Bnd& a, const Bnd& b) {            // :166-255
+__device__ float boxOverlap(const Bnd& a, const Bnd& b, const Trig& ta, const Trig& tb) {            // :166-255
     const float a_dx = a.w / 2, b_dx = b.w / 2, a_dy = a.l / 2, b_dy = b.l / 2;
     F2 ac[5], bc[5], cp[24], pc = {0.f, 0.f};          // the host's cross_points[16] cannot hold the 16 + 8 worst case either
     const F2 ca = {a.x, a.y}, cb = {b.x, b.y};
     int cnt = 0;
     ac[0] = F2{a.x - a_dx, a.y - a_dy}; ac[1] = F2{a.x + a_dx, a.y - a_dy}; ac[2] = F2{a.x + a_dx, a.y + a_dy}; ac[3] = F2{a.x - a_dx, a.y + a_dy};
     bc[0] = F2{b.x - b_dx, b.y - b_dy}; bc[1] = F2{b.x + b_dx, b.y - b_dy}; bc[2] = F2{b.x + b_dx, b.y + b_dy}; bc[3] = F2{b.x - b_dx, b.y + b_dy};
-    const float a_cos = (float)cos((double)a.rt), a_sin = (float)sin((double)a.rt);
-    const float b_cos = (float)cos((double)b.rt), b_sin = (float)sin((double)b.rt);
+    const float a_cos = ta.c, a_sin = ta.s, b_cos = tb.c, b_sin = tb.s;
     for (int k = 0; k < 4; ++k) { rotateAround(ca, a_cos, a_sin, ac[k]); rotateAround(cb, b_cos, b_sin, bc[k]); }
     ac[4] = ac[0]; bc[4] = bc[0];
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j)
             if (intersection(ac[i + 1], ac[i], bc[j + 1], bc[j], cp[cnt])) { pc.x += cp[cnt].x; pc.y += cp[cnt].y; ++cnt; }
     for (int k = 0; k < 4; ++k) {
-        if (checkBox2d(a, bc[k])) { pc.x += bc[k].x; pc.y += bc[k].y; cp[cnt++] = bc[k]; }
-        if (checkBox2d(b, ac[k])) { pc.x += ac[k].x; pc.y += ac[k].y; cp[cnt++] = ac[k]; }
+        if (checkBox2d(a, ta, bc[k])) { pc.x += bc[k].x; pc.y += bc[k].y; cp[cnt++] = bc[k]; }
+        if (checkBox2d(b, tb, ac[k])) { pc.x += ac[k].x; pc.y += ac[k].y; cp[cnt++] = ac[k]; }
     }
     if (cnt == 0) return 0.f;                                        // reference: 0/0 centroid, empty fan, area 0
     pc.x /= cnt; pc.y /= cnt;
@@ -108,7 +115,7 @@ __device__ float boxOverlap(const Bnd& a, const Bnd& b) {            // :166-255
 
 // ---- kernels -------------------------------------------------------------------------------
 __global__ void __launch_bounds__(512)
-nms_sort(const float* __restrict__ rows, const uint32_t* __restrict__ count, int max_boxes, uint32_t* __restrict__ order)
+nms_sort(const float* __restrict__ rows, const uint32_t* __restrict__ count, int max_boxes, uint32_t* __restrict__ order, float4* __restrict__ trig)
 {
     __shared__ unsigned long long sk[NMS_MAX];       // (score key << 32) | ~row : descending = score desc, row asc (stable)
     const int t = threadIdx.x;
@@ -131,13 +138,18 @@ nms_sort(const float* __restrict__ rows, const uint32_t* __restrict__ count, int
             }
             __syncthreads();
         }
-    if (t < n) order[t] = ~(uint32_t)sk[t];
+    if (t < n) {
+        const uint32_t src = ~(uint32_t)sk[t];
+        order[t] = src;
+        const Trig tg = boxTrig(rows[(size_t)src * 9 + 6]);           // of SORTED row t
+        trig[t] = make_float4(tg.c, tg.s, tg.cn, tg.sn);
+    }
 }
 
 // word (j, wi) of the TRANSPOSED suppression matrix: bit b = "sorted row i = 64 wi + b (i < j) suppresses sorted row j"
 __global__ void __launch_bounds__(64)
-nms_mask(const float* __restrict__ rows, const uint32_t* __restrict__ count, const uint32_t* __restrict__ order, int max_boxes,
-         float thresh, unsigned long long* __restrict__ maskT)
+nms_mask(const float* __restrict__ rows, const uint32_t* __restrict__ count, const uint32_t* __restrict__ order,
+         const float4* __restrict__ trig, int max_boxes, float thresh, unsigned long long* __restrict__ maskT)
 {
     int n = (int)*count; if (n > max_boxes) n = max_boxes;
     const int j = blockIdx.x, wi = blockIdx.y, lane = threadIdx.x, i = wi * 64 + lane;
@@ -151,7 +163,8 @@ nms_mask(const float* __restrict__ rows, const uint32_t* __restrict__ count, con
         const float reach = ri + rj + 0.1f;
         if (dx * dx + dy * dy <= reach * reach) {
             const float sa = bi.w * bi.l, sb = bj.w * bj.l;                        // helper.h:272-275 (i is the kept box, j the later one)
-            const float so = boxOverlap(bi, bj);
+            const float4 ti = trig[i], tj = trig[j];
+            const float so = boxOverlap(bi, bj, Trig{ti.x, ti.y, ti.z, ti.w}, Trig{tj.x, tj.y, tj.z, tj.w});
             const float iou = so / fmaxf(sa + sb - so, kThresHold);
             sup = iou >= thresh;
         }
@@ -261,7 +274,7 @@ public:
         return pos >= 0 && pos <= 4 && i32Lin(io[pos]);
     }
     size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override {
-        return alignUp(sizeof(uint32_t) * NMS_MAX) + alignUp(sizeof(unsigned long long) * NMS_MAX * NMS_WORDS);
+        return alignUp(sizeof(uint32_t) * NMS_MAX) + alignUp(sizeof(unsigned long long) * NMS_MAX * NMS_WORDS) + alignUp(sizeof(float4) * NMS_MAX);
     }
     int enqueue(const DsvtPluginTensorDesc* inDesc, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void* ws,
                 hipStream_t stream) override {
@@ -269,10 +282,11 @@ public:
         WsCarver c(ws);
         uint32_t* order = c.take<uint32_t>(NMS_MAX);
         unsigned long long* mask = c.take<unsigned long long>((size_t)NMS_MAX * NMS_WORDS);
+        float4* trig = c.take<float4>(NMS_MAX);
         const float* rows = static_cast<const float*>(in[0]);
         const uint32_t* count = static_cast<const uint32_t*>(in[1]);
-        hipLaunchKernelGGL(nms_sort, dim3(1), dim3(512), 0, stream, rows, count, max_boxes_, order);
-        hipLaunchKernelGGL(nms_mask, dim3(max_boxes_, cdiv(max_boxes_, 64)), dim3(64), 0, stream, rows, count, order, max_boxes_, thresh_, mask);
+        hipLaunchKernelGGL(nms_sort, dim3(1), dim3(512), 0, stream, rows, count, max_boxes_, order, trig);
+        hipLaunchKernelGGL(nms_mask, dim3(max_boxes_, cdiv(max_boxes_, 64)), dim3(64), 0, stream, rows, count, order, trig, max_boxes_, thresh_, mask);
         hipLaunchKernelGGL(nms_scan, dim3(1), dim3(512), 0, stream, rows, count, order, mask, max_boxes_, static_cast<float*>(out[0]),
                            static_cast<int32_t*>(out[1]), static_cast<uint32_t*>(out[2]), zeroFill);
         return lastError();
