@@ -141,10 +141,14 @@ __device__ __forceinline__ void mlpLayerNormLds(floatx4 (&acc)[MNT], const float
 // PQ = FC1 columns per piece: 64 => fifteen 24-row stages (24 KB).  A stage's MFMAs (0.2-0.35 us) are much shorter than a
 // DMA round trip (~2 us), so the ring has THREE slots and stage s+2 is requested when stage s starts: the end-of-stage wait
 // is a counted vmcnt that retires stage s+1 and leaves s+2 in flight.
-// RS = slots of the weight ring, D = RS - 1 = prefetch distance in stages.  With three slots a stage costs max(its MFMAs, half a DMA
-// round trip) ~ 1 us: fifteen stages = 15 us of a 44 us launch were DMA latency.  The elastic variant runs ONE workgroup per CU anyway,
-// so it takes six slots (147 KB): stage s + 5 is requested when stage s starts and the counted wait at the end of stage s leaves four
-// stages in flight.
+// RS = slots of the weight ring, D = RS - 1 = prefetch distance in stages.  Three slots (85 KB: two workgroups per CU) are the default.
+// Six slots (159 KB, DSVT_MLP_RING=6: stage s + 5 requested when stage s starts, four stages in flight behind the counted wait) were
+// built on the theory that the ~1.3 us a stage takes is DMA latency; measured (round 2, tools/trace_mlp.py + rocprofv3): 46.5 vs 47.6 us
+// host-launched, 46.3 vs 43.4 us inside the frame graph -- no gain, so latency is not what a stage waits for.  The timing ablations say
+// what is: without MFMAs the launch is as long as with them (45.9 us), without LayerNorms / GELU / stores / MFMAs it still takes 27 us.
+// That floor is the memory system: every one of the 256 workgroups streams the same 360 KB of weights L2 -> LDS, 92 MB per launch on
+// top of the 93 MB of activations, i.e. 185 MB in 44 us = 4.2 TB/s against the ~6.4 TB/s the LDS-DMA stream reaches chip-wide
+// (MI355X_MICROARCH.md "ldsdma-fill").  Fewer re-streamed weight bytes per row (more rows per workgroup) is the remaining lever.
 template <int MT, int NW, int PQ, int RS>
 __global__ void __launch_bounds__(64 * NW, (MT == 1 ? 3 : 2))
 encoder_mlp_stream_kernel(MlpStreamArgs a)
@@ -547,8 +551,8 @@ public:
         b.trace = tr;
         static int dbg = -1; if (dbg < 0) { const char* e = getenv("DSVT_MLP_DBG"); dbg = e ? atoi(e) : 0; }
         b.dbg = dbg;
-        static int ring = -1;          // DSVT_MLP_RING=3: the three-slot ring (two workgroups per CU) for the elastic variant too
-        if (ring < 0) { const char* e = getenv("DSVT_MLP_RING"); ring = e ? atoi(e) : 6; }
+        static int ring = -1;          // DSVT_MLP_RING=6: the six-slot ring (measured: no gain, see the kernel's header)
+        if (ring < 0) { const char* e = getenv("DSVT_MLP_RING"); ring = e ? atoi(e) : 3; }
         if (variant == 3 && ring == 6) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 10, 64, 6>), grid, dim3(640), 0, stream, b);
         else if (variant == 3) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 10, 64, 3>), grid, dim3(640), 0, stream, b);
         else if (variant == 2) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, 64, 3>), grid, dim3(512), 0, stream, b);
