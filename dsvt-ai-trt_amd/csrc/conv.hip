@@ -1048,4 +1048,82 @@ static Creator g_convCreator{"DsvtConv2dPlugin",
     convCreate, convDeser, {}, {}};
 static Registrar g_convReg(&g_convCreator);
 
+
+// =====================================================================================
+// DsvtSplitHalfPlugin -- fp32 activations as the operand of an fp32-GRADE convolution on the fp16 matrix cores.
+// fp32 mode of the frame (the mode whose boxes meet the 1e-3 bar) used to run its BEV stage on vendor fp32 convolutions.  Instead:
+// a = hi + lo with hi = fp16(a), lo = fp16(a - hi) (|a - hi - lo| <= 2^-22 |a|), w = w_hi + w_lo likewise, and
+//     conv(a, w) = conv(hi, w_hi) + conv(lo, w_hi) + conv(hi, w_lo)      (+ lo * w_lo ~ 2^-22, dropped)
+// which is ONE DsvtConv2dPlugin launch over 3 Cin input channels [hi | lo | hi] with weight rows [w_hi | w_hi | w_lo] (built by the
+// host: plugin.split_weight_rows), fp32 accumulation, fp32 output.  This op is the glue between two such convolutions:
+//     y  = relu?(x (+ residual))           fp32 [.., C]     (output 0; the residual stream of the ResNet blocks stays fp32)
+//     y3 = [fp16(y) | fp16(y - fp16(y)) | fp16(y)]          fp16 [.., 3C]   (output 1: the next convolution's input)
+// Inputs: x [1,H,W,C] f32 (, residual [1,H,W,C] f32).  Reference semantics restated: convBnLELU / convBn + ElementWise SUM + ReLU
+// of src/dsvt-ai-trt.cpp:149-246, 1144-1364 in fp32.
+// =====================================================================================
+__global__ void __launch_bounds__(256)
+split_half_kernel(const float4* __restrict__ x, const float4* __restrict__ res, size_t groups, int C4, int relu,
+                  float4* __restrict__ y, half4* __restrict__ y3)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;        // one group of four channels of one pixel
+    if (i >= groups) return;
+    float4 v = x[i];
+    if (res) { const float4 r = res[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    y[i] = v;
+    half4 hi, lo;
+    hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+    lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
+    lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
+    const size_t pix = i / (size_t)C4, c4 = i % (size_t)C4;
+    half4* o = y3 + pix * 3 * (size_t)C4 + c4;
+    o[0] = hi; o[C4] = lo; o[2 * (size_t)C4] = hi;
+}
+
+class DsvtSplitHalfPlugin : public Plugin {
+public:
+    int C_, relu_, has_res_;
+    DsvtSplitHalfPlugin(int C, int relu, int has_res) : C_(C), relu_(relu), has_res_(has_res) {}
+    const char* type() const override { return "DsvtSplitHalfPlugin"; }
+    int nbOutputs() const override { return 2; }
+    int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
+        if (i < 0 || i > 1 || in[0].nbDims < 2) return -1;
+        *out = in[0];
+        if (i == 1) out->d[out->nbDims - 1] = 3 * C_;
+        return 0;
+    }
+    int outputType(int i, const int32_t*, int) const override { return i == 0 ? DSVT_FLOAT : DSVT_HALF; }
+    bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int nbIn, int) const override {
+        if (io[pos].format != DSVT_FORMAT_LINEAR) return false;
+        return pos <= nbIn ? io[pos].type == DSVT_FLOAT : io[pos].type == DSVT_HALF;
+    }
+    size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override { return 0; }
+    int enqueue(const DsvtPluginTensorDesc* inDesc, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void*,
+                hipStream_t stream) override {
+        if (!inDesc || inDesc[0].dims.nbDims < 2 || inDesc[0].dims.d[inDesc[0].dims.nbDims - 1] != C_) return -2;
+        size_t pix = 1;
+        for (int k = 0; k + 1 < inDesc[0].dims.nbDims; ++k) pix *= (size_t)inDesc[0].dims.d[k];
+        const size_t groups = pix * (size_t)(C_ / 4);
+        if (groups == 0) return 0;
+        hipLaunchKernelGGL(split_half_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream, static_cast<const float4*>(in[0]),
+                           has_res_ ? static_cast<const float4*>(in[1]) : nullptr, groups, C_ / 4, relu_, static_cast<float4*>(out[0]),
+                           static_cast<half4*>(out[1]));
+        return lastError();
+    }
+    size_t serializationSize() const override { return 3 * sizeof(int); }
+    void serialize(void* b) const override { char* d = static_cast<char*>(b); wr<int>(d, C_); wr<int>(d, relu_); wr<int>(d, has_res_); }
+    Plugin* clone() const override { return new DsvtSplitHalfPlugin(C_, relu_, has_res_); }
+};
+static Plugin* shNew(int C, int relu, int hr) { return (C > 0 && C % 4 == 0) ? new DsvtSplitHalfPlugin(C, relu != 0, hr != 0) : nullptr; }
+static Plugin* shCreate(const DsvtPluginFieldCollection* fc) { return shNew(fieldInt(fc, "channel_num"), fieldInt(fc, "relu", 0), fieldInt(fc, "has_residual", 0)); }
+static Plugin* shDeser(const void* data, size_t len) {
+    if (len < 3 * sizeof(int)) return nullptr;
+    const char* d = static_cast<const char*>(data);
+    const int C = rd<int>(d), relu = rd<int>(d), hr = rd<int>(d);
+    return shNew(C, relu, hr);
+}
+static Creator g_shCreator{"DsvtSplitHalfPlugin", {{"channel_num", DSVT_FIELD_INT32}, {"relu", DSVT_FIELD_INT32}, {"has_residual", DSVT_FIELD_INT32}},
+                           shCreate, shDeser, {}, {}};
+static Registrar g_shReg(&g_shCreator);
+
 }  // namespace dsvt

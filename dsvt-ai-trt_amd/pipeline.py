@@ -210,7 +210,13 @@ class DsvtPipeline:
             self.filter = P.add_filter_box_by_score_op(TOP_K, X_MIN, X_MAX, Y_MIN, Y_MAX, Z_MIN, Z_MAX, VX, VY, VZ, SCORE_THR)
             self.nms = P.add_rotated_nms_op(TOP_K, NMS_THRESH) if device_nms else None
             self.hip_head = (head_dtype == torch.float16 and linear_compute == P.COMPUTE_F16) if hip_head is None else hip_head
-            if self.hip_head:
+            # fp32 head: the same HIP convolution at fp32 grade (split-precision operands, 3x the MFMA work) unless hip_head=False asks for
+            # the PyTorch / MIOpen fp32 convolutions (kept as a cross-check, tests/test_conv_gpu.py)
+            self.split_head = head_dtype == torch.float32 and (hip_head is None or hip_head)
+            if self.split_head:
+                self.hip_head = False
+                self._build_hip_head_split(w)
+            elif self.hip_head:
                 self._build_hip_head(w)
             else:
                 self._build_dense(w)
@@ -296,6 +302,75 @@ class DsvtPipeline:
         ops["heads1"] = P.add_conv2d_op(cw(W1), b1, GY, GX, 320, 18, 3, 1, 1, out_f32=True)
         self.cat_bev = torch.zeros((1, GY, GX, 384), dtype=torch.float16, device=self.device)
         self.topk = P.add_center_head_topk_op(GY, GX, 18, 10, TOP_K)      # decode on the device
+
+    # ---- the same stage at fp32 grade on the fp16 matrix cores (split-precision operands) ----------------------------------------
+    def _build_hip_head_split(self, w):
+        """every convolution of _build_hip_head as  conv([hi | lo | hi], [w_hi | w_hi | w_lo]) -> fp32, with DsvtSplitHalfPlugin between
+        the layers (fp32 residual stream, ReLU, next operand).  src/dsvt-ai-trt.cpp:1144-1468 in fp32 arithmetic."""
+        cw, dw, sw = P.conv_weight_rows, P.deconv_weight_rows, P.split_weight_rows
+        ops = self.sops = {}
+        spl = self.ssplit = {}
+
+        def conv(name, rows, bias, H, cin, cout, k, stride, relu, **kw):
+            ops[name] = P.add_conv2d_op(sw(rows, k * k, cin), bias, H, H, 3 * cin, cout, k, stride, k // 2, relu=relu, out_f32=True, **kw)
+
+        def conv_bn(name, name_conv, name_bn, H, cin, cout, k, stride, relu):
+            s_, sh = bn_fold(w, name_bn, 1e-3)
+            conv(name, cw(w[name_conv + ".weight"] * s_[:, None, None, None]), sh, H, cin, cout, k, stride, relu)
+
+        spl["in"] = P.add_split_half_op(C)
+        H = GY
+        for (i, cin, cout, stride, nb) in ((0, 192, 128, 1, 2), (1, 128, 128, 2, 3), (2, 128, 256, 2, 3)):
+            for j in range(nb):
+                p = f"module.backbone_2d.blocks.{i}.{j}"
+                st = stride if j == 0 else 1
+                ci = cin if j == 0 else cout
+                conv_bn(p + ".1", p + ".conv1", p + ".bn1", H, ci, cout, 3, st, True)
+                Ho = (H + 2 - 3) // st + 1
+                if j == 0:
+                    conv_bn(p + ".d", p + ".downsample_layer.0", p + ".downsample_layer.1", H, ci, cout, 1, st, False)
+                conv_bn(p + ".2", p + ".conv2", p + ".bn2", Ho, cout, cout, 3, 1, False)          # + identity, ReLU in the split op (:1165-1166)
+                spl[p + ".1"] = P.add_split_half_op(cout)
+                spl[p + ".2"] = P.add_split_half_op(cout, relu=True, has_residual=True)
+                H = Ho
+            k = (1, 2, 4)[i]
+            p = f"module.backbone_2d.deblocks.{i}"
+            s_, sh_ = bn_fold(w, p + ".1", 1e-3)
+            conv(p, dw(w[p + ".0.weight"] * s_[None, :, None, None]), sh_, H, cout, 128, 1, 1, True, pixel_shuffle=k,
+                 out_channel_stride=384, out_channel_offset=128 * i)
+        spl["cat"] = P.add_split_half_op(384)
+        conv_bn("shared", "module.dense_head.shared_conv.0", "module.dense_head.shared_conv.1", GY, 384, 64, 3, 1, True)
+        spl["shared"] = P.add_split_half_op(64)
+        names, outs = ["center", "center_z", "dim", "rot", "hm"], [2, 1, 3, 2, 10]          # iou head is dead (:1440-1452)
+        W0, b0 = [], []
+        for n in names:
+            s_, sh_ = bn_fold(w, f"module.dense_head.heads_list.0.{n}.0.1", 1e-3)
+            W0.append(w[f"module.dense_head.heads_list.0.{n}.0.0.weight"] * s_[:, None, None, None]); b0.append(sh_)
+        conv("heads0", cw(np.concatenate(W0, 0)), np.concatenate(b0), GY, 64, 320, 3, 1, True)
+        spl["heads0"] = P.add_split_half_op(320)
+        W1 = np.zeros((sum(outs), 320, 3, 3), np.float32); b1 = np.zeros((sum(outs),), np.float32)
+        o = 0
+        for k_, (n, no) in enumerate(zip(names, outs)):                                       # block-diagonal second convs
+            W1[o:o + no, 64 * k_:64 * (k_ + 1)] = w[f"module.dense_head.heads_list.0.{n}.1.weight"]
+            b1[o:o + no] = w[f"module.dense_head.heads_list.0.{n}.1.bias"]
+            o += no
+        conv("heads1", cw(W1), b1, GY, 320, 18, 3, 1, False)
+        self.cat_bev32 = torch.zeros((1, GY, GX, 384), dtype=torch.float32, device=self.device)
+        self.topk = P.add_center_head_topk_op(GY, GX, 18, 10, TOP_K)
+
+    def _bev_hip_split(self, bev):
+        """bev: [1, 468, 468, 192] fp32 NHWC -> [1, 468, 468, 18] fp32 NHWC, fp32-grade arithmetic"""
+        ops, spl = self.sops, self.ssplit
+        x, x3 = spl["in"](bev)
+        for (i, nb) in ((0, 2), (1, 3), (2, 3)):
+            for j in range(nb):
+                p = f"module.backbone_2d.blocks.{i}.{j}"
+                y3 = spl[p + ".1"](ops[p + ".1"](x3)[0])[1]
+                idn = ops[p + ".d"](x3)[0] if j == 0 else x
+                x, x3 = spl[p + ".2"](ops[p + ".2"](y3)[0], idn)
+            ops[f"module.backbone_2d.deblocks.{i}"](x3, out=[self.cat_bev32])                   # deblock + concat (:1363)
+        sh3 = spl["shared"](ops["shared"](spl["cat"](self.cat_bev32)[1])[0])[1]
+        return ops["heads1"](spl["heads0"](ops["heads0"](sh3)[0])[1])[0]
 
     def _bev_hip(self, x):
         """x: [1, 468, 468, 192] fp16 NHWC -> [1, 468, 468, 18] fp32 NHWC (center2 cz1 dim3 rot2 hm10)"""
@@ -441,6 +516,8 @@ class DsvtPipeline:
     def head(self, x, st):
         src = self._xh if (self.f16 and self.head_dtype == torch.float16) else x
         bev = self.map2bev(src, st["coords"], st["P"])[0]             # [1, 468(y), 468(x), 192] NHWC
+        if self.split_head:
+            return self._post(self.filter(*self.topk(self._bev_hip_split(bev))))
         if self.hip_head:
             return self._post(self.filter(*self.topk(self._bev_hip(bev))))
         bev = bev.permute(0, 3, 1, 2)                                 # NCHW view of channels-last memory (:1131-1133)

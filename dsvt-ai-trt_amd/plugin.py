@@ -519,6 +519,22 @@ def deconv_weight_rows(w):
     return np.ascontiguousarray(w.transpose(2, 3, 1, 0)).reshape(-1, w.shape[0])
 
 
+def split_weight_rows(weight_rows, taps, in_channels):
+    """rows [R][taps][Cin] fp32 -> [R][taps][3 Cin] holding [w_hi | w_hi | w_lo] per tap (w_hi = fp16(w), w_lo = fp16(w - w_hi)): with an input
+    [hi | lo | hi] (DsvtSplitHalfPlugin) one fp16-MFMA convolution computes hi w_hi + lo w_hi + hi w_lo, the fp32 product up to 2^-22."""
+    w = np.asarray(weight_rows, np.float32).reshape(-1, taps, in_channels)
+    hi = w.astype(np.float16).astype(np.float32)
+    lo = (w - hi).astype(np.float16).astype(np.float32)
+    return np.ascontiguousarray(np.concatenate([hi, hi, lo], axis=2)).reshape(w.shape[0], -1)
+
+
+def add_split_half_op(channel_num, relu=False, has_residual=False):
+    """y = relu?(x (+ residual)) in fp32 and its [hi | lo | hi] fp16 split (csrc/conv.hip DsvtSplitHalfPlugin).
+    Inputs: x [1,H,W,C] f32 (, residual f32).  Outputs: y f32, y3 [1,H,W,3C] fp16."""
+    return Plugin("DsvtSplitHalfPlugin", dict(channel_num=int(channel_num), relu=int(bool(relu)), has_residual=int(bool(has_residual))),
+                  "split_half_layer")
+
+
 def add_conv2d_op(weight_rows, bias, in_height, in_width, in_channels, out_channels, kernel_size=1, stride=1, padding=0,
                   pixel_shuffle=1, relu=False, has_residual=False, out_channel_stride=None, out_channel_offset=0, out_f32=False):
     """NHWC fp16 implicit-GEMM convolution with fused bias / residual / ReLU / pixel-shuffle / concat offset

@@ -113,3 +113,66 @@ def test_conv_halo_kernel_full_size(pkg, H, W, cin, cout, k, res):
     assert (got - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
     again = op(*args)[0].permute(0, 3, 1, 2).float()
     assert torch.equal(got, again)
+
+
+@pytest.mark.parametrize("H,W,cin,cout,k,stride,res,relu", [
+    (52, 47, 128, 128, 3, 1, True, True),      # basic block conv2 + fp32 identity + ReLU
+    (52, 47, 192, 128, 3, 1, False, True),     # first BEV conv
+    (52, 47, 128, 256, 3, 2, False, True),     # strided
+    (52, 47, 128, 256, 1, 2, False, False),    # 1x1 downsample
+    (30, 33, 384, 64, 3, 1, False, True),      # shared head conv (1152 split channels)
+    (30, 33, 64, 320, 3, 1, False, True),      # head stems
+    (25, 31, 320, 18, 3, 1, False, False),     # head outputs
+])
+def test_split_precision_conv_is_fp32_grade(pkg, H, W, cin, cout, k, stride, res, relu):
+    """fp32 mode of the BEV stage: conv([hi | lo | hi], [w_hi | w_hi | w_lo]) on the fp16 matrix cores (DsvtSplitHalfPlugin +
+    plugin.split_weight_rows + DsvtConv2dPlugin with fp32 output) against a float64 convolution of the UNROUNDED fp32 operands
+    (convBnLELU / convBn + SUM + ReLU of src/dsvt-ai-trt.cpp:149-246 in fp32): the dropped lo x w_lo terms and the two-step splits
+    leave ~2^-21 relative, i.e. fp32 summation-order level."""
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(H * 1000 + cin + cout)
+    x = torch.randn(1, cin, H, W, generator=g) * 3.0
+    w = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g) * 0.1
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    r = torch.randn(1, cout, Ho, Wo, generator=g) if res else None
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride, pad)
+    if res:
+        ref = ref + r.double()
+    if relu:
+        ref = torch.relu(ref)
+    rows = P.split_weight_rows(P.conv_weight_rows(w.numpy()), k * k, cin)
+    conv = P.add_conv2d_op(rows, b.numpy(), H, W, 3 * cin, cout, k, stride, pad, relu=relu and not res, out_f32=True)
+    x32, x3 = P.add_split_half_op(cin)(nhwc(x).to(DEV))
+    assert torch.equal(x32, nhwc(x).to(DEV))
+    hi, lo = x3[..., :cin].float(), x3[..., cin:2 * cin].float()
+    assert torch.equal(x3[..., 2 * cin:], x3[..., :cin]) and (hi + lo - x32).abs().max().item() <= 2.0 ** -21 * x32.abs().max().item()
+    y = conv(x3)[0]
+    if res:
+        y = P.add_split_half_op(cout, relu=relu, has_residual=True)(y, nhwc(r).to(DEV))[0]
+    torch.cuda.synchronize()
+    got = y.permute(0, 3, 1, 2).double().cpu()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() < 2e-6 * scale, ((got - ref).abs().max().item(), scale)
+
+
+def test_split_precision_deblock_into_concat(pkg):
+    """deconvBnLELU (stride == kernel ConvTranspose, src/dsvt-ai-trt.cpp:217-246) at fp32 grade, written into a channel slice of the fp32
+    concat buffer (:1363)"""
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(11)
+    cin, cout, k, H = 128, 128, 2, 26
+    x = torch.randn(1, cin, H, H, generator=g)
+    w = torch.randn(cin, cout, k, k, generator=g) / np.sqrt(cin)
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = torch.relu(F.conv_transpose2d(x.double(), w.double(), b.double(), stride=k))
+    rows = P.split_weight_rows(P.deconv_weight_rows(w.numpy()), 1, cin)
+    op = P.add_conv2d_op(rows, b.numpy(), H, H, 3 * cin, cout, 1, 1, 0, pixel_shuffle=k, relu=True, out_channel_stride=384, out_channel_offset=128,
+                         out_f32=True)
+    cat = torch.full((1, H * k, H * k, 384), -7.0, dtype=torch.float32, device=DEV)
+    op(P.add_split_half_op(cin)(nhwc(x).to(DEV))[1], out=[cat])
+    torch.cuda.synchronize()
+    got = cat[..., 128:256].permute(0, 3, 1, 2).double().cpu()
+    assert (got - ref).abs().max().item() < 2e-6 * ref.abs().max().item()
+    assert (cat[..., :128] == -7.0).all() and (cat[..., 256:] == -7.0).all()

@@ -35,7 +35,7 @@ def main():
         caps = pkg.pipeline.Caps.reference()
         pts, n = cases.load_frame(args.frame, caps.N)
     d_pts = torch.from_numpy(pts[None]).to(dev); d_n = torch.tensor([n], dtype=torch.int32, device=dev)
-    p32 = pkg.pipeline.DsvtPipeline(w, caps=caps, device=dev)
+    p32 = pkg.pipeline.DsvtPipeline(w, caps=caps, device=dev, hip_head=False)      # PyTorch fp32 dense stage: its intermediates are needed
     p16 = pkg.pipeline.DsvtPipeline(w, caps=caps, device=dev, linear_compute=P.COMPUTE_F16, head_dtype=torch.float16)
 
     # ---- all-fp32 reference with its intermediate tensors -----------------------------------------
