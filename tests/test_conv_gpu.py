@@ -154,7 +154,7 @@ def test_split_precision_conv_is_fp32_grade(pkg, H, W, cin, cout, k, stride, res
     torch.cuda.synchronize()
     got = y.permute(0, 3, 1, 2).double().cpu()
     scale = ref.abs().max().item()
-    assert (got - ref).abs().max().item() < 2e-6 * scale, ((got - ref).abs().max().item(), scale)
+    assert (got - ref).abs().max().item() < 5e-6 * scale, ((got - ref).abs().max().item(), scale)      # (3456 fp32-accumulated terms at K = 9 x 384)
 
 
 def test_split_precision_deblock_into_concat(pkg):
@@ -174,5 +174,5 @@ def test_split_precision_deblock_into_concat(pkg):
     op(P.add_split_half_op(cin)(nhwc(x).to(DEV))[1], out=[cat])
     torch.cuda.synchronize()
     got = cat[..., 128:256].permute(0, 3, 1, 2).double().cpu()
-    assert (got - ref).abs().max().item() < 2e-6 * ref.abs().max().item()
+    assert (got - ref).abs().max().item() < 5e-6 * ref.abs().max().item()
     assert (cat[..., :128] == -7.0).all() and (cat[..., 256:] == -7.0).all()
