@@ -9,6 +9,10 @@
 //   * ReLU and "+ constant" are monotone, so  max_points ReLU(W1a x0 + t_p) = ReLU(max_points(W1a x0) + t_p):
 //     both per-point maxima, m_p and U_p = max_points(W1a x0), come out of ONE pass over the points;
 //   * x0 is consumed from registers (the layer-0 tile is the B operand of layer 1, see mlp.hip).
+// Tiles (round 2): the median pillar holds ONE point and the mean 4.8, so "one pillar per 16-point MFMA tile" spent 3.6x the matrix work on
+// padding.  Pillars with <= 4 points are packed FOUR to a tile -- pillar q takes points 4q..4q+3, which in the x0 / u tile layouts is
+// exactly lane group g = q, so their maxima need no cross-lane step at all -- and only the larger pillars keep whole tiles (1..3 each):
+// 38k tiles -> 17k on the 180k-point frame.  A row of a GEMM tile depends on nothing but its own point, so the features are the same bits.
 // A workgroup owns 16 consecutive pillars; the compact point ids of a pillar are consecutive (Points2Features' canonical
 // order: pillar-major, then slot) and every 16-point MFMA tile belongs to one pillar, so the maxima are plain register
 // reductions: nothing is atomic, in LDS or in global memory.  After the point pass the workgroup computes t = W1b m (16 x 96 x 192 on the matrix cores, W1b fragments straight from L2) and
@@ -42,6 +46,7 @@ struct PfnArgs {
     float* out; _Float16* out16;       // vfeat [P,192] + fp16 copy
     unsigned long long* trace;         // debugging: phase timestamps of workgroup 0
     int dbg;                           // timing ablations (wrong results): 1 no m atomics, 2 no U atomics, 4 no layer-1 MFMA, 8 no epilogue
+    int pack;                          // 1: pillars with <= 4 points share tiles (default); 0: one pillar per tile (round-1 layout, A/B switch)
 };
 
 __device__ __forceinline__ uint32_t pfnKey(float f) {            // larger float <=> larger key; every key > 0
@@ -70,6 +75,7 @@ pfn_kernel(PfnArgs a)
     __shared__ __attribute__((aligned(16))) uint32_t sM[PF_PB * SM_LD];   // max_pillar(x0), float bits                      6 KB
     __shared__ __attribute__((aligned(16))) uint32_t sU[PF_PB * SU_LD];   // max_pillar(W1a x0), float bits                 12 KB
     __shared__ uint32_t sStart[PF_PB + 1];
+    __shared__ uint32_t sSmall[PF_PB], sLarge[PF_PB], sNum[2];           // pillars of the group with <= 4 points / more, and how many of each
     __shared__ __attribute__((aligned(16))) _Float16 sW1[3 * 12 * 512];                                                // 36 KB
     uint32_t P = *a.pillar_num; if (P > (uint32_t)a.max_pillars) P = a.max_pillars;
     const uint32_t ngroups = (P + PF_PB - 1) / PF_PB;
@@ -115,83 +121,131 @@ pfn_kernel(PfnArgs a)
 #pragma unroll
     for (int t = 0; t < 6; ++t) b0c[t] = a.b0[16 * t + r];
     mark();
-    // flat walk over this wave's (pillar, tile) pairs; the next tile's point rows are requested before the current tile's MFMAs
-    auto loadTile = [&](uint32_t base, uint32_t s0, uint32_t e0, float (&fbv)[3]) {
-        const uint32_t row = base + r;
-        const float* fr = a.feat + (size_t)(row < e0 ? row : s0) * PF_IN;
+    // ---- work units of this group: packed tiles of up to four small pillars first, then the larger pillars (1..3 tiles each)
+    if (tid < kWave) {
+        const bool valid = tid < npil;
+        const uint32_t c = valid ? sStart[tid + 1] - sStart[tid] : 0u;
+        const bool small = valid && a.pack && c <= 4u;
+        const unsigned long long ms = __ballot(small), ml = __ballot(valid && !small);
+        const unsigned long long below = (1ull << tid) - 1ull;
+        if (small) sSmall[__popcll(ms & below)] = (uint32_t)tid;
+        else if (valid) sLarge[__popcll(ml & below)] = (uint32_t)tid;
+        if (tid == 0) { sNum[0] = (uint32_t)__popcll(ms); sNum[1] = (uint32_t)__popcll(ml); }
+    }
+    __syncthreads();
+    const int nsmall = (int)sNum[0], nlarge = (int)sNum[1], npacked = (nsmall + 3) >> 2, nunits = npacked + nlarge;
+    // tiles of unit u; row of the point lane r works on in tile (u, t) (padding = the pillar's first point: duplicates do not change a maximum)
+    auto tilesOf = [&](int u) -> int {
+        if (u < npacked) return 1;
+        const uint32_t pl_ = sLarge[u - npacked];
+        return (int)((sStart[pl_ + 1] - sStart[pl_] + 15u) >> 4);
+    };
+    auto rowOf = [&](int u, int t) -> uint32_t {
+        if (u < npacked) {
+            const int idx = 4 * u + (r >> 2);
+            const uint32_t pl_ = sSmall[idx < nsmall ? idx : 4 * u];
+            const uint32_t s_ = sStart[pl_], c_ = sStart[pl_ + 1] - s_, i_ = (uint32_t)(r & 3);
+            return s_ + (i_ < c_ ? i_ : 0u);
+        }
+        const uint32_t pl_ = sLarge[u - npacked];
+        const uint32_t s_ = sStart[pl_], e_ = sStart[pl_ + 1], row = s_ + 16u * (uint32_t)t + (uint32_t)r;
+        return row < e_ ? row : s_;
+    };
+    auto loadRow = [&](uint32_t row, float (&fbv)[3]) {
+        const float* fr = a.feat + (size_t)row * PF_IN;
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) { const int k = 4 * ks + g; fbv[ks] = k < PF_IN ? fr[k] : 0.f; }
     };
-    int pl = wave;
-    bool have = pl < npil;
-    uint32_t s0 = 0, e0 = 0, base = 0;
+    int u = wave, t = 0;
+    bool have = u < nunits;
     float fb[3], fnext[3];
-    if (have) { s0 = sStart[pl]; e0 = sStart[pl + 1]; base = s0; loadTile(base, s0, e0, fnext); }
+    if (have) loadRow(rowOf(u, 0), fnext);
     float mx0[6], mxu[12];
 #pragma unroll
-    for (int t = 0; t < 6; ++t) mx0[t] = 0.f;
+    for (int k = 0; k < 6; ++k) mx0[k] = 0.f;
 #pragma unroll
-    for (int t = 0; t < 12; ++t) mxu[t] = -INFINITY;
+    for (int k = 0; k < 12; ++k) mxu[k] = -INFINITY;
     while (have) {
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) fb[ks] = fnext[ks];
-        // the tile after this one
-        const bool lastOfPillar = base + 16 >= e0;
-        int npl = pl; uint32_t ns0 = s0, ne0 = e0, nbase = base + 16;
-        if (lastOfPillar) { npl = pl + PF_NW; if (npl < npil) { ns0 = sStart[npl]; ne0 = sStart[npl + 1]; nbase = ns0; } }
-        const bool haveNext = npl < npil;
-        if (haveNext) loadTile(nbase, ns0, ne0, fnext);
+        const int cu = u, nt = tilesOf(cu);
+        const bool lastOfUnit = t + 1 >= nt;
+        // the tile after this one: its point rows are requested before the current tile's MFMAs
+        int nu = cu, ntile = t + 1;
+        if (lastOfUnit) { nu = cu + PF_NW; ntile = 0; }
+        const bool haveNext = nu < nunits;
+        if (haveNext) loadRow(rowOf(nu, ntile), fnext);
 
         floatx4 x0[6];
+        float m0[6], mu[12];
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            x0[t] = floatx4{b0f[t][0], b0f[t][1], b0f[t][2], b0f[t][3]};
-            floatx4 d0 = {b0c[t], b0c[t], b0c[t], b0c[t]};
+        for (int k = 0; k < 6; ++k) {
+            x0[k] = floatx4{b0f[k][0], b0f[k][1], b0f[k][2], b0f[k][3]};
+            floatx4 d0 = {b0c[k], b0c[k], b0c[k], b0c[k]};
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) {
-                x0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0f[t][ks], fb[ks], x0[t], 0, 0, 0);
-                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[ks], w0f[t][ks], d0, 0, 0, 0);
+                x0[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0f[k][ks], fb[ks], x0[k], 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[ks], w0f[k][ks], d0, 0, 0, 0);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) x0[t][i] = fmaxf(x0[t][i], 0.f);             // ReLU (:144)
-            mx0[t] = fmaxf(mx0[t], fmaxf(fmaxf(d0[0], d0[1]), fmaxf(d0[2], d0[3])));  // max(ReLU(.)) = max(0, max(.))
+            for (int i = 0; i < 4; ++i) x0[k][i] = fmaxf(x0[k][i], 0.f);             // ReLU (:144)
+            m0[k] = fmaxf(fmaxf(d0[0], d0[1]), fmaxf(d0[2], d0[3]));                 // this lane group's four points
         }
+#pragma unroll
+        for (int k = 0; k < 12; ++k) mu[k] = -INFINITY;
         if (!(a.dbg & 4)) {
             half8 f1[3];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
+            for (int s_ = 0; s_ < 3; ++s_) {
                 half8 h;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { h[i] = (_Float16)x0[2 * s][i]; h[4 + i] = (_Float16)x0[2 * s + 1][i]; }
-                f1[s] = h;
+                for (int i = 0; i < 4; ++i) { h[i] = (_Float16)x0[2 * s_][i]; h[4 + i] = (_Float16)x0[2 * s_ + 1][i]; }
+                f1[s_] = h;
             }
 #pragma unroll
-            for (int t = 0; t < 12; ++t) {
+            for (int k = 0; k < 12; ++k) {
                 floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < 3; ++s)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1[s], *reinterpret_cast<const half8*>(&sW1[((s * 12 + t) * 64 + lane) * 8]), acc, 0, 0, 0);
-                mxu[t] = fmaxf(mxu[t], fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
+                for (int s_ = 0; s_ < 3; ++s_)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1[s_], *reinterpret_cast<const half8*>(&sW1[((s_ * 12 + k) * 64 + lane) * 8]), acc, 0, 0, 0);
+                mu[k] = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
             }
         }
-        if (lastOfPillar) {
-            // across the four lane groups (points 4g'..4g'+3), then lane group 0 owns column 16t + r
+        if (cu < npacked) {
+            // packed tile: lane group g holds the maxima of ITS pillar (points 4g..4g+3): every lane writes column 16k + r of that row
+            const int idx = 4 * cu + g;
+            if (idx < nsmall) {
+                const uint32_t pl_ = sSmall[idx];
 #pragma unroll
-            for (int t = 0; t < 6; ++t) mx0[t] = maxOverLaneGroups(mx0[t]);
+                for (int k = 0; k < 6; ++k) sM[pl_ * SM_LD + 16 * k + r] = __float_as_uint(fmaxf(m0[k], 0.f));        // max(ReLU(.)) = max(0, max(.))
 #pragma unroll
-            for (int t = 0; t < 12; ++t) mxu[t] = maxOverLaneGroups(mxu[t]);
-            if (g == 0) {
-#pragma unroll
-                for (int t = 0; t < 6; ++t) sM[pl * SM_LD + 16 * t + r] = __float_as_uint(mx0[t]);
-#pragma unroll
-                for (int t = 0; t < 12; ++t) sU[pl * SU_LD + 16 * t + r] = __float_as_uint(mxu[t]);
+                for (int k = 0; k < 12; ++k) sU[pl_ * SU_LD + 16 * k + r] = __float_as_uint(mu[k]);
             }
+        } else {
 #pragma unroll
-            for (int t = 0; t < 6; ++t) mx0[t] = 0.f;
+            for (int k = 0; k < 6; ++k) mx0[k] = fmaxf(mx0[k], m0[k]);
 #pragma unroll
-            for (int t = 0; t < 12; ++t) mxu[t] = -INFINITY;
+            for (int k = 0; k < 12; ++k) mxu[k] = fmaxf(mxu[k], mu[k]);
+            if (lastOfUnit) {
+                // across the four lane groups (points 4g'..4g'+3 of every tile), then lane group 0 owns column 16k + r
+                const uint32_t pl_ = sLarge[cu - npacked];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) mx0[k] = maxOverLaneGroups(mx0[k]);
+#pragma unroll
+                for (int k = 0; k < 12; ++k) mxu[k] = maxOverLaneGroups(mxu[k]);
+                if (g == 0) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) sM[pl_ * SM_LD + 16 * k + r] = __float_as_uint(mx0[k]);
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) sU[pl_ * SU_LD + 16 * k + r] = __float_as_uint(mxu[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) mx0[k] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) mxu[k] = -INFINITY;
+            }
         }
-        pl = npl; s0 = ns0; e0 = ne0; base = nbase; have = haveNext;
+        u = nu; t = ntile; have = haveNext;
     }
     mark();
     __syncthreads();
@@ -250,6 +304,7 @@ static inline int pfnPermuteK(int p) {       // see mlp.hip: position p of a per
 class DsvtPillarFeatureNetPlugin : public Plugin {
 public:
     int max_pillars_;
+    int pack_ = 1;                                                  // pillars with <= 4 points share MFMA tiles (0: the round-1 one-pillar-per-tile layout)
     std::vector<float> w0_, b0_, w1_, b1_;
     float *w0_dev_ = nullptr, *b0_dev_ = nullptr, *b1_dev_ = nullptr; _Float16 *w1a_dev_ = nullptr, *w1b_dev_ = nullptr;
     bool ok_ = false;
@@ -306,6 +361,7 @@ public:
         a.pcnt = static_cast<const uint32_t*>(in[2]); a.pillar_num = static_cast<const uint32_t*>(in[3]); a.max_pillars = max_pillars_;
         a.w0 = w0_dev_; a.b0 = b0_dev_; a.w1a = w1a_dev_; a.w1b = w1b_dev_; a.b1 = b1_dev_;
         a.out = static_cast<float*>(out[0]); a.out16 = static_cast<_Float16*>(out[1]);
+        a.pack = pack_;
         if (zeroFill) {
             DSVT_CHECK(hipMemsetAsync(out[0], 0, sizeof(float) * (size_t)max_pillars_ * PF_C1, stream));
             DSVT_CHECK(hipMemsetAsync(out[1], 0, sizeof(_Float16) * (size_t)max_pillars_ * PF_C1, stream));
@@ -316,13 +372,17 @@ public:
         return lastError();
     }
     size_t nFloats() const { return w0_.size() + b0_.size() + w1_.size() + b1_.size(); }
-    size_t serializationSize() const override { return sizeof(int) + sizeof(float) * nFloats(); }
+    size_t serializationSize() const override { return 2 * sizeof(int) + sizeof(float) * nFloats(); }
     void serialize(void* buf) const override {
         char* d = static_cast<char*>(buf);
         wr<int>(d, max_pillars_);
         for (const std::vector<float>* v : {&w0_, &b0_, &w1_, &b1_}) { memcpy(d, v->data(), sizeof(float) * v->size()); d += sizeof(float) * v->size(); }
+        wr<int>(d, pack_);
     }
-    Plugin* clone() const override { return new DsvtPillarFeatureNetPlugin(max_pillars_, w0_.data(), b0_.data(), w1_.data(), b1_.data()); }
+    Plugin* clone() const override {
+        DsvtPillarFeatureNetPlugin* c = new DsvtPillarFeatureNetPlugin(max_pillars_, w0_.data(), b0_.data(), w1_.data(), b1_.data());
+        c->pack_ = pack_; return c;
+    }
 };
 static Plugin* pfnCreate(const DsvtPluginFieldCollection* fc) {
     const int mp = fieldInt(fc, "max_pillars_num");
@@ -333,7 +393,10 @@ static Plugin* pfnCreate(const DsvtPluginFieldCollection* fc) {
         if (!f || !f->data || f->length != need[i].len) return nullptr;
         p[i] = static_cast<const float*>(f->data);
     }
-    return mp > 0 ? new DsvtPillarFeatureNetPlugin(mp, p[0], p[1], p[2], p[3]) : nullptr;
+    if (mp <= 0) return nullptr;
+    DsvtPillarFeatureNetPlugin* pl = new DsvtPillarFeatureNetPlugin(mp, p[0], p[1], p[2], p[3]);
+    pl->pack_ = fieldInt(fc, "pack_small_pillars", 1) != 0;
+    return pl;
 }
 static Plugin* pfnDeser(const void* data, size_t len) {
     if (len < sizeof(int)) return nullptr;
@@ -343,11 +406,13 @@ static Plugin* pfnDeser(const void* data, size_t len) {
     if (mp <= 0 || len < sizeof(int) + n * sizeof(float)) return nullptr;
     std::vector<float> all(n); memcpy(all.data(), d, n * sizeof(float));
     const float* q = all.data();
-    return new DsvtPillarFeatureNetPlugin(mp, q, q + PF_C0 * PF_IN, q + PF_C0 * PF_IN + PF_C0, q + PF_C0 * PF_IN + PF_C0 + (size_t)PF_C1 * PF_C1);
+    DsvtPillarFeatureNetPlugin* pl = new DsvtPillarFeatureNetPlugin(mp, q, q + PF_C0 * PF_IN, q + PF_C0 * PF_IN + PF_C0, q + PF_C0 * PF_IN + PF_C0 + (size_t)PF_C1 * PF_C1);
+    if (len >= 2 * sizeof(int) + n * sizeof(float)) { const char* t = d + n * sizeof(float); pl->pack_ = rd<int>(t) != 0; }
+    return pl;
 }
 static Creator g_pfnCreator{"DsvtPillarFeatureNetPlugin",
     {{"max_pillars_num", DSVT_FIELD_INT32}, {"weight0", DSVT_FIELD_FLOAT32}, {"bias0", DSVT_FIELD_FLOAT32}, {"weight1", DSVT_FIELD_FLOAT32},
-     {"bias1", DSVT_FIELD_FLOAT32}},
+     {"bias1", DSVT_FIELD_FLOAT32}, {"pack_small_pillars", DSVT_FIELD_INT32}},
     pfnCreate, pfnDeser, {}, {}};
 static Registrar g_pfnReg(&g_pfnCreator);
 

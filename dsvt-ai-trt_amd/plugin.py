@@ -424,14 +424,14 @@ def add_pos_embed_op(max_rows, layer_input, pe_weights, pe_biases, weights, bias
                   "pos_embed_layer")
 
 
-def add_pillar_feature_net_op(max_pillars_num, weight0, bias0, weight1, bias1):
+def add_pillar_feature_net_op(max_pillars_num, weight0, bias0, weight1, bias1, pack_small_pillars=True):
     """Both PFN layers + both scatter-max reductions in one launch, no per-point activation in memory (csrc/pfn.hip).
     BatchNorm folded by the caller: weight0 [96,10], weight1 [192,192] (columns 0..95 act on x0, 96..191 on its pillar max).
     Inputs: feat [1,Nk,10], pidx [1,P,T], pcnt [1,P,1], pillar_num [1].  Outputs: pillar features [1,P,192] fp32 + fp16."""
     return Plugin("DsvtPillarFeatureNetPlugin", dict(
         max_pillars_num=int(max_pillars_num), weight0=np.asarray(weight0, np.float32).reshape(-1),
         bias0=np.asarray(bias0, np.float32).reshape(-1), weight1=np.ascontiguousarray(np.asarray(weight1, np.float32)).reshape(-1),
-        bias1=np.asarray(bias1, np.float32).reshape(-1)), "pillar_feature_net_layer")
+        bias1=np.asarray(bias1, np.float32).reshape(-1), pack_small_pillars=int(bool(pack_small_pillars))), "pillar_feature_net_layer")
 
 
 def add_rotated_nms_op(max_boxes=500, nms_thresh=0.01):

@@ -232,6 +232,12 @@ def test_pillar_feature_net_against_oracle(pkg, oracle, frame, capname, n_pts):
     assert err.mean() < 1.5e-4 * scale
     assert not got[np_:].any()
     assert np.abs(v16[0, :np_].float().cpu().numpy() - got[:np_]).max() <= 2.0 ** -11 * scale * 1.01
+    # packing pillars with <= 4 points four to an MFMA tile does not change a bit: a tile row depends on its own point only
+    v1, _ = P.add_pillar_feature_net_op(c["P"], W0, b0, W1, b1, pack_small_pillars=False)(feat, pidx, pcnt, Pn)
+    torch.cuda.synchronize()
+    assert torch.equal(v, v1)
+    cnts = host(pcnt)[0, :np_, 0]
+    assert (cnts <= 4).mean() > 0.4 and (cnts > 16).any()                    # both tile kinds are exercised
 
 
 # =====================================================================================================================
