@@ -364,6 +364,14 @@ def main():
                      algorithmic_mb_per_launch=round(tot_by / n_l / 1e6, 2))
             if r["traffic"] is not None:
                 r["traffic_source"] = "profiles/" + PMC_FILE
+            # the weight matrices are counted ONCE in the algorithmic bytes, but every workgroup streams its own copy L2 -> LDS: what the
+            # memory system carries per launch beside the activations (DESIGN.md "what bounds the backbone kernels")
+            wg_weights = {"DsvtEncoderMlpPlugin": 2 * (192 * 192 + 2 * 192 * 384), "DsvtLinearPlugin": 2 * 192 * 576 if f16 else 0}.get(ptype, 0)
+            if wg_weights and f16:
+                c0 = counts[0]
+                nwg = min(256, -(-c0["P"] // 128))
+                r["weights_restreamed_mb_per_launch"] = round(nwg * wg_weights / 1e6, 1)
+                r["fabric_gbs_incl_weight_stream"] = round((tot_by / n_l + nwg * wg_weights) / (avg_ms * 1e-3) / 1e9, 1)
             roofline_all.append((ptype, r))
         # the headline roofline object = the hot path's kernel with the largest share of the frame
         hot = [x for x in roofline_all if x[0] != "DsvtConv2dPlugin"] or roofline_all

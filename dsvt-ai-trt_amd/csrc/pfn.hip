@@ -71,8 +71,11 @@ pfn_kernel(PfnArgs a)
 {
     // (row strides 100 / 196 dwords: with 96 / 192 the sixteen pillar rows of a 16-byte read fall on two / one bank group,
     // SQ_LDS_BANK_CONFLICT was 40 % of the kernel's LDS cycles)
-    constexpr int SM_LD = PF_C0 + 4, SU_LD = PF_C1 + 4;
-    __shared__ __attribute__((aligned(16))) uint32_t sM[PF_PB * SM_LD];   // max_pillar(x0), float bits                      6 KB
+    // sM holds fp16: it is only ever read as the fp16 B operand of the per-pillar GEMM (rounding at the store = rounding at the read), and
+    // with 3.3 KB instead of 6.4 the workgroup needs 52.7 KB of LDS: THREE per CU (the group loop is a chain of exposed latencies --
+    // pillar starts, first point rows, W1b fragments -- that only other resident workgroups can hide)
+    constexpr int SM_LD = PF_C0 + 8, SU_LD = PF_C1 + 4;
+    __shared__ __attribute__((aligned(16))) _Float16 sM[PF_PB * SM_LD];   // max_pillar(x0) as fp16, 208-byte rows (conflict-free b128 reads)  3.3 KB
     __shared__ __attribute__((aligned(16))) uint32_t sU[PF_PB * SU_LD];   // max_pillar(W1a x0), float bits                 12 KB
     __shared__ uint32_t sStart[PF_PB + 1];
     __shared__ uint32_t sSmall[PF_PB], sLarge[PF_PB], sNum[2];           // pillars of the group with <= 4 points / more, and how many of each
@@ -102,7 +105,7 @@ pfn_kernel(PfnArgs a)
     const uint32_t pb0 = grp * PF_PB;
     const int npil = P - pb0 < (uint32_t)PF_PB ? (int)(P - pb0) : PF_PB;
 
-    for (int i = tid; i < PF_PB * SM_LD; i += 64 * PF_NW) sM[i] = 0u;
+    for (int i = tid; i < PF_PB * SM_LD; i += 64 * PF_NW) sM[i] = (_Float16)0.f;
     for (int i = tid; i < PF_PB * SU_LD; i += 64 * PF_NW) sU[i] = 0u;
     if (tid <= npil) {
         // first row of pillar pb0 + tid; the sentinel entry is one past the last pillar's rows
@@ -217,7 +220,7 @@ pfn_kernel(PfnArgs a)
             if (idx < nsmall) {
                 const uint32_t pl_ = sSmall[idx];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) sM[pl_ * SM_LD + 16 * k + r] = __float_as_uint(fmaxf(m0[k], 0.f));        // max(ReLU(.)) = max(0, max(.))
+                for (int k = 0; k < 6; ++k) sM[pl_ * SM_LD + 16 * k + r] = (_Float16)fmaxf(m0[k], 0.f);                // max(ReLU(.)) = max(0, max(.))
 #pragma unroll
                 for (int k = 0; k < 12; ++k) sU[pl_ * SU_LD + 16 * k + r] = __float_as_uint(mu[k]);
             }
@@ -235,7 +238,7 @@ pfn_kernel(PfnArgs a)
                 for (int k = 0; k < 12; ++k) mxu[k] = maxOverLaneGroups(mxu[k]);
                 if (g == 0) {
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) sM[pl_ * SM_LD + 16 * k + r] = __float_as_uint(mx0[k]);
+                    for (int k = 0; k < 6; ++k) sM[pl_ * SM_LD + 16 * k + r] = (_Float16)mx0[k];
 #pragma unroll
                     for (int k = 0; k < 12; ++k) sU[pl_ * SU_LD + 16 * k + r] = __float_as_uint(mxu[k]);
                 }
@@ -253,14 +256,7 @@ pfn_kernel(PfnArgs a)
     // ---- per-pillar half: t^T = W1b m^T (16 pillars x 96 -> 192); wave w owns column tiles w, w + 8 ----------------------------
     half8 mf[3];                                     // B fragment: lane (r, g) holds m[pillar r][32s + 8g + j]
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const uint4 lo = *reinterpret_cast<const uint4*>(&sM[r * SM_LD + 32 * s + 8 * g]);
-        const uint4 hi = *reinterpret_cast<const uint4*>(&sM[r * SM_LD + 32 * s + 8 * g + 4]);
-        half8 h;
-        h[0] = (_Float16)__uint_as_float(lo.x); h[1] = (_Float16)__uint_as_float(lo.y); h[2] = (_Float16)__uint_as_float(lo.z); h[3] = (_Float16)__uint_as_float(lo.w);
-        h[4] = (_Float16)__uint_as_float(hi.x); h[5] = (_Float16)__uint_as_float(hi.y); h[6] = (_Float16)__uint_as_float(hi.z); h[7] = (_Float16)__uint_as_float(hi.w);
-        mf[s] = h;
-    }
+    for (int s = 0; s < 3; ++s) mf[s] = *reinterpret_cast<const half8*>(&sM[r * SM_LD + 32 * s + 8 * g]);
     const bool pv = r < npil && !(a.dbg & 8);
 #pragma unroll
     for (int tt = 0; tt < (12 + PF_NW - 1) / PF_NW; ++tt) {
@@ -366,7 +362,7 @@ public:
             DSVT_CHECK(hipMemsetAsync(out[0], 0, sizeof(float) * (size_t)max_pillars_ * PF_C1, stream));
             DSVT_CHECK(hipMemsetAsync(out[1], 0, sizeof(_Float16) * (size_t)max_pillars_ * PF_C1, stream));
         }
-        int grid = 2 * pfnCUs(); if (grid > cdiv(max_pillars_, PF_PB)) grid = cdiv(max_pillars_, PF_PB);       // two resident workgroups per CU (54 KB of LDS each)
+        int grid = 3 * pfnCUs(); if (grid > cdiv(max_pillars_, PF_PB)) grid = cdiv(max_pillars_, PF_PB);       // three resident workgroups per CU (52.7 KB of LDS each)
         hipLaunchKernelGGL(pfn_kernel, dim3(grid), dim3(64 * PF_NW), 0, stream, a);
         if (tron) { (void)hipStreamSynchronize(stream); fprintf(stderr, "[pfn trace wg0]"); for (int i = 1; i < 24; ++i) fprintf(stderr, " %lld", (long long)(tr[i] - tr[0])); fprintf(stderr, "\n"); }
         return lastError();
