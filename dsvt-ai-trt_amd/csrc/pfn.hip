@@ -71,9 +71,8 @@ pfn_kernel(PfnArgs a)
 {
     // (row strides 100 / 196 dwords: with 96 / 192 the sixteen pillar rows of a 16-byte read fall on two / one bank group,
     // SQ_LDS_BANK_CONFLICT was 40 % of the kernel's LDS cycles)
-    // sM holds fp16: it is only ever read as the fp16 B operand of the per-pillar GEMM (rounding at the store = rounding at the read), and
-    // with 3.3 KB instead of 6.4 the workgroup needs 52.7 KB of LDS: THREE per CU (the group loop is a chain of exposed latencies --
-    // pillar starts, first point rows, W1b fragments -- that only other resident workgroups can hide)
+    // sM holds fp16: it is only ever read as the fp16 B operand of the per-pillar GEMM (rounding at the store = rounding at the read).
+    // (52.7 KB of LDS in all; a third resident workgroup per CU was measured: 82 vs 79 us, the group loop is not latency-starved.)
     constexpr int SM_LD = PF_C0 + 8, SU_LD = PF_C1 + 4;
     __shared__ __attribute__((aligned(16))) _Float16 sM[PF_PB * SM_LD];   // max_pillar(x0) as fp16, 208-byte rows (conflict-free b128 reads)  3.3 KB
     __shared__ __attribute__((aligned(16))) uint32_t sU[PF_PB * SU_LD];   // max_pillar(W1a x0), float bits                 12 KB
@@ -362,7 +361,7 @@ public:
             DSVT_CHECK(hipMemsetAsync(out[0], 0, sizeof(float) * (size_t)max_pillars_ * PF_C1, stream));
             DSVT_CHECK(hipMemsetAsync(out[1], 0, sizeof(_Float16) * (size_t)max_pillars_ * PF_C1, stream));
         }
-        int grid = 3 * pfnCUs(); if (grid > cdiv(max_pillars_, PF_PB)) grid = cdiv(max_pillars_, PF_PB);       // three resident workgroups per CU (52.7 KB of LDS each)
+        int grid = 2 * pfnCUs(); if (grid > cdiv(max_pillars_, PF_PB)) grid = cdiv(max_pillars_, PF_PB);       // two resident workgroups per CU (three: 82 vs 79 us)
         hipLaunchKernelGGL(pfn_kernel, dim3(grid), dim3(64 * PF_NW), 0, stream, a);
         if (tron) { (void)hipStreamSynchronize(stream); fprintf(stderr, "[pfn trace wg0]"); for (int i = 1; i < 24; ++i) fprintf(stderr, " %lld", (long long)(tr[i] - tr[0])); fprintf(stderr, "\n"); }
         return lastError();
