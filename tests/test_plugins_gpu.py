@@ -582,3 +582,51 @@ def test_fused_set_partition_capacity_and_generic_order(pkg, oracle):
             assert int(S[0]) == rg["S"] and (S_cap == 800 or rg["S"] <= 200)
             assert np.array_equal(c2d[0], rw["c2d"])
             assert np.array_equal(inds[0], rg["inds"]) and np.array_equal(mask[0], rg["mask"])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_integer_path_fuzz_against_oracle(pkg, oracle, seed):
+    """Randomised clouds and CAPACITIES through Points2Features, the per-configuration WindowPartition / GetSet plugins and the fused
+    DsvtSetPartitionPlugin, bit-exact against the oracle: clustered and uniform points, points exactly on cell borders and on the range
+    limits, out-of-range and duplicate points, and caps small enough that the pillar / kept-point / window / set lists overflow (the
+    truncation rules of DESIGN.md: lists stop at the first element that does not fit)."""
+    P, O = pkg.plugin, oracle
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 6000))
+    kind = seed % 4
+    if kind == 0:                                         # a few dense clusters: over-full pillars, full windows
+        centres = rng.uniform(-70, 70, (6, 2))
+        xy = centres[rng.integers(0, 6, n)] + rng.normal(0, 1.5, (n, 2))
+    elif kind == 1:                                       # uniform over (and beyond) the range
+        xy = rng.uniform(-80, 80, (n, 2))
+    elif kind == 2:                                       # exact multiples of the cell size: border arithmetic (floorf((p - min) / size))
+        xy = (rng.integers(-240, 241, (n, 2)) * 0.32).astype(np.float32) + rng.choice([0.0, -74.88 % 0.32], (n, 1))
+    else:                                                 # one window's worth of cells, heavily repeated points
+        xy = np.repeat(rng.uniform(10, 13.8, (max(n // 8, 1), 2)), 8, axis=0)[:n]
+        n = xy.shape[0]
+    z = rng.uniform(-6, 4, (n, 1)); it = rng.uniform(0, 255, (n, 1))
+    pts = np.concatenate([xy, z, it], 1).astype(np.float32)
+    if n > 4:
+        pts[0, :2] = (-74.88, -74.88); pts[1, :2] = (74.88, 0.0); pts[2, 2] = 3.0; pts[3, 2] = -5.0     # range limits: [min, max) on every axis
+    c = dict(N=8192, Nk=int(rng.choice([8192, 700])), P=int(rng.choice([4096, 150])), W=int(rng.choice([512, 20])), Vw=int(rng.choice([576, 40])))
+    S_cap = int(rng.choice([1024, 25]))
+    pad, n = cases.pad_points(pts, c["N"])
+    ref = O.points2features(pad, n, cases.p2f_cfg(c))
+    _, outs = run_voxelizer(P, c, pad, n)
+    check_voxelizer(outs, ref)
+    po = P.add_set_partition_op(c["W"], c["Vw"], 36, S_cap, c["P"], cases.GRID, cases.WINS)(outs[2], outs[4])
+    torch.cuda.synchronize()
+    for k, (win, shift) in enumerate(cases.WINS):
+        rw = O.window_partition(ref["coords"], ref["P"], cases.wp_cfg(c, k))
+        rg = O.get_set(rw["gidx"], rw["cinw"], rw["vcnt"], rw["W"], dict(cases.gs_cfg(c, k), max_win_num=S_cap))
+        wpo = P.add_window_partition(c["W"], c["Vw"], 468, 468, 1, *win, *shift)(outs[2], outs[4])
+        gso = P.add_get_set_op(c["W"], c["Vw"], 36, *win, max_set_num=S_cap)(wpo[0], wpo[1], wpo[2], wpo[3])
+        torch.cuda.synchronize()
+        assert int(host(wpo[3])[0]) == rw["W"] and np.array_equal(host(wpo[2])[0], rw["vcnt"])
+        assert np.array_equal(host(wpo[0])[0], rw["gidx"]) and np.array_equal(host(wpo[1])[0], rw["cinw"])
+        assert np.array_equal(host(wpo[4])[0], rw["c2d"]) and np.array_equal(host(wpo[5])[0], rw["xy"])
+        assert int(host(gso[2])[0]) == rg["S"]
+        assert np.array_equal(host(gso[0])[0], rg["inds"]) and np.array_equal(host(gso[1])[0], rg["mask"])
+        c2d, inds, mask, S = [host(t) for t in po[4 * k:4 * k + 4]]
+        assert int(S[0]) == rg["S"], (int(S[0]), rg["S"])
+        assert np.array_equal(c2d[0], rw["c2d"]) and np.array_equal(inds[0], rg["inds"]) and np.array_equal(mask[0], rg["mask"])
