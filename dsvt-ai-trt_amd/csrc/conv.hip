@@ -607,7 +607,7 @@ struct WideCfg {
     static constexpr int NPC = (HH * HS * 64 + 1023) / 1024;       // LDS-DMA pieces (16 pixels each) per halo phase
     static constexpr int HBYTES = NPC * 1024, WBYTES = SPS * CT * 1024;
     static constexpr int PPW = (NPC + NW - 1) / NW;                // pieces per wave per phase
-    static constexpr int RPW = SPS * CT / NW;                       // weight rows per wave per slab
+    static constexpr int RPW = (SPS * CT + NW - 1) / NW;            // weight rows per wave per slab (NW = 7: waves 0, 1 take three, the others two)
 };
 
 // NWB = weight slabs in LDS: 3 = the slab TWO ahead is requested when a slab starts and the slab-end wait leaves those requests
@@ -651,6 +651,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
 #pragma unroll
         for (int j = 0; j < C::RPW; ++j) {
             const int u = wave + NW * j, step = SPS * sl + u / CT, ph = step / 9, tap = step - 9 * ph;
+            if ((SPS * CT) % NW != 0 && u >= SPS * CT) break;
             const size_t row = (size_t)(2 * ((ph >> 1) * 9 + tap) + (ph & 1)) * NCT + ch * CT + u % CT;
             __builtin_amdgcn_global_load_lds((glds_src_t)(Wp + (row * 64 + lane) * 8), (glds_dst_t)(smem + 2 * WT_HBYTES + wb * WT_WBYTES + u * 1024), 16, 0, 0);
         }
@@ -678,6 +679,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     slabBarrier(0);
     if (LEAD == 2) weightRequests(1, chunk, 1);                   // (NSLAB >= 5; retired by the first slab-end wait)
 
+    const int wreq = (SPS * CT - wave + NW - 1) / NW;             // weight requests THIS wave issues per slab (what its counted wait leaves in flight)
     const int pb = ((RW * wave) * WT_HS + r) * 64;                // this lane's pixel of pixel tile 0, tap (0, 0)
     const int aoff = lane << 4;
     int wb = 0;
@@ -754,7 +756,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            slabBarrier(LEAD == 2 && wIssued ? C::RPW : 0);
+            slabBarrier(LEAD == 2 && wIssued ? wreq : 0);
             wb = (wb + 1) % NWB;
         }
         // residual / ReLU / store (the bias is in the accumulators)
@@ -851,8 +853,15 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
         }
         if (nwide >= numCUs() && wideOn != 4) {
             const int grid = numCUs();
+            // Item rounds.  Persistent workgroups (one per CU) walk the items, so a layer costs ceil(items / CUs) x rows-per-item: the 468 x 468
+            // layers are 30 x 15 = 450 items of 16 rows = TWO rounds on 256 CUs with the second a quarter empty; as 14-row items (seven
+            // waves) they are 34 x 15 = 510 = two FULL rounds of 14 rows: 28 row-units instead of 32 (DSVT_CONV_WIDE=11: always 16 rows)
+            const int n14 = cdiv(a.Ho, 14) * tilesX * nchunk;
+            const bool rows14 = wideOn != 11 && cdiv(n14, grid) * 14 < cdiv(nwide, grid) * 16;
             // (a third weight slab -- requests two slabs ahead -- measured 80.2 vs 82.6 us on the 128-channel layers, nothing elsewhere)
-            if (ctWide == 8) hipLaunchKernelGGL((conv_wide_kernel<8, 8, 40, 2, 3>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk, dbgW);
+            if (ctWide == 8 && rows14) hipLaunchKernelGGL((conv_wide_kernel<8, 7, 40, 2, 3>), dim3(grid), dim3(448), 0, stream, a, Wp, zeros, tilesX, n14, nchunk, dbgW);
+            else if (ctWide == 8) hipLaunchKernelGGL((conv_wide_kernel<8, 8, 40, 2, 3>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk, dbgW);
+            else if (rows14) hipLaunchKernelGGL((conv_wide_kernel<4, 7, 40, 4, 2>), dim3(grid), dim3(448), 0, stream, a, Wp, zeros, tilesX, n14, nchunk, dbgW);
             else hipLaunchKernelGGL((conv_wide_kernel<4, 8, 40, 4, 2>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk, dbgW);
             return lastError();
         }
