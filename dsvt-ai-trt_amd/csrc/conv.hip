@@ -853,11 +853,13 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
         }
         if (nwide >= numCUs() && wideOn != 4) {
             const int grid = numCUs();
-            // Item rounds.  Persistent workgroups (one per CU) walk the items, so a layer costs ceil(items / CUs) x rows-per-item: the 468 x 468
-            // layers are 30 x 15 = 450 items of 16 rows = TWO rounds on 256 CUs with the second a quarter empty; as 14-row items (seven
-            // waves) they are 34 x 15 = 510 = two FULL rounds of 14 rows: 28 row-units instead of 32 (DSVT_CONV_WIDE=11: always 16 rows)
+            // Item rounds (round-2 experiment, DSVT_CONV_WIDE=12).  Persistent workgroups (one per CU) walk the items: the 468 x 468 layers are
+            // 30 x 15 = 450 items of 16 rows = TWO rounds on 256 CUs with the second a quarter empty; as 14-row items on seven waves they
+            // are 34 x 15 = 510 = two FULL rounds of 14 rows, 28 row-units instead of 32.  Measured: no gain (convolutions 1.211 vs 1.199 ms
+            // per frame, 439 vs 442 frames/s): the quarter-empty second round is not idle time, its workgroups run faster on the freed
+            // memory system.  Kept behind the switch; results are identical.
             const int n14 = cdiv(a.Ho, 14) * tilesX * nchunk;
-            const bool rows14 = wideOn != 11 && cdiv(n14, grid) * 14 < cdiv(nwide, grid) * 16;
+            const bool rows14 = wideOn == 12 && cdiv(n14, grid) * 14 < cdiv(nwide, grid) * 16;
             // (a third weight slab -- requests two slabs ahead -- measured 80.2 vs 82.6 us on the 128-channel layers, nothing elsewhere)
             if (ctWide == 8 && rows14) hipLaunchKernelGGL((conv_wide_kernel<8, 7, 40, 2, 3>), dim3(grid), dim3(448), 0, stream, a, Wp, zeros, tilesX, n14, nchunk, dbgW);
             else if (ctWide == 8) hipLaunchKernelGGL((conv_wide_kernel<8, 8, 40, 2, 3>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk, dbgW);
