@@ -42,7 +42,7 @@ PEAK_F32_MATRIX_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Pe
 PEAK_F16_MATRIX_TFLOPS = 2500.0     # same guide: "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBS = 8000.0               # same guide: "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured float4 copy)
 N_POINTS = 180000
-PMC_FILE = "r02_b_pmc_traffic.json"
+PMC_FILE = "r02_c_pmc_traffic.json"
 FRAME_POOL = 4                      # distinct synthetic clouds cycled through by the steps
 
 
@@ -260,6 +260,10 @@ def main():
     prof = None if args.no_kernel_events else {"DsvtLinearPlugin": [], "DsvtEncoderMlpPlugin": [], "DsvtSetAttentionPlugin": [],
                                                "DsvtConv2dPlugin": [], "DsvtPillarFeatureNetPlugin": [], "DsvtPosEmbedPlugin": []}
     marks = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    # warm-up of the one collective: RCCL sets up its channels lazily at the first call of each kind (tens of ms: measured 45 ms on a size-1
+    # communicator, as much as 23 frames), which is start-up cost, not a property of the frame path
+    if world > 1 or args.rccl_single:
+        par.gather_results(results, K * world, rank, world, force_collective=args.rccl_single)
     par.barrier(); torch.cuda.synchronize()
     sampled = 0
     t0 = time.perf_counter()
