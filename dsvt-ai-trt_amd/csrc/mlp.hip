@@ -155,10 +155,13 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
 {
     constexpr int PQT = PQ / 16, PQS = PQ / 32, SR = 6 * PQT, SB = SR * 1024, NWO = MC / PQ, NPIECE = MF / PQ;
     constexpr int NST = NWO + 2 * NPIECE, NRW = SR / NW, D = RS - 1;
-    constexpr int LNP = 8 * MC * 4;                 // ln_g [4][192] | ln_b [4][192] of the final LayerNorms: six 1 KB DMA rows
+    // ln_g [4][192] | ln_b [4][192] of the final LayerNorms (six 1 KB DMA rows): with three slots they take the slot stage NST-3 leaves when
+    // the last piece starts (no LDS of their own: 78,848 B, two workgroups per CU); the deeper ring has no free slot then, they get 6 KB
+    constexpr bool LN_IN_RING = RS == 3;
+    constexpr int LNP = LN_IN_RING ? 0 : 8 * MC * 4;
     constexpr bool ELASTIC = MT == 1 && NW == 10;   // 8 .. 10 waves of 16 rows are live, chosen from the row count (see below)
     static_assert(12 * PQS == SR && (ELASTIC || (SR % NW == 0 && (NRW == 3 || NRW == 6))), "uniform request count per wave");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[RS * SB + MP_FLOATS * 4 + LNP];     // RS = 3: 84,992 B; RS = 6: 158,720 B (one workgroup per CU)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[RS * SB + MP_FLOATS * 4 + LNP];     // RS = 3: 78,848 B; RS = 6: 158,720 B (one workgroup per CU)
     const uint32_t cnt = *a.count;
     const int M = (int)(cnt < (uint32_t)a.max_rows ? cnt : (uint32_t)a.max_rows);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -260,15 +263,17 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
         if (pr < MP_FLOATS / 256)
             __builtin_amdgcn_global_load_lds((mlp_gsrc_t)(a.params + pr * 256 + lane * 4), (mlp_ldst_t)(lds + RS * SB + pr * 1024), 16, 0, 0);
     }
-    // the parameters of the final LayerNorms (ln_g | ln_b, 4 x 192 floats each): their own LDS rows, so that the epilogue's only global
-    // loads are x / xb
+    // the parameters of the final LayerNorms travel by LDS-DMA too, so that the epilogue's only global loads are x / xb
+    auto requestLnParams = [&](unsigned char* dst) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int pr = wave + j * nwa;
-        if (pr < 6)
-            __builtin_amdgcn_global_load_lds((mlp_gsrc_t)((pr < 3 ? a.ln_g + pr * 256 : a.ln_b + (pr - 3) * 256) + lane * 4),
-                                             (mlp_ldst_t)(lds + RS * SB + MP_FLOATS * 4 + pr * 1024), 16, 0, 0);
-    }
+        for (int j = 0; j < 6; ++j) {
+            const int pr = wave + j * nwa;
+            if (pr < 6)
+                __builtin_amdgcn_global_load_lds((mlp_gsrc_t)((pr < 3 ? a.ln_g + pr * 256 : a.ln_b + (pr - 3) * 256) + lane * 4),
+                                                 (mlp_ldst_t)(dst + pr * 1024), 16, 0, 0);
+        }
+    };
+    if (!LN_IN_RING) requestLnParams(lds + RS * SB + MP_FLOATS * 4);
 #pragma unroll
     for (int d = 1; d < D; ++d) request(d);
     // ---- prologue: the att row as the out-proj B operand, x straight into the out-proj accumulator -----------------
@@ -343,6 +348,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
     for (int q = 0; q < NPIECE; ++q) {
         const int stA = NWO + 2 * q, stB = stA + 1;
         if (stA + D < NST) request(stA + D);
+        else if (LN_IN_RING) requestLnParams(lds + (NST % RS) * SB);      // last piece: nothing left to stream, the slot stage NST-3 has just left is free
         const unsigned char* slotA = lbase + (stA % RS) * SB;
         floatx4 acc2[MT][PQT];
 #pragma unroll
@@ -398,7 +404,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
     }
     mark();
     // ---- s2 = LN2(s1 + f + b2) (already summed); x' = LN3(s2 + x); [x' = LN4(x' + xb)]: nothing in flight any more ------
-    const float* lnL = reinterpret_cast<const float*>(lds + RS * SB + MP_FLOATS * 4);        // ln_g [4][192] | ln_b [4][192]
+    const float* lnL = reinterpret_cast<const float*>(LN_IN_RING ? lds + (NST % RS) * SB : lds + RS * SB + MP_FLOATS * 4);        // ln_g [4][192] | ln_b [4][192]
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         int rcl = rc[mt];
