@@ -862,7 +862,10 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
             const bool rows14 = wideOn == 12 && cdiv(n14, grid) * 14 < cdiv(nwide, grid) * 16;
             // (a third weight slab -- requests two slabs ahead -- measured 80.2 vs 82.6 us on the 128-channel layers, nothing elsewhere)
             if (ctWide == 8 && rows14) hipLaunchKernelGGL((conv_wide_kernel<8, 7, 40, 2, 3>), dim3(grid), dim3(448), 0, stream, a, Wp, zeros, tilesX, n14, nchunk, dbgW);
-            else if (ctWide == 8) hipLaunchKernelGGL((conv_wide_kernel<8, 8, 40, 2, 3>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk, dbgW);
+            // halo row stride 36 pixels, not 40: 134,144 B of LDS instead of 142,336, which leaves room for the 23 KB workgroups of the
+            // OTHER frame's set-attention kernel on the same CU (two frames in flight: a gather-bound kernel under an MFMA-bound one)
+            else if (ctWide == 8 && wideOn == 13) hipLaunchKernelGGL((conv_wide_kernel<8, 8, 40, 2, 3>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk, dbgW);
+            else if (ctWide == 8) hipLaunchKernelGGL((conv_wide_kernel<8, 8, 36, 2, 3>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk, dbgW);
             else if (rows14) hipLaunchKernelGGL((conv_wide_kernel<4, 7, 40, 4, 2>), dim3(grid), dim3(448), 0, stream, a, Wp, zeros, tilesX, n14, nchunk, dbgW);
             else hipLaunchKernelGGL((conv_wide_kernel<4, 8, 40, 4, 2>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk, dbgW);
             return lastError();
