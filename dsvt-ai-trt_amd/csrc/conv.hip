@@ -832,6 +832,19 @@ static int haloTileRows(const ConvArgs&) {
     return 8;
 }
 
+// Persistent workgroups walk the items round-robin, so a launch takes ceil(items / slots) rounds whatever the grid is between
+// items / rounds and slots: the SMALLEST grid with that round count (450 items on 256 CUs: 225 workgroups of exactly two items) would
+// leave the other CUs to the kernels of the other frame in flight.  Round-2 experiment (DSVT_CONV_BALANCE=1): 532-535 vs 534-539 frames/s
+// with two frames in flight, 441 vs 442 with one -- free CUs are not what the second frame lacks; off by default.
+static int balancedGrid(int nitems, int slots) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("DSVT_CONV_BALANCE"); on = e ? atoi(e) : 0; }
+    if (nitems <= slots) return nitems;
+    if (!on) return slots;
+    const int rounds = cdiv(nitems, slots);
+    return cdiv(nitems, rounds);
+}
+
 static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16* zeros, hipStream_t stream) {
     const int th = haloTileRows(a);
     const int tilesX = cdiv(a.Wo, HTW), nchunk = cdiv(a.CoutRows, CNB);
@@ -847,12 +860,12 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
         // short K (the 64 -> 320 head stems: 9 slabs per item, the epilogue weighs as much as the MFMAs): 8-row x 128-channel tiles on
         // four waves, two independent workgroups per CU, 2655 items: 116-122 vs 130 us (no gain on the K >= 1152 layers)
         if (ctWide == 8 && (a.Cin <= 64 || wideOn == 6)) {
-            const int n8 = cdiv(a.Ho, 8) * tilesX * nchunk, grid = n8 < 2 * numCUs() ? n8 : 2 * numCUs();
+            const int n8 = cdiv(a.Ho, 8) * tilesX * nchunk, grid = balancedGrid(n8, 2 * numCUs());
             hipLaunchKernelGGL((conv_wide_kernel<8, 4, 36, 2, 2>), dim3(grid), dim3(256), 0, stream, a, Wp, zeros, tilesX, n8, nchunk, dbgW);
             return lastError();
         }
         if (nwide >= numCUs() && wideOn != 4) {
-            const int grid = numCUs();
+            const int grid = balancedGrid(nwide, numCUs());
             // Item rounds (round-2 experiment, DSVT_CONV_WIDE=12).  Persistent workgroups (one per CU) walk the items: the 468 x 468 layers are
             // 30 x 15 = 450 items of 16 rows = TWO rounds on 256 CUs with the second a quarter empty; as 14-row items on seven waves they
             // are 34 x 15 = 510 = two FULL rounds of 14 rows, 28 row-units instead of 32.  Measured: no gain (convolutions 1.211 vs 1.199 ms
@@ -879,7 +892,7 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
                 hipLaunchKernelGGL((conv_wide_kernel<4, 8, 40, 4, 2>), dim3(n16), dim3(512), 0, stream, a, Wp, zeros, tilesX, n16, nch64, dbgW);
                 return lastError();
             }
-            const int grid = nsmall < 2 * numCUs() ? nsmall : 2 * numCUs();
+            const int grid = balancedGrid(nsmall, 2 * numCUs());
             // 8 rows x 32 pixels x 64 channels: eight waves of ONE row each (117x117x256: 31.4 us; four waves of two rows: 35.6 us --
             // one wave per SIMD cannot hide its own LDS-DMA issue and wait time)
             if (wideOn == 9) hipLaunchKernelGGL((conv_wide_kernel<4, 4, 36, 4, 2>), dim3(grid), dim3(256), 0, stream, a, Wp, zeros, tilesX, nsmall, nch64, dbgW);
@@ -895,7 +908,7 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
     static int hb1 = -1;           // 4-row tiles run as two single-halo-buffer workgroups per CU (DSVT_CONV_HB1=0: one double-buffered)
     if (hb1 < 0) { const char* e = getenv("DSVT_CONV_HB1"); hb1 = e ? atoi(e) : 1; }
     const int slots = (th == 4 && hb1) ? 2 * numCUs() : numCUs();
-    int grid = nitems < slots ? nitems : slots;
+    int grid = balancedGrid(nitems, slots);
     if (gridCap > 0 && grid > gridCap) grid = gridCap;
 #define DSVT_HALO_LAUNCH(TH_, KS_, CTW_, HB_) hipLaunchKernelGGL((conv_halo_kernel<TH_, KS_, CTW_, HB_>), dim3(grid), dim3(64 * TH_), 0, stream, a, Wp, zeros, tilesX, nitems, nchunk, dbg)
 #define DSVT_HALO_TH(KS_, CTW_) do { if (th == 8) DSVT_HALO_LAUNCH(8, KS_, CTW_, 2); else if (hb1) DSVT_HALO_LAUNCH(4, KS_, CTW_, 1); else DSVT_HALO_LAUNCH(4, KS_, CTW_, 2); } while (0)
