@@ -17,8 +17,12 @@
 //                    inside bin B,) bitonic sort of <= 4096 (key, ~index) pairs in LDS, then the
 //                    first K are decoded: sigmoid, cell -> (xs, ys), gathers, exp, atan.
 // Order of the K rows: descending score, ties by ascending class * H*W + cell (the reference's TopK
-// leaves ties unspecified).  More than 4096 candidates sharing the top 24 key bits (a degenerate
-// heat map) are truncated in arrival order.
+// leaves ties unspecified).  The candidate lists are filled in atomic arrival order, which is harmless while
+// everything fits (the sort key carries the index); a degenerate heat map -- a constant one, e.g. an empty frame
+// whose head output is its bias -- can put more elements into the threshold bin than the lists hold.  topk_decode
+// then falls back to an EXACT selection (exactSelect: radix select on the 32 key bits, then on the index among the
+// elements equal to the threshold key, five passes of one workgroup over the heat map), so the K rows and their
+// order are the rule above on every input, run to run.
 #include "plugin_base.h"
 #include "device_utils.h"
 
@@ -93,7 +97,7 @@ topk_collect(const float* __restrict__ head, TopKParams p, const uint32_t* __res
     __shared__ uint32_t sh[258];
     uint32_t above;
     const uint32_t B = (uint32_t)thresholdBin(hist, p.K, sh, &above);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { count[2] = above; }     // for topk_decode's second level
+    if (blockIdx.x == 0 && threadIdx.x == 0) { count[2] = above; count[4] = B; }     // for topk_decode's second level / exact fallback
     const int HW = p.H * p.W;
     for (int px = blockIdx.x * 256 + threadIdx.x; px < HW; px += gridDim.x * 256) {
         const float* row = head + (size_t)px * p.C + p.off_hm;
@@ -111,6 +115,69 @@ topk_collect(const float* __restrict__ head, TopKParams p, const uint32_t* __res
     }
 }
 
+// Exact top-K of a heat map whose threshold bin does not fit the candidate lists (one 1024-thread workgroup).  B1 = threshold bin of the
+// key's top 12 bits, above1 = elements in higher bins (both from topk_collect).  Fills sk[0 .. K) with (key << 32) | ~index of exactly
+// the K largest elements by (key descending, index ascending); returns nothing the caller does not already know (K).
+__device__ void exactSelect(const float* __restrict__ head, const TopKParams& p, uint32_t B1, uint32_t above1, unsigned long long* sk,
+                            uint32_t* sub /* TK_BINS */, uint32_t* sh /* 4 */, uint32_t* nsel)
+{
+    const int t = threadIdx.x, HW = p.H * p.W;
+    auto clearSub = [&]() { for (int i = t; i < TK_BINS; i += 1024) sub[i] = 0; __syncthreads(); };
+    // suffix walk: largest bin b with count(bins >= b) >= need; sh[0] = b, sh[1] = count(bins > b)
+    auto suffixBin = [&](int nbins, uint32_t need) {
+        __syncthreads();
+        if (t == 0) {
+            uint32_t run = 0; int b = 0; uint32_t ab = 0;
+            for (int i = nbins - 1; i >= 0; --i) { if (run + sub[i] >= need) { b = i; ab = run; break; } run += sub[i]; }
+            sh[0] = (uint32_t)b; sh[1] = ab;
+        }
+        __syncthreads();
+    };
+    // prefix walk: smallest bin b with count(bins <= b) >= need; sh[0] = b, sh[1] = count(bins < b)
+    auto prefixBin = [&](int nbins, uint32_t need) {
+        __syncthreads();
+        if (t == 0) {
+            uint32_t run = 0; int b = nbins - 1; uint32_t bl = 0;
+            for (int i = 0; i < nbins; ++i) { if (run + sub[i] >= need) { b = i; bl = run; break; } run += sub[i]; }
+            sh[0] = (uint32_t)b; sh[1] = bl;
+        }
+        __syncthreads();
+    };
+    auto forAll = [&](auto&& fn) {
+        for (int px = t; px < HW; px += 1024) {
+            const float* row = head + (size_t)px * p.C + p.off_hm;
+            for (int c = 0; c < p.ncls; ++c) fn(floatKey(row[c]), (uint32_t)(c * HW + px));
+        }
+    };
+    uint32_t need = (uint32_t)p.K - above1;                       // wanted from bin B1 (>= 1)
+    clearSub();
+    forAll([&](uint32_t key, uint32_t) { if ((key >> 20) == B1) atomicAdd(&sub[(key >> 8) & 0xfffu], 1u); });
+    suffixBin(TK_BINS, need);
+    const uint32_t B2 = sh[0]; need -= sh[1];
+    clearSub();
+    forAll([&](uint32_t key, uint32_t) { if ((key >> 8) == ((B1 << 12) | B2)) atomicAdd(&sub[key & 0xffu], 1u); });
+    suffixBin(256, need);
+    const uint32_t T = (B1 << 20) | (B2 << 8) | sh[0]; need -= sh[1];      // the threshold key; `need` elements equal to it are wanted
+    clearSub();
+    forAll([&](uint32_t key, uint32_t idx) { if (key == T) atomicAdd(&sub[idx >> 11], 1u); });       // index < 2^22 (tkNew bounds it)
+    prefixBin(TK_BINS, need);
+    const uint32_t I1 = sh[0]; need -= sh[1];
+    clearSub();
+    forAll([&](uint32_t key, uint32_t idx) { if (key == T && (idx >> 11) == I1) atomicAdd(&sub[idx & 0x7ffu], 1u); });
+    prefixBin(2048, need);
+    const uint32_t X = (I1 << 11) | sh[0];                         // elements equal to T are taken up to index X
+    for (int i = t; i < TK_SORT; i += 1024) sk[i] = 0ull;
+    if (t == 0) *nsel = 0;
+    __syncthreads();
+    forAll([&](uint32_t key, uint32_t idx) {
+        if (key > T || (key == T && idx <= X)) {
+            const uint32_t slot = atomicAdd(nsel, 1u);
+            if (slot < TK_SORT) sk[slot] = ((unsigned long long)key << 32) | (uint32_t)~idx;
+        }
+    });
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(1024)
 topk_decode(const float* __restrict__ head, TopKParams p, const uint32_t* __restrict__ count,
             const uint2* __restrict__ cand, float* __restrict__ scores, int32_t* __restrict__ classes, int32_t* __restrict__ xs,
@@ -123,6 +190,7 @@ topk_decode(const float* __restrict__ head, TopKParams p, const uint32_t* __rest
     __shared__ uint32_t nsel;
     const int t = threadIdx.x;
     uint32_t Ma = count[3], Me = count[0];           // elements above the threshold bin (< K) / inside it
+    const bool listOverflow = Me > TK_CAP - TK_SORT || Ma > TK_SORT;      // the arrival-ordered lists dropped elements: exact path below
     if (Ma > TK_SORT) Ma = TK_SORT;
     if (Me > TK_CAP - TK_SORT) Me = TK_CAP - TK_SORT;
     for (int i = t; i < TK_SORT; i += 1024) sk[i] = 0ull;
@@ -155,8 +223,11 @@ topk_decode(const float* __restrict__ head, TopKParams p, const uint32_t* __rest
         }
     }
     __syncthreads();
+    // more candidates than the sort holds share the top 24 key bits, or the lists themselves overflowed: the degenerate case
+    bool exact = listOverflow || (Ma + Me > TK_SORT && nsel > TK_SORT);
+    if (exact) exactSelect(head, p, count[4], count[2], sk, sub, sh, &nsel);
     // bitonic sort, descending, of the smallest power of two >= the number of candidates (the rest of sk is zero = lowest)
-    uint32_t tot = (Ma + Me <= TK_SORT) ? Ma + Me : (nsel < TK_SORT ? nsel : TK_SORT);
+    uint32_t tot = exact ? (uint32_t)p.K : (Ma + Me <= TK_SORT) ? Ma + Me : (nsel < TK_SORT ? nsel : TK_SORT);
     int NS = 512;
     while (NS < (int)tot) NS <<= 1;
     for (int k = 2; k <= NS; k <<= 1)
@@ -243,7 +314,7 @@ public:
 };
 static Plugin* tkNew(const TopKParams& p) {
     if (p.H <= 0 || p.W <= 0 || p.C <= 0 || p.ncls <= 0 || p.K <= 0 || p.K > TK_SORT) return nullptr;
-    if ((long)p.H * p.W * p.ncls >= (1l << 32)) return nullptr;
+    if ((long)p.H * p.W * p.ncls >= (1l << 22)) return nullptr;        // the exact fallback selects on 22 index bits
     const int offs[5] = {p.off_center + 1, p.off_z, p.off_dim + 2, p.off_rot + 1, p.off_hm + p.ncls - 1};
     for (int o : offs) if (o < 0 || o >= p.C) return nullptr;
     return new CenterHeadTopKPlugin(p);

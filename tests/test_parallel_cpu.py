@@ -107,3 +107,16 @@ def test_shard_frames_partition():
             assert sorted(sum(parts, [])) == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
     assert par.ROW == 4501
+
+
+def test_bench_launcher_fails_loudly_without_gpus():
+    """`python bench.py --gpus N` launches its own ranks; where fewer than N GPUs are visible (none in the build container) it must exit non-zero
+    with a message and print no JSON line (never an `n_gpus` that is not the number of ranks that ran)"""
+    import subprocess, sys
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("needs a host with fewer than two GPUs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "visible" in (r.stdout + r.stderr) and "n_gpus" not in r.stdout
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout          # WORLD_SIZE disagrees with --gpus (or no GPU at all): refused either way

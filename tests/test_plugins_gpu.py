@@ -421,6 +421,38 @@ def test_center_head_topk_degenerate_heat_map(pkg):
     assert (sc[0, :3].cpu() - exp[:3]).abs().max() < 1e-6 and (sc[0, 3:].cpu() - exp[3]).abs().max() < 1e-6
     assert cls[0, :3].tolist() == [3, 9, 0]
     assert (ys[0, :3] * W + xs[0, :3]).tolist() == [7, 39999, 123]
+    # the 497 ties: ascending class * H*W + cell = class 0, cells 0 .. 497 without cell 123 (its class-0 logit is one of the picks)
+    assert cls[0, 3:].tolist() == [0] * 497
+    assert (ys[0, 3:] * W + xs[0, 3:]).tolist() == [c for c in range(498) if c != 123]
+
+
+@pytest.mark.parametrize("case", ["constant", "per_class_constant", "two_levels"])
+def test_center_head_topk_exact_selection_on_degenerate_maps(pkg, case):
+    """Heat maps whose threshold bin overflows the candidate lists (constant logits: an empty frame's head output is its bias) take the
+    exact fallback: K rows in descending score, ties in ascending class * H*W + cell order -- deterministically, run to run, equal to a
+    stable sort of all class x cell scores."""
+    P = pkg.plugin
+    H = W = 468
+    g = torch.Generator().manual_seed(3)
+    o = torch.zeros(1, H, W, 18)
+    if case == "constant":
+        o[..., 8:18] = -1.25
+    elif case == "per_class_constant":
+        o[..., 8:18] = torch.linspace(-2.1, -1.5, 10)
+    else:           # 70000 cells of class 4 share the largest value bit for bit, everything else is lower but in the same 12-bit bin
+        o[..., 8:18] = -1.52
+        cells = torch.randperm(H * W, generator=g)[:70000]
+        o.reshape(-1, 18)[cells, 8 + 4] = -1.5
+    o = o.to("cuda:0")
+    op = P.add_center_head_topk_op(H, W, 18, 10, 500)
+    a = [t.clone() for t in op(o)[:4]]
+    b = [t.clone() for t in op(o)[:4]]
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    logits = o.reshape(-1, 18)[:, 8:18].t().reshape(-1).cpu()                  # index = class * H*W + cell
+    order = torch.sort(logits, descending=True, stable=True).indices[:500]
+    assert (a[1][0].cpu().long() * H * W + a[3][0].cpu().long() * W + a[2][0].cpu().long()).tolist() == order.tolist()
+    assert (a[0][0].cpu() - torch.sigmoid(logits[order])).abs().max() < 1e-6
 
 
 def _nms_boxes(rng, n, spread):
