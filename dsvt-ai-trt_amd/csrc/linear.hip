@@ -585,8 +585,11 @@ linear_f16_rows_kernel(LinearArgs a, const _Float16* __restrict__ Wp, int ncu)
     __shared__ __attribute__((aligned(16))) unsigned char ring[4 * SBYTES + 4096];   // four weight stages + the bias (<= 1024 floats): one workgroup per CU
     const int M = rowLimit(a);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
-    const int need = (M + 16 * ncu - 1) / (16 * ncu);
-    const int nwa = need <= 8 ? 8 : need <= RW_NW ? need : 8;        // beyond 160 rows per CU: eight-wave workgroups in rounds
+    int need = (M + 16 * ncu - 1) / (16 * ncu);
+    // beyond 160 rows per CU the workgroups run in rounds (151 KB of LDS: one per CU); sized for TWO full rounds when that suffices
+    // (69k rows: 480 workgroups of nine waves = 2 rounds, not 540 of eight = 3)
+    if (need > RW_NW) need = (M + 32 * ncu - 1) / (32 * ncu);
+    const int nwa = need <= 8 ? 8 : need <= RW_NW ? need : 8;
     if (wave >= nwa) return;
     const int m0 = blockIdx.x * 16 * nwa;
     if (m0 >= M) return;

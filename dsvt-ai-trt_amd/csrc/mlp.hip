@@ -178,6 +178,10 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
     bool small = false;
     if (ELASTIC) {
         int need = (M + 16 * a.ncu - 1) / (16 * a.ncu);
+        // beyond ten live waves per CU (two frames per launch: ~270 rows per CU): TWO workgroups per CU (78.8 KB of LDS each), sized so
+        // that one round of 2 x ncu workgroups still covers the rows -- 69k rows = 480 workgroups of nine waves, not 540 of eight (a
+        // second round for 28 workgroups)
+        if (need > NW && RS == 3) need = (M + 32 * a.ncu - 1) / (32 * a.ncu);
         nwa = need <= 8 ? 8 : need <= NW ? need : 8;
         if (a.dbg & 32) nwa = 8;
         if (wave >= nwa) return;

@@ -497,7 +497,7 @@ static Registrar g_gsReg(&g_gsCreator);
 // attention / QKV ops consume.  Same reference lines as above: windowPartition.cu:278-470, getSet.cu:267-704.
 // =====================================================================================
 constexpr int kMaxCfg = 4;
-struct SPParams { int K, max_set_num, voxel_num_set, max_pillars; WPParams wp[kMaxCfg]; int dense_off[kMaxCfg + 1]; };
+struct SPParams { int K, max_set_num, voxel_num_set, max_pillars; WPParams wp[kMaxCfg]; int dense_off[kMaxCfg + 1]; int frames; };       // frames: coords.x = frame index < frames (Points2Features "frames")
 // the output tensors of one enqueue, passed by value as a kernel argument (no device-side pointer table that could go stale)
 struct SPOuts { uint32_t* c2d[kMaxCfg]; uint32_t* inds[kMaxCfg]; float* mask[kMaxCfg]; uint32_t* snum[kMaxCfg]; };
 
@@ -512,7 +512,13 @@ sp_count(const uint4* __restrict__ coords, const uint32_t* __restrict__ voxel_nu
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     uint32_t win = kNoneU, ix, iy, iz;
-    if (v < n) { winOf(coords[v], p, win, ix, iy, iz); vox_win[v] = win; }
+    if (v < n) {
+        const uint4 co = coords[v];
+        winOf(co, p, win, ix, iy, iz);
+        // several frames per call: the frame index (coords.x) is the slowest window coordinate
+        if (win != kNoneU) win = co.x < (uint32_t)sp.frames ? win + co.x * (uint32_t)(p.nwx * p.nwy * p.nwz) : kNoneU;
+        vox_win[v] = win;
+    }
     const uint32_t prev = __shfl_up(win, 1, kWave);                   // one atomic per run of equal windows (see wp_count)
     const bool head = lane == 0 || prev != win;
     const unsigned long long heads = __ballot(head);
@@ -777,7 +783,7 @@ public:
     void serialize(void* b) const override {
         char* d = static_cast<char*>(b);
         wr<int>(d, sp_.K); wr<int>(d, sp_.max_set_num); wr<int>(d, sp_.voxel_num_set); wr<int>(d, sp_.max_pillars);
-        wr<int>(d, sp_.wp[0].max_win_num); wr<int>(d, sp_.wp[0].max_voxel_num_per_win); wr<int>(d, sp_.wp[0].sx);
+        wr<int>(d, sp_.wp[0].max_win_num); wr<int>(d, sp_.wp[0].max_voxel_num_per_win); wr<int>(d, sp_.frames);
         for (int k = 0; k < sp_.K; ++k) {
             const WPParams& p = sp_.wp[k];
             wr<int>(d, p.sx); wr<int>(d, p.sy); wr<int>(d, p.sz); wr<int>(d, p.wx); wr<int>(d, p.wy); wr<int>(d, p.wz); wr<int>(d, p.hx); wr<int>(d, p.hy); wr<int>(d, p.hz);
@@ -785,9 +791,9 @@ public:
     }
     Plugin* clone() const override { return new DsvtSetPartitionPlugin(sp_); }
 };
-static Plugin* spNew(int K, int mw, int vw, int L, int ms, int mp, const int* shape, const int* wins, const int* shifts) {
-    if (K < 1 || K > kMaxCfg || mw <= 0 || vw <= 0 || L <= 0 || mp <= 0) return nullptr;
-    SPParams sp{}; sp.K = K; sp.max_set_num = ms > 0 ? ms : mw; sp.voxel_num_set = L; sp.max_pillars = mp;
+static Plugin* spNew(int K, int mw, int vw, int L, int ms, int mp, const int* shape, const int* wins, const int* shifts, int frames = 1) {
+    if (K < 1 || K > kMaxCfg || mw <= 0 || vw <= 0 || L <= 0 || mp <= 0 || frames < 1 || frames > 64) return nullptr;
+    SPParams sp{}; sp.K = K; sp.max_set_num = ms > 0 ? ms : mw; sp.voxel_num_set = L; sp.max_pillars = mp; sp.frames = frames;
     for (int k = 0; k < K; ++k) {
         WPParams& p = sp.wp[k];
         p.max_win_num = mw; p.max_voxel_num_per_win = vw; p.sx = shape[0]; p.sy = shape[1]; p.sz = shape[2];
@@ -795,7 +801,7 @@ static Plugin* spNew(int K, int mw, int vw, int L, int ms, int mp, const int* sh
         if (p.wx <= 0 || p.wy <= 0 || p.wz <= 0 || p.sx <= 0 || p.sy <= 0 || p.sz <= 0 || p.hx < 0 || p.hy < 0 || p.hz < 0) return nullptr;
         if ((long)p.wx * p.wy * p.wz > 8192) return nullptr;
         p.nwx = (int)(ceilf((float)(p.sx / p.wx)) + 1); p.nwy = (int)(ceilf((float)(p.sy / p.wy)) + 1); p.nwz = (int)(ceilf((float)(p.sz / p.wz)) + 1);   // windowPartition.cu:425-427
-        sp.dense_off[k + 1] = sp.dense_off[k] + p.nwx * p.nwy * p.nwz;
+        sp.dense_off[k + 1] = sp.dense_off[k] + p.nwx * p.nwy * p.nwz * frames;
     }
     return new DsvtSetPartitionPlugin(sp);
 }
@@ -805,12 +811,12 @@ static Plugin* spCreate(const DsvtPluginFieldCollection* fc) {
     int shape[3], wins[3 * kMaxCfg], shifts[3 * kMaxCfg];
     fieldInts(fc, "sparse_shape", shape, 3); fieldInts(fc, "win_shapes", wins, 3 * K); fieldInts(fc, "shift_lists", shifts, 3 * K);
     return spNew(K, fieldInt(fc, "max_win_num"), fieldInt(fc, "max_voxel_num_per_win"), fieldInt(fc, "voxel_num_set"), fieldInt(fc, "max_set_num", 0),
-                 fieldInt(fc, "max_pillars_num"), shape, wins, shifts);
+                 fieldInt(fc, "max_pillars_num"), shape, wins, shifts, fieldInt(fc, "frames", 1));
 }
 static Plugin* spDeser(const void* data, size_t len) {
     if (len < 7 * sizeof(int)) return nullptr;
     const char* d = static_cast<const char*>(data);
-    const int K = rd<int>(d), ms = rd<int>(d), L = rd<int>(d), mp = rd<int>(d), mw = rd<int>(d), vw = rd<int>(d); (void)rd<int>(d);
+    const int K = rd<int>(d), ms = rd<int>(d), L = rd<int>(d), mp = rd<int>(d), mw = rd<int>(d), vw = rd<int>(d), frames = rd<int>(d);
     if (K < 1 || K > kMaxCfg || len < sizeof(int) * (7 + 9 * (size_t)K)) return nullptr;
     int shape[3] = {0, 0, 0}, wins[3 * kMaxCfg], shifts[3 * kMaxCfg];
     for (int k = 0; k < K; ++k) {
@@ -818,12 +824,12 @@ static Plugin* spDeser(const void* data, size_t len) {
         for (int e = 0; e < 3; ++e) wins[3 * k + e] = rd<int>(d);
         for (int e = 0; e < 3; ++e) shifts[3 * k + e] = rd<int>(d);
     }
-    return spNew(K, mw, vw, L, ms, mp, shape, wins, shifts);
+    return spNew(K, mw, vw, L, ms, mp, shape, wins, shifts, frames);
 }
 static Creator g_spCreator{"DsvtSetPartitionPlugin",
     {{"max_win_num", DSVT_FIELD_INT32}, {"max_voxel_num_per_win", DSVT_FIELD_INT32}, {"voxel_num_set", DSVT_FIELD_INT32},
      {"max_set_num", DSVT_FIELD_INT32}, {"max_pillars_num", DSVT_FIELD_INT32}, {"sparse_shape", DSVT_FIELD_INT32},
-     {"num_configs", DSVT_FIELD_INT32}, {"win_shapes", DSVT_FIELD_INT32}, {"shift_lists", DSVT_FIELD_INT32}},
+     {"num_configs", DSVT_FIELD_INT32}, {"win_shapes", DSVT_FIELD_INT32}, {"shift_lists", DSVT_FIELD_INT32}, {"frames", DSVT_FIELD_INT32}},
     spCreate, spDeser, {}, {}};
 static Registrar g_spReg(&g_spCreator);
 

@@ -410,24 +410,25 @@ static Registrar g_geReg(&g_geCreator);
 // =====================================================================================
 __global__ void __launch_bounds__(256)
 map2bev_kernel(const float4* __restrict__ feat, const uint4* __restrict__ coords, const uint32_t* __restrict__ voxel_num,
-               int G, int gx, float4* __restrict__ bev)
+               int G, int gx, int gy, int frames, float4* __restrict__ bev)
 {
     size_t total = (size_t)(*voxel_num) * G;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         size_t p = i / G; int c = (int)(i % G);
         uint4 co = coords[p];                                                        // map2bev.cu:259-261: y = .z, x = .w
-        bev[((size_t)co.z * gx + co.w) * G + c] = feat[i];                           // :264
+        if (co.x >= (uint32_t)frames) continue;                                      // (.x = frame index of a multi-frame voxelizer, 0 otherwise)
+        bev[(((size_t)co.x * gy + co.z) * gx + co.w) * G + c] = feat[i];             // :264
     }
 }
 class Map2BevPlugin : public Plugin {
 public:
-    int max_pillars_num_, channel_num_, gx_, gy_;
-    Map2BevPlugin(int mp, int c, int gx, int gy) : max_pillars_num_(mp), channel_num_(c), gx_(gx), gy_(gy) {}
+    int max_pillars_num_, channel_num_, gx_, gy_, frames_ = 1;      // frames_ > 1 (field "frames"): coords.x selects one of `frames` stacked BEV maps
+    Map2BevPlugin(int mp, int c, int gx, int gy, int frames = 1) : max_pillars_num_(mp), channel_num_(c), gx_(gx), gy_(gy), frames_(frames) {}
     const char* type() const override { return "Map2BevPlugin"; }
     int nbOutputs() const override { return 1; }
     int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
         if (i != 0) return -1;
-        *out = dims4(in[0].d[0], gx_, gy_, channel_num_); return 0;                  // map2bev.cu: [1, gx, gy, C] (used as [y][x][C])
+        *out = dims4(frames_ > 1 ? frames_ : in[0].d[0], gx_, gy_, channel_num_); return 0;      // map2bev.cu: [1, gx, gy, C] (used as [y][x][C])
     }
     int outputType(int, const int32_t* t, int) const override { return t[0]; }
     bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int, int) const override {
@@ -442,24 +443,29 @@ public:
         const int esz = (inDesc && inDesc[0].type == DSVT_HALF) ? 2 : 4;
         if ((channel_num_ * esz) % 16 != 0) return -3;
         // the dense map must be zero wherever no pillar lands, so this fill is not optional (:303)
-        DSVT_CHECK(hipMemsetAsync(out[0], 0, (size_t)esz * gx_ * gy_ * channel_num_, stream));
+        DSVT_CHECK(hipMemsetAsync(out[0], 0, (size_t)esz * gx_ * gy_ * channel_num_ * frames_, stream));
         hipLaunchKernelGGL(map2bev_kernel, dim3(2048), dim3(256), 0, stream, static_cast<const float4*>(in[0]),
-                           static_cast<const uint4*>(in[1]), static_cast<const uint32_t*>(in[2]), channel_num_ * esz / 16, gx_,
+                           static_cast<const uint4*>(in[1]), static_cast<const uint32_t*>(in[2]), channel_num_ * esz / 16, gx_, gy_, frames_,
                            static_cast<float4*>(out[0]));
         return lastError();
     }
-    size_t serializationSize() const override { return 4 * sizeof(int); }
-    void serialize(void* b) const override { char* d = static_cast<char*>(b); wr<int>(d, max_pillars_num_); wr<int>(d, channel_num_); wr<int>(d, gx_); wr<int>(d, gy_); }
-    Plugin* clone() const override { return new Map2BevPlugin(max_pillars_num_, channel_num_, gx_, gy_); }
+    size_t serializationSize() const override { return (frames_ > 1 ? 5 : 4) * sizeof(int); }
+    void serialize(void* b) const override {
+        char* d = static_cast<char*>(b); wr<int>(d, max_pillars_num_); wr<int>(d, channel_num_); wr<int>(d, gx_); wr<int>(d, gy_);
+        if (frames_ > 1) wr<int>(d, frames_);
+    }
+    Plugin* clone() const override { return new Map2BevPlugin(max_pillars_num_, channel_num_, gx_, gy_, frames_); }
 };
-static Plugin* mbNew(int mp, int c, int gx, int gy) { return (mp > 0 && c > 0 && c % 4 == 0 && gx > 0 && gy > 0) ? new Map2BevPlugin(mp, c, gx, gy) : nullptr; }
+static Plugin* mbNew(int mp, int c, int gx, int gy, int frames = 1) {
+    return (mp > 0 && c > 0 && c % 4 == 0 && gx > 0 && gy > 0 && frames >= 1) ? new Map2BevPlugin(mp, c, gx, gy, frames) : nullptr;
+}
 static Plugin* mbCreate(const DsvtPluginFieldCollection* fc) {
-    return mbNew(fieldInt(fc, "max_pillars_num"), fieldInt(fc, "channel_num"), fieldInt(fc, "grid_size_x"), fieldInt(fc, "grid_size_y"));
+    return mbNew(fieldInt(fc, "max_pillars_num"), fieldInt(fc, "channel_num"), fieldInt(fc, "grid_size_x"), fieldInt(fc, "grid_size_y"), fieldInt(fc, "frames", 1));
 }
 static Plugin* mbDeser(const void* data, size_t len) {
     if (len < 4 * sizeof(int)) return nullptr;
     const char* d = static_cast<const char*>(data); int mp = rd<int>(d), c = rd<int>(d), gx = rd<int>(d), gy = rd<int>(d);
-    return mbNew(mp, c, gx, gy);
+    return mbNew(mp, c, gx, gy, len >= 5 * sizeof(int) ? rd<int>(d) : 1);
 }
 static Creator g_mbCreator{"Map2BevPlugin",
     {{"max_pillars_num", DSVT_FIELD_INT32}, {"channel_num", DSVT_FIELD_INT32}, {"grid_size_x", DSVT_FIELD_INT32}, {"grid_size_y", DSVT_FIELD_INT32}},

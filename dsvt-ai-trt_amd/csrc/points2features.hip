@@ -31,6 +31,7 @@ struct P2FParams {
     float min_x, max_x, min_y, max_y, min_z, max_z;
     float vx, vy, vz;
     int gx, gy, gz;
+    int frames;       // >= 1: the points tensor holds `frames` slabs of max_points_num rows with one count each (see the plugin class)
 };
 
 constexpr uint32_t kNone = 0xffffffffu;
@@ -40,10 +41,12 @@ __global__ void __launch_bounds__(256)
 p2f_count(const float4* __restrict__ pts, const uint32_t* __restrict__ n_ptr, P2FParams p,
           uint32_t* __restrict__ cell_cnt, uint32_t* __restrict__ pt_cell, uint32_t* __restrict__ pt_slot)
 {
-    uint32_t n = *n_ptr;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t fr = i / (uint32_t)p.max_points_num;           // frame of this row (0 when frames == 1)
+    if (fr >= (uint32_t)p.frames) return;
+    uint32_t n = n_ptr[fr];
     if (n > (uint32_t)p.max_points_num) n = p.max_points_num;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i - fr * (uint32_t)p.max_points_num >= n) return;
     float4 q = pts[i];
     uint32_t cell = kNone, slot = 0;
     if (!(q.x < p.min_x || q.x >= p.max_x || q.y < p.min_y || q.y >= p.max_y ||
@@ -59,7 +62,7 @@ p2f_count(const float4* __restrict__ pts, const uint32_t* __restrict__ n_ptr, P2
             c = (uint32_t)((iz * p.gy + iy) * p.gx + ix);
         }
         if (c < (uint32_t)(p.gx * p.gy * p.gz)) {
-            cell = c;
+            cell = c + fr * (uint32_t)(p.gx * p.gy * p.gz);       // frames are one more (slowest) grid dimension: pillars ascend by (frame, cell)
             slot = atomicAdd(&cell_cnt[cell], 1u);                // count only; order fixed later
         }
     }
@@ -158,8 +161,9 @@ p2f_scan(const uint32_t* __restrict__ cell_cnt, int ncell, P2FParams p, uint64_t
                 if (valid) {
                     pil_seg[eo] = ef; pil_full[eo] = f[j]; pil_ptoff[eo] = ek;
                     pcnt[eo] = k[j];                                              // :753
-                    const uint32_t cz = (uint32_t)cell / gxy, cyx = (uint32_t)cell % gxy;
-                    reinterpret_cast<uint4*>(coords)[eo] = make_uint4(0u, cz, cyx / (uint32_t)p.gx, cyx % (uint32_t)p.gx);       // :755-756 (z = 0 there)
+                    const uint32_t gxyz = gxy * (uint32_t)p.gz, fr = (uint32_t)cell / gxyz, cf = (uint32_t)cell % gxyz;
+                    const uint32_t cz = cf / gxy, cyx = cf % gxy;
+                    reinterpret_cast<uint4*>(coords)[eo] = make_uint4(fr, cz, cyx / (uint32_t)p.gx, cyx % (uint32_t)p.gx);       // :755-756 (batch = z = 0 there)
                 } else if (eo == 0 || (eo - 1 < maxP && ek <= maxN)) {
                     *pillar_num = eo; *point_num = ek;                              // the FIRST pillar that does not fit: P and Nk are its offsets
                 }
@@ -172,13 +176,15 @@ p2f_scan(const uint32_t* __restrict__ cell_cnt, int ncell, P2FParams p, uint64_t
 }
 
 __global__ void __launch_bounds__(256)
-p2f_scatter(const uint32_t* __restrict__ n_ptr, int max_points, const uint32_t* __restrict__ pt_cell,
+p2f_scatter(const uint32_t* __restrict__ n_ptr, int max_points, int frames, const uint32_t* __restrict__ pt_cell,
             const uint32_t* __restrict__ pt_slot, const uint32_t* __restrict__ cell_seg, uint32_t* __restrict__ sorted_idx)
 {
-    uint32_t n = *n_ptr;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t fr = i / (uint32_t)max_points;
+    if (fr >= (uint32_t)frames) return;
+    uint32_t n = n_ptr[fr];
     if (n > (uint32_t)max_points) n = max_points;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i - fr * (uint32_t)max_points >= n) return;
     uint32_t cell = pt_cell[i];
     if (cell == kNone) return;
     sorted_idx[cell_seg[cell] + pt_slot[i]] = i;
@@ -337,6 +343,11 @@ p2f_pillar(const float4* __restrict__ pts, P2FParams p, const uint32_t* __restri
     if (sl < (int)kept) p2fWriteFeat(feat + (size_t)(ptoff + sl) * p.feature_num, q, cx, cy, cz, p);
 }
 
+// frames > 1 (optional field "frames", not in the reference): SEVERAL frames per enqueue with their rows CONCATENATED -- the layout the
+// fused backbone ops want (rows = sum of the frames' pillars, one launch per layer for all of them), unlike the per-frame slabs a batched
+// enqueue of the C ABI gives.  Input 0 is [1, frames * max_points_num, 4] (frame f owns rows f * max_points_num ...), input 1 holds
+// `frames` counts; the frame index is one more, slowest, grid dimension: pillars ascend by (frame, cell), coords = (frame, z, y, x) -- the
+// batch slot the reference's coordinate layout already has (:755) -- and max_pillars_num / max_points_num_voxel_filter bound the totals.
 class Points2FeaturesPlugin : public Plugin {
 public:
     P2FParams p_;
@@ -360,7 +371,8 @@ public:
         if (pos == 0 || pos == 2) return io[pos].type == DSVT_FLOAT;
         return pos >= 1 && pos <= 7 && io[pos].type == DSVT_INT32;
     }
-    int ncell() const { return p_.gx * p_.gy * p_.gz; }
+    int ncell() const { return p_.gx * p_.gy * p_.gz * p_.frames; }
+    int rowsAll() const { return p_.max_points_num * p_.frames; }
     // cell histogram followed by the scan's ticket + tile states (one memset covers both); 16-byte aligned rows
     size_t cntWords() const { return ((size_t)ncell() + 3) / 4 * 4; }
     size_t headBytes() const { return sizeof(uint32_t) * cntWords() + sizeof(uint64_t) * (1 + (size_t)ntiles()); }
@@ -368,7 +380,7 @@ public:
     size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override {
         size_t s = 0;
         s += alignUp(headBytes()) + alignUp(sizeof(uint32_t) * ncell());   // cell_cnt + scan state, cell_seg
-        s += 3 * alignUp(sizeof(uint32_t) * p_.max_points_num);       // pt_cell, pt_slot, sorted_idx
+        s += 3 * alignUp(sizeof(uint32_t) * rowsAll());               // pt_cell, pt_slot, sorted_idx
         s += 3 * alignUp(sizeof(uint32_t) * p_.max_pillars_num);      // pil_seg, pil_full, pil_ptoff
         return s;                                                     // ~4.6 MB at 180k caps (reference: 176.8 MB, :262-277)
     }
@@ -388,9 +400,9 @@ public:
         uint32_t* cell_cnt = reinterpret_cast<uint32_t*>(head);
         uint64_t* scan_state = reinterpret_cast<uint64_t*>(head + sizeof(uint32_t) * cntWords());
         uint32_t* cell_seg = ws.take<uint32_t>(ncell());
-        uint32_t* pt_cell = ws.take<uint32_t>(p_.max_points_num);
-        uint32_t* pt_slot = ws.take<uint32_t>(p_.max_points_num);
-        uint32_t* sorted_idx = ws.take<uint32_t>(p_.max_points_num);
+        uint32_t* pt_cell = ws.take<uint32_t>(rowsAll());
+        uint32_t* pt_slot = ws.take<uint32_t>(rowsAll());
+        uint32_t* sorted_idx = ws.take<uint32_t>(rowsAll());
         uint32_t* pil_seg = ws.take<uint32_t>(p_.max_pillars_num);
         uint32_t* pil_full = ws.take<uint32_t>(p_.max_pillars_num);
         uint32_t* pil_ptoff = ws.take<uint32_t>(p_.max_pillars_num);
@@ -403,16 +415,17 @@ public:
             DSVT_CHECK(hipMemsetAsync(pcnt, 0, sizeof(uint32_t) * (size_t)p_.max_pillars_num, stream));
         }
         const int nt = ntiles();
-        hipLaunchKernelGGL(p2f_count, dim3(cdiv(p_.max_points_num, 256)), dim3(256), 0, stream, pts, n_ptr, p_, cell_cnt, pt_cell, pt_slot);
+        hipLaunchKernelGGL(p2f_count, dim3(cdiv(rowsAll(), 256)), dim3(256), 0, stream, pts, n_ptr, p_, cell_cnt, pt_cell, pt_slot);
         hipLaunchKernelGGL(p2f_scan, dim3(nt), dim3(256), 0, stream, cell_cnt, ncell(), p_, scan_state, nt, cell_seg,
                            pil_seg, pil_full, pil_ptoff, coords, pcnt, pillar_num, point_num);
-        hipLaunchKernelGGL(p2f_scatter, dim3(cdiv(p_.max_points_num, 256)), dim3(256), 0, stream, n_ptr, p_.max_points_num,
+        hipLaunchKernelGGL(p2f_scatter, dim3(cdiv(rowsAll(), 256)), dim3(256), 0, stream, n_ptr, p_.max_points_num, p_.frames,
                            pt_cell, pt_slot, cell_seg, sorted_idx);
         hipLaunchKernelGGL(p2f_pillar, dim3(cdiv(p_.max_pillars_num, 16)), dim3(256), 0, stream, pts, p_, pillar_num,
                            sorted_idx, pil_seg, pil_full, pil_ptoff, feat, pidx);
         return lastError();
     }
-    size_t serializationSize() const override { return 9 * sizeof(float) + 9 * sizeof(int); }      // :1033-1036
+    // the reference's 18 words (:1033-1036); one more only for a multi-frame plugin
+    size_t serializationSize() const override { return 9 * sizeof(float) + (p_.frames > 1 ? 10 : 9) * sizeof(int); }
     void serialize(void* buffer) const override {                                                  // :1038-1060
         char* d = static_cast<char*>(buffer);
         wr<int>(d, p_.max_points_num); wr<int>(d, p_.max_points_num_voxel_filter); wr<int>(d, p_.max_pillars_num);
@@ -420,6 +433,7 @@ public:
         wr<float>(d, p_.min_x); wr<float>(d, p_.max_x); wr<float>(d, p_.min_y); wr<float>(d, p_.max_y);
         wr<float>(d, p_.min_z); wr<float>(d, p_.max_z); wr<float>(d, p_.vx); wr<float>(d, p_.vy); wr<float>(d, p_.vz);
         wr<int>(d, p_.gx); wr<int>(d, p_.gy); wr<int>(d, p_.gz);
+        if (p_.frames > 1) wr<int>(d, p_.frames);
     }
     Plugin* clone() const override { return new Points2FeaturesPlugin(p_); }
 };
@@ -428,8 +442,8 @@ static bool validP2F(const P2FParams& p) {
     return p.max_points_num > 0 && p.max_points_num_voxel_filter > 0 && p.max_pillars_num > 0 &&
            p.point_feature_num == 4 && p.feature_num == 10 &&
            p.max_num_points_per_voxel > 0 && p.max_num_points_per_voxel <= kWave &&
-           p.gx > 0 && p.gy > 0 && p.gz > 0 && (long)p.gx * p.gy * p.gz < (1l << 30) && p.vx > 0 && p.vy > 0 && p.vz > 0 &&
-           p.max_points_num < (1 << 20);                      // the scan packs (occupied, full, kept) sums into 20 + 21 + 21 bits
+           p.gx > 0 && p.gy > 0 && p.gz > 0 && p.frames >= 1 && (long)p.gx * p.gy * p.gz * p.frames < (1l << 30) && p.vx > 0 && p.vy > 0 && p.vz > 0 &&
+           (long)p.max_points_num * p.frames < (1 << 20);     // the scan packs (occupied, full, kept) sums into 20 + 21 + 21 bits
 }
 
 static Plugin* p2fCreate(const DsvtPluginFieldCollection* fc) {                                    // :1113-1195
@@ -446,6 +460,7 @@ static Plugin* p2fCreate(const DsvtPluginFieldCollection* fc) {                 
     fieldInts(fc, "grid_size", g, 3);
     p.min_x = r[0]; p.max_x = r[3]; p.min_y = r[1]; p.max_y = r[4]; p.min_z = r[2]; p.max_z = r[5];
     p.vx = v[0]; p.vy = v[1]; p.vz = v[2]; p.gx = g[0]; p.gy = g[1]; p.gz = g[2];
+    p.frames = fieldInt(fc, "frames", 1);       // not a reference field: see the class comment
     return validP2F(p) ? new Points2FeaturesPlugin(p) : nullptr;
 }
 static Plugin* p2fDeserialize(const void* data, size_t len) {                                      // ctor :60-84
@@ -457,6 +472,7 @@ static Plugin* p2fDeserialize(const void* data, size_t len) {                   
     p.min_x = rd<float>(d); p.max_x = rd<float>(d); p.min_y = rd<float>(d); p.max_y = rd<float>(d);
     p.min_z = rd<float>(d); p.max_z = rd<float>(d); p.vx = rd<float>(d); p.vy = rd<float>(d); p.vz = rd<float>(d);
     p.gx = rd<int>(d); p.gy = rd<int>(d); p.gz = rd<int>(d);
+    p.frames = len >= 9 * sizeof(float) + 10 * sizeof(int) ? rd<int>(d) : 1;
     return validP2F(p) ? new Points2FeaturesPlugin(p) : nullptr;
 }
 

@@ -58,6 +58,14 @@ class Caps:
         return self.W >= nw and self.S >= -(-self.P // L_SET) + nw and self.Vw >= max(wx * wy * wz for (wx, wy, wz), _s in WINS)
 
     @classmethod
+    def for_frames(cls, frames, max_points=196608, pillars_per_frame=65536):
+        """capacities of a pipeline that takes `frames` frames per forward(): per-frame point capacity, total pillar / kept-point / window /
+        set capacities (windows: every frame can touch every window cell of the grid)"""
+        nw = cls.max_windows_of_grid()
+        return cls(max_points, max_points * frames, pillars_per_frame * frames, -(-(nw * frames) // 1024) * 1024, 576,
+                   max_sets=-(-(-(-(pillars_per_frame * frames) // L_SET) + nw * frames) // 1024) * 1024)
+
+    @classmethod
     def reference(cls):
         """include/params.h:24-27,68-69: the set capacity is MAX_WIN_NUM there"""
         return cls(50000, 30000, 10000, 800, 576, max_sets=800)
@@ -84,14 +92,21 @@ def fold_linear_bn(w, lin, bn, eps, bias=False):
 class DsvtPipeline:
     def __init__(self, weights, caps=None, blocks=4, with_head=True, ln_eps=0.0, head_dtype=torch.float32,
                  device="cuda:0", zero_fill=False, linear_compute=P.COMPUTE_F32, hip_head=None, fused_mlp=None,
-                 device_nms=False, pos_table=None, fork_partition=None):
+                 device_nms=False, pos_table=None, fork_partition=None, frames=1):
         """linear_compute: COMPUTE_F32 = fp32 MFMA everywhere (parity mode, boxes within 1e-3 of the
         fp32 oracle); COMPUTE_F16 = fp16 MFMA operands with fp32 accumulate/epilogues (BASELINE
         configs[2] "fp16").  head_dtype: precision of the dense BEV stage.  hip_head: run the BEV ResNet +
         CenterHead on DsvtConv2dPlugin (csrc/conv.hip, fp16) instead of PyTorch/MIOpen; default: on in fp16
         mode.  device_nms: append RotatedNmsPlugin (the reference's host nms_cpu, include/helper.h:257-283) so that
         forward() returns the final boxes instead of FilterBoxByScore's rows."""
+        """frames > 1 (fp16 fused path only): SEVERAL frames per forward() with their pillar rows concatenated -- one launch per backbone layer for
+        all of them (rows = sum of the frames' pillars), one stacked BEV map per frame, the per-frame dense stage / decode / NMS through the C
+        ABI's batched enqueue.  points [1, frames * caps.N, 4], n [frames] -> boxes [frames, 500, 9], count [frames].  caps.N stays the
+        per-frame point capacity; the pillar / kept-point / window / set capacities are totals over the frames."""
         self.caps = c = caps or Caps()
+        self.frames = int(frames)
+        if self.frames > 1 and not (linear_compute == P.COMPUTE_F16 and (pos_table is None or pos_table) and (fused_mlp is None or fused_mlp)):
+            raise ValueError("frames > 1 needs the fused fp16 path (table position embeddings, fused set partition)")
         self.blocks, self.with_head, self.device = blocks, with_head, torch.device(device)
         # fork_partition: WindowPartition / GetSet (12 tiny launches that only need the pillar coordinates) run on a side stream
         # while the pillar feature net runs on the frame's stream; inside a HIP-graph capture this becomes two parallel branches.
@@ -114,7 +129,7 @@ class DsvtPipeline:
         o16 = dict(output_mode=P.OUT_F16) if f16 else {}
         oboth = dict(output_mode=P.OUT_BOTH) if f16 else {}
         self.voxelizer = zf(P.add_voxel_generator(c.N, c.Nk, c.P, 4, 10, 48, X_MIN, X_MAX, Y_MIN, Y_MAX, Z_MIN, Z_MAX,
-                                                  VX, VY, VZ, GX, GY, GZ))
+                                                  VX, VY, VZ, GX, GY, GZ, frames=self.frames))
         # PFN: FC (no bias) + BN1d(1e-5) + ReLU, BN folded into the FC           (:268-286, :577, :587)
         W0, b0 = fold_linear_bn(w, "module.vfe.pfn_layers.0.linear", "module.vfe.pfn_layers.0.norm", 1e-5)
         W1, b1 = fold_linear_bn(w, "module.vfe.pfn_layers.1.linear", "module.vfe.pfn_layers.1.norm", 1e-5)
@@ -133,7 +148,7 @@ class DsvtPipeline:
         # (window coordinates, set indices / masks / counts) are produced
         self.fused_partition = f16 and (pos_table is None or pos_table) and (fused_mlp is None or fused_mlp)
         if self.fused_partition:
-            self.part = zf(P.add_set_partition_op(c.W, c.Vw, L_SET, c.S, c.P, (GX, GY, GZ), WINS))
+            self.part = zf(P.add_set_partition_op(c.W, c.Vw, L_SET, c.S, c.P, (GX, GY, GZ), WINS, frames=self.frames))
         self.pe, self.layers, self.res_ln = {}, {}, {}
         scale = np.float32(math.sqrt(C / H))
         for b in range(blocks):
@@ -206,7 +221,7 @@ class DsvtPipeline:
                 self.pe_all = None
         self.cat = torch.zeros((1, c.Nk, 192), dtype=torch.float32, device=self.device)
         if with_head:
-            self.map2bev = P.add_map_2_bev_op(c.P, C, GX, GY)
+            self.map2bev = P.add_map_2_bev_op(c.P, C, GX, GY, frames=self.frames)
             self.filter = P.add_filter_box_by_score_op(TOP_K, X_MIN, X_MAX, Y_MIN, Y_MAX, Z_MIN, Z_MAX, VX, VY, VZ, SCORE_THR)
             self.nms = P.add_rotated_nms_op(TOP_K, NMS_THRESH) if device_nms else None
             self.hip_head = (head_dtype == torch.float16 and linear_compute == P.COMPUTE_F16) if hip_head is None else hip_head
@@ -300,7 +315,7 @@ class DsvtPipeline:
             b1[o:o + no] = w[f"module.dense_head.heads_list.0.{n}.1.bias"]
             o += no
         ops["heads1"] = P.add_conv2d_op(cw(W1), b1, GY, GX, 320, 18, 3, 1, 1, out_f32=True)
-        self.cat_bev = torch.zeros((1, GY, GX, 384), dtype=torch.float16, device=self.device)
+        self.cat_bev = torch.zeros((self.frames, GY, GX, 384), dtype=torch.float16, device=self.device)
         self.topk = P.add_center_head_topk_op(GY, GX, 18, 10, TOP_K)      # decode on the device
 
     # ---- the same stage at fp32 grade on the fp16 matrix cores (split-precision operands) ----------------------------------------

@@ -321,9 +321,12 @@ class Plugin:
 # --------------------------------------------------------------------------------------
 def add_voxel_generator(max_points_num, max_points_num_voxel_filter, max_pillars_num, point_feature_num,
                         feature_num, max_num_points_per_voxel, x_min, x_max, y_min, y_max, z_min, z_max,
-                        voxel_size_x, voxel_size_y, voxel_size_z, grid_size_x, grid_size_y, grid_size_z):
-    """plugin_helper.h:15-123.  Inputs at call time: points[1,N,4] f32, points_size[1] i32."""
-    return Plugin("Points2FeaturesPlugin", dict(
+                        voxel_size_x, voxel_size_y, voxel_size_z, grid_size_x, grid_size_y, grid_size_z, frames=1):
+    """plugin_helper.h:15-123.  Inputs at call time: points[1,N,4] f32, points_size[1] i32.
+    frames > 1 (not in the reference): points [1, frames * N, 4] (frame f = rows f * N ...), points_size [frames]; the frames' pillars are
+    concatenated (ascending (frame, cell)), coords = (frame, z, y, x), max_pillars_num / max_points_num_voxel_filter bound the totals."""
+    extra = dict(frames=int(frames)) if frames != 1 else {}
+    return Plugin("Points2FeaturesPlugin", dict(extra, 
         max_points_num=max_points_num, max_points_num_voxel_filter=max_points_num_voxel_filter,
         max_pillars_num=max_pillars_num, point_feature_num=point_feature_num, feature_num=feature_num,
         max_num_points_per_voxel=max_num_points_per_voxel,
@@ -358,14 +361,15 @@ def add_get_set_op(max_win_num, max_voxel_num_per_win, voxel_num_set, win_shape_
     return Plugin("GetSetPlugin", f, "get_set_layer")
 
 
-def add_set_partition_op(max_win_num, max_voxel_num_per_win, voxel_num_set, max_set_num, max_pillars_num, sparse_shape, wins):
+def add_set_partition_op(max_win_num, max_voxel_num_per_win, voxel_num_set, max_set_num, max_pillars_num, sparse_shape, wins, frames=1):
     """WindowPartition + GetSet of several window configurations in four launches (csrc/partition_ops.hip DsvtSetPartitionPlugin).
     wins: [(win_shape xyz, shift xyz), ...].  Inputs: coords [1,P,4], pillar_num [1].  Outputs per configuration k: c2d_k [1,P,3]
     (= WindowPartition output 4), inds_k [1,2,S,36], mask_k [1,2,S,36], set_num_k [1] (= GetSet outputs 0..2)."""
     return Plugin("DsvtSetPartitionPlugin", dict(
         max_win_num=max_win_num, max_voxel_num_per_win=max_voxel_num_per_win, voxel_num_set=voxel_num_set, max_set_num=max_set_num,
         max_pillars_num=max_pillars_num, sparse_shape=[int(v) for v in sparse_shape], num_configs=len(wins),
-        win_shapes=[int(v) for w_, _s in wins for v in w_], shift_lists=[int(v) for _w, s_ in wins for v in s_]), "set_partition_layer")
+        win_shapes=[int(v) for w_, _s in wins for v in w_], shift_lists=[int(v) for _w, s_ in wins for v in s_], frames=int(frames)),
+        "set_partition_layer")
 
 
 def add_get_value_by_index_op(max_win_num, voxel_num_set, channel_num, axis_id):
@@ -374,9 +378,10 @@ def add_get_value_by_index_op(max_win_num, voxel_num_set, channel_num, axis_id):
                                                 channel_num=channel_num, axis_id=axis_id), "get_value_by_index_layer")
 
 
-def add_map_2_bev_op(max_pillars_num, channel_num, grid_size_x, grid_size_y):
-    """plugin_helper.h:371-425.  Inputs: voxel_features, coors, valid_voxel_num."""
-    return Plugin("Map2BevPlugin", dict(max_pillars_num=max_pillars_num, channel_num=channel_num,
+def add_map_2_bev_op(max_pillars_num, channel_num, grid_size_x, grid_size_y, frames=1):
+    """plugin_helper.h:371-425.  Inputs: voxel_features, coors, valid_voxel_num.  frames > 1: coords.x selects one of `frames` stacked maps."""
+    extra = dict(frames=int(frames)) if frames != 1 else {}
+    return Plugin("Map2BevPlugin", dict(extra, max_pillars_num=max_pillars_num, channel_num=channel_num,
                                         grid_size_x=grid_size_x, grid_size_y=grid_size_y), "map2bev_layer")
 
 

@@ -306,3 +306,40 @@ def test_weights_from_a_wts_file_give_the_same_boxes(pkg, weights, tmp_path):
     b = [t.clone() for t in _run(pkg, pkg.pipeline.DsvtPipeline(w2, **kw), pts, n)]
     torch.cuda.synchronize()
     assert int(a[1][0]) > 0 and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_two_frames_per_forward_equal_two_forwards(pkg, weights):
+    """DsvtPipeline(frames=2): the rows of both frames concatenated through ONE launch per backbone layer (Points2Features / set partition /
+    Map2Bev with the frame index as an extra grid dimension, rows = sum of the frames' pillars), the dense stage / decode / NMS per frame
+    through the C ABI's batched enqueue.  Every row, set and window is computed exactly as in its own single-frame run, so the final
+    boxes of each frame are the same BITS as a frames=1 pipeline gives for it -- on two different clouds, in both slot orders."""
+    P = pkg.plugin
+    kw = dict(linear_compute=P.COMPUTE_F16, head_dtype=torch.float16, device_nms=True, device=DEV)
+    one = pkg.pipeline.DsvtPipeline(weights, caps=pkg.pipeline.Caps(), **kw)
+    caps2 = pkg.pipeline.Caps.for_frames(2)
+    two = pkg.pipeline.DsvtPipeline(weights, caps=caps2, frames=2, **kw)
+    clouds = [pkg.synth.lidar_like(180000, 5), pkg.synth.lidar_like(120000, 6)]
+    singles = []
+    for p in clouds:
+        pts, n = cases.pad_points(p, one.caps.N)
+        r, c = _run(pkg, one, pts, n)
+        torch.cuda.synchronize()
+        singles.append((r[0].clone(), int(c[0])))
+    assert singles[0][1] > 0 and singles[1][1] > 0 and singles[0][1] != singles[1][1]
+    for order in ((0, 1), (1, 0)):
+        buf = np.zeros((1, 2 * caps2.N, 4), np.float32)
+        for slot, k in enumerate(order):
+            buf[0, slot * caps2.N:slot * caps2.N + clouds[k].shape[0]] = clouds[k]
+        n = torch.tensor([clouds[k].shape[0] for k in order], dtype=torch.int32, device=DEV)
+        rows, cnt = two.forward(torch.from_numpy(buf).to(DEV), n)
+        torch.cuda.synchronize()
+        assert rows.shape == (2, 500, 9) and cnt.shape == (2,)
+        for slot, k in enumerate(order):
+            assert int(cnt[slot]) == singles[k][1]
+            assert torch.equal(rows[slot], singles[k][0]), float((rows[slot] - singles[k][0]).abs().max())
+    # graph replay of the two-frame forward
+    pts_d = torch.from_numpy(buf).to(DEV)
+    two.capture(pts_d, n)
+    g_rows, g_cnt = two.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(g_rows, rows) and torch.equal(g_cnt, cnt)
