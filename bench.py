@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--streams", type=int, default=2,
                     help="frames in flight per GPU: independent pipeline instances on separate HIP streams (a single "
                          "180k-point frame leaves most kernels one wave per SIMD; overlapping two frames fills the gaps)")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="frames per forward(): their pillar rows are concatenated and every backbone layer is ONE launch for all of them "
+                         "(DsvtPipeline(frames=B)); a step is still one frame, --steps must be a multiple of B")
     ap.add_argument("--no-graph", action="store_true", help="launch every op from the host instead of replaying a HIP graph")
     ap.add_argument("--event-every", type=int, default=20,
                     help="every N-th timed step runs un-graphed with HIP events around each linear launch (roofline sample)")
@@ -180,7 +183,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    caps = pkg.pipeline.Caps()                      # 196608 points / 65536 pillars / 2048 windows+sets
+    FB = max(1, args.batch)
+    if args.steps % FB:
+        raise SystemExit(f"bench.py: --steps {args.steps} is not a multiple of --batch {FB}")
+    caps = pkg.pipeline.Caps() if FB == 1 else pkg.pipeline.Caps.for_frames(FB)     # 196608 points per frame; pillar / window / set capacities are totals
     weights = pkg.synth.make_weights()
     f16 = args.dtype == "f16"
     use_graph = not args.no_graph
@@ -188,27 +194,39 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
     pipes = [pkg.pipeline.DsvtPipeline(weights, caps=caps, device=dev,
                                        linear_compute=pkg.plugin.COMPUTE_F16 if f16 else pkg.plugin.COMPUTE_F32,
-                                       head_dtype=torch.float16 if f16 else torch.float32, device_nms=not args.no_nms)
+                                       head_dtype=torch.float16 if f16 else torch.float32, device_nms=not args.no_nms, frames=FB)
              for _ in range(NS)]
     pipe = pipes[0]
 
     # synthetic frames of this rank, resident in HBM before the timed region
     K = args.steps
-    pool = []
-    for i in range(min(FRAME_POOL, max(K, 1))):
-        p = pkg.synth.lidar_like(args.points, seed=rank * FRAME_POOL + i)
-        buf = np.zeros((1, caps.N, 4), np.float32)
-        buf[0, :p.shape[0]] = p
-        pool.append((torch.from_numpy(buf).to(dev), torch.tensor([p.shape[0]], dtype=torch.int32, device=dev)))
+    KB = K // FB                                    # forward() calls of this rank (FB frames each)
+    clouds = [pkg.synth.lidar_like(args.points, seed=rank * FRAME_POOL + i) for i in range(max(FB, min(FRAME_POOL, max(K, 1))))]
+    pool = []                                       # entries = the inputs of one forward(): FB consecutive clouds, frame f in rows f * caps.N ...
+    for j in range(max(1, len(clouds) // FB)):
+        buf = np.zeros((1, FB * caps.N, 4), np.float32); ns = []
+        for f in range(FB):
+            p = clouds[(j * FB + f) % len(clouds)]
+            buf[0, f * caps.N:f * caps.N + p.shape[0]] = p; ns.append(p.shape[0])
+        pool.append((torch.from_numpy(buf).to(dev), torch.tensor(ns, dtype=torch.int32, device=dev)))
     results = torch.zeros((K, par.ROW), dtype=torch.float32, device=dev)
     static_in = [(torch.zeros_like(pool[0][0]), torch.zeros_like(pool[0][1])) for _ in range(NS)]
 
     # --host-input: the frames wait in pinned host memory (where a loader thread would have read the .bin files) and only
     # the n x 16 bytes that exist + the count cross PCIe, asynchronously on the frame's stream
+    if args.host_input and FB != 1:
+        raise SystemExit("bench.py: --host-input is a single-frame option")
     host_pool = [(p_[0, :int(n_[0])].cpu().pin_memory(), n_.cpu().pin_memory(), int(n_[0])) for p_, n_ in pool] if args.host_input else None
 
+    def pack(boxes, cnt, rows):
+        """boxes [FB,500,9], cnt [FB] -> FB rows of the result buffer (two device ops, no host sync)"""
+        if FB == 1:
+            par.pack_result(boxes[0], cnt, rows[0])
+        else:
+            rows[:, :par.ROW - 1].copy_(boxes.reshape(FB, -1)); rows[:, par.ROW - 1].copy_(cnt.to(torch.float32))
+
     def run_frame(i, row, eager=False):
-        """frame i on pipeline/stream i % NS (must be called with that stream current)"""
+        """forward() call i (FB frames) on pipeline/stream i % NS (must be called with that stream current)"""
         s = i % NS
         pts, n = pool[i % len(pool)]
         if host_pool is not None:
@@ -221,9 +239,9 @@ def main():
             boxes, cnt = pipes[s].replay()
         else:
             boxes, cnt = pipes[s].forward(pts, n)
-        par.pack_result(boxes[0], cnt, row)
+        pack(boxes, cnt, row)
 
-    scratch = [torch.zeros((par.ROW,), dtype=torch.float32, device=dev) for _ in range(NS)]
+    scratch = [torch.zeros((FB, par.ROW), dtype=torch.float32, device=dev) for _ in range(NS)]
     for s in range(NS):
         with torch.cuda.stream(streams[s]):
             for i in range(max(args.warmup, 1)):
@@ -251,7 +269,7 @@ def main():
         if not replay_equals_eager:
             raise SystemExit("bench.py: the HIP-graph replay of a frame differs from its eager run")
     # device-side counts of each pooled frame (for the algorithmic flop count), read outside the timed region
-    counts = []
+    counts = []                                     # per pool entry: totals over its FB frames (what one launch processes)
     for pts, n in pool:
         st = pipe.voxel_stage(pts, n)
         counts.append(dict(P=int(st["P"][0]), Nk=int(st["Nk"][0]), S=[int(g[2][0]) for g in st["gss"]]))
@@ -259,7 +277,7 @@ def main():
 
     prof = None if args.no_kernel_events else {"DsvtLinearPlugin": [], "DsvtEncoderMlpPlugin": [], "DsvtSetAttentionPlugin": [],
                                                "DsvtConv2dPlugin": [], "DsvtPillarFeatureNetPlugin": [], "DsvtPosEmbedPlugin": []}
-    marks = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    marks = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(KB)]
     # warm-up of the one collective: RCCL sets up its channels lazily at the first call of each kind (tens of ms: measured 45 ms on a size-1
     # communicator, as much as 23 frames), which is start-up cost, not a property of the frame path
     if world > 1 or args.rccl_single:
@@ -267,17 +285,17 @@ def main():
     par.barrier(); torch.cuda.synchronize()
     sampled = 0
     t0 = time.perf_counter()
-    for i in range(K):
+    for i in range(KB):
         # roofline sample: every event_every-th step is launched op by op, alone on the GPU, with HIP events
         # around each linear launch (events cannot bracket kernels inside a graph replay); it stays inside the
         # timed region
-        ev = prof is not None and (not use_graph or i % args.event_every == args.event_every // 2)
+        ev = prof is not None and (not use_graph or (i * FB) % args.event_every == (args.event_every // 2) // FB * FB)
         if ev and (use_graph or NS > 1):
             torch.cuda.synchronize()
         pkg.plugin.PROFILE = prof if ev else None
         with torch.cuda.stream(streams[i % NS]):
             marks[i][0].record()
-            run_frame(i, results[i], eager=ev)
+            run_frame(i, results[i * FB:(i + 1) * FB], eager=ev)
             marks[i][1].record()
         if ev and (use_graph or NS > 1):
             torch.cuda.synchronize()
@@ -290,7 +308,7 @@ def main():
     pkg.plugin.PROFILE = None
     dt = par.max_over_ranks(dt, dev)
 
-    frame_ms = np.array([marks[i][0].elapsed_time(marks[i][1]) for i in range(K)])
+    frame_ms = np.array([marks[i][0].elapsed_time(marks[i][1]) for i in range(KB)])      # a frame is done when its forward() is
     roofline, roofline_all = None, []
     if prof is not None and sampled:
         pm = {}
@@ -400,7 +418,7 @@ def main():
                                          else "none (single process)"),
                        "graph_replay_equals_eager": replay_equals_eager,
                        "launch": "hip-graph replay per frame" if use_graph else "host launch per op",
-                       "frames_in_flight": NS,
+                       "frames_in_flight": NS * FB, "frames_per_forward": FB,
                        "caps": dict(points=caps.N, pillars=caps.P, windows=caps.W, sets=caps.S, overflow_free=caps.overflow_free()),
                        "frame0": counts[0]},
             "roofline": roofline,
@@ -413,8 +431,9 @@ def main():
             for pts, n in pool:
                 fb = pipe.forward(pts, n)
                 torch.cuda.synchronize()
-                k = int(n[0])
-                frames.append((pts[0, :k].cpu().numpy(), fb[0][0].cpu().numpy().copy(), int(fb[1][0])))
+                for f in range(FB):
+                    k = int(n[f])
+                    frames.append((pts[0, f * caps.N:f * caps.N + k].cpu().numpy(), fb[0][f].cpu().numpy().copy(), int(fb[1][f])))
             pipe.nms = nms_op
             line["cpu_baseline"] = cpu_baseline(caps, frames, whole_network=(weights,) if args.whole_network_cpu else None)
         else:
