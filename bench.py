@@ -4,6 +4,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
+Two frames per forward() (their pillar rows concatenated: one launch per backbone layer for both, `--batch`) on each of two streams
+(`--streams`) are the default: 558 frames/s against 532 with one frame per forward and 441 with a single frame in flight; p50_ms is
+the per-frame latency of that mode (a frame is done when its forward() is).
+
 A step = one frame through the whole pipeline (BASELINE.json configs[2]: Waymo-shaped
 180k-point synthetic cloud `lidar_like(180000, seed)`, 0.32 m pillars, 468x468 BEV grid, full
 4-block DSVT pillar backbone + BEV backbone + CenterHead + FilterBoxByScore), inputs already
@@ -148,9 +152,10 @@ def main():
     ap.add_argument("--streams", type=int, default=2,
                     help="frames in flight per GPU: independent pipeline instances on separate HIP streams (a single "
                          "180k-point frame leaves most kernels one wave per SIMD; overlapping two frames fills the gaps)")
-    ap.add_argument("--batch", type=int, default=1,
+    ap.add_argument("--batch", type=int, default=2,
                     help="frames per forward(): their pillar rows are concatenated and every backbone layer is ONE launch for all of them "
-                         "(DsvtPipeline(frames=B)); a step is still one frame, --steps must be a multiple of B")
+                         "(DsvtPipeline(frames=B)); a step is still one frame, --steps must be a multiple of B.  Measured (MI355X, streams x batch): "
+                         "1x1 441, 2x1 532, 1x2 458, 2x2 558, 3x2 521, 1x4 460 frames/s; p50 per frame 2.2 / 3.7 / 4.3 / 7.1 ms")
     ap.add_argument("--no-graph", action="store_true", help="launch every op from the host instead of replaying a HIP graph")
     ap.add_argument("--event-every", type=int, default=20,
                     help="every N-th timed step runs un-graphed with HIP events around each linear launch (roofline sample)")
@@ -183,7 +188,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    FB = max(1, args.batch)
+    FB = max(1, args.batch) if args.dtype == "f16" else 1          # (the fp32 mode has no multi-frame path)
+    if args.host_input:
+        FB = 1
     if args.steps % FB:
         raise SystemExit(f"bench.py: --steps {args.steps} is not a multiple of --batch {FB}")
     caps = pkg.pipeline.Caps() if FB == 1 else pkg.pipeline.Caps.for_frames(FB)     # 196608 points per frame; pillar / window / set capacities are totals
@@ -214,8 +221,6 @@ def main():
 
     # --host-input: the frames wait in pinned host memory (where a loader thread would have read the .bin files) and only
     # the n x 16 bytes that exist + the count cross PCIe, asynchronously on the frame's stream
-    if args.host_input and FB != 1:
-        raise SystemExit("bench.py: --host-input is a single-frame option")
     host_pool = [(p_[0, :int(n_[0])].cpu().pin_memory(), n_.cpu().pin_memory(), int(n_[0])) for p_, n_ in pool] if args.host_input else None
 
     def pack(boxes, cnt, rows):
@@ -350,9 +355,10 @@ def main():
                 Ho = (f["in_height"] + 2 * f["padding"] - f["kernel_size"]) // f["stride"] + 1
                 up = f.get("pixel_shuffle", 1)
                 taps = f["kernel_size"] ** 2
-                return (2.0 * Ho * Ho * up * up * f["out_channels"] * taps * f["in_channels"],
-                        2 * f["in_height"] ** 2 * f["in_channels"] + (4 if f.get("out_f32") else 2) * Ho * Ho * up * up * f["out_channels"]
-                        + 2 * up * up * f["out_channels"] * taps * f["in_channels"])
+                # (one enqueue = FB per-frame launches through the C ABI's batched enqueue)
+                return (FB * 2.0 * Ho * Ho * up * up * f["out_channels"] * taps * f["in_channels"],
+                        FB * (2 * f["in_height"] ** 2 * f["in_channels"] + (4 if f.get("out_f32") else 2) * Ho * Ho * up * up * f["out_channels"]
+                              + 2 * up * up * f["out_channels"] * taps * f["in_channels"]))
             return (0.0, 0.0)
 
         meta = {"DsvtLinearPlugin": ("linear_f16_rows_kernel (QKV: all column chunks of a row tile per workgroup, v_mfma_f32_16x16x32_f16, weights by LDS-DMA)" if f16 else "linear_f32_kernel (v_mfma_f32_16x16x4_f32)",
