@@ -157,8 +157,10 @@ def main():
                          "(DsvtPipeline(frames=B)); a step is still one frame, --steps must be a multiple of B.  Measured (MI355X, streams x batch): "
                          "1x1 441, 2x1 532, 1x2 458, 2x2 558, 3x2 521, 1x4 460 frames/s; p50 per frame 2.2 / 3.7 / 4.3 / 7.1 ms")
     ap.add_argument("--no-graph", action="store_true", help="launch every op from the host instead of replaying a HIP graph")
-    ap.add_argument("--event-every", type=int, default=20,
-                    help="every N-th timed step runs un-graphed with HIP events around each linear launch (roofline sample)")
+    ap.add_argument("--event-every", type=int, default=0,
+                    help="roofline sample: every N-th timed step runs un-graphed, alone on the GPU, with HIP events around each launch; "
+                         "0 (default) = only the LAST forward() of the timed region (one pipeline drain instead of one per sample: the "
+                         "three samples of the old default cost 5-8 %% of the measured rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-input", action="store_true", help="frames start in pinned host memory and are uploaded (n x 16 B) inside the timed region: the PCIe-inclusive rate quoted in DESIGN.md, never the headline value")
     ap.add_argument("--no-nms", action="store_true", help="stop at FilterBoxByScore (the reference engine's output) instead of the final boxes")
@@ -294,7 +296,10 @@ def main():
         # roofline sample: every event_every-th step is launched op by op, alone on the GPU, with HIP events
         # around each linear launch (events cannot bracket kernels inside a graph replay); it stays inside the
         # timed region
-        ev = prof is not None and (not use_graph or (i * FB) % args.event_every == (args.event_every // 2) // FB * FB)
+        if args.event_every > 0:
+            ev = prof is not None and (not use_graph or (i * FB) % args.event_every == (args.event_every // 2) // FB * FB)
+        else:
+            ev = prof is not None and (not use_graph or i == KB - 1)
         if ev and (use_graph or NS > 1):
             torch.cuda.synchronize()
         pkg.plugin.PROFILE = prof if ev else None
