@@ -46,7 +46,7 @@ PEAK_F32_MATRIX_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Pe
 PEAK_F16_MATRIX_TFLOPS = 2500.0     # same guide: "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBS = 8000.0               # same guide: "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured float4 copy)
 N_POINTS = 180000
-PMC_FILE = "r02_c_pmc_traffic.json"
+PMC_FILES = {1: "r02_d_pmc_traffic.json", 2: "r02_e_pmc_traffic.json"}      # FETCH_SIZE / WRITE_SIZE passes, by frames per forward()
 FRAME_POOL = 4                      # distinct synthetic clouds cycled through by the steps
 
 
@@ -323,7 +323,7 @@ def main():
     if prof is not None and sampled:
         pm = {}
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+            pm = json.load(open(os.path.join(ROOT, "profiles", PMC_FILES[FB])))
         except Exception:
             pass
 
@@ -396,13 +396,16 @@ def main():
                      ms_per_frame=round(tot_ms / sampled, 3), algorithmic_gflop_per_launch=round(tot_fl / n_l / 1e9, 3),
                      algorithmic_mb_per_launch=round(tot_by / n_l / 1e6, 2))
             if r["traffic"] is not None:
-                r["traffic_source"] = "profiles/" + PMC_FILE
+                r["traffic_source"] = "profiles/" + PMC_FILES[FB]
             # the weight matrices are counted ONCE in the algorithmic bytes, but every workgroup streams its own copy L2 -> LDS: what the
             # memory system carries per launch beside the activations (DESIGN.md "what bounds the backbone kernels")
             wg_weights = {"DsvtEncoderMlpPlugin": 2 * (192 * 192 + 2 * 192 * 384), "DsvtLinearPlugin": 2 * 192 * 576 if f16 else 0}.get(ptype, 0)
             if wg_weights and f16:
                 c0 = counts[0]
-                nwg = min(256, -(-c0["P"] // 128))
+                need = -(-c0["P"] // (16 * 256))                       # the kernels' tile plan: 8 .. 10 live waves of 16 rows, two rounds / two per CU beyond
+                if need > 10:
+                    need = -(-c0["P"] // (32 * 256))
+                nwg = -(-c0["P"] // (16 * (max(8, need) if need <= 10 else 8)))
                 r["weights_restreamed_mb_per_launch"] = round(nwg * wg_weights / 1e6, 1)
                 r["fabric_gbs_incl_weight_stream"] = round((tot_by / n_l + nwg * wg_weights) / (avg_ms * 1e-3) / 1e9, 1)
             roofline_all.append((ptype, r))
