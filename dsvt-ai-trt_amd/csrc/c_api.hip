@@ -124,7 +124,7 @@ int32_t dsvtPluginEnqueue(DsvtPlugin* p, const DsvtPluginTensorDesc* inDesc, con
     if (!p || !inputs || !outputs) return kErrNullArg;
     DSVT_GUARD(kErrException,
         const int B = (inDesc && outDesc && inDesc[0].dims.nbDims >= 1) ? inDesc[0].dims.d[0] : 1;
-        if (B > 1) {
+        if (B > 1 && !p->impl->handlesBatch()) {
             // enqueue's signature (like TensorRT's) does not carry the number of inputs: configurePlugin delivers it beforehand
             if (p->nbInputs < 1) return -2;
             return enqueueBatched(p->impl, B, p->nbInputs, inDesc, outDesc, inputs, outputs, ws, reinterpret_cast<hipStream_t>(stream));

@@ -44,6 +44,7 @@ struct ConvArgs {
     int Cout;                                    // real output channels
     int KH, KW, stride, pad, up, relu;
     int wide;                                    // halo kernel: 16-byte epilogue accesses are legal (channel strides / offsets % 8, Cout % 16, fp16 output)
+    int nb;                                      // images per launch (>= 1): image b = pixels b*H*W .. of `in`, b*Ho*up*Wo*up .. of `out` / `res`
 };
 
 
@@ -86,8 +87,15 @@ __device__ __forceinline__ void convStore(const ConvArgs& a, floatx4 acc, size_t
 // MT = 16-pixel MFMA tiles per wave, NW = waves per workgroup (128 pixels per workgroup either way)
 template <int KC, int MT, int NW>
 __global__ void __launch_bounds__(64 * NW, (MT == 1 ? 4 : 2))
-conv_f16_kernel(ConvArgs a)
+conv_f16_kernel(ConvArgs a_)
 {
+    ConvArgs a = a_;
+    {   // image blockIdx.z of a stack of a.nb images
+        const size_t b = blockIdx.z, opx = (size_t)a.Ho * a.up * a.Wo * a.up;
+        a.in += b * (size_t)a.H * a.W * a.Cin;
+        if (a.res) a.res += b * opx * a.res_ld;
+        a.out = a.out_f32 ? static_cast<void*>(static_cast<float*>(a.out) + b * opx * a.out_ld) : static_cast<void*>(static_cast<_Float16*>(a.out) + b * opx * a.out_ld);
+    }
     constexpr int NTHR = 64 * NW;
     constexpr int KSTEPS = KC / 32, LDW = KC + 16, WPT = (CNB * KC / 8 + NTHR - 1) / NTHR;     // WPT: uint4 weight loads per thread per slab
     __shared__ __attribute__((aligned(16))) _Float16 sW[2][CNB * LDW];
@@ -389,16 +397,18 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         hpos[j] = (hy << 16) | (hx << 4) | (slot ^ (hx & 7));         // 16-byte channel chunk of the pixel stored in this slot
     }
     int goff[HPW];                                                    // element offset into the input, or -1: zeros
-    auto setup = [&](int yy, int xx) {
+    const int perImg = nitems / a.nb;                                 // items of one image (items walk image after image)
+    auto setup = [&](int yy, int xx, int bb) {
 #pragma unroll
         for (int j = 0; j < HPW; ++j) {
             const int hx = (hpos[j] >> 4) & 0xfff;
             const int gy = yy - PAD + (hpos[j] >> 16), gx = xx - PAD + hx;
             const bool ok = hx < HWU && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            goff[j] = ok ? (gy * a.W + gx) * a.Cin + (hpos[j] & 15) * 8 : -1;
+            goff[j] = ok ? ((bb * a.H + gy) * a.W + gx) * a.Cin + (hpos[j] & 15) * 8 : -1;
         }
     };
-    auto decode = [&](int it, int& yy, int& xx, int& ch) {
+    auto decode = [&](int it, int& yy, int& xx, int& ch, int& bb) {
+        bb = it / perImg; it -= bb * perImg;
         ch = it % nchunk; const int t = it / nchunk;
         yy = (t / tilesX) * TH; xx = (t % tilesX) * HTW;
     };
@@ -430,7 +440,7 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         return n < 0 ? 0 : n > CTP ? CTP : n;
     };
     // bias / residual / ReLU / store of a finished item (tile origin ey, ex; 128-channel chunk ech)
-    auto epilogue = [&](int ey, int ex, int ech) {
+    auto epilogue = [&](int ey, int ex, int ech, int ebb) {
         const int n0 = ech * CNB, ctn = tilesOf(ech);
         const int sub = n0 / a.Cout, dy = sub / a.up, dx = sub - dy * a.up, cbase = n0 - sub * a.Cout;
         const int Wout = a.Wo * a.up;
@@ -438,7 +448,7 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         for (int m = 0; m < NM; ++m) {
             const int oy = ey + 2 * pg + ((m0 + m) >> 1), ox = ex + ((m0 + m) & 1) * 16 + r;
             const bool valid = oy < a.Ho && ox < a.Wo;
-            const size_t opix = valid ? (size_t)(oy * a.up + dy) * Wout + (ox * a.up + dx) : 0;
+            const size_t opix = valid ? (size_t)((ebb * a.Ho + oy) * a.up + dy) * Wout + (ox * a.up + dx) : 0;
             if (a.wide) {
 #pragma unroll
                 for (int t0 = 0; t0 + 1 < CTP; t0 += 2)
@@ -462,9 +472,9 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
 
     int item = blockIdx.x;
     if (item >= nitems) return;
-    int y0, x0, chunk;
-    decode(item, y0, x0, chunk);
-    setup(y0, x0);
+    int y0, x0, chunk, bimg;
+    decode(item, y0, x0, chunk, bimg);
+    setup(y0, x0, bimg);
     if (wave == 0) biasRequest(chunk);
 #pragma unroll
     for (int j = 0; j < HPW; ++j)
@@ -475,16 +485,16 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     int hb = 0, wb = 0;
     const int wcnt = (WROWS - wave + TH - 1) / TH;              // weight requests this wave issues per slab
     int nreqPrev = 0;                                           // halo requests issued during the previous slab
-    bool pending = false; int ey = 0, ex = 0, ech = 0;          // finished item whose epilogue has not run yet
+    bool pending = false; int ey = 0, ex = 0, ech = 0, ebb = 0;  // finished item whose epilogue has not run yet
     for (;;) {
         const int ctn = tilesOf(chunk);
-        int nitem = item, ny0 = y0, nx0 = x0, nch = chunk;
+        int nitem = item, ny0 = y0, nx0 = x0, nch = chunk, nbimg = bimg;
         bool have_next = true;
         for (int cc = 0; cc < NCC; ++cc) {
             int ncc = cc + 1;
             if (ncc == NCC) {
                 ncc = 0; nitem = item + gridDim.x; have_next = nitem < nitems;
-                if (have_next) { decode(nitem, ny0, nx0, nch); setup(ny0, nx0); }
+                if (have_next) { decode(nitem, ny0, nx0, nch, nbimg); setup(ny0, nx0, nbimg); }
             }
             const bool haloNext = have_next && !(dbg & 1);
             int nreq = 0;                                        // halo requests issued after the current slab's weight requests
@@ -498,7 +508,7 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                     if (tap == 0 && cc == 0) {
                         // epilogue of the previous item first: its stores are the oldest requests of this slab and have the
                         // whole MFMA block to complete
-                        if (pending && !(dbg & 8)) epilogue(ey, ex, ech);
+                        if (pending && !(dbg & 8)) epilogue(ey, ex, ech, ebb);
 #pragma unroll
                         for (int ct = 0; ct < CTP; ++ct) {
                             const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + BIAS_OFF + (cgc * 64 + ct * 16 + 4 * g) * 4);      // zeros without a bias
@@ -578,11 +588,11 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
             }
             if (HB == 2) hb ^= 1;
         }
-        pending = true; ey = y0; ex = x0; ech = chunk;
+        pending = true; ey = y0; ex = x0; ech = chunk; ebb = bimg;
         if (!have_next) break;
-        item = nitem; y0 = ny0; x0 = nx0; chunk = nch;
+        item = nitem; y0 = ny0; x0 = nx0; chunk = nch; bimg = nbimg;
     }
-    if (!(dbg & 8)) epilogue(ey, ex, ech);
+    if (!(dbg & 8)) epilogue(ey, ex, ech, ebb);
 }
 
 // -------------------------------------------------------------------------------------
@@ -633,17 +643,19 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     const int NSTEP = NP * 9, NSLAB = (NSTEP + SPS - 1) / SPS;    // (SPS = 4: the last slab may be partial; the packed weights end in a zero slab)
     const int NCT = a.CoutRows <= 64 ? 4 : (a.CoutRows + 127) / 128 * 8;      // 16-channel tiles per k-step of the packed weights
 
-    auto decode = [&](int it, int& yy, int& xx, int& ch) {
+    const int perImg = nitems / a.nb;                             // items of one image (items walk image after image)
+    auto decode = [&](int it, int& yy, int& xx, int& ch, int& bb) {
+        bb = it / perImg; it -= bb * perImg;
         ch = it % nchunk; const int t = it / nchunk;
         yy = (t / tilesX) * WT_ROWS; xx = (t % tilesX) * HTW;
     };
-    // piece pc of the halo of phase ph at tile origin (yy, xx) -> buffer hb
-    auto haloRequest = [&](int pc, int yy, int xx, int ph, int hb) {
+    // piece pc of the halo of phase ph at tile origin (yy, xx) of image bb -> buffer hb
+    auto haloRequest = [&](int pc, int yy, int xx, int ph, int hb, int bb) {
         const int lp = pc * 16 + (lane >> 2), hy = lp / WT_HS, hx = lp - hy * WT_HS;
         const int chunk = (lane & 3) ^ ((hx >> 1) & 2);
         const int gy = yy - 1 + hy, gx = xx - 1 + hx;
         const bool ok = hx < HTW + 2 && hy < C::HH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        const _Float16* src = ok ? a.in + (size_t)(gy * a.W + gx) * a.Cin + ph * 32 + chunk * 8 : zeros;
+        const _Float16* src = ok ? a.in + (size_t)((bb * a.H + gy) * a.W + gx) * a.Cin + ph * 32 + chunk * 8 : zeros;
         __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + hb * WT_HBYTES + pc * 1024), 16, 0, 0);
     };
     // the 16 fragment rows of slab sl (steps SPS sl ...) of chunk ch -> buffer wb
@@ -669,12 +681,12 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
 
     int item = blockIdx.x;
     if (item >= nitems) return;
-    int y0, x0, chunk;
-    decode(item, y0, x0, chunk);
+    int y0, x0, chunk, bimg;
+    decode(item, y0, x0, chunk, bimg);
     if (wave == 0) biasRequest(chunk);
 #pragma unroll
     for (int i = 0; i < PPW; ++i)
-        if (wave + NW * i < WT_NPC) haloRequest(wave + NW * i, y0, x0, 0, 0);
+        if (wave + NW * i < WT_NPC) haloRequest(wave + NW * i, y0, x0, 0, 0, bimg);
     weightRequests(0, chunk, 0);
     slabBarrier(0);
     if (LEAD == 2) weightRequests(1, chunk, 1);                   // (NSLAB >= 5; retired by the first slab-end wait)
@@ -685,9 +697,9 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     int wb = 0;
     floatx4 acc[CT][NM];
     for (;;) {
-        int nitem = item + gridDim.x, ny0 = 0, nx0 = 0, nch = 0;
+        int nitem = item + gridDim.x, ny0 = 0, nx0 = 0, nch = 0, nbimg = 0;
         const bool have_next = nitem < nitems;
-        if (have_next) decode(nitem, ny0, nx0, nch);
+        if (have_next) decode(nitem, ny0, nx0, nch, nbimg);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + BIAS_OFF + (ct * 16 + 4 * g) * 4);      // zeros without a bias
@@ -702,11 +714,11 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                 const int P = (SPS * s) / 9 + 1, k = s - (9 * (P - 1) + SPS - 1) / SPS;
                 const bool inItem = P < NP;
                 if (k < NRS && (inItem || have_next) && !(dbg & 1)) {
-                    const int yy = inItem ? y0 : ny0, xx = inItem ? x0 : nx0, ph = inItem ? P : 0;
+                    const int yy = inItem ? y0 : ny0, xx = inItem ? x0 : nx0, ph = inItem ? P : 0, bb = inItem ? bimg : nbimg;
 #pragma unroll
                     for (int i = 0; i < PPS; ++i) {
                         const int pc = wave + NW * (k * PPS + i);
-                        if (k * PPS + i < PPW && pc < WT_NPC) haloRequest(pc, yy, xx, ph, P & 1);
+                        if (k * PPS + i < PPW && pc < WT_NPC) haloRequest(pc, yy, xx, ph, P & 1, bb);
                     }
                 }
             }
@@ -773,7 +785,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                 for (int m = 0; m < NM; ++m) {
                     const int oy = y0 + RW * wave + (m >> 1), ox = x0 + (m & 1) * 16 + r;
                     valid[m] = oy < a.Ho && ox < a.Wo;
-                    opix[m] = valid[m] ? (size_t)(oy * a.up + dy) * Wout + (ox * a.up + dx) : 0;
+                    opix[m] = valid[m] ? (size_t)((bimg * a.Ho + oy) * a.up + dy) * Wout + (ox * a.up + dx) : 0;
                 }
 #pragma unroll
                 for (int b = 0; b < NBLK; ++b) {
@@ -802,7 +814,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                 for (int m = 0; m < NM; ++m) {
                     const int oy = y0 + RW * wave + (m >> 1), ox = x0 + (m & 1) * 16 + r;
                     if (!(oy < a.Ho && ox < a.Wo)) continue;
-                    const size_t opix = (size_t)(oy * a.up + dy) * Wout + (ox * a.up + dx);
+                    const size_t opix = (size_t)((bimg * a.Ho + oy) * a.up + dy) * Wout + (ox * a.up + dx);
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
                         if (ct < ctn) convStore<false>(a, acc[ct][m], opix, cbase + ct * 16 + 4 * g);
@@ -811,7 +823,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         }
         if (!have_next) break;
         // (the epilogue's loads and stores retire at the first slab end of the next item: nothing else is in flight)
-        item = nitem; y0 = ny0; x0 = nx0; chunk = nch;
+        item = nitem; y0 = ny0; x0 = nx0; chunk = nch; bimg = nbimg;
     }
 }
 
@@ -848,9 +860,10 @@ static int balancedGrid(int nitems, int slots) {
 static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16* zeros, hipStream_t stream) {
     const int th = haloTileRows(a);
     const int tilesX = cdiv(a.Wo, HTW), nchunk = cdiv(a.CoutRows, CNB);
+    const int NBI = a.nb;                                       // images: every item count below is per image x NBI
     static int wideOn = -1;        // DSVT_CONV_WIDE=0: every layer on the 8-row kernel
     if (wideOn < 0) { const char* e = getenv("DSVT_CONV_WIDE"); wideOn = e ? atoi(e) : 1; }
-    const int nwide = cdiv(a.Ho, 16) * tilesX * nchunk;
+    const int nwide = cdiv(a.Ho, 16) * tilesX * nchunk * NBI;
     // 16-row tiles when they fill the CUs, else 8-row x 64-channel tiles on four waves (two workgroups per CU).  (Two channel
     // tiles: 32 MFMAs per slab cannot hide the halo stream, 86.7 vs 85.6 us on the 320 -> 18 head layer: the 8-row kernel below.)
     const int ctWide = haloChannelTiles(a.CoutRows);
@@ -860,7 +873,7 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
         // short K (the 64 -> 320 head stems: 9 slabs per item, the epilogue weighs as much as the MFMAs): 8-row x 128-channel tiles on
         // four waves, two independent workgroups per CU, 2655 items: 116-122 vs 130 us (no gain on the K >= 1152 layers)
         if (ctWide == 8 && (a.Cin <= 64 || wideOn == 6)) {
-            const int n8 = cdiv(a.Ho, 8) * tilesX * nchunk, grid = balancedGrid(n8, 2 * numCUs());
+            const int n8 = cdiv(a.Ho, 8) * tilesX * nchunk * NBI, grid = balancedGrid(n8, 2 * numCUs());
             hipLaunchKernelGGL((conv_wide_kernel<8, 4, 36, 2, 2>), dim3(grid), dim3(256), 0, stream, a, Wp, zeros, tilesX, n8, nchunk, dbgW);
             return lastError();
         }
@@ -871,7 +884,7 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
             // are 34 x 15 = 510 = two FULL rounds of 14 rows, 28 row-units instead of 32.  Measured: no gain (convolutions 1.211 vs 1.199 ms
             // per frame, 439 vs 442 frames/s): the quarter-empty second round is not idle time, its workgroups run faster on the freed
             // memory system.  Kept behind the switch; results are identical.
-            const int n14 = cdiv(a.Ho, 14) * tilesX * nchunk;
+            const int n14 = cdiv(a.Ho, 14) * tilesX * nchunk * NBI;
             const bool rows14 = wideOn == 12 && cdiv(n14, grid) * 14 < cdiv(nwide, grid) * 16;
             // (a third weight slab -- requests two slabs ahead -- measured 80.2 vs 82.6 us on the 128-channel layers, nothing elsewhere)
             if (ctWide == 8 && rows14) hipLaunchKernelGGL((conv_wide_kernel<8, 7, 40, 2, 3>), dim3(grid), dim3(448), 0, stream, a, Wp, zeros, tilesX, n14, nchunk, dbgW);
@@ -884,10 +897,10 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
             return lastError();
         }
         if (wideOn != 2) {
-            const int nch64 = cdiv(a.CoutRows, 64), nsmall = cdiv(a.Ho, 8) * tilesX * nch64;
+            const int nch64 = cdiv(a.CoutRows, 64), nsmall = cdiv(a.Ho, 8) * tilesX * nch64 * NBI;
             // 16-row x 64-channel items on eight waves when they nearly fill the CUs (234x234x128: 240 items, one per CU, 40 LDS-DMA
             // pieces per wave and item instead of 59)
-            const int n16 = cdiv(a.Ho, 16) * tilesX * nch64;
+            const int n16 = cdiv(a.Ho, 16) * tilesX * nch64 * NBI;
             if (n16 * 10 >= numCUs() * 9 && n16 <= numCUs() && wideOn != 7 && wideOn != 10) {
                 hipLaunchKernelGGL((conv_wide_kernel<4, 8, 40, 4, 2>), dim3(n16), dim3(512), 0, stream, a, Wp, zeros, tilesX, n16, nch64, dbgW);
                 return lastError();
@@ -900,7 +913,7 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
             return lastError();
         }
     }
-    const int nitems = cdiv(a.Ho, th) * tilesX * nchunk;
+    const int nitems = cdiv(a.Ho, th) * tilesX * nchunk * NBI;
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("DSVT_CONV_DBG"); dbg = e ? atoi(e) : 0; }           // timing ablations only (wrong results)
     static int gridCap = -1;
@@ -921,7 +934,7 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
 }
 
 static int launchConv(const ConvArgs& a, int KC, hipStream_t stream) {
-    dim3 grid((unsigned)(cdiv(cdiv(a.Ho * a.Wo, CPX), 8) * 8), (unsigned)cdiv(a.CoutRows, CNB));
+    dim3 grid((unsigned)(cdiv(cdiv(a.Ho * a.Wo, CPX), 8) * 8), (unsigned)cdiv(a.CoutRows, CNB), (unsigned)a.nb);
     if (KC == 128) hipLaunchKernelGGL((conv_f16_kernel<128, 1, 8>), grid, dim3(512), 0, stream, a);
     else if (KC == 96) hipLaunchKernelGGL((conv_f16_kernel<96, 1, 8>), grid, dim3(512), 0, stream, a);
     else if (KC == 64) hipLaunchKernelGGL((conv_f16_kernel<64, 1, 8>), grid, dim3(512), 0, stream, a);
@@ -996,6 +1009,7 @@ public:
         if (w_dev_) (void)hipFree(w_dev_); if (b_dev_) (void)hipFree(b_dev_); if (wp_dev_) (void)hipFree(wp_dev_); if (zeros_dev_) (void)hipFree(zeros_dev_);
     }
     const char* type() const override { return "DsvtConv2dPlugin"; }
+    bool handlesBatch() const override { return true; }          // a stack of images is ONE launch: the persistent kernels walk image after image
     int nbOutputs() const override { return 1; }
     int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
         if (i != 0) return -1;
@@ -1019,6 +1033,8 @@ public:
         a.Ho = Ho(); a.Wo = Wo(); a.CoutRows = rows(); a.Cout = c_.Cout;
         a.KH = c_.KH; a.KW = c_.KW; a.stride = c_.stride; a.pad = c_.pad; a.up = c_.up; a.relu = c_.relu;
         a.wide = !c_.out_f32 && c_.Cout % 16 == 0 && c_.out_ld % 8 == 0 && c_.out_coff % 8 == 0 && (!c_.has_res || a.res_ld % 8 == 0);
+        a.nb = (inDesc && inDesc[0].dims.nbDims == 4 && inDesc[0].dims.d[0] > 1) ? inDesc[0].dims.d[0] : 1;
+        if ((long)a.nb * c_.H * c_.W * c_.Cin >= (1l << 31)) return -2;                // the halo kernel addresses the input with 32-bit element offsets
         if (wp_dev_) return launchConvHalo(a, wp_dev_, zeros_dev_, stream);
         return launchConv(a, KC(), stream);
     }

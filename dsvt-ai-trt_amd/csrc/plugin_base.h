@@ -44,6 +44,9 @@ public:
     virtual size_t serializationSize() const = 0;
     virtual void serialize(void* buffer) const = 0;
     virtual Plugin* clone() const = 0;
+    // true: enqueue() itself processes a leading batch dimension > 1 (one launch for all images); false (default): the C ABI layer runs
+    // the per-frame slabs one after the other (c_api.hip)
+    virtual bool handlesBatch() const { return false; }
     bool zeroFill = true;
     std::string layerName;
 };

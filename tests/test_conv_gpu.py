@@ -176,3 +176,44 @@ def test_split_precision_deblock_into_concat(pkg):
     got = cat[..., 128:256].permute(0, 3, 1, 2).double().cpu()
     assert (got - ref).abs().max().item() < 5e-6 * ref.abs().max().item()
     assert (cat[..., :128] == -7.0).all() and (cat[..., 256:] == -7.0).all()
+
+
+@pytest.mark.parametrize("H,W,cin,cout,k,stride,res,shuffle", [
+    (468, 468, 128, 128, 3, 1, True, 1),       # 16-row wide kernel, residual
+    (234, 234, 128, 128, 3, 1, True, 1),       # a variant chosen by item count: two images change the count
+    (117, 117, 256, 256, 3, 1, False, 1),
+    (468, 468, 64, 320, 3, 1, False, 1),       # head stems
+    (468, 468, 320, 18, 3, 1, False, 1),       # head outputs (fp32, narrow)
+    (468, 468, 128, 128, 3, 2, False, 1),      # stride-2 gather kernel (blockIdx.z = image)
+    (117, 117, 256, 128, 1, 1, False, 4),      # deblock: pixel shuffle into a channel slice
+])
+def test_conv_stack_of_images_is_one_launch(pkg, H, W, cin, cout, k, stride, res, shuffle):
+    """[B, H, W, C] input: DsvtConv2dPlugin walks the images inside ONE launch (handlesBatch); every image must come out exactly as when
+    it is convolved alone."""
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(H + cin + cout + k + stride)
+    B = 3
+    x = torch.randn(B, H, W, cin, generator=g).half().to(DEV)
+    if shuffle > 1:
+        w = torch.randn(cin, cout, shuffle, shuffle, generator=g) / np.sqrt(cin)
+        rows = P.deconv_weight_rows(w.numpy())
+    else:
+        w = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+        rows = P.conv_weight_rows(w.numpy())
+    b = (torch.randn(cout, generator=g) * 0.1).numpy()
+    pad = k // 2
+    Ho = ((H + 2 * pad - k) // stride + 1) * shuffle
+    kw = dict(relu=True, has_residual=res, out_f32=cout % 4 != 0, pixel_shuffle=shuffle)
+    if shuffle > 1:
+        kw.update(out_channel_stride=384, out_channel_offset=128)
+    r = torch.randn(B, Ho, Ho, cout, generator=g).half().to(DEV) if res else None
+    many = P.add_conv2d_op(rows, b, H, W, cin, cout, k, stride, pad, **kw)
+    one = P.add_conv2d_op(rows, b, H, W, cin, cout, k, stride, pad, **kw)
+    out = many(*([x] + ([r] if res else [])))[0]
+    torch.cuda.synchronize()
+    assert out.shape[0] == B
+    for i in range(B):
+        ref = one(*([x[i:i + 1].contiguous()] + ([r[i:i + 1].contiguous()] if res else [])))[0]
+        torch.cuda.synchronize()
+        sl = slice(128, 256) if shuffle > 1 else slice(None)
+        assert torch.equal(out[i][..., sl], ref[0][..., sl]), (i, float((out[i][..., sl].float() - ref[0][..., sl].float()).abs().max()))
