@@ -51,6 +51,7 @@ __global__ void __launch_bounds__(256)
 topk_hist(const float* __restrict__ head, TopKParams p, uint32_t* __restrict__ hist)
 {
     __shared__ uint32_t lh[TK_BINS];
+    head += (size_t)blockIdx.y * p.H * p.W * p.C; hist += (size_t)blockIdx.y * (TK_BINS + 64);      // blockIdx.y = frame of a stack
     for (int i = threadIdx.x; i < TK_BINS; i += 256) lh[i] = 0;
     __syncthreads();
     const int HW = p.H * p.W;
@@ -95,6 +96,8 @@ topk_collect(const float* __restrict__ head, TopKParams p, const uint32_t* __res
              uint2* __restrict__ cand)
 {
     __shared__ uint32_t sh[258];
+    head += (size_t)blockIdx.y * p.H * p.W * p.C; hist += (size_t)blockIdx.y * (TK_BINS + 64); count += (size_t)blockIdx.y * (TK_BINS + 64);
+    cand += (size_t)blockIdx.y * TK_CAP;
     uint32_t above;
     const uint32_t B = (uint32_t)thresholdBin(hist, p.K, sh, &above);
     if (blockIdx.x == 0 && threadIdx.x == 0) { count[2] = above; count[4] = B; }     // for topk_decode's second level / exact fallback
@@ -189,6 +192,11 @@ topk_decode(const float* __restrict__ head, TopKParams p, const uint32_t* __rest
     __shared__ uint32_t sh[4];
     __shared__ uint32_t nsel;
     const int t = threadIdx.x;
+    {   // blockIdx.x = frame of a stack
+        const size_t b = blockIdx.x, K = (size_t)p.K;
+        head += b * p.H * p.W * p.C; count += b * (TK_BINS + 64); cand += b * TK_CAP;
+        scores += b * K; classes += b * K; xs += b * K; ys += b * K; center += b * K * 2; center_z += b * K; angle += b * K; dim += b * K * 3;
+    }
     uint32_t Ma = count[3], Me = count[0];           // elements above the threshold bin (< K) / inside it
     const bool listOverflow = Me > TK_CAP - TK_SORT || Ma > TK_SORT;      // the arrival-ordered lists dropped elements: exact path below
     if (Ma > TK_SORT) Ma = TK_SORT;
@@ -266,6 +274,7 @@ public:
     TopKParams p_;
     explicit CenterHeadTopKPlugin(const TopKParams& p) : p_(p) {}
     const char* type() const override { return "CenterHeadTopKPlugin"; }
+    bool handlesBatch() const override { return true; }              // blockIdx.y / x = frame of a stack of head tensors
     int nbOutputs() const override { return 8; }
     int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
         const int b = in[0].d[0];
@@ -282,23 +291,24 @@ public:
         if (pos >= 2 && pos <= 4) return i32Linear(io[pos]);
         return pos >= 0 && pos <= 8 && f32Linear(io[pos]);
     }
-    size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override {
-        return alignUp(sizeof(uint32_t) * (TK_BINS + 64)) + alignUp(sizeof(uint2) * TK_CAP);
+    size_t workspaceSize(const DsvtPluginTensorDesc* in, int nbIn, const DsvtPluginTensorDesc*, int) const override {
+        const size_t nb = (in && nbIn > 0 && in[0].dims.nbDims >= 1 && in[0].dims.d[0] > 1) ? (size_t)in[0].dims.d[0] : 1;
+        return alignUp(sizeof(uint32_t) * (TK_BINS + 64) * nb) + alignUp(sizeof(uint2) * TK_CAP * nb);
     }
     int enqueue(const DsvtPluginTensorDesc* inDesc, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void* ws,
                 hipStream_t stream) override {
-        if (inDesc && inDesc[0].dims.nbDims > 0 && inDesc[0].dims.d[0] != 1) return -2;
+        const int nb = (inDesc && inDesc[0].dims.nbDims >= 1 && inDesc[0].dims.d[0] > 1) ? inDesc[0].dims.d[0] : 1;
         WsCarver c(ws);
-        uint32_t* hist = c.take<uint32_t>(TK_BINS + 64);
+        uint32_t* hist = c.take<uint32_t>((size_t)(TK_BINS + 64) * nb);          // per frame: histogram | counters
         uint32_t* count = hist + TK_BINS;
-        uint2* cand = c.take<uint2>(TK_CAP);
-        if (hipMemsetAsync(hist, 0, sizeof(uint32_t) * (TK_BINS + 64), stream) != hipSuccess) return lastError();
+        uint2* cand = c.take<uint2>((size_t)TK_CAP * nb);
+        if (hipMemsetAsync(hist, 0, sizeof(uint32_t) * (TK_BINS + 64) * nb, stream) != hipSuccess) return lastError();
         const float* head = static_cast<const float*>(in[0]);
         const int HW = p_.H * p_.W;
         int grid = cdiv(HW, 256); if (grid > 1024) grid = 1024;
-        hipLaunchKernelGGL(topk_hist, dim3(grid), dim3(256), 0, stream, head, p_, hist);
-        hipLaunchKernelGGL(topk_collect, dim3(grid), dim3(256), 0, stream, head, p_, hist, count, cand);
-        hipLaunchKernelGGL(topk_decode, dim3(1), dim3(1024), 0, stream, head, p_, count, cand, static_cast<float*>(out[0]),
+        hipLaunchKernelGGL(topk_hist, dim3(grid, nb), dim3(256), 0, stream, head, p_, hist);
+        hipLaunchKernelGGL(topk_collect, dim3(grid, nb), dim3(256), 0, stream, head, p_, hist, count, cand);
+        hipLaunchKernelGGL(topk_decode, dim3(nb), dim3(1024), 0, stream, head, p_, count, cand, static_cast<float*>(out[0]),
                            static_cast<int32_t*>(out[1]), static_cast<int32_t*>(out[2]), static_cast<int32_t*>(out[3]),
                            static_cast<float*>(out[4]), static_cast<float*>(out[5]), static_cast<float*>(out[6]),
                            static_cast<float*>(out[7]));

@@ -119,6 +119,7 @@ nms_sort(const float* __restrict__ rows, const uint32_t* __restrict__ count, int
 {
     __shared__ unsigned long long sk[NMS_MAX];       // (score key << 32) | ~row : descending = score desc, row asc (stable)
     const int t = threadIdx.x;
+    rows += (size_t)blockIdx.x * max_boxes * 9; count += blockIdx.x; order += (size_t)blockIdx.x * NMS_MAX; trig += (size_t)blockIdx.x * NMS_MAX;   // frame of a stack
     int n = (int)*count; if (n > max_boxes) n = max_boxes;
     unsigned long long e = 0ull;
     if (t < n) {
@@ -151,6 +152,8 @@ __global__ void __launch_bounds__(64)
 nms_mask(const float* __restrict__ rows, const uint32_t* __restrict__ count, const uint32_t* __restrict__ order,
          const float4* __restrict__ trig, int max_boxes, float thresh, unsigned long long* __restrict__ maskT)
 {
+    rows += (size_t)blockIdx.z * max_boxes * 9; count += blockIdx.z; order += (size_t)blockIdx.z * NMS_MAX; trig += (size_t)blockIdx.z * NMS_MAX;
+    maskT += (size_t)blockIdx.z * NMS_MAX * NMS_WORDS;                                                  // blockIdx.z = frame of a stack
     int n = (int)*count; if (n > max_boxes) n = max_boxes;
     const int j = blockIdx.x, wi = blockIdx.y, lane = threadIdx.x, i = wi * 64 + lane;
     if (j >= n) return;
@@ -182,6 +185,11 @@ nms_scan(const float* __restrict__ rows, const uint32_t* __restrict__ count, con
     __shared__ unsigned long long keptw[NMS_WORDS];
     __shared__ uint32_t kept[NMS_MAX];
     const int t = threadIdx.x, lane = t & 63;
+    {   // blockIdx.x = frame of a stack
+        const size_t b = blockIdx.x;
+        rows += b * max_boxes * 9; count += b; order += b * NMS_MAX; maskT += b * NMS_MAX * NMS_WORDS;
+        out_rows += b * max_boxes * 9; keep_idx += b * max_boxes; out_count += b;
+    }
     int n = (int)*count; if (n > max_boxes) n = max_boxes;
     {                                                // all loads of the mask in flight at once (8 per thread)
         unsigned long long v[NMS_WORDS];
@@ -261,6 +269,7 @@ public:
     int max_boxes_; float thresh_;
     RotatedNmsPlugin(int m, float t) : max_boxes_(m), thresh_(t) {}
     const char* type() const override { return "RotatedNmsPlugin"; }
+    bool handlesBatch() const override { return true; }              // blockIdx = frame of a stack of row sets
     int nbOutputs() const override { return 3; }
     int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
         if (i == 0) { *out = dims3(in[0].d[0], max_boxes_, 9); return 0; }
@@ -273,21 +282,22 @@ public:
         if (pos == 0 || pos == 2) return f32Lin(io[pos]);
         return pos >= 0 && pos <= 4 && i32Lin(io[pos]);
     }
-    size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override {
-        return alignUp(sizeof(uint32_t) * NMS_MAX) + alignUp(sizeof(unsigned long long) * NMS_MAX * NMS_WORDS) + alignUp(sizeof(float4) * NMS_MAX);
+    size_t workspaceSize(const DsvtPluginTensorDesc* in, int nbIn, const DsvtPluginTensorDesc*, int) const override {
+        const size_t nb = (in && nbIn > 0 && in[0].dims.nbDims >= 1 && in[0].dims.d[0] > 1) ? (size_t)in[0].dims.d[0] : 1;
+        return alignUp(sizeof(uint32_t) * NMS_MAX * nb) + alignUp(sizeof(unsigned long long) * NMS_MAX * NMS_WORDS * nb) + alignUp(sizeof(float4) * NMS_MAX * nb);
     }
     int enqueue(const DsvtPluginTensorDesc* inDesc, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void* ws,
                 hipStream_t stream) override {
-        if (inDesc && inDesc[0].dims.nbDims > 0 && inDesc[0].dims.d[0] != 1) return -2;
+        const int nb = (inDesc && inDesc[0].dims.nbDims >= 1 && inDesc[0].dims.d[0] > 1) ? inDesc[0].dims.d[0] : 1;
         WsCarver c(ws);
-        uint32_t* order = c.take<uint32_t>(NMS_MAX);
-        unsigned long long* mask = c.take<unsigned long long>((size_t)NMS_MAX * NMS_WORDS);
-        float4* trig = c.take<float4>(NMS_MAX);
+        uint32_t* order = c.take<uint32_t>((size_t)NMS_MAX * nb);
+        unsigned long long* mask = c.take<unsigned long long>((size_t)NMS_MAX * NMS_WORDS * nb);
+        float4* trig = c.take<float4>((size_t)NMS_MAX * nb);
         const float* rows = static_cast<const float*>(in[0]);
         const uint32_t* count = static_cast<const uint32_t*>(in[1]);
-        hipLaunchKernelGGL(nms_sort, dim3(1), dim3(512), 0, stream, rows, count, max_boxes_, order, trig);
-        hipLaunchKernelGGL(nms_mask, dim3(max_boxes_, cdiv(max_boxes_, 64)), dim3(64), 0, stream, rows, count, order, trig, max_boxes_, thresh_, mask);
-        hipLaunchKernelGGL(nms_scan, dim3(1), dim3(512), 0, stream, rows, count, order, mask, max_boxes_, static_cast<float*>(out[0]),
+        hipLaunchKernelGGL(nms_sort, dim3(nb), dim3(512), 0, stream, rows, count, max_boxes_, order, trig);
+        hipLaunchKernelGGL(nms_mask, dim3(max_boxes_, cdiv(max_boxes_, 64), nb), dim3(64), 0, stream, rows, count, order, trig, max_boxes_, thresh_, mask);
+        hipLaunchKernelGGL(nms_scan, dim3(nb), dim3(512), 0, stream, rows, count, order, mask, max_boxes_, static_cast<float*>(out[0]),
                            static_cast<int32_t*>(out[1]), static_cast<uint32_t*>(out[2]), zeroFill);
         return lastError();
     }

@@ -488,6 +488,11 @@ filter_box_kernel(const float* __restrict__ scores, const uint32_t* __restrict__
                   float* __restrict__ out, uint32_t* __restrict__ valid_num)
 {
     const int lane = threadIdx.x;
+    {   // blockIdx.x = frame of a stack of frames (every tensor has K rows per frame)
+        const size_t b = blockIdx.x, K = (size_t)p.max_top_k;
+        scores += b * K; classes += b * K; xs += b * K; ys += b * K; center += b * K * 2; center_z += b * K; angle += b * K; dim += b * K * 3;
+        out += b * K * 9; valid_num += b;
+    }
     uint32_t base = 0;
     for (int i0 = 0; i0 < p.max_top_k; i0 += kWave) {
         int i = i0 + lane;
@@ -523,6 +528,7 @@ public:
     FBParams p_;
     explicit FilterBoxByScorePlugin(const FBParams& p) : p_(p) {}
     const char* type() const override { return "FilterBoxByScorePlugin"; }
+    bool handlesBatch() const override { return true; }              // one wavefront per frame of a stack
     int nbOutputs() const override { return 2; }
     int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
         if (i == 0) { *out = dims3(in[0].d[0], p_.max_top_k, 9); return 0; }         // LAST_DIMS = 9
@@ -535,9 +541,10 @@ public:
         return pos >= 0 && pos <= 8 && f32Linear(io[pos]);
     }
     size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override { return 0; }
-    int enqueue(const DsvtPluginTensorDesc*, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void*,
+    int enqueue(const DsvtPluginTensorDesc* inDesc, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void*,
                 hipStream_t stream) override {
-        hipLaunchKernelGGL(filter_box_kernel, dim3(1), dim3(64), 0, stream, static_cast<const float*>(in[0]),
+        const int nb = (inDesc && inDesc[0].dims.nbDims >= 1 && inDesc[0].dims.d[0] > 1) ? inDesc[0].dims.d[0] : 1;
+        hipLaunchKernelGGL(filter_box_kernel, dim3(nb), dim3(64), 0, stream, static_cast<const float*>(in[0]),
                            static_cast<const uint32_t*>(in[1]), static_cast<const uint32_t*>(in[2]), static_cast<const uint32_t*>(in[3]),
                            static_cast<const float*>(in[4]), static_cast<const float*>(in[5]), static_cast<const float*>(in[6]),
                            static_cast<const float*>(in[7]), p_, true, static_cast<float*>(out[0]), static_cast<uint32_t*>(out[1]));
