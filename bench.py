@@ -46,7 +46,7 @@ PEAK_F32_MATRIX_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Pe
 PEAK_F16_MATRIX_TFLOPS = 2500.0     # same guide: "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBS = 8000.0               # same guide: "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured float4 copy)
 N_POINTS = 180000
-PMC_FILES = {1: "r02_d_pmc_traffic.json", 2: "r02_e_pmc_traffic.json"}      # FETCH_SIZE / WRITE_SIZE passes, by frames per forward()
+PMC_FILES = {1: "r02_d_pmc_traffic.json", 2: "r02_f_pmc_traffic.json"}      # FETCH_SIZE / WRITE_SIZE passes, by frames per forward()
 FRAME_POOL = 4                      # distinct synthetic clouds cycled through by the steps
 
 

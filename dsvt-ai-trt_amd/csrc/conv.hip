@@ -45,7 +45,9 @@ struct ConvArgs {
     int KH, KW, stride, pad, up, relu;
     int wide;                                    // halo kernel: 16-byte epilogue accesses are legal (channel strides / offsets % 8, Cout % 16, fp16 output)
     int nb;                                      // images per launch (>= 1): image b = pixels b*H*W .. of `in`, b*Ho*up*Wo*up .. of `out` / `res`
+    unsigned long long* trace;                   // debugging (DSVT_CONV_TRACE=1, tools/trace_conv.py): s_memtime stamps of waves 0 and NW/2, or nullptr
 };
+constexpr int CONV_TRACE_N = 256;               // stamps per traced wave
 
 
 // bias / residual / ReLU / store of four consecutive output channels co..co+3 of output pixel opix
@@ -334,7 +336,7 @@ typedef __attribute__((address_space(3))) void* glds_dst_t;
 
 // end of a K slab: this wave's LDS-DMA requests older than the youngest `keep` have landed, then the workgroup barrier
 // publishes them (LDS-DMA data is ordered for a ds_read only by the issuing wave's vmcnt followed by a barrier)
-__device__ __forceinline__ void slabBarrier(int keep) {
+__device__ __forceinline__ void slabWait(int keep) {
     switch (keep) {          // wave-uniform
         case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
         case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory"); break;
@@ -350,6 +352,9 @@ __device__ __forceinline__ void slabBarrier(int keep) {
         case 11: asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory"); break;
         default: asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); break;
     }
+}
+__device__ __forceinline__ void slabBarrier(int keep) {
+    slabWait(keep);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
@@ -636,6 +641,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     constexpr int NRS = (PPW + PPS - 1) / PPS;                    // ... over this many slabs
     constexpr int CH = CT > 4 ? 4 : CT;                           // A fragments read per batch
     constexpr int LEAD = NWB - 1;
+    constexpr bool TRICKLE = CT == 8 && NW == 8;                  // requests spread over the slab (see the slab loop)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WT_HBYTES + NWB * WT_WBYTES + 1024];      // halo[2] | wslab[NWB] | bias
     constexpr int BIAS_OFF = 2 * WT_HBYTES + NWB * WT_WBYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
@@ -659,14 +665,15 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + hb * WT_HBYTES + pc * 1024), 16, 0, 0);
     };
     // the 16 fragment rows of slab sl (steps SPS sl ...) of chunk ch -> buffer wb
+    auto weightRequest = [&](int sl, int ch, int wb, int j) {
+        const int u = wave + NW * j, step = SPS * sl + u / CT, ph = step / 9, tap = step - 9 * ph;
+        if ((SPS * CT) % NW != 0 && u >= SPS * CT) return;
+        const size_t row = (size_t)(2 * ((ph >> 1) * 9 + tap) + (ph & 1)) * NCT + ch * CT + u % CT;
+        __builtin_amdgcn_global_load_lds((glds_src_t)(Wp + (row * 64 + lane) * 8), (glds_dst_t)(smem + 2 * WT_HBYTES + wb * WT_WBYTES + u * 1024), 16, 0, 0);
+    };
     auto weightRequests = [&](int sl, int ch, int wb) {
 #pragma unroll
-        for (int j = 0; j < C::RPW; ++j) {
-            const int u = wave + NW * j, step = SPS * sl + u / CT, ph = step / 9, tap = step - 9 * ph;
-            if ((SPS * CT) % NW != 0 && u >= SPS * CT) break;
-            const size_t row = (size_t)(2 * ((ph >> 1) * 9 + tap) + (ph & 1)) * NCT + ch * CT + u % CT;
-            __builtin_amdgcn_global_load_lds((glds_src_t)(Wp + (row * 64 + lane) * 8), (glds_dst_t)(smem + 2 * WT_HBYTES + wb * WT_WBYTES + u * 1024), 16, 0, 0);
-        }
+        for (int j = 0; j < C::RPW; ++j) weightRequest(sl, ch, wb, j);
     };
 
     // the chunk's bias (CT * 16 floats) travels as one more LDS-DMA piece and the accumulators start from it: the epilogue of a
@@ -681,8 +688,14 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
 
     int item = blockIdx.x;
     if (item >= nitems) return;
+    int nmark = 0;
+    const bool tracing = a.trace != nullptr && (wave == 0 || wave == NW / 2);
+    auto mark = [&]() {
+        if (tracing) { if (lane == 0 && nmark < CONV_TRACE_N) a.trace[(size_t)(blockIdx.x * 2 + (wave != 0)) * CONV_TRACE_N + nmark] = clock64(); ++nmark; }
+    };
     int y0, x0, chunk, bimg;
     decode(item, y0, x0, chunk, bimg);
+    mark();
     if (wave == 0) biasRequest(chunk);
 #pragma unroll
     for (int i = 0; i < PPW; ++i)
@@ -709,29 +722,36 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
 #pragma unroll 1
         for (int s = 0; s < NSLAB; ++s) {
             // halo of phase P (the phase after the one this slab starts in): its buffer is free once phase P - 2 has ended, i.e.
-            // from slab s0 = ceil(9 (P - 1) / SPS) on, and the first slab that touches phase P is floor(9 P / SPS) > s0 + NRS - 1
-            {
-                const int P = (SPS * s) / 9 + 1, k = s - (9 * (P - 1) + SPS - 1) / SPS;
-                const bool inItem = P < NP;
-                if (k < NRS && (inItem || have_next) && !(dbg & 1)) {
-                    const int yy = inItem ? y0 : ny0, xx = inItem ? x0 : nx0, ph = inItem ? P : 0, bb = inItem ? bimg : nbimg;
+            // from slab s0 = ceil(9 (P - 1) / SPS) on, and the first slab that touches phase P is floor(9 P / SPS) > s0 + NRS - 1.
+            // Weights of the slab LEAD ahead.  With LEAD = 2 the halo requests of a slab come BEFORE its weight requests: the slab-end
+            // wait keeps exactly the weight requests in flight.  The requests of a slab are not issued in one go: a wave that issues
+            // is held while the CU's request path works through the queue (measured with s_memtime stamps, tools/trace_conv.py:
+            // 300 cycles per request when all eight waves issue at the slab start, 600-1350 cycles per slab with the matrix pipe
+            // idle), so request j goes out after the MFMAs of batch j * NBI / NREQ, when the wave would wait for the pipe anyway.
+            const int hP = (SPS * s) / 9 + 1, hk = s - (9 * (hP - 1) + SPS - 1) / SPS;
+            const bool hIn = hP < NP, hOn = hk < NRS && (hIn || have_next) && !(dbg & 1);
+            const int hyy = hIn ? y0 : ny0, hxx = hIn ? x0 : nx0, hph = hIn ? hP : 0, hbb = hIn ? bimg : nbimg;
+            const int wt = s + LEAD, wbt = (wb + LEAD) % NWB;
+            const bool wIn = wt < NSLAB, wIssued = (wIn || have_next) && !(dbg & 2);
+            const int wsl = wIn ? wt : wt - NSLAB, wch = wIn ? chunk : nch;
+            auto request = [&](int j) {                                // j: 0 .. NREQ - 1 (compile-time after unrolling)
+                const int jh = LEAD == 2 ? j : j - C::RPW, jw = LEAD == 2 ? j - PPS : j;       // (LEAD = 1: weights first, they are awaited at this slab's end)
+                if (jh >= 0 && jh < PPS) {
+                    const int pc = wave + NW * (hk * PPS + jh);
+                    if (hOn && hk * PPS + jh < PPW && pc < WT_NPC) haloRequest(pc, hyy, hxx, hph, hP & 1, hbb);
+                }
+                if (jw >= 0 && jw < C::RPW && wIssued) {
+                    if (jw == 0 && !wIn && wt == NSLAB && wave == 0) biasRequest(nch);   // (before the weights: retired with the older requests)
+                    weightRequest(wsl, wch, wbt, jw);
+                }
+            };
+            constexpr int NREQ = PPS + C::RPW;
+            mark();                                                  // [5 s + 1] slab start
+            if (!TRICKLE) {
 #pragma unroll
-                    for (int i = 0; i < PPS; ++i) {
-                        const int pc = wave + NW * (k * PPS + i);
-                        if (k * PPS + i < PPW && pc < WT_NPC) haloRequest(pc, yy, xx, ph, P & 1, bb);
-                    }
-                }
+                for (int j = 0; j < NREQ; ++j) request(j);
             }
-            // weights of the slab LEAD ahead, AFTER this slab's halo requests: the slab-end wait keeps exactly these in flight
-            bool wIssued = false;
-            if (!(dbg & 2)) {
-                const int t = s + LEAD, wbt = (wb + LEAD) % NWB;
-                if (t < NSLAB) { weightRequests(t, chunk, wbt); wIssued = true; }
-                else if (have_next) {
-                    if (t == NSLAB && wave == 0) biasRequest(nch);   // (before the weights: retired with the older requests)
-                    weightRequests(t - NSLAB, nch, wbt); wIssued = true;
-                }
-            }
+            mark();                                                  // [5 s + 2] requests issued
             // fragments are double buffered by hand: the reads of batch b + 1 (CH channel tiles x 4 pixel tiles = 4 CH MFMAs) are
             // issued BEFORE the MFMAs of batch b (left to itself hipcc emits read, s_waitcnt lgkmcnt(0), 8 MFMAs, read, ...)
             {
@@ -766,11 +786,25 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                                 acc[c0 + ct][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[b & 1][ct], Bf[u & 1][m], acc[c0 + ct][m], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    if (TRICKLE) {
+                        constexpr int NBI = (LEAD == 2 || NB == 1) ? NB : NB - 1;      // (LEAD = 1: nothing in the last batch, the slab-end wait follows it)
+#pragma unroll
+                        for (int j = 0; j < NREQ; ++j)
+                            if (j * NBI / NREQ == b) request(j);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
-            slabBarrier(LEAD == 2 && wIssued ? wreq : 0);
+            if (a.trace) {                                           // (wave-uniform; the wait and the barrier stamped apart)
+                mark();                                              // [5 s + 3] MFMAs issued
+                slabWait(LEAD == 2 && wIssued ? wreq : 0);
+                mark();                                              // [5 s + 4] own requests landed
+                __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+                mark();                                              // [5 s + 5] barrier passed
+            } else slabBarrier(LEAD == 2 && wIssued ? wreq : 0);
             wb = (wb + 1) % NWB;
         }
+        mark();
         // residual / ReLU / store (the bias is in the accumulators)
         if (!(dbg & 8)) {
             const int n0 = chunk * CT * 16;
@@ -821,6 +855,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                 }
             }
         }
+        mark();
         if (!have_next) break;
         // (the epilogue's loads and stores retire at the first slab end of the next item: nothing else is in flight)
         item = nitem; y0 = ny0; x0 = nx0; chunk = nch; bimg = nbimg;
@@ -1035,6 +1070,27 @@ public:
         a.wide = !c_.out_f32 && c_.Cout % 16 == 0 && c_.out_ld % 8 == 0 && c_.out_coff % 8 == 0 && (!c_.has_res || a.res_ld % 8 == 0);
         a.nb = (inDesc && inDesc[0].dims.nbDims == 4 && inDesc[0].dims.d[0] > 1) ? inDesc[0].dims.d[0] : 1;
         if ((long)a.nb * c_.H * c_.W * c_.Cin >= (1l << 31)) return -2;                // the halo kernel addresses the input with 32-bit element offsets
+        static int tron = -1;                                                          // tools/trace_conv.py
+        if (tron < 0) { const char* e = getenv("DSVT_CONV_TRACE"); tron = e ? atoi(e) : 0; }
+        if (tron && wp_dev_) {
+            static unsigned long long* tr = nullptr;
+            const size_t n = (size_t)4096 * 2 * CONV_TRACE_N;
+            if (!tr && hipMalloc(&tr, n * 8) != hipSuccess) return -3;
+            (void)hipMemsetAsync(tr, 0, n * 8, stream);
+            a.trace = tr;
+            const int rc = launchConvHalo(a, wp_dev_, zeros_dev_, stream);
+            (void)hipStreamSynchronize(stream);
+            std::vector<unsigned long long> h(n);
+            (void)hipMemcpy(h.data(), tr, n * 8, hipMemcpyDeviceToHost);
+            for (int wg : {0, 1, 131, 255})
+                for (int hw = 0; hw < 2; ++hw) {
+                    const unsigned long long* t = h.data() + (size_t)(wg * 2 + hw) * CONV_TRACE_N;
+                    fprintf(stderr, "[conv trace wg%d wave%s t0=%llu]", wg, hw ? "N/2" : "0", t[0] - h[0]);
+                    for (int i = 1; i < CONV_TRACE_N && t[i]; ++i) fprintf(stderr, " %lld", (long long)(t[i] - t[0]));
+                    fprintf(stderr, "\n");
+                }
+            return rc;
+        }
         if (wp_dev_) return launchConvHalo(a, wp_dev_, zeros_dev_, stream);
         return launchConv(a, KC(), stream);
     }

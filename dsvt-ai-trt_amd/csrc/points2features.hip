@@ -35,7 +35,8 @@ struct P2FParams {
 };
 
 constexpr uint32_t kNone = 0xffffffffu;
-constexpr int kTile = 1024;     // cells per scan tile (256 threads x 4)
+constexpr int kCPT = 16;         // consecutive cells per thread of the scan
+constexpr int kTile = 256 * kCPT;   // cells per scan tile: the look-back chain is one link per tile (1024-cell tiles, 428 links for two frames: 43 us)
 
 __global__ void __launch_bounds__(256)
 p2f_count(const float4* __restrict__ pts, const uint32_t* __restrict__ n_ptr, P2FParams p,
@@ -101,17 +102,20 @@ p2f_scan(const uint32_t* __restrict__ cell_cnt, int ncell, P2FParams p, uint64_t
     __syncthreads();
     const int tile = (int)s_tile;
     uint64_t* state = scan_state + 1;
-    const int base = tile * kTile + threadIdx.x * 4;
-    uint32_t c[4], o[4], f[4], k[4], so = 0, sf = 0, sk = 0;
-    if (base + 3 < ncell) {
-        const uint4 v = *reinterpret_cast<const uint4*>(cell_cnt + base);
-        c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+    const int base = tile * kTile + threadIdx.x * kCPT;
+    uint32_t c[kCPT], o[kCPT], f[kCPT], k[kCPT], so = 0, sf = 0, sk = 0;
+    if (base + kCPT - 1 < ncell) {
+#pragma unroll
+        for (int q = 0; q < kCPT / 4; ++q) {
+            const uint4 v = *reinterpret_cast<const uint4*>(cell_cnt + base + 4 * q);
+            c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+        }
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) c[j] = (base + j) < ncell ? cell_cnt[base + j] : 0;
+        for (int j = 0; j < kCPT; ++j) c[j] = (base + j) < ncell ? cell_cnt[base + j] : 0;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { cellTriple(c[j], T, o[j], f[j], k[j]); so += o[j]; sf += f[j]; sk += k[j]; }
+    for (int j = 0; j < kCPT; ++j) { cellTriple(c[j], T, o[j], f[j], k[j]); so += o[j]; sf += f[j]; sk += k[j]; }
     uint32_t to, tf, tk;
     uint32_t eo = blockExclusiveScan<256>(so, smem, &to);
     uint32_t ef = blockExclusiveScan<256>(sf, smem, &tf);
@@ -150,7 +154,7 @@ p2f_scan(const uint32_t* __restrict__ cell_cnt, int ncell, P2FParams p, uint64_t
     const uint32_t maxP = (uint32_t)p.max_pillars_num, maxN = (uint32_t)p.max_points_num_voxel_filter;
     const uint32_t gxy = (uint32_t)(p.gx * p.gy);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < kCPT; ++j) {
         const int cell = base + j;
         if (cell < ncell) {
             cell_seg[cell] = ef;
