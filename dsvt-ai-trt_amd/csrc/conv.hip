@@ -629,7 +629,7 @@ struct WideCfg {
 // in flight (one slab of MFMAs, 0.5-1 us, is shorter than an L2 -> LDS round trip under load); 2 where LDS must hold two workgroups.
 // RW = tile rows per wave: 2 (64 pixels, four pixel tiles) or 1 (32 pixels, two pixel tiles: twice the waves on the same tile --
 // for the small layers, where one wave per SIMD cannot hide its own LDS-DMA issue and wait time)
-template <int CT, int NW, int HS, int SPS = (CT == 8 ? 2 : 4), int NWB = 3, int RW = 2>
+template <int CT, int NW, int HS, int SPS = (CT == 8 ? 2 : 4), int NWB = 3, int RW = 2, bool TR = false>
 __global__ void __launch_bounds__(64 * NW, (NW * (RW == 1 ? 1 : 2) <= 8 && (NW == 4 || RW == 1)) ? 2 : 1)
 conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __restrict__ zeros, int tilesX, int nitems, int nchunk, int dbg)
 {
@@ -641,7 +641,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     constexpr int NRS = (PPW + PPS - 1) / PPS;                    // ... over this many slabs
     constexpr int CH = CT > 4 ? 4 : CT;                           // A fragments read per batch
     constexpr int LEAD = NWB - 1;
-    constexpr bool TRICKLE = CT == 8 && NW == 8;                  // requests spread over the slab (see the slab loop)
+    constexpr bool TRICKLE = CT == 8 && NW == 8 && LEAD == 2;     // requests spread over the slab (see the slab loop)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WT_HBYTES + NWB * WT_WBYTES + 1024];      // halo[2] | wslab[NWB] | bias
     constexpr int BIAS_OFF = 2 * WT_HBYTES + NWB * WT_WBYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
@@ -689,9 +689,11 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     int item = blockIdx.x;
     if (item >= nitems) return;
     int nmark = 0;
-    const bool tracing = a.trace != nullptr && (wave == 0 || wave == NW / 2);
+    const bool tracing = TR && a.trace != nullptr && (wave == 0 || wave == NW / 2);      // (TR: the instrumented instantiation, tools/trace_conv.py)
     auto mark = [&]() {
-        if (tracing) { if (lane == 0 && nmark < CONV_TRACE_N) a.trace[(size_t)(blockIdx.x * 2 + (wave != 0)) * CONV_TRACE_N + nmark] = clock64(); ++nmark; }
+        if constexpr (TR) {
+            if (tracing) { if (lane == 0 && nmark < CONV_TRACE_N) a.trace[(size_t)(blockIdx.x * 2 + (wave != 0)) * CONV_TRACE_N + nmark] = clock64(); ++nmark; }
+        }
     };
     int y0, x0, chunk, bimg;
     decode(item, y0, x0, chunk, bimg);
@@ -723,11 +725,13 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         for (int s = 0; s < NSLAB; ++s) {
             // halo of phase P (the phase after the one this slab starts in): its buffer is free once phase P - 2 has ended, i.e.
             // from slab s0 = ceil(9 (P - 1) / SPS) on, and the first slab that touches phase P is floor(9 P / SPS) > s0 + NRS - 1.
-            // Weights of the slab LEAD ahead.  With LEAD = 2 the halo requests of a slab come BEFORE its weight requests: the slab-end
-            // wait keeps exactly the weight requests in flight.  The requests of a slab are not issued in one go: a wave that issues
-            // is held while the CU's request path works through the queue (measured with s_memtime stamps, tools/trace_conv.py:
-            // 300 cycles per request when all eight waves issue at the slab start, 600-1350 cycles per slab with the matrix pipe
-            // idle), so request j goes out after the MFMAs of batch j * NBI / NREQ, when the wave would wait for the pipe anyway.
+            // Weights of the slab LEAD ahead; the halo requests of a slab come BEFORE its weight requests: with LEAD = 2 the slab-end
+            // wait keeps exactly the weight requests in flight.  In the 128-channel kernel (TRICKLE) the requests of a slab are not
+            // issued in one go: a wave that issues is held while the CU's request path works through its queue (s_memtime stamps,
+            // tools/trace_conv.py: 300 cycles per request when all eight waves issue at the slab start, 600-1350 cycles per slab
+            // with the matrix pipe idle), so request j goes out after the MFMAs of batch j * NB / NREQ, when the wave would wait
+            // for the pipe anyway: 88 -> 84 us (128 -> 128 channels), 123 -> 115 us (192 -> 128).  (Neutral to harmful on the
+            // 64-channel variants, whose slabs hold four steps: 384 -> 64 channels 125 -> 144 us.)
             const int hP = (SPS * s) / 9 + 1, hk = s - (9 * (hP - 1) + SPS - 1) / SPS;
             const bool hIn = hP < NP, hOn = hk < NRS && (hIn || have_next) && !(dbg & 1);
             const int hyy = hIn ? y0 : ny0, hxx = hIn ? x0 : nx0, hph = hIn ? hP : 0, hbb = hIn ? bimg : nbimg;
@@ -735,7 +739,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
             const bool wIn = wt < NSLAB, wIssued = (wIn || have_next) && !(dbg & 2);
             const int wsl = wIn ? wt : wt - NSLAB, wch = wIn ? chunk : nch;
             auto request = [&](int j) {                                // j: 0 .. NREQ - 1 (compile-time after unrolling)
-                const int jh = LEAD == 2 ? j : j - C::RPW, jw = LEAD == 2 ? j - PPS : j;       // (LEAD = 1: weights first, they are awaited at this slab's end)
+                const int jh = j, jw = j - PPS;
                 if (jh >= 0 && jh < PPS) {
                     const int pc = wave + NW * (hk * PPS + jh);
                     if (hOn && hk * PPS + jh < PPW && pc < WT_NPC) haloRequest(pc, hyy, hxx, hph, hP & 1, hbb);
@@ -747,9 +751,18 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
             };
             constexpr int NREQ = PPS + C::RPW;
             mark();                                                  // [5 s + 1] slab start
-            if (!TRICKLE) {
+            if constexpr (!TRICKLE) {                                // all requests of the slab at its start
+                if (hOn) {
 #pragma unroll
-                for (int j = 0; j < NREQ; ++j) request(j);
+                    for (int i = 0; i < PPS; ++i) {
+                        const int pc = wave + NW * (hk * PPS + i);
+                        if (hk * PPS + i < PPW && pc < WT_NPC) haloRequest(pc, hyy, hxx, hph, hP & 1, hbb);
+                    }
+                }
+                if (wIssued) {
+                    if (!wIn && wt == NSLAB && wave == 0) biasRequest(nch);   // (before the weights: retired with the older requests)
+                    weightRequests(wsl, wch, wbt);
+                }
             }
             mark();                                                  // [5 s + 2] requests issued
             // fragments are double buffered by hand: the reads of batch b + 1 (CH channel tiles x 4 pixel tiles = 4 CH MFMAs) are
@@ -787,15 +800,14 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (TRICKLE) {
-                        constexpr int NBI = (LEAD == 2 || NB == 1) ? NB : NB - 1;      // (LEAD = 1: nothing in the last batch, the slab-end wait follows it)
 #pragma unroll
                         for (int j = 0; j < NREQ; ++j)
-                            if (j * NBI / NREQ == b) request(j);
+                            if (j * NB / NREQ == b) request(j);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
-            if (a.trace) {                                           // (wave-uniform; the wait and the barrier stamped apart)
+            if (TR && a.trace) {                                     // (wave-uniform; the wait and the barrier stamped apart)
                 mark();                                              // [5 s + 3] MFMAs issued
                 slabWait(LEAD == 2 && wIssued ? wreq : 0);
                 mark();                                              // [5 s + 4] own requests landed
@@ -926,6 +938,7 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
             // halo row stride 36 pixels, not 40: 134,144 B of LDS instead of 142,336, which leaves room for the 23 KB workgroups of the
             // OTHER frame's set-attention kernel on the same CU (two frames in flight: a gather-bound kernel under an MFMA-bound one)
             else if (ctWide == 8 && wideOn == 13) hipLaunchKernelGGL((conv_wide_kernel<8, 8, 40, 2, 3>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk, dbgW);
+            else if (ctWide == 8 && a.trace) hipLaunchKernelGGL((conv_wide_kernel<8, 8, 36, 2, 3, 2, true>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk, dbgW);
             else if (ctWide == 8) hipLaunchKernelGGL((conv_wide_kernel<8, 8, 36, 2, 3>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk, dbgW);
             else if (rows14) hipLaunchKernelGGL((conv_wide_kernel<4, 7, 40, 4, 2>), dim3(grid), dim3(448), 0, stream, a, Wp, zeros, tilesX, n14, nchunk, dbgW);
             else hipLaunchKernelGGL((conv_wide_kernel<4, 8, 40, 4, 2>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk, dbgW);
