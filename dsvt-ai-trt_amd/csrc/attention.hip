@@ -41,6 +41,7 @@ struct AttnArgs {
     const uint32_t* set_num; int max_sets;
     void* out; int out_ld;               // fp32 or (IO16) fp16
     int C, H;
+    int dbg;                             // timing ablations of the fp16 kernel (wrong results): 1 no gathers, 2 no stores, 4 no arithmetic
 };
 
 // IO16: Q/K/V rows arrive as fp16 and the result is written as fp16; the arithmetic in between
@@ -209,7 +210,8 @@ constexpr int AQL = 104;      // halfs per staged Q / K row
 constexpr int AVL = 40;       // halfs per staged V^T row (36 keys + 4: 80-byte rows, conflict-free 8-byte fragment reads; the reads of
                               // keys >= 40 -- lane groups g >= 2 of the third key tile -- run into the next row and are discarded)
 
-__global__ void __launch_bounds__(256)
+// (waves-per-SIMD hint 6: 73 registers = six workgroups per CU; without it hipcc takes 76 + 36 accumulation registers = four)
+__global__ void __launch_bounds__(256, 6)
 set_attention_f16_kernel(AttnArgs a)
 {
     __shared__ __attribute__((aligned(16))) _Float16 sQ[AL * AQL];
@@ -263,7 +265,8 @@ set_attention_f16_kernel(AttnArgs a)
     ahalf8 val[NIT];
 #pragma unroll
     for (int k = 0; k < NIT; ++k)
-        val[k] = *reinterpret_cast<const ahalf8*>(static_cast<const _Float16*>(a.qkv) + (size_t)rowOf[k] * a.qkv_ld + segOf[k] * a.C + hq * (AHB * ADH) + c8Of[k]);
+        val[k] = (a.dbg & 1) ? ahalf8{0, 0, 0, 0, 0, 0, 0, 0}
+                             : *reinterpret_cast<const ahalf8*>(static_cast<const _Float16*>(a.qkv) + (size_t)rowOf[k] * a.qkv_ld + segOf[k] * a.C + hq * (AHB * ADH) + c8Of[k]);
     if (tid < AL) sRow[tid] = myRow;
     if (tid < AHB * AL) sMask[tid / AL][tid % AL] = myMask;
 #pragma unroll
@@ -276,6 +279,7 @@ set_attention_f16_kernel(AttnArgs a)
             for (int j = 0; j < 8; ++j) sVt[(c8Of[k] + j) * AVL + slotOf[k]] = val[k][j];
         }
     __syncthreads();
+    if (a.dbg & 4) return;
 
     const int hoff = wave * ADH;
     const ahalf8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -296,34 +300,32 @@ set_attention_f16_kernel(AttnArgs a)
                 sc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t], qf[u], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     }
     // ---- softmax over keys for each query column (lane holds keys 16t + 4g + i, query 16u + r) ----
+    // The ablations (DSVT_ATTN_DBG, tools/one_attn.py) put 21 of the launch's 33 us in this arithmetic, not in the gathers: seven
+    // workgroups per CU share four SIMDs and expf alone expanded to 13 instructions x 36 scores per lane.  Here a score costs one add
+    // (mask; -inf for the padded keys 36..47, so no select), one fma and one v_exp_f32 (exp2 of (s - max) * log2 e: arguments <= 0),
+    // and the row sum one v_rcp_f32 -- both within 1 ulp, far below the fp16 rounding of P that follows.
+    constexpr float kLog2e = 1.4426950408889634f;
     float mk[3][4];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { int key = 16 * t + 4 * g + i; mk[t][i] = key < AL ? sMask[wave][key] : 0.f; }
+        for (int i = 0; i < 4; ++i) { int key = 16 * t + 4 * g + i; mk[t][i] = key < AL ? sMask[wave][key] : -INFINITY; }
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int key = 16 * t + 4 * g + i;
-                float v = key < AL ? sc[t][u][i] + mk[t][i] : -INFINITY;
-                sc[t][u][i] = v; mx = fmaxf(mx, v);
-            }
+            for (int i = 0; i < 4; ++i) { const float v = sc[t][u][i] + mk[t][i]; sc[t][u][i] = v; mx = fmaxf(mx, v); }
         mx = fmaxf(mx, __shfl_xor(mx, 16, kWave)); mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+        const float nm = -mx * kLog2e;
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int key = 16 * t + 4 * g + i;
-                float e = key < AL ? expf(sc[t][u][i] - mx) : 0.f;
-                sc[t][u][i] = e; sum += e;
-            }
+            for (int i = 0; i < 4; ++i) { const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[t][u][i], kLog2e, nm)); sc[t][u][i] = e; sum += e; }
         sum += __shfl_xor(sum, 16, kWave); sum += __shfl_xor(sum, 32, kWave);
-        float inv = 1.0f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -356,6 +358,7 @@ set_attention_f16_kernel(AttnArgs a)
     }
     // ---- write back: lane holds query 16u + r, channels 16dt + 4g + i -------------------------
     const int h = hq * AHB + wave;
+    if (a.dbg & 2) return;
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         const int q = 16 * u + r;
@@ -371,7 +374,10 @@ set_attention_f16_kernel(AttnArgs a)
     }
 }
 
-static int launchAttention(const AttnArgs& a, bool io16, hipStream_t stream) {
+static int launchAttention(const AttnArgs& a_, bool io16, hipStream_t stream) {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("DSVT_ATTN_DBG"); dbg = e ? atoi(e) : 0; }
+    AttnArgs a = a_; a.dbg = dbg;
     dim3 grid((unsigned)(a.max_sets * (a.H / AHB))), block(256);
     static int f16mma = -1;        // DSVT_ATTN_F32MMA=1: fp16 I/O on the fp32 matrix instructions (the previous kernel)
     if (f16mma < 0) { const char* e = getenv("DSVT_ATTN_F32MMA"); f16mma = (e && atoi(e)) ? 0 : 1; }

@@ -19,3 +19,9 @@ op = pipe.layers[(0, 0)]["attn"]
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
     op(qkv, inds, mask, S)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(50):
+    op(qkv, inds, mask, S)
+e1.record(); torch.cuda.synchronize()
+print(f"attention {e0.elapsed_time(e1) / 50 * 1e3:.1f} us per launch (DSVT_ATTN_DBG={os.environ.get('DSVT_ATTN_DBG', '0')})")
