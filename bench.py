@@ -4,9 +4,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Two frames per forward() (their pillar rows concatenated: one launch per backbone layer for both, `--batch`) on each of two streams
-(`--streams`) are the default: 558 frames/s against 532 with one frame per forward and 441 with a single frame in flight; p50_ms is
-the per-frame latency of that mode (a frame is done when its forward() is).
+Four frames per forward() (their pillar rows concatenated: one launch per backbone layer for all of them, `--batch`; BASELINE
+configs[3] puts four frames on each GPU per batch) on each of two streams (`--streams`) are the default.  Measured on one MI355X
+(frames/s, p50 per-frame ms; a frame is done when its forward() is), frames per forward x streams:
+    1 x 1  455 / 2.2      1 x 2  540 / 3.7      2 x 1  513 / 3.9      2 x 2  575 / 6.8
+    3 x 2  606 / 9.6      4 x 1  539 / 7.4      4 x 2  623 / 12.4 (default)
+`--batch 1 --streams 1` is the latency mode (the reference's own: one frame at a time).
 
 A step = one frame through the whole pipeline (BASELINE.json configs[2]: Waymo-shaped
 180k-point synthetic cloud `lidar_like(180000, seed)`, 0.32 m pillars, 468x468 BEV grid, full
@@ -46,7 +49,7 @@ PEAK_F32_MATRIX_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Pe
 PEAK_F16_MATRIX_TFLOPS = 2500.0     # same guide: "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBS = 8000.0               # same guide: "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured float4 copy)
 N_POINTS = 180000
-PMC_FILES = {1: "r02_d_pmc_traffic.json", 2: "r02_f_pmc_traffic.json"}      # FETCH_SIZE / WRITE_SIZE passes, by frames per forward()
+PMC_FILES = {1: "r02_g_batch1_pmc_traffic.json", 2: "r02_g_pmc_traffic.json", 4: "r02_h_pmc_traffic.json"}      # FETCH_SIZE / WRITE_SIZE passes, by frames per forward()
 FRAME_POOL = 4                      # distinct synthetic clouds cycled through by the steps
 
 
@@ -152,10 +155,9 @@ def main():
     ap.add_argument("--streams", type=int, default=2,
                     help="frames in flight per GPU: independent pipeline instances on separate HIP streams (a single "
                          "180k-point frame leaves most kernels one wave per SIMD; overlapping two frames fills the gaps)")
-    ap.add_argument("--batch", type=int, default=2,
+    ap.add_argument("--batch", type=int, default=4,
                     help="frames per forward(): their pillar rows are concatenated and every backbone layer is ONE launch for all of them "
-                         "(DsvtPipeline(frames=B)); a step is still one frame, --steps must be a multiple of B.  Measured (MI355X, streams x batch): "
-                         "1x1 441, 2x1 532, 1x2 458, 2x2 558, 3x2 521, 1x4 460 frames/s; p50 per frame 2.2 / 3.7 / 4.3 / 7.1 ms")
+                         "(DsvtPipeline(frames=B)); a step is still one frame, --steps must be a multiple of B (the table in this file's docstring)")
     ap.add_argument("--no-graph", action="store_true", help="launch every op from the host instead of replaying a HIP graph")
     ap.add_argument("--event-every", type=int, default=0,
                     help="roofline sample: every N-th timed step runs un-graphed, alone on the GPU, with HIP events around each launch; "
@@ -193,8 +195,8 @@ def main():
     FB = max(1, args.batch) if args.dtype == "f16" else 1          # (the fp32 mode has no multi-frame path)
     if args.host_input:
         FB = 1
-    if args.steps % FB:
-        raise SystemExit(f"bench.py: --steps {args.steps} is not a multiple of --batch {FB}")
+    while args.steps % FB:          # exactly K timed frames: the largest frames-per-forward <= --batch that divides K
+        FB -= 1
     caps = pkg.pipeline.Caps() if FB == 1 else pkg.pipeline.Caps.for_frames(FB)     # 196608 points per frame; pillar / window / set capacities are totals
     weights = pkg.synth.make_weights()
     f16 = args.dtype == "f16"

@@ -109,6 +109,7 @@ struct MlpStreamArgs {
     unsigned long long* trace;                       // debugging: per-workgroup phase timestamps, or nullptr
     int ncu;                                         // CUs of the device (tile plan, see the kernel)
     int dbg;                                         // timing ablations (wrong results): 1 no LN1, 2 no GELU, 4 no final LNs, 8 no stores, 16 no MFMA
+    int sel, thr;                                    // 0: run; 1: run only when the row count is > thr; 2: only when it is <= thr (see enqueue)
 };
 
 __device__ __forceinline__ void mlpStageBarrier() {
@@ -164,6 +165,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
     __shared__ __attribute__((aligned(16))) unsigned char lds[RS * SB + MP_FLOATS * 4 + LNP];     // RS = 3: 78,848 B; RS = 6: 158,720 B (one workgroup per CU)
     const uint32_t cnt = *a.count;
     const int M = (int)(cnt < (uint32_t)a.max_rows ? cnt : (uint32_t)a.max_rows);
+    if ((a.sel == 1 && M <= a.thr) || (a.sel == 2 && M > a.thr)) return;     // the other kernel of the pair takes this row count
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Tile plan.  One workgroup per CU takes 41-45 us whatever the row count; a CU that hosts two 128-row workgroups takes 58-62 us
     // (measured, tools/mlp_rows.py), so 269 tiles on 256 CUs cost as much as 512.
@@ -178,9 +180,10 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
     bool small = false;
     if (ELASTIC) {
         int need = (M + 16 * a.ncu - 1) / (16 * a.ncu);
-        // beyond ten live waves per CU (two frames per launch: ~270 rows per CU): TWO workgroups per CU (78.8 KB of LDS each), sized so
-        // that one round of 2 x ncu workgroups still covers the rows -- 69k rows = 480 workgroups of nine waves, not 540 of eight (a
-        // second round for 28 workgroups)
+        // beyond ten live waves per CU (two frames per launch: ~270 rows per CU): TWO workgroups per CU one after the other, sized so
+        // that two rounds of ncu workgroups still cover the rows -- 69k rows = 480 workgroups of nine waves, not 540 of eight (a
+        // third round for 28 workgroups).  (LDS -- 78.8 KB -- would let two share a CU, the registers do not: 84 + 84 accumulation
+        // registers per wave = three waves per SIMD = twelve wave slots per CU.)
         if (need > NW && RS == 3) need = (M + 32 * a.ncu - 1) / (32 * a.ncu);
         nwa = need <= 8 ? 8 : need <= NW ? need : 8;
         if (a.dbg & 32) nwa = 8;
@@ -549,9 +552,26 @@ public:
         static int ncu = 0;
         if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }
         b.ncu = ncu;
-        const int over = max_rows_ - ncu * MROWS;
-        static int variant = -1;       // DSVT_MLP_VARIANT=1: <2,4> four waves x 32 rows + small overflow workgroups; 2: <1,8>; default 3: <1,10> elastic
-        if (variant < 0) { const char* e = getenv("DSVT_MLP_VARIANT"); variant = e ? atoi(e) : 3; }
+        // Kernel by row count.  Up to 2.5 x 128 rows per CU (one or two frames per launch): <1,10> elastic, ONE workgroup per CU at a time
+        // (168 registers per wave).  Beyond (three or more frames per launch): <2,4>, four waves x 32 rows at 256 registers, of which TWO
+        // share a CU (one wave of each per SIMD) and overlap each other's LayerNorm / GELU / store phases with MFMA + DMA -- a CU hosting
+        // two takes 58-62 us for 256 rows where the elastic kernel takes 2 x 44: three frames 121 vs 147 us per launch, four 155 vs 186
+        // (two frames: 539 workgroups = one full round of 512 and a 27-workgroup third of 43 us: 100 vs 89 us, hence the threshold).
+        // The count lives on the device, so a plugin whose capacity spans both regimes launches BOTH kernels and the one whose regime it
+        // is not returns at once (an empty launch: ~2 us).  DSVT_MLP_VARIANT forces one: 1 = <2,4> + small overflow workgroups,
+        // 2 = <1,8>, 3 = <1,10> elastic.
+        static int forced = -1;
+        if (forced < 0) { const char* e = getenv("DSVT_MLP_VARIANT"); forced = e ? atoi(e) : 0; }
+        const int thr = 5 * ncu * MROWS / 2;
+        if (!forced && max_rows_ > thr) {
+            b.thr = thr;
+            b.sel = 2; int rc = launchVariant(b, 3, stream); if (rc) return rc;
+            b.sel = 1; return launchVariant(b, 1, stream);
+        }
+        return launchVariant(b, forced ? forced : 3, stream);
+    }
+    int launchVariant(MlpStreamArgs b, int variant, hipStream_t stream) const {
+        const int ncu = b.ncu, over = max_rows_ - ncu * MROWS;
         const int srows = 16 * (variant == 2 ? 1 : 2) * MLP_SW;                 // rows of a small workgroup
         const int gsmall = over > 0 ? ncu + cdiv(over < MLP_SMALL_MAX ? over : MLP_SMALL_MAX, srows) : 0;
         const int gfull = cdiv(max_rows_, MROWS);                               // (covers the elastic variant too: >= 128 rows per workgroup)

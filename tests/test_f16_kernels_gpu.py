@@ -164,7 +164,10 @@ def _mlp_reference(att16, x, xb, w, lp, block, n, mimic_roundings=True):
 @pytest.mark.parametrize("block_ln,MR,n", [(False, 8192, 5504), (True, 8192, 5504), (False, 8192, 1), (True, 8192, 17),
                                              (True, 65536, 34483),      # nine live waves per workgroup
                                              (False, 65536, 39000),     # ten
-                                             (True, 65536, 50000)])     # eight-wave workgroups in rounds
+                                             (True, 65536, 50000),      # eight-wave workgroups in rounds
+                                             (True, 131072, 103449),    # capacity of three frames: four waves x 32 rows, two workgroups per CU
+                                             (False, 131072, 33000),    # ... with few rows: the elastic kernel takes them, the other one returns at once
+                                             (False, 196608, 137932)])  # four frames
 def test_encoder_mlp_f16_against_reference_wiring(pkg, oracle, block_ln, MR, n):
     P = pkg.plugin
     rng = np.random.default_rng(7 * n + block_ln)

@@ -343,3 +343,36 @@ def test_two_frames_per_forward_equal_two_forwards(pkg, weights):
     g_rows, g_cnt = two.replay()
     torch.cuda.synchronize()
     assert torch.equal(g_rows, rows) and torch.equal(g_cnt, cnt)
+
+
+def test_four_frames_per_forward_equal_single_frame_forwards(pkg, weights):
+    """DsvtPipeline(frames=4), bench.py's default (BASELINE configs[3]: four frames per GPU and batch).  At this row count the encoder MLP
+    runs its four-wave x 32-row kernel (two workgroups per CU) instead of the elastic one; both accumulate every row's dot products in
+    the same k order, so the boxes are still the bits of the single-frame runs -- four different clouds, one of them small."""
+    P = pkg.plugin
+    kw = dict(linear_compute=P.COMPUTE_F16, head_dtype=torch.float16, device_nms=True, device=DEV)
+    one = pkg.pipeline.DsvtPipeline(weights, caps=pkg.pipeline.Caps(), **kw)
+    caps4 = pkg.pipeline.Caps.for_frames(4)
+    four = pkg.pipeline.DsvtPipeline(weights, caps=caps4, frames=4, **kw)
+    clouds = [pkg.synth.lidar_like(180000, 11), pkg.synth.lidar_like(150000, 12), pkg.synth.lidar_like(180000, 13), pkg.synth.lidar_like(30000, 14)]
+    singles = []
+    for p in clouds:
+        pts, n = cases.pad_points(p, one.caps.N)
+        r, c = _run(pkg, one, pts, n)
+        torch.cuda.synchronize()
+        singles.append((r[0].clone(), int(c[0])))
+    buf = np.zeros((1, 4 * caps4.N, 4), np.float32)
+    for slot, p in enumerate(clouds):
+        buf[0, slot * caps4.N:slot * caps4.N + p.shape[0]] = p
+    n = torch.tensor([p.shape[0] for p in clouds], dtype=torch.int32, device=DEV)
+    pts_d = torch.from_numpy(buf).to(DEV)
+    rows, cnt = four.forward(pts_d, n)
+    torch.cuda.synchronize()
+    assert rows.shape == (4, 500, 9) and cnt.shape == (4,)
+    for slot in range(4):
+        assert int(cnt[slot]) == singles[slot][1] and singles[slot][1] > 0
+        assert torch.equal(rows[slot], singles[slot][0]), (slot, float((rows[slot] - singles[slot][0]).abs().max()))
+    four.capture(pts_d, n)
+    g_rows, g_cnt = four.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(g_rows, rows) and torch.equal(g_cnt, cnt)
