@@ -474,6 +474,7 @@ static inline int permuteK(int p) {
 class DsvtEncoderMlpPlugin : public Plugin {
 public:
     int max_rows_, has_block_ln_; float eps_;
+    int frames_ = 0;                                              // optional field "frames": frames whose rows one launch carries (0 = unknown: decided by the row count on the device)
     std::vector<float> wo_, w1_, w2_, bo_, b1_, b2_, lg_, lb_;     // as given (natural order)
     float *lg_dev_ = nullptr, *lb_dev_ = nullptr;
     _Float16* wp_dev_ = nullptr; float* prm_dev_ = nullptr;       // stage image + LDS parameter block of the streamed kernel
@@ -563,6 +564,7 @@ public:
         static int forced = -1;
         if (forced < 0) { const char* e = getenv("DSVT_MLP_VARIANT"); forced = e ? atoi(e) : 0; }
         const int thr = 5 * ncu * MROWS / 2;
+        if (!forced && frames_ > 0) return launchVariant(b, frames_ >= 3 ? 1 : 3, stream);       // the caller said which regime its launches are in (either kernel is correct for any count)
         if (!forced && max_rows_ > thr) {
             b.thr = thr;
             b.sel = 2; int rc = launchVariant(b, 3, stream); if (rc) return rc;
@@ -594,17 +596,20 @@ public:
         return lastError();
     }
     size_t nFloats() const { return wo_.size() + w1_.size() + w2_.size() + bo_.size() + b1_.size() + b2_.size() + 2 * (size_t)(3 + has_block_ln_) * MC; }
-    size_t serializationSize() const override { return 2 * sizeof(int) + sizeof(float) + sizeof(float) * nFloats(); }
+    size_t serializationSize() const override { return 2 * sizeof(int) + sizeof(float) + sizeof(float) * nFloats() + (frames_ ? sizeof(int) : 0); }
     void serialize(void* buf) const override {
         char* d = static_cast<char*>(buf);
         wr<int>(d, max_rows_); wr<int>(d, has_block_ln_); wr<float>(d, eps_);
         auto put = [&](const std::vector<float>& v, size_t n) { memcpy(d, v.data(), sizeof(float) * n); d += sizeof(float) * n; };
         put(wo_, wo_.size()); put(w1_, w1_.size()); put(w2_, w2_.size()); put(bo_, bo_.size()); put(b1_, b1_.size()); put(b2_, b2_.size());
         put(lg_, (size_t)(3 + has_block_ln_) * MC); put(lb_, (size_t)(3 + has_block_ln_) * MC);
+        if (frames_) wr<int>(d, frames_);                            // (trailing, only when set: older blobs stay valid)
     }
     Plugin* clone() const override {
-        return new DsvtEncoderMlpPlugin(max_rows_, has_block_ln_, eps_, wo_.data(), w1_.data(), w2_.data(), bo_.data(), b1_.data(), b2_.data(),
-                                        lg_.data(), lb_.data());
+        auto* p = new DsvtEncoderMlpPlugin(max_rows_, has_block_ln_, eps_, wo_.data(), w1_.data(), w2_.data(), bo_.data(), b1_.data(), b2_.data(),
+                                           lg_.data(), lb_.data());
+        p->frames_ = frames_;
+        return p;
     }
 };
 
@@ -620,7 +625,10 @@ static Plugin* mlpCreate(const DsvtPluginFieldCollection* fc) {
         if (!f || !f->data || f->length != need[i].len) return nullptr;
         p[i] = static_cast<const float*>(f->data);
     }
-    return new DsvtEncoderMlpPlugin(max_rows, hb, fieldFloat(fc, "ln_eps", 0.f), p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
+    auto* pl = new DsvtEncoderMlpPlugin(max_rows, hb, fieldFloat(fc, "ln_eps", 0.f), p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
+    const int fr = fieldInt(fc, "frames", 0);
+    pl->frames_ = fr > 0 ? fr : 0;
+    return pl;
 }
 static Plugin* mlpDeser(const void* data, size_t len) {
     if (len < 2 * sizeof(int) + sizeof(float)) return nullptr;
@@ -634,13 +642,18 @@ static Plugin* mlpDeser(const void* data, size_t len) {
     const float* wo = q; q += MC * MC; const float* w1 = q; q += MF * MC; const float* w2 = q; q += MC * MF;
     const float* bo = q; q += MC; const float* b1 = q; q += MF; const float* b2 = q; q += MC;
     const float* lg = q; q += (3 + hb) * MC; const float* lb = q;
-    return new DsvtEncoderMlpPlugin(max_rows, hb, eps, wo, w1, w2, bo, b1, b2, lg, lb);
+    auto* pl = new DsvtEncoderMlpPlugin(max_rows, hb, eps, wo, w1, w2, bo, b1, b2, lg, lb);
+    if (len >= 2 * sizeof(int) + sizeof(float) + n * sizeof(float) + sizeof(int)) {
+        int fr; memcpy(&fr, d + n * sizeof(float), sizeof(int));
+        pl->frames_ = fr > 0 ? fr : 0;
+    }
+    return pl;
 }
 static Creator g_mlpCreator{"DsvtEncoderMlpPlugin",
     {{"max_rows", DSVT_FIELD_INT32}, {"has_block_norm", DSVT_FIELD_INT32}, {"ln_eps", DSVT_FIELD_FLOAT32},
      {"out_proj_weight", DSVT_FIELD_FLOAT32}, {"out_proj_bias", DSVT_FIELD_FLOAT32}, {"linear1_weight", DSVT_FIELD_FLOAT32},
      {"linear1_bias", DSVT_FIELD_FLOAT32}, {"linear2_weight", DSVT_FIELD_FLOAT32}, {"linear2_bias", DSVT_FIELD_FLOAT32},
-     {"ln_weights", DSVT_FIELD_FLOAT32}, {"ln_bias", DSVT_FIELD_FLOAT32}},
+     {"ln_weights", DSVT_FIELD_FLOAT32}, {"ln_bias", DSVT_FIELD_FLOAT32}, {"frames", DSVT_FIELD_INT32}},
     mlpCreate, mlpDeser, {}, {}};
 static Registrar g_mlpReg(&g_mlpCreator);
 

@@ -178,7 +178,7 @@ class DsvtPipeline:
                         mlp=zf(P.add_encoder_mlp_op(w[lp + ".win_attn.self_attn.out_proj.weight"], w[lp + ".win_attn.self_attn.out_proj.bias"],
                                                     w[lp + ".win_attn.linear1.weight"], w[lp + ".win_attn.linear1.bias"],
                                                     w[lp + ".win_attn.linear2.weight"], w[lp + ".win_attn.linear2.bias"],
-                                                    [ln(".win_attn.norm1")] + lns2, c.P, ln_eps=ln_eps)))
+                                                    [ln(".win_attn.norm1")] + lns2, c.P, ln_eps=ln_eps, frames=self.frames)))
                     L_["attn"].win = b % 2
                     continue
                 self.layers[(b, l)] = dict(

@@ -557,16 +557,18 @@ def add_conv2d_op(weight_rows, bias, in_height, in_width, in_channels, out_chann
 
 
 def add_encoder_mlp_op(out_proj_weight, out_proj_bias, linear1_weight, linear1_bias, linear2_weight, linear2_bias,
-                       layer_norms, max_rows, ln_eps=0.0):
+                       layer_norms, max_rows, ln_eps=0.0, frames=0):
     """Everything after the attention core of one DSVT encoder layer in one launch (csrc/mlp.hip):
     s1 = LN1(att Wo^T + bo + x); h = GELU(s1 W1^T + b1); x' = LN3(LN2(s1 + h W2^T + b2) + x) [; x' = LN4(x' + xb)].
     layer_norms: [(gamma, beta)] x 3 (norm1, norm2, encoder norm) or x 4 (+ block residual norm).
-    Inputs: att [1,P,192] fp16, count [1], x [1,P,192] fp32 (, xb [1,P,192] fp32).  Outputs: x' fp32, x' fp16."""
+    Inputs: att [1,P,192] fp16, count [1], x [1,P,192] fp32 (, xb [1,P,192] fp32).  Outputs: x' fp32, x' fp16.
+    frames: how many frames' rows a launch carries (picks the kernel: >= 3 the two-workgroups-per-CU one); 0 = decided on the device."""
     f = lambda a: np.asarray(a, np.float32).reshape(-1)
     assert len(layer_norms) in (3, 4)
     return Plugin("DsvtEncoderMlpPlugin", dict(
         max_rows=max_rows, has_block_norm=int(len(layer_norms) == 4), ln_eps=float(ln_eps),
         out_proj_weight=f(out_proj_weight), out_proj_bias=f(out_proj_bias), linear1_weight=f(linear1_weight),
         linear1_bias=f(linear1_bias), linear2_weight=f(linear2_weight), linear2_bias=f(linear2_bias),
-        ln_weights=np.concatenate([f(g) for g, _ in layer_norms]), ln_bias=np.concatenate([f(b) for _, b in layer_norms])),
+        ln_weights=np.concatenate([f(g) for g, _ in layer_norms]), ln_bias=np.concatenate([f(b) for _, b in layer_norms]),
+        **({"frames": int(frames)} if frames else {})),
         "encoder_mlp_layer")
