@@ -368,8 +368,10 @@ def main():
                               + 2 * up * up * f["out_channels"] * taps * f["in_channels"]))
             return (0.0, 0.0)
 
-        meta = {"DsvtLinearPlugin": ("linear_f16_rows_kernel (QKV: all column chunks of a row tile per workgroup, v_mfma_f32_16x16x32_f16, weights by LDS-DMA)" if f16 else "linear_f32_kernel (v_mfma_f32_16x16x4_f32)",
-                                     "hbm" if f16 else "mfma", "linear_f16_rows_kernel" if f16 else "linear_f32_kernel<true>"),
+        resident_qkv = f16 and FB >= 3          # (csrc/linear.hip: row capacity of three or more frames -> the resident-weights kernel)
+        meta = {"DsvtLinearPlugin": (("linear_f16_resident_kernel (QKV: half of W_qkv resident in LDS per CU, waves walk 16-row tiles, v_mfma_f32_16x16x32_f16)" if resident_qkv else
+                                      "linear_f16_rows_kernel (QKV: all column chunks of a row tile per workgroup, v_mfma_f32_16x16x32_f16, weights by LDS-DMA)") if f16 else "linear_f32_kernel (v_mfma_f32_16x16x4_f32)",
+                                     "hbm" if f16 else "mfma", ("linear_f16_resident_kernel" if resident_qkv else "linear_f16_rows_kernel") if f16 else "linear_f32_kernel<true>"),
                 "DsvtEncoderMlpPlugin": ("encoder_mlp_stream_kernel (out-proj+LN -> FC1+GELU -> FC2+LN+LN, v_mfma_f32_16x16x32_f16, weights by LDS-DMA)", "hbm", "encoder_mlp_stream_kernel"),
                 "DsvtSetAttentionPlugin": ("set_attention_f16_kernel (v_mfma_f32_16x16x32_f16)" if f16 else "set_attention_kernel (v_mfma_f32_16x16x4_f32)", "hbm",
                                            "set_attention_f16_kernel" if f16 else "set_attention_kernel"),
@@ -408,6 +410,8 @@ def main():
                 if need > 10:
                     need = -(-c0["P"] // (32 * 256))
                 nwg = -(-c0["P"] // (16 * (max(8, need) if need <= 10 else 8)))
+                if FB >= 3:                                            # three or more frames per launch: the other kernel of each pair
+                    nwg = 256 // 2 if ptype == "DsvtLinearPlugin" else -(-c0["P"] // 128)      # resident QKV: each CU loads its half once; MLP <2,4>: 128-row workgroups
                 r["weights_restreamed_mb_per_launch"] = round(nwg * wg_weights / 1e6, 1)
                 r["fabric_gbs_incl_weight_stream"] = round((tot_by / n_l + nwg * wg_weights) / (avg_ms * 1e-3) / 1e9, 1)
             roofline_all.append((ptype, r))

@@ -704,6 +704,134 @@ linear_f16_rows_kernel(LinearArgs a, const _Float16* __restrict__ Wp, int ncu)
     }
 }
 
+// -------------------------------------------------------------------------------------
+// QKV with the weights RESIDENT in LDS (round 2), for launches that carry three or more frames' rows.  The kernel above re-streams all
+// 216 KB of W_qkv for every 128-160 rows, through one ten-wave workgroup per CU whose waves move in lockstep (load rows, three chunks,
+// store).  Here a CU keeps HALF of the output columns' weights -- three 96-column stages, 108 KB -- in LDS for the whole launch
+// (workgroups alternate between the two halves, so every activation row is read by two workgroups: 384 B more per row next to the
+// 1152 B it produces) and its eight waves walk the 16-row tiles independently: no barrier after the prologue, the rows of a wave's
+// next tile are loaded while it computes the current one (register ping-pong), the window-cell index of the tile after that (the
+// position table's gather index) one tile earlier still.  Measured per launch, rows of 1 / 2 / 4 frames: 26.5 / 42.4 / 75.8 us
+// against 24.7 / 44.0 / 85.4 for the streamed kernel (the 108 KB prologue of every CU costs what one frame's rows save); 265 MB
+// of traffic in 76 us = 3.5 TB/s -- twelve waves at 168 registers: the same 76 us.
+constexpr int RS_NW = 8, RS_SPT = 3;
+template <bool TABLE>             // the A2 rows are gathered through the window cell (a2_c2d)
+__global__ void __launch_bounds__(64 * RS_NW, 2)
+linear_f16_resident_kernel(LinearArgs a, const _Float16* __restrict__ Wp)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char ring[RS_SPT * SBYTES + 4096];   // three weight stages + the bias
+    const int M = rowLimit(a);
+    if (M <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int ntype = a.N / (96 * RS_SPT);
+    const int type = (int)blockIdx.x % ntype, j = (int)blockIdx.x / ntype, nj = (int)gridDim.x / ntype;
+    for (int row = wave; row < RS_SPT * SROWS; row += RS_NW)
+        __builtin_amdgcn_global_load_lds((glds_src_t)(Wp + ((size_t)(type * RS_SPT) * SROWS + row) * 512 + lane * 8), (glds_dst_t)(ring + row * 1024), 16, 0, 0);
+    if (wave < 4) {
+        const int f0 = wave * 256 + lane * 4;
+        const float* src = a.bias ? a.bias + (f0 + 3 < a.N ? f0 : 0) : reinterpret_cast<const float*>(Wp);       // (unused lanes: any valid address)
+        __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(ring + RS_SPT * SBYTES + wave * 1024), 16, 0, 0);
+    }
+    const uint32_t bias_lds = (uint32_t)(uintptr_t)(glds_dst_t)(ring + RS_SPT * SBYTES);
+    const int ntile = (M + 15) >> 4, step = nj * RS_NW;
+    int tt = j * RS_NW + wave;
+    // the window cell of this lane's row of tile t (the position table's gather index), as loaded: the multiply waits for the load,
+    // so it is left to the tile that USES the index (one tile later).  Prefetches past the last tile re-read the last tile (no
+    // branch around a load: a value merged from two paths is copied, and the copy waits for the load)
+    const bool hasA2 = a.add_cols > 0;
+    auto cellOf = [&](int t) -> int2 {
+        t = t < ntile ? t : ntile - 1;
+        const int row = t * 16 + r, rc = row < M ? row : M - 1;
+        if (!TABLE) return make_int2(0, rc);
+        const int32_t* c = a.a2_c2d + (size_t)rc * 3;
+        return make_int2(c[1], c[2]);
+    };
+    auto loadRows = [&](int t, int2 cell, half8 (&x)[NSTEP], half8 (&p)[NSTEP]) {
+        t = t < ntile ? t : ntile - 1;
+        const int row = t * 16 + r, rc = row < M ? row : M - 1;
+        const size_t o = (size_t)rc * KS + g * 8, o2 = (size_t)((TABLE ? cell.x * a.a2_wx : 0) + cell.y) * KS + g * 8;
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) x[s] = *reinterpret_cast<const half8*>(static_cast<const _Float16*>(a.A) + o + s * 32);
+        if (hasA2) {
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) p[s] = *reinterpret_cast<const half8*>(static_cast<const _Float16*>(a.A2) + o2 + s * 32);
+        } else {
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) p[s] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    };
+    const unsigned char* slot = ring + lane * 16;
+    // one 16-row tile: fp += fx, three stages of 36 MFMAs, bias / fp16 / wide stores per stage
+    auto tile = [&](int t, half8 (&fx)[NSTEP], half8 (&fp)[NSTEP]) {
+        const int row = t * 16 + r;
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) fp[s] += fx[s];
+#pragma unroll
+        for (int h = 0; h < RS_SPT; ++h) {
+            const int n0 = (type * RS_SPT + h) * 96;
+            const bool add = n0 < a.add_cols;
+            floatx4 acc[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) acc[u] = floatx4{0.f, 0.f, 0.f, 0.f};
+            const unsigned char* sp = slot + h * SBYTES;
+#pragma unroll
+            for (int ks = 0; ks < NSTEP; ++ks) {
+                const half8 f = add ? fp[ks] : fx[ks];
+#pragma unroll
+                for (int u = 0; u < 6; ++u)
+                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(sp + (ks * 6 + u) * 1024), f, acc[u], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 6; u += 2) {
+                floatx4 X = acc[u], Y = acc[u + 1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(X[i]), __float_as_uint(Y[i]), false, false);
+                    X[i] = __uint_as_float(sw[0]); Y[i] = __uint_as_float(sw[1]);
+                }
+                const int col = n0 + u * 16 + (g & 1) * 16 + (g >> 1) * 8;       // the lane's eight columns after the swap are contiguous
+                if (a.bias) {
+                    const uint32_t ad = bias_lds + (uint32_t)col * 4u;
+                    floatx4 b0, b1;
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b0), "=&v"(b1) : "v"(ad));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { X[i] += b0[i]; Y[i] += b1[i]; }
+                }
+                if (row < M) {
+                    half8 hv = {(_Float16)X[0], (_Float16)X[1], (_Float16)X[2], (_Float16)X[3], (_Float16)Y[0], (_Float16)Y[1], (_Float16)Y[2], (_Float16)Y[3]};
+                    *reinterpret_cast<half8*>(a.out16 + (size_t)row * a.out_ld + col) = hv;
+                }
+            }
+        }
+    };
+    half8 xa[NSTEP], pa[NSTEP], xb[NSTEP], pb[NSTEP];
+    loadRows(tt, cellOf(tt), xa, pa);
+    int2 cellN = cellOf(tt + step);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the weights (and the first rows) have landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    while (tt < ntile) {
+        const int tn = tt + step;
+        loadRows(tn, cellN, xb, pb);
+        const int2 cell2 = cellOf(tn + step);
+        tile(tt, xa, pa);
+        if (tn >= ntile) break;
+        tt = tn + step;
+        loadRows(tt, cell2, xa, pa);
+        cellN = cellOf(tt + step);
+        tile(tn, xb, pb);
+    }
+}
+
+static int launchLinearF16Resident(const LinearArgs& a, const _Float16* Wp, hipStream_t stream) {
+    static int ncu = 0;
+    if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }
+    const int ntype = a.N / (96 * RS_SPT);
+    if (a.a2_c2d) hipLaunchKernelGGL(linear_f16_resident_kernel<true>, dim3(ncu / ntype * ntype), dim3(64 * RS_NW), 0, stream, a, Wp);
+    else hipLaunchKernelGGL(linear_f16_resident_kernel<false>, dim3(ncu / ntype * ntype), dim3(64 * RS_NW), 0, stream, a, Wp);
+    return lastError();
+}
+
 int launchLinearF16Rows(const LinearArgs& a, const _Float16* Wp, hipStream_t stream) {
     static int ncu = 0;
     if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }
@@ -716,8 +844,12 @@ int launchLinearF16Stream(const LinearArgs& a, const _Float16* Wp, hipStream_t s
     static int rowsOn = -1;        // DSVT_LINEAR_ROWS=0: one column chunk per workgroup for every layer
     if (rowsOn < 0) { const char* e = getenv("DSVT_LINEAR_ROWS"); rowsOn = e ? atoi(e) : 1; }
     if (rowsOn && a.N > BN && a.a_half && !a.pe_xy && a.out16 && !a.out && a.act == ACT_NONE && a.n_ln == 0 && a.row_mult == 1 &&
-        (a.add_cols % BN) == 0 && a.N <= 1024 && !a.trace)
+        (a.add_cols % BN) == 0 && a.N <= 1024 && !a.trace) {
+        static int resident = -1;  // DSVT_LINEAR_RESIDENT=0: the streamed whole-row kernel for every shape; 2: the resident one whatever the row capacity
+        if (resident < 0) { const char* e = getenv("DSVT_LINEAR_RESIDENT"); resident = e ? atoi(e) : 1; }
+        if (resident && a.N == 96 * RS_SPT * 2 && (a.add_cols % 96) == 0 && (a.max_rows >= 3 * 65536 || resident == 2)) return launchLinearF16Resident(a, Wp, stream);
         return launchLinearF16Rows(a, Wp, stream);
+    }
     dim3 grid(cdiv(a.max_rows, BM16), a.N / BN);
     const int amode = a.pe_xy ? 2 : a.a_half ? 1 : 0;
     static int mt2 = -1;           // DSVT_STREAM_MT=2: 4 waves x 32 rows (<= 256 VGPRs); default 8 waves x 16 rows (<= 128 VGPRs, 4 waves/SIMD):

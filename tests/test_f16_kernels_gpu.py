@@ -246,7 +246,9 @@ def test_pillar_feature_net_against_oracle(pkg, oracle, frame, capname, n_pts):
 # =====================================================================================================================
 # linear_f16_rows_kernel (the QKV projection: DsvtLinearPlugin, N = 576, add_cols = 384, fp16 in / out)
 # =====================================================================================================================
-@pytest.mark.parametrize("MR,n", [(65536, 34483), (65536, 39000), (65536, 50000), (8192, 100), (8192, 5504), (8192, 1)])
+@pytest.mark.parametrize("MR,n", [(65536, 34483), (65536, 39000), (65536, 50000), (8192, 100), (8192, 5504), (8192, 1),
+                                  # row capacity of three or more frames: linear_f16_resident_kernel (weights resident in LDS, waves walk the tiles)
+                                  (262144, 137932), (262144, 100), (196608, 190001), (262144, 1)])
 @pytest.mark.parametrize("table", [False, True])
 def test_qkv_rows_kernel_against_fp64_product(pkg, MR, n, table):
     """q = k = (x + pos) Wqk^T + b, v = x Wv^T + b (getValueByIndex.cu:282-355 + src/dsvt-ai-trt.cpp:328-330, per voxel row) on
