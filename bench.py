@@ -146,8 +146,8 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=240)      # (timed frames; the un-graphed roofline sample is the last forward: 60 steps read 1.5 % lower)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--dtype", choices=["f32", "f16"], default="f16",
                     help="f16: fp16 MFMA operands / fp16 dense head, fp32 accumulate + LayerNorm/softmax/decode "
