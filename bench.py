@@ -8,7 +8,7 @@ Four frames per forward() (their pillar rows concatenated: one launch per backbo
 configs[3] puts four frames on each GPU per batch) on each of two streams (`--streams`) are the default.  Measured on one MI355X
 (frames/s, p50 per-frame ms; a frame is done when its forward() is), frames per forward x streams:
     1 x 1  455 / 2.2      1 x 2  540 / 3.7      2 x 1  513 / 3.9      2 x 2  575 / 6.8
-    3 x 2  606 / 9.6      4 x 1  539 / 7.4      4 x 2  623 / 12.4 (default)
+    3 x 2  606 / 9.6      4 x 1  579 / 7.0      4 x 2  647 / 12.3 (default)
 `--batch 1 --streams 1` is the latency mode (the reference's own: one frame at a time).
 
 A step = one frame through the whole pipeline (BASELINE.json configs[2]: Waymo-shaped
