@@ -192,6 +192,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    if args.batch > 4:
+        raise SystemExit("bench.py: --batch <= 4 (Points2Features packs the running count of occupied cells into 20 bits of its scan state: "
+                         "4 x 468 x 468 cells fit, 5 do not, and the plugin rejects the fields)")
     FB = max(1, args.batch) if args.dtype == "f16" else 1          # (the fp32 mode has no multi-frame path)
     if args.host_input:
         FB = 1
