@@ -279,3 +279,36 @@ def test_qkv_rows_kernel_against_fp64_product(pkg, MR, n, table):
     assert err.max().item() < 1e-3 * scale, (err.max().item(), scale)
     assert err.mean().item() < 1e-4 * scale
     assert not got[0, n:].any()
+
+
+def test_encoder_mlp_frames_field_picks_the_kernel_not_the_result(pkg):
+    """optional field `frames` of DsvtEncoderMlpPlugin: 1-2 = the elastic kernel, >= 3 = four waves x 32 rows (two workgroups per CU), absent =
+    decided by the row count on the device.  Either kernel is correct for any count and both sum a row's products in the same k order: same
+    bits from all three, before and after a serialise / deserialise round trip (the field travels as a trailing int)."""
+    P = pkg.plugin
+    rng = np.random.default_rng(11)
+    C, MR, n = 192, 131072, 70001
+    w = pkg.synth.make_weights(with_bev=False)
+    lp = "module.backbone_3d.stage_0.0.encoder_list.0"
+    ln = lambda k: (w[k + ".weight"], w[k + ".bias"])
+    lns = [ln(lp + ".win_attn.norm1"), ln(lp + ".win_attn.norm2"), ln(lp + ".norm")]
+    att = torch.from_numpy(r16(rng.standard_normal((1, MR, C)))).half().to(DEV)
+    x = torch.from_numpy(rng.standard_normal((1, MR, C)).astype(np.float32)).to(DEV)
+    cnt = scalar(n)
+    mk = lambda fr: P.add_encoder_mlp_op(w[lp + ".win_attn.self_attn.out_proj.weight"], w[lp + ".win_attn.self_attn.out_proj.bias"],
+                                         w[lp + ".win_attn.linear1.weight"], w[lp + ".win_attn.linear1.bias"],
+                                         w[lp + ".win_attn.linear2.weight"], w[lp + ".win_attn.linear2.bias"], lns, MR, frames=fr)
+    outs = {}
+    for fr in (0, 2, 4):
+        op = mk(fr)
+        outs[fr] = [t.clone() for t in op(att, cnt, x)]
+        blob = op.serialize()
+        again = P.Plugin.deserialize("DsvtEncoderMlpPlugin", blob)
+        assert again.serialize() == blob
+        o2 = again(att, cnt, x)
+        torch.cuda.synchronize()
+        assert torch.equal(o2[0], outs[fr][0]) and torch.equal(o2[1], outs[fr][1])
+    assert len(mk(4).serialize()) == len(mk(0).serialize()) + 4
+    for fr in (2, 4):
+        assert torch.equal(outs[fr][0][0, :n], outs[0][0][0, :n]) and torch.equal(outs[fr][1][0, :n], outs[0][1][0, :n])
+    assert float(outs[0][0][0, :n].abs().max()) > 0.1
