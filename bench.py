@@ -19,6 +19,8 @@ processes K frames of its own (weak scaling) and the per-frame results are gathe
 with ONE collective inside the timed region.  Rank 0 prints one JSON line.
 
 Extra objects in the line:
+  single_frame_mode  (N = 1) the same kernels with ONE frame per forward and one in flight -- the reference's own mode: frames/s and p50,
+                measured live after the timed region; never the headline value.
   roofline      the dominant hand-written kernel (the MFMA linear kernel): algorithmic flops per
                 launch / average launch duration, measured with HIP events around every launch
                 during the timed steps, against the dense fp32-matrix peak of gfx950.
@@ -164,6 +166,7 @@ def main():
                          "0 (default) = only the LAST forward() of the timed region (one pipeline drain instead of one per sample: the "
                          "three samples of the old default cost 5-8 %% of the measured rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency-mode", action="store_true", help="skip the single-frame-mode measurement (N = 1 only) that follows the timed region")
     ap.add_argument("--host-input", action="store_true", help="frames start in pinned host memory and are uploaded (n x 16 B) inside the timed region: the PCIe-inclusive rate quoted in DESIGN.md, never the headline value")
     ap.add_argument("--no-nms", action="store_true", help="stop at FilterBoxByScore (the reference engine's output) instead of the final boxes")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline = null)")
@@ -447,6 +450,40 @@ def main():
             "roofline": roofline,
             "roofline_other_kernels": [r for _, r in roofline_all if r is not roofline],
         }
+        if world == 1 and f16 and FB > 1 and not args.no_latency_mode:
+            # the reference's own mode beside the headline: ONE frame per forward, one in flight (graph replay), same clouds --
+            # what a caller who wants latency, not throughput, gets from the same kernels; measured after the timed region
+            c1 = pkg.pipeline.Caps()
+            p1 = pkg.pipeline.DsvtPipeline(weights, caps=c1, device=dev, linear_compute=pkg.plugin.COMPUTE_F16, head_dtype=torch.float16,
+                                           device_nms=not args.no_nms)
+            one = []
+            for cl in clouds[:FRAME_POOL]:
+                b1 = np.zeros((1, c1.N, 4), np.float32); b1[0, :cl.shape[0]] = cl
+                one.append((torch.from_numpy(b1).to(dev), torch.tensor([cl.shape[0]], dtype=torch.int32, device=dev)))
+            sin = (torch.zeros_like(one[0][0]), torch.zeros_like(one[0][1]))
+            for pts1, n1 in one[:2]:
+                p1.forward(pts1, n1)
+            torch.cuda.synchronize()
+            sin[0].copy_(one[0][0]); sin[1].copy_(one[0][1])
+            p1.capture(*sin)
+            KL = 64
+            ev1 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(KL)]
+            for i in range(-8, KL):
+                pts1, n1 = one[i % len(one)]
+                if i >= 0:
+                    ev1[i][0].record()
+                sin[0].copy_(pts1); sin[1].copy_(n1)
+                p1.replay()
+                if i >= 0:
+                    ev1[i][1].record()
+                if i == -1:
+                    torch.cuda.synchronize(); tl0 = time.perf_counter()
+            torch.cuda.synchronize()
+            dl = time.perf_counter() - tl0
+            line["single_frame_mode"] = {"frames_per_forward": 1, "frames_in_flight": 1, "frames": KL, "value": round(KL / dl, 1), "unit": "frames/s",
+                                         "p50_ms": round(float(np.median([a.elapsed_time(b) for a, b in ev1])), 4),
+                                         "note": "same kernels, one frame at a time (the reference's mode); not the headline value"}
+            del p1
         if not args.no_cpu_baseline and world == 1:
             # the FilterBoxByScore rows of the pooled frames as the GPU produced them (the reference's D2H payload)
             frames = []
