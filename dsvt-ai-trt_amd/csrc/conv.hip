@@ -833,27 +833,45 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                     valid[m] = oy < a.Ho && ox < a.Wo;
                     opix[m] = valid[m] ? (size_t)((bimg * a.Ho + oy) * a.up + dy) * Wout + (ox * a.up + dx) : 0;
                 }
+                // The residual rows of EIGHT blocks at a time first (32 registers: the fragment buffers have just left them; all sixteen at
+                // once spill), without a branch around any load (a lane with nothing to add reads the tensor's first bytes): written as
+                // "load, add, store" per block, hipcc kept that order and awaited every load with vmcnt(0) -- sixteen dependent round trips
+                // per item, each behind the previous block's store: a residual input cost a 468 x 468 layer 70 us of 340
+                // (tools/conv_sequence.py).
+                constexpr int RB = NBLK < 8 ? NBLK : 8;
+                const bool hasRes = a.res != nullptr;
 #pragma unroll
-                for (int b = 0; b < NBLK; ++b) {
-                    const int m = b / TP, tp = b % TP, co = cbase + tp * 32 + cg8;
-                    if (2 * tp >= ctn) continue;
-                    floatx4 X = acc[2 * tp][m], Y = acc[2 * tp + 1][m];
+                for (int b0 = 0; b0 < NBLK; b0 += RB) {
+                    half8 rv[RB];
+                    if (hasRes) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(X[i]), __float_as_uint(Y[i]), false, false);
-                        X[i] = __uint_as_float(sw[0]); Y[i] = __uint_as_float(sw[1]);
+                        for (int j = 0; j < RB; ++j) {
+                            const int b = b0 + j, m = b / TP, tp = b % TP, co = cbase + tp * 32 + cg8;
+                            const bool ok = valid[m] && co < a.Cout && 2 * tp < ctn;
+                            rv[j] = *reinterpret_cast<const half8*>(a.res + (ok ? opix[m] * a.res_ld + co : 0));
+                        }
                     }
-                    if (!valid[m] || co >= a.Cout) continue;
-                    float v[8] = {X[0], X[1], X[2], X[3], Y[0], Y[1], Y[2], Y[3]};
-                    if (a.res) {
-                        const half8 rv = *reinterpret_cast<const half8*>(a.res + opix[m] * a.res_ld + co);
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) v[i] += (float)rv[i];
+                    for (int j = 0; j < RB; ++j) {
+                        const int b = b0 + j, m = b / TP, tp = b % TP, co = cbase + tp * 32 + cg8;
+                        if (2 * tp >= ctn) continue;
+                        floatx4 X = acc[2 * tp][m], Y = acc[2 * tp + 1][m];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(X[i]), __float_as_uint(Y[i]), false, false);
+                            X[i] = __uint_as_float(sw[0]); Y[i] = __uint_as_float(sw[1]);
+                        }
+                        if (!valid[m] || co >= a.Cout) continue;
+                        float v[8] = {X[0], X[1], X[2], X[3], Y[0], Y[1], Y[2], Y[3]};
+                        if (hasRes) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) v[i] += (float)rv[j][i];
+                        }
+                        half8 h;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) h[i] = (_Float16)(a.relu ? fmaxf(v[i], 0.f) : v[i]);
+                        *reinterpret_cast<half8*>(static_cast<_Float16*>(a.out) + opix[m] * a.out_ld + a.out_coff + co) = h;
                     }
-                    half8 h;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) h[i] = (_Float16)(a.relu ? fmaxf(v[i], 0.f) : v[i]);
-                    *reinterpret_cast<half8*>(static_cast<_Float16*>(a.out) + opix[m] * a.out_ld + a.out_coff + co) = h;
                 }
             } else {                                                  // (not a layer of this network)
 #pragma unroll
