@@ -892,6 +892,110 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     }
 }
 
+// -------------------------------------------------------------------------------------
+// 1 x 1 stride-1 layers (the shortcut of the first block and the three deblocks = 1 x 1 + pixel shuffle) as a streaming GEMM
+// with the weights RESIDENT in LDS (round 2).  The halo kernel above treats a 1 x 1 layer like a 3 x 3 one: per 8-row x 32-pixel x
+// 128-channel item it streams the input tile and the weight slabs through LDS -- for the 256 -> 16 x 128 deblock that is the same
+// 140 KB of input sixteen times (once per 128-column chunk) plus 64 KB of weights per item, 737 MB of LDS-DMA per four-frame
+// launch at the ~25 GB/s a CU's request path delivers: 141 us for 252 MB of HBM traffic.  Here a CU keeps one column GROUP of the
+// weights (up to 16 column tiles x Cin: <= 128 KB, DMA'd once from the halo kernel's fragment image) and its waves walk
+// 16-pixel tiles of the flat pixel list independently, like linear_f16_resident_kernel: rows straight from global into B
+// fragments (next tile's rows in flight while this one computes), no barrier after the prologue; a 128-column stage of a group is
+// one sub-pixel (dy, dx) of the pixel shuffle, so the epilogue is the wide one (bias, ReLU, fp16, 16-byte stores).
+// Needs Cout == 128, Cin in {128, 192, 256}, fp16 output with 16-byte alignment, no residual.
+constexpr int C1_NW = 8;
+template <int KSTEPS>
+__global__ void __launch_bounds__(64 * C1_NW, 2)
+conv1x1_resident_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT, int ngroup, int CTG)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[KSTEPS * 16 * 1024 + 1024];        // [k-step][column tile of the group] | bias
+    constexpr int BIAS_OFF = KSTEPS * 16 * 1024;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int type = (int)blockIdx.x % ngroup, j = (int)blockIdx.x / ngroup, nj = (int)gridDim.x / ngroup;
+    for (int u = wave; u < KSTEPS * CTG; u += C1_NW) {
+        const int q = u / CTG, t = u - q * CTG;
+        __builtin_amdgcn_global_load_lds((glds_src_t)(Wp + (((size_t)q * NCT + type * CTG + t) * 64 + lane) * 8), (glds_dst_t)(smem + u * 1024), 16, 0, 0);
+    }
+    if (wave == 0) {                                                 // 128 floats (zeros without a bias: any valid address, multiplied away below)
+        const float* src = a.bias ? a.bias + (lane < 32 ? lane * 4 : 0) : reinterpret_cast<const float*>(Wp);
+        __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + BIAS_OFF), 16, 0, 0);
+    }
+    const int HW = a.H * a.W, NPIX = a.nb * HW, ntile = (NPIX + 15) >> 4, step = nj * C1_NW;
+    const float invHW = 1.0f / (float)HW, invW = 1.0f / (float)a.W;
+    auto loadRows = [&](int t, half8 (&x)[KSTEPS]) {
+        t = t < ntile ? t : ntile - 1;                               // (past the end: the last tile again, no branch around a load)
+        const int p = t * 16 + r, pc = p < NPIX ? p : NPIX - 1;
+        const _Float16* src = a.in + (size_t)pc * a.Cin + g * 8;
+#pragma unroll
+        for (int q = 0; q < KSTEPS; ++q) x[q] = *reinterpret_cast<const half8*>(src + q * 32);
+    };
+    const unsigned char* slot = smem + lane * 16;
+    const int nstage = CTG >> 3;                                     // 128-column stages of this group
+    const int Wout = a.Wo * a.up;
+    auto tile = [&](int t, const half8 (&x)[KSTEPS]) {
+        const int p = t * 16 + r;
+        const bool valid = p < NPIX;
+        // pixel -> (image, y, x): float quotients corrected by one step (exact for these sizes; belt and braces)
+        const int pc = valid ? p : 0;
+        int b = (int)(((float)pc + 0.5f) * invHW); b -= (b * HW > pc); b += ((b + 1) * HW <= pc);
+        const int rem = pc - b * HW;
+        int y = (int)(((float)rem + 0.5f) * invW); y -= (y * a.W > rem); y += ((y + 1) * a.W <= rem);
+        const int xq = rem - y * a.W;
+        for (int st = 0; st < nstage; ++st) {
+            const int sub = type * nstage + st, dy = sub / a.up, dx = sub - dy * a.up;
+            const size_t opix = (size_t)((b * a.Ho + y) * a.up + dy) * Wout + (xq * a.up + dx);
+            floatx4 acc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + BIAS_OFF + (u * 16 + 4 * g) * 4);
+                acc[u] = a.bias ? b4 : floatx4{0.f, 0.f, 0.f, 0.f};
+            }
+            const unsigned char* sp = slot + (st * 8) * 1024;
+#pragma unroll
+            for (int q = 0; q < KSTEPS; ++q)
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(sp + (size_t)(q * CTG + u) * 1024), x[q], acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) convStoreWide<false>(a, acc[u], acc[u + 1], valid, opix, u * 16, g);
+        }
+    };
+    int tt = j * C1_NW + wave;
+    half8 xa[KSTEPS], xb[KSTEPS];
+    loadRows(tt, xa);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the weights (and the first rows) have landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    while (tt < ntile) {
+        const int tn = tt + step;
+        loadRows(tn, xb);
+        tile(tt, xa);
+        if (tn >= ntile) break;
+        tt = tn + step;
+        loadRows(tt, xa);
+        tile(tn, xb);
+    }
+}
+
+static int numCUs();
+static bool conv1x1ResidentEligible(const ConvArgs& a) {
+    static int on = -1;            // DSVT_CONV_1X1_RESIDENT=0: the halo kernel for the 1 x 1 layers too
+    if (on < 0) { const char* e = getenv("DSVT_CONV_1X1_RESIDENT"); on = e ? atoi(e) : 1; }
+    return on && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.Cout == 128 && a.CoutRows % 128 == 0 && a.wide && !a.res &&
+           !a.out_f32 && (a.Cin == 128 || a.Cin == 192 || a.Cin == 256);
+}
+
+static int launchConv1x1Resident(const ConvArgs& a, const _Float16* Wp, hipStream_t stream) {
+    const int NCT = cdiv(a.CoutRows, CNB) * 8;                      // fragment rows per k-step of the halo image
+    const int CTG = NCT < 16 ? NCT : 16, ngroup = NCT / CTG;        // (NCT is 8 or a multiple of 16 for these layers)
+    if (NCT % CTG != 0) return -3;
+    const int grid = numCUs() / ngroup * ngroup;
+    if (a.Cin == 128) hipLaunchKernelGGL((conv1x1_resident_kernel<4>), dim3(grid), dim3(64 * C1_NW), 0, stream, a, Wp, NCT, ngroup, CTG);
+    else if (a.Cin == 192) hipLaunchKernelGGL((conv1x1_resident_kernel<6>), dim3(grid), dim3(64 * C1_NW), 0, stream, a, Wp, NCT, ngroup, CTG);
+    else hipLaunchKernelGGL((conv1x1_resident_kernel<8>), dim3(grid), dim3(64 * C1_NW), 0, stream, a, Wp, NCT, ngroup, CTG);
+    return lastError();
+}
+
 // 16-channel tiles per workgroup of the halo kernel (and of its packed weights)
 static int haloChannelTiles(int coutRows) { return coutRows <= 32 ? 2 : coutRows <= 64 ? 4 : 8; }
 
@@ -1122,6 +1226,7 @@ public:
                 }
             return rc;
         }
+        if (wp_dev_ && conv1x1ResidentEligible(a)) return launchConv1x1Resident(a, wp_dev_, stream);
         if (wp_dev_) return launchConvHalo(a, wp_dev_, zeros_dev_, stream);
         return launchConv(a, KC(), stream);
     }
