@@ -904,7 +904,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
 // one sub-pixel (dy, dx) of the pixel shuffle, so the epilogue is the wide one (bias, ReLU, fp16, 16-byte stores).
 // Needs Cout == 128, Cin in {128, 192, 256}, fp16 output with 16-byte alignment, no residual.
 constexpr int C1_NW = 8;
-template <int KSTEPS>
+template <int KSTEPS, bool STRIDED>       // STRIDED: stride 2 (the shortcuts of the second and third stage): output pixel (y, x) reads input pixel (2y, 2x)
 __global__ void __launch_bounds__(64 * C1_NW, 2)
 conv1x1_resident_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT, int ngroup, int CTG)
 {
@@ -916,38 +916,50 @@ conv1x1_resident_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT, in
         const int q = u / CTG, t = u - q * CTG;
         __builtin_amdgcn_global_load_lds((glds_src_t)(Wp + (((size_t)q * NCT + type * CTG + t) * 64 + lane) * 8), (glds_dst_t)(smem + u * 1024), 16, 0, 0);
     }
-    if (wave == 0) {                                                 // 128 floats (zeros without a bias: any valid address, multiplied away below)
-        const float* src = a.bias ? a.bias + (lane < 32 ? lane * 4 : 0) : reinterpret_cast<const float*>(Wp);
+    if (wave == 0) {                                                 // Cout <= 256 floats (without a bias: any valid address, not used below)
+        const float* src = a.bias ? a.bias + (lane * 4 < a.Cout ? lane * 4 : 0) : reinterpret_cast<const float*>(Wp);
         __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + BIAS_OFF), 16, 0, 0);
     }
-    const int HW = a.H * a.W, NPIX = a.nb * HW, ntile = (NPIX + 15) >> 4, step = nj * C1_NW;
-    const float invHW = 1.0f / (float)HW, invW = 1.0f / (float)a.W;
+    const int HW = a.Ho * a.Wo, NPIX = a.nb * HW, ntile = (NPIX + 15) >> 4, step = nj * C1_NW;      // OUTPUT pixels (before the pixel shuffle)
+    const float invHW = 1.0f / (float)HW, invW = 1.0f / (float)a.Wo;
+    // output pixel -> (image, y, x): float quotients corrected by one step (exact for these sizes; belt and braces)
+    auto split = [&](int pc, int& b, int& y, int& xq) {
+        b = (int)(((float)pc + 0.5f) * invHW); b -= (b * HW > pc); b += ((b + 1) * HW <= pc);
+        const int rem = pc - b * HW;
+        y = (int)(((float)rem + 0.5f) * invW); y -= (y * a.Wo > rem); y += ((y + 1) * a.Wo <= rem);
+        xq = rem - y * a.Wo;
+    };
     auto loadRows = [&](int t, half8 (&x)[KSTEPS]) {
         t = t < ntile ? t : ntile - 1;                               // (past the end: the last tile again, no branch around a load)
         const int p = t * 16 + r, pc = p < NPIX ? p : NPIX - 1;
-        const _Float16* src = a.in + (size_t)pc * a.Cin + g * 8;
+        size_t ipix = (size_t)pc;
+        if (STRIDED) { int b, y, xq; split(pc, b, y, xq); ipix = (size_t)(b * a.H + y * a.stride) * a.W + xq * a.stride; }
+        const _Float16* src = a.in + ipix * a.Cin + g * 8;
 #pragma unroll
         for (int q = 0; q < KSTEPS; ++q) x[q] = *reinterpret_cast<const half8*>(src + q * 32);
     };
     const unsigned char* slot = smem + lane * 16;
     const int nstage = CTG >> 3;                                     // 128-column stages of this group
     const int Wout = a.Wo * a.up;
+    int sdy[2], sdx[2], scb[2];                                      // per stage of this group (<= 2): sub-pixel of the shuffle, first channel
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const int n0 = (type * nstage + st) * 128, sub = n0 / a.Cout;
+        sdy[st] = sub / a.up; sdx[st] = sub - sdy[st] * a.up; scb[st] = n0 - sub * a.Cout;
+    }
     auto tile = [&](int t, const half8 (&x)[KSTEPS]) {
         const int p = t * 16 + r;
         const bool valid = p < NPIX;
-        // pixel -> (image, y, x): float quotients corrected by one step (exact for these sizes; belt and braces)
-        const int pc = valid ? p : 0;
-        int b = (int)(((float)pc + 0.5f) * invHW); b -= (b * HW > pc); b += ((b + 1) * HW <= pc);
-        const int rem = pc - b * HW;
-        int y = (int)(((float)rem + 0.5f) * invW); y -= (y * a.W > rem); y += ((y + 1) * a.W <= rem);
-        const int xq = rem - y * a.W;
-        for (int st = 0; st < nstage; ++st) {
-            const int sub = type * nstage + st, dy = sub / a.up, dx = sub - dy * a.up;
+        int b, y, xq; split(valid ? p : 0, b, y, xq);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            if (st >= nstage) break;
+            const int dy = sdy[st], dx = sdx[st], cbase = scb[st];
             const size_t opix = (size_t)((b * a.Ho + y) * a.up + dy) * Wout + (xq * a.up + dx);
             floatx4 acc[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + BIAS_OFF + (u * 16 + 4 * g) * 4);
+                const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + BIAS_OFF + (cbase + u * 16 + 4 * g) * 4);
                 acc[u] = a.bias ? b4 : floatx4{0.f, 0.f, 0.f, 0.f};
             }
             const unsigned char* sp = slot + (st * 8) * 1024;
@@ -957,7 +969,7 @@ conv1x1_resident_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT, in
                 for (int u = 0; u < 8; ++u)
                     acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(sp + (size_t)(q * CTG + u) * 1024), x[q], acc[u], 0, 0, 0);
 #pragma unroll
-            for (int u = 0; u < 8; u += 2) convStoreWide<false>(a, acc[u], acc[u + 1], valid, opix, u * 16, g);
+            for (int u = 0; u < 8; u += 2) convStoreWide<false>(a, acc[u], acc[u + 1], valid, opix, cbase + u * 16, g);
         }
     };
     int tt = j * C1_NW + wave;
@@ -978,21 +990,25 @@ conv1x1_resident_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT, in
 }
 
 static int numCUs();
-static bool conv1x1ResidentEligible(const ConvArgs& a) {
-    static int on = -1;            // DSVT_CONV_1X1_RESIDENT=0: the halo kernel for the 1 x 1 layers too
+static bool conv1x1ResidentShape(int KH, int KW, int stride, int pad, int Cin, int Cout, int rows) {
+    static int on = -1;            // DSVT_CONV_1X1_RESIDENT=0: the halo / gather kernels for the 1 x 1 layers too
     if (on < 0) { const char* e = getenv("DSVT_CONV_1X1_RESIDENT"); on = e ? atoi(e) : 1; }
-    return on && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.Cout == 128 && a.CoutRows % 128 == 0 && a.wide && !a.res &&
-           !a.out_f32 && (a.Cin == 128 || a.Cin == 192 || a.Cin == 256);
+    return on && KH == 1 && KW == 1 && (stride == 1 || stride == 2) && pad == 0 && (Cout == 128 || Cout == 256) && rows % 128 == 0 &&
+           (Cin == 128 || Cin == 192 || Cin == 256);
+}
+static bool conv1x1ResidentEligible(const ConvArgs& a) {
+    return conv1x1ResidentShape(a.KH, a.KW, a.stride, a.pad, a.Cin, a.Cout, a.CoutRows) && a.wide && !a.res && !a.out_f32 && (a.stride == 1 || a.up == 1);
 }
 
 static int launchConv1x1Resident(const ConvArgs& a, const _Float16* Wp, hipStream_t stream) {
     const int NCT = cdiv(a.CoutRows, CNB) * 8;                      // fragment rows per k-step of the halo image
     const int CTG = NCT < 16 ? NCT : 16, ngroup = NCT / CTG;        // (NCT is 8 or a multiple of 16 for these layers)
     if (NCT % CTG != 0) return -3;
-    const int grid = numCUs() / ngroup * ngroup;
-    if (a.Cin == 128) hipLaunchKernelGGL((conv1x1_resident_kernel<4>), dim3(grid), dim3(64 * C1_NW), 0, stream, a, Wp, NCT, ngroup, CTG);
-    else if (a.Cin == 192) hipLaunchKernelGGL((conv1x1_resident_kernel<6>), dim3(grid), dim3(64 * C1_NW), 0, stream, a, Wp, NCT, ngroup, CTG);
-    else hipLaunchKernelGGL((conv1x1_resident_kernel<8>), dim3(grid), dim3(64 * C1_NW), 0, stream, a, Wp, NCT, ngroup, CTG);
+    const dim3 grid(numCUs() / ngroup * ngroup), block(64 * C1_NW);
+#define DSVT_C1(K_) do { if (a.stride == 2) hipLaunchKernelGGL((conv1x1_resident_kernel<K_, true>), grid, block, 0, stream, a, Wp, NCT, ngroup, CTG); \
+                         else hipLaunchKernelGGL((conv1x1_resident_kernel<K_, false>), grid, block, 0, stream, a, Wp, NCT, ngroup, CTG); } while (0)
+    if (a.Cin == 128) DSVT_C1(4); else if (a.Cin == 192) DSVT_C1(6); else DSVT_C1(8);
+#undef DSVT_C1
     return lastError();
 }
 
@@ -1153,7 +1169,7 @@ public:
             ok_ = hipMalloc(&b_dev_, sizeof(float) * nb) == hipSuccess && hipMemset(b_dev_, 0, sizeof(float) * nb) == hipSuccess &&
                   hipMemcpy(b_dev_, b_.data(), sizeof(float) * c.Cout, hipMemcpyHostToDevice) == hipSuccess;
         }
-        if (ok_ && haloEligible()) {
+        if (ok_ && (haloEligible() || conv1x1ResidentShape(c.KH, c.KW, c.stride, c.pad, c.Cin, c.Cout, rows()))) {
             // [k-step q = (cc * taps + tap) * 2 + ks][16-channel tile ct][lane (r, g)][8] <- W[ct*16 + r][tap][cc*64 + ks*32 + g*8 + j];
             // one 16 KB slab of zero padding at the end: the last slab of a narrow layer is requested whole
             const int T = c.KH * c.KW, NCC = c.Cin / 64, R = rows(), ctw = haloChannelTiles(R);
@@ -1207,7 +1223,7 @@ public:
         if ((long)a.nb * c_.H * c_.W * c_.Cin >= (1l << 31)) return -2;                // the halo kernel addresses the input with 32-bit element offsets
         static int tron = -1;                                                          // tools/trace_conv.py
         if (tron < 0) { const char* e = getenv("DSVT_CONV_TRACE"); tron = e ? atoi(e) : 0; }
-        if (tron && wp_dev_) {
+        if (tron && wp_dev_ && haloEligible()) {
             static unsigned long long* tr = nullptr;
             const size_t n = (size_t)4096 * 2 * CONV_TRACE_N;
             if (!tr && hipMalloc(&tr, n * 8) != hipSuccess) return -3;
@@ -1227,7 +1243,7 @@ public:
             return rc;
         }
         if (wp_dev_ && conv1x1ResidentEligible(a)) return launchConv1x1Resident(a, wp_dev_, stream);
-        if (wp_dev_) return launchConvHalo(a, wp_dev_, zeros_dev_, stream);
+        if (wp_dev_ && haloEligible()) return launchConvHalo(a, wp_dev_, zeros_dev_, stream);
         return launchConv(a, KC(), stream);
     }
     size_t serializationSize() const override { return 14 * sizeof(int) + sizeof(int) + sizeof(float) * (w_.size() + b_.size()); }
