@@ -190,13 +190,14 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
         if (wave >= nwa) return;
         m0 = blockIdx.x * 16 * nwa;
     } else {
-        const int T = (M + MROWS - 1) / MROWS, over = M - a.ncu * MROWS;
-        const bool plan = T > a.ncu && over <= MLP_SMALL_MAX && !(a.dbg & 32);
+        constexpr int WGR = 16 * MT * NW;                // rows of a full workgroup (128; 256 for <2, 8>)
+        const int T = (M + WGR - 1) / WGR, over = M - a.ncu * WGR;
+        const bool plan = WGR == MROWS && T > a.ncu && over <= MLP_SMALL_MAX && !(a.dbg & 32);
         const int FULL = plan ? a.ncu : T;
         small = (int)blockIdx.x >= FULL;
-        m0 = blockIdx.x * MROWS;
+        m0 = blockIdx.x * WGR;
         if (small) {
-            m0 = FULL * MROWS + ((int)blockIdx.x - FULL) * 16 * MT * MLP_SW;
+            m0 = FULL * WGR + ((int)blockIdx.x - FULL) * 16 * MT * MLP_SW;
             if (wave >= MLP_SW) return;
             nwa = MLP_SW;
         }
@@ -560,7 +561,7 @@ public:
         // (two frames: 539 workgroups = one full round of 512 and a 27-workgroup third of 43 us: 100 vs 89 us, hence the threshold).
         // The count lives on the device, so a plugin whose capacity spans both regimes launches BOTH kernels and the one whose regime it
         // is not returns at once (an empty launch: ~2 us).  DSVT_MLP_VARIANT forces one: 1 = <2,4> + small overflow workgroups,
-        // 2 = <1,8>, 3 = <1,10> elastic.
+        // 2 = <1,8>, 3 = <1,10> elastic, 4 = <2,8>.
         static int forced = -1;
         if (forced < 0) { const char* e = getenv("DSVT_MLP_VARIANT"); forced = e ? atoi(e) : 0; }
         const int thr = 5 * ncu * MROWS / 2;
@@ -588,6 +589,7 @@ public:
         if (variant == 3 && ring == 6) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 10, 64, 6>), grid, dim3(640), 0, stream, b);
         else if (variant == 3) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 10, 64, 3>), grid, dim3(640), 0, stream, b);
         else if (variant == 2) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, 64, 3>), grid, dim3(512), 0, stream, b);
+        else if (variant == 4) hipLaunchKernelGGL((encoder_mlp_stream_kernel<2, 8, 64, 3>), dim3(cdiv(max_rows_, 256)), dim3(512), 0, stream, b);   // experiment: ONE ring for 256 rows, eight waves in lockstep: 188 vs 155 us per four-frame launch for two independent <2,4> workgroups per CU
         else hipLaunchKernelGGL((encoder_mlp_stream_kernel<2, 4, 64, 3>), grid, dim3(256), 0, stream, b);
         if (tron) {
             (void)hipStreamSynchronize(stream);
