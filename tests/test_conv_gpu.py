@@ -28,6 +28,13 @@ def nhwc(t):      # NCHW tensor -> contiguous [1,H,W,C]
     (52, 47, 128, 256, 1, 2, False, False),    # 1x1 downsample
     (30, 33, 384, 64, 3, 1, False, True),      # shared head conv
     (30, 33, 64, 320, 3, 1, False, True),      # five head stems at once (KC=64, 3 chunks, last one partial)
+    # 1 x 1 layers on the resident-weights streaming kernel (conv1x1_resident_kernel): fewer pixels than one 16-pixel tile, odd sizes,
+    # six k-steps (192 input channels), stride 2 with an odd input size, 256 output channels
+    (5, 3, 128, 128, 1, 1, False, True),
+    (7, 9, 192, 128, 1, 1, False, True),
+    (37, 41, 256, 128, 1, 1, False, False),
+    (7, 9, 128, 128, 1, 2, False, False),
+    (117, 117, 128, 256, 1, 2, False, True),
 ])
 def test_conv_matches_torch(pkg, H, W, cin, cout, k, stride, res, relu):
     P = pkg.plugin
@@ -87,7 +94,8 @@ def test_deconv_pixel_shuffle_and_concat(pkg, k, cin):
 @pytest.mark.parametrize("H,W,cin,cout,k,res", [
     (468, 468, 128, 128, 3, True),      # 885 (8-row) / 705 (10-row) tiles over 256 CUs: every workgroup walks several items
     (234, 234, 64, 320, 3, False),      # three 128-channel chunks per tile, the last one half full
-    (117, 117, 256, 256, 1, False),     # 1x1: no halo, one slab per 64-channel chunk
+    (117, 117, 256, 256, 1, False),     # 1x1: the resident-weights kernel, one 16-tile column group (two 128-column stages)
+    (468, 468, 192, 128, 1, False),     # the first block's shortcut at full size: six k-steps, one stage
     (468, 468, 192, 128, 3, False),     # first BEV conv on the 16-row kernel: six 32-channel phases, 27 slabs
     (468, 468, 64, 384, 3, False),      # head stems on the 16-row kernel: two phases, three chunks, 1350 items
     (250, 200, 128, 128, 3, True),      # 16-row kernel with ragged bottom / right tiles, grid = item count
