@@ -376,3 +376,33 @@ def test_four_frames_per_forward_equal_single_frame_forwards(pkg, weights):
     g_rows, g_cnt = four.replay()
     torch.cuda.synchronize()
     assert torch.equal(g_rows, rows) and torch.equal(g_cnt, cnt)
+
+
+def test_four_frames_per_forward_with_an_empty_and_a_one_point_frame(pkg, weights):
+    """ragged stack: [180k points, NO points, ONE point, 120k points] in one forward() -- the empty frames contribute no pillar rows,
+    no sets and an all-bias BEV map (whose top-K takes the exact fallback), the others must come out as from their own single-frame
+    runs, bit for bit, whatever sits in the neighbouring slots."""
+    P = pkg.plugin
+    kw = dict(linear_compute=P.COMPUTE_F16, head_dtype=torch.float16, device_nms=True, device=DEV)
+    one = pkg.pipeline.DsvtPipeline(weights, caps=pkg.pipeline.Caps(), **kw)
+    caps4 = pkg.pipeline.Caps.for_frames(4)
+    four = pkg.pipeline.DsvtPipeline(weights, caps=caps4, frames=4, **kw)
+    single_pt = np.array([[3.1, -7.9, -1.0, 0.5]], np.float32)
+    clouds = [pkg.synth.lidar_like(180000, 21), np.zeros((0, 4), np.float32), single_pt, pkg.synth.lidar_like(120000, 22)]
+    singles = []
+    for p in clouds:
+        pts, n = cases.pad_points(p, one.caps.N)
+        r, c = _run(pkg, one, pts, n)
+        torch.cuda.synchronize()
+        singles.append((r[0].clone(), int(c[0])))
+    buf = np.zeros((1, 4 * caps4.N, 4), np.float32)
+    for slot, p in enumerate(clouds):
+        buf[0, slot * caps4.N:slot * caps4.N + p.shape[0]] = p
+    n = torch.tensor([p.shape[0] for p in clouds], dtype=torch.int32, device=DEV)
+    rows, cnt = four.forward(torch.from_numpy(buf).to(DEV), n)
+    torch.cuda.synchronize()
+    assert singles[0][1] > 0 and singles[3][1] > 0
+    for slot in range(4):
+        assert int(cnt[slot]) == singles[slot][1], (slot, int(cnt[slot]), singles[slot][1])
+        k = singles[slot][1]
+        assert torch.equal(rows[slot][:k], singles[slot][0][:k]), (slot, float((rows[slot][:k] - singles[slot][0][:k]).abs().max()))
