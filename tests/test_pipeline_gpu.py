@@ -22,9 +22,10 @@ def weights(pkg):
 
 def _frame_and_caps(pkg, frame):
     """a reference frame under the reference caps, or `lidar_like(N, 0)` (frame = "lidar<N>") under the Waymo-sized caps"""
-    if frame.startswith("lidar"):
+    if frame.startswith("lidar"):                 # "lidar<N>" (seed 0) or "lidar<N>s<seed>"
         caps = pkg.pipeline.Caps()
-        pts, n = cases.pad_points(pkg.synth.lidar_like(int(frame[5:]), 0), caps.N)
+        npts, _, seed = frame[5:].partition("s")
+        pts, n = cases.pad_points(pkg.synth.lidar_like(int(npts), int(seed or 0)), caps.N)
     else:
         caps = pkg.pipeline.Caps.reference()
         pts, n = cases.load_frame(frame, caps.N)
@@ -161,7 +162,7 @@ def _box_errors(got, n_got, exp, n_exp):
 F16_TOL = dict(xy=1.2e-3, z=3e-3, size=6e-3, score=1e-3, yaw=1e-1)
 
 
-@pytest.mark.parametrize("frame", ["000000", "000003", "000004", "lidar180000"])
+@pytest.mark.parametrize("frame", ["000000", "000003", "000004", "lidar180000", "lidar60000s3", "lidar196000s5"])
 def test_boxes_f16_mode(pkg, oracle, weights, frame):
     """BASELINE configs[2] precision ("fp16"): fp16 MFMA operands / fp16 BEV activations, fp32 accumulate,
     fp32 LayerNorm / softmax / decode -- the mode bench.py times by default, on the three distinct reference frames and on the
