@@ -99,7 +99,7 @@ def test_config1_60k_cloud_one_block_fp32(pkg, oracle, weights):
     assert not x[0, Pn:].any()
 
 
-@pytest.mark.parametrize("frame", ["000000", "000004", "lidar180000"])
+@pytest.mark.parametrize("frame", ["000000", "000004", "lidar180000", "lidar60000s3"])
 def test_boxes_reference_frames(pkg, oracle, weights, frame):
     """fp32 mode of the HIP path against the oracle at the north-star tolerance, on reference frames and on the bench frame
     (BASELINE configs[2] size: 180k points, 34.5k pillars, 1714 / 1158 sets)."""
