@@ -893,6 +893,119 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
 }
 
 // -------------------------------------------------------------------------------------
+// Narrow 3 x 3 layers whose weights are BLOCK-DIAGONAL over 64-channel phases (round 2): the CenterHead's five output
+// convolutions (64 -> 2 / 1 / 3 / 2 / 10, src/dsvt-ai-trt.cpp:1378-1468) arrive as ONE 320 -> 18 layer whose output channel n reads
+// only the 64 input channels of its head.  The halo kernel computes it densely: per 8-row x 32-pixel item 218 KB of halo (five phases)
+// and 184 KB of weights through LDS, 1.4 GB of LDS-DMA per four-frame launch at the ~21 GB/s per CU that path delivers: 271 us.
+// Here a workgroup belongs to ONE phase (= head) for the whole launch: its 18 fragment rows of weights (one 16-channel tile x 9 taps
+// x 2 k-steps, 18 KB) are resident, and per item only that phase's halo (51 KB with the row padding) streams, double buffered -- 0.9 GB per launch.
+// A zero weight contributes an exact +0 to an fp32 sum, so the outputs are the dense kernel's bits.
+__global__ void __launch_bounds__(512, 1)
+conv3x3_grouped_narrow_kernel(ConvArgs a, const _Float16* __restrict__ Wg, const int* __restrict__ chanTab, const _Float16* __restrict__ zeros,
+                              int tilesX, int tilesY, int NCC)
+{
+    constexpr int TH = 8, HS = HHS, HH = TH + 2, HWU = HTW + 2, HBYTES = HH * HS * 128, NI = HH * HS / 8, HPW = (NI + TH - 1) / TH;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HBYTES + 18 * 1024];            // halo[2] | the phase's weights
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int pg = wave >> 1, m0 = 2 * (wave & 1);                      // rows 2 pg, 2 pg + 1; pixel tiles m0, m0 + 1 of the row pair's four
+    const int cc = (int)blockIdx.x % NCC, j = (int)blockIdx.x / NCC, nj = ((int)gridDim.x - cc + NCC - 1) / NCC;
+    const int ntile = a.nb * tilesY * tilesX;
+    if (j >= ntile) return;
+    for (int u = wave; u < 18; u += TH)
+        __builtin_amdgcn_global_load_lds((glds_src_t)(Wg + (((size_t)cc * 18 + u) * 64 + lane) * 8), (glds_dst_t)(smem + 2 * HBYTES + u * 1024), 16, 0, 0);
+    int ch[4]; float bs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ch[i] = chanTab[cc * 16 + 4 * g + i];
+        bs[i] = (ch[i] >= 0 && a.bias) ? a.bias[ch[i]] : 0.f;
+    }
+    int hpos[HPW], goff[HPW];
+#pragma unroll
+    for (int q = 0; q < HPW; ++q) {
+        const int lp = 8 * (wave + q * TH) + (lane >> 3), slot = lane & 7;
+        const int hy = lp / HS, hx = lp - hy * HS;
+        hpos[q] = (hy << 16) | (hx << 4) | (slot ^ (hx & 7));
+    }
+    auto decode = [&](int t, int& yy, int& xx, int& bb) {
+        const int per = tilesY * tilesX;
+        bb = t / per; t -= bb * per;
+        yy = (t / tilesX) * TH; xx = (t % tilesX) * HTW;
+    };
+    auto setup = [&](int yy, int xx, int bb) {
+#pragma unroll
+        for (int q = 0; q < HPW; ++q) {
+            const int hx = (hpos[q] >> 4) & 0xfff;
+            const int gy = yy - 1 + (hpos[q] >> 16), gx = xx - 1 + hx;
+            const bool ok = hx < HWU && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            goff[q] = ok ? ((bb * a.H + gy) * a.W + gx) * a.Cin + cc * 64 + (hpos[q] & 15) * 8 : -1;
+        }
+    };
+    auto haloRequests = [&](int hb) {
+#pragma unroll
+        for (int q = 0; q < HPW; ++q)
+            if (NI % TH == 0 || wave + q * TH < NI) {
+                const _Float16* src = goff[q] >= 0 ? a.in + goff[q] : zeros;
+                __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + hb * HBYTES + (wave + q * TH) * 1024), 16, 0, 0);
+            }
+    };
+    int pbase[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) pbase[m] = ((2 * pg + ((m0 + m) >> 1)) * HS + ((m0 + m) & 1) * 16 + r) * 128;
+    int swz[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) swz[kx] = (g ^ ((r + kx) & 7)) << 4;
+    const unsigned char* wres = smem + 2 * HBYTES + (lane << 4);
+
+    int t = j, y0, x0, bimg;
+    decode(t, y0, x0, bimg);
+    setup(y0, x0, bimg);
+    haloRequests(0);
+    slabBarrier(0);
+    int hb = 0;
+    for (;;) {
+        const int tn = t + nj;
+        const bool have_next = tn < ntile;
+        int ny0 = 0, nx0 = 0, nb_ = 0;
+        if (have_next) { decode(tn, ny0, nx0, nb_); setup(ny0, nx0, nb_); haloRequests(hb ^ 1); }
+        floatx4 acc[2] = {floatx4{bs[0], bs[1], bs[2], bs[3]}, floatx4{bs[0], bs[1], bs[2], bs[3]}};      // (the sums start from the bias, like the dense kernel's)
+        const unsigned char* hbp = smem + hb * HBYTES;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky, toff = (ky * HS + kx) * 128, sw = swz[kx];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const half8 A = *reinterpret_cast<const half8*>(wres + ((tap * 2 + ks) << 10));
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const half8 B = *reinterpret_cast<const half8*>(hbp + pbase[m] + toff + (sw ^ (ks << 6)));
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, acc[m], 0, 0, 0);
+                }
+            }
+        }
+        if (have_next) slabBarrier(0);                               // the next halo has landed; everyone is done with this one
+        // (the stores after the wait: they drain under the next item's MFMAs instead of being awaited with the halo.  The same loop with the
+        // halo staged through registers, one or two items ahead with counted waits: 200 / 206 us against 197 -- the floor of this tiling is
+        // its halo traffic, 10 x 34 pixels read per 8 x 32 written)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int oy = y0 + 2 * pg + ((m0 + m) >> 1), ox = x0 + ((m0 + m) & 1) * 16 + r;
+            if (!(oy < a.Ho && ox < a.Wo)) continue;
+            const size_t opix = (size_t)(bimg * a.Ho + oy) * a.Wo + ox;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (ch[i] < 0) continue;
+                float v = acc[m][i];
+                if (a.relu) v = fmaxf(v, 0.f);
+                if (a.out_f32) static_cast<float*>(a.out)[opix * a.out_ld + a.out_coff + ch[i]] = v;
+                else static_cast<_Float16*>(a.out)[opix * a.out_ld + a.out_coff + ch[i]] = (_Float16)v;
+            }
+        }
+        if (!have_next) break;
+        hb ^= 1; t = tn; y0 = ny0; x0 = nx0; bimg = nb_;
+    }
+}
+
+// -------------------------------------------------------------------------------------
 // 1 x 1 stride-1 layers (the shortcut of the first block and the three deblocks = 1 x 1 + pixel shuffle) as a streaming GEMM
 // with the weights RESIDENT in LDS (round 2).  The halo kernel above treats a 1 x 1 layer like a 3 x 3 one: per 8-row x 32-pixel x
 // 128-channel item it streams the input tile and the weight slabs through LDS -- for the 256 -> 16 x 128 deblock that is the same
@@ -1140,6 +1253,7 @@ public:
     _Float16* w_dev_ = nullptr; float* b_dev_ = nullptr;
     _Float16* wp_dev_ = nullptr;         // fragment-packed copy for the halo kernel (stride-1 layers)
     _Float16* zeros_dev_ = nullptr;      // 256 zero bytes: LDS-DMA source of out-of-image halo pixels
+    _Float16* wg_dev_ = nullptr; int* chan_dev_ = nullptr; int groups_ = 0;      // block-diagonal narrow 3 x 3 layer: per-phase weight tiles + channel table
     bool ok_ = false;
     bool haloEligible() const {
         static int on = -1;
@@ -1190,9 +1304,48 @@ public:
                   hipMemcpy(wp_dev_, wp.data(), sizeof(_Float16) * wp.size(), hipMemcpyHostToDevice) == hipSuccess &&
                   hipMalloc(&zeros_dev_, 256) == hipSuccess && hipMemset(zeros_dev_, 0, 256) == hipSuccess;
         }
+        if (ok_ && zeros_dev_) packGrouped(wh);
+    }
+    // A narrow 3 x 3 stride-1 layer every output channel of which reads ONE 64-channel phase of the input (the CenterHead's five output
+    // convolutions folded into one block-diagonal layer): per phase one 16-channel tile of fragment rows [tap][k-step] and the table of the
+    // tile's real channels.  Anything else (a channel that reads two phases, more than 16 channels on a phase) stays on the dense kernels.
+    void packGrouped(const std::vector<_Float16>& wh) {
+        static int on = -1;        // DSVT_CONV_GROUPED=0: the dense halo kernel for block-diagonal layers too
+        if (on < 0) { const char* e = getenv("DSVT_CONV_GROUPED"); on = e ? atoi(e) : 1; }
+        const ConvCfg& c = c_;
+        if (!on || c.KH != 3 || c.KW != 3 || c.stride != 1 || c.pad != 1 || c.up != 1 || c.has_res || c.Cin % 64 != 0 || c.Cin < 128 || c.Cout > 64) return;
+        const int NCC = c.Cin / 64;
+        std::vector<std::vector<int>> chans(NCC);
+        for (int n = 0; n < c.Cout; ++n) {
+            int phase = -1;
+            for (int tap = 0; tap < 9; ++tap)
+                for (int k = 0; k < c.Cin; ++k)
+                    if (w_[((size_t)n * 9 + tap) * c.Cin + k] != 0.f) {
+                        if (phase >= 0 && phase != k / 64) return;                 // reads two phases: dense
+                        phase = k / 64;
+                    }
+            chans[phase < 0 ? 0 : phase].push_back(n);
+        }
+        for (auto& v : chans) if (v.size() > 16) return;
+        std::vector<_Float16> wg((size_t)NCC * 18 * 512, (_Float16)0.f);
+        std::vector<int> tab((size_t)NCC * 16, -1);
+        for (int cc = 0; cc < NCC; ++cc)
+            for (size_t i = 0; i < chans[cc].size(); ++i) {
+                const int n = chans[cc][i];
+                tab[cc * 16 + i] = n;
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int ks = 0; ks < 2; ++ks)
+                        for (int gq = 0; gq < 4; ++gq)
+                            for (int jq = 0; jq < 8; ++jq)
+                                wg[(((size_t)cc * 18 + tap * 2 + ks) * 64 + gq * 16 + i) * 8 + jq] = wh[((size_t)n * 9 + tap) * c.Cin + cc * 64 + ks * 32 + gq * 8 + jq];
+            }
+        if (hipMalloc(&wg_dev_, sizeof(_Float16) * wg.size()) != hipSuccess || hipMalloc(&chan_dev_, sizeof(int) * tab.size()) != hipSuccess ||
+            hipMemcpy(wg_dev_, wg.data(), sizeof(_Float16) * wg.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(chan_dev_, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) { ok_ = false; return; }
+        groups_ = NCC;
     }
     ~DsvtConv2dPlugin() override {
-        if (w_dev_) (void)hipFree(w_dev_); if (b_dev_) (void)hipFree(b_dev_); if (wp_dev_) (void)hipFree(wp_dev_); if (zeros_dev_) (void)hipFree(zeros_dev_);
+        if (w_dev_) (void)hipFree(w_dev_); if (b_dev_) (void)hipFree(b_dev_); if (wp_dev_) (void)hipFree(wp_dev_); if (zeros_dev_) (void)hipFree(zeros_dev_); if (wg_dev_) (void)hipFree(wg_dev_); if (chan_dev_) (void)hipFree(chan_dev_);
     }
     const char* type() const override { return "DsvtConv2dPlugin"; }
     bool handlesBatch() const override { return true; }          // a stack of images is ONE launch: the persistent kernels walk image after image
@@ -1241,6 +1394,11 @@ public:
                     fprintf(stderr, "\n");
                 }
             return rc;
+        }
+        if (groups_ > 0) {
+            const int tilesX = cdiv(a.Wo, HTW), tilesY = cdiv(a.Ho, 8);
+            hipLaunchKernelGGL(conv3x3_grouped_narrow_kernel, dim3(numCUs()), dim3(512), 0, stream, a, wg_dev_, chan_dev_, zeros_dev_, tilesX, tilesY, groups_);
+            return lastError();
         }
         if (wp_dev_ && conv1x1ResidentEligible(a)) return launchConv1x1Resident(a, wp_dev_, stream);
         if (wp_dev_ && haloEligible()) return launchConvHalo(a, wp_dev_, zeros_dev_, stream);

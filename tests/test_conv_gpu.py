@@ -225,3 +225,31 @@ def test_conv_stack_of_images_is_one_launch(pkg, H, W, cin, cout, k, stride, res
         torch.cuda.synchronize()
         sl = slice(128, 256) if shuffle > 1 else slice(None)
         assert torch.equal(out[i][..., sl], ref[0][..., sl]), (i, float((out[i][..., sl].float() - ref[0][..., sl].float()).abs().max()))
+
+
+@pytest.mark.parametrize("H,W,B", [(468, 468, 1), (61, 45, 3), (7, 5, 2)])
+def test_block_diagonal_narrow_conv_on_the_grouped_kernel(pkg, H, W, B):
+    """The CenterHead's five output convolutions (64 -> 2 / 1 / 3 / 2 / 10) as ONE 320 -> 18 layer with block-diagonal weights:
+    conv3x3_grouped_narrow_kernel (one 64-channel phase per workgroup, weights resident) against PyTorch, and -- bit for bit -- against
+    the dense halo kernel, reached by making one structural zero a value that is non-zero in fp32 and zero in fp16."""
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(H * 7 + W)
+    heads = [2, 1, 3, 2, 10]
+    cin, cout = 64 * len(heads), sum(heads)
+    w = torch.zeros(cout, cin, 3, 3)
+    n0 = 0
+    for h, n in enumerate(heads):
+        w[n0:n0 + n, 64 * h:64 * (h + 1)] = torch.randn(n, 64, 3, 3, generator=g) / 24.0
+        n0 += n
+    b = torch.randn(cout, generator=g) * 0.1
+    x = torch.randn(B, cin, H, W, generator=g).half().to(DEV)
+    xin = x.permute(0, 2, 3, 1).contiguous()
+    mk = lambda ww: P.add_conv2d_op(P.conv_weight_rows(ww.numpy()), b.numpy(), H, W, cin, cout, 3, 1, 1, out_f32=True)
+    got = mk(w)(xin)[0]
+    w_dense = w.clone(); w_dense[0, 100, 1, 1] = 1e-30            # channel 0 now "reads" phase 1 as well: dense path, same fp16 weights
+    ref_dense = mk(w_dense)(xin)[0]
+    torch.cuda.synchronize()
+    assert got.dtype == torch.float32 and tuple(got.shape) == (B, H, W, cout)
+    assert torch.equal(got, ref_dense), float((got - ref_dense).abs().max())
+    ref = _ref(x, w.half().to(DEV), b.to(DEV), 1, 1)
+    assert (got.permute(0, 3, 1, 2) - ref).abs().max().item() < 1e-3 * ref.abs().max().item()
