@@ -1006,6 +1006,125 @@ conv3x3_grouped_narrow_kernel(ConvArgs a, const _Float16* __restrict__ Wg, const
 }
 
 // -------------------------------------------------------------------------------------
+// 3 x 3 stride-1 layers with 64 INPUT channels and a multiple of 64 output channels (round 2): the CenterHead's five stems as one
+// 64 -> 320 layer.  On conv_wide_kernel<8, 4, 36, 2, 2> an 8-row x 32-pixel x 128-channel item streams 147 KB of weights beside 46 KB of
+// halo: 2 GB of LDS-DMA per four-frame launch, which is what bounds it (415-439 us; its MFMAs would take ~215).  Here a workgroup owns
+// 64 output channels for the whole launch -- 72 fragment rows of weights (four channel tiles x 9 taps x 2 k-steps, 72 KB) resident --
+// and walks 8-row x 32-pixel tiles of which only the halo moves: 0.9 GB per launch.  LDS holds ONE halo buffer beside the weights
+// (51 + 72 KB); the next item's halo waits in seven staging registers per lane, requested before this item's 144 MFMAs per wave and
+// written to LDS after them (through registers a one-item lead costs no second buffer; measured equal to a DMA double buffer on the
+// narrow kernel above).  Wave (pg, half) = rows 2 pg, 2 pg + 1 x two pixel tiles x all four channel tiles (0.75 fragment reads per MFMA).
+__global__ void __launch_bounds__(512, 1)
+conv3x3_c64_resident_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT, const _Float16* __restrict__ zeros, int tilesX, int tilesY, int NTY)
+{
+    constexpr int TH = 8, HS = HHS, HH = TH + 2, HWU = HTW + 2, HBYTES = HH * HS * 128, NI = HH * HS / 8, HPW = (NI + TH - 1) / TH;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[HBYTES + 72 * 1024 + 1024];        // halo | weights [k-step][4 tiles] | bias (64 floats)
+    constexpr int W_OFF = HBYTES, BIAS_OFF = HBYTES + 72 * 1024;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int pg = wave >> 1, m0 = 2 * (wave & 1);
+    const int ty = (int)blockIdx.x % NTY, j = (int)blockIdx.x / NTY, nj = ((int)gridDim.x - ty + NTY - 1) / NTY;
+    const int ntile = a.nb * tilesY * tilesX;
+    if (j >= ntile) return;
+    // the halo image's rows [q = tap * 2 + ks][16-channel tile ct of NCT]: this type's four tiles of every k-step
+    for (int u = wave; u < 72; u += TH) {
+        const int q = u >> 2, ct = u & 3;
+        __builtin_amdgcn_global_load_lds((glds_src_t)(Wp + (((size_t)q * NCT + ty * 4 + ct) * 64 + lane) * 8), (glds_dst_t)(smem + W_OFF + u * 1024), 16, 0, 0);
+    }
+    if (wave == 0) {                                                 // this type's 64 bias values (any valid address without a bias: unused)
+        const float* src = a.bias ? a.bias + ((ty * 64) % a.Cout) + (lane < 16 ? lane * 4 : 0) : reinterpret_cast<const float*>(Wp);
+        __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + BIAS_OFF), 16, 0, 0);
+    }
+    int hpos[HPW], goff[HPW];
+#pragma unroll
+    for (int q = 0; q < HPW; ++q) {
+        const int lp = 8 * (wave + q * TH) + (lane >> 3), slot = lane & 7;
+        const int hy = lp / HS, hx = lp - hy * HS;
+        hpos[q] = (hy << 16) | (hx << 4) | (slot ^ (hx & 7));
+    }
+    auto decode = [&](int t, int& yy, int& xx, int& bb) {
+        const int per = tilesY * tilesX;
+        bb = t / per; t -= bb * per;
+        yy = (t / tilesX) * TH; xx = (t % tilesX) * HTW;
+    };
+    half8 stage[HPW];
+    auto haloLoad = [&](int t) {                                     // tile t (clamped: no branch around a load) -> staging registers
+        int yy, xx, bb;
+        decode(t < ntile ? t : ntile - 1, yy, xx, bb);
+#pragma unroll
+        for (int q = 0; q < HPW; ++q) {
+            const int hx = (hpos[q] >> 4) & 0xfff;
+            const int gy = yy - 1 + (hpos[q] >> 16), gx = xx - 1 + hx;
+            const bool ok = hx < HWU && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            goff[q] = ok ? ((bb * a.H + gy) * a.W + gx) * a.Cin + (hpos[q] & 15) * 8 : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < HPW; ++q)
+            if (NI % TH == 0 || wave + q * TH < NI) stage[q] = *reinterpret_cast<const half8*>(goff[q] >= 0 ? a.in + goff[q] : zeros);
+    };
+    auto haloWrite = [&]() {
+#pragma unroll
+        for (int q = 0; q < HPW; ++q)
+            if (NI % TH == 0 || wave + q * TH < NI) *reinterpret_cast<half8*>(smem + (wave + q * TH) * 1024 + lane * 16) = stage[q];
+    };
+    int pbase[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) pbase[m] = ((2 * pg + ((m0 + m) >> 1)) * HS + ((m0 + m) & 1) * 16 + r) * 128;
+    int swz[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) swz[kx] = (g ^ ((r + kx) & 7)) << 4;
+    const unsigned char* wres = smem + W_OFF + (lane << 4);
+    const int n0 = ty * 64, sub = n0 / a.Cout, cbase = n0 - sub * a.Cout;       // (no pixel shuffle on these layers: sub = 0)
+
+    int t = j;
+    haloLoad(t);
+    haloWrite();
+    slabBarrier(0);                                                  // halo of the first item, weights and bias
+    for (;;) {
+        const int tn = t + nj;
+        const bool have_next = tn < ntile;
+        haloLoad(tn);                                                // in flight under this item's MFMAs
+        int y0, x0, bimg;
+        decode(t, y0, x0, bimg);
+        floatx4 acc[4][2];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + BIAS_OFF + (ct * 16 + 4 * g) * 4);
+            acc[ct][0] = a.bias ? b4 : floatx4{0.f, 0.f, 0.f, 0.f}; acc[ct][1] = acc[ct][0];
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky, toff = (ky * HS + kx) * 128, sw = swz[kx];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                half8 A[4], B[2];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) A[ct] = *reinterpret_cast<const half8*>(wres + (((tap * 2 + ks) * 4 + ct) << 10));
+#pragma unroll
+                for (int m = 0; m < 2; ++m) B[m] = *reinterpret_cast<const half8*>(smem + pbase[m] + toff + (sw ^ (ks << 6)));
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[ct][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ct], B[m], acc[ct][m], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                             // everyone is done with this halo
+        if (have_next) haloWrite();
+        __syncthreads();
+        // (the stores after the barriers: they drain under the next item's MFMAs)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int oy = y0 + 2 * pg + ((m0 + m) >> 1), ox = x0 + ((m0 + m) & 1) * 16 + r;
+            const bool valid = oy < a.Ho && ox < a.Wo;
+            const size_t opix = valid ? (size_t)(bimg * a.Ho + oy) * a.Wo + ox : 0;
+            convStoreWide<false>(a, acc[0][m], acc[1][m], valid, opix, cbase, g);
+            convStoreWide<false>(a, acc[2][m], acc[3][m], valid, opix, cbase + 32, g);
+        }
+        if (!have_next) break;
+        t = tn;
+    }
+}
+
+// -------------------------------------------------------------------------------------
 // 1 x 1 stride-1 layers (the shortcut of the first block and the three deblocks = 1 x 1 + pixel shuffle) as a streaming GEMM
 // with the weights RESIDENT in LDS (round 2).  The halo kernel above treats a 1 x 1 layer like a 3 x 3 one: per 8-row x 32-pixel x
 // 128-channel item it streams the input tile and the weight slabs through LDS -- for the 256 -> 16 x 128 deblock that is the same
@@ -1111,6 +1230,13 @@ static bool conv1x1ResidentShape(int KH, int KW, int stride, int pad, int Cin, i
 }
 static bool conv1x1ResidentEligible(const ConvArgs& a) {
     return conv1x1ResidentShape(a.KH, a.KW, a.stride, a.pad, a.Cin, a.Cout, a.CoutRows) && a.wide && !a.res && !a.out_f32 && (a.stride == 1 || a.up == 1);
+}
+
+static bool conv3x3C64Eligible(const ConvArgs& a) {
+    static int on = -1;            // DSVT_CONV_C64_RESIDENT=0: conv_wide_kernel for the 64-input-channel 3 x 3 layers too
+    if (on < 0) { const char* e = getenv("DSVT_CONV_C64_RESIDENT"); on = e ? atoi(e) : 1; }
+    return on && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.up == 1 && a.Cin == 64 && a.CoutRows == a.Cout && a.Cout % 64 == 0 &&
+           a.wide && !a.res && !a.out_f32;
 }
 
 static int launchConv1x1Resident(const ConvArgs& a, const _Float16* Wp, hipStream_t stream) {
@@ -1401,6 +1527,11 @@ public:
             return lastError();
         }
         if (wp_dev_ && conv1x1ResidentEligible(a)) return launchConv1x1Resident(a, wp_dev_, stream);
+        if (wp_dev_ && conv3x3C64Eligible(a)) {
+            const int tilesX = cdiv(a.Wo, HTW), tilesY = cdiv(a.Ho, 8);
+            hipLaunchKernelGGL(conv3x3_c64_resident_kernel, dim3(numCUs()), dim3(512), 0, stream, a, wp_dev_, cdiv(a.CoutRows, CNB) * 8, zeros_dev_, tilesX, tilesY, a.CoutRows / 64);
+            return lastError();
+        }
         if (wp_dev_ && haloEligible()) return launchConvHalo(a, wp_dev_, zeros_dev_, stream);
         return launchConv(a, KC(), stream);
     }
