@@ -7,8 +7,8 @@
 Four frames per forward() (their pillar rows concatenated: one launch per backbone layer for all of them, `--batch`; BASELINE
 configs[3] puts four frames on each GPU per batch) on each of two streams (`--streams`) are the default.  Measured on one MI355X
 (frames/s, p50 per-frame ms; a frame is done when its forward() is), frames per forward x streams:
-    1 x 1  455 / 2.2      1 x 2  540 / 3.7      2 x 1  513 / 3.9      2 x 2  575 / 6.8
-    3 x 2  606 / 9.6      4 x 1  579 / 7.0      4 x 2  647 / 12.3 (default)
+    1 x 1  471 / 2.1      1 x 2  577 / 3.4      2 x 2  603 / 6.6
+    3 x 2  644 / 9.2      4 x 1  595 / 6.7      4 x 2  663 / 11.9 (default)
 `--batch 1 --streams 1` is the latency mode (the reference's own: one frame at a time).
 
 A step = one frame through the whole pipeline (BASELINE.json configs[2]: Waymo-shaped
