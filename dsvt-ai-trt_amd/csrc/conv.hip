@@ -1529,7 +1529,8 @@ public:
         if (wp_dev_ && conv1x1ResidentEligible(a)) return launchConv1x1Resident(a, wp_dev_, stream);
         if (wp_dev_ && conv3x3C64Eligible(a)) {
             const int tilesX = cdiv(a.Wo, HTW), tilesY = cdiv(a.Ho, 8);
-            hipLaunchKernelGGL(conv3x3_c64_resident_kernel, dim3(numCUs()), dim3(512), 0, stream, a, wp_dev_, cdiv(a.CoutRows, CNB) * 8, zeros_dev_, tilesX, tilesY, a.CoutRows / 64);
+            const int ctw = haloChannelTiles(a.CoutRows), NCT = ctw < 8 ? ctw : cdiv(a.CoutRows, CNB) * 8;      // column tiles per k-step of the halo image
+            hipLaunchKernelGGL(conv3x3_c64_resident_kernel, dim3(numCUs()), dim3(512), 0, stream, a, wp_dev_, NCT, zeros_dev_, tilesX, tilesY, a.CoutRows / 64);
             return lastError();
         }
         if (wp_dev_ && haloEligible()) return launchConvHalo(a, wp_dev_, zeros_dev_, stream);

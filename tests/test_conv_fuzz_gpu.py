@@ -1,0 +1,81 @@
+"""Random small shapes through the convolution kernels that keep their weights resident in LDS (round 2): the 1 x 1 streaming GEMM
+(stride 1 / 2, pixel shuffle), the 64-input-channel 3 x 3 kernel and the block-diagonal narrow 3 x 3 kernel -- images smaller than a
+tile, ragged right / bottom tiles, stacks of images -- against PyTorch on the same fp16 operands."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def _cases(seed, n):
+    rng = np.random.default_rng(seed)
+    return [tuple(int(v) for v in (rng.integers(1, 70), rng.integers(1, 90), rng.integers(1, 4), rng.integers(0, 1 << 30))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("H,W,B,seed", _cases(11, 24))
+def test_fuzz_conv1x1_resident(pkg, H, W, B, seed):
+    P = pkg.plugin
+    rng = np.random.default_rng(seed)
+    cin = int(rng.choice([128, 192, 256])); stride = int(rng.choice([1, 1, 2])); up = 1 if stride == 2 else int(rng.choice([1, 2, 4]))
+    cout = 128 if up > 1 else int(rng.choice([128, 256]))
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(B, cin, H, W, generator=g).half().to(DEV)
+    b = (torch.randn(cout, generator=g) * 0.1)
+    if up > 1:
+        w = torch.randn(cin, cout, up, up, generator=g) / np.sqrt(cin)
+        ref = torch.relu(F.conv_transpose2d(x.float(), w.half().float().to(DEV), b.to(DEV), stride=up))
+        op = P.add_conv2d_op(P.deconv_weight_rows(w.numpy()), b.numpy(), H, W, cin, cout, 1, 1, 0, pixel_shuffle=up, relu=True)
+    else:
+        w = torch.randn(cout, cin, 1, 1, generator=g) / np.sqrt(cin)
+        ref = torch.relu(F.conv2d(x.float(), w.half().float().to(DEV), b.to(DEV), stride))
+        op = P.add_conv2d_op(P.conv_weight_rows(w.numpy()), b.numpy(), H, W, cin, cout, 1, stride, 0, relu=True)
+    got = op(_nhwc(x))[0]
+    torch.cuda.synchronize()
+    assert tuple(got.shape) == (B, ref.shape[2], ref.shape[3], cout)
+    assert (got.permute(0, 3, 1, 2).float() - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("H,W,B,seed", _cases(12, 20))
+def test_fuzz_conv3x3_c64_resident(pkg, H, W, B, seed):
+    P = pkg.plugin
+    rng = np.random.default_rng(seed)
+    cout = int(rng.choice([64, 128, 320]))
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(B, 64, H, W, generator=g).half().to(DEV)
+    w = torch.randn(cout, 64, 3, 3, generator=g) / 24.0
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = torch.relu(F.conv2d(x.float(), w.half().float().to(DEV), b.to(DEV), 1, 1))
+    got = P.add_conv2d_op(P.conv_weight_rows(w.numpy()), b.numpy(), H, W, 64, cout, 3, 1, 1, relu=True)(_nhwc(x))[0]
+    torch.cuda.synchronize()
+    assert (got.permute(0, 3, 1, 2).float() - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("H,W,B,seed", _cases(13, 20))
+def test_fuzz_block_diagonal_narrow_conv(pkg, H, W, B, seed):
+    P = pkg.plugin
+    rng = np.random.default_rng(seed)
+    nph = int(rng.integers(2, 6))
+    heads = [int(rng.integers(1, 13)) for _ in range(nph)]
+    order = rng.permutation(nph)                               # the phases need not come in channel order
+    cin, cout = 64 * nph, sum(heads)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    w = torch.zeros(cout, cin, 3, 3)
+    n0 = 0
+    for h, n in enumerate(heads):
+        ph = int(order[h])
+        w[n0:n0 + n, 64 * ph:64 * (ph + 1)] = torch.randn(n, 64, 3, 3, generator=g) / 24.0
+        n0 += n
+    b = torch.randn(cout, generator=g) * 0.1
+    x = torch.randn(B, cin, H, W, generator=g).half().to(DEV)
+    ref = F.conv2d(x.float(), w.half().float().to(DEV), b.to(DEV), 1, 1)
+    got = P.add_conv2d_op(P.conv_weight_rows(w.numpy()), b.numpy(), H, W, cin, cout, 3, 1, 1, out_f32=True)(_nhwc(x))[0]
+    torch.cuda.synchronize()
+    assert got.dtype == torch.float32
+    assert (got.permute(0, 3, 1, 2) - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())
