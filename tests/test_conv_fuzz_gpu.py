@@ -79,3 +79,22 @@ def test_fuzz_block_diagonal_narrow_conv(pkg, H, W, B, seed):
     torch.cuda.synchronize()
     assert got.dtype == torch.float32
     assert (got.permute(0, 3, 1, 2) - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("H,W,B,seed", _cases(14, 12))
+def test_fuzz_conv3x3_wide_kernels_with_residual(pkg, H, W, B, seed):
+    """the 3 x 3 "phase" kernels (whichever variant the item count picks) with a residual input: the epilogue loads the residual rows of
+    eight blocks before their stores"""
+    P = pkg.plugin
+    rng = np.random.default_rng(seed)
+    H, W = 2 * H, 2 * W                                        # up to 138 x 178: from one tile to several rounds of items
+    cin = int(rng.choice([128, 192, 256])); cout = int(rng.choice([128, 256]))
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(B, cin, H, W, generator=g).half().to(DEV)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
+    b = torch.randn(cout, generator=g) * 0.1
+    r = torch.randn(B, cout, H, W, generator=g).half().to(DEV)
+    ref = torch.relu(F.conv2d(x.float(), w.half().float().to(DEV), b.to(DEV), 1, 1) + r.float())
+    got = P.add_conv2d_op(P.conv_weight_rows(w.numpy()), b.numpy(), H, W, cin, cout, 3, 1, 1, relu=True, has_residual=True)(_nhwc(x), _nhwc(r))[0]
+    torch.cuda.synchronize()
+    assert (got.permute(0, 3, 1, 2).float() - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())

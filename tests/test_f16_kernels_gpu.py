@@ -312,3 +312,29 @@ def test_encoder_mlp_frames_field_picks_the_kernel_not_the_result(pkg):
     for fr in (2, 4):
         assert torch.equal(outs[fr][0][0, :n], outs[0][0][0, :n]) and torch.equal(outs[fr][1][0, :n], outs[0][1][0, :n])
     assert float(outs[0][0][0, :n].abs().max()) > 0.1
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_qkv_resident_kernel_row_counts(pkg, seed):
+    """linear_f16_resident_kernel (row capacity of four frames) on random row counts -- fewer rows than waves, a ragged last tile, the
+    capacity itself -- with the position rows gathered through the window-cell table"""
+    P = pkg.plugin
+    rng = np.random.default_rng(100 + seed)
+    MR, C, wx = 262144, 192, 24
+    n = int([1, 15, 16 * 8 * 128 + 3, rng.integers(2, MR), rng.integers(2, MR), MR][seed])
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn((1, MR, C), generator=g).half()
+    W = (torch.randn((3 * C, C), generator=g) / np.sqrt(C)); b = torch.randn(3 * C, generator=g) * 0.1
+    tab = (torch.randn((1, wx * wx, C), generator=g) * 0.5).half()
+    c2d = torch.zeros((1, MR, 3), dtype=torch.int32)
+    c2d[0, :, 1] = torch.randint(0, wx, (MR,), generator=g); c2d[0, :, 2] = torch.randint(0, wx, (MR,), generator=g)
+    op = P.add_linear_op(W.numpy(), b.numpy(), MR, add_cols=2 * C, compute_type=P.COMPUTE_F16, input_half=True, output_mode=P.OUT_F16, add_gather_width=wx)
+    got = op(x.to(DEV), torch.tensor([n], dtype=torch.int32, device=DEV), tab.to(DEV), c2d.to(DEV))[0]
+    torch.cuda.synchronize()
+    Wd = W.half().double().to(DEV)
+    xd = x[0, :n].to(DEV); pos = tab[0].to(DEV)[(c2d[0, :n, 1] * wx + c2d[0, :n, 2]).long().to(DEV)]
+    xs = (xd.float() + pos.float()).half().double()
+    ref = torch.cat([xs @ Wd[:2 * C].T, xd.double() @ Wd[2 * C:].T], 1) + b.double().to(DEV)
+    err = (got[0, :n].double() - ref).abs()
+    assert err.max().item() < 1e-3 * ref.abs().max().item()
+    assert not got[0, n:].any()
