@@ -167,7 +167,11 @@ def _mlp_reference(att16, x, xb, w, lp, block, n, mimic_roundings=True):
                                              (True, 65536, 50000),      # eight-wave workgroups in rounds
                                              (True, 131072, 103449),    # capacity of three frames: four waves x 32 rows, two workgroups per CU
                                              (False, 131072, 33000),    # ... with few rows: the elastic kernel takes them, the other one returns at once
-                                             (False, 196608, 137932)])  # four frames
+                                             (False, 196608, 137932),   # four frames
+                                             (True, 196608, 81921),     # the first row count of the four-wave kernel's regime (threshold 2.5 x 128 x 256)
+                                             (False, 196608, 81920),    # ... and the last of the elastic one's
+                                             (True, 196608, 131072),    # exactly two rounds of two workgroups per CU
+                                             (False, 262144, 131105)])  # ... and 33 rows more: one wave of a third round
 def test_encoder_mlp_f16_against_reference_wiring(pkg, oracle, block_ln, MR, n):
     P = pkg.plugin
     rng = np.random.default_rng(7 * n + block_ln)
