@@ -163,8 +163,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every op from the host instead of replaying a HIP graph")
     ap.add_argument("--event-every", type=int, default=0,
                     help="roofline sample: every N-th timed step runs un-graphed, alone on the GPU, with HIP events around each launch; "
-                         "0 (default) = only the LAST forward() of the timed region (one pipeline drain instead of one per sample: the "
-                         "three samples of the old default cost 5-8 %% of the measured rate)")
+                         "0 (default) = only the FIRST forward() of the timed region (it runs alone before the streams fill: no pipeline drain; "
+                         "sampling the last forward cost 8 %% at --steps 20, three samples 5-8 %% at 60)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency-mode", action="store_true", help="skip the single-frame-mode measurement (N = 1 only) that follows the timed region")
     ap.add_argument("--host-input", action="store_true", help="frames start in pinned host memory and are uploaded (n x 16 B) inside the timed region: the PCIe-inclusive rate quoted in DESIGN.md, never the headline value")
@@ -307,7 +307,7 @@ def main():
         if args.event_every > 0:
             ev = prof is not None and (not use_graph or (i * FB) % args.event_every == (args.event_every // 2) // FB * FB)
         else:
-            ev = prof is not None and (not use_graph or i == KB - 1)
+            ev = prof is not None and (not use_graph or i == 0)       # the FIRST forward: nothing is in flight yet, so running it alone drains no other stream
         if ev and (use_graph or NS > 1):
             torch.cuda.synchronize()
         pkg.plugin.PROFILE = prof if ev else None
