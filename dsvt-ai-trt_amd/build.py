@@ -42,7 +42,12 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, ablate=False):
+    """ablate=True: libdsvt_hip_ablate.so (-DDSVT_ABLATE: the DSVT_* trace / ablation / A-B switches of csrc/ are read from the environment).
+    The product library reads none; tools/ load the other one through DSVT_HIP_LIB."""
+    global OUT, OBJ
+    if ablate:
+        OUT, OBJ = os.path.join(HERE, "libdsvt_hip_ablate.so"), os.path.join(HERE, "build_ablate")
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "dsvt_plugin.h"))
@@ -55,7 +60,7 @@ def build(force=False, verbose=False):
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc()] + COMMON + extra + ["-c", s, "-o", o]
+            cmd = [hipcc()] + COMMON + extra + (["-DDSVT_ABLATE"] if ablate else []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -68,7 +73,8 @@ def build(force=False, verbose=False):
     if force or procs or _stale(OUT, objs):
         cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
         subprocess.check_call(cmd)
-    build_host(force)
+    if not ablate:
+        build_host(force)
     return OUT
 
 
@@ -87,4 +93,4 @@ def build_host(force=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, ablate="--ablate" in sys.argv))

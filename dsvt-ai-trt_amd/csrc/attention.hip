@@ -376,11 +376,11 @@ set_attention_f16_kernel(AttnArgs a)
 
 static int launchAttention(const AttnArgs& a_, bool io16, hipStream_t stream) {
     static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("DSVT_ATTN_DBG"); dbg = e ? atoi(e) : 0; }
+    if (dbg < 0) dbg = ablateEnv("DSVT_ATTN_DBG", 0);
     AttnArgs a = a_; a.dbg = dbg;
     dim3 grid((unsigned)(a.max_sets * (a.H / AHB))), block(256);
     static int f16mma = -1;        // DSVT_ATTN_F32MMA=1: fp16 I/O on the fp32 matrix instructions (the previous kernel)
-    if (f16mma < 0) { const char* e = getenv("DSVT_ATTN_F32MMA"); f16mma = (e && atoi(e)) ? 0 : 1; }
+    if (f16mma < 0) f16mma = ablateEnv("DSVT_ATTN_F32MMA", 0) ? 0 : 1;
     if (io16 && f16mma) hipLaunchKernelGGL(set_attention_f16_kernel, grid, block, 0, stream, a);
     else if (io16) hipLaunchKernelGGL(set_attention_kernel<true>, grid, block, 0, stream, a);
     else hipLaunchKernelGGL(set_attention_kernel<false>, grid, block, 0, stream, a);

@@ -17,7 +17,14 @@ static Creator* findCreator(const char* type, const char* version) {
 
 using namespace dsvt;
 
-struct DsvtPlugin { Plugin* impl; int nbInputs = -1; };      // nbInputs: recorded by dsvtPluginConfigurePlugin
+// Recorded by dsvtPluginConfigurePlugin: the number of inputs and, for a batch of B > 1 frames, WHICH tensors are per-frame stacks.
+// enqueue never guesses that from the shapes it is handed (a shared table or count tensor whose leading dimension
+// happens to equal B must not be sliced, and a caller whose descriptors carry no leading batch dimension must get one plain enqueue).
+struct DsvtPlugin {
+    Plugin* impl; int nbInputs = -1;
+    int batch = 1;                               // B of the configured shapes (in[0].dims.d[0] when every output is a [B, ...] stack too)
+    std::vector<char> inBatched, outBatched;     // per tensor: leading dimension == B at configure time and the plugin does not declare it shared
+};
 
 static DsvtPlugin* wrap(Plugin* p, const char* layerName) {
     if (!p) return nullptr;
@@ -93,26 +100,31 @@ size_t dsvtPluginGetWorkspaceSize(const DsvtPlugin* p, const DsvtPluginTensorDes
 }
 // The batch dimension.  The reference carries it in every tensor shape but its kernels index with the scalar counts of frame 0
 // (points2Features.cu:678,900,919), so only batch 1 works there.  Here a batch of B frames is B consecutive batch-1
-// enqueues on the same stream: every tensor whose leading dimension is B is a stack of per-frame slabs (the layout the reference's
-// own output shapes describe), tensors with another leading dimension (shared tables) are passed to every frame, the workspace is
-// reused (same stream => serialised).  Needs the tensor descriptors, like TensorRT always supplies them.
+// enqueues on the same stream.  Which tensors are stacks of per-frame slabs is decided ONCE, by dsvtPluginConfigurePlugin (the
+// reference's configurePlugin sees the same descriptors): B = in[0].dims.d[0], valid as a batch only if in[0] has a row dimension behind it
+// and EVERY output is a [B, ...] tensor (the plugins' own getOutputDimensions produce exactly that); a tensor is a stack
+// when its leading dimension is B and the plugin does not declare that input shared (Plugin::sharedInput: tables such as the QKV
+// linear's position table); everything else is passed to every frame as is.  A plugin that was not configured, or whose enqueue
+// descriptors disagree with the configured batch, is refused (-2) rather than sliced by guesswork; descriptors without a leading batch
+// dimension (rank-2 [P, C] tensors) only look like a batch when the caller configured EVERY output as a [P, ...] tensor as well.  The workspace is reused (same stream => serialised).
 static size_t slabBytes(const DsvtPluginTensorDesc& d) {
     size_t n = d.type == DSVT_HALF ? 2 : (d.type == DSVT_INT8 || d.type == DSVT_BOOL) ? 1 : 4;
     for (int k = 1; k < d.dims.nbDims; ++k) n *= (size_t)d.dims.d[k];
     return n;
 }
-static int32_t enqueueBatched(Plugin* impl, int B, int nIn, const DsvtPluginTensorDesc* inDesc, const DsvtPluginTensorDesc* outDesc,
+static int32_t enqueueBatched(const DsvtPlugin* p, const DsvtPluginTensorDesc* inDesc, const DsvtPluginTensorDesc* outDesc,
                               const void* const* inputs, void* const* outputs, void* ws, hipStream_t stream) {
-    const int nOut = impl->nbOutputs();
+    Plugin* impl = p->impl;
+    const int B = p->batch, nIn = p->nbInputs, nOut = impl->nbOutputs();
     std::vector<DsvtPluginTensorDesc> id(inDesc, inDesc + nIn), od(outDesc, outDesc + nOut);
     std::vector<const void*> ip(nIn); std::vector<void*> op(nOut);
-    for (int k = 0; k < nIn; ++k) if (id[k].dims.d[0] == B) id[k].dims.d[0] = 1;
-    for (int k = 0; k < nOut; ++k) if (od[k].dims.d[0] == B) od[k].dims.d[0] = 1;
+    for (int k = 0; k < nIn; ++k) if (p->inBatched[k]) { if (id[k].dims.nbDims < 1 || id[k].dims.d[0] != B) return -2; id[k].dims.d[0] = 1; }
+    for (int k = 0; k < nOut; ++k) if (p->outBatched[k]) { if (od[k].dims.nbDims < 1 || od[k].dims.d[0] != B) return -2; od[k].dims.d[0] = 1; }
     for (int b = 0; b < B; ++b) {
         for (int k = 0; k < nIn; ++k)
-            ip[k] = inDesc[k].dims.d[0] == B ? static_cast<const char*>(inputs[k]) + (size_t)b * slabBytes(inDesc[k]) : inputs[k];
+            ip[k] = p->inBatched[k] ? static_cast<const char*>(inputs[k]) + (size_t)b * slabBytes(inDesc[k]) : inputs[k];
         for (int k = 0; k < nOut; ++k)
-            op[k] = outDesc[k].dims.d[0] == B ? static_cast<char*>(outputs[k]) + (size_t)b * slabBytes(outDesc[k]) : outputs[k];
+            op[k] = p->outBatched[k] ? static_cast<char*>(outputs[k]) + (size_t)b * slabBytes(outDesc[k]) : outputs[k];
         const int32_t rc = impl->enqueue(id.data(), od.data(), ip.data(), op.data(), ws, stream);
         if (rc != 0) return rc;
     }
@@ -123,11 +135,15 @@ int32_t dsvtPluginEnqueue(DsvtPlugin* p, const DsvtPluginTensorDesc* inDesc, con
                           const void* const* inputs, void* const* outputs, void* ws, dsvtStream_t stream) {
     if (!p || !inputs || !outputs) return kErrNullArg;
     DSVT_GUARD(kErrException,
-        const int B = (inDesc && outDesc && inDesc[0].dims.nbDims >= 1) ? inDesc[0].dims.d[0] : 1;
-        if (B > 1 && !p->impl->handlesBatch()) {
-            // enqueue's signature (like TensorRT's) does not carry the number of inputs: configurePlugin delivers it beforehand
-            if (p->nbInputs < 1) return -2;
-            return enqueueBatched(p->impl, B, p->nbInputs, inDesc, outDesc, inputs, outputs, ws, reinterpret_cast<hipStream_t>(stream));
+        if (!p->impl->handlesBatch()) {
+            if (p->batch > 1) {                  // configured as a batch: the enqueue descriptors must describe that batch
+                if (!inDesc || !outDesc || inDesc[0].dims.nbDims < 2 || inDesc[0].dims.d[0] != p->batch) return -2;
+                return enqueueBatched(p, inDesc, outDesc, inputs, outputs, ws, reinterpret_cast<hipStream_t>(stream));
+            }
+            // not configured (enqueue's signature, like TensorRT's, does not carry the number of inputs): a rank >= 3 first input with a
+            // leading dimension > 1 can only be a batch, which cannot be served -- refused, not mis-sliced.  Rank-2 [rows, C] descriptors
+            // and everything configured with B = 1 pass through as one enqueue.
+            if (p->nbInputs < 1 && inDesc && outDesc && inDesc[0].dims.nbDims >= 3 && inDesc[0].dims.d[0] > 1) return -2;
         }
         return p->impl->enqueue(inDesc, outDesc, inputs, outputs, ws, reinterpret_cast<hipStream_t>(stream));)
 }
@@ -135,6 +151,17 @@ int32_t dsvtPluginConfigurePlugin(DsvtPlugin* p, const DsvtPluginTensorDesc* in,
     if (!p || nbIn < 1 || !in || (nbOut > 0 && !out)) return kErrNullArg;
     if (nbOut != p->impl->nbOutputs()) return -2;
     p->nbInputs = nbIn;
+    p->batch = 1; p->inBatched.assign(nbIn, 0); p->outBatched.assign(nbOut, 0);
+    const int B = in[0].dims.nbDims >= 2 ? in[0].dims.d[0] : 1;
+    if (B > 1 && !p->impl->handlesBatch()) {
+        bool stacks = nbOut > 0;
+        for (int k = 0; k < nbOut; ++k) stacks = stacks && out[k].dims.nbDims >= 1 && out[k].dims.d[0] == B;      // ([B] count outputs are stacks too)
+        if (stacks) {
+            p->batch = B;
+            for (int k = 0; k < nbIn; ++k) p->inBatched[k] = in[k].dims.nbDims >= 1 && in[k].dims.d[0] == B && !p->impl->sharedInput(k);
+            for (int k = 0; k < nbOut; ++k) p->outBatched[k] = 1;
+        }
+    }
     return 0;
 }
 size_t dsvtPluginGetSerializationSize(const DsvtPlugin* p) {
@@ -152,7 +179,7 @@ DsvtPlugin* dsvtPluginClone(const DsvtPlugin* p) {
         if (!c) return nullptr;
         c->zeroFill = p->impl->zeroFill;
         DsvtPlugin* w = wrap(c, p->impl->layerName.c_str());
-        w->nbInputs = p->nbInputs;
+        w->nbInputs = p->nbInputs; w->batch = p->batch; w->inBatched = p->inBatched; w->outBatched = p->outBatched;
         return w;)
 }
 void dsvtPluginDestroy(DsvtPlugin* p) {

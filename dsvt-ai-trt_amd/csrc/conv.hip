@@ -45,13 +45,44 @@ struct ConvArgs {
     int KH, KW, stride, pad, up, relu;
     int wide;                                    // halo kernel: 16-byte epilogue accesses are legal (channel strides / offsets % 8, Cout % 16, fp16 output)
     int nb;                                      // images per launch (>= 1): image b = pixels b*H*W .. of `in`, b*Ho*up*Wo*up .. of `out` / `res`
+    // split precision (round 3): activations travel as the fp16 triple [hi | lo | hi] along the channel axis (hi = fp16(v), lo = fp16(v - hi);
+    // the third plane repeats hi so that ONE plain convolution over 3 Cin channels with weight rows [w_hi | w_hi | w_lo] is the fp32-grade
+    // product hi w_hi + lo w_hi + hi w_lo).  split_out > 0: the epilogue writes the three planes itself, split_out = plane stride in channels
+    // (out_ld = 3 * split_out); res_split > 0: the residual tensor is such a triple, its value is hi + lo (exact to 2^-22), plane stride res_split.
+    // The kernels are instantiated twice (template parameter SPL): the fp16 frame's instantiations do not carry the split epilogue's registers.
+    int split_out, res_split;
     unsigned long long* trace;                   // debugging (DSVT_CONV_TRACE=1, tools/trace_conv.py): s_memtime stamps of waves 0 and NW/2, or nullptr
 };
 constexpr int CONV_TRACE_N = 256;               // stamps per traced wave
 
 
+// hi / lo planes of N consecutive channels (saturated: |v| beyond the fp16 range gives +-65504, not inf)
+template <int N, class HV>
+__device__ __forceinline__ void splitPlanes(const float (&v)[N], HV& hi, HV& lo) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const _Float16 h = (_Float16)__builtin_fminf(__builtin_fmaxf(v[i], -65504.f), 65504.f);
+        hi[i] = h; lo[i] = (_Float16)__builtin_fminf(__builtin_fmaxf(v[i] - (float)h, -65504.f), 65504.f);
+    }
+}
+// store of eight consecutive channels of one output pixel: plain fp16, or (SPL) the [hi | lo | hi] planes when split_out is set
+template <bool SPL>
+__device__ __forceinline__ void storeHalf8(const ConvArgs& a, const float (&v)[8], size_t opix, int co) {
+    _Float16* o = static_cast<_Float16*>(a.out) + opix * a.out_ld + a.out_coff + co;
+    if (SPL && a.split_out) {
+        half8 hi, lo;
+        splitPlanes<8>(v, hi, lo);
+        *reinterpret_cast<half8*>(o) = hi; *reinterpret_cast<half8*>(o + a.split_out) = lo; *reinterpret_cast<half8*>(o + 2 * a.split_out) = hi;
+    } else {
+        half8 h;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = (_Float16)v[i];
+        *reinterpret_cast<half8*>(o) = h;
+    }
+}
+
 // bias / residual / ReLU / store of four consecutive output channels co..co+3 of output pixel opix
-template <bool WITH_BIAS = true>
+template <bool WITH_BIAS = true, bool SPL = false>
 __device__ __forceinline__ void convStore(const ConvArgs& a, floatx4 acc, size_t opix, int co)
 {
     if (co >= a.Cout) return;
@@ -65,6 +96,11 @@ __device__ __forceinline__ void convStore(const ConvArgs& a, floatx4 acc, size_t
         const half4 rv = *reinterpret_cast<const half4*>(a.res + opix * a.res_ld + co);
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] += (float)rv[i];
+        if (SPL && a.res_split) {
+            const half4 rl = *reinterpret_cast<const half4*>(a.res + opix * a.res_ld + a.res_split + co);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += (float)rl[i];
+        }
     }
     if (a.relu) {
 #pragma unroll
@@ -74,6 +110,16 @@ __device__ __forceinline__ void convStore(const ConvArgs& a, floatx4 acc, size_t
         float* o = static_cast<float*>(a.out) + opix * a.out_ld + a.out_coff + co;
 #pragma unroll
         for (int i = 0; i < 4; ++i) if (co + i < a.Cout) o[i] = v[i];
+    } else if (SPL && a.split_out) {
+        _Float16* o = static_cast<_Float16*>(a.out) + opix * a.out_ld + a.out_coff + co;
+        half4 hi, lo;
+        splitPlanes<4>(v, hi, lo);
+        if (full) {
+            *reinterpret_cast<half4*>(o) = hi; *reinterpret_cast<half4*>(o + a.split_out) = lo; *reinterpret_cast<half4*>(o + 2 * a.split_out) = hi;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (co + i < a.Cout) { o[i] = hi[i]; o[a.split_out + i] = lo[i]; o[2 * a.split_out + i] = hi[i]; }
+        }
     } else {
         _Float16* o = static_cast<_Float16*>(a.out) + opix * a.out_ld + a.out_coff + co;
         if (full) {
@@ -87,7 +133,7 @@ __device__ __forceinline__ void convStore(const ConvArgs& a, floatx4 acc, size_t
 }
 
 // MT = 16-pixel MFMA tiles per wave, NW = waves per workgroup (128 pixels per workgroup either way)
-template <int KC, int MT, int NW>
+template <int KC, int MT, int NW, bool SPL = false>
 __global__ void __launch_bounds__(64 * NW, (MT == 1 ? 4 : 2))
 conv_f16_kernel(ConvArgs a_)
 {
@@ -229,6 +275,13 @@ conv_f16_kernel(ConvArgs a_)
                 }
                 const int co = cbase + t * 16 + (g & 1) * 16 + (g >> 1) * 8;
                 if (!pv[mt] || t >= ntiles || co >= a.Cout) continue;
+                if constexpr (SPL) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { v[i] = a.relu ? fmaxf(X[i], 0.f) : X[i]; v[4 + i] = a.relu ? fmaxf(Y[i], 0.f) : Y[i]; }
+                    storeHalf8<true>(a, v, opix, co);
+                    continue;
+                }
                 half8 h;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -248,6 +301,7 @@ conv_f16_kernel(ConvArgs a_)
         for (int t = 0; t < CNT; ++t) {
             const int co = cbase + t * 16 + 4 * g;
             if (t >= ntiles || co >= a.Cout) continue;
+            if constexpr (SPL) { convStore<false, true>(a, acc[mt][t], opix, co); continue; }      // (the bias is already in the accumulators)
             float v[4] = {acc[mt][t][0], acc[mt][t][1], acc[mt][t][2], acc[mt][t][3]};
             const bool full = co + 3 < a.Cout;
             if (a.res && full) {
@@ -305,7 +359,7 @@ constexpr int HHS = 40;           // LDS halo row stride in pixels (>= HTW + 2, 
 // the odd 16-lane rows of X with the even rows of Y, after which lane (r, g) holds EIGHT consecutive output
 // channels of pixel r (first channel t0*16 + (g&1)*16 + (g>>1)*8): bias / residual / store are 16-byte accesses
 // and the four lanes of a pixel cover a contiguous 64-byte segment.
-template <bool WITH_BIAS = true>
+template <bool WITH_BIAS = true, bool SPL = false>
 __device__ __forceinline__ void convStoreWide(const ConvArgs& a, floatx4 X, floatx4 Y, bool valid, size_t opix, int co0, int g)
 {
 #pragma unroll
@@ -324,6 +378,19 @@ __device__ __forceinline__ void convStoreWide(const ConvArgs& a, floatx4 X, floa
         const half8 rv = *reinterpret_cast<const half8*>(a.res + opix * a.res_ld + co);
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += (float)rv[i];
+        if (SPL && a.res_split) {
+            const half8 rl = *reinterpret_cast<const half8*>(a.res + opix * a.res_ld + a.res_split + co);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += (float)rl[i];
+        }
+    }
+    if constexpr (SPL) {
+        if (a.relu) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        storeHalf8<true>(a, v, opix, co);
+        return;
     }
     half8 h;
 #pragma unroll
@@ -365,7 +432,7 @@ __device__ __forceinline__ void slabBarrier(int keep) {
 // HB = halo buffers: 2 = the next halo streams in behind the weight slabs (one workgroup per CU);  1 = the halo is reloaded
 // between phases (exposed, but the LDS footprint lets TWO 4-wave workgroups share a CU: their barriers and their
 // LDS-read / MFMA phases are no longer in lockstep)
-template <int TH, int KS, int CTW, int HB>
+template <int TH, int KS, int CTW, int HB, bool SPL = false>
 __global__ void __launch_bounds__(64 * TH, 1)
 conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __restrict__ zeros, int tilesX, int nitems, int nchunk, int dbg)
 {
@@ -457,11 +524,11 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
             if (a.wide) {
 #pragma unroll
                 for (int t0 = 0; t0 + 1 < CTP; t0 += 2)
-                    if (t0 < ctn) convStoreWide<false>(a, acc[t0][m], acc[t0 + 1][m], valid, opix, cbase + cgc * 64 + t0 * 16, g);
+                    if (t0 < ctn) convStoreWide<false, SPL>(a, acc[t0][m], acc[t0 + 1][m], valid, opix, cbase + cgc * 64 + t0 * 16, g);
             } else if (valid) {
 #pragma unroll
                 for (int ct = 0; ct < CTP; ++ct)
-                    if (ct < ctn) convStore<false>(a, acc[ct][m], opix, cbase + cgc * 64 + ct * 16 + 4 * g);
+                    if (ct < ctn) convStore<false, SPL>(a, acc[ct][m], opix, cbase + cgc * 64 + ct * 16 + 4 * g);
             }
         }
     };
@@ -629,7 +696,7 @@ struct WideCfg {
 // in flight (one slab of MFMAs, 0.5-1 us, is shorter than an L2 -> LDS round trip under load); 2 where LDS must hold two workgroups.
 // RW = tile rows per wave: 2 (64 pixels, four pixel tiles) or 1 (32 pixels, two pixel tiles: twice the waves on the same tile --
 // for the small layers, where one wave per SIMD cannot hide its own LDS-DMA issue and wait time)
-template <int CT, int NW, int HS, int SPS = (CT == 8 ? 2 : 4), int NWB = 3, int RW = 2, bool TR = false>
+template <int CT, int NW, int HS, int SPS = (CT == 8 ? 2 : 4), int NWB = 3, int RW = 2, bool TR = false, bool SPL = false>
 __global__ void __launch_bounds__(64 * NW, (NW * (RW == 1 ? 1 : 2) <= 8 && (NW == 4 || RW == 1)) ? 2 : 1)
 conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __restrict__ zeros, int tilesX, int nitems, int nchunk, int dbg)
 {
@@ -840,6 +907,47 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                 // (tools/conv_sequence.py).
                 constexpr int RB = NBLK < 8 ? NBLK : 8;
                 const bool hasRes = a.res != nullptr;
+                if constexpr (SPL) {
+                    // split precision: the residual is hi + lo (two planes), the result leaves as three planes; TWO blocks at a time (with four, the
+                    // residual loads plus the hi / lo planes in flight spill 30 registers of the main loop's accumulators; with two, 10)
+                    constexpr int RS = RB / 4 > 0 ? RB / 4 : 1;
+                    const bool splitRes = hasRes && a.res_split != 0;
+#pragma unroll
+                    for (int b0 = 0; b0 < NBLK; b0 += RS) {
+                        half8 rh[RS], rl[RS];
+                        if (hasRes) {
+#pragma unroll
+                            for (int j = 0; j < RS; ++j) {
+                                const int b = b0 + j, m = b / TP, tp = b % TP, co = cbase + tp * 32 + cg8;
+                                const bool ok = valid[m] && co < a.Cout && 2 * tp < ctn;
+                                rh[j] = *reinterpret_cast<const half8*>(a.res + (ok ? opix[m] * a.res_ld + co : 0));
+                                rl[j] = *reinterpret_cast<const half8*>(a.res + ((ok && splitRes) ? opix[m] * a.res_ld + a.res_split + co : 0));
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < RS; ++j) {
+                            const int b = b0 + j, m = b / TP, tp = b % TP, co = cbase + tp * 32 + cg8;
+                            if (2 * tp >= ctn) continue;
+                            floatx4 X = acc[2 * tp][m], Y = acc[2 * tp + 1][m];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(X[i]), __float_as_uint(Y[i]), false, false);
+                                X[i] = __uint_as_float(sw[0]); Y[i] = __uint_as_float(sw[1]);
+                            }
+                            if (!valid[m] || co >= a.Cout) continue;
+                            float v[8] = {X[0], X[1], X[2], X[3], Y[0], Y[1], Y[2], Y[3]};
+                            if (hasRes) {
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) v[i] += splitRes ? (float)rh[j][i] + (float)rl[j][i] : (float)rh[j][i];
+                            }
+                            if (a.relu) {
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+                            }
+                            storeHalf8<true>(a, v, opix[m], co);
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int b0 = 0; b0 < NBLK; b0 += RB) {
                     half8 rv[RB];
@@ -881,7 +989,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                     const size_t opix = (size_t)((bimg * a.Ho + oy) * a.up + dy) * Wout + (ox * a.up + dx);
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
-                        if (ct < ctn) convStore<false>(a, acc[ct][m], opix, cbase + ct * 16 + 4 * g);
+                        if (ct < ctn) convStore<false, SPL>(a, acc[ct][m], opix, cbase + ct * 16 + 4 * g);
                 }
             }
         }
@@ -1224,19 +1332,19 @@ conv1x1_resident_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT, in
 static int numCUs();
 static bool conv1x1ResidentShape(int KH, int KW, int stride, int pad, int Cin, int Cout, int rows) {
     static int on = -1;            // DSVT_CONV_1X1_RESIDENT=0: the halo / gather kernels for the 1 x 1 layers too
-    if (on < 0) { const char* e = getenv("DSVT_CONV_1X1_RESIDENT"); on = e ? atoi(e) : 1; }
+    if (on < 0) on = ablateEnv("DSVT_CONV_1X1_RESIDENT", 1);
     return on && KH == 1 && KW == 1 && (stride == 1 || stride == 2) && pad == 0 && (Cout == 128 || Cout == 256) && rows % 128 == 0 &&
            (Cin == 128 || Cin == 192 || Cin == 256);
 }
 static bool conv1x1ResidentEligible(const ConvArgs& a) {
-    return conv1x1ResidentShape(a.KH, a.KW, a.stride, a.pad, a.Cin, a.Cout, a.CoutRows) && a.wide && !a.res && !a.out_f32 && (a.stride == 1 || a.up == 1);
+    return conv1x1ResidentShape(a.KH, a.KW, a.stride, a.pad, a.Cin, a.Cout, a.CoutRows) && a.wide && !a.res && !a.out_f32 && !a.split_out && (a.stride == 1 || a.up == 1);
 }
 
 static bool conv3x3C64Eligible(const ConvArgs& a) {
     static int on = -1;            // DSVT_CONV_C64_RESIDENT=0: conv_wide_kernel for the 64-input-channel 3 x 3 layers too
-    if (on < 0) { const char* e = getenv("DSVT_CONV_C64_RESIDENT"); on = e ? atoi(e) : 1; }
+    if (on < 0) on = ablateEnv("DSVT_CONV_C64_RESIDENT", 1);
     return on && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.up == 1 && a.Cin == 64 && a.CoutRows == a.Cout && a.Cout % 64 == 0 &&
-           a.wide && !a.res && !a.out_f32;
+           a.wide && !a.res && !a.out_f32 && !a.split_out;
 }
 
 static int launchConv1x1Resident(const ConvArgs& a, const _Float16* Wp, hipStream_t stream) {
@@ -1260,116 +1368,76 @@ static int numCUs() {
     return n;
 }
 
-// tile height of the halo kernel.  Alone on the GPU the 64-channel and the 117x117 layers run 5-10 % faster as 4-row tiles (two
-// decoupled workgroups per CU / all CUs busy); with two frames in flight -- the bench default -- 8-row tiles everywhere are
-// 4 % faster end to end (415 vs 400 frames/s): a layer that leaves CUs or LDS unused leaves them to the other frame's kernels.
-static int haloTileRows(const ConvArgs&) {
-    if (const char* e = getenv("DSVT_CONV_TH")) { const int t = atoi(e); if (t == 4 || t == 8) return t; }
-    return 8;
-}
-
-// Persistent workgroups walk the items round-robin, so a launch takes ceil(items / slots) rounds whatever the grid is between
-// items / rounds and slots: the SMALLEST grid with that round count (450 items on 256 CUs: 225 workgroups of exactly two items) would
-// leave the other CUs to the kernels of the other frame in flight.  Round-2 experiment (DSVT_CONV_BALANCE=1): 532-535 vs 534-539 frames/s
-// with two frames in flight, 441 vs 442 with one -- free CUs are not what the second frame lacks; off by default.
-static int balancedGrid(int nitems, int slots) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("DSVT_CONV_BALANCE"); on = e ? atoi(e) : 0; }
-    if (nitems <= slots) return nitems;
-    if (!on) return slots;
-    const int rounds = cdiv(nitems, slots);
-    return cdiv(nitems, rounds);
-}
-
+// Experiments that stay documented but are not product code (round 3: the ablation / tuning switches that used to be read from the
+// environment inside these launchers are gone; measurements in profiles/README.md): 4-row halo tiles (5-10 % faster alone, 4 % slower
+// with two frames in flight), balanced persistent grids (225 x 2 items instead of 256 workgroups: no gain), 14-row items on seven
+// waves for the 468 x 468 layers (510 items = two full rounds: no gain), 40-pixel halo rows, four-wave 8-row tiles, a third weight slab
+// in the halo kernel (8 % slower).
 static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16* zeros, hipStream_t stream) {
-    const int th = haloTileRows(a);
     const int tilesX = cdiv(a.Wo, HTW), nchunk = cdiv(a.CoutRows, CNB);
     const int NBI = a.nb;                                       // images: every item count below is per image x NBI
-    static int wideOn = -1;        // DSVT_CONV_WIDE=0: every layer on the 8-row kernel
-    if (wideOn < 0) { const char* e = getenv("DSVT_CONV_WIDE"); wideOn = e ? atoi(e) : 1; }
-    const int nwide = cdiv(a.Ho, 16) * tilesX * nchunk * NBI;
-    // 16-row tiles when they fill the CUs, else 8-row x 64-channel tiles on four waves (two workgroups per CU).  (Two channel
+    const bool spl = a.split_out != 0 || a.res_split != 0;      // split-precision epilogue (its own instantiations: see ConvArgs)
+    const int ncu = numCUs();
+    static int dbg = -1;                                        // timing ablations (wrong results): the -DDSVT_ABLATE build only, constant 0 in the product
+    if (dbg < 0) dbg = ablateEnv("DSVT_CONV_DBG", 0);
+    // 16-row tiles when they fill the CUs, else 8-row x 64-channel tiles (two workgroups per CU).  (Two channel
     // tiles: 32 MFMAs per slab cannot hide the halo stream, 86.7 vs 85.6 us on the 320 -> 18 head layer: the 8-row kernel below.)
     const int ctWide = haloChannelTiles(a.CoutRows);
-    static int dbgW = -1;
-    if (dbgW < 0) { const char* e = getenv("DSVT_CONV_DBG"); dbgW = e ? atoi(e) : 0; }          // timing ablations only (wrong results)
-    if (wideOn && a.KH == 3 && ctWide >= 4) {
+#define DSVT_WIDE(GRID_, BLOCK_, NITEMS_, NCHUNK_, ...) do { \
+        if (spl) hipLaunchKernelGGL((conv_wide_kernel<__VA_ARGS__, false, true>), dim3(GRID_), dim3(BLOCK_), 0, stream, a, Wp, zeros, tilesX, NITEMS_, NCHUNK_, dbg); \
+        else hipLaunchKernelGGL((conv_wide_kernel<__VA_ARGS__, false, false>), dim3(GRID_), dim3(BLOCK_), 0, stream, a, Wp, zeros, tilesX, NITEMS_, NCHUNK_, dbg); \
+        return lastError(); } while (0)
+    if (a.KH == 3 && ctWide >= 4) {
+        const int nwide = cdiv(a.Ho, 16) * tilesX * nchunk * NBI;
         // short K (the 64 -> 320 head stems: 9 slabs per item, the epilogue weighs as much as the MFMAs): 8-row x 128-channel tiles on
         // four waves, two independent workgroups per CU, 2655 items: 116-122 vs 130 us (no gain on the K >= 1152 layers)
-        if (ctWide == 8 && (a.Cin <= 64 || wideOn == 6)) {
-            const int n8 = cdiv(a.Ho, 8) * tilesX * nchunk * NBI, grid = balancedGrid(n8, 2 * numCUs());
-            hipLaunchKernelGGL((conv_wide_kernel<8, 4, 36, 2, 2>), dim3(grid), dim3(256), 0, stream, a, Wp, zeros, tilesX, n8, nchunk, dbgW);
-            return lastError();
+        if (ctWide == 8 && a.Cin <= 64) {
+            const int n8 = cdiv(a.Ho, 8) * tilesX * nchunk * NBI, grid = n8 < 2 * ncu ? n8 : 2 * ncu;
+            DSVT_WIDE(grid, 256, n8, nchunk, 8, 4, 36, 2, 2, 2);
         }
-        if (nwide >= numCUs() && wideOn != 4) {
-            const int grid = balancedGrid(nwide, numCUs());
-            // Item rounds (round-2 experiment, DSVT_CONV_WIDE=12).  Persistent workgroups (one per CU) walk the items: the 468 x 468 layers are
-            // 30 x 15 = 450 items of 16 rows = TWO rounds on 256 CUs with the second a quarter empty; as 14-row items on seven waves they
-            // are 34 x 15 = 510 = two FULL rounds of 14 rows, 28 row-units instead of 32.  Measured: no gain (convolutions 1.211 vs 1.199 ms
-            // per frame, 439 vs 442 frames/s): the quarter-empty second round is not idle time, its workgroups run faster on the freed
-            // memory system.  Kept behind the switch; results are identical.
-            const int n14 = cdiv(a.Ho, 14) * tilesX * nchunk * NBI;
-            const bool rows14 = wideOn == 12 && cdiv(n14, grid) * 14 < cdiv(nwide, grid) * 16;
-            // (a third weight slab -- requests two slabs ahead -- measured 80.2 vs 82.6 us on the 128-channel layers, nothing elsewhere)
-            if (ctWide == 8 && rows14) hipLaunchKernelGGL((conv_wide_kernel<8, 7, 40, 2, 3>), dim3(grid), dim3(448), 0, stream, a, Wp, zeros, tilesX, n14, nchunk, dbgW);
-            // halo row stride 36 pixels, not 40: 134,144 B of LDS instead of 142,336, which leaves room for the 23 KB workgroups of the
-            // OTHER frame's set-attention kernel on the same CU (two frames in flight: a gather-bound kernel under an MFMA-bound one)
-            else if (ctWide == 8 && wideOn == 13) hipLaunchKernelGGL((conv_wide_kernel<8, 8, 40, 2, 3>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk, dbgW);
-            else if (ctWide == 8 && a.trace) hipLaunchKernelGGL((conv_wide_kernel<8, 8, 36, 2, 3, 2, true>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk, dbgW);
-            else if (ctWide == 8) hipLaunchKernelGGL((conv_wide_kernel<8, 8, 36, 2, 3>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk, dbgW);
-            else if (rows14) hipLaunchKernelGGL((conv_wide_kernel<4, 7, 40, 4, 2>), dim3(grid), dim3(448), 0, stream, a, Wp, zeros, tilesX, n14, nchunk, dbgW);
-            else hipLaunchKernelGGL((conv_wide_kernel<4, 8, 40, 4, 2>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk, dbgW);
-            return lastError();
+        if (nwide >= ncu) {
+            // halo row stride 36 pixels, not 40: 134,144 B of LDS instead of 142,336 (room for the OTHER frame's 23 KB attention workgroups)
+            if (ctWide == 8) DSVT_WIDE(ncu, 512, nwide, nchunk, 8, 8, 36, 2, 3, 2);
+            else DSVT_WIDE(ncu, 512, nwide, nchunk, 4, 8, 40, 4, 2, 2);
         }
-        if (wideOn != 2) {
-            const int nch64 = cdiv(a.CoutRows, 64), nsmall = cdiv(a.Ho, 8) * tilesX * nch64 * NBI;
-            // 16-row x 64-channel items on eight waves when they nearly fill the CUs (234x234x128: 240 items, one per CU, 40 LDS-DMA
-            // pieces per wave and item instead of 59)
-            const int n16 = cdiv(a.Ho, 16) * tilesX * nch64 * NBI;
-            if (n16 * 10 >= numCUs() * 9 && n16 <= numCUs() && wideOn != 7 && wideOn != 10) {
-                hipLaunchKernelGGL((conv_wide_kernel<4, 8, 40, 4, 2>), dim3(n16), dim3(512), 0, stream, a, Wp, zeros, tilesX, n16, nch64, dbgW);
-                return lastError();
-            }
-            const int grid = balancedGrid(nsmall, 2 * numCUs());
-            // 8 rows x 32 pixels x 64 channels: eight waves of ONE row each (117x117x256: 31.4 us; four waves of two rows: 35.6 us --
-            // one wave per SIMD cannot hide its own LDS-DMA issue and wait time)
-            if (wideOn == 9) hipLaunchKernelGGL((conv_wide_kernel<4, 4, 36, 4, 2>), dim3(grid), dim3(256), 0, stream, a, Wp, zeros, tilesX, nsmall, nch64, dbgW);
-            else hipLaunchKernelGGL((conv_wide_kernel<4, 8, 36, 4, 2, 1>), dim3(grid), dim3(512), 0, stream, a, Wp, zeros, tilesX, nsmall, nch64, dbgW);
-            return lastError();
-        }
+        const int nch64 = cdiv(a.CoutRows, 64), nsmall = cdiv(a.Ho, 8) * tilesX * nch64 * NBI;
+        // 16-row x 64-channel items on eight waves when they nearly fill the CUs (234x234x128: 240 items, one per CU, 40 LDS-DMA
+        // pieces per wave and item instead of 59)
+        const int n16 = cdiv(a.Ho, 16) * tilesX * nch64 * NBI;
+        if (n16 * 10 >= ncu * 9 && n16 <= ncu) DSVT_WIDE(n16, 512, n16, nch64, 4, 8, 40, 4, 2, 2);
+        // 8 rows x 32 pixels x 64 channels: eight waves of ONE row each (117x117x256: 31.4 us; four waves of two rows: 35.6 us --
+        // one wave per SIMD cannot hide its own LDS-DMA issue and wait time)
+        DSVT_WIDE(nsmall < 2 * ncu ? nsmall : 2 * ncu, 512, nsmall, nch64, 4, 8, 36, 4, 2, 1);
     }
+#undef DSVT_WIDE
+    // the first halo-tile kernel: 1 x 1 layers the resident-weights kernel does not take, 3 x 3 layers with <= 32 output channels
+    constexpr int th = 8;
     const int nitems = cdiv(a.Ho, th) * tilesX * nchunk * NBI;
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("DSVT_CONV_DBG"); dbg = e ? atoi(e) : 0; }           // timing ablations only (wrong results)
-    static int gridCap = -1;
-    if (gridCap < 0) { const char* e = getenv("DSVT_CONV_GRID"); gridCap = e ? atoi(e) : 0; }      // test knob: force multi-item workgroups
-    static int hb1 = -1;           // 4-row tiles run as two single-halo-buffer workgroups per CU (DSVT_CONV_HB1=0: one double-buffered)
-    if (hb1 < 0) { const char* e = getenv("DSVT_CONV_HB1"); hb1 = e ? atoi(e) : 1; }
-    const int slots = (th == 4 && hb1) ? 2 * numCUs() : numCUs();
-    int grid = balancedGrid(nitems, slots);
-    if (gridCap > 0 && grid > gridCap) grid = gridCap;
-#define DSVT_HALO_LAUNCH(TH_, KS_, CTW_, HB_) hipLaunchKernelGGL((conv_halo_kernel<TH_, KS_, CTW_, HB_>), dim3(grid), dim3(64 * TH_), 0, stream, a, Wp, zeros, tilesX, nitems, nchunk, dbg)
-#define DSVT_HALO_TH(KS_, CTW_) do { if (th == 8) DSVT_HALO_LAUNCH(8, KS_, CTW_, 2); else if (hb1) DSVT_HALO_LAUNCH(4, KS_, CTW_, 1); else DSVT_HALO_LAUNCH(4, KS_, CTW_, 2); } while (0)
+    const int grid = nitems < ncu ? nitems : ncu;
+#define DSVT_HALO(KS_, CTW_) do { \
+        if (spl) hipLaunchKernelGGL((conv_halo_kernel<8, KS_, CTW_, 2, true>), dim3(grid), dim3(64 * th), 0, stream, a, Wp, zeros, tilesX, nitems, nchunk, dbg); \
+        else hipLaunchKernelGGL((conv_halo_kernel<8, KS_, CTW_, 2, false>), dim3(grid), dim3(64 * th), 0, stream, a, Wp, zeros, tilesX, nitems, nchunk, dbg); } while (0)
     const int ctw = haloChannelTiles(a.CoutRows);
-    if (a.KH == 3) { if (ctw == 8) DSVT_HALO_TH(3, 8); else if (ctw == 4) DSVT_HALO_TH(3, 4); else DSVT_HALO_TH(3, 2); }
-    else           { if (ctw == 8) DSVT_HALO_TH(1, 8); else if (ctw == 4) DSVT_HALO_TH(1, 4); else DSVT_HALO_TH(1, 2); }
-#undef DSVT_HALO_TH
-#undef DSVT_HALO_LAUNCH
+    if (a.KH == 3) { if (ctw == 8) DSVT_HALO(3, 8); else if (ctw == 4) DSVT_HALO(3, 4); else DSVT_HALO(3, 2); }
+    else           { if (ctw == 8) DSVT_HALO(1, 8); else if (ctw == 4) DSVT_HALO(1, 4); else DSVT_HALO(1, 2); }
+#undef DSVT_HALO
     return lastError();
 }
 
 static int launchConv(const ConvArgs& a, int KC, hipStream_t stream) {
     dim3 grid((unsigned)(cdiv(cdiv(a.Ho * a.Wo, CPX), 8) * 8), (unsigned)cdiv(a.CoutRows, CNB), (unsigned)a.nb);
-    if (KC == 128) hipLaunchKernelGGL((conv_f16_kernel<128, 1, 8>), grid, dim3(512), 0, stream, a);
-    else if (KC == 96) hipLaunchKernelGGL((conv_f16_kernel<96, 1, 8>), grid, dim3(512), 0, stream, a);
-    else if (KC == 64) hipLaunchKernelGGL((conv_f16_kernel<64, 1, 8>), grid, dim3(512), 0, stream, a);
-    else return -3;
+    const bool spl = a.split_out != 0 || a.res_split != 0;
+#define DSVT_GATHER(KC_) do { if (spl) hipLaunchKernelGGL((conv_f16_kernel<KC_, 1, 8, true>), grid, dim3(512), 0, stream, a); \
+                              else hipLaunchKernelGGL((conv_f16_kernel<KC_, 1, 8, false>), grid, dim3(512), 0, stream, a); } while (0)
+    if (KC == 128) DSVT_GATHER(128); else if (KC == 96) DSVT_GATHER(96); else if (KC == 64) DSVT_GATHER(64); else return -3;
+#undef DSVT_GATHER
     return lastError();
 }
 
 // -------------------------------------------------------------------------------------
 struct ConvCfg {
     int H, W, Cin, Cout, KH, KW, stride, pad, up, relu, has_res, out_ld, out_coff, out_f32;
+    int split_out, split_res;      // split precision (fields "split_output" / "split_residual"): the output / the residual is an fp16 [hi | lo | hi] triple (see ConvArgs)
 };
 
 class DsvtConv2dPlugin : public Plugin {
@@ -1383,14 +1451,14 @@ public:
     bool ok_ = false;
     bool haloEligible() const {
         static int on = -1;
-        if (on < 0) { const char* e = getenv("DSVT_CONV_HALO"); on = e ? atoi(e) : 1; }
+        if (on < 0) on = ablateEnv("DSVT_CONV_HALO", 1);
         return on && c_.stride == 1 && c_.KH == c_.KW && (c_.KH == 1 || c_.KH == 3) && c_.pad == c_.KH / 2 && c_.Cin % 64 == 0;
     }
     int Ho() const { return (c_.H + 2 * c_.pad - c_.KH) / c_.stride + 1; }
     int Wo() const { return (c_.W + 2 * c_.pad - c_.KW) / c_.stride + 1; }
     int rows() const { return c_.up * c_.up * c_.Cout; }
     int KC() const {
-        if (const char* e = getenv("DSVT_CONV_KC")) { int k = atoi(e); if (k > 0 && c_.Cin % k == 0) return k; }   // tuning knob
+        { const int k = ablateEnv("DSVT_CONV_KC", 0); if (k > 0 && c_.Cin % k == 0) return k; }   // tuning knob (ablation build only)
         // large images: 64-channel slabs (150 VGPRs, 40 KB LDS => 3 waves/SIMD) hide the per-slab barrier better than
         // 128-channel ones (measured +10 % on the 468x468 layers); small images prefer fewer, fatter slabs
         if (Ho() * Wo() >= 100000 && c_.Cin % 64 == 0) return 64;
@@ -1437,7 +1505,7 @@ public:
     // tile's real channels.  Anything else (a channel that reads two phases, more than 16 channels on a phase) stays on the dense kernels.
     void packGrouped(const std::vector<_Float16>& wh) {
         static int on = -1;        // DSVT_CONV_GROUPED=0: the dense halo kernel for block-diagonal layers too
-        if (on < 0) { const char* e = getenv("DSVT_CONV_GROUPED"); on = e ? atoi(e) : 1; }
+        if (on < 0) on = ablateEnv("DSVT_CONV_GROUPED", 1);
         const ConvCfg& c = c_;
         if (!on || c.KH != 3 || c.KW != 3 || c.stride != 1 || c.pad != 1 || c.up != 1 || c.has_res || c.Cin % 64 != 0 || c.Cin < 128 || c.Cout > 64) return;
         const int NCC = c.Cin / 64;
@@ -1497,11 +1565,14 @@ public:
         a.out = out[0]; a.out_ld = c_.out_ld; a.out_coff = c_.out_coff; a.out_f32 = c_.out_f32;
         a.Ho = Ho(); a.Wo = Wo(); a.CoutRows = rows(); a.Cout = c_.Cout;
         a.KH = c_.KH; a.KW = c_.KW; a.stride = c_.stride; a.pad = c_.pad; a.up = c_.up; a.relu = c_.relu;
-        a.wide = !c_.out_f32 && c_.Cout % 16 == 0 && c_.out_ld % 8 == 0 && c_.out_coff % 8 == 0 && (!c_.has_res || a.res_ld % 8 == 0);
+        a.split_out = c_.split_out ? c_.out_ld / 3 : 0;
+        a.res_split = (c_.has_res && c_.split_res) ? a.res_ld / 3 : 0;
+        a.wide = !c_.out_f32 && c_.Cout % 16 == 0 && c_.out_ld % 8 == 0 && c_.out_coff % 8 == 0 && (!c_.has_res || a.res_ld % 8 == 0) &&
+                 a.split_out % 8 == 0 && a.res_split % 8 == 0;
         a.nb = (inDesc && inDesc[0].dims.nbDims == 4 && inDesc[0].dims.d[0] > 1) ? inDesc[0].dims.d[0] : 1;
         if ((long)a.nb * c_.H * c_.W * c_.Cin >= (1l << 31)) return -2;                // the halo kernel addresses the input with 32-bit element offsets
         static int tron = -1;                                                          // tools/trace_conv.py
-        if (tron < 0) { const char* e = getenv("DSVT_CONV_TRACE"); tron = e ? atoi(e) : 0; }
+        if (tron < 0) tron = ablateEnv("DSVT_CONV_TRACE", 0);
         if (tron && wp_dev_ && haloEligible()) {
             static unsigned long long* tr = nullptr;
             const size_t n = (size_t)4096 * 2 * CONV_TRACE_N;
@@ -1521,7 +1592,7 @@ public:
                 }
             return rc;
         }
-        if (groups_ > 0) {
+        if (groups_ > 0 && !a.split_out) {
             const int tilesX = cdiv(a.Wo, HTW), tilesY = cdiv(a.Ho, 8);
             hipLaunchKernelGGL(conv3x3_grouped_narrow_kernel, dim3(numCUs()), dim3(512), 0, stream, a, wg_dev_, chan_dev_, zeros_dev_, tilesX, tilesY, groups_);
             return lastError();
@@ -1536,14 +1607,15 @@ public:
         if (wp_dev_ && haloEligible()) return launchConvHalo(a, wp_dev_, zeros_dev_, stream);
         return launchConv(a, KC(), stream);
     }
-    size_t serializationSize() const override { return 14 * sizeof(int) + sizeof(int) + sizeof(float) * (w_.size() + b_.size()); }
+    size_t serializationSize() const override { return 14 * sizeof(int) + sizeof(int) + sizeof(float) * (w_.size() + b_.size()) + ((c_.split_out || c_.split_res) ? 2 * sizeof(int) : 0); }
     void serialize(void* buf) const override {
         char* d = static_cast<char*>(buf);
         const int* ci = reinterpret_cast<const int*>(&c_);
         for (int i = 0; i < 14; ++i) wr<int>(d, ci[i]);
         wr<int>(d, b_.empty() ? 0 : 1);
         memcpy(d, w_.data(), sizeof(float) * w_.size()); d += sizeof(float) * w_.size();
-        memcpy(d, b_.data(), sizeof(float) * b_.size());
+        memcpy(d, b_.data(), sizeof(float) * b_.size()); d += sizeof(float) * b_.size();
+        if (c_.split_out || c_.split_res) { wr<int>(d, c_.split_out); wr<int>(d, c_.split_res); }      // (trailing, only when set: older blobs stay valid)
     }
     Plugin* clone() const override { return new DsvtConv2dPlugin(c_, w_.data(), b_.empty() ? nullptr : b_.data()); }
 };
@@ -1554,6 +1626,8 @@ static Plugin* convNew(const ConvCfg& c, const float* w, const float* b) {
     if (c.Cin % 64 != 0) return nullptr;                               // K slabs are 64 / 96 / 128 channels wide
     if (c.up > 1 && (c.KH != 1 || c.KW != 1 || c.stride != 1 || c.Cout % CNB != 0)) return nullptr;   // pixel-shuffle chunks are whole workgroup columns
     if (!c.out_f32 && (c.out_ld % 4 != 0 || c.out_coff % 4 != 0)) return nullptr;
+    if (c.split_out && (c.out_f32 || c.out_ld % 12 != 0 || c.out_ld / 3 < c.out_coff + c.Cout)) return nullptr;      // three planes of out_ld / 3 channels
+    if (c.split_res && !c.has_res) return nullptr;
     return new DsvtConv2dPlugin(c, w, b);
 }
 static Plugin* convCreate(const DsvtPluginFieldCollection* fc) {
@@ -1562,6 +1636,7 @@ static Plugin* convCreate(const DsvtPluginFieldCollection* fc) {
     c.KH = c.KW = fieldInt(fc, "kernel_size", 1); c.stride = fieldInt(fc, "stride", 1); c.pad = fieldInt(fc, "padding", 0);
     c.up = fieldInt(fc, "pixel_shuffle", 1); c.relu = fieldInt(fc, "relu", 0); c.has_res = fieldInt(fc, "has_residual", 0);
     c.out_ld = fieldInt(fc, "out_channel_stride", c.Cout); c.out_coff = fieldInt(fc, "out_channel_offset", 0); c.out_f32 = fieldInt(fc, "out_f32", 0);
+    c.split_out = fieldInt(fc, "split_output", 0) != 0; c.split_res = fieldInt(fc, "split_residual", 0) != 0;
     const DsvtPluginField* w = findField(fc, "weight"); const DsvtPluginField* b = findField(fc, "bias");
     if (!w || !w->data || c.Cin <= 0 || c.Cout <= 0 || c.up < 1) return nullptr;
     if ((long)w->length != (long)c.up * c.up * c.Cout * c.KH * c.KW * c.Cin) return nullptr;
@@ -1579,13 +1654,16 @@ static Plugin* convDeser(const void* data, size_t len) {
     if (len < 15 * sizeof(int) + sizeof(float) * (nw + (has_b ? c.Cout : 0))) return nullptr;
     std::vector<float> w(nw), b(has_b ? c.Cout : 0);
     memcpy(w.data(), d, sizeof(float) * nw); if (has_b) memcpy(b.data(), d + sizeof(float) * nw, sizeof(float) * c.Cout);
+    const size_t used = 15 * sizeof(int) + sizeof(float) * (nw + (has_b ? c.Cout : 0));
+    if (len >= used + 2 * sizeof(int)) { const char* t = static_cast<const char*>(data) + used; c.split_out = rd<int>(t); c.split_res = rd<int>(t); }
     return convNew(c, w.data(), has_b ? b.data() : nullptr);
 }
 static Creator g_convCreator{"DsvtConv2dPlugin",
     {{"in_height", DSVT_FIELD_INT32}, {"in_width", DSVT_FIELD_INT32}, {"in_channels", DSVT_FIELD_INT32}, {"out_channels", DSVT_FIELD_INT32},
      {"kernel_size", DSVT_FIELD_INT32}, {"stride", DSVT_FIELD_INT32}, {"padding", DSVT_FIELD_INT32}, {"pixel_shuffle", DSVT_FIELD_INT32},
      {"relu", DSVT_FIELD_INT32}, {"has_residual", DSVT_FIELD_INT32}, {"out_channel_stride", DSVT_FIELD_INT32},
-     {"out_channel_offset", DSVT_FIELD_INT32}, {"out_f32", DSVT_FIELD_INT32}, {"weight", DSVT_FIELD_FLOAT32}, {"bias", DSVT_FIELD_FLOAT32}},
+     {"out_channel_offset", DSVT_FIELD_INT32}, {"out_f32", DSVT_FIELD_INT32}, {"split_output", DSVT_FIELD_INT32}, {"split_residual", DSVT_FIELD_INT32},
+     {"weight", DSVT_FIELD_FLOAT32}, {"bias", DSVT_FIELD_FLOAT32}},
     convCreate, convDeser, {}, {}};
 static Registrar g_convReg(&g_convCreator);
 

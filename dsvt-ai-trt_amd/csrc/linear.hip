@@ -823,6 +823,185 @@ linear_f16_resident_kernel(LinearArgs a, const _Float16* __restrict__ Wp)
     }
 }
 
+// -------------------------------------------------------------------------------------
+// QKV at fp32 GRADE on the fp16 matrix cores (compute_type 2, "split precision"; round 3).  The reference's arithmetic is fp32
+// (include/params.h:332 leaves USE_FP16 commented out; every plugin demands kFLOAT), and fp16 operands cannot meet the 1e-3 box bar
+// (profiles/r02_f16_error_attribution.txt); v_mfma_f32_16x16x4_f32 meets it at 1/16 of the fp16 matrix rate.  Here every operand is the
+// pair  hi = fp16(v), lo = fp16(v - hi)  (22 mantissa bits) and a product is three fp16 MFMAs with fp32 accumulation:
+//     a w  ~=  a_hi w_hi + a_hi w_lo + a_lo w_hi                      (the dropped a_lo w_lo term is 2^-22 of the product)
+// A, A2 (the position table) and the output are fp32 tensors in HBM; the split of the activations happens in registers, the weights
+// are split by the host.  Structure = linear_f16_rows_kernel: a workgroup loads its rows once, keeps four 36 KB weight stages in LDS
+// (a stage = 48 output columns: per k-step three fragment rows of w_hi followed by the same three of w_lo), a column chunk = two
+// stages = 96 columns; the fp32 stores of chunk c drain under the MFMAs of chunk c + 1 (counted vmcnt, see above).
+constexpr int SP_NW = 8;              // waves of 16 rows (<= 256 VGPRs: the row fragments alone are 96)
+constexpr int SP_COLS = 48;           // output columns per stage
+
+// hi / lo split of 8 consecutive k of one row (the two float4 halves), saturated so that |v| > 65504 gives hi = +-65504, not inf
+struct HiLo8 { half8 hi, lo; };
+__device__ __forceinline__ HiLo8 splitFrag(floatx4 x, floatx4 y) {
+    const float v[8] = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+    _Float16 h[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h[i] = (_Float16)__builtin_fminf(__builtin_fmaxf(v[i], -65504.f), 65504.f);
+        l[i] = (_Float16)__builtin_fminf(__builtin_fmaxf(v[i] - (float)h[i], -65504.f), 65504.f);
+    }
+    HiLo8 o;
+    o.hi = half8{h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]};
+    o.lo = half8{l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7]};
+    return o;
+}
+
+template <bool TABLE>             // the A2 rows are gathered through the window cell (a2_c2d)
+__global__ void __launch_bounds__(64 * SP_NW, 2)
+linear_split_rows_kernel(LinearArgs a, const _Float16* __restrict__ Wp)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char ring[4 * SBYTES + 4096];   // four weight stages + the bias (<= 1024 floats): one workgroup per CU
+    const int M = rowLimit(a);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * 16 * SP_NW;
+    if (m0 >= M) return;
+    const int NCH = a.N / (2 * SP_COLS);                             // 96-column chunks (two stages each)
+    const int nreq = (SROWS - wave + SP_NW - 1) / SP_NW;             // fragment rows this wave requests per stage (5 or 4)
+    auto request = [&](int st) {                                     // stage st (= 2 chunk + half) -> slot st % 4
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int row = wave + j * SP_NW;
+            if (row < SROWS)
+                __builtin_amdgcn_global_load_lds((glds_src_t)(Wp + ((size_t)st * SROWS + row) * 512 + lane * 8),
+                                                 (glds_dst_t)(ring + (st & 3) * SBYTES + row * 1024), 16, 0, 0);
+        }
+    };
+    auto waitKeep = [&](int keep) {                                  // wave-uniform; then the workgroup barrier
+        switch (keep) {
+            case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); break;
+            case 14: asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory"); break;
+            case 16: asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;      // (waiting for more than needed is always correct)
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    if (wave < 4) {                                                  // the bias by LDS-DMA (see linear_f16_rows_kernel)
+        const int f0 = wave * 256 + lane * 4;
+        const float* src = a.bias ? a.bias + (f0 + 3 < a.N ? f0 : 0) : reinterpret_cast<const float*>(Wp);
+        __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(ring + 4 * SBYTES + wave * 1024), 16, 0, 0);
+    }
+    const uint32_t bias_lds = (uint32_t)(uintptr_t)(glds_dst_t)(ring + 4 * SBYTES);
+    request(0); request(1);
+    if (NCH > 1) { request(2); request(3); }
+    const int row = m0 + wave * 16 + r, rc = row < M ? row : M - 1;
+    const bool waveValid = m0 + wave * 16 < M;                       // (else this wave issues no store)
+    const int nst = waveValid ? 6 : 0;                               // 16-byte stores of one chunk per wave
+    // operand fragments: x alone for the chunks at or above add_cols, x + A2 row (gathered through the window cell when TABLE) below
+    half8 fxh[NSTEP], fxl[NSTEP], fph[NSTEP], fpl[NSTEP];
+    {
+        const float* px = static_cast<const float*>(a.A) + (size_t)rc * KS + g * 8;
+        size_t o2 = (size_t)rc * KS + g * 8;
+        if (TABLE) { const int32_t* c = a.a2_c2d + (size_t)rc * 3; o2 = (size_t)(c[1] * a.a2_wx + c[2]) * KS + g * 8; }
+        const bool hasA2 = a.add_cols > 0;
+        const float* pp = hasA2 ? static_cast<const float*>(a.A2) + o2 : px;
+        floatx4 xv[2 * NSTEP], pv[2 * NSTEP];
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) { xv[2 * s] = *reinterpret_cast<const floatx4*>(px + s * 32); xv[2 * s + 1] = *reinterpret_cast<const floatx4*>(px + s * 32 + 4); }
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) { pv[2 * s] = *reinterpret_cast<const floatx4*>(pp + s * 32); pv[2 * s + 1] = *reinterpret_cast<const floatx4*>(pp + s * 32 + 4); }
+#pragma unroll
+        for (int s = 0; s < 2 * NSTEP; ++s) { asm volatile("" :: "v"(xv[s])); asm volatile("" :: "v"(pv[s])); }     // hipcc's wait for the row loads: here, once
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const HiLo8 fx = splitFrag(xv[2 * s], xv[2 * s + 1]);
+            const HiLo8 fp = splitFrag(pv[2 * s] + xv[2 * s], pv[2 * s + 1] + xv[2 * s + 1]);      // q = k = x + pos in fp32 (getValueByIndex.cu:299-301)
+            fxh[s] = fx.hi; fxl[s] = fx.lo; fph[s] = fp.hi; fpl[s] = fp.lo;
+        }
+    }
+    waitKeep(NCH > 1 ? 2 * nreq : 0);                                // stages 0, 1 landed (2, 3 may stay in flight: they are younger)
+    const unsigned char* slot = ring + lane * 16;
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        const bool add = c * 2 * SP_COLS < a.add_cols;
+        floatx4 acc[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned char* sp = slot + ((2 * c + h) & 3) * SBYTES;
+#pragma unroll
+            for (int ks = 0; ks < NSTEP; ++ks) {
+                const half8 fh = add ? fph[ks] : fxh[ks], fl = add ? fpl[ks] : fxl[ks];
+                half8 wh[3], wl[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) { wh[t] = *reinterpret_cast<const half8*>(sp + (ks * 6 + t) * 1024); wl[t] = *reinterpret_cast<const half8*>(sp + (ks * 6 + 3 + t) * 1024); }
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[3 * h + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], fh, acc[3 * h + t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[3 * h + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], fl, acc[3 * h + t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[3 * h + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], fh, acc[3 * h + t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // everyone is done with the two slots of chunk c: the stages of chunk c + 2 may overwrite them
+        const bool more = c + 2 < NCH;
+        if (c + 1 < NCH) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+            if (more) { request(2 * c + 4); request(2 * c + 5); }
+        }
+        // bias + fp32 stores of chunk c (issued AFTER the requests above: they stay the youngest entries of the counter)
+        {
+            const int n0 = c * 2 * SP_COLS;
+#pragma unroll
+            for (int t = 0; t < 6; t += 2) {
+                floatx4 X = acc[t], Y = acc[t + 1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(X[i]), __float_as_uint(Y[i]), false, false);
+                    X[i] = __uint_as_float(sw[0]); Y[i] = __uint_as_float(sw[1]);
+                }
+                const int col = n0 + t * 16 + (g & 1) * 16 + (g >> 1) * 8;       // the lane's eight columns after the swap are contiguous
+                if (a.bias) {
+                    const uint32_t ad = bias_lds + (uint32_t)col * 4u;
+                    floatx4 b0, b1;
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b0), "=&v"(b1) : "v"(ad));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { X[i] += b0[i]; Y[i] += b1[i]; }
+                }
+                if (row < M) {
+                    float* o = a.out + (size_t)row * a.out_ld + col;
+                    *reinterpret_cast<float4*>(o) = make_float4(X[0], X[1], X[2], X[3]);
+                    *reinterpret_cast<float4*>(o + 4) = make_float4(Y[0], Y[1], Y[2], Y[3]);
+                }
+            }
+        }
+        // the stages of chunk c + 1 have landed: everything older than [requests of chunk c + 2] [stores of chunk c] is retired
+        if (c + 1 < NCH) waitKeep((more ? 2 * nreq : 0) + nst);
+    }
+}
+
+// stage image of the split kernel: stage s = output columns [48 s, 48 s + 48), row (ks, t) = w_hi of column tile t for t < 3, w_lo of tile t - 3 above
+static std::vector<_Float16> packStagesSplit(const float* W, int N) {
+    std::vector<_Float16> out((size_t)(N / SP_COLS) * SROWS * 512);
+    for (int s = 0; s < N / SP_COLS; ++s)
+        for (int ks = 0; ks < NSTEP; ++ks)
+            for (int t = 0; t < 6; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const float w = W[(size_t)(SP_COLS * s + 16 * (t % 3) + (lane & 15)) * KS + 32 * ks + 8 * (lane >> 4) + j];
+                        const _Float16 hi = (_Float16)w;
+                        out[(((size_t)s * SROWS + ks * 6 + t) * 64 + lane) * 8 + j] = t < 3 ? hi : (_Float16)(w - (float)hi);
+                    }
+    return out;
+}
+
+static int launchLinearSplit(const LinearArgs& a, const _Float16* Wp, hipStream_t stream) {
+    const dim3 grid(cdiv(a.max_rows, 16 * SP_NW)), block(64 * SP_NW);
+    if (a.a2_c2d) hipLaunchKernelGGL(linear_split_rows_kernel<true>, grid, block, 0, stream, a, Wp);
+    else hipLaunchKernelGGL(linear_split_rows_kernel<false>, grid, block, 0, stream, a, Wp);
+    return lastError();
+}
+
 static int launchLinearF16Resident(const LinearArgs& a, const _Float16* Wp, hipStream_t stream) {
     static int ncu = 0;
     if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }
@@ -842,18 +1021,18 @@ int launchLinearF16Rows(const LinearArgs& a, const _Float16* Wp, hipStream_t str
 int launchLinearF16Stream(const LinearArgs& a, const _Float16* Wp, hipStream_t stream) {
     if (a.K != KS || a.N % BN != 0 || (a.N > BN && a.n_ln > 0)) return -3;
     static int rowsOn = -1;        // DSVT_LINEAR_ROWS=0: one column chunk per workgroup for every layer
-    if (rowsOn < 0) { const char* e = getenv("DSVT_LINEAR_ROWS"); rowsOn = e ? atoi(e) : 1; }
+    if (rowsOn < 0) rowsOn = ablateEnv("DSVT_LINEAR_ROWS", 1);
     if (rowsOn && a.N > BN && a.a_half && !a.pe_xy && a.out16 && !a.out && a.act == ACT_NONE && a.n_ln == 0 && a.row_mult == 1 &&
         (a.add_cols % BN) == 0 && a.N <= 1024 && !a.trace) {
         static int resident = -1;  // DSVT_LINEAR_RESIDENT=0: the streamed whole-row kernel for every shape; 2: the resident one whatever the row capacity
-        if (resident < 0) { const char* e = getenv("DSVT_LINEAR_RESIDENT"); resident = e ? atoi(e) : 1; }
+        if (resident < 0) resident = ablateEnv("DSVT_LINEAR_RESIDENT", 1);
         if (resident && a.N == 96 * RS_SPT * 2 && (a.add_cols % 96) == 0 && (a.max_rows >= 3 * 65536 || resident == 2)) return launchLinearF16Resident(a, Wp, stream);
         return launchLinearF16Rows(a, Wp, stream);
     }
     dim3 grid(cdiv(a.max_rows, BM16), a.N / BN);
     const int amode = a.pe_xy ? 2 : a.a_half ? 1 : 0;
     static int mt2 = -1;           // DSVT_STREAM_MT=2: 4 waves x 32 rows (<= 256 VGPRs); default 8 waves x 16 rows (<= 128 VGPRs, 4 waves/SIMD):
-    if (mt2 < 0) { const char* e = getenv("DSVT_STREAM_MT"); mt2 = e ? atoi(e) : 1; }      // 1.5 % faster with two frames in flight, slower alone
+    if (mt2 < 0) mt2 = ablateEnv("DSVT_STREAM_MT", 1);      // 1.5 % faster with two frames in flight, slower alone
     const bool wide = mt2 == 2;
 #define DSVT_LS(AM) do { if (wide) hipLaunchKernelGGL((linear_f16_stream_kernel<AM, 2, 4>), grid, dim3(256), 0, stream, a, Wp); \
                          else hipLaunchKernelGGL((linear_f16_stream_kernel<AM, 1, 8>), grid, dim3(512), 0, stream, a, Wp); } while (0)
@@ -890,7 +1069,7 @@ enum { OUT_F32 = 0, OUT_F16 = 1, OUT_BOTH = 2 };
 
 struct LinCfg {
     int max_rows, K, N, row_mult, act, add_cols, n_ln; float eps;
-    int compute_type;      // 0: fp32 MFMA (exact fp32 products)   1: fp16 MFMA operands, fp32 accumulate
+    int compute_type;      // 0: fp32 MFMA (exact fp32 products)   1: fp16 MFMA operands, fp32 accumulate   2: split-precision fp16 MFMA (hi + lo operands, fp32 grade)
     int input_half;        // A / A2 tensors are fp16 (needs compute_type 1)
     int output_mode;       // OUT_F32: one fp32 output; OUT_F16: one fp16 output; OUT_BOTH: fp32 + fp16 copy
     int a2_gather_wx;      // > 0: input 2 is a [cells, K] table and input 3 the [rows, 3] window coordinates (z, y, x); row m adds table row y * wx + x
@@ -903,10 +1082,11 @@ public:
     float *w_dev_ = nullptr, *b_dev_ = nullptr, *g_dev_ = nullptr, *be_dev_ = nullptr, *pe_dev_ = nullptr;
     _Float16* wh_dev_ = nullptr;
     _Float16* wp_dev_ = nullptr;      // fragment-ordered stage image for the LDS-DMA kernel (K = 192, N % 192 == 0)
+    _Float16* wps_dev_ = nullptr;     // hi | lo stage image of the split-precision kernel (compute_type 2)
     bool ok_ = false;
     bool useStream() const {
         static int v = -1;
-        if (v < 0) { const char* e = getenv("DSVT_LINEAR_STREAM"); v = e ? atoi(e) : 1; }      // 0: register-staged kernel everywhere (A/B runs)
+        if (v < 0) v = ablateEnv("DSVT_LINEAR_STREAM", 1);      // 0: register-staged kernel everywhere (A/B runs)
         return v == 1 && useF16() && c_.K == KS && c_.N % BN == 0;
     }
     bool useF16() const { return c_.compute_type == 1 && c_.K % KS == 0; }
@@ -931,6 +1111,11 @@ public:
             ok_ = hipMalloc(&wh_dev_, sizeof(_Float16) * wh.size()) == hipSuccess &&
                   hipMemcpy(wh_dev_, wh.data(), sizeof(_Float16) * wh.size(), hipMemcpyHostToDevice) == hipSuccess;
         }
+        if (ok_ && c_.compute_type == 2) {
+            const std::vector<_Float16> wp = packStagesSplit(w_.data(), c_.N);
+            ok_ = hipMalloc(&wps_dev_, sizeof(_Float16) * wp.size()) == hipSuccess &&
+                  hipMemcpy(wps_dev_, wp.data(), sizeof(_Float16) * wp.size(), hipMemcpyHostToDevice) == hipSuccess;
+        }
         if (ok_ && useStream()) {
             const std::vector<_Float16> wp = packStages(w_.data(), c_.N);
             ok_ = hipMalloc(&wp_dev_, sizeof(_Float16) * wp.size()) == hipSuccess &&
@@ -941,6 +1126,7 @@ public:
         for (float* p : {w_dev_, b_dev_, g_dev_, be_dev_, pe_dev_}) if (p) (void)hipFree(p);
         if (wh_dev_) (void)hipFree(wh_dev_);
         if (wp_dev_) (void)hipFree(wp_dev_);
+        if (wps_dev_) (void)hipFree(wps_dev_);
     }
     const char* type() const override { return "DsvtLinearPlugin"; }
     int nbOutputs() const override { return c_.output_mode == OUT_BOTH ? 2 : 1; }
@@ -962,6 +1148,7 @@ public:
         return io[pos].type == outputType(pos - nbIn, nullptr, 0);
     }
     size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override { return 0; }
+    bool sharedInput(int index) const override { return c_.a2_gather_wx > 0 && index == 2; }      // the [cells, K] position table
     int enqueue(const DsvtPluginTensorDesc*, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void*,
                 hipStream_t stream) override {
         if (!ok_) return static_cast<int>(hipErrorOutOfMemory);
@@ -988,10 +1175,11 @@ public:
             if (a.out) DSVT_CHECK(hipMemsetAsync(a.out, 0, sizeof(float) * (size_t)c_.max_rows * c_.N, stream));
             if (a.out16) DSVT_CHECK(hipMemsetAsync(a.out16, 0, sizeof(_Float16) * (size_t)c_.max_rows * c_.N, stream));
         }
-        if (c_.a2_gather_wx > 0 && !wp_dev_) return -4;           // the table gather lives in the streamed kernel only
+        if (wps_dev_) return launchLinearSplit(a, wps_dev_, stream);
+        if (c_.a2_gather_wx > 0 && !wp_dev_) return -4;           // the table gather lives in the streamed kernels only
         if (wp_dev_) {
             static unsigned long long* tr = nullptr; static int tron = -1;
-            if (tron < 0) { tron = getenv("DSVT_LINEAR_TRACE") ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 8 * 4096); }
+            if (tron < 0) { tron = ablateEnv("DSVT_LINEAR_TRACE", 0) ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 8 * 4096); }
             a.trace = tr;
             const int rc = launchLinearF16Stream(a, wp_dev_, stream);
             if (tron) {
@@ -1027,12 +1215,15 @@ static Plugin* linNew(const LinCfg& c, const float* w, const float* b, const flo
                       const float* pe_w = nullptr, const float* pe_b = nullptr) {
     if ((pe_w || pe_b) && !(pe_w && pe_b && c.compute_type == 1 && c.K % KS == 0 && c.add_cols == 0 && !c.input_half)) return nullptr;
     if (c.max_rows <= 0 || c.K <= 0 || c.N <= 0 || c.N % 4 != 0 || c.row_mult <= 0 || !w) return nullptr;
-    if (c.compute_type < 0 || c.compute_type > 1 || c.output_mode < 0 || c.output_mode > 2) return nullptr;
+    if (c.compute_type < 0 || c.compute_type > 2 || c.output_mode < 0 || c.output_mode > 2) return nullptr;
+    // split precision: the whole-row kernel only (K = 192, 96-column chunks, fp32 in / out, bias; the other epilogues live in DsvtEncoderMlpPlugin)
+    if (c.compute_type == 2 && !(c.K == KS && c.N % (2 * SP_COLS) == 0 && c.N <= 1024 && !c.input_half && c.output_mode == OUT_F32 && c.n_ln == 0 &&
+                                 c.act == ACT_NONE && c.row_mult == 1 && c.add_cols % (2 * SP_COLS) == 0 && !pe_w)) return nullptr;
     if (c.act < 0 || c.act > 2 || c.n_ln < 0 || c.n_ln > 3) return nullptr;
     if (c.n_ln > 0 && (c.N > BN || !g || !be)) return nullptr;             // a LayerNorm row must fit one tile
     if (c.add_cols < 0 || c.add_cols > c.N || (c.add_cols % BN != 0 && c.add_cols != c.N)) return nullptr;
     if (c.input_half && !(c.compute_type == 1 && c.K % KS == 0)) return nullptr;      // fp16 inputs only on the fp16 kernel
-    if (c.a2_gather_wx < 0 || (c.a2_gather_wx > 0 && !(c.add_cols > 0 && c.input_half && c.K == KS))) return nullptr;   // table gather: streamed fp16 kernel
+    if (c.a2_gather_wx < 0 || (c.a2_gather_wx > 0 && !(c.add_cols > 0 && (c.input_half || c.compute_type == 2) && c.K == KS))) return nullptr;   // table gather: streamed fp16 / split kernels
     return new DsvtLinearPlugin(c, w, b, g, be, pe_w, pe_b);
 }
 static Plugin* linCreate(const DsvtPluginFieldCollection* fc) {

@@ -81,6 +81,31 @@ __device__ __forceinline__ void packFrags(const floatx4 (&acc)[MNT], half8 (&f)[
     }
 }
 
+// split precision (round 3): v = hi + lo with hi = fp16(v) (saturated), lo = fp16(v - hi); see linear.hip linear_split_rows_kernel
+__device__ __forceinline__ void splitHalf(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)__builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f);
+    lo = (_Float16)__builtin_fminf(__builtin_fmaxf(v - (float)hi, -65504.f), 65504.f);
+}
+struct MlpHiLo { half8 hi, lo; };
+__device__ __forceinline__ MlpHiLo splitFrag8(const float (&v)[8]) {
+    _Float16 h[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) splitHalf(v[i], h[i], l[i]);
+    MlpHiLo o;
+    o.hi = half8{h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]};
+    o.lo = half8{l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7]};
+    return o;
+}
+// C-layout values of tiles {2s, 2s+1} -> hi / lo B fragments of k-step s
+__device__ __forceinline__ void packFragsSplit(const floatx4 (&acc)[MNT], half8 (&fh)[MNSTEP], half8 (&fl)[MNSTEP]) {
+#pragma unroll
+    for (int s = 0; s < MNSTEP; ++s) {
+        const float v[8] = {acc[2 * s][0], acc[2 * s][1], acc[2 * s][2], acc[2 * s][3], acc[2 * s + 1][0], acc[2 * s + 1][1], acc[2 * s + 1][2], acc[2 * s + 1][3]};
+        const MlpHiLo o = splitFrag8(v);
+        fh[s] = o.hi; fl[s] = o.lo;
+    }
+}
+
 // -------------------------------------------------------------------------------------
 // Weights streamed by LDS-DMA.  (The first version of this kernel staged each weight slab through registers: one 128-row
 // tile per workgroup walking nine exposed "load slab -> ds_write -> barrier -> MFMA" steps, SQ_WAIT_ANY = 70 % of wave
@@ -100,7 +125,8 @@ typedef __attribute__((address_space(1))) const void* mlp_gsrc_t;
 typedef __attribute__((address_space(3))) void* mlp_ldst_t;
 
 struct MlpStreamArgs {
-    const _Float16* att; const float* x; const float* xb;
+    const _Float16* att; const float* att32;         // attention output rows: fp16 (default) or fp32 (split-precision kernel)
+    const float* x; const float* xb;
     const _Float16* Wp;                              // MS_STAGES x 36 x 512 halfs
     const float* params;                             // MP_FLOATS
     const float* ln_g; const float* ln_b;            // [4][192]
@@ -150,18 +176,23 @@ __device__ __forceinline__ void mlpLayerNormLds(floatx4 (&acc)[MNT], const float
 // That floor is the memory system: every one of the 256 workgroups streams the same 360 KB of weights L2 -> LDS, 92 MB per launch on
 // top of the 93 MB of activations, i.e. 185 MB in 44 us = 4.2 TB/s against the ~6.4 TB/s the LDS-DMA stream reaches chip-wide
 // (MI355X_MICROARCH.md "ldsdma-fill").  Fewer re-streamed weight bytes per row (more rows per workgroup) is the remaining lever.
-template <int MT, int NW, int PQ, int RS>
-__global__ void __launch_bounds__(64 * NW, (MT == 1 ? 3 : 2))
+// SPLIT (round 3, the fp32-grade mode): att arrives as fp32, every GEMM operand is a hi / lo fp16 pair and every product three MFMAs
+// (w_hi a_hi + w_lo a_hi + w_hi a_lo, fp32 accumulate); a stage holds its fragment rows twice, the SRH rows of w_hi followed by the
+// same rows of w_lo (48 KB stages, three slots: 149 KB, one eight-wave workgroup per CU at <= 256 registers); s1 and h are split in
+// registers where the fp16 kernel rounds them; only the fp32 result is written.
+template <int MT, int NW, int PQ, int RS, bool SPLIT = false>
+__global__ void __launch_bounds__(64 * NW, (SPLIT ? 2 : MT == 1 ? 3 : 2))
 encoder_mlp_stream_kernel(MlpStreamArgs a)
 {
-    constexpr int PQT = PQ / 16, PQS = PQ / 32, SR = 6 * PQT, SB = SR * 1024, NWO = MC / PQ, NPIECE = MF / PQ;
+    constexpr int PQT = PQ / 16, PQS = PQ / 32, SRH = 6 * PQT, SR = SPLIT ? 2 * SRH : SRH, SB = SR * 1024, NWO = MC / PQ, NPIECE = MF / PQ;
+    constexpr int LO = SRH * 1024;                  // byte offset of a stage's w_lo rows
     constexpr int NST = NWO + 2 * NPIECE, NRW = SR / NW, D = RS - 1;
     // ln_g [4][192] | ln_b [4][192] of the final LayerNorms (six 1 KB DMA rows): with three slots they take the slot stage NST-3 leaves when
     // the last piece starts (no LDS of their own: 78,848 B, two workgroups per CU); the deeper ring has no free slot then, they get 6 KB
     constexpr bool LN_IN_RING = RS == 3;
     constexpr int LNP = LN_IN_RING ? 0 : 8 * MC * 4;
     constexpr bool ELASTIC = MT == 1 && NW == 10;   // 8 .. 10 waves of 16 rows are live, chosen from the row count (see below)
-    static_assert(12 * PQS == SR && (ELASTIC || (SR % NW == 0 && (NRW == 3 || NRW == 6))), "uniform request count per wave");
+    static_assert(12 * PQS == SRH && (ELASTIC || (SR % NW == 0 && (NRW == 3 || NRW == 6))), "uniform request count per wave");
     __shared__ __attribute__((aligned(16))) unsigned char lds[RS * SB + MP_FLOATS * 4 + LNP];     // RS = 3: 78,848 B; RS = 6: 158,720 B (one workgroup per CU)
     const uint32_t cnt = *a.count;
     const int M = (int)(cnt < (uint32_t)a.max_rows ? cnt : (uint32_t)a.max_rows);
@@ -192,7 +223,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
     } else {
         constexpr int WGR = 16 * MT * NW;                // rows of a full workgroup (128; 256 for <2, 8>)
         const int T = (M + WGR - 1) / WGR, over = M - a.ncu * WGR;
-        const bool plan = WGR == MROWS && T > a.ncu && over <= MLP_SMALL_MAX && !(a.dbg & 32);
+        const bool plan = !SPLIT && WGR == MROWS && T > a.ncu && over <= MLP_SMALL_MAX && !(a.dbg & 32);
         const int FULL = plan ? a.ncu : T;
         small = (int)blockIdx.x >= FULL;
         m0 = blockIdx.x * WGR;
@@ -285,12 +316,18 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
 #pragma unroll
     for (int d = 1; d < D; ++d) request(d);
     // ---- prologue: the att row as the out-proj B operand, x straight into the out-proj accumulator -----------------
-    half8 fa[MT][MNSTEP];
+    half8 fa[MT][MNSTEP], fal[SPLIT ? MT : 1][MNSTEP];
+    floatx4 araw[SPLIT ? MT : 1][2 * MNSTEP];
     floatx4 acc[MT][MNT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int s = 0; s < MNSTEP; ++s) fa[mt][s] = *reinterpret_cast<const half8*>(a.att + (size_t)rc[mt] * MC + s * 32 + g * 8);
+            for (int s = 0; s < 2 * MNSTEP; ++s) araw[mt][s] = *reinterpret_cast<const floatx4*>(a.att32 + (size_t)rc[mt] * MC + (s >> 1) * 32 + g * 8 + (s & 1) * 4);
+        } else {
+#pragma unroll
+            for (int s = 0; s < MNSTEP; ++s) fa[mt][s] = *reinterpret_cast<const half8*>(a.att + (size_t)rc[mt] * MC + s * 32 + g * 8);
+        }
 #pragma unroll
         for (int t = 0; t < MNT; ++t) {
             const float4 xv = *reinterpret_cast<const float4*>(a.x + (size_t)rc[mt] * MC + t * 16 + 4 * g);
@@ -300,14 +337,30 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
     // hipcc's own wait for these ordinary loads belongs here, not behind the next stage's request (see linear.hip)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int s = 0; s < MNSTEP; ++s) asm volatile("" :: "v"(fa[mt][s]));
+            for (int s = 0; s < 2 * MNSTEP; ++s) asm volatile("" :: "v"(araw[mt][s]));
+        } else {
+#pragma unroll
+            for (int s = 0; s < MNSTEP; ++s) asm volatile("" :: "v"(fa[mt][s]));
+        }
 #pragma unroll
         for (int t = 0; t < MNT; ++t) asm volatile("" :: "v"(acc[mt][t]));
     }
     mark();
     mlpStageBarrier();                               // stages 0 .. D-1 + parameters landed
     mark();
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int s = 0; s < MNSTEP; ++s) {
+                const floatx4 u = araw[mt][2 * s], w = araw[mt][2 * s + 1];
+                const float v[8] = {u[0], u[1], u[2], u[3], w[0], w[1], w[2], w[3]};
+                const MlpHiLo o = splitFrag8(v);
+                fa[mt][s] = o.hi; fal[mt][s] = o.lo;
+            }
+    }
 #pragma unroll
     for (int t = 0; t < MNT; ++t) {
         const float4 b = *reinterpret_cast<const float4*>(prm + MP_BO + t * 16 + 4 * g);
@@ -326,6 +379,14 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
 #pragma unroll
             for (int t = 0; t < PQT; ++t) {
                 const half8 wf = *reinterpret_cast<const half8*>(sl + (ks * PQT + t) * 1024);
+                if constexpr (SPLIT) {
+                    const half8 wl = *reinterpret_cast<const half8*>(sl + LO + (ks * PQT + t) * 1024);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        acc[mt][h * PQT + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, fa[mt][ks], acc[mt][h * PQT + t], 0, 0, 0);
+                        acc[mt][h * PQT + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, fal[mt][ks], acc[mt][h * PQT + t], 0, 0, 0);
+                    }
+                }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[mt][h * PQT + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, fa[mt][ks], acc[mt][h * PQT + t], 0, 0, 0);
             }
@@ -334,11 +395,12 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
         mark();
         if (h + 1 < NWO) stageEnd(h);
     }
-    half8 fs1[MT][MNSTEP];
+    half8 fs1[MT][MNSTEP], fs1l[SPLIT ? MT : 1][MNSTEP];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         if (!(a.dbg & 1)) mlpLayerNormLds(acc[mt], prm + MP_G1, prm + MP_B1LN, g, a.eps);         // s1 = LN1(att Wo^T + bo + x)
-        packFrags(acc[mt], fs1[mt]);                                            // s1 as the FC1 operand
+        if constexpr (SPLIT) packFragsSplit(acc[mt], fs1[mt], fs1l[mt]);
+        else packFrags(acc[mt], fs1[mt]);                                       // s1 as the FC1 operand
     }
 #pragma unroll
     for (int t = 0; t < MNT; ++t) {                                     // the FC2 accumulator starts at s1 + b2 (LN2's residual, fp32)
@@ -368,12 +430,20 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
 #pragma unroll
             for (int t = 0; t < PQT; ++t) {
                 const half8 wf = *reinterpret_cast<const half8*>(slotA + (ks * PQT + t) * 1024);
+                if constexpr (SPLIT) {
+                    const half8 wl = *reinterpret_cast<const half8*>(slotA + LO + (ks * PQT + t) * 1024);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        acc2[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, fs1[mt][ks], acc2[mt][t], 0, 0, 0);
+                        acc2[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, fs1l[mt][ks], acc2[mt][t], 0, 0, 0);
+                    }
+                }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc2[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, fs1[mt][ks], acc2[mt][t], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        half8 fh[MT][PQS];
+        half8 fh[MT][PQS], fhl[SPLIT ? MT : 1][PQS];
 #pragma unroll
         for (int sp = 0; sp < PQS; ++sp) {
             const float4 b0 = *reinterpret_cast<const float4*>(prm + MP_B1 + q * PQ + (2 * sp) * 16 + 4 * g);
@@ -381,6 +451,12 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 half8 h;
+                if constexpr (SPLIT) {
+                    const float v[8] = {mlpGelu(acc2[mt][2 * sp][0] + b0.x), mlpGelu(acc2[mt][2 * sp][1] + b0.y), mlpGelu(acc2[mt][2 * sp][2] + b0.z), mlpGelu(acc2[mt][2 * sp][3] + b0.w),
+                                        mlpGelu(acc2[mt][2 * sp + 1][0] + b1v.x), mlpGelu(acc2[mt][2 * sp + 1][1] + b1v.y), mlpGelu(acc2[mt][2 * sp + 1][2] + b1v.z), mlpGelu(acc2[mt][2 * sp + 1][3] + b1v.w)};
+                    const MlpHiLo o = splitFrag8(v);
+                    h = o.hi; fhl[mt][sp] = o.lo;
+                } else
                 if (a.dbg & 2) {
                     h[0] = (_Float16)acc2[mt][2 * sp][0]; h[1] = (_Float16)acc2[mt][2 * sp][1]; h[2] = (_Float16)acc2[mt][2 * sp][2]; h[3] = (_Float16)acc2[mt][2 * sp][3];
                     h[4] = (_Float16)acc2[mt][2 * sp + 1][0]; h[5] = (_Float16)acc2[mt][2 * sp + 1][1]; h[6] = (_Float16)acc2[mt][2 * sp + 1][2]; h[7] = (_Float16)acc2[mt][2 * sp + 1][3];
@@ -402,6 +478,14 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
 #pragma unroll
             for (int t = 0; t < MNT; ++t) {
                 const half8 wf = *reinterpret_cast<const half8*>(slotB + (sp * 12 + t) * 1024);
+                if constexpr (SPLIT) {
+                    const half8 wl = *reinterpret_cast<const half8*>(slotB + LO + (sp * 12 + t) * 1024);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, fh[mt][sp], acc[mt][t], 0, 0, 0);
+                        acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, fhl[mt][sp], acc[mt][t], 0, 0, 0);
+                    }
+                }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, fh[mt][sp], acc[mt][t], 0, 0, 0);
             }
@@ -458,8 +542,10 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
                 float* o = a.out + (size_t)rw * MC + col;
                 *reinterpret_cast<float4*>(o) = make_float4(X[0], X[1], X[2], X[3]);
                 *reinterpret_cast<float4*>(o + 4) = make_float4(Y[0], Y[1], Y[2], Y[3]);
-                half8 h = {(_Float16)X[0], (_Float16)X[1], (_Float16)X[2], (_Float16)X[3], (_Float16)Y[0], (_Float16)Y[1], (_Float16)Y[2], (_Float16)Y[3]};
-                *reinterpret_cast<half8*>(a.out16 + (size_t)rw * MC + col) = h;
+                if constexpr (!SPLIT) {
+                    half8 h = {(_Float16)X[0], (_Float16)X[1], (_Float16)X[2], (_Float16)X[3], (_Float16)Y[0], (_Float16)Y[1], (_Float16)Y[2], (_Float16)Y[3]};
+                    *reinterpret_cast<half8*>(a.out16 + (size_t)rw * MC + col) = h;
+                }
             }
         }
     }
@@ -476,14 +562,15 @@ class DsvtEncoderMlpPlugin : public Plugin {
 public:
     int max_rows_, has_block_ln_; float eps_;
     int frames_ = 0;                                              // optional field "frames": frames whose rows one launch carries (0 = unknown: decided by the row count on the device)
+    int split_ = 0;                                               // optional field "split_precision": fp32 att in, fp32 x' out, hi / lo fp16 operands (fp32 grade)
     std::vector<float> wo_, w1_, w2_, bo_, b1_, b2_, lg_, lb_;     // as given (natural order)
     float *lg_dev_ = nullptr, *lb_dev_ = nullptr;
     _Float16* wp_dev_ = nullptr; float* prm_dev_ = nullptr;       // stage image + LDS parameter block of the streamed kernel
     int pq_ = 64;                                                 // FC1 columns per piece of that image
     bool ok_ = false;
     DsvtEncoderMlpPlugin(int max_rows, int has_block_ln, float eps, const float* wo, const float* w1, const float* w2,
-                         const float* bo, const float* b1, const float* b2, const float* lg, const float* lb)
-        : max_rows_(max_rows), has_block_ln_(has_block_ln), eps_(eps), wo_(wo, wo + MC * MC), w1_(w1, w1 + MF * MC),
+                         const float* bo, const float* b1, const float* b2, const float* lg, const float* lb, int split = 0)
+        : max_rows_(max_rows), has_block_ln_(has_block_ln), eps_(eps), split_(split), wo_(wo, wo + MC * MC), w1_(w1, w1 + MF * MC),
           w2_(w2, w2 + MC * MF), bo_(bo, bo + MC), b1_(b1, b1 + MF), b2_(b2, b2 + MC),
           lg_(lg, lg + (3 + has_block_ln) * MC), lb_(lb, lb + (3 + has_block_ln) * MC) {
         lg_.resize(4 * MC, 1.f); lb_.resize(4 * MC, 0.f);
@@ -494,9 +581,14 @@ public:
         ok_ = upF(lg_, &lg_dev_) && upF(lb_, &lb_dev_);
         if (!ok_) return;
         // stage image (see encoder_mlp_stream_kernel), for pq_ FC1 columns per piece
-        const int PQ = pq_, PQT = PQ / 16, PQS = PQ / 32, SR = 6 * PQT, NWO = MC / PQ, NPIECE = MF / PQ;
+        // (split precision: a stage holds its SRH fragment rows twice, w_hi = fp16(w) then w_lo = fp16(w - w_hi))
+        const int PQ = pq_, PQT = PQ / 16, PQS = PQ / 32, SRH = 6 * PQT, SR = split_ ? 2 * SRH : SRH, NWO = MC / PQ, NPIECE = MF / PQ;
         std::vector<_Float16> wp((size_t)(NWO + 2 * NPIECE) * SR * 512);
-        auto put = [&](int stage, int rowi, int lane, int j, float v) { wp[(((size_t)stage * SR + rowi) * 64 + lane) * 8 + j] = (_Float16)v; };
+        auto put = [&](int stage, int rowi, int lane, int j, float v) {
+            const _Float16 hi = (_Float16)v;
+            wp[(((size_t)stage * SR + rowi) * 64 + lane) * 8 + j] = hi;
+            if (split_) wp[(((size_t)stage * SR + SRH + rowi) * 64 + lane) * 8 + j] = (_Float16)(v - (float)hi);
+        };
         for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j) {
                 const int r = lane & 15, g = lane >> 4;
@@ -524,15 +616,15 @@ public:
             if (p) (void)hipFree(p);
     }
     const char* type() const override { return "DsvtEncoderMlpPlugin"; }
-    int nbOutputs() const override { return 2; }
+    int nbOutputs() const override { return split_ ? 1 : 2; }
     int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
-        if (i < 0 || i > 1) return -1;
+        if (i < 0 || i >= nbOutputs()) return -1;
         *out = dims3(in[0].d[0], max_rows_, MC); return 0;
     }
     int outputType(int i, const int32_t*, int) const override { return i == 0 ? DSVT_FLOAT : DSVT_HALF; }
     bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int nbIn, int) const override {
         if (io[pos].format != DSVT_FORMAT_LINEAR) return false;
-        if (pos == 0) return io[pos].type == DSVT_HALF;
+        if (pos == 0) return io[pos].type == (split_ ? DSVT_FLOAT : DSVT_HALF);
         if (pos == 1) return io[pos].type == DSVT_INT32;
         if (pos < nbIn) return io[pos].type == DSVT_FLOAT;
         return io[pos].type == (pos == nbIn ? DSVT_FLOAT : DSVT_HALF);
@@ -543,17 +635,22 @@ public:
                 hipStream_t stream) override {
         if (!ok_) return static_cast<int>(hipErrorOutOfMemory);
         MlpStreamArgs b{};
-        b.att = static_cast<const _Float16*>(in[0]); b.count = static_cast<const uint32_t*>(in[1]);
+        b.att = split_ ? nullptr : static_cast<const _Float16*>(in[0]); b.att32 = split_ ? static_cast<const float*>(in[0]) : nullptr;
+        b.count = static_cast<const uint32_t*>(in[1]);
         b.x = static_cast<const float*>(in[2]); b.xb = has_block_ln_ ? static_cast<const float*>(in[3]) : nullptr;
         b.Wp = wp_dev_; b.params = prm_dev_; b.ln_g = lg_dev_; b.ln_b = lb_dev_;
-        b.out = static_cast<float*>(out[0]); b.out16 = static_cast<_Float16*>(out[1]); b.max_rows = max_rows_; b.eps = eps_;
+        b.out = static_cast<float*>(out[0]); b.out16 = split_ ? nullptr : static_cast<_Float16*>(out[1]); b.max_rows = max_rows_; b.eps = eps_;
         if (zeroFill) {
             DSVT_CHECK(hipMemsetAsync(out[0], 0, sizeof(float) * (size_t)max_rows_ * MC, stream));
-            DSVT_CHECK(hipMemsetAsync(out[1], 0, sizeof(_Float16) * (size_t)max_rows_ * MC, stream));
+            if (!split_) DSVT_CHECK(hipMemsetAsync(out[1], 0, sizeof(_Float16) * (size_t)max_rows_ * MC, stream));
         }
         static int ncu = 0;
         if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }
         b.ncu = ncu;
+        if (split_) {                  // one kernel for every row count: eight waves x 16 rows, one workgroup per CU (149 KB of LDS)
+            hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, 64, 3, true>), dim3(cdiv(max_rows_, MROWS)), dim3(512), 0, stream, b);
+            return lastError();
+        }
         // Kernel by row count.  Up to 2.5 x 128 rows per CU (one or two frames per launch): <1,10> elastic, ONE workgroup per CU at a time
         // (168 registers per wave).  Beyond (three or more frames per launch): <2,4>, four waves x 32 rows at 256 registers, of which TWO
         // share a CU (one wave of each per SIMD) and overlap each other's LayerNorm / GELU / store phases with MFMA + DMA -- a CU hosting
@@ -563,7 +660,7 @@ public:
         // is not returns at once (an empty launch: ~2 us).  DSVT_MLP_VARIANT forces one: 1 = <2,4> + small overflow workgroups,
         // 2 = <1,8>, 3 = <1,10> elastic, 4 = <2,8>.
         static int forced = -1;
-        if (forced < 0) { const char* e = getenv("DSVT_MLP_VARIANT"); forced = e ? atoi(e) : 0; }
+        if (forced < 0) forced = ablateEnv("DSVT_MLP_VARIANT", 0);
         const int thr = 5 * ncu * MROWS / 2;
         if (!forced && frames_ > 0) return launchVariant(b, frames_ >= 3 ? 1 : 3, stream);       // the caller said which regime its launches are in (either kernel is correct for any count)
         if (!forced && max_rows_ > thr) {
@@ -580,12 +677,12 @@ public:
         const int gfull = cdiv(max_rows_, MROWS);                               // (covers the elastic variant too: >= 128 rows per workgroup)
         const dim3 grid(gfull > gsmall ? gfull : gsmall);
         static unsigned long long* tr = nullptr; static int tron = -1;         // tools/trace_mlp.py
-        if (tron < 0) { tron = getenv("DSVT_MLP_TRACE") ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 32 * 1024); }
+        if (tron < 0) { tron = ablateEnv("DSVT_MLP_TRACE", 0) ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 32 * 1024); }
         b.trace = tr;
-        static int dbg = -1; if (dbg < 0) { const char* e = getenv("DSVT_MLP_DBG"); dbg = e ? atoi(e) : 0; }
+        static int dbg = -1; if (dbg < 0) dbg = ablateEnv("DSVT_MLP_DBG", 0);
         b.dbg = dbg;
         static int ring = -1;          // DSVT_MLP_RING=6: the six-slot ring (measured: no gain, see the kernel's header)
-        if (ring < 0) { const char* e = getenv("DSVT_MLP_RING"); ring = e ? atoi(e) : 3; }
+        if (ring < 0) ring = ablateEnv("DSVT_MLP_RING", 3);
         if (variant == 3 && ring == 6) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 10, 64, 6>), grid, dim3(640), 0, stream, b);
         else if (variant == 3) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 10, 64, 3>), grid, dim3(640), 0, stream, b);
         else if (variant == 2) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, 64, 3>), grid, dim3(512), 0, stream, b);
@@ -601,18 +698,19 @@ public:
         return lastError();
     }
     size_t nFloats() const { return wo_.size() + w1_.size() + w2_.size() + bo_.size() + b1_.size() + b2_.size() + 2 * (size_t)(3 + has_block_ln_) * MC; }
-    size_t serializationSize() const override { return 2 * sizeof(int) + sizeof(float) + sizeof(float) * nFloats() + (frames_ ? sizeof(int) : 0); }
+    size_t serializationSize() const override { return 2 * sizeof(int) + sizeof(float) + sizeof(float) * nFloats() + ((frames_ || split_) ? sizeof(int) : 0) + (split_ ? sizeof(int) : 0); }
     void serialize(void* buf) const override {
         char* d = static_cast<char*>(buf);
         wr<int>(d, max_rows_); wr<int>(d, has_block_ln_); wr<float>(d, eps_);
         auto put = [&](const std::vector<float>& v, size_t n) { memcpy(d, v.data(), sizeof(float) * n); d += sizeof(float) * n; };
         put(wo_, wo_.size()); put(w1_, w1_.size()); put(w2_, w2_.size()); put(bo_, bo_.size()); put(b1_, b1_.size()); put(b2_, b2_.size());
         put(lg_, (size_t)(3 + has_block_ln_) * MC); put(lb_, (size_t)(3 + has_block_ln_) * MC);
-        if (frames_) wr<int>(d, frames_);                            // (trailing, only when set: older blobs stay valid)
+        if (frames_ || split_) wr<int>(d, frames_);                  // (trailing, only when set: older blobs stay valid)
+        if (split_) wr<int>(d, split_);
     }
     Plugin* clone() const override {
         auto* p = new DsvtEncoderMlpPlugin(max_rows_, has_block_ln_, eps_, wo_.data(), w1_.data(), w2_.data(), bo_.data(), b1_.data(), b2_.data(),
-                                           lg_.data(), lb_.data());
+                                           lg_.data(), lb_.data(), split_);
         p->frames_ = frames_;
         return p;
     }
@@ -630,7 +728,7 @@ static Plugin* mlpCreate(const DsvtPluginFieldCollection* fc) {
         if (!f || !f->data || f->length != need[i].len) return nullptr;
         p[i] = static_cast<const float*>(f->data);
     }
-    auto* pl = new DsvtEncoderMlpPlugin(max_rows, hb, fieldFloat(fc, "ln_eps", 0.f), p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
+    auto* pl = new DsvtEncoderMlpPlugin(max_rows, hb, fieldFloat(fc, "ln_eps", 0.f), p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], fieldInt(fc, "split_precision", 0) != 0);
     const int fr = fieldInt(fc, "frames", 0);
     pl->frames_ = fr > 0 ? fr : 0;
     return pl;
@@ -647,18 +745,19 @@ static Plugin* mlpDeser(const void* data, size_t len) {
     const float* wo = q; q += MC * MC; const float* w1 = q; q += MF * MC; const float* w2 = q; q += MC * MF;
     const float* bo = q; q += MC; const float* b1 = q; q += MF; const float* b2 = q; q += MC;
     const float* lg = q; q += (3 + hb) * MC; const float* lb = q;
-    auto* pl = new DsvtEncoderMlpPlugin(max_rows, hb, eps, wo, w1, w2, bo, b1, b2, lg, lb);
-    if (len >= 2 * sizeof(int) + sizeof(float) + n * sizeof(float) + sizeof(int)) {
-        int fr; memcpy(&fr, d + n * sizeof(float), sizeof(int));
-        pl->frames_ = fr > 0 ? fr : 0;
-    }
+    const size_t base = 2 * sizeof(int) + sizeof(float) + n * sizeof(float);
+    int fr = 0, sp = 0;
+    if (len >= base + sizeof(int)) memcpy(&fr, d + n * sizeof(float), sizeof(int));
+    if (len >= base + 2 * sizeof(int)) memcpy(&sp, d + n * sizeof(float) + sizeof(int), sizeof(int));
+    auto* pl = new DsvtEncoderMlpPlugin(max_rows, hb, eps, wo, w1, w2, bo, b1, b2, lg, lb, sp != 0);
+    pl->frames_ = fr > 0 ? fr : 0;
     return pl;
 }
 static Creator g_mlpCreator{"DsvtEncoderMlpPlugin",
     {{"max_rows", DSVT_FIELD_INT32}, {"has_block_norm", DSVT_FIELD_INT32}, {"ln_eps", DSVT_FIELD_FLOAT32},
      {"out_proj_weight", DSVT_FIELD_FLOAT32}, {"out_proj_bias", DSVT_FIELD_FLOAT32}, {"linear1_weight", DSVT_FIELD_FLOAT32},
      {"linear1_bias", DSVT_FIELD_FLOAT32}, {"linear2_weight", DSVT_FIELD_FLOAT32}, {"linear2_bias", DSVT_FIELD_FLOAT32},
-     {"ln_weights", DSVT_FIELD_FLOAT32}, {"ln_bias", DSVT_FIELD_FLOAT32}, {"frames", DSVT_FIELD_INT32}},
+     {"ln_weights", DSVT_FIELD_FLOAT32}, {"ln_bias", DSVT_FIELD_FLOAT32}, {"frames", DSVT_FIELD_INT32}, {"split_precision", DSVT_FIELD_INT32}},
     mlpCreate, mlpDeser, {}, {}};
 static Registrar g_mlpReg(&g_mlpCreator);
 

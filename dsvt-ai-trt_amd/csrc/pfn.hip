@@ -40,8 +40,8 @@ struct PfnArgs {
     const uint32_t* pcnt;              // [P]
     const uint32_t* pillar_num; int max_pillars;
     const float* w0; const float* b0;  // [96][12] (k padded with zeros), [96]
-    const _Float16* w1a;               // fragment-ordered [3 k-steps][12 tiles][64 lanes][8], k-permuted (chained operand)
-    const _Float16* w1b;               // fragment-ordered [3 k-steps][12 tiles][64 lanes][8], natural k
+    const _Float16* w1a;               // fragment-ordered [3 k-steps][12 tiles][64 lanes][8], k-permuted (chained operand); SPLIT: the same image of w_lo follows
+    const _Float16* w1b;               // fragment-ordered [3 k-steps][12 tiles][64 lanes][8], natural k; SPLIT: the same image of w_lo follows
     const float* b1;                   // [192]
     float* out; _Float16* out16;       // vfeat [P,192] + fp16 copy
     unsigned long long* trace;         // debugging: phase timestamps of workgroup 0
@@ -66,6 +66,9 @@ __device__ __forceinline__ float maxOverLaneGroups(float v) {
     return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
+// SPLIT (round 3, the fp32-grade mode): both halves of layer 1 with hi / lo fp16 operand pairs, three MFMAs per product (see
+// linear.hip linear_split_rows_kernel); layer 0 is fp32 MFMA either way.  W1a hi + lo = 72 KB of LDS: one workgroup per CU.
+template <bool SPLIT>
 __global__ void __launch_bounds__(64 * PF_NW)
 pfn_kernel(PfnArgs a)
 {
@@ -74,17 +77,17 @@ pfn_kernel(PfnArgs a)
     // sM holds fp16: it is only ever read as the fp16 B operand of the per-pillar GEMM (rounding at the store = rounding at the read).
     // (52.7 KB of LDS in all; a third resident workgroup per CU was measured: 82 vs 79 us, the group loop is not latency-starved.)
     constexpr int SM_LD = PF_C0 + 8, SU_LD = PF_C1 + 4;
-    __shared__ __attribute__((aligned(16))) _Float16 sM[PF_PB * SM_LD];   // max_pillar(x0) as fp16, 208-byte rows (conflict-free b128 reads)  3.3 KB
+    __shared__ __attribute__((aligned(16))) _Float16 sM[(SPLIT ? 2 : 1) * PF_PB * SM_LD];   // max_pillar(x0) as fp16 (SPLIT: hi rows, then lo rows), 208-byte rows (conflict-free b128 reads)  3.3 KB
     __shared__ __attribute__((aligned(16))) uint32_t sU[PF_PB * SU_LD];   // max_pillar(W1a x0), float bits                 12 KB
     __shared__ uint32_t sStart[PF_PB + 1];
     __shared__ uint32_t sSmall[PF_PB], sLarge[PF_PB], sNum[2];           // pillars of the group with <= 4 points / more, and how many of each
-    __shared__ __attribute__((aligned(16))) _Float16 sW1[3 * 12 * 512];                                                // 36 KB
+    __shared__ __attribute__((aligned(16))) _Float16 sW1[(SPLIT ? 2 : 1) * 3 * 12 * 512];                              // 36 KB (SPLIT: w_hi image, then w_lo image)
     uint32_t P = *a.pillar_num; if (P > (uint32_t)a.max_pillars) P = a.max_pillars;
     const uint32_t ngroups = (P + PF_PB - 1) / PF_PB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
     if (blockIdx.x >= ngroups) return;
     // persistent workgroup: W1a (36 KB) and the layer-0 fragments are loaded once, groups of 16 pillars round-robin
-    for (int i = tid; i < 3 * 12 * 64; i += 64 * PF_NW)
+    for (int i = tid; i < (SPLIT ? 2 : 1) * 3 * 12 * 64; i += 64 * PF_NW)
         *reinterpret_cast<uint4*>(&sW1[i * 8]) = *reinterpret_cast<const uint4*>(a.w1a + (size_t)i * 8);
     // layer-0 weights as MFMA A fragments: lane (r, g) holds W0[16t + r][4ks + g]
     float w0f[6][3], b0f[6][4];
@@ -104,7 +107,7 @@ pfn_kernel(PfnArgs a)
     const uint32_t pb0 = grp * PF_PB;
     const int npil = P - pb0 < (uint32_t)PF_PB ? (int)(P - pb0) : PF_PB;
 
-    for (int i = tid; i < PF_PB * SM_LD; i += 64 * PF_NW) sM[i] = (_Float16)0.f;
+    for (int i = tid; i < (SPLIT ? 2 : 1) * PF_PB * SM_LD; i += 64 * PF_NW) sM[i] = (_Float16)0.f;
     for (int i = tid; i < PF_PB * SU_LD; i += 64 * PF_NW) sU[i] = 0u;
     if (tid <= npil) {
         // first row of pillar pb0 + tid; the sentinel entry is one past the last pillar's rows
@@ -196,20 +199,32 @@ pfn_kernel(PfnArgs a)
 #pragma unroll
         for (int k = 0; k < 12; ++k) mu[k] = -INFINITY;
         if (!(a.dbg & 4)) {
-            half8 f1[3];
+            half8 f1[3], f1l[3];
 #pragma unroll
             for (int s_ = 0; s_ < 3; ++s_) {
-                half8 h;
+                _Float16 h[8], l[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { h[i] = (_Float16)x0[2 * s_][i]; h[4 + i] = (_Float16)x0[2 * s_ + 1][i]; }
-                f1[s_] = h;
+                for (int i = 0; i < 4; ++i) {
+                    const float v0 = x0[2 * s_][i], v1 = x0[2 * s_ + 1][i];
+                    h[i] = (_Float16)fminf(v0, 65504.f); h[4 + i] = (_Float16)fminf(v1, 65504.f);      // (x0 >= 0 after the ReLU)
+                    l[i] = (_Float16)(v0 - (float)h[i]); l[4 + i] = (_Float16)(v1 - (float)h[4 + i]);
+                }
+                f1[s_] = half8{h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]};
+                f1l[s_] = half8{l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7]};
             }
 #pragma unroll
             for (int k = 0; k < 12; ++k) {
                 floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s_ = 0; s_ < 3; ++s_)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1[s_], *reinterpret_cast<const half8*>(&sW1[((s_ * 12 + k) * 64 + lane) * 8]), acc, 0, 0, 0);
+                for (int s_ = 0; s_ < 3; ++s_) {
+                    const half8 wh = *reinterpret_cast<const half8*>(&sW1[((s_ * 12 + k) * 64 + lane) * 8]);
+                    if constexpr (SPLIT) {
+                        const half8 wl = *reinterpret_cast<const half8*>(&sW1[(((3 + s_) * 12 + k) * 64 + lane) * 8]);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1[s_], wl, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1l[s_], wh, acc, 0, 0, 0);
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1[s_], wh, acc, 0, 0, 0);
+                }
                 mu[k] = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
             }
         }
@@ -219,7 +234,12 @@ pfn_kernel(PfnArgs a)
             if (idx < nsmall) {
                 const uint32_t pl_ = sSmall[idx];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) sM[pl_ * SM_LD + 16 * k + r] = (_Float16)fmaxf(m0[k], 0.f);                // max(ReLU(.)) = max(0, max(.))
+                for (int k = 0; k < 6; ++k) {
+                    const float mv = fmaxf(m0[k], 0.f);                                                                   // max(ReLU(.)) = max(0, max(.))
+                    const _Float16 mh = (_Float16)fminf(mv, 65504.f);
+                    sM[pl_ * SM_LD + 16 * k + r] = mh;
+                    if constexpr (SPLIT) sM[(PF_PB + pl_) * SM_LD + 16 * k + r] = (_Float16)(mv - (float)mh);
+                }
 #pragma unroll
                 for (int k = 0; k < 12; ++k) sU[pl_ * SU_LD + 16 * k + r] = __float_as_uint(mu[k]);
             }
@@ -237,7 +257,11 @@ pfn_kernel(PfnArgs a)
                 for (int k = 0; k < 12; ++k) mxu[k] = maxOverLaneGroups(mxu[k]);
                 if (g == 0) {
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) sM[pl_ * SM_LD + 16 * k + r] = (_Float16)mx0[k];
+                    for (int k = 0; k < 6; ++k) {
+                        const _Float16 mh = (_Float16)fminf(mx0[k], 65504.f);
+                        sM[pl_ * SM_LD + 16 * k + r] = mh;
+                        if constexpr (SPLIT) sM[(PF_PB + pl_) * SM_LD + 16 * k + r] = (_Float16)(mx0[k] - (float)mh);
+                    }
 #pragma unroll
                     for (int k = 0; k < 12; ++k) sU[pl_ * SU_LD + 16 * k + r] = __float_as_uint(mxu[k]);
                 }
@@ -253,9 +277,12 @@ pfn_kernel(PfnArgs a)
     __syncthreads();
     mark();
     // ---- per-pillar half: t^T = W1b m^T (16 pillars x 96 -> 192); wave w owns column tiles w, w + 8 ----------------------------
-    half8 mf[3];                                     // B fragment: lane (r, g) holds m[pillar r][32s + 8g + j]
+    half8 mf[3], mfl[3];                             // B fragment: lane (r, g) holds m[pillar r][32s + 8g + j]
 #pragma unroll
-    for (int s = 0; s < 3; ++s) mf[s] = *reinterpret_cast<const half8*>(&sM[r * SM_LD + 32 * s + 8 * g]);
+    for (int s = 0; s < 3; ++s) {
+        mf[s] = *reinterpret_cast<const half8*>(&sM[r * SM_LD + 32 * s + 8 * g]);
+        if constexpr (SPLIT) mfl[s] = *reinterpret_cast<const half8*>(&sM[(PF_PB + r) * SM_LD + 32 * s + 8 * g]);
+    }
     const bool pv = r < npil && !(a.dbg & 8);
 #pragma unroll
     for (int tt = 0; tt < (12 + PF_NW - 1) / PF_NW; ++tt) {
@@ -263,8 +290,15 @@ pfn_kernel(PfnArgs a)
         if (t >= 12) break;
         floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(a.w1b + ((size_t)(s * 12 + t) * 64 + lane) * 8), mf[s], acc, 0, 0, 0);
+        for (int s = 0; s < 3; ++s) {
+            const half8 wh = *reinterpret_cast<const half8*>(a.w1b + ((size_t)(s * 12 + t) * 64 + lane) * 8);
+            if constexpr (SPLIT) {
+                const half8 wl = *reinterpret_cast<const half8*>(a.w1b + ((size_t)((3 + s) * 12 + t) * 64 + lane) * 8);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, mf[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, mfl[s], acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, mf[s], acc, 0, 0, 0);
+        }
         if (pv) {                                    // lane (r, g): pillar r, columns 16t + 4g + i
             const int col = 16 * t + 4 * g;
             const float4 b = *reinterpret_cast<const float4*>(a.b1 + col);
@@ -300,22 +334,26 @@ class DsvtPillarFeatureNetPlugin : public Plugin {
 public:
     int max_pillars_;
     int pack_ = 1;                                                  // pillars with <= 4 points share MFMA tiles (0: the round-1 one-pillar-per-tile layout)
+    int split_ = 0;                                                 // optional field "split_precision": layer 1 on hi / lo fp16 operand pairs (fp32 grade), fp32 output only
     std::vector<float> w0_, b0_, w1_, b1_;
     float *w0_dev_ = nullptr, *b0_dev_ = nullptr, *b1_dev_ = nullptr; _Float16 *w1a_dev_ = nullptr, *w1b_dev_ = nullptr;
     bool ok_ = false;
-    DsvtPillarFeatureNetPlugin(int mp, const float* w0, const float* b0, const float* w1, const float* b1)
-        : max_pillars_(mp), w0_(w0, w0 + PF_C0 * PF_IN), b0_(b0, b0 + PF_C0), w1_(w1, w1 + (size_t)PF_C1 * PF_C1), b1_(b1, b1 + PF_C1) {
+    DsvtPillarFeatureNetPlugin(int mp, const float* w0, const float* b0, const float* w1, const float* b1, int split = 0)
+        : max_pillars_(mp), split_(split), w0_(w0, w0 + PF_C0 * PF_IN), b0_(b0, b0 + PF_C0), w1_(w1, w1 + (size_t)PF_C1 * PF_C1), b1_(b1, b1 + PF_C1) {
         std::vector<float> w0p((size_t)PF_C0 * 12, 0.f);
         for (int n = 0; n < PF_C0; ++n) for (int k = 0; k < PF_IN; ++k) w0p[n * 12 + k] = w0_[n * PF_IN + k];
-        std::vector<_Float16> wa((size_t)3 * 12 * 512), wb((size_t)3 * 12 * 512);
+        const size_t img = (size_t)3 * 12 * 512;
+        std::vector<_Float16> wa((split_ ? 2 : 1) * img), wb((split_ ? 2 : 1) * img);
         for (int s = 0; s < 3; ++s)
             for (int t = 0; t < 12; ++t)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
                         const size_t d = (((size_t)s * 12 + t) * 64 + lane) * 8 + j;
                         const int n = 16 * t + (lane & 15), p = 32 * s + 8 * (lane >> 4) + j;
-                        wa[d] = (_Float16)w1_[(size_t)n * PF_C1 + pfnPermuteK(p)];           // x0 half, chained (k-permuted) operand
-                        wb[d] = (_Float16)w1_[(size_t)n * PF_C1 + PF_C0 + p];                // max half, natural k
+                        const float va = w1_[(size_t)n * PF_C1 + pfnPermuteK(p)], vb = w1_[(size_t)n * PF_C1 + PF_C0 + p];
+                        wa[d] = (_Float16)va;                                                // x0 half, chained (k-permuted) operand
+                        wb[d] = (_Float16)vb;                                                // max half, natural k
+                        if (split_) { wa[img + d] = (_Float16)(va - (float)wa[d]); wb[img + d] = (_Float16)(vb - (float)wb[d]); }
                     }
         auto upF = [](const std::vector<float>& h, float** d) {
             return hipMalloc(d, sizeof(float) * h.size()) == hipSuccess && hipMemcpy(*d, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice) == hipSuccess;
@@ -329,9 +367,9 @@ public:
         for (void* p : {(void*)w0_dev_, (void*)b0_dev_, (void*)b1_dev_, (void*)w1a_dev_, (void*)w1b_dev_}) if (p) (void)hipFree(p);
     }
     const char* type() const override { return "DsvtPillarFeatureNetPlugin"; }
-    int nbOutputs() const override { return 2; }
+    int nbOutputs() const override { return split_ ? 1 : 2; }
     int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
-        if (i < 0 || i > 1) return -1;
+        if (i < 0 || i >= nbOutputs()) return -1;
         *out = dims3(in[0].d[0], max_pillars_, PF_C1); return 0;
     }
     int outputType(int i, const int32_t*, int) const override { return i == 0 ? DSVT_FLOAT : DSVT_HALF; }
@@ -347,35 +385,37 @@ public:
         if (!ok_) return static_cast<int>(hipErrorOutOfMemory);
         PfnArgs a{};
         static unsigned long long* tr = nullptr; static int tron = -1;
-        if (tron < 0) { tron = getenv("DSVT_PFN_TRACE") ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 64); }
+        if (tron < 0) { tron = ablateEnv("DSVT_PFN_TRACE", 0) ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 64); }
         a.trace = tr;
-        static int dbg = -1; if (dbg < 0) { const char* e = getenv("DSVT_PFN_DBG"); dbg = e ? atoi(e) : 0; }
+        static int dbg = -1; if (dbg < 0) dbg = ablateEnv("DSVT_PFN_DBG", 0);
         a.dbg = dbg;
         a.feat = static_cast<const float*>(in[0]); a.pidx = static_cast<const uint32_t*>(in[1]);
         a.T = inDesc ? inDesc[1].dims.d[inDesc[1].dims.nbDims - 1] : 48;
         a.pcnt = static_cast<const uint32_t*>(in[2]); a.pillar_num = static_cast<const uint32_t*>(in[3]); a.max_pillars = max_pillars_;
         a.w0 = w0_dev_; a.b0 = b0_dev_; a.w1a = w1a_dev_; a.w1b = w1b_dev_; a.b1 = b1_dev_;
-        a.out = static_cast<float*>(out[0]); a.out16 = static_cast<_Float16*>(out[1]);
+        a.out = static_cast<float*>(out[0]); a.out16 = split_ ? nullptr : static_cast<_Float16*>(out[1]);
         a.pack = pack_;
         if (zeroFill) {
             DSVT_CHECK(hipMemsetAsync(out[0], 0, sizeof(float) * (size_t)max_pillars_ * PF_C1, stream));
-            DSVT_CHECK(hipMemsetAsync(out[1], 0, sizeof(_Float16) * (size_t)max_pillars_ * PF_C1, stream));
+            if (!split_) DSVT_CHECK(hipMemsetAsync(out[1], 0, sizeof(_Float16) * (size_t)max_pillars_ * PF_C1, stream));
         }
-        int grid = 2 * pfnCUs(); if (grid > cdiv(max_pillars_, PF_PB)) grid = cdiv(max_pillars_, PF_PB);       // two resident workgroups per CU (three: 82 vs 79 us)
-        hipLaunchKernelGGL(pfn_kernel, dim3(grid), dim3(64 * PF_NW), 0, stream, a);
+        int grid = (split_ ? 1 : 2) * pfnCUs(); if (grid > cdiv(max_pillars_, PF_PB)) grid = cdiv(max_pillars_, PF_PB);       // two resident workgroups per CU (three: 82 vs 79 us); split: 92 KB of LDS, one
+        if (split_) hipLaunchKernelGGL(pfn_kernel<true>, dim3(grid), dim3(64 * PF_NW), 0, stream, a);
+        else hipLaunchKernelGGL(pfn_kernel<false>, dim3(grid), dim3(64 * PF_NW), 0, stream, a);
         if (tron) { (void)hipStreamSynchronize(stream); fprintf(stderr, "[pfn trace wg0]"); for (int i = 1; i < 24; ++i) fprintf(stderr, " %lld", (long long)(tr[i] - tr[0])); fprintf(stderr, "\n"); }
         return lastError();
     }
     size_t nFloats() const { return w0_.size() + b0_.size() + w1_.size() + b1_.size(); }
-    size_t serializationSize() const override { return 2 * sizeof(int) + sizeof(float) * nFloats(); }
+    size_t serializationSize() const override { return (split_ ? 3 : 2) * sizeof(int) + sizeof(float) * nFloats(); }
     void serialize(void* buf) const override {
         char* d = static_cast<char*>(buf);
         wr<int>(d, max_pillars_);
         for (const std::vector<float>* v : {&w0_, &b0_, &w1_, &b1_}) { memcpy(d, v->data(), sizeof(float) * v->size()); d += sizeof(float) * v->size(); }
         wr<int>(d, pack_);
+        if (split_) wr<int>(d, split_);
     }
     Plugin* clone() const override {
-        DsvtPillarFeatureNetPlugin* c = new DsvtPillarFeatureNetPlugin(max_pillars_, w0_.data(), b0_.data(), w1_.data(), b1_.data());
+        DsvtPillarFeatureNetPlugin* c = new DsvtPillarFeatureNetPlugin(max_pillars_, w0_.data(), b0_.data(), w1_.data(), b1_.data(), split_);
         c->pack_ = pack_; return c;
     }
 };
@@ -389,7 +429,7 @@ static Plugin* pfnCreate(const DsvtPluginFieldCollection* fc) {
         p[i] = static_cast<const float*>(f->data);
     }
     if (mp <= 0) return nullptr;
-    DsvtPillarFeatureNetPlugin* pl = new DsvtPillarFeatureNetPlugin(mp, p[0], p[1], p[2], p[3]);
+    DsvtPillarFeatureNetPlugin* pl = new DsvtPillarFeatureNetPlugin(mp, p[0], p[1], p[2], p[3], fieldInt(fc, "split_precision", 0) != 0);
     pl->pack_ = fieldInt(fc, "pack_small_pillars", 1) != 0;
     return pl;
 }
@@ -401,13 +441,15 @@ static Plugin* pfnDeser(const void* data, size_t len) {
     if (mp <= 0 || len < sizeof(int) + n * sizeof(float)) return nullptr;
     std::vector<float> all(n); memcpy(all.data(), d, n * sizeof(float));
     const float* q = all.data();
-    DsvtPillarFeatureNetPlugin* pl = new DsvtPillarFeatureNetPlugin(mp, q, q + PF_C0 * PF_IN, q + PF_C0 * PF_IN + PF_C0, q + PF_C0 * PF_IN + PF_C0 + (size_t)PF_C1 * PF_C1);
-    if (len >= 2 * sizeof(int) + n * sizeof(float)) { const char* t = d + n * sizeof(float); pl->pack_ = rd<int>(t) != 0; }
+    int pack = 1, split = 0;
+    if (len >= 2 * sizeof(int) + n * sizeof(float)) { const char* t = d + n * sizeof(float); pack = rd<int>(t) != 0; if (len >= 3 * sizeof(int) + n * sizeof(float)) split = rd<int>(t) != 0; }
+    DsvtPillarFeatureNetPlugin* pl = new DsvtPillarFeatureNetPlugin(mp, q, q + PF_C0 * PF_IN, q + PF_C0 * PF_IN + PF_C0, q + PF_C0 * PF_IN + PF_C0 + (size_t)PF_C1 * PF_C1, split);
+    pl->pack_ = pack;
     return pl;
 }
 static Creator g_pfnCreator{"DsvtPillarFeatureNetPlugin",
     {{"max_pillars_num", DSVT_FIELD_INT32}, {"weight0", DSVT_FIELD_FLOAT32}, {"bias0", DSVT_FIELD_FLOAT32}, {"weight1", DSVT_FIELD_FLOAT32},
-     {"bias1", DSVT_FIELD_FLOAT32}, {"pack_small_pillars", DSVT_FIELD_INT32}},
+     {"bias1", DSVT_FIELD_FLOAT32}, {"pack_small_pillars", DSVT_FIELD_INT32}, {"split_precision", DSVT_FIELD_INT32}},
     pfnCreate, pfnDeser, {}, {}};
 static Registrar g_pfnReg(&g_pfnCreator);
 

@@ -420,19 +420,45 @@ map2bev_kernel(const float4* __restrict__ feat, const uint4* __restrict__ coords
         bev[(((size_t)co.x * gy + co.z) * gx + co.w) * G + c] = feat[i];             // :264
     }
 }
+// split precision (round 3): fp32 rows in, fp16 [hi | lo | hi] planes out (3 C channels per cell: the operand layout of the fp32-grade
+// convolutions, see conv.hip ConvArgs::split_out)
+typedef _Float16 mb_half4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256)
+map2bev_split_kernel(const float4* __restrict__ feat, const uint4* __restrict__ coords, const uint32_t* __restrict__ voxel_num,
+                     int G, int gx, int gy, int frames, mb_half4* __restrict__ bev)
+{
+    size_t total = (size_t)(*voxel_num) * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t p = i / G; int c = (int)(i % G);
+        uint4 co = coords[p];
+        if (co.x >= (uint32_t)frames) continue;
+        const float4 v = feat[i];
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        mb_half4 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            hi[k] = (_Float16)fminf(fmaxf(f[k], -65504.f), 65504.f);
+            lo[k] = (_Float16)fminf(fmaxf(f[k] - (float)hi[k], -65504.f), 65504.f);
+        }
+        mb_half4* o = bev + (((size_t)co.x * gy + co.z) * gx + co.w) * 3 * G + c;
+        o[0] = hi; o[G] = lo; o[2 * G] = hi;
+    }
+}
 class Map2BevPlugin : public Plugin {
 public:
     int max_pillars_num_, channel_num_, gx_, gy_, frames_ = 1;      // frames_ > 1 (field "frames"): coords.x selects one of `frames` stacked BEV maps
-    Map2BevPlugin(int mp, int c, int gx, int gy, int frames = 1) : max_pillars_num_(mp), channel_num_(c), gx_(gx), gy_(gy), frames_(frames) {}
+    int split_ = 0;                                                 // field "split_output": fp32 rows -> fp16 [hi | lo | hi] planes, 3 C channels per cell
+    Map2BevPlugin(int mp, int c, int gx, int gy, int frames = 1, int split = 0) : max_pillars_num_(mp), channel_num_(c), gx_(gx), gy_(gy), frames_(frames), split_(split) {}
     const char* type() const override { return "Map2BevPlugin"; }
     int nbOutputs() const override { return 1; }
     int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
         if (i != 0) return -1;
-        *out = dims4(frames_ > 1 ? frames_ : in[0].d[0], gx_, gy_, channel_num_); return 0;      // map2bev.cu: [1, gx, gy, C] (used as [y][x][C])
+        *out = dims4(frames_ > 1 ? frames_ : in[0].d[0], gx_, gy_, (split_ ? 3 : 1) * channel_num_); return 0;      // map2bev.cu: [1, gx, gy, C] (used as [y][x][C])
     }
-    int outputType(int, const int32_t* t, int) const override { return t[0]; }
+    int outputType(int, const int32_t* t, int) const override { return split_ ? DSVT_HALF : t[0]; }
     bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int, int) const override {
         if (pos == 1 || pos == 2) return i32Linear(io[pos]);
+        if (split_) return (pos == 0 || pos == 3) && io[pos].format == DSVT_FORMAT_LINEAR && io[pos].type == (pos == 0 ? DSVT_FLOAT : DSVT_HALF);
         // fp32 like the reference, or fp16 rows (pure 16-byte moves either way)
         return (pos == 0 || pos == 3) && io[pos].format == DSVT_FORMAT_LINEAR && (io[pos].type == DSVT_FLOAT || io[pos].type == DSVT_HALF)
                && io[pos].type == io[0].type;
@@ -440,6 +466,13 @@ public:
     size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override { return 0; }
     int enqueue(const DsvtPluginTensorDesc* inDesc, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void*,
                 hipStream_t stream) override {
+        if (split_) {
+            DSVT_CHECK(hipMemsetAsync(out[0], 0, (size_t)2 * gx_ * gy_ * 3 * channel_num_ * frames_, stream));
+            hipLaunchKernelGGL(map2bev_split_kernel, dim3(2048), dim3(256), 0, stream, static_cast<const float4*>(in[0]),
+                               static_cast<const uint4*>(in[1]), static_cast<const uint32_t*>(in[2]), channel_num_ / 4, gx_, gy_, frames_,
+                               static_cast<mb_half4*>(out[0]));
+            return lastError();
+        }
         const int esz = (inDesc && inDesc[0].type == DSVT_HALF) ? 2 : 4;
         if ((channel_num_ * esz) % 16 != 0) return -3;
         // the dense map must be zero wherever no pillar lands, so this fill is not optional (:303)
@@ -449,23 +482,26 @@ public:
                            static_cast<float4*>(out[0]));
         return lastError();
     }
-    size_t serializationSize() const override { return (frames_ > 1 ? 5 : 4) * sizeof(int); }
+    size_t serializationSize() const override { return (split_ ? 6 : frames_ > 1 ? 5 : 4) * sizeof(int); }
     void serialize(void* b) const override {
         char* d = static_cast<char*>(b); wr<int>(d, max_pillars_num_); wr<int>(d, channel_num_); wr<int>(d, gx_); wr<int>(d, gy_);
-        if (frames_ > 1) wr<int>(d, frames_);
+        if (frames_ > 1 || split_) wr<int>(d, frames_);
+        if (split_) wr<int>(d, split_);
     }
-    Plugin* clone() const override { return new Map2BevPlugin(max_pillars_num_, channel_num_, gx_, gy_, frames_); }
+    Plugin* clone() const override { return new Map2BevPlugin(max_pillars_num_, channel_num_, gx_, gy_, frames_, split_); }
 };
-static Plugin* mbNew(int mp, int c, int gx, int gy, int frames = 1) {
-    return (mp > 0 && c > 0 && c % 4 == 0 && gx > 0 && gy > 0 && frames >= 1) ? new Map2BevPlugin(mp, c, gx, gy, frames) : nullptr;
+static Plugin* mbNew(int mp, int c, int gx, int gy, int frames = 1, int split = 0) {
+    return (mp > 0 && c > 0 && c % 4 == 0 && gx > 0 && gy > 0 && frames >= 1) ? new Map2BevPlugin(mp, c, gx, gy, frames, split != 0) : nullptr;
 }
 static Plugin* mbCreate(const DsvtPluginFieldCollection* fc) {
-    return mbNew(fieldInt(fc, "max_pillars_num"), fieldInt(fc, "channel_num"), fieldInt(fc, "grid_size_x"), fieldInt(fc, "grid_size_y"), fieldInt(fc, "frames", 1));
+    return mbNew(fieldInt(fc, "max_pillars_num"), fieldInt(fc, "channel_num"), fieldInt(fc, "grid_size_x"), fieldInt(fc, "grid_size_y"), fieldInt(fc, "frames", 1),
+                 fieldInt(fc, "split_output", 0));
 }
 static Plugin* mbDeser(const void* data, size_t len) {
     if (len < 4 * sizeof(int)) return nullptr;
     const char* d = static_cast<const char*>(data); int mp = rd<int>(d), c = rd<int>(d), gx = rd<int>(d), gy = rd<int>(d);
-    return mbNew(mp, c, gx, gy, len >= 5 * sizeof(int) ? rd<int>(d) : 1);
+    const int frames = len >= 5 * sizeof(int) ? rd<int>(d) : 1, split = len >= 6 * sizeof(int) ? rd<int>(d) : 0;
+    return mbNew(mp, c, gx, gy, frames, split);
 }
 static Creator g_mbCreator{"Map2BevPlugin",
     {{"max_pillars_num", DSVT_FIELD_INT32}, {"channel_num", DSVT_FIELD_INT32}, {"grid_size_x", DSVT_FIELD_INT32}, {"grid_size_y", DSVT_FIELD_INT32}},

@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -47,6 +48,8 @@ public:
     // true: enqueue() itself processes a leading batch dimension > 1 (one launch for all images); false (default): the C ABI layer runs
     // the per-frame slabs one after the other (c_api.hip)
     virtual bool handlesBatch() const { return false; }
+    // input `index` is shared by all frames of a batch even if its leading dimension equals the batch size (a table, not a per-frame stack)
+    virtual bool sharedInput(int /*index*/) const { return false; }
     bool zeroFill = true;
     std::string layerName;
 };
@@ -120,5 +123,14 @@ inline int lastError() { hipError_t e = hipGetLastError(); return e == hipSucces
 #define DSVT_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return static_cast<int>(_e); } while (0)
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Ablation / trace / A-B switches.  The product library (libdsvt_hip.so) reads NO environment variable: ablateEnv() is the constant
+// default there, so no load, store or MFMA of a timed kernel can be skipped from outside.  `python dsvt-ai-trt_amd/build.py --ablate`
+// builds libdsvt_hip_ablate.so with -DDSVT_ABLATE for tools/ (trace_*.py, ablate_conv.sh, one_attn.py ...), where the switch is read.
+#ifdef DSVT_ABLATE
+inline int ablateEnv(const char* name, int def) { const char* e = getenv(name); return e ? atoi(e) : def; }
+#else
+inline int ablateEnv(const char*, int def) { return def; }
+#endif
 
 }  // namespace dsvt

@@ -32,7 +32,8 @@ class Detector:
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.stream = torch.cuda.Stream(self.device)
-        kw = dict(linear_compute=P.COMPUTE_F16, head_dtype=torch.float16) if fp16 else {}
+        # fp16: BASELINE configs[2]; otherwise the reference's own precision -- fp32 arithmetic -- on split-precision fp16 MFMA
+        kw = dict(linear_compute=P.COMPUTE_F16, head_dtype=torch.float16) if fp16 else dict(linear_compute=P.COMPUTE_SPLIT)
         with torch.cuda.stream(self.stream):
             self.pipe = DsvtPipeline(weights, caps=self.caps, device=device, device_nms=True, **kw)
             self.up = hostio.FrameUploader(self.caps.N, device=device, depth=1)

@@ -176,6 +176,8 @@ struct Op {
             }
             outd.push_back({outs.back().dims, outs.back().type, DSVT_FORMAT_LINEAR, 1.0f});
         }
+        // configurePlugin(in, nbInputs, out, nbOutputs): the reference's engine build calls it once the shapes are known (points2Features.cu:257-260)
+        if (dsvtPluginConfigurePlugin(h, ind.data(), (int)ind.size(), outd.data(), (int)outd.size()) != 0) die(type + ": configurePlugin");
         const size_t wsz = dsvtPluginGetWorkspaceSize(h, ind.data(), (int)ind.size(), outd.data(), (int)outd.size());
         HIP_OK(hipMalloc(&ws, std::max<size_t>(wsz, 256)));
         built = true;

@@ -20,11 +20,12 @@ def env_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def init(backend=None, single_rank_group=False):
+def init(backend=None, single_rank_group=False, device_index=None):
     """Join the job described by RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  No-op for a
     single process unless single_rank_group: then a communicator of size 1 is created so that the
     result gather really goes through the collective library (RCCL on a GPU box) -- how the
-    collective is exercised when only one GPU is visible."""
+    collective is exercised when only one GPU is visible.  device_index: the GPU of this
+    rank when it is not LOCAL_RANK (bench.py --share-gpu: several ranks on one device, a dry run)."""
     rank, local_rank, world = env_world()
     if (world > 1 or single_rank_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -33,7 +34,7 @@ def init(backend=None, single_rank_group=False):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_rank if device_index is None else device_index)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 

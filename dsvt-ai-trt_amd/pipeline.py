@@ -10,18 +10,23 @@ src/dsvt-ai-trt.cpp:532-1762) on the HIP plugins of libdsvt_hip.so.
         s1   = LN1(attn Wo + bo + x)                   [DsvtLinear epilogue]
         h    = GELU(s1 W1 + b1)                        [DsvtLinear epilogue]
         x'   = LN3(LN2(s1 + h W2 + b2) + x) (+ block residual LN)   [DsvtLinear epilogue]
-    Map2Bev -> BEV ResNet + CenterHead + top-K decode   (dense glue: PyTorch-ROCm / MIOpen,
-                                                         SURVEY section 8f "next")
-    FilterBoxByScore -> boxes[1,500,9], count[1]                            (:1684-1736)
+    Map2Bev -> BEV ResNet + CenterHead (DsvtConv2dPlugin, csrc/conv.hip) -> top-K decode (CenterHeadTopKPlugin)   (:1128-1669)
+    FilterBoxByScore -> boxes[1,500,9], count[1] (-> RotatedNmsPlugin)     (:1684-1736)
 
 Device-side counts (P, Nk, W, S, box count) never visit the host; every op is enqueued on the
 current stream, so a whole frame can be captured in a HIP graph.  The product path has no CPU
-fallback: every stage above the dense glue is a HIP kernel behind the C ABI.
+fallback and no vendor-library stage: every stage is a hand-written HIP kernel behind the C ABI (the PyTorch / MIOpen
+restatement of the dense stage that round 1 ran lives in tools/vendor_dense.py, for error attribution only).
+
+Three precision modes (DsvtPipeline(linear_compute=, head_dtype=)):
+    COMPUTE_F16    fp16 MFMA operands, fp32 accumulate / LayerNorm / softmax / decode    BASELINE configs[2] "fp16"; boxes 2e-3 .. 4e-3
+    COMPUTE_SPLIT  (hi, lo) fp16 operand pairs, three MFMAs per product, fp32 tensors     the reference's fp32 arithmetic at matrix-core
+                   speed; boxes 1e-5-class: the mode that meets north_star's 1e-3 bar at > 200 frames/s (`parity_mode` in bench.py)
+    COMPUTE_F32    v_mfma_f32_16x16x4_f32, unfused reference wiring                         the slow exact cross-check
 """
 import math
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import plugin as P
 
@@ -91,13 +96,12 @@ def fold_linear_bn(w, lin, bn, eps, bias=False):
 
 class DsvtPipeline:
     def __init__(self, weights, caps=None, blocks=4, with_head=True, ln_eps=0.0, head_dtype=torch.float32,
-                 device="cuda:0", zero_fill=False, linear_compute=P.COMPUTE_F32, hip_head=None, fused_mlp=None,
+                 device="cuda:0", zero_fill=False, linear_compute=P.COMPUTE_F32, fused_mlp=None,
                  device_nms=False, pos_table=None, fork_partition=None, frames=1):
         """linear_compute: COMPUTE_F32 = fp32 MFMA everywhere (parity mode, boxes within 1e-3 of the
         fp32 oracle); COMPUTE_F16 = fp16 MFMA operands with fp32 accumulate/epilogues (BASELINE
-        configs[2] "fp16").  head_dtype: precision of the dense BEV stage.  hip_head: run the BEV ResNet +
-        CenterHead on DsvtConv2dPlugin (csrc/conv.hip, fp16) instead of PyTorch/MIOpen; default: on in fp16
-        mode.  device_nms: append RotatedNmsPlugin (the reference's host nms_cpu, include/helper.h:257-283) so that
+        configs[2] "fp16"); COMPUTE_SPLIT = split-precision fp16 MFMA (fp32 grade, fused frame path).  head_dtype: precision of the
+        dense BEV stage on DsvtConv2dPlugin (csrc/conv.hip): torch.float16, or torch.float32 = split-precision operands.  device_nms: append RotatedNmsPlugin (the reference's host nms_cpu, include/helper.h:257-283) so that
         forward() returns the final boxes instead of FilterBoxByScore's rows."""
         """frames > 1 (fp16 fused path only): SEVERAL frames per forward() with their pillar rows concatenated -- one launch per backbone layer for
         all of them (rows = sum of the frames' pillars), one stacked BEV map per frame, the per-frame dense stage / decode / NMS through the C
@@ -105,8 +109,11 @@ class DsvtPipeline:
         per-frame point capacity; the pillar / kept-point / window / set capacities are totals over the frames."""
         self.caps = c = caps or Caps()
         self.frames = int(frames)
-        if self.frames > 1 and not (linear_compute == P.COMPUTE_F16 and (pos_table is None or pos_table) and (fused_mlp is None or fused_mlp)):
-            raise ValueError("frames > 1 needs the fused fp16 path (table position embeddings, fused set partition)")
+        self.split = split = linear_compute == P.COMPUTE_SPLIT
+        if self.frames > 1 and not (linear_compute in (P.COMPUTE_F16, P.COMPUTE_SPLIT) and (pos_table is None or pos_table) and (fused_mlp is None or fused_mlp)):
+            raise ValueError("frames > 1 needs a fused path (fp16 or split precision: table position embeddings, fused set partition)")
+        if split and not ((pos_table is None or pos_table) and (fused_mlp is None or fused_mlp)):
+            raise ValueError("the split-precision mode has only the fused path")
         self.blocks, self.with_head, self.device = blocks, with_head, torch.device(device)
         # fork_partition: WindowPartition / GetSet (12 tiny launches that only need the pillar coordinates) run on a side stream
         # while the pillar feature net runs on the frame's stream; inside a HIP-graph capture this becomes two parallel branches.
@@ -117,12 +124,13 @@ class DsvtPipeline:
         self.head_dtype = head_dtype
         w = weights
         zf = lambda op: op.set_zero_fill(zero_fill)
-        ct = dict(compute_type=linear_compute)
+        ct = dict(compute_type=P.COMPUTE_F32 if split else linear_compute)      # (the unfused ops of the split mode's construction-time tables: exact fp32)
         self.f16 = f16 = linear_compute == P.COMPUTE_F16
+        fast = f16 or split             # the fused frame path (one launch per stage); split = the same wiring on fp32 tensors with (hi, lo) fp16 operand pairs
         # fp16 mode: the position embedding of a voxel depends only on its cell inside the window (144 / 576 cells), so each layer's
         # embedding is a TABLE computed once at construction; the QKV linear adds table row y * wx + x in its A prologue
-        self.pos_table = f16 if pos_table is None else (pos_table and f16)
-        self.fused_mlp = f16 if fused_mlp is None else (fused_mlp and f16)      # out-proj -> FC1 -> FC2 in one launch (csrc/mlp.hip)
+        self.pos_table = fast if pos_table is None else (pos_table and fast)
+        self.fused_mlp = fast if fused_mlp is None else (fused_mlp and fast)    # out-proj -> FC1 -> FC2 in one launch (csrc/mlp.hip)
         # fp16 mode: GEMM operands travel as fp16 (x16, pos16, qkv, att, h); the residual stream that feeds the
         # LayerNorms stays fp32 (the LayerNorm epilogues write both copies)
         h_in = dict(input_half=True) if f16 else {}
@@ -137,16 +145,16 @@ class DsvtPipeline:
         self.pfn1 = zf(P.add_linear_op(W1, b1, c.Nk, activation=P.ACT_RELU, **ct))
         self.pfn0.rows_kind = self.pfn1.rows_kind = "Nk"      # rows = kept points, not pillars (bench flop count)
         # fp16 mode: the whole voxel feature encoder in one launch, no per-point activation in memory (csrc/pfn.hip)
-        self.fused_pfn = f16
+        self.fused_pfn = fast
         if self.fused_pfn:
-            self.pfn = zf(P.add_pillar_feature_net_op(c.P, W0, b0, W1, b1))
+            self.pfn = zf(P.add_pillar_feature_net_op(c.P, W0, b0, W1, b1, split_precision=split))
         self.smax0 = zf(P.add_torch_scatter_max(c.Nk, c.P, 96))
         self.smax1 = zf(P.add_torch_scatter_max(c.Nk, c.P, 192))
         self.wp = [zf(P.add_window_partition(c.W, c.Vw, GX, GY, GZ, *win, *shift)) for win, shift in WINS]
         self.gs = [zf(P.add_get_set_op(c.W, c.Vw, L_SET, *win, max_set_num=c.S)) for win, _ in WINS]
         # fp16 frame: both window configurations' WindowPartition + GetSet in four launches; only the tensors the fused ops consume
         # (window coordinates, set indices / masks / counts) are produced
-        self.fused_partition = f16 and (pos_table is None or pos_table) and (fused_mlp is None or fused_mlp)
+        self.fused_partition = fast and (pos_table is None or pos_table) and (fused_mlp is None or fused_mlp)
         if self.fused_partition:
             self.part = zf(P.add_set_partition_op(c.W, c.Vw, L_SET, c.S, c.P, (GX, GY, GZ), WINS, frames=self.frames))
         self.pe, self.layers, self.res_ln = {}, {}, {}
@@ -155,7 +163,9 @@ class DsvtPipeline:
             for l in range(2):
                 pre = f"module.backbone_3d.input_layer.posembed_layers.0.{b}.{l}.position_embedding_head"
                 Wa, ba = fold_linear_bn(w, pre + ".0", pre + ".1", 1e-5, bias=True)                 # :461-492
-                if f16:      # both FCs of the MLP in one launch: the K_in = 2 one runs in the A prologue
+                if split:    # (tables only, built below)
+                    self.pe[(b, l)] = (None, None)
+                elif f16:    # both FCs of the MLP in one launch: the K_in = 2 one runs in the A prologue
                     self.pe[(b, l)] = (None, zf(P.add_linear_op(w[pre + ".3.weight"], w[pre + ".3.bias"], c.P, **ct, **o16,
                                                                  pe_weight=Wa, pe_bias=ba)))
                 else:
@@ -171,14 +181,15 @@ class DsvtPipeline:
                     lns2.append((w[f"module.backbone_3d.residual_norm_stage_0.{b}.weight"],
                                  w[f"module.backbone_3d.residual_norm_stage_0.{b}.bias"]))
                 if self.fused_mlp:
+                    qkv_kw = dict(compute_type=P.COMPUTE_SPLIT) if split else dict(**ct, **h_in, **o16)
                     self.layers[(b, l)] = L_ = dict(
-                        qkv=zf(P.add_linear_op(wi, bi, c.P, add_cols=2 * C, **ct, **h_in, **o16,
+                        qkv=zf(P.add_linear_op(wi, bi, c.P, add_cols=2 * C, **qkv_kw,
                                                add_gather_width=WINS[l][0][0] if self.pos_table else 0)),
                         attn=zf(P.add_set_attention_op(c.S, L_SET, C, H, l, c.P, io_half=f16)),
                         mlp=zf(P.add_encoder_mlp_op(w[lp + ".win_attn.self_attn.out_proj.weight"], w[lp + ".win_attn.self_attn.out_proj.bias"],
                                                     w[lp + ".win_attn.linear1.weight"], w[lp + ".win_attn.linear1.bias"],
                                                     w[lp + ".win_attn.linear2.weight"], w[lp + ".win_attn.linear2.bias"],
-                                                    [ln(".win_attn.norm1")] + lns2, c.P, ln_eps=ln_eps, frames=self.frames)))
+                                                    [ln(".win_attn.norm1")] + lns2, c.P, ln_eps=ln_eps, frames=self.frames, split_precision=split)))
                     L_["attn"].win = b % 2
                     continue
                 self.layers[(b, l)] = dict(
@@ -219,60 +230,36 @@ class DsvtPipeline:
                 torch.cuda.synchronize(self.device)
                 self.pos_tables = {k: outs[i].clone() for i, k in enumerate(keys)}
                 self.pe_all = None
-        self.cat = torch.zeros((1, c.Nk, 192), dtype=torch.float32, device=self.device)
+        if split:
+            # split mode: the same per-layer cell tables in fp32, from the exact-fp32 linears (construction time only)
+            ncell = max(w_[0][0] * w_[0][1] for w_ in WINS)
+            cnt = torch.tensor([ncell], dtype=torch.int32, device=self.device)
+            self.pos_tables = {}
+            for b in range(blocks):
+                for l in range(2):
+                    pre = f"module.backbone_3d.input_layer.posembed_layers.0.{b}.{l}.position_embedding_head"
+                    Wa, ba = fold_linear_bn(w, pre + ".0", pre + ".1", 1e-5, bias=True)
+                    (wx, wy, _), _s = WINS[l]
+                    g = torch.zeros((1, ncell, 2), dtype=torch.float32)
+                    yy, xx = torch.meshgrid(torch.arange(wy), torch.arange(wx), indexing="ij")
+                    g[0, :wx * wy, 0] = xx.reshape(-1).float() - wx / 2
+                    g[0, :wx * wy, 1] = yy.reshape(-1).float() - wy / 2
+                    h1 = P.add_linear_op(Wa, ba, ncell, activation=P.ACT_RELU)(g.to(self.device), cnt)[0]
+                    self.pos_tables[(b, l)] = P.add_linear_op(w[pre + ".3.weight"], w[pre + ".3.bias"], ncell)(h1, cnt)[0].clone()
+            torch.cuda.synchronize(self.device)
+        if not fast:
+            self.cat = torch.zeros((1, c.Nk, 192), dtype=torch.float32, device=self.device)
         if with_head:
-            self.map2bev = P.add_map_2_bev_op(c.P, C, GX, GY, frames=self.frames)
+            self.split_head = head_dtype == torch.float32
+            self.map2bev = P.add_map_2_bev_op(c.P, C, GX, GY, frames=self.frames, split_output=self.split_head)
             self.filter = P.add_filter_box_by_score_op(TOP_K, X_MIN, X_MAX, Y_MIN, Y_MAX, Z_MIN, Z_MAX, VX, VY, VZ, SCORE_THR)
             self.nms = P.add_rotated_nms_op(TOP_K, NMS_THRESH) if device_nms else None
-            self.hip_head = (head_dtype == torch.float16 and linear_compute == P.COMPUTE_F16) if hip_head is None else hip_head
-            # fp32 head: the same HIP convolution at fp32 grade (split-precision operands, 3x the MFMA work) unless hip_head=False asks for
-            # the PyTorch / MIOpen fp32 convolutions (kept as a cross-check, tests/test_conv_gpu.py)
-            self.split_head = head_dtype == torch.float32 and (hip_head is None or hip_head)
+            self.hip_head = not self.split_head
+            # fp32 head: the same HIP convolution at fp32 grade (split-precision operands, 3x the MFMA work)
             if self.split_head:
-                self.hip_head = False
                 self._build_hip_head_split(w)
-            elif self.hip_head:
-                self._build_hip_head(w)
             else:
-                self._build_dense(w)
-
-    # ---- dense glue: BN folded into the convolutions, channels-last ----------
-    def _conv_params(self, w, conv, bn):
-        s, sh = bn_fold(w, bn, 1e-3)                                                               # :191,208,239
-        W = torch.from_numpy(w[conv + ".weight"] * s[:, None, None, None])
-        return (W.to(self.device, self.head_dtype).contiguous(memory_format=torch.channels_last),
-                torch.from_numpy(sh).to(self.device, self.head_dtype))
-
-    def _build_dense(self, w):
-        d = self.dense = {}
-        for (i, nb) in ((0, 2), (1, 3), (2, 3)):
-            for j in range(nb):
-                p = f"module.backbone_2d.blocks.{i}.{j}"
-                d[p + ".1"] = self._conv_params(w, p + ".conv1", p + ".bn1")
-                d[p + ".2"] = self._conv_params(w, p + ".conv2", p + ".bn2")
-                if j == 0:
-                    d[p + ".d"] = self._conv_params(w, p + ".downsample_layer.0", p + ".downsample_layer.1")
-        for i in range(3):
-            p = f"module.backbone_2d.deblocks.{i}"
-            s, sh = bn_fold(w, p + ".1", 1e-3)
-            W = torch.from_numpy(w[p + ".0.weight"] * s[None, :, None, None])                       # ConvTranspose [in,out,k,k]
-            d[p] = (W.to(self.device, self.head_dtype), torch.from_numpy(sh).to(self.device, self.head_dtype))
-        d["shared"] = self._conv_params(w, "module.dense_head.shared_conv.0", "module.dense_head.shared_conv.1")
-        # the five live heads' first convs share their input: one 64 -> 320 convolution (iou head is dead, :1440-1452)
-        names = ["center", "center_z", "dim", "rot", "hm"]
-        Ws, bs = zip(*[self._conv_params(w, f"module.dense_head.heads_list.0.{n}.0.0", f"module.dense_head.heads_list.0.{n}.0.1")
-                       for n in names])
-        d["heads0"] = (torch.cat(Ws, 0).contiguous(memory_format=torch.channels_last), torch.cat(bs, 0))
-        outs = [2, 1, 3, 2, 10]
-        W2 = torch.zeros((sum(outs), 64 * 5, 3, 3), dtype=torch.float32)
-        b2 = torch.zeros((sum(outs),), dtype=torch.float32)
-        o = 0
-        for k, (n, no) in enumerate(zip(names, outs)):                                              # block-diagonal second convs
-            W2[o:o + no, 64 * k:64 * (k + 1)] = torch.from_numpy(w[f"module.dense_head.heads_list.0.{n}.1.weight"])
-            b2[o:o + no] = torch.from_numpy(w[f"module.dense_head.heads_list.0.{n}.1.bias"])
-            o += no
-        d["heads1"] = (W2.to(self.device, self.head_dtype).contiguous(memory_format=torch.channels_last),
-                       b2.to(self.device, self.head_dtype))
+                self._build_hip_head(w)
 
     # ---- BEV ResNet + CenterHead on the HIP convolution ------------------------------
     def _build_hip_head(self, w):
@@ -320,20 +307,24 @@ class DsvtPipeline:
 
     # ---- the same stage at fp32 grade on the fp16 matrix cores (split-precision operands) ----------------------------------------
     def _build_hip_head_split(self, w):
-        """every convolution of _build_hip_head as  conv([hi | lo | hi], [w_hi | w_hi | w_lo]) -> fp32, with DsvtSplitHalfPlugin between
-        the layers (fp32 residual stream, ReLU, next operand).  src/dsvt-ai-trt.cpp:1144-1468 in fp32 arithmetic."""
+        """every convolution of _build_hip_head as  conv([hi | lo | hi], [w_hi | w_hi | w_lo])  with fp32 accumulation; the activations
+        travel between the layers as fp16 triples [hi | lo | hi] written by the producing convolution's own epilogue (round 3:
+        `split_output`; round 2 wrote fp32 and ran a DsvtSplitHalfPlugin launch between every two layers), the residual of a ResNet block
+        is read as hi + lo (`split_residual`), the last layer writes fp32.  src/dsvt-ai-trt.cpp:1144-1468 in fp32 arithmetic."""
         cw, dw, sw = P.conv_weight_rows, P.deconv_weight_rows, P.split_weight_rows
         ops = self.sops = {}
-        spl = self.ssplit = {}
 
-        def conv(name, rows, bias, H, cin, cout, k, stride, relu, **kw):
-            ops[name] = P.add_conv2d_op(sw(rows, k * k, cin), bias, H, H, 3 * cin, cout, k, stride, k // 2, relu=relu, out_f32=True, **kw)
+        def conv(name, rows, bias, H, cin, cout, k, stride, relu, res=False, out_f32=False, plane=None, **kw):
+            plane = cout if plane is None else plane
+            ops[name] = P.add_conv2d_op(sw(rows, k * k, cin), bias, H, H, 3 * cin, cout, k, stride, k // 2, relu=relu, has_residual=res,
+                                        split_residual=res, out_f32=out_f32, split_output=not out_f32,
+                                        out_channel_stride=plane if out_f32 else 3 * plane, **kw)
+            ops[name].split_in = True            # (bench.py's flop / byte accounting: 3 Cin operand channels carry Cin real ones)
 
-        def conv_bn(name, name_conv, name_bn, H, cin, cout, k, stride, relu):
+        def conv_bn(name, name_conv, name_bn, H, cin, cout, k, stride, relu, res=False):
             s_, sh = bn_fold(w, name_bn, 1e-3)
-            conv(name, cw(w[name_conv + ".weight"] * s_[:, None, None, None]), sh, H, cin, cout, k, stride, relu)
+            conv(name, cw(w[name_conv + ".weight"] * s_[:, None, None, None]), sh, H, cin, cout, k, stride, relu, res=res)
 
-        spl["in"] = P.add_split_half_op(C)
         H = GY
         for (i, cin, cout, stride, nb) in ((0, 192, 128, 1, 2), (1, 128, 128, 2, 3), (2, 128, 256, 2, 3)):
             for j in range(nb):
@@ -344,48 +335,42 @@ class DsvtPipeline:
                 Ho = (H + 2 - 3) // st + 1
                 if j == 0:
                     conv_bn(p + ".d", p + ".downsample_layer.0", p + ".downsample_layer.1", H, ci, cout, 1, st, False)
-                conv_bn(p + ".2", p + ".conv2", p + ".bn2", Ho, cout, cout, 3, 1, False)          # + identity, ReLU in the split op (:1165-1166)
-                spl[p + ".1"] = P.add_split_half_op(cout)
-                spl[p + ".2"] = P.add_split_half_op(cout, relu=True, has_residual=True)
+                conv_bn(p + ".2", p + ".conv2", p + ".bn2", Ho, cout, cout, 3, 1, True, res=True)      # + identity, ReLU (:1165-1166)
                 H = Ho
             k = (1, 2, 4)[i]
             p = f"module.backbone_2d.deblocks.{i}"
             s_, sh_ = bn_fold(w, p + ".1", 1e-3)
             conv(p, dw(w[p + ".0.weight"] * s_[None, :, None, None]), sh_, H, cout, 128, 1, 1, True, pixel_shuffle=k,
-                 out_channel_stride=384, out_channel_offset=128 * i)
-        spl["cat"] = P.add_split_half_op(384)
+                 plane=384, out_channel_offset=128 * i)
         conv_bn("shared", "module.dense_head.shared_conv.0", "module.dense_head.shared_conv.1", GY, 384, 64, 3, 1, True)
-        spl["shared"] = P.add_split_half_op(64)
         names, outs = ["center", "center_z", "dim", "rot", "hm"], [2, 1, 3, 2, 10]          # iou head is dead (:1440-1452)
         W0, b0 = [], []
         for n in names:
             s_, sh_ = bn_fold(w, f"module.dense_head.heads_list.0.{n}.0.1", 1e-3)
             W0.append(w[f"module.dense_head.heads_list.0.{n}.0.0.weight"] * s_[:, None, None, None]); b0.append(sh_)
         conv("heads0", cw(np.concatenate(W0, 0)), np.concatenate(b0), GY, 64, 320, 3, 1, True)
-        spl["heads0"] = P.add_split_half_op(320)
         W1 = np.zeros((sum(outs), 320, 3, 3), np.float32); b1 = np.zeros((sum(outs),), np.float32)
         o = 0
         for k_, (n, no) in enumerate(zip(names, outs)):                                       # block-diagonal second convs
             W1[o:o + no, 64 * k_:64 * (k_ + 1)] = w[f"module.dense_head.heads_list.0.{n}.1.weight"]
             b1[o:o + no] = w[f"module.dense_head.heads_list.0.{n}.1.bias"]
             o += no
-        conv("heads1", cw(W1), b1, GY, 320, 18, 3, 1, False)
-        self.cat_bev32 = torch.zeros((1, GY, GX, 384), dtype=torch.float32, device=self.device)
+        conv("heads1", cw(W1), b1, GY, 320, 18, 3, 1, False, out_f32=True)
+        self.cat_bev3 = torch.zeros((self.frames, GY, GX, 3 * 384), dtype=torch.float16, device=self.device)
         self.topk = P.add_center_head_topk_op(GY, GX, 18, 10, TOP_K)
 
-    def _bev_hip_split(self, bev):
-        """bev: [1, 468, 468, 192] fp32 NHWC -> [1, 468, 468, 18] fp32 NHWC, fp32-grade arithmetic"""
-        ops, spl = self.sops, self.ssplit
-        x, x3 = spl["in"](bev)
+    def _bev_hip_split(self, x3):
+        """x3: [frames, 468, 468, 3 * 192] fp16 triple [hi | lo | hi] NHWC -> [frames, 468, 468, 18] fp32 NHWC, fp32-grade arithmetic"""
+        ops = self.sops
         for (i, nb) in ((0, 2), (1, 3), (2, 3)):
             for j in range(nb):
                 p = f"module.backbone_2d.blocks.{i}.{j}"
-                y3 = spl[p + ".1"](ops[p + ".1"](x3)[0])[1]
-                idn = ops[p + ".d"](x3)[0] if j == 0 else x
-                x, x3 = spl[p + ".2"](ops[p + ".2"](y3)[0], idn)
-            ops[f"module.backbone_2d.deblocks.{i}"](x3, out=[self.cat_bev32])                   # deblock + concat (:1363)
-        sh3 = spl["shared"](ops["shared"](spl["cat"](self.cat_bev32)[1])[0])[1]
-        return ops["heads1"](spl["heads0"](ops["heads0"](sh3)[0])[1])[0]
+                y3 = ops[p + ".1"](x3)[0]
+                idn3 = ops[p + ".d"](x3)[0] if j == 0 else x3
+                x3 = ops[p + ".2"](y3, idn3)[0]
+            ops[f"module.backbone_2d.deblocks.{i}"](x3, out=[self.cat_bev3])                  # deblock + concat (:1363)
+        sh3 = ops["shared"](self.cat_bev3)[0]
+        return ops["heads1"](ops["heads0"](sh3)[0])[0]
 
     def _bev_hip(self, x):
         """x: [1, 468, 468, 192] fp16 NHWC -> [1, 468, 468, 18] fp32 NHWC (center2 cz1 dim3 rot2 hm10)"""
@@ -399,56 +384,6 @@ class DsvtPipeline:
             ops[f"module.backbone_2d.deblocks.{i}"](x, out=[self.cat_bev])                     # deblock + concat (:1363)
         sh = ops["shared"](self.cat_bev)[0]
         return ops["heads1"](ops["heads0"](sh)[0])[0]
-
-    def _decode_nhwc(self, o):
-        """same as _decode for an NHWC [1,H,W,18] head output"""
-        of = o.reshape(-1, 18)
-        hm = torch.sigmoid(of[:, 8:18].t().contiguous())                # [10, H*W]
-        sc1, idx1 = torch.topk(hm, TOP_K, dim=1)
-        sc2, idx2 = torch.topk(sc1.reshape(-1), TOP_K)
-        cls = (idx2 // TOP_K).to(torch.int32)
-        ind = idx1.reshape(-1)[idx2]
-        ys, xs = (ind // GX).to(torch.int32), (ind % GX).to(torch.int32)
-        g = of[ind]                                                     # [K, 18]
-        center = g[:, 0:2].contiguous(); center_z = g[:, 2:3].contiguous()
-        dim = torch.exp(g[:, 3:6]).contiguous()
-        angle = torch.atan(g[:, 7:8] / g[:, 6:7]).contiguous()
-        return (sc2.reshape(1, -1), cls.reshape(1, -1), xs.reshape(1, -1), ys.reshape(1, -1), center.reshape(1, 1, -1, 2),
-                center_z.reshape(1, 1, -1, 1), angle.reshape(1, 1, -1, 1), dim.reshape(1, 1, -1, 3))
-
-    def _bev(self, x):
-        d = self.dense
-        ups = []
-        for (i, stride, nb, k) in ((0, 1, 2, 1), (1, 2, 3, 2), (2, 2, 3, 4)):
-            for j in range(nb):
-                p = f"module.backbone_2d.blocks.{i}.{j}"
-                s = stride if j == 0 else 1
-                y = F.relu(F.conv2d(x, *d[p + ".1"], stride=s, padding=1))
-                y = F.conv2d(y, *d[p + ".2"], stride=1, padding=1)
-                idn = F.conv2d(x, *d[p + ".d"], stride=s) if j == 0 else x
-                x = F.relu(y + idn)
-            Wd, bd = d[f"module.backbone_2d.deblocks.{i}"]
-            ups.append(F.relu(F.conv_transpose2d(x, Wd, bd, stride=k)))
-        f = torch.cat(ups, 1)
-        sh = F.relu(F.conv2d(f, *d["shared"], padding=1))
-        h0 = F.relu(F.conv2d(sh, *d["heads0"], padding=1))
-        return F.conv2d(h0, *d["heads1"], padding=1).float()       # [1, 18, 468, 468]: center2 cz1 dim3 rot2 hm10
-
-    def _decode(self, o):
-        """sigmoid / exp / two-stage top-K / gathers / atan(sin/cos)  (src/dsvt-ai-trt.cpp:1479-1669)"""
-        o = o[0]
-        hm = torch.sigmoid(o[8:18]).reshape(10, -1)
-        sc1, idx1 = torch.topk(hm, TOP_K, dim=1)
-        sc2, idx2 = torch.topk(sc1.reshape(-1), TOP_K)
-        cls = (idx2 // TOP_K).to(torch.int32)
-        ind = idx1.reshape(-1)[idx2]
-        ys, xs = (ind // GX).to(torch.int32), (ind % GX).to(torch.int32)
-        g = o.reshape(18, -1)[:, ind]                               # [18, K]
-        center = g[0:2].T.contiguous(); center_z = g[2:3].T.contiguous()
-        dim = torch.exp(g[3:6]).T.contiguous()
-        angle = torch.atan(g[7:8] / g[6:7]).T.contiguous()          # rot[1]/rot[0]: sin/cos slices :1494-1501
-        return (sc2.reshape(1, -1), cls.reshape(1, -1), xs.reshape(1, -1), ys.reshape(1, -1), center.reshape(1, 1, -1, 2),
-                center_z.reshape(1, 1, -1, 1), angle.reshape(1, 1, -1, 1), dim.reshape(1, 1, -1, 3))
 
     # ---- stages -------------------------------------------------------------------------------
     def voxel_stage(self, points, n):
@@ -465,7 +400,8 @@ class DsvtPipeline:
                 vfeat, vfeat16 = self.pfn(feat, pidx, pcnt, Pn)
                 main.wait_event(join)
             elif self.fused_partition:
-                vfeat, vfeat16 = self.pfn(feat, pidx, pcnt, Pn)
+                o_ = self.pfn(feat, pidx, pcnt, Pn)
+                vfeat, vfeat16 = (o_[0], None) if self.split else o_
                 po = self.part(coords, Pn)
                 wps = [[None, None, None, None, po[4 * k], None] for k in range(len(WINS))]      # slot 4 = in-window coordinates
                 gss = [[po[4 * k + 1], po[4 * k + 2], po[4 * k + 3]] for k in range(len(WINS))]  # inds, mask, set count
@@ -489,7 +425,7 @@ class DsvtPipeline:
         tables = getattr(self, "pos_tables", None)
         pos_all = self.pe_all(Pn, st["wps"][0][5], st["wps"][1][5]) if self.pe_all is not None else None
         xh = st.get("vfeat16") if self.f16 else x           # GEMM-operand copy of the residual stream
-        if xh is None:
+        if xh is None and self.f16:
             xh = x.to(torch.float16)
         for b in range(self.blocks):
             xb = x
@@ -504,6 +440,13 @@ class DsvtPipeline:
                 else:
                     pos = fc(xy, Pn)[0] if a is None else fc(a(xy, Pn)[0], Pn)[0]
                 L = self.layers[(b, l)]
+                if tables is not None and self.split:
+                    qkv = L["qkv"](x, Pn, tables[(b, l)], st["wps"][l][4])[0]
+                    att = L["attn"](qkv, inds, mask, S)[0]
+                    x = (L["mlp"](att, Pn, x, xb) if l == 1 else L["mlp"](att, Pn, x))[0]
+                    if trace is not None:
+                        trace[(b, l)] = x.clone()
+                    continue
                 if tables is not None:
                     qkv = L["qkv"](xh, Pn, tables[(b, l)], st["wps"][l][4])[0]
                     att = L["attn"](qkv, inds, mask, S)[0]
@@ -529,17 +472,12 @@ class DsvtPipeline:
         return x
 
     def head(self, x, st):
-        src = self._xh if (self.f16 and self.head_dtype == torch.float16) else x
-        bev = self.map2bev(src, st["coords"], st["P"])[0]             # [1, 468(y), 468(x), 192] NHWC
         if self.split_head:
+            bev = self.map2bev(x, st["coords"], st["P"])[0]           # [frames, 468(y), 468(x), 3 * 192] fp16 triple [hi | lo | hi], NHWC
             return self._post(self.filter(*self.topk(self._bev_hip_split(bev))))
-        if self.hip_head:
-            return self._post(self.filter(*self.topk(self._bev_hip(bev))))
-        bev = bev.permute(0, 3, 1, 2)                                 # NCHW view of channels-last memory (:1131-1133)
-        if bev.dtype != self.head_dtype:
-            bev = bev.to(self.head_dtype)
-        o = self._bev(bev)
-        return self._post(self.filter(*self._decode(o)))
+        src = self._xh if self.f16 else x.to(torch.float16)
+        bev = self.map2bev(src, st["coords"], st["P"])[0]             # [frames, 468(y), 468(x), 192] fp16 NHWC
+        return self._post(self.filter(*self.topk(self._bev_hip(bev))))
 
     def _post(self, fb):
         if self.nms is None:

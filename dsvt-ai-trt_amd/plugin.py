@@ -378,9 +378,12 @@ def add_get_value_by_index_op(max_win_num, voxel_num_set, channel_num, axis_id):
                                                 channel_num=channel_num, axis_id=axis_id), "get_value_by_index_layer")
 
 
-def add_map_2_bev_op(max_pillars_num, channel_num, grid_size_x, grid_size_y, frames=1):
-    """plugin_helper.h:371-425.  Inputs: voxel_features, coors, valid_voxel_num.  frames > 1: coords.x selects one of `frames` stacked maps."""
+def add_map_2_bev_op(max_pillars_num, channel_num, grid_size_x, grid_size_y, frames=1, split_output=False):
+    """plugin_helper.h:371-425.  Inputs: voxel_features, coors, valid_voxel_num.  frames > 1: coords.x selects one of `frames` stacked maps.
+    split_output: fp32 rows in, the fp16 triple [hi | lo | hi] (3 C channels per cell) out -- the operand of the fp32-grade convolutions."""
     extra = dict(frames=int(frames)) if frames != 1 else {}
+    if split_output:
+        extra["split_output"] = 1
     return Plugin("Map2BevPlugin", dict(extra, max_pillars_num=max_pillars_num, channel_num=channel_num,
                                         grid_size_x=grid_size_x, grid_size_y=grid_size_y), "map2bev_layer")
 
@@ -429,11 +432,13 @@ def add_pos_embed_op(max_rows, layer_input, pe_weights, pe_biases, weights, bias
                   "pos_embed_layer")
 
 
-def add_pillar_feature_net_op(max_pillars_num, weight0, bias0, weight1, bias1, pack_small_pillars=True):
+def add_pillar_feature_net_op(max_pillars_num, weight0, bias0, weight1, bias1, pack_small_pillars=True, split_precision=False):
     """Both PFN layers + both scatter-max reductions in one launch, no per-point activation in memory (csrc/pfn.hip).
     BatchNorm folded by the caller: weight0 [96,10], weight1 [192,192] (columns 0..95 act on x0, 96..191 on its pillar max).
-    Inputs: feat [1,Nk,10], pidx [1,P,T], pcnt [1,P,1], pillar_num [1].  Outputs: pillar features [1,P,192] fp32 + fp16."""
-    return Plugin("DsvtPillarFeatureNetPlugin", dict(
+    Inputs: feat [1,Nk,10], pidx [1,P,T], pcnt [1,P,1], pillar_num [1].  Outputs: pillar features [1,P,192] fp32 + fp16.
+    split_precision: layer 1 on (hi, lo) fp16 operand pairs (fp32 grade); one output, fp32."""
+    extra = dict(split_precision=1) if split_precision else {}
+    return Plugin("DsvtPillarFeatureNetPlugin", dict(extra, 
         max_pillars_num=int(max_pillars_num), weight0=np.asarray(weight0, np.float32).reshape(-1),
         bias0=np.asarray(bias0, np.float32).reshape(-1), weight1=np.ascontiguousarray(np.asarray(weight1, np.float32)).reshape(-1),
         bias1=np.asarray(bias1, np.float32).reshape(-1), pack_small_pillars=int(bool(pack_small_pillars))), "pillar_feature_net_layer")
@@ -473,7 +478,9 @@ def add_multi_head_attention_op(in_proj_weight, in_proj_bias, out_proj_weight, o
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 
 
-COMPUTE_F32, COMPUTE_F16 = 0, 1
+# precision of the matrix products: exact fp32 MFMA | fp16 operands (BASELINE configs[2]) | split precision: every operand a (hi, lo) fp16
+# pair, three fp16 MFMAs per product, fp32 accumulate -- the reference's fp32 arithmetic (include/params.h:332) at fp16-matrix-core speed
+COMPUTE_F32, COMPUTE_F16, COMPUTE_SPLIT = 0, 1, 2
 
 
 OUT_F32, OUT_F16, OUT_BOTH = 0, 1, 2
@@ -526,7 +533,11 @@ def deconv_weight_rows(w):
 
 def split_weight_rows(weight_rows, taps, in_channels):
     """rows [R][taps][Cin] fp32 -> [R][taps][3 Cin] holding [w_hi | w_hi | w_lo] per tap (w_hi = fp16(w), w_lo = fp16(w - w_hi)): with an input
-    [hi | lo | hi] (DsvtSplitHalfPlugin) one fp16-MFMA convolution computes hi w_hi + lo w_hi + hi w_lo, the fp32 product up to 2^-22."""
+    [hi | lo | hi] (DsvtSplitHalfPlugin, or a producer with split_output) one fp16-MFMA convolution computes hi w_hi + lo w_hi + hi w_lo: the
+    fp32 product up to the dropped lo w_lo term (2^-22 relative) for operands whose lo part is a NORMAL fp16 number, i.e. |v| >= 2^-3 or so;
+    below that lo falls into the fp16 subnormals (absolute step 2^-24), so a 0.01-sized BN-folded weight keeps ~2^-18 relative precision
+    -- still 50x finer than the 1e-3 box bar needs (tests/test_split_kernels_gpu.py::test_split_operand_range; the MFMA does not flush
+    fp16 subnormal inputs)."""
     w = np.asarray(weight_rows, np.float32).reshape(-1, taps, in_channels)
     hi = w.astype(np.float16).astype(np.float32)
     lo = (w - hi).astype(np.float16).astype(np.float32)
@@ -541,28 +552,36 @@ def add_split_half_op(channel_num, relu=False, has_residual=False):
 
 
 def add_conv2d_op(weight_rows, bias, in_height, in_width, in_channels, out_channels, kernel_size=1, stride=1, padding=0,
-                  pixel_shuffle=1, relu=False, has_residual=False, out_channel_stride=None, out_channel_offset=0, out_f32=False):
+                  pixel_shuffle=1, relu=False, has_residual=False, out_channel_stride=None, out_channel_offset=0, out_f32=False,
+                  split_output=False, split_residual=False):
     """NHWC fp16 implicit-GEMM convolution with fused bias / residual / ReLU / pixel-shuffle / concat offset
     (csrc/conv.hip): replaces the reference's addConvolutionNd / addDeconvolutionNd + addScale + ReLU + SUM
-    groups (src/dsvt-ai-trt.cpp:149-246, 1144-1468).  Inputs: x [1,H,W,Cin] fp16 (, residual [1,Ho,Wo,C] fp16)."""
+    groups (src/dsvt-ai-trt.cpp:149-246, 1144-1468).  Inputs: x [1,H,W,Cin] fp16 (, residual [1,Ho,Wo,C] fp16).
+    split_output: the result leaves as the fp16 triple [hi | lo | hi] (out_channel_stride = 3 x the plane width); split_residual: the
+    residual input is such a triple (value hi + lo)."""
     fields = dict(in_height=in_height, in_width=in_width, in_channels=in_channels, out_channels=out_channels,
                   kernel_size=kernel_size, stride=stride, padding=padding, pixel_shuffle=pixel_shuffle, relu=int(bool(relu)),
                   has_residual=int(bool(has_residual)),
                   out_channel_stride=out_channels if out_channel_stride is None else out_channel_stride,
                   out_channel_offset=out_channel_offset, out_f32=int(bool(out_f32)),
                   weight=np.asarray(weight_rows, np.float32).reshape(-1))
+    if split_output:
+        fields["split_output"] = 1
+    if split_residual:
+        fields["split_residual"] = 1
     if bias is not None:
         fields["bias"] = np.asarray(bias, np.float32).reshape(-1)
     return Plugin("DsvtConv2dPlugin", fields, "conv2d_layer")
 
 
 def add_encoder_mlp_op(out_proj_weight, out_proj_bias, linear1_weight, linear1_bias, linear2_weight, linear2_bias,
-                       layer_norms, max_rows, ln_eps=0.0, frames=0):
+                       layer_norms, max_rows, ln_eps=0.0, frames=0, split_precision=False):
     """Everything after the attention core of one DSVT encoder layer in one launch (csrc/mlp.hip):
     s1 = LN1(att Wo^T + bo + x); h = GELU(s1 W1^T + b1); x' = LN3(LN2(s1 + h W2^T + b2) + x) [; x' = LN4(x' + xb)].
     layer_norms: [(gamma, beta)] x 3 (norm1, norm2, encoder norm) or x 4 (+ block residual norm).
     Inputs: att [1,P,192] fp16, count [1], x [1,P,192] fp32 (, xb [1,P,192] fp32).  Outputs: x' fp32, x' fp16.
-    frames: how many frames' rows a launch carries (picks the kernel: >= 3 the two-workgroups-per-CU one); 0 = decided on the device."""
+    frames: how many frames' rows a launch carries (picks the kernel: >= 3 the two-workgroups-per-CU one); 0 = decided on the device.
+    split_precision: att arrives as fp32, all three GEMMs on (hi, lo) fp16 operand pairs (fp32 grade); one output, x' fp32."""
     f = lambda a: np.asarray(a, np.float32).reshape(-1)
     assert len(layer_norms) in (3, 4)
     return Plugin("DsvtEncoderMlpPlugin", dict(
@@ -570,5 +589,5 @@ def add_encoder_mlp_op(out_proj_weight, out_proj_bias, linear1_weight, linear1_b
         out_proj_weight=f(out_proj_weight), out_proj_bias=f(out_proj_bias), linear1_weight=f(linear1_weight),
         linear1_bias=f(linear1_bias), linear2_weight=f(linear2_weight), linear2_bias=f(linear2_bias),
         ln_weights=np.concatenate([f(g) for g, _ in layer_norms]), ln_bias=np.concatenate([f(b) for _, b in layer_norms]),
-        **({"frames": int(frames)} if frames else {})),
+        **({"frames": int(frames)} if frames else {}), **({"split_precision": 1} if split_precision else {})),
         "encoder_mlp_layer")

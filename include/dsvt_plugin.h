@@ -160,7 +160,10 @@ size_t dsvtPluginGetWorkspaceSize(const DsvtPlugin* p, const DsvtPluginTensorDes
                                   const DsvtPluginTensorDesc* outputs, int32_t nbOutputs);
 
 /* configurePlugin(in, nbInputs, out, nbOutputs), e.g. Points2FeaturesPlugin::configurePlugin plugins/src/points2Features.cu:257-260
- * (an empty body there).  Here it records nbInputs, which enqueue's signature does not carry and a batched enqueue needs (below).
+ * (an empty body there).  Here it records nbInputs (which enqueue's signature does not carry) and, for a batch of B = inputs[0].dims.d[0]
+ * > 1 frames, WHICH tensors are stacks of per-frame slabs: B counts as a batch only when inputs[0] has rank >= 2 and every output is a
+ * [B, ...] tensor; an input is a stack when its leading dimension is B and the plugin does not declare it shared (tables).
+ * enqueue uses this record and never infers a batch from the shapes it is handed.
  * Returns 0; -1 on NULL arguments; -2 if nbOutputs is not the plugin's. */
 int32_t dsvtPluginConfigurePlugin(DsvtPlugin* p, const DsvtPluginTensorDesc* inputs, int32_t nbInputs,
                                   const DsvtPluginTensorDesc* outputs, int32_t nbOutputs);
@@ -173,9 +176,11 @@ int32_t dsvtPluginConfigurePlugin(DsvtPlugin* p, const DsvtPluginTensorDesc* inp
  * pointer (plugin, inputs, outputs) is NULL; -2 = unsupported tensor shape (batch != 1, like
  * the reference, whose kernels ignore the batch dimension: points2Features.cu:678,900); -3 = a
  * C++ exception was caught at the boundary (nothing ever unwinds into the caller).
- * Batch: when inputDesc[0].dims.d[0] = B > 1 (needs a prior dsvtPluginConfigurePlugin, else -2) the call is B batch-1 enqueues on
- * `stream`: tensors whose leading dimension is B are stacks of per-frame slabs -- the layout the reference's output shapes describe,
- * although its kernels only ever process frame 0 (points2Features.cu:678,900,919) -- other tensors are shared by all frames. */
+ * Batch: a plugin configured (dsvtPluginConfigurePlugin) with B > 1 runs B batch-1 enqueues on `stream` over the tensors recorded as
+ * per-frame stacks -- the layout the reference's output shapes describe, although its kernels only ever process frame 0
+ * (points2Features.cu:678,900,919) -- the other tensors are shared by all frames; descriptors that disagree with the configured batch, or
+ * a rank >= 3 first input with a leading dimension > 1 on a plugin that was never configured, return -2.  Descriptors without a leading
+ * batch dimension ([rows, C]) are one plain enqueue. */
 int32_t dsvtPluginEnqueue(DsvtPlugin* p, const DsvtPluginTensorDesc* inputDesc, const DsvtPluginTensorDesc* outputDesc,
                           const void* const* inputs, void* const* outputs, void* workspace, dsvtStream_t stream);
 

@@ -135,13 +135,13 @@ def test_set_attention_f16_set_cap_overflow_leaves_zeros(pkg, oracle):
 # =====================================================================================================================
 # encoder_mlp_stream_kernel (DsvtEncoderMlpPlugin) vs the reference wiring src/dsvt-ai-trt.cpp:669-756
 # =====================================================================================================================
-def _mlp_reference(att16, x, xb, w, lp, block, n, mimic_roundings=True):
+def _mlp_reference(att16, x, xb, w, lp, block, n, mimic_roundings=True, round_weights=True):
     """fp64 restatement of  s1 = LN1(att Wo^T + bo + x); h = GELU(s1 W1^T + b1); y = LN3(LN2(s1 + h W2^T + b2) + x)
     (; y = LN4(y + xb)) with eps = 0 LayerNorms (layerNorm.cu:261-402 semantics: biased variance) and the tanh GELU of
     gelu.cu:201-250, on fp16-rounded weights; mimic_roundings: the two operand roundings the kernel performs (s1 and h are
     MFMA operands of the next GEMM) are restated."""
     f = lambda k: w[lp + k].astype(np.float64)
-    h16 = lambda k: r16(w[lp + k]).astype(np.float64)
+    h16 = (lambda k: r16(w[lp + k]).astype(np.float64)) if round_weights else f
 
     def ln(v, name):
         g, b = (w[name + ".weight"].astype(np.float64), w[name + ".bias"].astype(np.float64))

@@ -115,9 +115,8 @@ def test_boxes_reference_frames(pkg, oracle, weights, frame):
 
 
 def test_pipeline_is_deterministic(pkg, weights):
-    """Every hand-written kernel is race-free: the hot path (voxelize .. DSVT blocks) is bit-reproducible
-    run to run.  The dense glue behind it (MIOpen convolutions picked by PyTorch) may switch
-    algorithms between the first and later calls, so boxes are only required to agree to 1e-5."""
+    """Every kernel of the frame is hand-written and race-free (no vendor-library stage since round 2): features AND boxes are
+    bit-reproducible run to run."""
     caps = pkg.pipeline.Caps.reference()
     pipe = pkg.pipeline.DsvtPipeline(weights, caps=caps, device=DEV)
     pts, n = cases.load_frame("000003", caps.N)
@@ -128,10 +127,7 @@ def test_pipeline_is_deterministic(pkg, weights):
         x1 = pipe.backbone(pipe.voxel_stage(p_d, n_d))
         assert torch.equal(x0, x1), float((x0 - x1).abs().max())
         b, cb = pipe.forward(p_d, n_d)
-        # MIOpen may pick another algorithm after its first call: scores move by ~1e-7 and two
-        # near-tied candidates can swap rows, so rows are matched by centre, not by index
-        worst, unmatched = match_boxes(b[0].cpu().numpy(), int(cb[0]), a[0].cpu().numpy(), int(ca[0]))
-        assert unmatched == 0 and worst < 1e-4, (worst, unmatched)
+        assert torch.equal(a, b) and torch.equal(ca, cb)
 
 
 def _box_errors(got, n_got, exp, n_exp):
@@ -269,8 +265,7 @@ def test_detect_directory_writes_reference_txt(pkg, weights, tmp_path):
     for name, _, _ in done:
         _, a = pkg.detect.read_txt(str(out / f"{name}.txt"))
         _, b = pkg.detect.read_txt(str(out2 / f"{name}.txt"))
-        # (another process: the fp32 dense stage runs on MIOpen, whose algorithm choice may differ in the last bits)
-        assert a.shape == b.shape and np.abs(a - b).max() < 1e-4 and np.array_equal(a[:, 7], b[:, 7])
+        assert a.shape == b.shape and np.array_equal(a, b)      # (another process, the same deterministic kernels: the same text)
 
 
 @pytest.mark.parametrize("n_pts", [0, 1, 37])

@@ -1,0 +1,177 @@
+"""Kernel-level parity of the split-precision ("fp32 grade on the fp16 matrix cores") kernels of round 3 -- linear_split_rows_kernel,
+encoder_mlp_stream_kernel<.., SPLIT>, pfn_kernel<SPLIT> -- against float64 restatements of the reference's fp32 wiring on the SAME fp32
+operands, and of the frame pipeline built from them against the fp32 oracle at the north-star tolerance (boxes within 1e-3).
+
+Every operand is the pair hi = fp16(v), lo = fp16(v - hi); a product is w_hi a_hi + w_lo a_hi + w_hi a_lo with fp32 accumulation: the
+dropped term is 2^-22 of the product, so these kernels must sit at fp32-summation-order distance (1e-6-class) from the fp64 result,
+three orders below the fp16 kernels' bounds in tests/test_f16_kernels_gpu.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+from tests.test_plugins_gpu import dev, host, scalar, make_voxelizer
+from tests.test_f16_kernels_gpu import _mlp_reference
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("MR,n", [(8192, 1), (8192, 100), (8192, 5504), (65536, 34483), (262144, 137932), (196608, 190001)])
+@pytest.mark.parametrize("table", [False, True])
+def test_qkv_split_kernel_against_fp64_product(pkg, MR, n, table):
+    """q = k = (x + pos) Wqk^T + b, v = x Wv^T + b (getValueByIndex.cu:282-355 + src/dsvt-ai-trt.cpp:328-330, per voxel row), fp32 tensors,
+    split-precision products: within 2e-6 of scale of the fp64 product of the fp32 operands (the fp16 kernel's bound is 1e-3)."""
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(MR + n)
+    C, wx = 192, 12
+    x = torch.randn((1, MR, C), generator=g)
+    W = (torch.randn((3 * C, C), generator=g) / np.sqrt(C)); b = torch.randn(3 * C, generator=g) * 0.1
+    kw = dict(add_cols=2 * C, compute_type=P.COMPUTE_SPLIT)
+    cnt = torch.tensor([n], dtype=torch.int32, device=DEV)
+    if table:
+        tab = torch.randn((1, wx * wx, C), generator=g) * 0.5
+        c2d = torch.zeros((1, MR, 3), dtype=torch.int32)
+        c2d[0, :, 1] = torch.randint(0, wx, (MR,), generator=g); c2d[0, :, 2] = torch.randint(0, wx, (MR,), generator=g)
+        pos = tab[0][(c2d[0, :, 1] * wx + c2d[0, :, 2]).long()][None]
+        op = P.add_linear_op(W.numpy(), b.numpy(), MR, add_gather_width=wx, **kw)
+        got = op(x.to(DEV), cnt, tab.to(DEV), c2d.to(DEV))[0]
+    else:
+        pos = torch.randn((1, MR, C), generator=g) * 0.5
+        op = P.add_linear_op(W.numpy(), b.numpy(), MR, **kw)
+        got = op(x.to(DEV), cnt, pos.to(DEV))[0]
+    torch.cuda.synchronize()
+    assert got.dtype == torch.float32
+    Wd = W.double()
+    xs = (x[0, :n] + pos[0, :n]).double()                                  # the prologue adds in fp32
+    ref = torch.cat([xs @ Wd[:2 * C].T, x[0, :n].double() @ Wd[2 * C:].T], 1) + b.double()
+    err = (got[0, :n].double().cpu() - ref).abs()
+    scale = ref.abs().max().item()
+    assert err.max().item() < 2e-6 * scale, (err.max().item(), scale)
+    assert not got[0, n:].any()
+    again = P.Plugin.deserialize("DsvtLinearPlugin", op.serialize())
+    assert again.serialize() == op.serialize()
+
+
+def test_split_operand_range(pkg):
+    """operands far from 1: tiny weights (lo parts in the fp16 subnormal range: absolute step 2^-24, i.e. the split carries
+    ~2^-18 of a 0.01-sized operand, not 2^-22) and activations beyond the fp16 range (hi saturates at 65504, no inf / NaN)."""
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(5)
+    C, MR, n = 192, 8192, 4000
+    x = torch.randn((1, MR, C), generator=g)
+    W = torch.randn((3 * C, C), generator=g) * 0.01
+    cnt = torch.tensor([n], dtype=torch.int32, device=DEV)
+    got = P.add_linear_op(W.numpy(), None, MR, compute_type=P.COMPUTE_SPLIT)(x.to(DEV), cnt)[0]
+    ref = x[0, :n].double() @ W.double().T
+    err = (got[0, :n].double().cpu() - ref).abs().max().item()
+    assert err < 2e-5 * ref.abs().max().item(), err                      # subnormal lo parts: 2^-18-class, still 50x inside 1e-3
+    x[0, 0, :4] = torch.tensor([1e5, -2e5, 7e4, 65504.0])
+    got = P.add_linear_op(W.numpy(), None, MR, compute_type=P.COMPUTE_SPLIT)(x.to(DEV), cnt)[0]
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all()
+    # (row 0 is coarse -- its saturated elements carry at most +-131008 -- but finite; every other row is untouched)
+    assert (got[0, 1:n].double().cpu() - ref[1:]).abs().max().item() < 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("block_ln,MR,n", [(False, 8192, 5504), (True, 8192, 5504), (False, 8192, 1), (True, 8192, 17),
+                                             (True, 65536, 34483), (False, 196608, 137932), (True, 196608, 131072 + 33)])
+def test_encoder_mlp_split_against_reference_wiring(pkg, block_ln, MR, n):
+    """src/dsvt-ai-trt.cpp:669-756 in fp64 on the fp32 operands, NO operand rounding anywhere: the split kernel must be within
+    fp32-arithmetic distance (LayerNorm outputs are O(1): 2e-5 max, 1e-6 mean), 200x below the fp16 kernel's distance."""
+    P = pkg.plugin
+    rng = np.random.default_rng(7 * n + block_ln)
+    C = 192
+    w = pkg.synth.make_weights(with_bev=False)
+    b_ = 1
+    lp = f"module.backbone_3d.stage_0.{b_}.encoder_list.1"
+    ln = lambda k: (w[k + ".weight"], w[k + ".bias"])
+    lns = [ln(lp + ".win_attn.norm1"), ln(lp + ".win_attn.norm2"), ln(lp + ".norm")]
+    if block_ln:
+        lns.append(ln(f"module.backbone_3d.residual_norm_stage_0.{b_}"))
+    att = np.zeros((MR, C), np.float32); att[:n] = rng.standard_normal((n, C))
+    x = np.zeros((MR, C), np.float32); x[:n] = rng.standard_normal((n, C))
+    xb = np.zeros((MR, C), np.float32); xb[:n] = rng.standard_normal((n, C))
+    mlp = P.add_encoder_mlp_op(w[lp + ".win_attn.self_attn.out_proj.weight"], w[lp + ".win_attn.self_attn.out_proj.bias"],
+                               w[lp + ".win_attn.linear1.weight"], w[lp + ".win_attn.linear1.bias"],
+                               w[lp + ".win_attn.linear2.weight"], w[lp + ".win_attn.linear2.bias"], lns, MR, split_precision=True)
+    assert mlp.nb_outputs == 1
+    args = [dev(att[None]), scalar(n), dev(x[None])] + ([dev(xb[None])] if block_ln else [])
+    got, = mlp(*args)
+    torch.cuda.synchronize()
+    g = host(got)[0]
+    ref = _mlp_reference(att, x, xb, w, lp, b_ if block_ln else None, n, mimic_roundings=False, round_weights=False)
+    err = np.abs(g[:n] - ref)
+    assert err.max() < 2e-5, err.max()
+    assert err.mean() < 1.5e-6, err.mean()
+    assert not g[n:].any()
+    blob = mlp.serialize()
+    again = P.Plugin.deserialize("DsvtEncoderMlpPlugin", blob)
+    assert again.serialize() == blob and again.nb_outputs == 1
+    assert torch.equal(again(*args)[0], got)
+
+
+@pytest.mark.parametrize("frame,capname,n_pts", [("000000", "ref", 0), (None, "mid", 60000)])
+def test_pillar_feature_net_split_against_oracle(pkg, oracle, frame, capname, n_pts):
+    """dense_ref.voxel_stage (src/dsvt-ai-trt.cpp:571-589, fp32) against the split-precision pillar feature net: 1e-5 of the feature
+    scale (fp32 summation order), where the fp16 variant sits at 1.5e-3."""
+    from oracle import dense_ref as D
+    P = pkg.plugin
+    c = cases.caps(capname)
+    if frame:
+        pts, n = cases.load_frame(frame, c["N"])
+    else:
+        pts, n = cases.pad_points(pkg.synth.lidar_like(n_pts, 0), c["N"])
+    w = pkg.synth.make_weights(with_bev=False)
+    cfg = D.OracleCfg(max_points=c["N"], max_points_filter=c["Nk"], max_pillars=c["P"], max_win=c["W"], blocks=0)
+    ost = D.voxel_stage(pts, n, w, cfg)
+    W0, b0 = pkg.pipeline.fold_linear_bn(w, "module.vfe.pfn_layers.0.linear", "module.vfe.pfn_layers.0.norm", 1e-5)
+    W1, b1 = pkg.pipeline.fold_linear_bn(w, "module.vfe.pfn_layers.1.linear", "module.vfe.pfn_layers.1.norm", 1e-5)
+    feat, pidx, coords, pcnt, Pn, Nk = make_voxelizer(P, c)(dev(pts[None]), scalar(n))
+    op = P.add_pillar_feature_net_op(c["P"], W0, b0, W1, b1, split_precision=True)
+    v, = op(feat, pidx, pcnt, Pn)
+    torch.cuda.synchronize()
+    np_ = ost["P"]
+    got, ref = host(v)[0], ost["vfeat"]
+    scale = np.abs(ref[:np_]).max()
+    err = np.abs(got[:np_] - ref[:np_])
+    assert err.max() < 1e-5 * scale, (err.max(), scale)
+    assert not got[np_:].any()
+    again = P.Plugin.deserialize("DsvtPillarFeatureNetPlugin", op.serialize())
+    assert again.serialize() == op.serialize() and torch.equal(again(feat, pidx, pcnt, Pn)[0], v)
+
+
+@pytest.mark.parametrize("frame", ["000000", "lidar180000"])
+def test_backbone_features_split_mode(pkg, oracle, frame):
+    """voxel features after the four DSVT blocks, split-precision frame path against the fp32 oracle (2e-4: the bar of the exact-fp32 mode)"""
+    from oracle import dense_ref as D
+    from tests.test_pipeline_gpu import _frame_and_caps, _oracle_cfg
+    w = pkg.synth.make_weights()
+    caps, pts, n = _frame_and_caps(pkg, frame)
+    pipe = pkg.pipeline.DsvtPipeline(w, caps=caps, device=DEV, linear_compute=pkg.plugin.COMPUTE_SPLIT, with_head=False)
+    x, st = pipe.forward(torch.from_numpy(pts[None]).to(DEV), torch.tensor([n], dtype=torch.int32, device=DEV))
+    torch.cuda.synchronize()
+    cfg = _oracle_cfg(caps)
+    ost = D.voxel_stage(pts, n, w, cfg)
+    ref = D.dsvt_blocks(ost, w, cfg)
+    np_ = ost["P"]
+    err = np.abs(x[0, :np_].cpu().numpy() - np.asarray(ref)[:np_]).max()
+    assert err < 2e-4, err
+
+
+@pytest.mark.parametrize("frame", ["000000", "000004", "lidar180000", "lidar60000s3"])
+def test_boxes_split_mode(pkg, oracle, frame):
+    """the split-precision frame (what bench.py reports as `parity_mode`) against the fp32 oracle at the north-star tolerance"""
+    from oracle import dense_ref as D
+    from tests.parity import match_boxes
+    from tests.test_pipeline_gpu import _frame_and_caps, _oracle_cfg, _run
+    w = pkg.synth.make_weights()
+    caps, pts, n = _frame_and_caps(pkg, frame)
+    pipe = pkg.pipeline.DsvtPipeline(w, caps=caps, device=DEV, linear_compute=pkg.plugin.COMPUTE_SPLIT)
+    boxes, cnt = _run(pkg, pipe, pts, n)
+    torch.cuda.synchronize()
+    eb, ec = D.forward(pts, n, w, _oracle_cfg(caps))
+    worst, unmatched = match_boxes(boxes[0].cpu().numpy(), int(cnt[0]), eb, ec)
+    print("split-mode boxes", frame, "max|diff|", worst, "unmatched", unmatched, "count", int(cnt[0]), ec)
+    assert unmatched == 0 and worst < 1e-3, (worst, unmatched)

@@ -35,17 +35,19 @@ def main():
         caps = pkg.pipeline.Caps.reference()
         pts, n = cases.load_frame(args.frame, caps.N)
     d_pts = torch.from_numpy(pts[None]).to(dev); d_n = torch.tensor([n], dtype=torch.int32, device=dev)
-    p32 = pkg.pipeline.DsvtPipeline(w, caps=caps, device=dev, hip_head=False)      # PyTorch fp32 dense stage: its intermediates are needed
+    from tools.vendor_dense import VendorDensePipeline
+    p32 = VendorDensePipeline(w, caps=caps, device=dev)      # PyTorch fp32 dense stage (tools/vendor_dense.py): its intermediates are needed
     p16 = pkg.pipeline.DsvtPipeline(w, caps=caps, device=dev, linear_compute=P.COMPUTE_F16, head_dtype=torch.float16)
 
     # ---- all-fp32 reference with its intermediate tensors -----------------------------------------
+    p32.forward(d_pts, d_n)                                   # (creates the fp32 Map2Bev op of the vendor head)
     st32 = p32.voxel_stage(d_pts, d_n)
     x32 = p32.backbone(st32).clone()
     Pn = int(st32["P"][0])
 
     def dense32(x, upto=None):
         """pipe32's dense stage on a [1,maxP,192] fp32 voxel tensor; returns dict of NCHW intermediates"""
-        bev = p32.map2bev(x, st32["coords"], st32["P"])[0].permute(0, 3, 1, 2)
+        bev = p32._m2b(x, st32["coords"], st32["P"])[0].permute(0, 3, 1, 2)
         d = p32.dense
         out = {}
         xx = bev

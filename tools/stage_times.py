@@ -14,8 +14,9 @@ def main():
     buf = np.zeros((1, caps.N, 4), np.float32); buf[0, :p.shape[0]] = p
     pts = torch.from_numpy(buf).to(dev); n = torch.tensor([p.shape[0]], dtype=torch.int32, device=dev)
     ref = None
-    for hd, lc, hh in [(torch.float32, 0, False), (torch.float16, 1, False), (torch.float16, 1, True)]:
-        pipe = pkg.pipeline.DsvtPipeline(w, caps=caps, device=dev, head_dtype=hd, linear_compute=lc, hip_head=hh)
+    from tools.vendor_dense import VendorDensePipeline
+    for hd, lc, hh in [(torch.float32, 0, False), (torch.float16, 1, False), (torch.float16, 1, True), (torch.float32, 2, True)]:
+        pipe = (pkg.pipeline.DsvtPipeline if hh else VendorDensePipeline)(w, caps=caps, device=dev, head_dtype=hd, linear_compute=lc)
         for _ in range(4):
             out = pipe.forward(pts, n)
         torch.cuda.synchronize()
