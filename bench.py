@@ -439,6 +439,7 @@ def main():
                                                                "really goes through RCCL (SURVEY 8e: exercising the collective on one device)")
     ap.add_argument("--share-gpu", action="store_true", help="N > visible GPUs: rank r uses GPU r mod visible (a launcher / RCCL dry run on one device; "
                                                              "the line is marked and is NOT a scaling number)")
+    ap.add_argument("--dump-rows", default=None, help="rank 0 saves the gathered result rows [K * N, 4501] of the headline mode as .npy (tests: the gather against single-process rows)")
     ap.add_argument("--no-whole-network-cpu", action="store_true", help="cpu_baseline skips the whole network on the CPU oracle (~10 s; also drops box_err_vs_oracle)")
     args = ap.parse_args()
     # the product library reads no environment switch (csrc/plugin_base.h ablateEnv), and a timed run must not load another build either
@@ -463,7 +464,9 @@ def main():
     if ngpu < lr + 1 and not shared:
         raise SystemExit(f"bench.py: rank {os.environ.get('RANK')} has no GPU (only {ngpu} visible)")
     dev_index = lr % ngpu
-    rank, local_rank, world = par.init(single_rank_group=args.rccl_single, device_index=dev_index)
+    # RCCL refuses two ranks of a communicator on one device ("Duplicate GPU detected", probed with tools/rccl_same_device.py), so the
+    # shared-device dry run gathers through gloo (rows staged through the host); every other run is nccl = RCCL
+    rank, local_rank, world = par.init(single_rank_group=args.rccl_single, device_index=dev_index, backend="gloo" if shared else None)
     par.barrier()
     pkg = G.load_package()
     par = pkg.parallel
@@ -480,9 +483,11 @@ def main():
 
     # synthetic frames of this rank, resident in HBM before the timed region
     K = args.steps
-    nclouds = max(FB, min(FRAME_POOL, max(K, 1)))
-    nclouds = -(-nclouds // FB) * FB                # whole forwards; >= NS distinct pool entries when the steps allow it
-    clouds = [pkg.synth.lidar_like(args.points, seed=rank * FRAME_POOL + i) for i in range(max(nclouds, min(K, FB * max(1, args.streams))))]
+    # distinct clouds of this rank: whole forwards, at least one per stream when the steps allow it (so that the streams do not replay the
+    # same four clouds), seeds rank * C + i
+    nclouds = -(-max(FB, min(FRAME_POOL, max(K, 1))) // FB) * FB
+    nclouds = max(nclouds, (min(K, FB * max(1, args.streams)) // FB) * FB)
+    clouds = [pkg.synth.lidar_like(args.points, seed=rank * nclouds + i) for i in range(nclouds)]
     pool = []                                       # entries = the inputs of one forward(): FB consecutive clouds, frame f in rows f * caps.N ...
     for j in range(max(1, len(clouds) // FB)):
         buf = np.zeros((1, FB * caps.N, 4), np.float32); ns = []
@@ -519,6 +524,8 @@ def main():
         total = K * world
         if world > 1:
             assert gathered is not None and gathered.shape[0] == total
+        if args.dump_rows and mode == args.dtype:
+            np.save(args.dump_rows, gathered.cpu().numpy())
         med = float(np.median(dts))
         rest = dts[1:] if (sampled and len(dts) > 1) else dts
         out = dict(value=round(total / med, 3), ms_per_step=round(1e3 * med / K, 4), p50_ms=round(float(np.median(frame_ms)), 4), repeats=len(dts),
@@ -554,9 +561,10 @@ def main():
                                    "468x468 BEV, full 4-block DSVT pillar backbone + BEV ResNet + CenterHead + top-K decode + "
                                    "FilterBoxByScore" + ("" if args.no_nms else " + rotated NMS (final boxes)") + "; seeded random weights (dsvt.wts is not shipped)",
                        "frames_per_gpu": K, "parallelism": f"frame-batch dp{world}, one result gather",
-                       "frames": f"{len(clouds)} distinct clouds per rank, seeds rank * {FRAME_POOL} + i, cycled (BASELINE configs[3]: "
-                                 f"32 frames lidar_like(180000, 0..31), 4 per GPU on 8 GPUs)",
-                       "result_gather": ("rccl gather" if world > 1 else "rccl gather (communicator of size 1)" if args.rccl_single
+                       "frames": f"{len(clouds)} distinct clouds per rank, seeds rank * {len(clouds)} + i, cycled (BASELINE configs[3]: "
+                                 f"32 frames lidar_like(180000, 0..31) over 8 GPUs, four frames per forward)",
+                       "result_gather": ("gloo gather through the host (ranks share a device: RCCL refuses duplicate GPUs)" if shared else
+                                         "rccl gather" if world > 1 else "rccl gather (communicator of size 1)" if args.rccl_single
                                          else "none (single process)"),
                        "graph_replay_equals_eager": head["graph_replay_equals_eager"],
                        "launch": "hip-graph replay per forward" if not args.no_graph else "host launch per op",
@@ -568,8 +576,9 @@ def main():
             "roofline_other_kernels": head["roofline_other_kernels"],
         }
         if shared:
-            line["config"]["shared_gpu"] = (f"{world} ranks on {ngpu} visible GPU(s) (--share-gpu): a launcher / RCCL dry run, NOT a scaling number -- "
+            line["config"]["shared_gpu"] = (f"{world} ranks on {ngpu} visible GPU(s) (--share-gpu): a launcher / sharding / gather dry run, NOT a scaling number -- "
                                             "n_gpus counts ranks, the ranks time-share the device")
+            line["metric"] += " [DRY RUN: ranks share a device]"
     mode_rows = {}
 
     def fb_rows(run_, tag):

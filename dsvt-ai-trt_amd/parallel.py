@@ -62,7 +62,11 @@ def gather_results(local, n_frames, rank, world, dst=0, force_collective=False):
     if world == 1 and not (force_collective and dist.is_initialized()):
         return local
     per = (n_frames + world - 1) // world
-    pad = torch.zeros((per, ROW), dtype=local.dtype, device=local.device)
+    # gloo gathers host tensors only: device rows are staged through the host (the CPU tests, and bench.py --share-gpu, where RCCL
+    # refuses two ranks on one device: "Duplicate GPU detected"); with nccl (= RCCL) the rows never leave the devices
+    stage = local.is_cuda and dist.get_backend() == "gloo"
+    gdev = torch.device("cpu") if stage else local.device
+    pad = torch.zeros((per, ROW), dtype=local.dtype, device=gdev)
     pad[:local.shape[0]].copy_(local)
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
     dist.gather(pad, bufs, dst=dst)
@@ -71,7 +75,7 @@ def gather_results(local, n_frames, rank, world, dst=0, force_collective=False):
     out = torch.empty((n_frames, ROW), dtype=local.dtype, device=local.device)
     for r in range(world):
         ids = shard_frames(n_frames, r, world)
-        out[ids] = bufs[r][:len(ids)]
+        out[ids] = bufs[r][:len(ids)].to(local.device)
     return out
 
 
@@ -83,6 +87,6 @@ def barrier():
 def max_over_ranks(value, device):
     if not dist.is_initialized():
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t[0])

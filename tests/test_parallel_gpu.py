@@ -38,3 +38,43 @@ def test_bench_single_rank_collective_line():
     assert line["n_gpus"] == 1 and line["config"]["result_gather"] == "rccl gather (communicator of size 1)"
     assert line["config"]["graph_replay_equals_eager"] is True
     assert line["value"] > 0
+
+
+def test_bench_two_ranks_sharing_the_gpu_gather_the_right_rows(pkg, tmp_path):
+    """Multi-rank dry run that can fail (gpurun boxes have ONE GPU): `bench.py --gpus 2 --share-gpu` launches two ranks through
+    torch.distributed.run, both on device 0; each runs its own frames (seeds 4 rank + i) through its own pipelines and the rows are
+    gathered between the two PROCESSES (gloo, staged through the host: RCCL refuses two ranks on one device -- "Duplicate GPU
+    detected", tools/rccl_same_device.py; the RCCL gather itself is covered by the size-1 communicator tests above).  The gathered
+    rows must be, bit for bit, what a single process computes for the same clouds, in global frame order f -> rank f mod 2; and the line
+    must say that it is a dry run, not a scaling number."""
+    import numpy as np
+    import torch
+    dump = str(tmp_path / "rows.npy")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "8", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-kernel-events", "--no-parity-mode", "--no-latency-mode", "--dump-rows", dump],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and "DRY RUN" in line["metric"] and "NOT a scaling number" in line["config"]["shared_gpu"]
+    assert line["config"]["result_gather"].startswith("gloo gather") and line["config"]["frames_per_forward"] == 4
+    got = np.load(dump)
+    assert got.shape == (16, 4501)
+    # single-process rows of the same clouds: rank r owns lidar_like(180000, 8 r + i), i = 0..7: two forwards of four frames
+    P = pkg.plugin
+    caps = pkg.pipeline.Caps.for_frames(4)
+    pipe = pkg.pipeline.DsvtPipeline(pkg.synth.make_weights(), caps=caps, device="cuda:0", linear_compute=P.COMPUTE_F16, head_dtype=torch.float16,
+                                     device_nms=True, frames=4)
+    rows = {}
+    for rk in range(2):
+        part = []
+        for fw in range(2):
+            buf = np.zeros((1, 4 * caps.N, 4), np.float32); ns = []
+            for f in range(4):
+                p = pkg.synth.lidar_like(180000, 8 * rk + 4 * fw + f); buf[0, f * caps.N:f * caps.N + len(p)] = p; ns.append(len(p))
+            boxes, cnt = pipe.forward(torch.from_numpy(buf).to("cuda:0"), torch.tensor(ns, dtype=torch.int32, device="cuda:0"))
+            torch.cuda.synchronize()
+            part.append(np.concatenate([boxes.reshape(4, -1).cpu().numpy(), cnt.float().cpu().numpy()[:, None]], 1))
+        rows[rk] = np.concatenate(part, 0)
+    for f in range(16):
+        assert np.array_equal(got[f], rows[f % 2][f // 2]), f
+    assert got[:, -1].min() > 0
