@@ -146,6 +146,8 @@ def cpu_baseline(caps, frames, n_parallel_frames=32, whole_network=None, mode_ro
         O.get_set(wp["gidx"], wp["cinw"], wp["vcnt"], wp["W"], gc)
     t_pre = time.perf_counter() - t0
     out = dict(value=round(1.0 / t_1, 2), unit="frames/s", cores=1, kind="port", cpu_model=cpu_model(), host_cores=cores,
+               definition="v2 (rounds 2+): the reference's HOST path per SURVEY 8(d) -- loadData + save_result + nms_cpu, one thread; round 1's key of the same "
+                          "name timed the whole network on the CPU oracle, which is `whole_network_port` here",
                sample=f"reference host path (loadData of a {frames[0][0].shape[0]}-point .bin zero-padded to {caps.N} + save_result + "
                       f"nms_cpu on the {frames[0][2]} FilterBoxByScore rows the GPU produced), {reps} frames, 1 thread",
                ms_per_frame=round(1e3 * t_1, 3), nms_kept=int(kept),
@@ -201,6 +203,7 @@ class ModeRun:
         self.static_in = [(torch.zeros_like(pool[0][0]), torch.zeros_like(pool[0][1])) for _ in range(NS)]
         self.scratch = [torch.zeros((FB, par.ROW), dtype=torch.float32, device=dev) for _ in range(NS)]
         self.replay_equals_eager = None
+        self.collective = world > 1 or args.rccl_single
 
     def pack(self, boxes, cnt, rows):
         """boxes [FB,500,9], cnt [FB] -> FB rows of the result buffer (two device ops, no host sync)"""
@@ -291,8 +294,14 @@ class ModeRun:
         dt0, fm0, sampled, gathered = self.timed(results, K, prof, sample=True)
         dts, fms = [dt0], []
         R = 1 if dt0 >= MIN_TIMED_S else min(MAX_REPEATS, max(3, int(np.ceil(MIN_TIMED_S / dt0))))
-        if self.world > 1:                                 # every rank takes the same number of repeats
-            R = int(self.par.max_over_ranks(float(R), self.dev))
+        if self.collective:
+            # ONE timed region when a communicator exists (N > 1, or --rccl-single): measured on this stack (ROCm 7.2, RCCL of torch 2.10), a
+            # third barrier / gather / barrier / all-reduce round interleaved with HIP-graph replays hangs (one stream) or faults (two) --
+            # `--rccl-single --repeats 3`; one or two rounds, round 2's protocol, are fine.  The N = 1 line without a communicator -- the
+            # one a short --steps makes noisy -- repeats.
+            R = 1
+        if self.args.repeats > 0:
+            R = self.args.repeats
         for _ in range(1, R):
             dt, frame_ms, _sm, g = self.timed(results, K, prof, sample=False)
             dts.append(dt); fms.extend(frame_ms)
@@ -439,6 +448,7 @@ def main():
                                                                "really goes through RCCL (SURVEY 8e: exercising the collective on one device)")
     ap.add_argument("--share-gpu", action="store_true", help="N > visible GPUs: rank r uses GPU r mod visible (a launcher / RCCL dry run on one device; "
                                                              "the line is marked and is NOT a scaling number)")
+    ap.add_argument("--repeats", type=int, default=0, help="repeats of the K-step timed loop (0 = as many as cover half a second, at least 3 when one is shorter than that)")
     ap.add_argument("--dump-rows", default=None, help="rank 0 saves the gathered result rows [K * N, 4501] of the headline mode as .npy (tests: the gather against single-process rows)")
     ap.add_argument("--no-whole-network-cpu", action="store_true", help="cpu_baseline skips the whole network on the CPU oracle (~10 s; also drops box_err_vs_oracle)")
     args = ap.parse_args()
@@ -569,7 +579,8 @@ def main():
                        "graph_replay_equals_eager": head["graph_replay_equals_eager"],
                        "launch": "hip-graph replay per forward" if not args.no_graph else "host launch per op",
                        "frames_in_flight": run.NS * FB, "frames_per_forward": FB,
-                       "timing": f"K = {K} steps per repeat between barrier + synchronize; value = median of `repeats` repeats; repeat 0 carries the roofline sample",
+                       "timing": f"K = {K} steps per repeat between barrier + synchronize; value = median of `repeats` repeats; repeat 0 carries the roofline sample"
+                                 + ("; ONE repeat when a communicator exists (RCCL rounds interleaved with graph replays beyond two hang on this stack)" if run.collective else ""),
                        "caps": dict(points=caps.N, pillars=caps.P, windows=caps.W, sets=caps.S, overflow_free=caps.overflow_free()),
                        "frame0": head["frame0"]},
             "roofline": head["roofline"],

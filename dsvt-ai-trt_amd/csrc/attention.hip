@@ -42,6 +42,7 @@ struct AttnArgs {
     void* out; int out_ld;               // fp32 or (IO16) fp16
     int C, H;
     int dbg;                             // timing ablations of the fp16 kernel (wrong results): 1 no gathers, 2 no stores, 4 no arithmetic
+    int split;                           // fp32 I/O on the split-precision kernel (hi / lo fp16 operand pairs) instead of v_mfma_f32_16x16x4_f32
 };
 
 // IO16: Q/K/V rows arrive as fp16 and the result is written as fp16; the arithmetic in between
@@ -374,6 +375,182 @@ set_attention_f16_kernel(AttnArgs a)
     }
 }
 
+// -------------------------------------------------------------------------------------
+// Split precision (round 3): fp32 Q / K / V rows in, fp32 rows out, the two products of the attention core at fp32 GRADE on the fp16
+// matrix cores.  The fp32 kernel at the top of this file spends its time in 126 v_mfma_f32_16x16x4_f32 per head (32 cycles each) and
+// in fp32 LDS images; here every operand is the pair hi = fp16(v), lo = fp16(v - hi) and a product is three 16x16x32 fp16 MFMAs:
+//     S^T = K_hi Q_hi^T + K_lo Q_hi^T + K_hi Q_lo^T            (27 MFMAs per head)
+//     O^T = V_hi^T P_hi^T + V_lo^T P_hi^T + V_hi^T P_lo^T      (36 MFMAs per head; P split in registers after the fp32 softmax)
+// Layouts are set_attention_f16_kernel's (Q / K rows of 104 halfs, V transposed in 40-half rows), twice: 46.8 KB of LDS, three
+// workgroups per CU.  Softmax in fp32 with v_exp_f32 / v_rcp_f32 (1 ulp each: fp32 grade).
+__global__ void __launch_bounds__(256, 3)
+set_attention_split_kernel(AttnArgs a)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 sQ[2][AL * AQL];                 // [hi | lo]
+    __shared__ __attribute__((aligned(16))) _Float16 sK[2][AL * AQL];
+    __shared__ __attribute__((aligned(16))) _Float16 sVt[2][AHB * ADH * AVL + 16];
+    __shared__ uint32_t sRow[AL];
+    __shared__ float sMask[AHB][AL];
+
+    const int nhb = a.H / AHB;
+    const int set = blockIdx.x / nhb, hq = blockIdx.x % nhb;
+    uint32_t S = *a.set_num; if (S > (uint32_t)a.max_sets) S = a.max_sets;
+    if ((uint32_t)set >= S) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+
+    uint32_t myRow = (uint32_t)(set * AL + (tid < AL ? tid : 0)); float myMask = 0.f;
+    if (a.inds && tid < AL) myRow = a.inds[(size_t)set * AL + tid];
+    if (tid < AHB * AL) myMask = a.mask[(size_t)set * a.mask_set_stride + (size_t)(hq * AHB + tid / AL) * a.mask_head_stride + tid % AL];
+    // ---- stage the 36 gathered fp32 rows as hi / lo fp16: Q, K as rows, V transposed (see set_attention_f16_kernel for the order of the
+    // loads: all indices, all rows, then the LDS writes).  Item = (slot, Q | K, 4-channel chunk) / (4-channel chunk, slot) for V.
+    constexpr int NQK = (AL * 2 * 24 + 255) / 256, NV = (24 * AL + 255) / 256, NIT = NQK + NV;
+    int slotOf[NIT], segOf[NIT], c4Of[NIT]; bool live[NIT];
+#pragma unroll
+    for (int k = 0; k < NQK; ++k) {
+        const int i = tid + 256 * k; live[k] = i < AL * 2 * 24;
+        const int ii = live[k] ? i : 0, rem = ii % 48;
+        slotOf[k] = ii / 48; segOf[k] = rem / 24; c4Of[k] = (rem % 24) * 4;
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = tid + 256 * k; live[NQK + k] = i < 24 * AL;
+        const int ii = live[NQK + k] ? i : 0;
+        slotOf[NQK + k] = ii % AL; segOf[NQK + k] = 2; c4Of[NQK + k] = (ii / AL) * 4;
+    }
+    uint32_t rowOf[NIT];
+    if (a.inds) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) rowOf[k] = a.inds[(size_t)set * AL + slotOf[k]];
+    } else {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) rowOf[k] = (uint32_t)(set * AL + slotOf[k]);
+    }
+    floatx4 val[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k)
+        val[k] = *reinterpret_cast<const floatx4*>(static_cast<const float*>(a.qkv) + (size_t)rowOf[k] * a.qkv_ld + segOf[k] * a.C + hq * (AHB * ADH) + c4Of[k]);
+    if (tid < AL) sRow[tid] = myRow;
+    if (tid < AHB * AL) sMask[tid / AL][tid % AL] = myMask;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        if (!live[k]) continue;
+        _Float16 h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h[j] = (_Float16)__builtin_fminf(__builtin_fmaxf(val[k][j], -65504.f), 65504.f);
+            l[j] = (_Float16)__builtin_fminf(__builtin_fmaxf(val[k][j] - (float)h[j], -65504.f), 65504.f);
+        }
+        if (k < NQK) {
+            _Float16* dh = (segOf[k] == 0 ? sQ[0] : sK[0]) + slotOf[k] * AQL + c4Of[k];
+            _Float16* dl = (segOf[k] == 0 ? sQ[1] : sK[1]) + slotOf[k] * AQL + c4Of[k];
+            *reinterpret_cast<ahalf4*>(dh) = ahalf4{h[0], h[1], h[2], h[3]};
+            *reinterpret_cast<ahalf4*>(dl) = ahalf4{l[0], l[1], l[2], l[3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sVt[0][(c4Of[k] + j) * AVL + slotOf[k]] = h[j]; sVt[1][(c4Of[k] + j) * AVL + slotOf[k]] = l[j]; }
+        }
+    }
+    __syncthreads();
+
+    const int hoff = wave * ADH;
+    const ahalf8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // ---- S^T[key][query] = sum_d K[key][d] Q[query][d] ----------------------------------------------
+    floatx4 sc[3][3];
+    {
+        ahalf8 kh[3], kl[3], qh[3], ql[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            int row = 16 * t + r; row = row < AL ? row : AL - 1;          // rows >= 36 are padding: clamp, mask later
+            const int o = row * AQL + hoff + g * 8;
+            kh[t] = g < 3 ? *reinterpret_cast<const ahalf8*>(&sK[0][o]) : zero8; kl[t] = g < 3 ? *reinterpret_cast<const ahalf8*>(&sK[1][o]) : zero8;
+            qh[t] = g < 3 ? *reinterpret_cast<const ahalf8*>(&sQ[0][o]) : zero8; ql[t] = g < 3 ? *reinterpret_cast<const ahalf8*>(&sQ[1][o]) : zero8;
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                floatx4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[t], qh[u], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[t], ql[u], c, 0, 0, 0);
+                sc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[t], qh[u], c, 0, 0, 0);
+            }
+    }
+    // ---- softmax over keys for each query column (lane holds keys 16t + 4g + i, query 16u + r) ----
+    constexpr float kLog2e = 1.4426950408889634f;
+    float mk[3][4];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { int key = 16 * t + 4 * g + i; mk[t][i] = key < AL ? sMask[wave][key] : -INFINITY; }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float v = sc[t][u][i] + mk[t][i]; sc[t][u][i] = v; mx = fmaxf(mx, v); }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, kWave)); mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float e = __builtin_amdgcn_exp2f((sc[t][u][i] - mx) * kLog2e); sc[t][u][i] = e; sum += e; }
+        sum += __shfl_xor(sum, 16, kWave); sum += __shfl_xor(sum, 32, kWave);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sc[t][u][i] *= inv;
+    }
+    // ---- O[query][d] = sum_key P[query][key] V[key][d] -------------------------------------------------
+    ahalf8 vb[2][2][2];                  // [hi | lo][channel tile][k-step]
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const bool dv = 16 * dt + r < ADH;
+            const _Float16* pv = &sVt[pl][(hoff + (dv ? 16 * dt + r : 0)) * AVL + 4 * g];
+            const ahalf4 v0 = *reinterpret_cast<const ahalf4*>(pv), v1 = *reinterpret_cast<const ahalf4*>(pv + 16), v2 = *reinterpret_cast<const ahalf4*>(pv + 32);
+            ahalf8 b0 = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            ahalf8 b1 = {v2[0], v2[1], v2[2], v2[3], 0, 0, 0, 0};
+            vb[pl][dt][0] = dv ? b0 : zero8; vb[pl][dt][1] = (dv && g == 0) ? b1 : zero8;      // keys 32 + 4g + i: only g = 0 is real (and staged)
+        }
+    floatx4 oc[3][2];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        _Float16 ph[12], pl_[12];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float p = sc[t][u][i]; ph[4 * t + i] = (_Float16)p; pl_[4 * t + i] = (_Float16)(p - (float)ph[4 * t + i]); }      // 0 <= p <= 1
+        const ahalf8 p0h = {ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]}, p1h = {ph[8], ph[9], ph[10], ph[11], 0, 0, 0, 0};
+        const ahalf8 p0l = {pl_[0], pl_[1], pl_[2], pl_[3], pl_[4], pl_[5], pl_[6], pl_[7]}, p1l = {pl_[8], pl_[9], pl_[10], pl_[11], 0, 0, 0, 0};
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            floatx4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[1][dt][0], p0h, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[1][dt][1], p1h, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[0][dt][0], p0l, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[0][dt][1], p1l, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[0][dt][0], p0h, c, 0, 0, 0);
+            oc[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[0][dt][1], p1h, c, 0, 0, 0);
+        }
+    }
+    // ---- write back: lane holds query 16u + r, channels 16dt + 4g + i -------------------------
+    const int h = hq * AHB + wave;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int q = 16 * u + r;
+        if (q >= AL) continue;
+        if (a.inds && sMask[wave][q] < 0.f) continue;      // duplicate slot: the first occurrence writes the identical row
+        float* dst = static_cast<float*>(a.out) + (size_t)sRow[q] * a.out_ld + h * ADH + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            if (16 * dt + 4 * g >= ADH) continue;
+            *reinterpret_cast<floatx4*>(dst + 16 * dt) = oc[u][dt];
+        }
+    }
+}
+
 static int launchAttention(const AttnArgs& a_, bool io16, hipStream_t stream) {
     static int dbg = -1;
     if (dbg < 0) dbg = ablateEnv("DSVT_ATTN_DBG", 0);
@@ -383,6 +560,7 @@ static int launchAttention(const AttnArgs& a_, bool io16, hipStream_t stream) {
     if (f16mma < 0) f16mma = ablateEnv("DSVT_ATTN_F32MMA", 0) ? 0 : 1;
     if (io16 && f16mma) hipLaunchKernelGGL(set_attention_f16_kernel, grid, block, 0, stream, a);
     else if (io16) hipLaunchKernelGGL(set_attention_kernel<true>, grid, block, 0, stream, a);
+    else if (a.split) hipLaunchKernelGGL(set_attention_split_kernel, grid, block, 0, stream, a);
     else hipLaunchKernelGGL(set_attention_kernel<false>, grid, block, 0, stream, a);
     return lastError();
 }
@@ -510,12 +688,12 @@ public:
     bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int, int) const override {
         if (pos == 1 || pos == 3) return i32Lin(io[pos]);
         if (pos == 2) return f32Lin(io[pos]);
-        return (pos == 0 || pos == 4) && io[pos].format == DSVT_FORMAT_LINEAR && io[pos].type == (io_half_ ? DSVT_HALF : DSVT_FLOAT);
+        return (pos == 0 || pos == 4) && io[pos].format == DSVT_FORMAT_LINEAR && io[pos].type == (io_half_ == 1 ? DSVT_HALF : DSVT_FLOAT);
     }
     size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override { return 0; }
     int enqueue(const DsvtPluginTensorDesc*, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void*,
                 hipStream_t stream) override {
-        if (zeroFill) DSVT_CHECK(hipMemsetAsync(out[0], 0, (io_half_ ? 2 : 4) * (size_t)max_pillars_num_ * C_, stream));   // mapSetFeature2voxel.cu:314
+        if (zeroFill) DSVT_CHECK(hipMemsetAsync(out[0], 0, (io_half_ == 1 ? 2 : 4) * (size_t)max_pillars_num_ * C_, stream));   // mapSetFeature2voxel.cu:314
         AttnArgs aa{};
         aa.qkv = in[0]; aa.qkv_ld = 3 * C_;
         aa.inds = static_cast<const uint32_t*>(in[1]) + (size_t)axis_id_ * max_win_num_ * L_;    // getValueByIndex.cu:292
@@ -523,8 +701,8 @@ public:
         // the two axes mask the same slots, so axis 0 is used here too
         aa.mask = static_cast<const float*>(in[2]); aa.mask_set_stride = L_; aa.mask_head_stride = 0;
         aa.set_num = static_cast<const uint32_t*>(in[3]); aa.max_sets = max_win_num_;
-        aa.out = out[0]; aa.out_ld = C_; aa.C = C_; aa.H = H_;
-        return launchAttention(aa, io_half_ != 0, stream);
+        aa.out = out[0]; aa.out_ld = C_; aa.C = C_; aa.H = H_; aa.split = io_half_ == 2;
+        return launchAttention(aa, io_half_ == 1, stream);
     }
     size_t serializationSize() const override { return 7 * sizeof(int); }
     void serialize(void* buf) const override {
@@ -534,7 +712,7 @@ public:
     Plugin* clone() const override { return new DsvtSetAttentionPlugin(max_win_num_, L_, C_, H_, axis_id_, max_pillars_num_, io_half_); }
 };
 static Plugin* saNew(int mw, int L, int C, int H, int axis, int mp, int io_half) {
-    return (attnShapeOk(mw, L, C, H) && (axis == 0 || axis == 1) && mp > 0 && (io_half == 0 || io_half == 1))
+    return (attnShapeOk(mw, L, C, H) && (axis == 0 || axis == 1) && mp > 0 && io_half >= 0 && io_half <= 2)      // io_half 2: fp32 I/O, split-precision products
                ? new DsvtSetAttentionPlugin(mw, L, C, H, axis, mp, io_half) : nullptr;
 }
 static Plugin* saCreate(const DsvtPluginFieldCollection* fc) {

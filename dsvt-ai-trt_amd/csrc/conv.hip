@@ -1397,6 +1397,15 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
         }
         if (nwide >= ncu) {
             // halo row stride 36 pixels, not 40: 134,144 B of LDS instead of 142,336 (room for the OTHER frame's 23 KB attention workgroups)
+            // Round-3 experiments, measured and dropped (one wave per SIMD loses both times -- a lone wave cannot hide its own LDS-DMA issue,
+            // fragment-read latency and barrier waits, whatever it saves in fragment reads):
+            //  * conv_wide_kernel<8, 4, 36, 2, 3, 4>: four waves of FOUR rows, 128 pixels x 128 channels = 256 accumulator registers per wave,
+            //    16 fragment reads per 64 MFMAs instead of 12 per 32 -- hipcc spills 111-138 of the 512 registers; a 468 x 468 128 -> 128 layer
+            //    takes 425 us per four frames against 278;
+            //  * a split-native variant for the fp32-grade mode (per (32-channel group, tap) step the hi AND lo halo planes and the w_hi AND
+            //    w_lo rows in LDS, three MFMAs per fragment pair: a third less halo / weight traffic and 0.25 fragment reads per MFMA instead
+            //    of 0.375; LDS only holds 8-row tiles then, four waves of two rows): correct (boxes within 1e-5) and 364 registers without a
+            //    spill, but 860-1054 us per 468 x 468 128 -> 128 layer against 831-954 for the plain kernel walking the [hi | lo | hi] triple.
             if (ctWide == 8) DSVT_WIDE(ncu, 512, nwide, nchunk, 8, 8, 36, 2, 3, 2);
             else DSVT_WIDE(ncu, 512, nwide, nchunk, 4, 8, 40, 4, 2, 2);
         }

@@ -26,6 +26,7 @@ struct LinearArgs {
     // gathered A2 (streamed fp16 kernel only): when a2_c2d != nullptr row m adds A2 row c2d[m][1] * a2_wx + c2d[m][2] (the window
     // cell of voxel m, WindowPartition output 4) instead of A2 row m: A2 is then a per-layer TABLE of position embeddings
     const int32_t* a2_c2d; int a2_wx;
+    int a2_wy;            // 3-D windows: the table row is (c2d[m][0] * a2_wy + c2d[m][1]) * a2_wx + c2d[m][2]; 0 for the pillar model (z = 0)
     float eps;
     unsigned long long* trace;    // debugging: per-workgroup phase timestamps (s_memtime) of the streamed kernel, or nullptr
 };

@@ -471,7 +471,7 @@ __device__ __forceinline__ void linearStreamBody(const LinearArgs a, const _Floa
                 size_t o2 = o;
                 if (a.a2_c2d) {                          // table row = window cell of this voxel
                     const int32_t* c = a.a2_c2d + (size_t)rc[mt] * 3;
-                    o2 = (size_t)(c[1] * a.a2_wx + c[2]) * KS + g * 8;
+                    o2 = (size_t)((c[0] * a.a2_wy + c[1]) * a.a2_wx + c[2]) * KS + g * 8;
                 }
 #pragma unroll
                 for (int s = 0; s < NSTEP; ++s) f[mt][s] = loadFrag<AMODE == 1, true>(a.A, a.A2, o + s * 32, o2 + s * 32);
@@ -637,7 +637,7 @@ linear_f16_rows_kernel(LinearArgs a, const _Float16* __restrict__ Wp, int ncu)
     {
         const size_t o = (size_t)rc * KS + g * 8;
         size_t o2 = o;
-        if (a.a2_c2d) { const int32_t* c = a.a2_c2d + (size_t)rc * 3; o2 = (size_t)(c[1] * a.a2_wx + c[2]) * KS + g * 8; }
+        if (a.a2_c2d) { const int32_t* c = a.a2_c2d + (size_t)rc * 3; o2 = (size_t)((c[0] * a.a2_wy + c[1]) * a.a2_wx + c[2]) * KS + g * 8; }
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) fx[s] = *reinterpret_cast<const half8*>(static_cast<const _Float16*>(a.A) + o + s * 32);
 #pragma unroll
@@ -744,7 +744,7 @@ linear_f16_resident_kernel(LinearArgs a, const _Float16* __restrict__ Wp)
         const int row = t * 16 + r, rc = row < M ? row : M - 1;
         if (!TABLE) return make_int2(0, rc);
         const int32_t* c = a.a2_c2d + (size_t)rc * 3;
-        return make_int2(c[1], c[2]);
+        return make_int2(c[0] * a.a2_wy + c[1], c[2]);      // (z * wy + y, x): a2_wy = 0 for the pillar model's 2-D tables
     };
     auto loadRows = [&](int t, int2 cell, half8 (&x)[NSTEP], half8 (&p)[NSTEP]) {
         t = t < ntile ? t : ntile - 1;
@@ -900,7 +900,7 @@ linear_split_rows_kernel(LinearArgs a, const _Float16* __restrict__ Wp)
     {
         const float* px = static_cast<const float*>(a.A) + (size_t)rc * KS + g * 8;
         size_t o2 = (size_t)rc * KS + g * 8;
-        if (TABLE) { const int32_t* c = a.a2_c2d + (size_t)rc * 3; o2 = (size_t)(c[1] * a.a2_wx + c[2]) * KS + g * 8; }
+        if (TABLE) { const int32_t* c = a.a2_c2d + (size_t)rc * 3; o2 = (size_t)((c[0] * a.a2_wy + c[1]) * a.a2_wx + c[2]) * KS + g * 8; }
         const bool hasA2 = a.add_cols > 0;
         const float* pp = hasA2 ? static_cast<const float*>(a.A2) + o2 : px;
         floatx4 xv[2 * NSTEP], pv[2 * NSTEP];
@@ -1073,6 +1073,7 @@ struct LinCfg {
     int input_half;        // A / A2 tensors are fp16 (needs compute_type 1)
     int output_mode;       // OUT_F32: one fp32 output; OUT_F16: one fp16 output; OUT_BOTH: fp32 + fp16 copy
     int a2_gather_wx;      // > 0: input 2 is a [cells, K] table and input 3 the [rows, 3] window coordinates (z, y, x); row m adds table row y * wx + x
+    int a2_gather_wy;      // > 0 (optional field "add_gather_height", 3-D windows: BASELINE configs[4]): table row (z * wy + y) * wx + x
 };
 
 class DsvtLinearPlugin : public Plugin {
@@ -1161,7 +1162,7 @@ public:
         }
         a.count = static_cast<const uint32_t*>(in[idx++]);
         a.A2 = c_.add_cols > 0 ? in[idx++] : nullptr;
-        if (c_.a2_gather_wx > 0) { a.a2_c2d = static_cast<const int32_t*>(in[idx++]); a.a2_wx = c_.a2_gather_wx; }
+        if (c_.a2_gather_wx > 0) { a.a2_c2d = static_cast<const int32_t*>(in[idx++]); a.a2_wx = c_.a2_gather_wx; a.a2_wy = c_.a2_gather_wy; }
         for (int s = 0; s < c_.n_ln; ++s) {
             a.res[s] = static_cast<const float*>(in[idx++]);
             a.gamma[s] = g_dev_ + (size_t)s * c_.N; a.beta[s] = be_dev_ + (size_t)s * c_.N;
@@ -1194,7 +1195,7 @@ public:
         return useF16() ? launchLinearF16(a, wh_dev_, stream) : launchLinearF32(a, stream);
     }
     size_t serializationSize() const override {
-        return 13 * sizeof(int) + sizeof(float) + sizeof(float) * (w_.size() + b_.size() + g_.size() + be_.size() + pe_.size());
+        return 13 * sizeof(int) + sizeof(float) + sizeof(float) * (w_.size() + b_.size() + g_.size() + be_.size() + pe_.size()) + (c_.a2_gather_wy > 0 ? sizeof(int) : 0);
     }
     void serialize(void* buf) const override {
         char* d = static_cast<char*>(buf);
@@ -1202,6 +1203,7 @@ public:
         wr<int>(d, c_.n_ln); wr<float>(d, c_.eps); wr<int>(d, b_.empty() ? 0 : 1); wr<int>(d, c_.compute_type);
         wr<int>(d, c_.input_half); wr<int>(d, c_.output_mode); wr<int>(d, pe_.empty() ? 0 : 1); wr<int>(d, c_.a2_gather_wx);
         for (const std::vector<float>* v : {&w_, &b_, &g_, &be_, &pe_}) { memcpy(d, v->data(), sizeof(float) * v->size()); d += sizeof(float) * v->size(); }
+        if (c_.a2_gather_wy > 0) wr<int>(d, c_.a2_gather_wy);       // (trailing, only when set: older blobs stay valid)
     }
     Plugin* clone() const override {
         DsvtLinearPlugin* p = new DsvtLinearPlugin(c_, w_.data(), b_.empty() ? nullptr : b_.data(), g_.data(), be_.data());
@@ -1223,6 +1225,7 @@ static Plugin* linNew(const LinCfg& c, const float* w, const float* b, const flo
     if (c.n_ln > 0 && (c.N > BN || !g || !be)) return nullptr;             // a LayerNorm row must fit one tile
     if (c.add_cols < 0 || c.add_cols > c.N || (c.add_cols % BN != 0 && c.add_cols != c.N)) return nullptr;
     if (c.input_half && !(c.compute_type == 1 && c.K % KS == 0)) return nullptr;      // fp16 inputs only on the fp16 kernel
+    if (c.a2_gather_wy < 0 || (c.a2_gather_wy > 0 && c.a2_gather_wx <= 0)) return nullptr;
     if (c.a2_gather_wx < 0 || (c.a2_gather_wx > 0 && !(c.add_cols > 0 && (c.input_half || c.compute_type == 2) && c.K == KS))) return nullptr;   // table gather: streamed fp16 / split kernels
     return new DsvtLinearPlugin(c, w, b, g, be, pe_w, pe_b);
 }
@@ -1234,7 +1237,7 @@ static Plugin* linCreate(const DsvtPluginFieldCollection* fc) {
     c.row_mult = fieldInt(fc, "row_mult", 1); c.act = fieldInt(fc, "activation"); c.add_cols = fieldInt(fc, "add_cols");
     c.n_ln = fieldInt(fc, "num_layer_norms"); c.eps = fieldFloat(fc, "ln_eps", 0.f); c.compute_type = fieldInt(fc, "compute_type", 0);
     c.input_half = fieldInt(fc, "input_half", 0); c.output_mode = fieldInt(fc, "output_mode", 0);
-    c.a2_gather_wx = fieldInt(fc, "add_gather_width", 0);
+    c.a2_gather_wx = fieldInt(fc, "add_gather_width", 0); c.a2_gather_wy = fieldInt(fc, "add_gather_height", 0);
     if (!w || !w->data || c.K <= 0 || c.N <= 0 || w->length != c.K * c.N) return nullptr;
     if (b && b->data && b->length != c.N) return nullptr;
     if (c.n_ln > 0 && (!g || !be || g->length != c.n_ln * c.N || be->length != c.n_ln * c.N)) return nullptr;
@@ -1258,6 +1261,7 @@ static Plugin* linDeser(const void* data, size_t len) {
     memcpy(all.data(), d, need * sizeof(float));
     const float* w = all.data(); const float* b = has_b ? w + (size_t)c.K * c.N : nullptr;
     const float* g = w + (size_t)c.K * c.N + (has_b ? c.N : 0); const float* be = g + (size_t)c.n_ln * c.N;
+    { const size_t used = 13 * sizeof(int) + sizeof(float) + need * sizeof(float); if (len >= used + sizeof(int)) { const char* t = static_cast<const char*>(data) + used; c.a2_gather_wy = rd<int>(t); } }
     if (has_pe) {                                  // stored as [w0 | w1 | b]; rebuild the [K][2] weight the constructor expects
         const float* pe = be + (size_t)c.n_ln * c.N;
         std::vector<float> pw(2 * (size_t)c.K);
@@ -1270,7 +1274,7 @@ static Creator g_linCreator{"DsvtLinearPlugin",
     {{"max_rows", DSVT_FIELD_INT32}, {"in_features", DSVT_FIELD_INT32}, {"out_features", DSVT_FIELD_INT32},
      {"row_mult", DSVT_FIELD_INT32}, {"activation", DSVT_FIELD_INT32}, {"add_cols", DSVT_FIELD_INT32},
      {"num_layer_norms", DSVT_FIELD_INT32}, {"ln_eps", DSVT_FIELD_FLOAT32}, {"compute_type", DSVT_FIELD_INT32},
-     {"input_half", DSVT_FIELD_INT32}, {"output_mode", DSVT_FIELD_INT32}, {"add_gather_width", DSVT_FIELD_INT32},
+     {"input_half", DSVT_FIELD_INT32}, {"output_mode", DSVT_FIELD_INT32}, {"add_gather_width", DSVT_FIELD_INT32}, {"add_gather_height", DSVT_FIELD_INT32},
      {"weight", DSVT_FIELD_FLOAT32}, {"bias", DSVT_FIELD_FLOAT32}, {"ln_weights", DSVT_FIELD_FLOAT32}, {"ln_bias", DSVT_FIELD_FLOAT32},
      {"pe_weight", DSVT_FIELD_FLOAT32}, {"pe_bias", DSVT_FIELD_FLOAT32}},
     linCreate, linDeser, {}, {}};

@@ -131,7 +131,11 @@ wp_fill(const uint4* __restrict__ coords, WPParams p, const uint32_t* __restrict
     extern __shared__ uint32_t lds[];
     const uint32_t r = blockIdx.x;
     if (r >= *win_num) return;
-    const uint32_t w = rank2win[r], n = win_cnt[w], seg = win_seg[w];
+    // A window can only hold more voxels than its dynamic LDS (2 x pow2(volume) words) when the caller hands in DUPLICATE pillar
+    // coordinates, which Points2Features cannot produce; the surplus segment entries are then dropped (which ones is as unspecified as
+    // the reference's racy order beyond its cap, windowPartition.cu:305) instead of being sorted out of bounds.
+    uint32_t cap2 = 2; { const uint32_t v3 = (uint32_t)(p.wx * p.wy * p.wz); uint32_t c1 = 1; while (c1 < v3) c1 <<= 1; cap2 = 2 * c1; }
+    const uint32_t w = rank2win[r], n = win_cnt[w] < cap2 ? win_cnt[w] : cap2, seg = win_seg[w];
     const uint32_t Vw = p.max_voxel_num_per_win;
     // Voxel ids ascend with the cell key y * GX + x (Points2Features' canonical order), so inside a window of a one-level grid
     // "ascending voxel id" IS the row-major order of the in-window cells: the rank of a voxel is the number of occupied cells
@@ -547,9 +551,9 @@ sp_scan(const uint32_t* __restrict__ win_cnt, SPParams sp, uint32_t* __restrict_
     rank2win += (size_t)k * p.max_win_num; set_base += (size_t)k * p.max_win_num;
     const uint32_t L = (uint32_t)sp.voxel_num_set, Vw = (uint32_t)p.max_voxel_num_per_win;
     uint32_t carry_o = 0, carry_f = 0, carry_s = 0;
-    // four consecutive windows per thread: a 4096-window chunk per round of three workgroup scans (a 6400-window configuration of four
-    // frames is two rounds, not seven: 32 -> 12 us)
-    constexpr int WPT = 4;
+    // eight consecutive windows per thread: an 8192-window chunk per round of three workgroup scans (a 6400-window configuration of four
+    // frames is ONE round, not seven: 32 -> 19 us with four windows per thread)
+    constexpr int WPT = 8;
     for (int b = 0; b < dense; b += 1024 * WPT) {
         const int w0 = b + threadIdx.x * WPT;
         uint32_t c[WPT], so = 0, sf = 0;
@@ -663,7 +667,8 @@ sp_window(const uint4* __restrict__ coords, SPParams sp, const uint32_t* __restr
     rank2win += (size_t)k * p.max_win_num; set_base += (size_t)k * p.max_win_num;
     win_cnt += sp.dense_off[k]; win_seg += sp.dense_off[k]; sorted_vox += (size_t)k * sp.max_pillars;
     uint32_t* c2d = outs.c2d[k]; uint32_t* inds = outs.inds[k]; float* mask = outs.mask[k];
-    const uint32_t w = rank2win[r], nall = win_cnt[w], seg = win_seg[w];
+    // (a window with more voxels than its LDS region -- duplicate pillar coordinates only -- is truncated: see wp_fill)
+    const uint32_t w = rank2win[r], nall = win_cnt[w] < (uint32_t)cap_words ? win_cnt[w] : (uint32_t)cap_words, seg = win_seg[w];
     const uint32_t Vw = (uint32_t)p.max_voxel_num_per_win, L = (uint32_t)sp.voxel_num_set, MS = (uint32_t)sp.max_set_num;
     orderWindowVoxels(coords, p, nall, seg, sorted_vox, lds, bits);
     // ---- WindowPartition outputs that survive: in-window coordinates per voxel (:362-364); voxels beyond the cap are dropped (:305)

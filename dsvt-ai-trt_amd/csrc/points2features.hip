@@ -38,37 +38,56 @@ constexpr uint32_t kNone = 0xffffffffu;
 constexpr int kCPT = 16;         // consecutive cells per thread of the scan
 constexpr int kTile = 256 * kCPT;   // cells per scan tile: the look-back chain is one link per tile (1024-cell tiles, 428 links for two frames: 43 us)
 
+// cell key of one point, or kNone (out of range / out of the grid)
+__device__ __forceinline__ uint32_t p2fCellOf(const float4 q, const P2FParams& p, uint32_t fr) {
+    if (q.x < p.min_x || q.x >= p.max_x || q.y < p.min_y || q.y >= p.max_y || q.z < p.min_z || q.z >= p.max_z) return kNone;   // points2Features.cu:683-685
+    int ix = (int)floorf((q.x - p.min_x) / p.vx);             // :687
+    int iy = (int)floorf((q.y - p.min_y) / p.vy);             // :688
+    // fp32 rounding can give ix == gx for a point just below max_x; like the reference
+    // (:689-690) the linear index then aliases the first cell of the next row.  Only an
+    // index past the last cell (undefined behaviour in the reference) is dropped.
+    uint32_t c = (uint32_t)(iy * p.gx + ix);
+    if (p.gz > 1) {                                           // 3-D grid (not in the reference): same floorf rule for z
+        int iz = (int)floorf((q.z - p.min_z) / p.vz);
+        c = (uint32_t)((iz * p.gy + iy) * p.gx + ix);
+    }
+    if (c >= (uint32_t)(p.gx * p.gy * p.gz)) return kNone;
+    return c + fr * (uint32_t)(p.gx * p.gy * p.gz);           // frames are one more (slowest) grid dimension: pillars ascend by (frame, cell)
+}
+
+// FOUR points per thread (round 3): the kernel is bound by the round trip of its returning atomic -- 246 GB/s on a pure float4 stream with
+// one point per thread (profiles/r02_h_*: 46.8 us for four frames) -- so a thread issues its four loads, then its four atomics, and only
+// then waits: four round trips in flight per lane instead of one.  Rows i, i + 256, i + 512, i + 768 of a 1024-row block: every access
+// of a wave stays a contiguous 1 KB.
+constexpr int kPPT = 4;
 __global__ void __launch_bounds__(256)
 p2f_count(const float4* __restrict__ pts, const uint32_t* __restrict__ n_ptr, P2FParams p,
           uint32_t* __restrict__ cell_cnt, uint32_t* __restrict__ pt_cell, uint32_t* __restrict__ pt_slot)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t fr = i / (uint32_t)p.max_points_num;           // frame of this row (0 when frames == 1)
-    if (fr >= (uint32_t)p.frames) return;
-    uint32_t n = n_ptr[fr];
-    if (n > (uint32_t)p.max_points_num) n = p.max_points_num;
-    if (i - fr * (uint32_t)p.max_points_num >= n) return;
-    float4 q = pts[i];
-    uint32_t cell = kNone, slot = 0;
-    if (!(q.x < p.min_x || q.x >= p.max_x || q.y < p.min_y || q.y >= p.max_y ||
-          q.z < p.min_z || q.z >= p.max_z)) {                     // points2Features.cu:683-685
-        int ix = (int)floorf((q.x - p.min_x) / p.vx);             // :687
-        int iy = (int)floorf((q.y - p.min_y) / p.vy);             // :688
-        // fp32 rounding can give ix == gx for a point just below max_x; like the reference
-        // (:689-690) the linear index then aliases the first cell of the next row.  Only an
-        // index past the last cell (undefined behaviour in the reference) is dropped.
-        uint32_t c = (uint32_t)(iy * p.gx + ix);
-        if (p.gz > 1) {                                           // 3-D grid (not in the reference): same floorf rule for z
-            int iz = (int)floorf((q.z - p.min_z) / p.vz);
-            c = (uint32_t)((iz * p.gy + iy) * p.gx + ix);
+    const uint32_t i0 = blockIdx.x * (256u * kPPT) + threadIdx.x;
+    const uint32_t total = (uint32_t)p.max_points_num * (uint32_t)p.frames;
+    float4 q[kPPT]; uint32_t fr[kPPT]; bool live[kPPT];
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) {
+        const uint32_t i = i0 + 256u * k;
+        fr[k] = i / (uint32_t)p.max_points_num;                   // frame of this row (0 when frames == 1)
+        live[k] = i < total;
+        if (live[k]) {
+            uint32_t n = n_ptr[fr[k]];
+            if (n > (uint32_t)p.max_points_num) n = p.max_points_num;
+            live[k] = i - fr[k] * (uint32_t)p.max_points_num < n;
         }
-        if (c < (uint32_t)(p.gx * p.gy * p.gz)) {
-            cell = c + fr * (uint32_t)(p.gx * p.gy * p.gz);       // frames are one more (slowest) grid dimension: pillars ascend by (frame, cell)
-            slot = atomicAdd(&cell_cnt[cell], 1u);                // count only; order fixed later
-        }
+        q[k] = live[k] ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    pt_cell[i] = cell;
-    pt_slot[i] = slot;
+    uint32_t cell[kPPT], slot[kPPT];
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) {
+        cell[k] = live[k] ? p2fCellOf(q[k], p, fr[k]) : kNone;
+        slot[k] = cell[k] != kNone ? atomicAdd(&cell_cnt[cell[k]], 1u) : 0u;      // count only; order fixed later
+    }
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k)
+        if (live[k]) { pt_cell[i0 + 256u * k] = cell[k]; pt_slot[i0 + 256u * k] = slot[k]; }
 }
 
 __device__ __forceinline__ void cellTriple(uint32_t c, uint32_t T, uint32_t& occ, uint32_t& full, uint32_t& kept) {
@@ -77,20 +96,20 @@ __device__ __forceinline__ void cellTriple(uint32_t c, uint32_t T, uint32_t& occ
 
 // ---- single-pass scan over the cells ------------------------------------------------------------------------------
 // Three running sums travel together: occupied cells (-> pillar id), full point counts (-> segment offset) and kept point
-// counts (-> compact point offset).  A tile publishes one 64-bit word: flag (2 bits: 1 = aggregate of this tile, 2 = inclusive
-// prefix up to and including it) | occupied (20) | full (21) | kept (21); validP2F bounds max_points_num so that they fit.
+// counts (-> compact point offset).  Round 2 packed all three into ONE 64-bit word behind a 2-bit flag (20 + 21 + 21 bits), which capped
+// max_points_num x frames at 2^20: five frames per launch, or a million-point cap, were rejected.  Round 3 (CUB's layout for wide
+// types): a tile owns one FLAG word and two value slots of three 32-bit sums -- its aggregate and its inclusive prefix.  A slot is
+// written once, BEFORE the release store that moves the flag to the state that names it (1 = aggregate valid, 2 = inclusive prefix valid),
+// and a reader that acquires a flag value reads the slot that value names: the look-back polls one 4-byte word per predecessor, as before,
+// and the sums are full 32-bit counters.  (A first version with two independently flagged 64-bit words cost 41 us per four-frame launch
+// against 28 for the packed word: twice the polling traffic.)
 // Tiles take their index from a ticket counter, so a tile only ever waits for tiles that are already running.
-constexpr uint64_t kFlagAgg = 1ull << 62, kFlagInc = 2ull << 62;
-__device__ __forceinline__ uint64_t packState(uint64_t flag, uint32_t o, uint32_t f, uint32_t k) {
-    return flag | ((uint64_t)o << 42) | ((uint64_t)f << 21) | (uint64_t)k;
-}
-__device__ __forceinline__ void unpackState(uint64_t w, uint32_t& o, uint32_t& f, uint32_t& k) {
-    o = (uint32_t)((w >> 42) & 0xfffffu); f = (uint32_t)((w >> 21) & 0x1fffffu); k = (uint32_t)(w & 0x1fffffu);
-}
+constexpr uint32_t kFlagAgg = 1u, kFlagInc = 2u;
+constexpr int kStateWords = 8;                    // per tile: flag | pad | aggregate (occupied, full, kept) | inclusive (occupied, full, kept)
 
-// scan_state: [0] ticket counter (as uint64), [1 + t] state of tile t -- zeroed by the same memset as cell_cnt
+// scan_state: 32-bit words; [0] ticket counter, [8 + 8 t ..] the kStateWords of tile t -- zeroed by the same memset as cell_cnt
 __global__ void __launch_bounds__(256)
-p2f_scan(const uint32_t* __restrict__ cell_cnt, int ncell, P2FParams p, uint64_t* __restrict__ scan_state, int ntiles,
+p2f_scan(const uint32_t* __restrict__ cell_cnt, int ncell, P2FParams p, uint32_t* __restrict__ scan_state, int ntiles,
          uint32_t* __restrict__ cell_seg, uint32_t* __restrict__ pil_seg, uint32_t* __restrict__ pil_full,
          uint32_t* __restrict__ pil_ptoff, uint32_t* __restrict__ coords, uint32_t* __restrict__ pcnt,
          uint32_t* __restrict__ pillar_num, uint32_t* __restrict__ point_num)
@@ -98,10 +117,10 @@ p2f_scan(const uint32_t* __restrict__ cell_cnt, int ncell, P2FParams p, uint64_t
     __shared__ uint32_t smem[256 / kWave + 1];
     __shared__ uint32_t s_tile, s_pref[3];
     const uint32_t T = p.max_num_points_per_voxel;
-    if (threadIdx.x == 0) s_tile = (uint32_t)atomicAdd(reinterpret_cast<unsigned long long*>(scan_state), 1ull);
+    if (threadIdx.x == 0) s_tile = atomicAdd(scan_state, 1u);
     __syncthreads();
     const int tile = (int)s_tile;
-    uint64_t* state = scan_state + 1;
+    uint32_t* state = scan_state + kStateWords;
     const int base = tile * kTile + threadIdx.x * kCPT;
     uint32_t c[kCPT], o[kCPT], f[kCPT], k[kCPT], so = 0, sf = 0, sk = 0;
     if (base + kCPT - 1 < ncell) {
@@ -123,29 +142,40 @@ p2f_scan(const uint32_t* __restrict__ cell_cnt, int ncell, P2FParams p, uint64_t
     // ---- decoupled look-back (wave 0): prefix of all earlier tiles --------------------------------------------------
     if (threadIdx.x < kWave) {
         const int lane = threadIdx.x;
-        if (lane == 0)
-            __hip_atomic_store(&state[tile], packState(tile == 0 ? kFlagInc : kFlagAgg, to, tf, tk), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t* mine = state + (size_t)tile * kStateWords;
+        if (lane == 0) {
+            const int slot = tile == 0 ? 5 : 2;                               // (tile 0's aggregate IS its inclusive prefix)
+            mine[slot] = to; mine[slot + 1] = tf; mine[slot + 2] = tk;
+            __hip_atomic_store(mine, tile == 0 ? kFlagInc : kFlagAgg, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
         uint32_t po = 0, pf = 0, pk = 0;
         int back = tile - 1;
         while (back >= 0) {
             const int t = back - lane;
-            uint64_t w;
-            // every lane polls its predecessor until it has published something
-            do { w = t >= 0 ? __hip_atomic_load(&state[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : kFlagInc; } while (__any((w >> 62) == 0));
+            const uint32_t* st = state + (size_t)(t >= 0 ? t : 0) * kStateWords;
+            uint32_t fl;
+            // every lane polls its predecessor's flag until it has published something
+            do { fl = t >= 0 ? __hip_atomic_load(st, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : kFlagInc; } while (__any(fl == 0u));
             // nearest predecessor holding an inclusive prefix: lanes below it contribute aggregates, it contributes the prefix
-            const uint64_t inc = __ballot((w >> 62) == 2);
-            const int first = __ffsll((long long)inc) - 1;                    // >= 0 when any (lanes with t < 0 count as "inclusive 0")
-            uint32_t a, b_, d; unpackState(w, a, b_, d);
-            const bool take = first < 0 || lane <= first;
-            if (t < 0 || !take) { a = 0; b_ = 0; d = 0; }
+            const int first = __ffsll((long long)__ballot(fl == kFlagInc)) - 1;       // >= 0 when any (lanes with t < 0 count as "inclusive 0")
+            const bool take = t >= 0 && (first < 0 || lane <= first);
+            uint32_t a = 0, b_ = 0, d = 0;
+            if (take) {                                                       // the slot the acquired flag value names (written before that flag)
+                const int slot = fl == kFlagInc ? 5 : 2;
+                a = __hip_atomic_load(st + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b_ = __hip_atomic_load(st + slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                d = __hip_atomic_load(st + slot + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             po += waveSum(a); pf += waveSum(b_); pk += waveSum(d);
             if (first >= 0) break;
             back -= kWave;
         }
         if (lane == 0) {
             s_pref[0] = po; s_pref[1] = pf; s_pref[2] = pk;
-            if (tile > 0)
-                __hip_atomic_store(&state[tile], packState(kFlagInc, po + to, pf + tf, pk + tk), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (tile > 0) {
+                mine[5] = po + to; mine[6] = pf + tf; mine[7] = pk + tk;
+                __hip_atomic_store(mine, kFlagInc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     __syncthreads();
@@ -379,7 +409,7 @@ public:
     int rowsAll() const { return p_.max_points_num * p_.frames; }
     // cell histogram followed by the scan's ticket + tile states (one memset covers both); 16-byte aligned rows
     size_t cntWords() const { return ((size_t)ncell() + 3) / 4 * 4; }
-    size_t headBytes() const { return sizeof(uint32_t) * cntWords() + sizeof(uint64_t) * (1 + (size_t)ntiles()); }
+    size_t headBytes() const { return sizeof(uint32_t) * (cntWords() + (size_t)kStateWords * (1 + (size_t)ntiles())); }
     int ntiles() const { return cdiv(ncell(), kTile); }
     size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override {
         size_t s = 0;
@@ -402,7 +432,7 @@ public:
         WsCarver ws(workspace);
         char* head = ws.take<char>(headBytes());
         uint32_t* cell_cnt = reinterpret_cast<uint32_t*>(head);
-        uint64_t* scan_state = reinterpret_cast<uint64_t*>(head + sizeof(uint32_t) * cntWords());
+        uint32_t* scan_state = reinterpret_cast<uint32_t*>(head + sizeof(uint32_t) * cntWords());
         uint32_t* cell_seg = ws.take<uint32_t>(ncell());
         uint32_t* pt_cell = ws.take<uint32_t>(rowsAll());
         uint32_t* pt_slot = ws.take<uint32_t>(rowsAll());
@@ -419,7 +449,7 @@ public:
             DSVT_CHECK(hipMemsetAsync(pcnt, 0, sizeof(uint32_t) * (size_t)p_.max_pillars_num, stream));
         }
         const int nt = ntiles();
-        hipLaunchKernelGGL(p2f_count, dim3(cdiv(rowsAll(), 256)), dim3(256), 0, stream, pts, n_ptr, p_, cell_cnt, pt_cell, pt_slot);
+        hipLaunchKernelGGL(p2f_count, dim3(cdiv(rowsAll(), 256 * kPPT)), dim3(256), 0, stream, pts, n_ptr, p_, cell_cnt, pt_cell, pt_slot);
         hipLaunchKernelGGL(p2f_scan, dim3(nt), dim3(256), 0, stream, cell_cnt, ncell(), p_, scan_state, nt, cell_seg,
                            pil_seg, pil_full, pil_ptoff, coords, pcnt, pillar_num, point_num);
         hipLaunchKernelGGL(p2f_scatter, dim3(cdiv(rowsAll(), 256)), dim3(256), 0, stream, n_ptr, p_.max_points_num, p_.frames,
@@ -447,7 +477,7 @@ static bool validP2F(const P2FParams& p) {
            p.point_feature_num == 4 && p.feature_num == 10 &&
            p.max_num_points_per_voxel > 0 && p.max_num_points_per_voxel <= kWave &&
            p.gx > 0 && p.gy > 0 && p.gz > 0 && p.frames >= 1 && (long)p.gx * p.gy * p.gz * p.frames < (1l << 30) && p.vx > 0 && p.vy > 0 && p.vz > 0 &&
-           (long)p.max_points_num * p.frames < (1 << 20);     // the scan packs (occupied, full, kept) sums into 20 + 21 + 21 bits
+           (long)p.max_points_num * p.frames < (1l << 31);    // the scan's running sums and the row indices are 32-bit
 }
 
 static Plugin* p2fCreate(const DsvtPluginFieldCollection* fc) {                                    // :1113-1195

@@ -185,7 +185,7 @@ class DsvtPipeline:
                     self.layers[(b, l)] = L_ = dict(
                         qkv=zf(P.add_linear_op(wi, bi, c.P, add_cols=2 * C, **qkv_kw,
                                                add_gather_width=WINS[l][0][0] if self.pos_table else 0)),
-                        attn=zf(P.add_set_attention_op(c.S, L_SET, C, H, l, c.P, io_half=f16)),
+                        attn=zf(P.add_set_attention_op(c.S, L_SET, C, H, l, c.P, io_half=f16, split_precision=split)),
                         mlp=zf(P.add_encoder_mlp_op(w[lp + ".win_attn.self_attn.out_proj.weight"], w[lp + ".win_attn.self_attn.out_proj.bias"],
                                                     w[lp + ".win_attn.linear1.weight"], w[lp + ".win_attn.linear1.bias"],
                                                     w[lp + ".win_attn.linear2.weight"], w[lp + ".win_attn.linear2.bias"],

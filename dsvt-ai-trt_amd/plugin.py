@@ -487,7 +487,8 @@ OUT_F32, OUT_F16, OUT_BOTH = 0, 1, 2
 
 
 def add_linear_op(weight, bias, max_rows, row_mult=1, activation=ACT_NONE, add_cols=0, layer_norms=(), ln_eps=0.0,
-                  compute_type=COMPUTE_F32, input_half=False, output_mode=OUT_F32, pe_weight=None, pe_bias=None, add_gather_width=0):
+                  compute_type=COMPUTE_F32, input_half=False, output_mode=OUT_F32, pe_weight=None, pe_bias=None, add_gather_width=0,
+                  add_gather_height=0):
     """FC with fused prologue/epilogue (csrc/linear.hip), used where the reference calls
     addFullyConnected (src/dsvt-ai-trt.cpp:283,476,490,506,525) + ElementWise/LayerNorm/GELU.
     Inputs: A [1,rows,K], count [1], (A2 if add_cols), then one residual per LayerNorm stage.
@@ -499,6 +500,8 @@ def add_linear_op(weight, bias, max_rows, row_mult=1, activation=ACT_NONE, add_c
     fields = dict(max_rows=max_rows, in_features=K, out_features=N, row_mult=row_mult, activation=activation,
                   add_cols=add_cols, num_layer_norms=len(layer_norms), ln_eps=float(ln_eps), compute_type=compute_type,
                   input_half=int(bool(input_half)), output_mode=output_mode, add_gather_width=int(add_gather_width), weight=weight.reshape(-1))
+    if add_gather_height:      # 3-D windows (BASELINE configs[4]): table row (z * wy + y) * wx + x
+        fields["add_gather_height"] = int(add_gather_height)
     if bias is not None:
         fields["bias"] = np.asarray(bias, np.float32).reshape(-1)
     if pe_weight is not None:      # fused K_in = 2 first FC (+BN, ReLU) of the position-embedding MLP: input 0 becomes xy [1,rows,2]
@@ -510,12 +513,15 @@ def add_linear_op(weight, bias, max_rows, row_mult=1, activation=ACT_NONE, add_c
     return Plugin("DsvtLinearPlugin", fields, "linear_layer")
 
 
-def add_set_attention_op(max_win_num, voxel_num_set, channel_num, num_heads, axis_id, max_pillars_num, io_half=False):
+def add_set_attention_op(max_win_num, voxel_num_set, channel_num, num_heads, axis_id, max_pillars_num, io_half=False, split_precision=False):
     """GetValueByIndex + attention core + MapSetFeature2Voxel fused (csrc/attention.hip).
-    Inputs: qkv [1,P,3C] (per-voxel projections), inds [1,2,S,36], mask [1,2,S,36], valid_set_num [1]."""
+    Inputs: qkv [1,P,3C] (per-voxel projections), inds [1,2,S,36], mask [1,2,S,36], valid_set_num [1].
+    io_half: fp16 rows in / out on fp16 MFMA.  split_precision: fp32 rows in / out, both products on (hi, lo) fp16 operand pairs
+    (fp32 grade, set_attention_split_kernel) instead of v_mfma_f32_16x16x4_f32."""
+    assert not (io_half and split_precision)
     return Plugin("DsvtSetAttentionPlugin", dict(max_win_num=max_win_num, voxel_num_set=voxel_num_set,
                                                  channel_num=channel_num, num_heads=num_heads, axis_id=axis_id,
-                                                 max_pillars_num=max_pillars_num, io_half=int(bool(io_half))),
+                                                 max_pillars_num=max_pillars_num, io_half=2 if split_precision else int(bool(io_half))),
                   "set_attention_layer")
 
 

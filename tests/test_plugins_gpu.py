@@ -614,6 +614,21 @@ def test_fused_set_partition_capacity_and_generic_order(pkg, oracle):
             assert int(S[0]) == rg["S"] and (S_cap == 800 or rg["S"] <= 200)
             assert np.array_equal(c2d[0], rw["c2d"])
             assert np.array_equal(inds[0], rg["inds"]) and np.array_equal(mask[0], rg["mask"])
+    # duplicate pillar coordinates (an input Points2Features never produces): 3000 copies of one cell put more voxels into a window than
+    # its LDS region (2 x pow2(144) = 512 words) holds.  The surplus is dropped -- which ones is unspecified, like the reference's racy
+    # order beyond its cap -- but nothing is read or written out of bounds: the kernels return, every index names one of the copies and
+    # the other windows' sets are untouched.
+    dup = vox["coords"].copy()
+    dup[:3000] = dup[0]
+    for op_ in (lambda: P.add_set_partition_op(c["W"], c["Vw"], 36, 800, c["P"], cases.GRID, cases.WINS)(dev(dup[None]), scalar(vox["P"])),):
+        po = op_()
+        torch.cuda.synchronize()
+        for k in range(2):
+            inds, S = host(po[4 * k + 1])[0], int(host(po[4 * k + 3])[0])
+            assert 0 < S <= 800 and inds[:, :S].max() < vox["P"]
+    wpo = P.add_window_partition(c["W"], c["Vw"], 468, 468, 1, 12, 12, 1, 0, 0, 0)(dev(dup[None]), scalar(vox["P"]))
+    torch.cuda.synchronize()
+    assert int(host(wpo[3])[0]) > 0 and host(wpo[0])[0].max() < vox["P"]
 
 
 @pytest.mark.parametrize("seed", range(12))

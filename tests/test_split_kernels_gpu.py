@@ -175,3 +175,69 @@ def test_boxes_split_mode(pkg, oracle, frame):
     worst, unmatched = match_boxes(boxes[0].cpu().numpy(), int(cnt[0]), eb, ec)
     print("split-mode boxes", frame, "max|diff|", worst, "unmatched", unmatched, "count", int(cnt[0]), ec)
     assert unmatched == 0 and worst < 1e-3, (worst, unmatched)
+
+
+# =====================================================================================================================
+# set_attention_split_kernel (DsvtSetAttentionPlugin split_precision) vs GetValueByIndex -> multHeadAttention core -> MapSetFeature2Voxel
+# =====================================================================================================================
+def _run_attention_split(P, c, qkv, gs, axis):
+    op = P.add_set_attention_op(c["W"], 36, 192, 8, axis, c["P"], split_precision=True)
+    out = op(dev(qkv[None]), dev(gs["inds"][None]), dev(gs["mask"][None]), scalar(gs["S"]))[0]
+    torch.cuda.synchronize()
+    again = P.Plugin.deserialize("DsvtSetAttentionPlugin", op.serialize())
+    assert torch.equal(again(dev(qkv[None]), dev(gs["inds"][None]), dev(gs["mask"][None]), scalar(gs["S"]))[0], out)
+    return out[0].cpu().numpy()
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+@pytest.mark.parametrize("win", [0, 1])
+def test_set_attention_split_reference_frame(pkg, oracle, axis, win):
+    """frame 000000 (454 / 272 sets, two thirds of the slots masked duplicates) on fp32 rows: the split-precision attention core against
+    the oracle's gather -> dense_ref.mha core -> scatter, and against the exact-fp32-MFMA kernel of the same plugin.
+    Two logit regimes.  (a) the stress data of the fp16 test (logit sigma 4.4, tails beyond 20): a (hi, lo) operand carries 22 mantissa bits, so a
+    logit sum_d k_d q_d is off by up to ~3 x 2^-22 x sum |k_d q_d| ~ 3e-5 in the tails, and the softmax turns an ABSOLUTE logit error into a RELATIVE
+    probability error: 3e-4 of scale at the maximum over a million outputs (measured 1.1e-4), 1e-6 on average (measured 4e-8) -- the fp16 kernel's
+    bound on the same data is 1.5e-3 / 1.5e-4.  (b) logits of the size the network produces (Q through the 1 / sqrt(24)-scaled projection: sigma ~1):
+    2e-5 of scale.  The frame-level bars are test_backbone_features_split_mode / test_boxes_split_mode."""
+    from tests.test_f16_kernels_gpu import _attention_reference
+    P, O = pkg.plugin, oracle
+    c = cases.caps("ref")
+    pts, n = cases.load_frame("000000", c["N"])
+    vox = O.points2features(pts, n, cases.p2f_cfg(c))
+    rw = O.window_partition(vox["coords"], vox["P"], cases.wp_cfg(c, win))
+    gs = O.get_set(rw["gidx"], rw["cinw"], rw["vcnt"], rw["W"], cases.gs_cfg(c, win))
+    rng = np.random.default_rng(100 + 2 * win + axis)
+    Pn = vox["P"]
+    base = rng.standard_normal((Pn, 576)).astype(np.float32)
+    for qs, bmax, bmean in ((0.6, 3e-4, 1e-6), (0.6 / np.sqrt(24.0), 2e-5, 3e-7)):
+        qkv = np.zeros((c["P"], 576), np.float32)
+        qkv[:Pn] = base * np.array([qs] * 192 + [1.5] * 192 + [1.0] * 192, np.float32)
+        ref = _attention_reference(O, qkv, gs, axis, c["P"])
+        got = _run_attention_split(P, c, qkv, gs, axis)
+        err = np.abs(got[:Pn] - ref[:Pn])
+        scale = max(1.0, np.abs(ref).max())
+        print(f"split attention win {win} axis {axis} q-scale {qs:.3f}: max err {err.max():.2e}, mean {err.mean():.2e}, scale {scale:.2f}")
+        assert err.max() < bmax * scale and err.mean() < bmean * scale, (qs, err.max(), err.mean())
+        assert not got[Pn:].any()
+        exact = P.add_set_attention_op(c["W"], 36, 192, 8, axis, c["P"])(dev(qkv[None]), dev(gs["inds"][None]), dev(gs["mask"][None]), scalar(gs["S"]))[0]
+        assert np.abs(got - exact[0].cpu().numpy()).max() < bmax * scale
+
+
+@pytest.mark.parametrize("case", ["empty", "one_voxel", "five_voxels", "full_window", "37_voxels"])
+def test_set_attention_split_small_sets(pkg, oracle, case):
+    """S = 0; S = 1 with 35 / 31 duplicate slots; a full 12x12 window (4 sets, no duplicates); 37 voxels (2 sets, 35 duplicates)"""
+    from tests.test_f16_kernels_gpu import _attention_reference, _synthetic_sets
+    P, O = pkg.plugin, oracle
+    c = cases.caps("ref")
+    cells = {"empty": [], "one_voxel": [(100, 200)], "five_voxels": [(24, 24), (24, 25), (25, 24), (30, 35), (35, 30)],
+             "full_window": [(120 + y, 240 + x) for y in range(12) for x in range(12)],
+             "37_voxels": [(120 + i // 12, 240 + i % 12) for i in range(37)]}[case]
+    Pn, gs = _synthetic_sets(O, c, cells)
+    rng = np.random.default_rng(len(cells))
+    qkv = np.zeros((c["P"], 576), np.float32); qkv[:Pn] = rng.standard_normal((Pn, 576))
+    for axis in (0, 1):
+        ref = _attention_reference(O, qkv, gs, axis, c["P"])
+        got = _run_attention_split(P, c, qkv, gs, axis)
+        assert np.abs(got - ref).max() < 3e-4 * max(1.0, np.abs(ref).max())
+        if case == "one_voxel":      # softmax over one live key = that voxel's V row: hi + lo reproduces the fp32 value to 2^-22
+            assert np.abs(got[0] - qkv[0, 384:]).max() < 1e-6
