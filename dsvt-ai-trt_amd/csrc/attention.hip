@@ -502,6 +502,40 @@ set_attention_split_kernel(AttnArgs a)
 #pragma unroll
             for (int i = 0; i < 4; ++i) sc[t][u][i] *= inv;
     }
+#ifdef DSVT_ABLATE
+    if (a.dbg == 99 || a.dbg == 98) {       // debugging: the probabilities (99) of keys 0..23 instead of the output channels
+        const int h_ = hq * AHB + wave;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int q = 16 * u + r;
+            if (q >= AL || (a.inds && sMask[wave][q] < 0.f)) continue;
+            float* dst = static_cast<float*>(a.out) + (size_t)sRow[q] * a.out_ld + h_ * ADH;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const int key = 16 * t + 4 * g + i; if (key < ADH) dst[key] = sc[t][u][i]; }
+        }
+        return;
+    }
+    if (a.dbg == 97 || a.dbg == 96) {       // debugging: the hi (97) / lo (96) parts of the probabilities of keys 0..23, as the PV product sees them
+        const int h_ = hq * AHB + wave;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int q = 16 * u + r;
+            if (q >= AL || (a.inds && sMask[wave][q] < 0.f)) continue;
+            float* dst = static_cast<float*>(a.out) + (size_t)sRow[q] * a.out_ld + h_ * ADH;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int key = 16 * t + 4 * g + i;
+                    const float p = sc[t][u][i]; const _Float16 hh = (_Float16)p; float d = p - (float)hh; asm volatile("" : "+v"(d)); const _Float16 ll = (_Float16)d;
+                    if (key < ADH) dst[key] = a.dbg == 97 ? (float)hh : (float)ll;
+                }
+        }
+        return;
+    }
+#endif
     // ---- O[query][d] = sum_key P[query][key] V[key][d] -------------------------------------------------
     ahalf8 vb[2][2][2];                  // [hi | lo][channel tile][k-step]
 #pragma unroll
@@ -522,7 +556,17 @@ set_attention_split_kernel(AttnArgs a)
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const float p = sc[t][u][i]; ph[4 * t + i] = (_Float16)p; pl_[4 * t + i] = (_Float16)(p - (float)ph[4 * t + i]); }      // 0 <= p <= 1
+            for (int i = 0; i < 4; ++i) {                                  // 0 <= p <= 1
+                // p as a materialised fp32 value FIRST.  hipcc (-ffp-contract=fast, the HIP default) otherwise fuses "e * inv -> half" into
+                // v_fma_mixlo_f16 for the RESIDUAL (one rounding of the exact product) while the hi FRAGMENT is v_cvt_pk_f16_f32 of the fp32-rounded
+                // product (two roundings): in the rare double-rounding cases the two hi values differ by one fp16 ulp and the pair (hi, lo) is off by
+                // 2^-14 of probability mass -- found as 15 outlier (row, head) pairs of 44,000 at 1e-4 (tools/dbg_attn_split*.py; the other split
+                // helpers clamp before they convert, which materialises the value)
+                float p = sc[t][u][i];
+                asm volatile("" : "+v"(p));
+                ph[4 * t + i] = (_Float16)p;
+                pl_[4 * t + i] = (_Float16)(p - (float)ph[4 * t + i]);
+            }
         const ahalf8 p0h = {ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]}, p1h = {ph[8], ph[9], ph[10], ph[11], 0, 0, 0, 0};
         const ahalf8 p0l = {pl_[0], pl_[1], pl_[2], pl_[3], pl_[4], pl_[5], pl_[6], pl_[7]}, p1l = {pl_[8], pl_[9], pl_[10], pl_[11], 0, 0, 0, 0};
 #pragma unroll

@@ -207,7 +207,10 @@ pfn_kernel(PfnArgs a)
                 for (int i = 0; i < 4; ++i) {
                     const float v0 = x0[2 * s_][i], v1 = x0[2 * s_ + 1][i];
                     h[i] = (_Float16)fminf(v0, 65504.f); h[4 + i] = (_Float16)fminf(v1, 65504.f);      // (x0 >= 0 after the ReLU)
-                    l[i] = (_Float16)(v0 - (float)h[i]); l[4 + i] = (_Float16)(v1 - (float)h[4 + i]);
+                    // (the residuals as fp32 values first; the hi parts come from the clamped, i.e. materialised, value: see attention.hip on hipcc's fused conversions)
+                    float d0 = v0 - (float)h[i], d1 = v1 - (float)h[4 + i];
+                    asm volatile("" : "+v"(d0), "+v"(d1));
+                    l[i] = (_Float16)d0; l[4 + i] = (_Float16)d1;
                 }
                 f1[s_] = half8{h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]};
                 f1l[s_] = half8{l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7]};
@@ -238,7 +241,7 @@ pfn_kernel(PfnArgs a)
                     const float mv = fmaxf(m0[k], 0.f);                                                                   // max(ReLU(.)) = max(0, max(.))
                     const _Float16 mh = (_Float16)fminf(mv, 65504.f);
                     sM[pl_ * SM_LD + 16 * k + r] = mh;
-                    if constexpr (SPLIT) sM[(PF_PB + pl_) * SM_LD + 16 * k + r] = (_Float16)(mv - (float)mh);
+                    if constexpr (SPLIT) { float dm = mv - (float)mh; asm volatile("" : "+v"(dm)); sM[(PF_PB + pl_) * SM_LD + 16 * k + r] = (_Float16)dm; }
                 }
 #pragma unroll
                 for (int k = 0; k < 12; ++k) sU[pl_ * SU_LD + 16 * k + r] = __float_as_uint(mu[k]);
@@ -260,7 +263,7 @@ pfn_kernel(PfnArgs a)
                     for (int k = 0; k < 6; ++k) {
                         const _Float16 mh = (_Float16)fminf(mx0[k], 65504.f);
                         sM[pl_ * SM_LD + 16 * k + r] = mh;
-                        if constexpr (SPLIT) sM[(PF_PB + pl_) * SM_LD + 16 * k + r] = (_Float16)(mx0[k] - (float)mh);
+                        if constexpr (SPLIT) { float dm = mx0[k] - (float)mh; asm volatile("" : "+v"(dm)); sM[(PF_PB + pl_) * SM_LD + 16 * k + r] = (_Float16)dm; }
                     }
 #pragma unroll
                     for (int k = 0; k < 12; ++k) sU[pl_ * SU_LD + 16 * k + r] = __float_as_uint(mxu[k]);

@@ -193,12 +193,13 @@ def _run_attention_split(P, c, qkv, gs, axis):
 @pytest.mark.parametrize("win", [0, 1])
 def test_set_attention_split_reference_frame(pkg, oracle, axis, win):
     """frame 000000 (454 / 272 sets, two thirds of the slots masked duplicates) on fp32 rows: the split-precision attention core against
-    the oracle's gather -> dense_ref.mha core -> scatter, and against the exact-fp32-MFMA kernel of the same plugin.
-    Two logit regimes.  (a) the stress data of the fp16 test (logit sigma 4.4, tails beyond 20): a (hi, lo) operand carries 22 mantissa bits, so a
-    logit sum_d k_d q_d is off by up to ~3 x 2^-22 x sum |k_d q_d| ~ 3e-5 in the tails, and the softmax turns an ABSOLUTE logit error into a RELATIVE
-    probability error: 3e-4 of scale at the maximum over a million outputs (measured 1.1e-4), 1e-6 on average (measured 4e-8) -- the fp16 kernel's
-    bound on the same data is 1.5e-3 / 1.5e-4.  (b) logits of the size the network produces (Q through the 1 / sqrt(24)-scaled projection: sigma ~1):
-    2e-5 of scale.  The frame-level bars are test_backbone_features_split_mode / test_boxes_split_mode."""
+    the oracle's gather -> dense_ref.mha core -> scatter, and against the exact-fp32-MFMA kernel of the same plugin, in two logit regimes:
+    (a) the stress data of the fp16 test (logit sigma 4.4, tails beyond 20; the softmax turns an absolute logit error into a relative
+    probability error) and (b) logits of the size the network produces (Q through the 1 / sqrt(24)-scaled projection, sigma ~1).  Measured
+    1.1e-6 / 3.4e-7 of scale at the maximum over a million outputs, 4e-8 / 2e-8 on average -- the fp16 kernel's bound on (a) is 1.5e-3 / 1.5e-4.
+    (These bounds found a real defect: hipcc's default -ffp-contract=fast fused "e * inv -> half" into v_fma_mixlo_f16 for the residual but
+    converted the fp32-rounded product for the hi fragment; in the rare double-rounding cases hi and lo disagreed by one fp16 ulp: 15 of
+    44,000 (row, head) pairs off by 1e-4.  See the comment at the P split in csrc/attention.hip and tools/dbg_attn_split*.py.)"""
     from tests.test_f16_kernels_gpu import _attention_reference
     P, O = pkg.plugin, oracle
     c = cases.caps("ref")
@@ -209,7 +210,7 @@ def test_set_attention_split_reference_frame(pkg, oracle, axis, win):
     rng = np.random.default_rng(100 + 2 * win + axis)
     Pn = vox["P"]
     base = rng.standard_normal((Pn, 576)).astype(np.float32)
-    for qs, bmax, bmean in ((0.6, 3e-4, 1e-6), (0.6 / np.sqrt(24.0), 2e-5, 3e-7)):
+    for qs, bmax, bmean in ((0.6, 4e-6, 1e-7), (0.6 / np.sqrt(24.0), 1.5e-6, 6e-8)):
         qkv = np.zeros((c["P"], 576), np.float32)
         qkv[:Pn] = base * np.array([qs] * 192 + [1.5] * 192 + [1.0] * 192, np.float32)
         ref = _attention_reference(O, qkv, gs, axis, c["P"])
@@ -238,6 +239,6 @@ def test_set_attention_split_small_sets(pkg, oracle, case):
     for axis in (0, 1):
         ref = _attention_reference(O, qkv, gs, axis, c["P"])
         got = _run_attention_split(P, c, qkv, gs, axis)
-        assert np.abs(got - ref).max() < 3e-4 * max(1.0, np.abs(ref).max())
+        assert np.abs(got - ref).max() < 4e-6 * max(1.0, np.abs(ref).max())
         if case == "one_voxel":      # softmax over one live key = that voxel's V row: hi + lo reproduces the fp32 value to 2^-22
             assert np.abs(got[0] - qkv[0, 384:]).max() < 1e-6
