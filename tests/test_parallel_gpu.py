@@ -50,9 +50,15 @@ def test_bench_two_ranks_sharing_the_gpu_gather_the_right_rows(pkg, tmp_path):
     import numpy as np
     import torch
     dump = str(tmp_path / "rows.npy")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "8", "--warmup", "2",
-                        "--no-cpu-baseline", "--no-kernel-events", "--no-parity-mode", "--no-latency-mode", "--dump-rows", dump],
-                       capture_output=True, text=True, timeout=1500)
+    # (--no-graph: two PROCESSES replaying HIP graphs on one device fault on this stack -- "Memory access fault by GPU node", with one
+    # stream or two, ROCm 7.2; host-launched kernels from two processes are fine.  Not a configuration the product runs in: one process per GPU.)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--no-graph", "--steps", "8", "--warmup", "2",
+           "--no-cpu-baseline", "--no-kernel-events", "--no-parity-mode", "--no-latency-mode", "--dump-rows", dump]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
+    if r.returncode != 0 and "Memory access fault by GPU" in r.stderr:
+        # two processes on ONE device: roughly one run in three or four dies with the platform's "Memory access fault" (seen with graph replays
+        # every time, with host launches sometimes; never with one process per device).  One retry; any other failure, and a second fault, fail.
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and "DRY RUN" in line["metric"] and "NOT a scaling number" in line["config"]["shared_gpu"]
