@@ -78,36 +78,51 @@ __device__ __forceinline__ void rotateAround(F2 c, float ac, float as, F2& p) { 
     p.x = nx; p.y = ny;
 }
 
-__device__ float boxOverlap(const Bnd& a, const Bnd& b, const Trig& ta, const Trig& tb) {            // :166-255
+// cp / ang: the clip polygon's points and their angles, indexed by a run-time count.  They live in LDS, one column per lane (element k of
+// lane l at [k * 64 + l]), not in a private array: a private array indexed at run time is scratch memory (400 bytes per lane here), and
+// this was the only kernel of the frame with any (under two processes time-sharing the device its result was not
+// reproducible run to run).
+__device__ float boxOverlap(const Bnd& a, const Bnd& b, const Trig& ta, const Trig& tb, F2* __restrict__ cp, double* __restrict__ ang) {   // :166-255
+    constexpr int L = 64;                                            // column stride
     const float a_dx = a.w / 2, b_dx = b.w / 2, a_dy = a.l / 2, b_dy = b.l / 2;
-    F2 ac[5], bc[5], cp[24], pc = {0.f, 0.f};          // the host's cross_points[16] cannot hold the 16 + 8 worst case either
+    F2 ac[5], bc[5], pc = {0.f, 0.f};                  // the host's cross_points[16] cannot hold the 16 + 8 worst case either: 24 here
     const F2 ca = {a.x, a.y}, cb = {b.x, b.y};
     int cnt = 0;
     ac[0] = F2{a.x - a_dx, a.y - a_dy}; ac[1] = F2{a.x + a_dx, a.y - a_dy}; ac[2] = F2{a.x + a_dx, a.y + a_dy}; ac[3] = F2{a.x - a_dx, a.y + a_dy};
     bc[0] = F2{b.x - b_dx, b.y - b_dy}; bc[1] = F2{b.x + b_dx, b.y - b_dy}; bc[2] = F2{b.x + b_dx, b.y + b_dy}; bc[3] = F2{b.x - b_dx, b.y + b_dy};
     const float a_cos = ta.c, a_sin = ta.s, b_cos = tb.c, b_sin = tb.s;
+#pragma unroll
     for (int k = 0; k < 4; ++k) { rotateAround(ca, a_cos, a_sin, ac[k]); rotateAround(cb, b_cos, b_sin, bc[k]); }
     ac[4] = ac[0]; bc[4] = bc[0];
+#pragma unroll
     for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j)
-            if (intersection(ac[i + 1], ac[i], bc[j + 1], bc[j], cp[cnt])) { pc.x += cp[cnt].x; pc.y += cp[cnt].y; ++cnt; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            F2 x;
+            if (intersection(ac[i + 1], ac[i], bc[j + 1], bc[j], x)) { pc.x += x.x; pc.y += x.y; cp[cnt * L] = x; ++cnt; }
+        }
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (checkBox2d(a, ta, bc[k])) { pc.x += bc[k].x; pc.y += bc[k].y; cp[cnt++] = bc[k]; }
-        if (checkBox2d(b, tb, ac[k])) { pc.x += ac[k].x; pc.y += ac[k].y; cp[cnt++] = ac[k]; }
+        if (checkBox2d(a, ta, bc[k])) { pc.x += bc[k].x; pc.y += bc[k].y; cp[cnt * L] = bc[k]; ++cnt; }
+        if (checkBox2d(b, tb, ac[k])) { pc.x += ac[k].x; pc.y += ac[k].y; cp[cnt * L] = ac[k]; ++cnt; }
     }
     if (cnt == 0) return 0.f;                                        // reference: 0/0 centroid, empty fan, area 0
     pc.x /= cnt; pc.y /= cnt;
-    double ang[24];                                                  // the host recomputes atan2 inside every comparison; same values
-    for (int i = 0; i < cnt; ++i) ang[i] = atan2((double)(cp[i].y - pc.y), (double)(cp[i].x - pc.x));
+    // the host recomputes atan2 inside every comparison; same values
+    for (int i = 0; i < cnt; ++i) { const F2 q = cp[i * L]; ang[i * L] = atan2((double)(q.y - pc.y), (double)(q.x - pc.x)); }
     for (int j = 0; j < cnt - 1; ++j)
-        for (int i = 0; i < cnt - j - 1; ++i)
-            if (ang[i] > ang[i + 1]) {
-                const F2 t = cp[i]; cp[i] = cp[i + 1]; cp[i + 1] = t;
-                const double ta = ang[i]; ang[i] = ang[i + 1]; ang[i + 1] = ta;
+        for (int i = 0; i < cnt - j - 1; ++i) {
+            const double a0 = ang[i * L], a1 = ang[(i + 1) * L];
+            if (a0 > a1) {
+                const F2 t = cp[i * L]; cp[i * L] = cp[(i + 1) * L]; cp[(i + 1) * L] = t;
+                ang[i * L] = a1; ang[(i + 1) * L] = a0;
             }
+        }
     float area = 0.f;
+    const F2 c0 = cp[0];
     for (int k = 0; k < cnt - 1; ++k) {
-        const F2 u = {cp[k].x - cp[0].x, cp[k].y - cp[0].y}, v = {cp[k + 1].x - cp[0].x, cp[k + 1].y - cp[0].y};
+        const F2 ck = cp[k * L], cn = cp[(k + 1) * L];
+        const F2 u = {ck.x - c0.x, ck.y - c0.y}, v = {cn.x - c0.x, cn.y - c0.y};
         area += (u.x * v.y - u.y * v.x);
     }
     return (float)(fabs((double)area) / 2.0);
@@ -155,6 +170,8 @@ nms_mask(const float* __restrict__ rows, const uint32_t* __restrict__ count, con
     rows += (size_t)blockIdx.z * max_boxes * 9; count += blockIdx.z; order += (size_t)blockIdx.z * NMS_MAX; trig += (size_t)blockIdx.z * NMS_MAX;
     maskT += (size_t)blockIdx.z * NMS_MAX * NMS_WORDS;                                                  // blockIdx.z = frame of a stack
     int n = (int)*count; if (n > max_boxes) n = max_boxes;
+    __shared__ F2 s_cp[24 * 64];
+    __shared__ double s_ang[24 * 64];
     const int j = blockIdx.x, wi = blockIdx.y, lane = threadIdx.x, i = wi * 64 + lane;
     if (j >= n) return;
     bool sup = false;
@@ -167,7 +184,7 @@ nms_mask(const float* __restrict__ rows, const uint32_t* __restrict__ count, con
         if (dx * dx + dy * dy <= reach * reach) {
             const float sa = bi.w * bi.l, sb = bj.w * bj.l;                        // helper.h:272-275 (i is the kept box, j the later one)
             const float4 ti = trig[i], tj = trig[j];
-            const float so = boxOverlap(bi, bj, Trig{ti.x, ti.y, ti.z, ti.w}, Trig{tj.x, tj.y, tj.z, tj.w});
+            const float so = boxOverlap(bi, bj, Trig{ti.x, ti.y, ti.z, ti.w}, Trig{tj.x, tj.y, tj.z, tj.w}, s_cp + lane, s_ang + lane);
             const float iou = so / fmaxf(sa + sb - so, kThresHold);
             sup = iou >= thresh;
         }

@@ -56,8 +56,9 @@ def test_bench_two_ranks_sharing_the_gpu_gather_the_right_rows(pkg, tmp_path):
            "--no-cpu-baseline", "--no-kernel-events", "--no-parity-mode", "--no-latency-mode", "--dump-rows", dump]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
     if r.returncode != 0 and "Memory access fault by GPU" in r.stderr:
-        # two processes on ONE device: roughly one run in three or four dies with the platform's "Memory access fault" (seen with graph replays
-        # every time, with host launches sometimes; never with one process per device).  One retry; any other failure, and a second fault, fail.
+        # two processes on ONE device: the platform's "Memory access fault" (with graph replays every time, with host launches seen once;
+        # never with one process per device).  One retry for that message only; any other failure, and a second fault, fail.  A row
+        # MISMATCH is never retried: that was a real finding in round 3 (nms_mask's 400 bytes of scratch per lane, below).
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -84,3 +85,19 @@ def test_bench_two_ranks_sharing_the_gpu_gather_the_right_rows(pkg, tmp_path):
     for f in range(16):
         assert np.array_equal(got[f], rows[f % 2][f // 2]), f
     assert got[:, -1].min() > 0
+
+
+def test_two_processes_time_sharing_the_device_are_reproducible():
+    """Two processes, each with two pipelines on two streams and different clouds, launch forwards back to back for a few seconds on
+    the ONE device; every plugin's output buffers must equal those of the process's first iteration.  This is the configuration that
+    exposed (round 3) the only run-to-run difference the frame path ever had: nms_mask kept its clip polygon in a private array indexed
+    at run time = 400 bytes of scratch per lane, and with two processes on the device about 1 iteration in 100 kept or dropped one box
+    differently (inputs identical, RotatedNmsPlugin's outputs not).  The arrays are in LDS now and the kernel has no scratch."""
+    env = dict(os.environ, SECONDS="12")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "dbg_two_proc.py"), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              text=True, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-2000:]
+        last = [l for l in o.splitlines() if l.startswith("rank")][-1]
+        assert last.endswith("iterations differing per stream: none"), o[-2000:]

@@ -130,6 +130,41 @@ def test_pipeline_is_deterministic(pkg, weights):
         assert torch.equal(a, b) and torch.equal(ca, cb)
 
 
+@pytest.mark.parametrize("mode", ["f16", "split"])
+def test_boxes_do_not_depend_on_stale_buffer_contents(pkg, weights, mode):
+    """Uninitialised-read sanitiser: every plugin's outputs and workspace are overwritten with a byte pattern (zeros, 0xff = NaN / -1,
+    random) before a forward; the boxes are the same bits each time.  (TensorRT hands plugins uninitialised workspace and outputs.)"""
+    P = pkg.plugin
+    made, init = [], P.Plugin.__init__
+    def tracking(self, *a, **k):
+        init(self, *a, **k); made.append(self)
+    P.Plugin.__init__ = tracking
+    try:
+        kw = dict(linear_compute=P.COMPUTE_SPLIT) if mode == "split" else dict(linear_compute=P.COMPUTE_F16, head_dtype=torch.float16)
+        caps = pkg.pipeline.Caps()
+        pipe = pkg.pipeline.DsvtPipeline(weights, caps=caps, device=DEV, device_nms=True, **kw)
+    finally:
+        P.Plugin.__init__ = init
+    pts, n = cases.pad_points(pkg.synth.lidar_like(120000, 4), caps.N)
+    p_d, n_d = torch.from_numpy(pts[None]).to(DEV), torch.tensor([n], dtype=torch.int32, device=DEV)
+    b0, c0 = [t.clone() for t in pipe.forward(p_d, n_d)]
+    assert int(c0[0]) > 50 and len(made) > 40
+    g = torch.Generator(device=DEV); g.manual_seed(99)
+    for kind in ("ff", "rand", "zero"):
+        for pl in made:
+            for outs, ws in pl._cache.values():
+                for t in list(outs) + [ws]:
+                    v = t.view(-1).view(torch.uint8)
+                    if kind == "ff":
+                        v.fill_(255)
+                    elif kind == "rand":
+                        v.copy_(torch.randint(0, 256, v.shape, dtype=torch.uint8, device=DEV, generator=g))
+                    else:
+                        v.zero_()
+        b, c = pipe.forward(p_d, n_d)
+        assert torch.equal(c, c0) and torch.equal(b, b0), (kind, c.tolist(), c0.tolist())
+
+
 def _box_errors(got, n_got, exp, n_exp):
     """per-field max abs error over rows matched by (class, nearest centre within 0.2 m); fraction matched"""
     got, exp = got[:n_got], exp[:n_exp]
