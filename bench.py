@@ -385,7 +385,7 @@ def roofline_rows(prof, sampled, counts, pool_len, FB, mode, n_points_per_launch
             "DsvtPosEmbedPlugin": ("posembed_batched_kernel (8 position-embedding MLPs, v_mfma_f32_16x16x32_f16)", "hbm", "posembed_batched_kernel"),
             "DsvtPillarFeatureNetPlugin": ("pfn_kernel (both PFN layers + scatter-max, v_mfma_f32_16x16x4_f32 + 16x16x32_f16)" + sp_, "mfma", "pfn_kernel"),
             "DsvtConv2dPlugin": ("conv_wide_kernel / conv_halo_kernel / conv_f16_kernel (implicit GEMM, v_mfma_f32_16x16x32_f16)" + (" on [hi | lo | hi] x [w_hi | w_hi | w_lo]: three MFMAs per fp32-grade product" if split else ""), "mfma", "conv_wide_kernelILi8ELi8"),
-            "Points2FeaturesPlugin": ("p2f_count -> p2f_scan -> p2f_scatter -> p2f_pillar (+ one memset): the voxelizer chain, SURVEY 8a-1", "hbm", "p2f_"),
+            "Points2FeaturesPlugin": ("p2f_partition -> p2f_bins -> p2f_pillar: the voxelizer, SURVEY 8a-1", "hbm", "p2f_"),
             "DsvtSetPartitionPlugin": ("sp_count -> sp_scan -> sp_scatter -> sp_window (+ one memset): WindowPartition + GetSet of both window configurations, SURVEY 8a-3/4", "hbm", "sp_"),
             "Map2BevPlugin": ("map2bev_kernel + the zero fill of the dense map (plugins/src/map2bev.cu:250-310)", "hbm", "map2bev")}
     rows_out = []

@@ -58,4 +58,29 @@ __device__ __forceinline__ uint32_t blockExclusiveScan(uint32_t v, uint32_t* sme
     return res;
 }
 
+// The same for K values per thread at once (one set of barriers).  `smem` needs K * (NT/64 + 1) words; v[] becomes the exclusive
+// prefixes, total[] the sums.
+template <int NT, int K>
+__device__ __forceinline__ void blockExclusiveScanK(uint32_t (&v)[K], uint32_t* smem, uint32_t (&total)[K]) {
+    constexpr int NW = NT / kWave;
+    const int lane = laneId(), wave = threadIdx.x / kWave;
+    uint32_t inc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { inc[k] = waveInclusiveScan(v[k]); if (lane == kWave - 1) smem[k * (NW + 1) + wave] = inc[k]; }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t w = lane < NW ? smem[k * (NW + 1) + lane] : 0;
+            const uint32_t wi = waveInclusiveScan(w);
+            if (lane < NW) smem[k * (NW + 1) + lane] = wi - w;
+            if (lane == NW - 1) smem[k * (NW + 1) + NW] = wi;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) { const uint32_t res = smem[k * (NW + 1) + wave] + inc[k] - v[k]; total[k] = smem[k * (NW + 1) + NW]; v[k] = res; }
+    __syncthreads();
+}
+
 }  // namespace dsvt

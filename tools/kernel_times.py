@@ -2,7 +2,7 @@
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1]); pat = sys.argv[2] if len(sys.argv) > 2 else ""
 cur = db.cursor()
-starts = [r[0] for r in cur.execute("select start from kernels where name like '%p2f_count%' order by start")]
+starts = [r[0] for r in cur.execute("select start from kernels where name like '%p2f_partition%' order by start")]
 t0, t1 = starts[-4], starts[-1]
 rows = list(cur.execute("select name, count(*), avg(end-start), sum(end-start) from kernels where start>=? and start<? group by name order by 4 desc", (t0, t1)))
 tot = sum(r[3] for r in rows)

@@ -11,7 +11,7 @@ def main():
     db = sqlite3.connect(sys.argv[1])
     keep = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     cur = db.cursor()
-    starts = [r[0] for r in cur.execute("select start from kernels where name like '%p2f_count%' order by start")]
+    starts = [r[0] for r in cur.execute("select start from kernels where name like '%p2f_partition%' order by start")]
     keep = min(keep, len(starts) - 1)
     t0, t1 = starts[-keep - 1], starts[-1]
     iv = sorted(cur.execute("select start, end from kernels where start>=? and start<?", (t0, t1)))

@@ -1,6 +1,6 @@
 """Summarise a rocprofv3 --kernel-trace run (rocpd sqlite .db) into the per-kernel table that is
 committed under profiles/.  Steady state = the frames between the (first_frame)-th and the last
-launch of the voxelizer's first kernel (p2f_count), so MIOpen's find-mode trials and the warm-up
+launch of the voxelizer's first kernel (p2f_partition), so MIOpen's find-mode trials and the warm-up
 frames are excluded.
 
     python tools/prof_summary.py gpurun_out/prof_x/bench_results.db [frames_to_keep] > profiles/xxx.txt
@@ -13,7 +13,7 @@ def main():
     db = sqlite3.connect(sys.argv[1])
     keep = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     cur = db.cursor()
-    starts = [r[0] for r in cur.execute("select start from kernels where name like '%p2f_count%' order by start")]
+    starts = [r[0] for r in cur.execute("select start from kernels where name like '%p2f_partition%' order by start")]
     if len(starts) < keep + 1:
         keep = len(starts) - 1
     t0, t1 = starts[-keep - 1], starts[-1]
