@@ -112,6 +112,40 @@ def test_points2features_edge_cases(pkg, oracle):
     check_voxelizer(outs, ref)
 
 
+def test_points2features_slow_paths_of_the_bucket_pass(pkg, oracle):
+    """The voxelizer's bins keep the slots of up to 12288 points in LDS, take their pieces from the first 1024 partition blocks and hold
+    2048 cells; beyond any of the three a slower path runs (csrc/points2features.hip p2f_bins).  All three against the oracle, bit for bit."""
+    P = pkg.plugin
+    rng = np.random.default_rng(11)
+    # (a) one bin with 40k points: a 30 m x 1 m strip (plus a sparse background)
+    c = dict(N=65536, Nk=65536, P=16384, W=64, Vw=576)
+    pts = np.zeros((c["N"], 4), np.float32)
+    m = 40000
+    pts[:m, 0] = rng.uniform(-15, 15, m); pts[:m, 1] = rng.uniform(1.0, 2.0, m); pts[:m, 2] = rng.uniform(-4, 2, m); pts[:m, 3] = rng.random(m)
+    bg = 20000
+    pts[m:m + bg, 0] = rng.uniform(-70, 70, bg); pts[m:m + bg, 1] = rng.uniform(-70, 70, bg); pts[m:m + bg, 2] = rng.uniform(-4, 2, bg)
+    pts[:m + bg] = pts[rng.permutation(m + bg)]
+    ref = oracle.points2features(pts, m + bg, cases.p2f_cfg(c))
+    assert ref["pcnt"].max() == 48
+    _, outs = run_voxelizer(P, c, pts, m + bg)
+    check_voxelizer(outs, ref)
+    # (b) 2.2M points: 1075 partition blocks
+    c = dict(N=2_200_000, Nk=2_200_000, P=262144, W=64, Vw=576)
+    pts, n = cases.pad_points(pkg.synth.lidar_like(2_200_000, 7), c["N"])
+    ref = oracle.points2features(pts, n, cases.p2f_cfg(c))
+    _, outs = run_voxelizer(P, c, pts, n)
+    check_voxelizer(outs, ref)
+    # (c) a grid of 17.5M cells (468 x 468 x 80): two 2048-cell sub-ranges per bin
+    c = dict(N=131072, Nk=131072, P=131072, W=64, Vw=576)
+    grid, vox = [468, 468, 80], [0.32, 0.32, 0.1]
+    pts, n = cases.pad_points(pkg.synth.lidar_like(120000, 3), c["N"])
+    ref = oracle.points2features(pts, n, dict(cases.p2f_cfg(c), voxel_size=vox, grid_size=grid))
+    assert ref["coords"][:ref["P"], 1].max() > 40
+    op = P.add_voxel_generator(c["N"], c["Nk"], c["P"], 4, 10, 48, -74.88, 74.88, -74.88, 74.88, -5.0, 3.0, *vox, *grid)
+    outs = op(dev(pts[None]), scalar(n)); torch.cuda.synchronize()
+    check_voxelizer(outs, ref)
+
+
 def test_points2features_is_deterministic_and_order_invariant(pkg, oracle):
     c = cases.caps("ref")
     raw, n = cases.load_frame("000000", c["N"])
