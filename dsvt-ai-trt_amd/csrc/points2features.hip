@@ -42,6 +42,11 @@ struct P2FParams {
 };
 
 constexpr uint32_t kNone = 0xffffffffu;
+#ifdef DSVT_ABLATE
+#define P2F_DBG(bits) ((dbg) & (bits))
+#else
+#define P2F_DBG(bits) 0
+#endif
 constexpr int kBlk = 2048;          // points of a partition block (eight per thread)
 constexpr int kBinCells = 2048;     // cells whose tables one pass of p2f_bins keeps in LDS
 constexpr int kMaxBins = 8192;      // bins p2f_partition histograms in LDS (32 KB); beyond, a bin holds several 2048-cell sub-ranges
@@ -55,7 +60,7 @@ struct P2FPlan {
     int nsub;         // 2048-cell sub-ranges per bin (1 unless the grid has more than kMaxBins * 2048 cells)
     int nbins;
     int ncell;        // cells of all frames
-    int dbg;          // timing ablations (wrong results; tools/, the ablate build): 1 no placement stores, 2 no point / index loads, 4 no LDS atomic in the placement
+    int dbg;          // timing ablations of p2f_pillar (wrong results; compiled only into the ablate build, tools/trace_p2f.sh): 64 no feature stores, 128 no point-id stores, 256 no whole-wavefront passes
     unsigned long long* trace;      // debugging (tools/, the ablate build): wall-clock stamps of p2f_bins' phases, 8 per bin, or nullptr
 };
 
@@ -500,7 +505,7 @@ p2f_pillar(P2FParams p, int dbg, const uint32_t* __restrict__ pillar_num, const 
     // five waves per SIMD instead of seven.)
     for (int k = 0; k < 4; ++k) {
         const uint32_t nk = __shfl(nfull, 16 * k, kWave);
-        if (nk > 16u && !(dbg & 256))
+        if (nk > 16u && !P2F_DBG(256))
             p2fPillarWave(pid0 + (uint32_t)k * S, __shfl(rec.x, 16 * k, kWave), nk, __shfl(rec.z, 16 * k, kWave), p, srt, part_pts, part_idx, feat, pidx,
                           sel_lds + (threadIdx.x / kWave) * kWave);
     }
@@ -533,10 +538,10 @@ p2f_pillar(P2FParams p, int dbg, const uint32_t* __restrict__ pillar_num, const 
     }
     const int ni = (int)kept;
     cx = cx / ni; cy = cy / ni; cz = cz / ni;
-    if (!(dbg & 128))
+    if (!P2F_DBG(128))
     for (uint32_t e = (uint32_t)sl; e < T; e += 16u) pidx[(size_t)pid * T + e] = e < kept ? ptoff + e : 0u;   // :829-830
-    if (sl < (int)kept && !(dbg & 64)) p2fWriteFeat(feat + (size_t)(ptoff + sl) * p.feature_num, q, cx, cy, cz, p);
-    if ((dbg & 64) && cx + q.x == 123.f) feat[0] = cx;
+    if (sl < (int)kept && !P2F_DBG(64)) p2fWriteFeat(feat + (size_t)(ptoff + sl) * p.feature_num, q, cx, cy, cz, p);
+    if (P2F_DBG(64) && cx + q.x == 123.f) feat[0] = cx;       // (keeps the arithmetic alive)
 }
 
 // frames > 1 (optional field "frames", not in the reference): SEVERAL frames per enqueue with their rows CONCATENATED -- the layout the
@@ -624,7 +629,6 @@ public:
                            tab, part_pts, part_key, part_idx, scan_state, (int)stateWords());
         hipLaunchKernelGGL(p2f_bins, dim3(pl.nbins), dim3(kBT), 0, stream, p_, pl, tab, part_key, srt, scan_state,
                            pil_rec, coords, pcnt, pillar_num, point_num);
-        if (!(pl.dbg & 63))
         hipLaunchKernelGGL(p2f_pillar, dim3(cdiv(cdiv(p_.max_pillars_num, 16), 4) * 4), dim3(256), 0, stream,     // four groups of S = cap / 16 wavefronts
                            p_, pl.dbg, pillar_num, srt, part_pts, part_idx,
                            pil_rec, feat, pidx);
