@@ -61,20 +61,29 @@ const DsvtPluginFieldCollection* dsvtGetFieldNames(const char* type, const char*
 DsvtPlugin* dsvtCreatePlugin(const char* type, const char* version, const char* layerName,
                              const DsvtPluginFieldCollection* fc) {
     DSVT_GUARD(nullptr,
+        createError().clear();
         Creator* c = findCreator(type, version);
-        if (!c || !fc || fc->nbFields < 0 || (fc->nbFields > 0 && !fc->fields)) return nullptr;
+        if (!c) { createError() = "no plugin of this type and version is registered"; return nullptr; }
+        if (!fc || fc->nbFields < 0 || (fc->nbFields > 0 && !fc->fields)) { createError() = "null or malformed field collection"; return nullptr; }
         fieldError() = false;
         Plugin* p = c->create(fc);
-        if (p && fieldError()) { delete p; p = nullptr; }      // an array field shorter than what the creator reads
+        if (p && fieldError()) { delete p; p = nullptr; createError() = "an array field is shorter than the number of elements the creator reads"; }
+        if (!p && createError().empty()) createError() = "the creator rejected the field values (missing field, value out of range, or a capacity this build does not support)";
         return wrap(p, layerName);)
 }
 
 DsvtPlugin* dsvtDeserializePlugin(const char* type, const char* version, const char* layerName,
                                   const void* data, size_t len) {
     DSVT_GUARD(nullptr,
+        createError().clear();
         Creator* c = findCreator(type, version);
-        return (c && data) ? wrap(c->deserialize(data, len), layerName) : nullptr;)
+        if (!c || !data) { createError() = !c ? "no plugin of this type and version is registered" : "null serial data"; return nullptr; }
+        Plugin* p = c->deserialize(data, len);
+        if (!p && createError().empty()) createError() = "the serialized blob is too short or holds values the plugin rejects";
+        return wrap(p, layerName);)
 }
+
+const char* dsvtGetLastCreateError(void) { return createError().c_str(); }
 
 const char* dsvtPluginGetType(const DsvtPlugin* p) { return p ? p->impl->type() : nullptr; }
 const char* dsvtPluginGetVersion(const DsvtPlugin*) { return DSVT_PLUGIN_VERSION; }

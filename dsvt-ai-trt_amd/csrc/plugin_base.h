@@ -86,6 +86,8 @@ inline float fieldFloat(const DsvtPluginFieldCollection* fc, const char* name, f
 // a fixed number of elements, so length <= 1 means "unspecified" here too; a caller that DOES state a length states the truth, and a
 // field shorter than what the creator reads is an error (fieldError() makes dsvtCreatePlugin return NULL instead of reading past it).
 inline bool& fieldError() { static thread_local bool e = false; return e; }
+// why the last dsvtCreatePlugin / dsvtDeserializePlugin of this thread returned NULL (dsvtGetLastCreateError); creators that can say set it
+inline std::string& createError() { static thread_local std::string m; return m; }
 inline bool fieldHolds(const DsvtPluginField* f, long n) {
     if (f && f->data && f->length > 1 && f->length < n) { fieldError() = true; return false; }
     return f && f->data;

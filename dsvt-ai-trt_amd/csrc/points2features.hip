@@ -29,6 +29,7 @@
 #include "plugin_base.h"
 #include "device_utils.h"
 #include <cstdio>
+#include <string>
 
 namespace dsvt {
 
@@ -659,11 +660,15 @@ public:
 };
 
 static bool validP2F(const P2FParams& p) {
-    return p.max_points_num > 0 && p.max_points_num_voxel_filter > 0 && p.max_pillars_num > 0 &&
-           p.point_feature_num == 4 && p.feature_num == 10 &&
-           p.max_num_points_per_voxel > 0 && p.max_num_points_per_voxel <= kWave &&
-           p.gx > 0 && p.gy > 0 && p.gz > 0 && p.frames >= 1 && (long)p.gx * p.gy * p.gz * p.frames < (1l << 30) && p.vx > 0 && p.vy > 0 && p.vz > 0 &&
-           ((long)p.max_points_num + kBlk) * p.frames < (1l << 31);    // the row indices and the slot numbers are 32-bit; the look-back word holds 30 bits of pillars, 32 of points
+    auto no = [](const char* why) { createError() = std::string("Points2FeaturesPlugin: ") + why; return false; };
+    if (p.max_points_num <= 0 || p.max_points_num_voxel_filter <= 0 || p.max_pillars_num <= 0) return no("max_points_num, max_points_num_voxel_filter and max_pillars_num must be positive");
+    if (p.point_feature_num != 4 || p.feature_num != 10) return no("point_feature_num must be 4 and feature_num 10 (x, y, z, intensity -> the reference's ten features)");
+    if (p.max_num_points_per_voxel <= 0 || p.max_num_points_per_voxel > kWave) return no("max_num_points_per_voxel must be in 1 .. 64 (one wavefront lane per kept point)");
+    if (p.gx <= 0 || p.gy <= 0 || p.gz <= 0 || p.frames < 1) return no("grid_size and frames must be positive");
+    if (!(p.vx > 0 && p.vy > 0 && p.vz > 0)) return no("voxel_size must be positive");
+    if ((long)p.gx * p.gy * p.gz * p.frames >= (1l << 30)) return no("grid cells x frames must stay below 2^30 (the look-back word holds a 30-bit pillar count)");
+    if (((long)p.max_points_num + kBlk) * p.frames >= (1l << 31)) return no("(max_points_num + 2048) x frames must stay below 2^31 (32-bit row indices and slot numbers)");
+    return true;
 }
 
 static Plugin* p2fCreate(const DsvtPluginFieldCollection* fc) {                                    // :1113-1195

@@ -156,7 +156,7 @@ struct Op {
         if (!dsvtGetFieldNames(pluginType, DSVT_PLUGIN_VERSION)) die(std::string("no creator for ") + pluginType);
         DsvtPluginFieldCollection fc{(int32_t)fld.f.size(), fld.f.data()};
         h = dsvtCreatePlugin(pluginType, DSVT_PLUGIN_VERSION, layer, &fc);
-        if (!h) die(std::string("createPlugin(") + pluginType + ") rejected its fields");
+        if (!h) die(std::string("createPlugin(") + pluginType + ") rejected its fields: " + dsvtGetLastCreateError());
         if (!zeroFill) dsvtPluginSetZeroFill(h, 0);
     }
     // first call: size outputs / workspace from the plugin (getOutputDimensions / getOutputDataType / getWorkspaceSize)

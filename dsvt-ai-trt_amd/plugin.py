@@ -82,6 +82,8 @@ def _load():
     lib.dsvtPluginDestroy.argtypes = [C.c_void_p]
     lib.dsvtPluginSetZeroFill.argtypes = [C.c_void_p, C.c_int32]
     lib.dsvtGetBuildInfo.restype = C.c_char_p
+    lib.dsvtGetLastCreateError.restype = C.c_char_p
+    lib.dsvtGetLastCreateError.argtypes = []
     return lib
 
 
@@ -97,7 +99,7 @@ EXPORTED_SYMBOLS = [
     "dsvtDeserializePlugin", "dsvtPluginGetType", "dsvtPluginGetVersion", "dsvtPluginGetNbOutputs",
     "dsvtPluginGetOutputDimensions", "dsvtPluginGetOutputDataType", "dsvtPluginSupportsFormatCombination",
     "dsvtPluginGetWorkspaceSize", "dsvtPluginConfigurePlugin", "dsvtPluginEnqueue", "dsvtPluginGetSerializationSize",
-    "dsvtPluginSerialize", "dsvtPluginClone", "dsvtPluginDestroy", "dsvtPluginSetZeroFill", "dsvtGetBuildInfo",
+    "dsvtPluginSerialize", "dsvtPluginClone", "dsvtPluginDestroy", "dsvtPluginSetZeroFill", "dsvtGetBuildInfo", "dsvtGetLastCreateError",
 ]
 
 
@@ -174,7 +176,8 @@ class Plugin:
             fc = PluginFieldCollection(len(flist), arr_t)
             _handle = LIB.dsvtCreatePlugin(plugin_type.encode(), version.encode(), layer_name.encode(), C.byref(fc))
             if not _handle:
-                raise ValueError(f"createPlugin({plugin_type}) rejected fields {fields}")
+                why = LIB.dsvtGetLastCreateError()
+                raise ValueError(f"createPlugin({plugin_type}) rejected fields {fields}: {why.decode() if why else 'no reason given'}")
         self._h = C.c_void_p(_handle)
         self.fields = {k: (v if not isinstance(v, np.ndarray) or v.size <= 8 else v.shape) for k, v in (fields or {}).items()}
         self.nb_outputs = LIB.dsvtPluginGetNbOutputs(self._h)

@@ -130,6 +130,11 @@ const DsvtPluginFieldCollection* dsvtGetFieldNames(const char* pluginType, const
 DsvtPlugin* dsvtCreatePlugin(const char* pluginType, const char* pluginVersion, const char* layerName,
                              const DsvtPluginFieldCollection* fc);
 
+/* Why the calling thread's last dsvtCreatePlugin / dsvtDeserializePlugin returned NULL ("" after a success).  The reference reports such
+ * failures through the TensorRT logger (e.g. the printf / assert lines of plugins/src/points2Features.cu:1113-1195); there is no logger
+ * object in this ABI, so the text is kept per thread.  The pointer is valid until the thread's next create / deserialize call. */
+const char* dsvtGetLastCreateError(void);
+
 /* IPluginCreator::deserializePlugin(name, data, length), e.g. points2Features.cu:1196-1200 */
 DsvtPlugin* dsvtDeserializePlugin(const char* pluginType, const char* pluginVersion, const char* layerName,
                                   const void* serialData, size_t serialLength);

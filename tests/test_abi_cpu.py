@@ -195,3 +195,19 @@ def test_plain_c_client_compiles_links_and_runs(pkg, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "abi_client ok" in out.stdout and "gfx950" in out.stdout
+
+
+def test_create_failure_says_why(pkg):
+    """dsvtGetLastCreateError: a rejected createPlugin leaves its reason for the calling thread (the reference logs through TensorRT)"""
+    P = pkg.plugin
+    with pytest.raises(ValueError) as e:
+        P.add_voxel_generator(1 << 29, 1 << 29, 65536, 4, 10, 48, -74.88, 74.88, -74.88, 74.88, -5.0, 3.0, 0.32, 0.32, 8.0, 468, 468, 1, frames=8)
+    assert "2^31" in str(e.value)
+    with pytest.raises(ValueError) as e:
+        P.add_voxel_generator(4096, 4096, 64, 4, 10, 200, -74.88, 74.88, -74.88, 74.88, -5.0, 3.0, 0.32, 0.32, 8.0, 468, 468, 1)
+    assert "max_num_points_per_voxel" in str(e.value)
+    L = P.LIB
+    assert not L.dsvtCreatePlugin(b"NoSuchPlugin", b"1", b"x", None)
+    assert b"registered" in L.dsvtGetLastCreateError()
+    ok = P.add_voxel_generator(4096, 4096, 64, 4, 10, 48, -74.88, 74.88, -74.88, 74.88, -5.0, 3.0, 0.32, 0.32, 8.0, 468, 468, 1)
+    assert ok is not None and L.dsvtGetLastCreateError() == b""
