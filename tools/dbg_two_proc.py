@@ -34,7 +34,7 @@ def snap(s):
                 d[(i, pl.plugin_type, j, k)] = t.clone()
     d[("boxes",)] = pipes[s]._last[0].clone(); d[("cnt",)] = pipes[s]._last[1].clone()
     return d
-refs, bad, first = None, {}, {}
+refs, bad, first, detail = None, {}, {}, []
 t_end = time.time() + float(os.environ.get("SECONDS", "40"))
 it = 0
 while time.time() < t_end:
@@ -51,7 +51,13 @@ while time.time() < t_end:
             if diffs:
                 bad.setdefault(s, []).append(it)
                 first.setdefault((s, it), diffs[:6])
+                if len(detail) < 4:
+                    k = diffs[0]; a, b_ = cur[s][k].reshape(-1), refs[s][k].reshape(-1)
+                    ne = (a != b_).nonzero().reshape(-1)
+                    detail.append((s, it, k, int(ne.numel()), ne[:4].tolist(), a[ne[:4]].tolist(), b_[ne[:4]].tolist(), tuple(cur[s][k].shape)))
     it += 1
 print("rank", RANK, "iters", it, "cnt", [r[("cnt",)].tolist() for r in refs], "iterations differing per stream:", {s: v[:10] for s, v in bad.items()} or "none")
 for k, v in list(first.items())[:5]:
     print("   stream/iter", k, "first differing buffers", v)
+for d in detail:
+    print("   detail (stream, iter, buffer, differing elements, first indices, got, expected, shape):", d)
