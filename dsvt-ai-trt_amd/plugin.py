@@ -93,6 +93,22 @@ LIB = _load()
 # {plugin_type: [(start_event, end_event, plugin), ...]} every enqueue of a listed plugin type is
 # bracketed by HIP events on the launching stream.
 PROFILE = None
+# Test seam (tests/test_pipeline_gpu.py::test_no_plugin_writes_outside_its_buffers): with GUARD_BYTES > 0 every output and workspace the
+# convenience call path allocates sits between two bands of GUARD_BYTES 0xA5 bytes, listed in GUARDED as (whole uint8 buffer, payload bytes).
+GUARD_BYTES = 0
+GUARDED = []
+
+
+def _alloc(shape, dtype, device, zero):
+    if not GUARD_BYTES:
+        return torch.zeros(shape, dtype=dtype, device=device) if zero else torch.empty(shape, dtype=dtype, device=device)
+    n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+    whole = torch.full((n + 2 * GUARD_BYTES,), 0xA5, dtype=torch.uint8, device=device)
+    payload = whole[GUARD_BYTES:GUARD_BYTES + n]
+    if zero:
+        payload.zero_()
+    GUARDED.append((whole, n))
+    return payload.view(dtype).view(shape)
 
 EXPORTED_SYMBOLS = [
     "dsvtGetNbPluginTypes", "dsvtGetPluginTypeName", "dsvtGetFieldNames", "dsvtCreatePlugin",
@@ -290,10 +306,10 @@ class Plugin:
             for i in range(self.nb_outputs):
                 shp = self.get_output_dimensions(i, shapes)
                 dt = _torch_dtype(self.get_output_data_type(i, codes))
-                outs.append(torch.zeros(shp, dtype=dt, device=inputs[0].device))
+                outs.append(_alloc(shp, dt, inputs[0].device, True))
             wsz = self.get_workspace_size([_desc(s, c) for s, c in zip(shapes, codes)],
                                           [_desc(o.shape, _dt_code(o)) for o in outs])
-            ws = torch.empty(max(wsz, 256), dtype=torch.uint8, device=inputs[0].device)
+            ws = _alloc((max(wsz, 256),), torch.uint8, inputs[0].device, False)
             ent = (outs, ws)
             self._cache[sig] = ent
         outs, ws = ent

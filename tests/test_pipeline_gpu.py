@@ -165,6 +165,33 @@ def test_boxes_do_not_depend_on_stale_buffer_contents(pkg, weights, mode):
         assert torch.equal(c, c0) and torch.equal(b, b0), (kind, c.tolist(), c0.tolist())
 
 
+@pytest.mark.parametrize("mode,frames", [("f16", 4), ("split", 1), ("f16", 1)])
+def test_no_plugin_writes_outside_its_buffers(pkg, weights, mode, frames):
+    """Guard-band sanitiser: every output and workspace of every plugin of the frame is allocated between two 4 KB bands of 0xA5 bytes
+    (plugin.GUARD_BYTES); after forwards over dense, sparse and empty frames every band is intact."""
+    P = pkg.plugin
+    P.GUARD_BYTES, P.GUARDED[:] = 4096, []
+    try:
+        kw = dict(linear_compute=P.COMPUTE_SPLIT) if mode == "split" else dict(linear_compute=P.COMPUTE_F16, head_dtype=torch.float16)
+        caps = pkg.pipeline.Caps() if frames == 1 else pkg.pipeline.Caps.for_frames(frames)
+        pipe = pkg.pipeline.DsvtPipeline(weights, caps=caps, device=DEV, device_nms=True, frames=frames, **kw)
+        counts = []
+        for trial, npts in enumerate([[180000, 60000, 0, 196608][:frames], [1, 37, 120000, 5][:frames]]):
+            buf = np.zeros((1, frames * caps.N, 4), np.float32)
+            for f, m in enumerate(npts):
+                if m:
+                    p = pkg.synth.lidar_like(m, 20 + 4 * trial + f); buf[0, f * caps.N:f * caps.N + len(p)] = p
+            b, c = pipe.forward(torch.from_numpy(buf).to(DEV), torch.tensor(npts, dtype=torch.int32, device=DEV))
+            torch.cuda.synchronize()
+            counts.append(c.tolist())
+        assert len(P.GUARDED) > 100 and max(counts[0]) > 50
+        G = P.GUARD_BYTES
+        for whole, n in P.GUARDED:
+            assert bool((whole[:G] == 0xA5).all()) and bool((whole[G + n:] == 0xA5).all()), (n, int((whole[:G] != 0xA5).sum()), int((whole[G + n:] != 0xA5).sum()))
+    finally:
+        P.GUARD_BYTES, P.GUARDED[:] = 0, []
+
+
 def _box_errors(got, n_got, exp, n_exp):
     """per-field max abs error over rows matched by (class, nearest centre within 0.2 m); fraction matched"""
     got, exp = got[:n_got], exp[:n_exp]
