@@ -1244,8 +1244,11 @@ conv3x3_c64_resident_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT
 // one sub-pixel (dy, dx) of the pixel shuffle, so the epilogue is the wide one (bias, ReLU, fp16, 16-byte stores).
 // Needs Cout == 128, Cin in {128, 192, 256}, fp16 output with 16-byte alignment, no residual.
 constexpr int C1_NW = 8;
-template <int KSTEPS, bool STRIDED>       // STRIDED: stride 2 (the shortcuts of the second and third stage): output pixel (y, x) reads input pixel (2y, 2x)
-__global__ void __launch_bounds__(64 * C1_NW, 2)
+// MT = 16-pixel tiles a wave works on together.  One tile: every MFMA reads its own 1 KB weight fragment from LDS (8 cycles of the CU's LDS
+// port for an 8-cycle MFMA -- the 256 -> 16 x 128 deblock ran at half the rate of either).  Two tiles: a fragment feeds two MFMAs (the rows of
+// both tiles in registers: 2 x 2 x KSTEPS x 4 registers, which is why it is the ONE-workgroup-per-CU configuration, KSTEPS = 8 -- 129 KB of weights).
+template <int KSTEPS, bool STRIDED, int MT = 1>       // STRIDED: stride 2 (the shortcuts of the second and third stage): output pixel (y, x) reads input pixel (2y, 2x)
+__global__ void __launch_bounds__(64 * C1_NW, MT == 1 ? 2 : 1)
 conv1x1_resident_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT, int ngroup, int CTG)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[KSTEPS * 16 * 1024 + 1024];        // [k-step][column tile of the group] | bias
@@ -1260,7 +1263,7 @@ conv1x1_resident_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT, in
         const float* src = a.bias ? a.bias + (lane * 4 < a.Cout ? lane * 4 : 0) : reinterpret_cast<const float*>(Wp);
         __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + BIAS_OFF), 16, 0, 0);
     }
-    const int HW = a.Ho * a.Wo, NPIX = a.nb * HW, ntile = (NPIX + 15) >> 4, step = nj * C1_NW;      // OUTPUT pixels (before the pixel shuffle)
+    const int HW = a.Ho * a.Wo, NPIX = a.nb * HW, ntile = (NPIX + 16 * MT - 1) / (16 * MT), step = nj * C1_NW;      // OUTPUT pixels (before the pixel shuffle), MT x 16 per wave step
     const float invHW = 1.0f / (float)HW, invW = 1.0f / (float)a.Wo;
     // output pixel -> (image, y, x): float quotients corrected by one step (exact for these sizes; belt and braces)
     auto split = [&](int pc, int& b, int& y, int& xq) {
@@ -1269,14 +1272,17 @@ conv1x1_resident_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT, in
         y = (int)(((float)rem + 0.5f) * invW); y -= (y * a.Wo > rem); y += ((y + 1) * a.Wo <= rem);
         xq = rem - y * a.Wo;
     };
-    auto loadRows = [&](int t, half8 (&x)[KSTEPS]) {
+    auto loadRows = [&](int t, half8 (&x)[MT][KSTEPS]) {
         t = t < ntile ? t : ntile - 1;                               // (past the end: the last tile again, no branch around a load)
-        const int p = t * 16 + r, pc = p < NPIX ? p : NPIX - 1;
-        size_t ipix = (size_t)pc;
-        if (STRIDED) { int b, y, xq; split(pc, b, y, xq); ipix = (size_t)(b * a.H + y * a.stride) * a.W + xq * a.stride; }
-        const _Float16* src = a.in + ipix * a.Cin + g * 8;
 #pragma unroll
-        for (int q = 0; q < KSTEPS; ++q) x[q] = *reinterpret_cast<const half8*>(src + q * 32);
+        for (int m = 0; m < MT; ++m) {
+            const int p = (t * MT + m) * 16 + r, pc = p < NPIX ? p : NPIX - 1;
+            size_t ipix = (size_t)pc;
+            if (STRIDED) { int b, y, xq; split(pc, b, y, xq); ipix = (size_t)(b * a.H + y * a.stride) * a.W + xq * a.stride; }
+            const _Float16* src = a.in + ipix * a.Cin + g * 8;
+#pragma unroll
+            for (int q = 0; q < KSTEPS; ++q) x[m][q] = *reinterpret_cast<const half8*>(src + q * 32);
+        }
     };
     const unsigned char* slot = smem + lane * 16;
     const int nstage = CTG >> 3;                                     // 128-column stages of this group
@@ -1287,45 +1293,74 @@ conv1x1_resident_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT, in
         const int n0 = (type * nstage + st) * 128, sub = n0 / a.Cout;
         sdy[st] = sub / a.up; sdx[st] = sub - sdy[st] * a.up; scb[st] = n0 - sub * a.Cout;
     }
-    auto tile = [&](int t, const half8 (&x)[KSTEPS]) {
-        const int p = t * 16 + r;
-        const bool valid = p < NPIX;
-        int b, y, xq; split(valid ? p : 0, b, y, xq);
+    auto tile = [&](int t, const half8 (&x)[MT][KSTEPS]) {
+        bool valid[MT]; int b[MT], y[MT], xq[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int p = (t * MT + m) * 16 + r;
+            valid[m] = p < NPIX;
+            split(valid[m] ? p : 0, b[m], y[m], xq[m]);
+        }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             if (st >= nstage) break;
             const int dy = sdy[st], dx = sdx[st], cbase = scb[st];
-            const size_t opix = (size_t)((b * a.Ho + y) * a.up + dy) * Wout + (xq * a.up + dx);
-            floatx4 acc[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + BIAS_OFF + (cbase + u * 16 + 4 * g) * 4);
-                acc[u] = a.bias ? b4 : floatx4{0.f, 0.f, 0.f, 0.f};
-            }
             const unsigned char* sp = slot + (st * 8) * 1024;
+            constexpr int UB = 8 / MT;                               // column tiles per accumulator block (the rows of MT pixel tiles fill the registers)
 #pragma unroll
-            for (int q = 0; q < KSTEPS; ++q)
+            for (int u0 = 0; u0 < 8; u0 += UB) {
+                floatx4 acc[MT][UB];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(sp + (size_t)(q * CTG + u) * 1024), x[q], acc[u], 0, 0, 0);
+                for (int u = 0; u < UB; ++u) {
+                    const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + BIAS_OFF + (cbase + (u0 + u) * 16 + 4 * g) * 4);
 #pragma unroll
-            for (int u = 0; u < 8; u += 2) convStoreWide<false>(a, acc[u], acc[u + 1], valid, opix, cbase + u * 16, g);
+                    for (int m = 0; m < MT; ++m) acc[m][u] = a.bias ? b4 : floatx4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int q = 0; q < KSTEPS; ++q)
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        const half8 wf = *reinterpret_cast<const half8*>(sp + (size_t)(q * CTG + u0 + u) * 1024);
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) acc[m][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, x[m][q], acc[m][u], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const size_t opix = (size_t)((b[m] * a.Ho + y[m]) * a.up + dy) * Wout + (xq[m] * a.up + dx);
+#pragma unroll
+                    for (int u = 0; u < UB; u += 2) convStoreWide<false>(a, acc[m][u], acc[m][u + 1], valid[m], opix, cbase + (u0 + u) * 16, g);
+                }
+            }
         }
     };
     int tt = j * C1_NW + wave;
-    half8 xa[KSTEPS], xb[KSTEPS];
-    loadRows(tt, xa);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the weights (and the first rows) have landed
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    while (tt < ntile) {
-        const int tn = tt + step;
-        loadRows(tn, xb);
-        tile(tt, xa);
-        if (tn >= ntile) break;
-        tt = tn + step;
+    if constexpr (MT == 1) {
+        half8 xa[MT][KSTEPS], xb[MT][KSTEPS];
         loadRows(tt, xa);
-        tile(tn, xb);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the weights (and the first rows) have landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        while (tt < ntile) {
+            const int tn = tt + step;
+            loadRows(tn, xb);
+            tile(tt, xa);
+            if (tn >= ntile) break;
+            tt = tn + step;
+            loadRows(tt, xa);
+            tile(tn, xb);
+        }
+    } else {
+        // two pixel tiles: their rows are 2 x KSTEPS x 4 registers, a second set does not fit -- the wave that shares the SIMD covers the load
+        half8 xa[MT][KSTEPS];
+        loadRows(tt, xa);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        while (tt < ntile) {
+            tile(tt, xa);
+            tt += step;
+            if (tt < ntile) loadRows(tt, xa);
+        }
     }
 }
 
@@ -1354,7 +1389,9 @@ static int launchConv1x1Resident(const ConvArgs& a, const _Float16* Wp, hipStrea
     const dim3 grid(numCUs() / ngroup * ngroup), block(64 * C1_NW);
 #define DSVT_C1(K_) do { if (a.stride == 2) hipLaunchKernelGGL((conv1x1_resident_kernel<K_, true>), grid, block, 0, stream, a, Wp, NCT, ngroup, CTG); \
                          else hipLaunchKernelGGL((conv1x1_resident_kernel<K_, false>), grid, block, 0, stream, a, Wp, NCT, ngroup, CTG); } while (0)
-    if (a.Cin == 128) DSVT_C1(4); else if (a.Cin == 192) DSVT_C1(6); else DSVT_C1(8);
+    if (a.Cin == 128) DSVT_C1(4); else if (a.Cin == 192) DSVT_C1(6);
+    else if (a.stride == 2) hipLaunchKernelGGL((conv1x1_resident_kernel<8, true>), grid, block, 0, stream, a, Wp, NCT, ngroup, CTG);
+    else hipLaunchKernelGGL((conv1x1_resident_kernel<8, false, 2>), grid, block, 0, stream, a, Wp, NCT, ngroup, CTG);       // (129 KB of weights: one workgroup per CU either way)
 #undef DSVT_C1
     return lastError();
 }
