@@ -1122,19 +1122,23 @@ conv3x3_grouped_narrow_kernel(ConvArgs a, const _Float16* __restrict__ Wg, const
 // (51 + 72 KB); the next item's halo waits in seven staging registers per lane, requested before this item's 144 MFMAs per wave and
 // written to LDS after them (through registers a one-item lead costs no second buffer; measured equal to a DMA double buffer on the
 // narrow kernel above).  Wave (pg, half) = rows 2 pg, 2 pg + 1 x two pixel tiles x all four channel tiles (0.75 fragment reads per MFMA).
+// Round 3: SIXTEEN-row items (18 x 34 halo pixels of 128 bytes = 78 KB beside the 72 KB of weights: 151 KB), wave w = rows 2w, 2w + 1 = FOUR pixel
+// tiles x all four channel tiles: 4 + 4 fragment reads per 16 MFMAs = 0.5 per MFMA.  With eight-row items (two pixel tiles per wave, 0.75 reads
+// per MFMA) the kernel sat exactly on the LDS port -- a 1 KB fragment read occupies it for 8 cycles, as long as an MFMA occupies one of the four
+// matrix pipes, so r reads per MFMA cap the CU at 0.25 / r of its MFMA peak: 0.33 x 2.5 = 0.83 PFLOP/s, measured 0.80.
+constexpr int C64_TH = 16, C64_HS = 34;
 __global__ void __launch_bounds__(512, 1)
 conv3x3_c64_resident_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT, const _Float16* __restrict__ zeros, int tilesX, int tilesY, int NTY)
 {
-    constexpr int TH = 8, HS = HHS, HH = TH + 2, HWU = HTW + 2, HBYTES = HH * HS * 128, NI = HH * HS / 8, HPW = (NI + TH - 1) / TH;
+    constexpr int TH = C64_TH, NWV = 8, HS = C64_HS, HH = TH + 2, HWU = HTW + 2, NI = (HH * HS + 7) / 8, HBYTES = NI * 1024, HPW = (NI + NWV - 1) / NWV;
     __shared__ __attribute__((aligned(16))) unsigned char smem[HBYTES + 72 * 1024 + 1024];        // halo | weights [k-step][4 tiles] | bias (64 floats)
     constexpr int W_OFF = HBYTES, BIAS_OFF = HBYTES + 72 * 1024;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
-    const int pg = wave >> 1, m0 = 2 * (wave & 1);
     const int ty = (int)blockIdx.x % NTY, j = (int)blockIdx.x / NTY, nj = ((int)gridDim.x - ty + NTY - 1) / NTY;
     const int ntile = a.nb * tilesY * tilesX;
     if (j >= ntile) return;
     // the halo image's rows [q = tap * 2 + ks][16-channel tile ct of NCT]: this type's four tiles of every k-step
-    for (int u = wave; u < 72; u += TH) {
+    for (int u = wave; u < 72; u += NWV) {
         const int q = u >> 2, ct = u & 3;
         __builtin_amdgcn_global_load_lds((glds_src_t)(Wp + (((size_t)q * NCT + ty * 4 + ct) * 64 + lane) * 8), (glds_dst_t)(smem + W_OFF + u * 1024), 16, 0, 0);
     }
@@ -1142,10 +1146,10 @@ conv3x3_c64_resident_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT
         const float* src = a.bias ? a.bias + ((ty * 64) % a.Cout) + (lane < 16 ? lane * 4 : 0) : reinterpret_cast<const float*>(Wp);
         __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + BIAS_OFF), 16, 0, 0);
     }
-    int hpos[HPW], goff[HPW];
+    int hpos[HPW];
 #pragma unroll
     for (int q = 0; q < HPW; ++q) {
-        const int lp = 8 * (wave + q * TH) + (lane >> 3), slot = lane & 7;
+        const int lp = 8 * (wave + q * NWV) + (lane >> 3), slot = lane & 7;
         const int hy = lp / HS, hx = lp - hy * HS;
         hpos[q] = (hy << 16) | (hx << 4) | (slot ^ (hx & 7));
     }
@@ -1158,25 +1162,26 @@ conv3x3_c64_resident_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT
     auto haloLoad = [&](int t) {                                     // tile t (clamped: no branch around a load) -> staging registers
         int yy, xx, bb;
         decode(t < ntile ? t : ntile - 1, yy, xx, bb);
+        int goff[HPW];
 #pragma unroll
         for (int q = 0; q < HPW; ++q) {
-            const int hx = (hpos[q] >> 4) & 0xfff;
-            const int gy = yy - 1 + (hpos[q] >> 16), gx = xx - 1 + hx;
-            const bool ok = hx < HWU && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const int hy = hpos[q] >> 16, hx = (hpos[q] >> 4) & 0xfff;
+            const int gy = yy - 1 + hy, gx = xx - 1 + hx;
+            const bool ok = hy < HH && hx < HWU && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
             goff[q] = ok ? ((bb * a.H + gy) * a.W + gx) * a.Cin + (hpos[q] & 15) * 8 : -1;
         }
 #pragma unroll
         for (int q = 0; q < HPW; ++q)
-            if (NI % TH == 0 || wave + q * TH < NI) stage[q] = *reinterpret_cast<const half8*>(goff[q] >= 0 ? a.in + goff[q] : zeros);
+            if (NI % NWV == 0 || wave + q * NWV < NI) stage[q] = *reinterpret_cast<const half8*>(goff[q] >= 0 ? a.in + goff[q] : zeros);
     };
     auto haloWrite = [&]() {
 #pragma unroll
         for (int q = 0; q < HPW; ++q)
-            if (NI % TH == 0 || wave + q * TH < NI) *reinterpret_cast<half8*>(smem + (wave + q * TH) * 1024 + lane * 16) = stage[q];
+            if (NI % NWV == 0 || wave + q * NWV < NI) *reinterpret_cast<half8*>(smem + (wave + q * NWV) * 1024 + lane * 16) = stage[q];
     };
-    int pbase[2];
+    int pbase[4];                                                    // pixel tile m of this wave: row 2 wave + (m >> 1), columns 16 (m & 1) ...
 #pragma unroll
-    for (int m = 0; m < 2; ++m) pbase[m] = ((2 * pg + ((m0 + m) >> 1)) * HS + ((m0 + m) & 1) * 16 + r) * 128;
+    for (int m = 0; m < 4; ++m) pbase[m] = ((2 * wave + (m >> 1)) * HS + (m & 1) * 16 + r) * 128;
     int swz[3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) swz[kx] = (g ^ ((r + kx) & 7)) << 4;
@@ -1193,26 +1198,27 @@ conv3x3_c64_resident_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT
         haloLoad(tn);                                                // in flight under this item's MFMAs
         int y0, x0, bimg;
         decode(t, y0, x0, bimg);
-        floatx4 acc[4][2];
+        floatx4 acc[4][4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + BIAS_OFF + (ct * 16 + 4 * g) * 4);
-            acc[ct][0] = a.bias ? b4 : floatx4{0.f, 0.f, 0.f, 0.f}; acc[ct][1] = acc[ct][0];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[ct][m] = a.bias ? b4 : floatx4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - 3 * ky, toff = (ky * HS + kx) * 128, sw = swz[kx];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                half8 A[4], B[2];
+                half8 A[4], B[4];
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) A[ct] = *reinterpret_cast<const half8*>(wres + (((tap * 2 + ks) * 4 + ct) << 10));
 #pragma unroll
-                for (int m = 0; m < 2; ++m) B[m] = *reinterpret_cast<const half8*>(smem + pbase[m] + toff + (sw ^ (ks << 6)));
+                for (int m = 0; m < 4; ++m) B[m] = *reinterpret_cast<const half8*>(smem + pbase[m] + toff + (sw ^ (ks << 6)));
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) acc[ct][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ct], B[m], acc[ct][m], 0, 0, 0);
+                    for (int m = 0; m < 4; ++m) acc[ct][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ct], B[m], acc[ct][m], 0, 0, 0);
             }
         }
         __syncthreads();                                             // everyone is done with this halo
@@ -1220,8 +1226,8 @@ conv3x3_c64_resident_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT
         __syncthreads();
         // (the stores after the barriers: they drain under the next item's MFMAs)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int oy = y0 + 2 * pg + ((m0 + m) >> 1), ox = x0 + ((m0 + m) & 1) * 16 + r;
+        for (int m = 0; m < 4; ++m) {
+            const int oy = y0 + 2 * wave + (m >> 1), ox = x0 + (m & 1) * 16 + r;
             const bool valid = oy < a.Ho && ox < a.Wo;
             const size_t opix = valid ? (size_t)(bimg * a.Ho + oy) * a.Wo + ox : 0;
             convStoreWide<false>(a, acc[0][m], acc[1][m], valid, opix, cbase, g);
@@ -1645,7 +1651,7 @@ public:
         }
         if (wp_dev_ && conv1x1ResidentEligible(a)) return launchConv1x1Resident(a, wp_dev_, stream);
         if (wp_dev_ && conv3x3C64Eligible(a)) {
-            const int tilesX = cdiv(a.Wo, HTW), tilesY = cdiv(a.Ho, 8);
+            const int tilesX = cdiv(a.Wo, HTW), tilesY = cdiv(a.Ho, C64_TH);
             const int ctw = haloChannelTiles(a.CoutRows), NCT = ctw < 8 ? ctw : cdiv(a.CoutRows, CNB) * 8;      // column tiles per k-step of the halo image
             hipLaunchKernelGGL(conv3x3_c64_resident_kernel, dim3(numCUs()), dim3(512), 0, stream, a, wp_dev_, NCT, zeros_dev_, tilesX, tilesY, a.CoutRows / 64);
             return lastError();
