@@ -101,6 +101,18 @@ pfn_kernel(PfnArgs a)
     int nmark = 0;
     auto mark = [&]() { if (a.trace && blockIdx.x == 0 && tid == 0 && nmark < 32) a.trace[nmark] = clock64(); ++nmark; };
     mark();
+    // first row of pillar pb0 + tid of group g (the sentinel entry, tid == npil, is one past the last pillar's rows).  A group is ~8 us of
+    // mostly dependent round trips, so the NEXT group's entries are requested before this group's point pass and wait in a register.
+    auto startOf = [&](uint32_t g) -> uint32_t {
+        if (g >= ngroups) return 0u;
+        const uint32_t pb = g * PF_PB;
+        const int np = P - pb < (uint32_t)PF_PB ? (int)(P - pb) : PF_PB;
+        if (tid > np) return 0u;
+        const uint32_t p = pb + (tid < np ? tid : np - 1);
+        const uint32_t s = a.pidx[(size_t)p * a.T];
+        return tid < np ? s : s + a.pcnt[p];
+    };
+    uint32_t myStart = startOf(blockIdx.x);
   for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     __syncthreads();                                 // everyone is done with the previous group's tables
     mark();
@@ -109,12 +121,8 @@ pfn_kernel(PfnArgs a)
 
     for (int i = tid; i < (SPLIT ? 2 : 1) * PF_PB * SM_LD; i += 64 * PF_NW) sM[i] = (_Float16)0.f;
     for (int i = tid; i < PF_PB * SU_LD; i += 64 * PF_NW) sU[i] = 0u;
-    if (tid <= npil) {
-        // first row of pillar pb0 + tid; the sentinel entry is one past the last pillar's rows
-        const uint32_t p = pb0 + (tid < npil ? tid : npil - 1);
-        const uint32_t s = a.pidx[(size_t)p * a.T];
-        sStart[tid] = tid < npil ? s : s + a.pcnt[p];
-    }
+    if (tid <= npil) sStart[tid] = myStart;
+    myStart = startOf(grp + gridDim.x);               // (in flight under this group's work)
     __syncthreads();
     // ---- point pass: one pillar at a time per wave, 16 points per MFMA tile (a short tile is padded with copies of the
     // pillar's first point: duplicates do not change a maximum).  Every tile belongs to ONE pillar, so the pillar maxima are
