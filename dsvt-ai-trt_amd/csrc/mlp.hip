@@ -222,9 +222,17 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
         m0 = blockIdx.x * 16 * nwa;
     } else {
         constexpr int WGR = 16 * MT * NW;                // rows of a full workgroup (128; 256 for <2, 8>)
-        const int T = (M + WGR - 1) / WGR, over = M - a.ncu * WGR;
-        const bool plan = !SPLIT && WGR == MROWS && T > a.ncu && over <= MLP_SMALL_MAX && !(a.dbg & 32);
-        const int FULL = plan ? a.ncu : T;
+        const int T = (M + WGR - 1) / WGR;
+        // Rounds: two full workgroups share a CU, so 2 ncu of them are a round.  What is left after the whole rounds -- at most
+        // MLP_SMALL_MAX rows -- runs as small workgroups: after a half round (the rows just overflow one tile per CU; round 2's rule), or,
+        // round 3, after any number of whole rounds: four frames per launch are 1074 tiles = two rounds of 512 and 50 more, which as full
+        // workgroups are a third round of one lonely workgroup per CU (44 us of the launch's 158).
+        int FULL = T;
+        if (!SPLIT && WGR == MROWS && !(a.dbg & 32)) {
+            const int base = T / (2 * a.ncu) * (2 * a.ncu), rem = T - base;
+            if (base > 0 && rem > 0 && M - base * WGR <= MLP_SMALL_MAX) FULL = base;
+            else if (rem > a.ncu && M - (base + a.ncu) * WGR <= MLP_SMALL_MAX) FULL = base + a.ncu;
+        }
         small = (int)blockIdx.x >= FULL;
         m0 = blockIdx.x * WGR;
         if (small) {
@@ -673,9 +681,9 @@ public:
     int launchVariant(MlpStreamArgs b, int variant, hipStream_t stream) const {
         const int ncu = b.ncu, over = max_rows_ - ncu * MROWS;
         const int srows = 16 * (variant == 2 ? 1 : 2) * MLP_SW;                 // rows of a small workgroup
-        const int gsmall = over > 0 ? ncu + cdiv(over < MLP_SMALL_MAX ? over : MLP_SMALL_MAX, srows) : 0;
+        (void)over;
         const int gfull = cdiv(max_rows_, MROWS);                               // (covers the elastic variant too: >= 128 rows per workgroup)
-        const dim3 grid(gfull > gsmall ? gfull : gsmall);
+        const dim3 grid(gfull + cdiv(MLP_SMALL_MAX, srows));                    // full workgroups of the whole rounds + the small ones of the remainder (the rest exit at once)
         static unsigned long long* tr = nullptr; static int tron = -1;         // tools/trace_mlp.py
         if (tron < 0) { tron = ablateEnv("DSVT_MLP_TRACE", 0) ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 32 * 1024); }
         b.trace = tr;
