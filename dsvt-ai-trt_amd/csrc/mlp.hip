@@ -38,7 +38,8 @@ constexpr int MNT = MC / 16;                      // 12 column tiles
 constexpr int MNSTEP = MC / 32;                   // 6 k-steps per 192-wide slab
 constexpr int MROWS = 128;
 constexpr int MLP_SMALL_MAX = 8192;        // rows beyond one tile per CU that are cut into small workgroups
-constexpr int MLP_SW = 1;                  // waves of a small workgroup, 32 rows each (two waves: 53.6 vs 50.1 us at 34.5k rows)
+constexpr int MLP_SW = 2;                  // waves of a small workgroup, 32 rows each (round 2, one frame on this kernel: two waves 53.6 vs one 50.1 us; round 3, the tail
+                                           // after two whole rounds at four frames: 1.25 vs 1.27 ms per eight launches, three waves 1.27-1.30)
 
 __device__ __forceinline__ float mlpGelu(float x) {
     // 0.5 (1 + tanh u) = 1 / (1 + exp(-2u)),  u = x (B + C x^2):  seven VALU operations (the constants carry the -2 log2(e) of
