@@ -243,7 +243,7 @@ __device__ __forceinline__ void p2fPillarWave(uint32_t pid, uint32_t seg, uint32
 // bins: the wait for the slowest predecessor is hidden behind the bin's own work.  Bins with more than kCap points, and launches with
 // more than kBT partition blocks, take a slower path (binary search per entry) for what the list does not hold.
 constexpr unsigned long long kFlagAgg = 1ull << 62, kFlagInc = 2ull << 62, kFlagMask = 3ull << 62;
-constexpr int kCap = 12288;        // entries of a bin whose slots p2f_bins lists in LDS (48 KB)
+constexpr int kCap = 16384;        // entries of a bin whose slots p2f_bins lists in LDS (64 KB; the 180k-point bench clouds put 12.1k - 12.5k into the bins that cross the sensor)
 
 __global__ void __launch_bounds__(kBT)
 p2f_bins(P2FParams p, P2FPlan pl, const uint16_t* __restrict__ tab, const uint32_t* __restrict__ part_key,
