@@ -113,7 +113,7 @@ def test_points2features_edge_cases(pkg, oracle):
 
 
 def test_points2features_slow_paths_of_the_bucket_pass(pkg, oracle):
-    """The voxelizer's bins keep the slots of up to 12288 points in LDS, take their pieces from the first 1024 partition blocks and hold
+    """The voxelizer's bins keep the slots of up to 16384 points in LDS, take their pieces from the first 1024 partition blocks and hold
     2048 cells; beyond any of the three a slower path runs (csrc/points2features.hip p2f_bins).  All three against the oracle, bit for bit."""
     P = pkg.plugin
     rng = np.random.default_rng(11)
