@@ -573,9 +573,8 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
             bool wIssued = false;
 #pragma unroll
             for (int tap = 0; tap < T; ++tap) {
-                constexpr int dummy = 0; (void)dummy;
                 const int tl = tap % TPS, grp = tap / TPS;
-                const bool lastTap = tap == T - 1, endOfSlab = tl == TPS - 1 || lastTap, lastGroup = grp == NG - 1;
+                const bool lastTap = tap == T - 1, endOfSlab = tl == TPS - 1 || lastTap;
                 if (tl == 0) {
                     if (tap == 0 && cc == 0) {
                         // epilogue of the previous item first: its stores are the oldest requests of this slab and have the
