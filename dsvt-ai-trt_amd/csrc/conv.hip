@@ -20,6 +20,7 @@
 // Workgroup = 4 waves = 128 pixels x 128 output channels; wave = 32 pixels.
 #include "plugin_base.h"
 #include "device_utils.h"
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -51,6 +52,15 @@ struct ConvArgs {
     // (out_ld = 3 * split_out); res_split > 0: the residual tensor is such a triple, its value is hi + lo (exact to 2^-22), plane stride res_split.
     // The kernels are instantiated twice (template parameter SPL): the fp16 frame's instantiations do not carry the split epilogue's registers.
     int split_out, res_split;
+    // round 4, the cheaper fp32-grade product: the two correction terms lo w_hi + hi w_lo need ~5 bits, so they run as OCP fp8 (e4m3) blocks of
+    // v_mfma_scale_f32_16x16x128_f8f6f4 (2.4 x the fp16 rate, tools/ubench/mfma_mx.hip) instead of two more fp16 MFMAs per k-step.  The third plane of
+    // a split tensor then holds the fp8 operands ("x8 plane"): per 32 channels 64 bytes [lo8 0..15 | hi8 0..15 | lo8 16..31 | hi8 16..31] with
+    // lo8 = e4m3(2^11 (v - hi)), hi8 = e4m3(v), both saturated at +-448 (x8Store).
+    //   x8_out : the epilogue writes [hi | lo | x8] instead of [hi | lo | hi]
+    //   alias3 : (kernels that still walk three fp16 planes) first channel of the third plane, whose phases read plane 0 instead; 0 = off
+    //   xscale : (conv_wide_kernel<.., MX>) E8M0 scale byte per weight row: 127 - 11 - e with w_hi8 = e4m3(2^e w_hi), w_lo8 = e4m3(2^(e + 11) w_lo)
+    int x8_out, alias3;
+    const unsigned char* xscale;
     unsigned long long* trace;                   // debugging (DSVT_CONV_TRACE=1, tools/trace_conv.py): s_memtime stamps of waves 0 and NW/2, or nullptr
 };
 constexpr int CONV_TRACE_N = 256;               // stamps per traced wave
@@ -65,14 +75,29 @@ __device__ __forceinline__ void splitPlanes(const float (&v)[N], HV& hi, HV& lo)
         hi[i] = h; lo[i] = (_Float16)__builtin_fminf(__builtin_fmaxf(v[i] - (float)h, -65504.f), 65504.f);
     }
 }
-// store of eight consecutive channels of one output pixel: plain fp16, or (SPL) the [hi | lo | hi] planes when split_out is set
+// x8 plane of N (4 or 8) consecutive channels starting at plane channel c (c % N == 0); hi = the fp16 plane values already computed
+template <int N, class HV>
+__device__ __forceinline__ void x8Store(unsigned char* xplane, int c, const float (&v)[N], const HV& hi) {
+    unsigned lo8[N / 4], hi8[N / 4];
+#pragma unroll
+    for (int i = 0; i < N; i += 4) {
+        lo8[i / 4] = packE4m3((v[i] - (float)hi[i]) * 2048.f, (v[i + 1] - (float)hi[i + 1]) * 2048.f, (v[i + 2] - (float)hi[i + 2]) * 2048.f, (v[i + 3] - (float)hi[i + 3]) * 2048.f);
+        hi8[i / 4] = packE4m3(v[i], v[i + 1], v[i + 2], v[i + 3]);
+    }
+    unsigned char* p = xplane + x8Offset(c);
+    if constexpr (N == 8) { *reinterpret_cast<uint2*>(p) = make_uint2(lo8[0], lo8[1]); *reinterpret_cast<uint2*>(p + 16) = make_uint2(hi8[0], hi8[1]); }
+    else { *reinterpret_cast<unsigned*>(p) = lo8[0]; *reinterpret_cast<unsigned*>(p + 16) = hi8[0]; }
+}
+// store of eight consecutive channels of one output pixel: plain fp16, or (SPL) the [hi | lo | hi] / [hi | lo | x8] planes when split_out is set
 template <bool SPL>
 __device__ __forceinline__ void storeHalf8(const ConvArgs& a, const float (&v)[8], size_t opix, int co) {
     _Float16* o = static_cast<_Float16*>(a.out) + opix * a.out_ld + a.out_coff + co;
     if (SPL && a.split_out) {
         half8 hi, lo;
         splitPlanes<8>(v, hi, lo);
-        *reinterpret_cast<half8*>(o) = hi; *reinterpret_cast<half8*>(o + a.split_out) = lo; *reinterpret_cast<half8*>(o + 2 * a.split_out) = hi;
+        *reinterpret_cast<half8*>(o) = hi; *reinterpret_cast<half8*>(o + a.split_out) = lo;
+        if (a.x8_out) x8Store<8>(reinterpret_cast<unsigned char*>(static_cast<_Float16*>(a.out) + opix * a.out_ld + 2 * a.split_out), a.out_coff + co, v, hi);
+        else *reinterpret_cast<half8*>(o + 2 * a.split_out) = hi;
     } else {
         half8 h;
 #pragma unroll
@@ -114,11 +139,20 @@ __device__ __forceinline__ void convStore(const ConvArgs& a, floatx4 acc, size_t
         _Float16* o = static_cast<_Float16*>(a.out) + opix * a.out_ld + a.out_coff + co;
         half4 hi, lo;
         splitPlanes<4>(v, hi, lo);
+        unsigned char* xp = reinterpret_cast<unsigned char*>(static_cast<_Float16*>(a.out) + opix * a.out_ld + 2 * a.split_out);
         if (full) {
-            *reinterpret_cast<half4*>(o) = hi; *reinterpret_cast<half4*>(o + a.split_out) = lo; *reinterpret_cast<half4*>(o + 2 * a.split_out) = hi;
+            *reinterpret_cast<half4*>(o) = hi; *reinterpret_cast<half4*>(o + a.split_out) = lo;
+            if (a.x8_out) x8Store<4>(xp, a.out_coff + co, v, hi);
+            else *reinterpret_cast<half4*>(o + 2 * a.split_out) = hi;
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (co + i < a.Cout) { o[i] = hi[i]; o[a.split_out + i] = lo[i]; o[2 * a.split_out + i] = hi[i]; }
+            for (int i = 0; i < 4; ++i) if (co + i < a.Cout) {
+                o[i] = hi[i]; o[a.split_out + i] = lo[i];
+                if (a.x8_out) {
+                    const int xo = x8Offset(a.out_coff + co + i);
+                    xp[xo] = (unsigned char)packE4m3((v[i] - (float)hi[i]) * 2048.f, 0.f, 0.f, 0.f); xp[xo + 16] = (unsigned char)packE4m3(v[i], 0.f, 0.f, 0.f);
+                } else o[2 * a.split_out + i] = hi[i];
+            }
         }
     } else {
         _Float16* o = static_cast<_Float16*>(a.out) + opix * a.out_ld + a.out_coff + co;
@@ -199,7 +233,8 @@ conv_f16_kernel(ConvArgs a_)
         for (int mt = 0; mt < MT; ++mt) {
             const int yi = py[mt] * a.stride + ky - a.pad, xi = px[mt] * a.stride + kx - a.pad;
             const bool inb = yi >= 0 && yi < a.H && xi >= 0 && xi < a.W;
-            const _Float16* src = a.in + ((size_t)(inb ? yi : 0) * a.W + (inb ? xi : 0)) * a.Cin + cc * KC + g * 8;
+            const int c0 = (a.alias3 && cc * KC >= a.alias3) ? cc * KC - a.alias3 : cc * KC;     // (the phases of an x8 third plane read plane 0)
+            const _Float16* src = a.in + ((size_t)(inb ? yi : 0) * a.W + (inb ? xi : 0)) * a.Cin + c0 + g * 8;
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
                 half8 v = *reinterpret_cast<const half8*>(src + ks * 32);
@@ -485,7 +520,8 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         yy = (t / tilesX) * TH; xx = (t % tilesX) * HTW;
     };
     auto haloRequest = [&](int j, int cc, int hb) {                   // wave-uniform j: one LDS-DMA of 1 KB
-        const _Float16* src = goff[j] >= 0 ? a.in + goff[j] + cc * 64 : zeros;
+        const int c0 = (a.alias3 && cc * 64 >= a.alias3) ? cc * 64 - a.alias3 : cc * 64;          // (the phases of an x8 third plane read plane 0)
+        const _Float16* src = goff[j] >= 0 ? a.in + goff[j] + c0 : zeros;
         __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + hb * HBYTES + (wave + j * TH) * 1024), 16, 0, 0);
     };
     auto weightRequests = [&](int q0, int ch, int wb) {               // slab starting at k-step q0 (= 2 (cc T + tap))
@@ -695,24 +731,47 @@ struct WideCfg {
 // in flight (one slab of MFMAs, 0.5-1 us, is shorter than an L2 -> LDS round trip under load); 2 where LDS must hold two workgroups.
 // RW = tile rows per wave: 2 (64 pixels, four pixel tiles) or 1 (32 pixels, two pixel tiles: twice the waves on the same tile --
 // for the small layers, where one wave per SIMD cannot hide its own LDS-DMA issue and wait time)
-template <int CT, int NW, int HS, int SPS = (CT == 8 ? 2 : 4), int NWB = 3, int RW = 2, bool TR = false, bool SPL = false>
+// MX (round 4; implies the split epilogue): the input is a split tensor [hi | lo | x8] of C = Cin / 3 real channels and the K loop is the fp32-grade
+// product at HALF the matrix-pipe time of the [hi | lo | hi] walk: C / 32 "main" phases of the hi plane (nine fp16 k-steps each, as before) followed by
+// C / 32 "cross" phases of the x8 plane (64 B per pixel too: the halo machinery does not change), each FIVE steps of
+// v_mfma_scale_f32_16x16x128_f8f6f4: the K = 128 of step j are taps 2j, 2j + 1 x [lo8 | hi8] of the phase's 32 channels -- lane group g of the B
+// operand reads tap 2j + (g >> 1), chunks (g & 1) and 2 + (g & 1) of its pixel (conflict-free with the same column swizzle: enumerated over the
+// ds_read_b128 lane groups), lane group g of the A operand holds e4m3(2^e w_hi) (g even: pairs with lo8) or e4m3(2^(e + 11) w_lo) (g odd: pairs with
+// hi8) of row n, and the row's scale byte 127 - 11 - e undoes both factors (tap 9 of the fifth step: zero weights).  Per 32 channels and tile pair:
+// 9 fp16 + 5 fp8 MFMAs = 9 x 16 + 5 x 27 cycles of the pipe instead of 27 x 16.  A cross step's fragments are 2 KB per channel tile (two lane-linear
+// 1 KB rows: bytes 0..15 and 16..31 of every lane), so a weight slab holds SPS / 2 cross steps.  Packed weights: DsvtConv2dPlugin::packMX.
+typedef int intx4 __attribute__((ext_vector_type(4)));
+typedef int intx8 __attribute__((ext_vector_type(8)));
+template <int OP>
+__device__ __forceinline__ floatx4 mfmaX8(const intx8& A, const intx8& B, const floatx4& c, int scaleA) {
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, c, 0, 0, OP, scaleA, 0, 127);          // fp8 x fp8; byte OP of scaleA; scale_b = 2^0
+}
+__device__ __forceinline__ floatx4 mfmaX8(int op, const intx8& A, const intx8& B, const floatx4& c, int scaleA) {      // (op is a constant after unrolling)
+    switch (op & 3) { case 0: return mfmaX8<0>(A, B, c, scaleA); case 1: return mfmaX8<1>(A, B, c, scaleA); case 2: return mfmaX8<2>(A, B, c, scaleA); default: return mfmaX8<3>(A, B, c, scaleA); }
+}
+
+template <int CT, int NW, int HS, int SPS = (CT == 8 ? 2 : 4), int NWB = 3, int RW = 2, bool TR = false, bool SPL = false, bool MX = false>
 __global__ void __launch_bounds__(64 * NW, (NW * (RW == 1 ? 1 : 2) <= 8 && (NW == 4 || RW == 1)) ? 2 : 1)
 conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __restrict__ zeros, int tilesX, int nitems, int nchunk, int dbg)
 {
+    static_assert(!MX || SPL, "the MX K loop reads a split tensor and writes one");
     using C = WideCfg<CT, NW, HS, SPS, RW>;
+    constexpr int XPS = SPS / 2;                                  // cross steps per weight slab
     constexpr int NM = 2 * RW;                                    // 16-pixel tiles per wave
     static_assert(SPS == 2 || SPS == 4, "nine-step phases and two halo buffers: a slab spans at most four steps");
     constexpr int WT_HS = HS, WT_HBYTES = C::HBYTES, WT_WBYTES = C::WBYTES, WT_NPC = C::NPC, WT_ROWS = C::ROWS, PPW = C::PPW;
     constexpr int PPS = SPS == 2 ? (PPW + 2) / 3 : PPW;           // halo pieces a wave requests per slab
     constexpr int NRS = (PPW + PPS - 1) / PPS;                    // ... over this many slabs
-    constexpr int CH = CT > 4 ? 4 : CT;                           // A fragments read per batch
+    constexpr int CH = CT > 4 ? 4 : CT;    // A fragments read per batch
     constexpr int LEAD = NWB - 1;
-    constexpr bool TRICKLE = CT == 8 && NW == 8 && LEAD == 2;     // requests spread over the slab (see the slab loop)
+    constexpr bool TRICKLE = CT == 8 && NW == 8 && LEAD == 2 && !MX;     // requests spread over the slab (see the slab loop)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WT_HBYTES + NWB * WT_WBYTES + 1024];      // halo[2] | wslab[NWB] | bias
     constexpr int BIAS_OFF = 2 * WT_HBYTES + NWB * WT_WBYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
-    const int NP = a.Cin >> 5;                                    // 32-channel phases (even: Cin % 64 == 0)
-    const int NSTEP = NP * 9, NSLAB = (NSTEP + SPS - 1) / SPS;    // (SPS = 4: the last slab may be partial; the packed weights end in a zero slab)
+    const int NPM = MX ? a.Cin / 96 : a.Cin >> 5;                 // 32-channel phases of fp16 k-steps (MX: of the hi plane; a.Cin = 3 C)
+    const int NP = MX ? 2 * NPM : NPM;                            // halo phases (even)
+    const int NSTEP = NPM * 9, NSA = (NSTEP + SPS - 1) / SPS;     // (SPS = 4: the last fp16 slab may be partial; the packed weights end in a zero slab)
+    const int NSLAB = NSA + (MX ? (5 * NPM + XPS - 1) / XPS : 0);
     const int NCT = a.CoutRows <= 64 ? 4 : (a.CoutRows + 127) / 128 * 8;      // 16-channel tiles per k-step of the packed weights
 
     const int perImg = nitems / a.nb;                             // items of one image (items walk image after image)
@@ -727,14 +786,22 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         const int chunk = (lane & 3) ^ ((hx >> 1) & 2);
         const int gy = yy - 1 + hy, gx = xx - 1 + hx;
         const bool ok = hx < HTW + 2 && hy < C::HH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        const _Float16* src = ok ? a.in + (size_t)((bb * a.H + gy) * a.W + gx) * a.Cin + ph * 32 + chunk * 8 : zeros;
+        const int coff = (MX && ph >= NPM) ? 64 * NPM + (ph - NPM) * 32 : ph * 32;           // (MX: phase NPM + q = 64 bytes of the x8 plane, which starts at channel 2 C)
+        const _Float16* src = ok ? a.in + (size_t)((bb * a.H + gy) * a.W + gx) * a.Cin + coff + chunk * 8 : zeros;
         __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + hb * WT_HBYTES + pc * 1024), 16, 0, 0);
     };
     // the 16 fragment rows of slab sl (steps SPS sl ...) of chunk ch -> buffer wb
     auto weightRequest = [&](int sl, int ch, int wb, int j) {
-        const int u = wave + NW * j, step = SPS * sl + u / CT, ph = step / 9, tap = step - 9 * ph;
+        const int u = wave + NW * j;
         if ((SPS * CT) % NW != 0 && u >= SPS * CT) return;
-        const size_t row = (size_t)(2 * ((ph >> 1) * 9 + tap) + (ph & 1)) * NCT + ch * CT + u % CT;
+        size_t row;
+        if (MX) {         // packMX: [9 NPM fp16 steps][NCT][1 KB] | [5 NPM cross steps][NCT][2][1 KB]
+            if (sl < NSA) row = (size_t)(SPS * sl + u / CT) * NCT + ch * CT + u % CT;
+            else row = (size_t)NSTEP * NCT + ((size_t)(XPS * (sl - NSA) + u / (2 * CT)) * NCT + ch * CT + (u % (2 * CT)) / 2) * 2 + (u & 1);
+        } else {
+            const int step = SPS * sl + u / CT, ph = step / 9, tap = step - 9 * ph;
+            row = (size_t)(2 * ((ph >> 1) * 9 + tap) + (ph & 1)) * NCT + ch * CT + u % CT;
+        }
         __builtin_amdgcn_global_load_lds((glds_src_t)(Wp + (row * 64 + lane) * 8), (glds_dst_t)(smem + 2 * WT_HBYTES + wb * WT_WBYTES + u * 1024), 16, 0, 0);
     };
     auto weightRequests = [&](int sl, int ch, int wb) {
@@ -749,6 +816,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     auto biasRequest = [&](int ch) {
         const int n0 = ch * CT * 16, sub = n0 / a.Cout, co = n0 - sub * a.Cout + lane * 4;
         const void* src = (biasInit && lane < CT * 4 && co < a.Cout) ? static_cast<const void*>(a.bias + co) : static_cast<const void*>(zeros);
+        if (MX && lane >= 32 && lane < 32 + CT) src = a.xscale + n0 + (lane - 32) * 16;      // the chunk's scale bytes (the table is padded to whole chunks): LDS bytes 512 ..
         __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + BIAS_OFF), 16, 0, 0);
     };
 
@@ -787,8 +855,15 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
 #pragma unroll
             for (int m = 0; m < NM; ++m) acc[ct][m] = b4;
         }
-#pragma unroll 1
-        for (int s = 0; s < NSLAB; ++s) {
+        int xs[(CT + 3) / 4] = {};                                   // MX: scale byte of row (ct, r) in byte ct & 3 of xs[ct >> 2]
+        if constexpr (MX) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) xs[ct >> 2] |= (int)smem[BIAS_OFF + 512 + ct * 16 + r] << (8 * (ct & 3));
+        }
+        // one slab; CROSS (compile time): a slab of the MX loop's fp8 steps (s >= NSA).  Two loops over this body, not one loop with a branch:
+        // with both bodies in one loop hipcc spilled 141 registers of the accumulators into the MFMA stream
+        auto slab = [&](const int s, auto crossTag) {
+            constexpr bool CROSS = decltype(crossTag)::value;
             // halo of phase P (the phase after the one this slab starts in): its buffer is free once phase P - 2 has ended, i.e.
             // from slab s0 = ceil(9 (P - 1) / SPS) on, and the first slab that touches phase P is floor(9 P / SPS) > s0 + NRS - 1.
             // Weights of the slab LEAD ahead; the halo requests of a slab come BEFORE its weight requests: with LEAD = 2 the slab-end
@@ -798,7 +873,11 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
             // with the matrix pipe idle), so request j goes out after the MFMAs of batch j * NB / NREQ, when the wave would wait
             // for the pipe anyway: 88 -> 84 us (128 -> 128 channels), 123 -> 115 us (192 -> 128).  (Neutral to harmful on the
             // 64-channel variants, whose slabs hold four steps: 384 -> 64 channels 125 -> 144 us.)
-            const int hP = (SPS * s) / 9 + 1, hk = s - (9 * (hP - 1) + SPS - 1) / SPS;
+            int hP = (SPS * s) / 9 + 1, hk = s - (9 * (hP - 1) + SPS - 1) / SPS;
+            if constexpr (CROSS) {                                    // cross phase q0 = five steps: the same rule on its own step count
+                const int q0 = (XPS * (s - NSA)) / 5;
+                hP = NPM + q0 + 1; hk = s - NSA - (5 * q0 + XPS - 1) / XPS;
+            }
             const bool hIn = hP < NP, hOn = hk < NRS && (hIn || have_next) && !(dbg & 1);
             const int hyy = hIn ? y0 : ny0, hxx = hIn ? x0 : nx0, hph = hIn ? hP : 0, hbb = hIn ? bimg : nbimg;
             const int wt = s + LEAD, wbt = (wb + LEAD) % NWB;
@@ -833,7 +912,57 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
             mark();                                                  // [5 s + 2] requests issued
             // fragments are double buffered by hand: the reads of batch b + 1 (CH channel tiles x 4 pixel tiles = 4 CH MFMAs) are
             // issued BEFORE the MFMAs of batch b (left to itself hipcc emits read, s_waitcnt lgkmcnt(0), 8 MFMAs, read, ...)
-            {
+            if constexpr (CROSS) {
+                {
+                    // a slab of cross steps: step x = (phase q, tap pair pr); batches of CHX channel tiles x NM pixel tiles; the B fragments of a step
+                    // stay in ONE buffer (32 registers), the A fragments are double buffered
+                    constexpr int CHX = 1, BPX = CT / CHX, NBX = XPS * BPX;
+                    intx8 Bx[NM], Ax[2][CHX];
+                    auto loadBx = [&](int u) {
+                        const int x = XPS * (s - NSA) + u, q = x / 5, pr = x - 5 * q;
+                        int tap = 2 * pr + (g >> 1); tap = tap > 8 ? 8 : tap;                 // (tap 9: zero weights)
+                        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;                    // tap / 3 for 0 .. 8
+                        const int slot = (g & 1) ^ (((r + kx) >> 1) & 2);
+                        const unsigned char* hbp = smem + ((NPM + q) & 1) * WT_HBYTES + (ky * WT_HS + kx) * 64 + pb;
+#pragma unroll
+                        for (int m = 0; m < NM; ++m) {
+                            const unsigned char* pp = hbp + ((m >> 1) * WT_HS + (m & 1) * 16) * 64;
+                            const intx4 lo = *reinterpret_cast<const intx4*>(pp + (slot << 4)), hi = *reinterpret_cast<const intx4*>(pp + ((slot ^ 2) << 4));
+                            Bx[m] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+                    };
+                    auto loadAx = [&](int u, int c0, intx8 (&A)[CHX]) {
+                        const unsigned char* wbp = smem + 2 * WT_HBYTES + wb * WT_WBYTES + (u * CT + c0) * 2048 + aoff;
+#pragma unroll
+                        for (int ct = 0; ct < CHX; ++ct) {
+                            const intx4 lo = *reinterpret_cast<const intx4*>(wbp + ct * 2048), hi = *reinterpret_cast<const intx4*>(wbp + ct * 2048 + 1024);
+                            A[ct] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+                    };
+                    loadBx(0); loadAx(0, 0, Ax[0]);
+#pragma unroll
+                    for (int b = 0; b < NBX; ++b) {
+                        const int u = b / BPX, c0 = (b % BPX) * CHX;
+                        if (b + 1 < NBX) loadAx((b + 1) / BPX, ((b + 1) % BPX) * CHX, Ax[(b + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (XPS * (s - NSA) + u < 5 * NPM) {
+#pragma unroll
+                            for (int ct = 0; ct < CHX; ++ct)
+#pragma unroll
+                                for (int m = 0; m < NM; ++m)
+                                    acc[c0 + ct][m] = mfmaX8(c0 + ct, Ax[b & 1][ct], Bx[m], acc[c0 + ct][m], xs[(c0 + ct) >> 2]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (b + 1 < NBX && (b + 1) % BPX == 0) loadBx((b + 1) / BPX);
+                        if (TRICKLE) {
+#pragma unroll
+                            for (int j = 0; j < NREQ; ++j)
+                                if (j * NBX / NREQ == b) request(j);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            } else {
                 constexpr int BPS = CT / CH, NB = SPS * BPS;          // batches per step / per slab
                 half8 Bf[2][NM], Af[2][CH];
                 auto loadB = [&](int u, half8 (&B)[NM]) {
@@ -881,6 +1010,12 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                 mark();                                              // [5 s + 5] barrier passed
             } else slabBarrier(LEAD == 2 && wIssued ? wreq : 0);
             wb = (wb + 1) % NWB;
+        };
+#pragma unroll 1
+        for (int s = 0; s < NSA; ++s) slab(s, std::false_type{});
+        if constexpr (MX) {
+#pragma unroll 1
+            for (int s = NSA; s < NSLAB; ++s) slab(s, std::true_type{});
         }
         mark();
         // residual / ReLU / store (the bias is in the accumulators)
@@ -1429,6 +1564,22 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
         if (spl) hipLaunchKernelGGL((conv_wide_kernel<__VA_ARGS__, false, true>), dim3(GRID_), dim3(BLOCK_), 0, stream, a, Wp, zeros, tilesX, NITEMS_, NCHUNK_, dbg); \
         else hipLaunchKernelGGL((conv_wide_kernel<__VA_ARGS__, false, false>), dim3(GRID_), dim3(BLOCK_), 0, stream, a, Wp, zeros, tilesX, NITEMS_, NCHUNK_, dbg); \
         return lastError(); } while (0)
+#define DSVT_WIDE_MX(GRID_, BLOCK_, NITEMS_, NCHUNK_, ...) do { \
+        hipLaunchKernelGGL((conv_wide_kernel<__VA_ARGS__, false, true, true>), dim3(GRID_), dim3(BLOCK_), 0, stream, a, Wp, zeros, tilesX, NITEMS_, NCHUNK_, dbg); \
+        return lastError(); } while (0)
+    if (a.xscale) {                                             // split input [hi | lo | x8] on the fp16 + fp8 K loop (packMX image); same tile choices as below
+        if (a.KH != 3 || ctWide < 4) return -3;
+        const int nwide = cdiv(a.Ho, 16) * tilesX * nchunk * NBI;
+        if (nwide >= ncu) {
+            if (ctWide == 8) DSVT_WIDE_MX(ncu, 512, nwide, nchunk, 8, 8, 36, 2, 3, 2);
+            else DSVT_WIDE_MX(ncu, 512, nwide, nchunk, 4, 8, 40, 4, 2, 2);
+        }
+        const int nch64 = cdiv(a.CoutRows, 64), nsmall = cdiv(a.Ho, 8) * tilesX * nch64 * NBI;
+        const int n16 = cdiv(a.Ho, 16) * tilesX * nch64 * NBI;
+        if (n16 * 10 >= ncu * 9 && n16 <= ncu) DSVT_WIDE_MX(n16, 512, n16, nch64, 4, 8, 40, 4, 2, 2);
+        DSVT_WIDE_MX(nsmall < 2 * ncu ? nsmall : 2 * ncu, 512, nsmall, nch64, 4, 8, 36, 4, 2, 1);
+    }
+#undef DSVT_WIDE_MX
     if (a.KH == 3 && ctWide >= 4) {
         const int nwide = cdiv(a.Ho, 16) * tilesX * nchunk * NBI;
         // short K (the 64 -> 320 head stems: 9 slabs per item, the epilogue weighs as much as the MFMAs): 8-row x 128-channel tiles on
@@ -1488,8 +1639,25 @@ static int launchConv(const ConvArgs& a, int KC, hipStream_t stream) {
 // -------------------------------------------------------------------------------------
 struct ConvCfg {
     int H, W, Cin, Cout, KH, KW, stride, pad, up, relu, has_res, out_ld, out_coff, out_f32;
-    int split_out, split_res;      // split precision (fields "split_output" / "split_residual"): the output / the residual is an fp16 [hi | lo | hi] triple (see ConvArgs)
+    int split_out, split_res;      // split precision (fields "split_output" / "split_residual"): the output / the residual is an fp16 [hi | lo | hi] triple (see ConvArgs); split_out = 2: [hi | lo | x8]
+    int split_in;                  // field "split_input": the input is a split tensor [hi | lo | x8] (Cin = 3 C).  1: the weight rows are the host's [w_hi | w_hi | w_lo] and the phases
+                                   // of the third plane read plane 0; 2: the weight rows are the REAL fp32 rows [R][9][C] and the layer runs on conv_wide_kernel<.., MX>
 };
+
+// OCP e4m3 byte of f: round to nearest even, saturated at +-448 (what packE4m3 does on the device)
+static unsigned char e4m3Encode(float f) {
+    if (f != f) return 0x7f;
+    const unsigned char sgn = std::signbit(f) ? 0x80 : 0;
+    const float v = std::fabs(f);
+    if (v >= 448.f) return sgn | 0x7e;
+    if (v < std::ldexp(1.f, -6)) return sgn | (unsigned char)std::nearbyint(v * 512.f);      // subnormals, step 2^-9 (8 = the first normal)
+    int e; const float m = std::frexp(v, &e);                     // v = m 2^e, m in [0.5, 1)
+    float q = std::nearbyint(m * 16.f);                           // 8 .. 16
+    if (q == 16.f) { q = 8.f; ++e; }
+    const int E = e - 1 + 7;
+    if (E > 15 || (E == 15 && q > 14.f)) return sgn | 0x7e;
+    return sgn | (unsigned char)((E << 3) | ((int)q - 8));
+}
 
 class DsvtConv2dPlugin : public Plugin {
 public:
@@ -1499,7 +1667,9 @@ public:
     _Float16* wp_dev_ = nullptr;         // fragment-packed copy for the halo kernel (stride-1 layers)
     _Float16* zeros_dev_ = nullptr;      // 256 zero bytes: LDS-DMA source of out-of-image halo pixels
     _Float16* wg_dev_ = nullptr; int* chan_dev_ = nullptr; int groups_ = 0;      // block-diagonal narrow 3 x 3 layer: per-phase weight tiles + channel table
+    unsigned char* xscale_dev_ = nullptr;                                        // split_in == 2: scale byte per weight row (wp_dev_ holds the packMX image)
     bool ok_ = false;
+    int cinW() const { return c_.split_in == 2 ? c_.Cin / 3 : c_.Cin; }         // channels per tap of a weight row
     bool haloEligible() const {
         static int on = -1;
         if (on < 0) on = ablateEnv("DSVT_CONV_HALO", 1);
@@ -1515,10 +1685,65 @@ public:
         if (Ho() * Wo() >= 100000 && c_.Cin % 64 == 0) return 64;
         return c_.Cin % 128 == 0 ? 128 : c_.Cin % 96 == 0 ? 96 : 64;
     }
+    // split_in == 2: fragment image of the fp16 + fp8 K loop (conv_wide_kernel<.., MX>) from the real fp32 rows [R][9][C]:
+    //   [fp16 step t = (phase t / 9, tap t % 9)][16-channel tile][lane (r, g)][8 halfs] <- fp16(W[tile 16 + r][tap][32 phase + 8 g + j])
+    //   [cross step x = (phase x / 5, tap pair x % 5)][tile][h][lane (r, g)][16 bytes]  <- e4m3 of W_hi 2^e (g even) or W_lo 2^(e + 11) (g odd) at
+    //       [tile 16 + r][tap 2 (x % 5) + (g >> 1)][32 phase + 16 h + j], zero for tap 9;  e = the row's exponent that brings max |w| under 448
+    // and the scale byte 127 - 11 - e per row (one shared power of two for both kinds of fp8 block: a_lo8 carries 2^11, w_lo8 carries 2^(e + 11)).
+    void packMX() {
+        const ConvCfg& c = c_;
+        const int C = c.Cin / 3, NPM = C / 32, R = rows();
+        const int ctw = haloChannelTiles(R), NCT = ctw < 8 ? ctw : cdiv(R, CNB) * 8;
+        const size_t mainRows = (size_t)9 * NPM * NCT, crossRows = (size_t)5 * NPM * NCT * 2;
+        std::vector<unsigned char> img((mainRows + crossRows + (size_t)4 * NCT) * 1024, 0);          // (+ slack: a partial four-step slab is requested whole)
+        std::vector<unsigned char> sc((size_t)NCT * 16, 127 - 11);
+        std::vector<int> ex(R, 0);
+        for (int n = 0; n < R; ++n) {
+            float mx = 0.f;
+            for (size_t i = 0; i < (size_t)9 * C; ++i) mx = std::fmax(mx, std::fabs(w_[(size_t)n * 9 * C + i]));
+            int e = mx > 0.f ? (int)std::floor(std::log2(448.f / mx)) : 0;
+            e = e < -60 ? -60 : e > 60 ? 60 : e;
+            ex[n] = e; sc[n] = (unsigned char)(127 - 11 - e);
+        }
+        _Float16* img16 = reinterpret_cast<_Float16*>(img.data());
+        for (int t = 0; t < 9 * NPM; ++t)
+            for (int tile = 0; tile < NCT; ++tile)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int n = tile * 16 + (lane & 15), ph = t / 9, tap = t % 9;
+                    if (n >= R) continue;
+                    const size_t dst = (((size_t)t * NCT + tile) * 64 + lane) * 8, src = ((size_t)n * 9 + tap) * C + ph * 32 + (lane >> 4) * 8;
+                    for (int j = 0; j < 8; ++j) img16[dst + j] = (_Float16)w_[src + j];
+                }
+        for (int x = 0; x < 5 * NPM; ++x)
+            for (int tile = 0; tile < NCT; ++tile)
+                for (int h = 0; h < 2; ++h)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int n = tile * 16 + (lane & 15), g = lane >> 4, q = x / 5, tap = 2 * (x % 5) + (g >> 1);
+                        if (n >= R || tap > 8) continue;
+                        const size_t dst = (mainRows + ((size_t)x * NCT + tile) * 2 + h) * 1024 + (size_t)lane * 16, src = ((size_t)n * 9 + tap) * C + q * 32 + h * 16;
+                        for (int j = 0; j < 16; ++j) {
+                            const float wv = w_[src + j], hi = (float)(_Float16)wv;
+                            img[dst + j] = (g & 1) ? e4m3Encode(std::ldexp(wv - hi, ex[n] + 11)) : e4m3Encode(std::ldexp(hi, ex[n]));
+                        }
+                    }
+        ok_ = hipMalloc(&wp_dev_, img.size()) == hipSuccess && hipMemcpy(wp_dev_, img.data(), img.size(), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMalloc(&xscale_dev_, sc.size()) == hipSuccess && hipMemcpy(xscale_dev_, sc.data(), sc.size(), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMalloc(&zeros_dev_, 256) == hipSuccess && hipMemset(zeros_dev_, 0, 256) == hipSuccess;
+    }
     DsvtConv2dPlugin(const ConvCfg& c, const float* w, const float* b) : c_(c) {
-        const size_t nw = (size_t)rows() * c.KH * c.KW * c.Cin;
+        const size_t nw = (size_t)rows() * c.KH * c.KW * cinW();
         w_.assign(w, w + nw);
         if (b) b_.assign(b, b + c.Cout);
+        if (c.split_in == 2) {
+            ok_ = true;
+            if (b) {
+                const size_t nb = ((size_t)c.Cout + 3) / 4 * 4;
+                ok_ = hipMalloc(&b_dev_, sizeof(float) * nb) == hipSuccess && hipMemset(b_dev_, 0, sizeof(float) * nb) == hipSuccess &&
+                      hipMemcpy(b_dev_, b_.data(), sizeof(float) * c.Cout, hipMemcpyHostToDevice) == hipSuccess;
+            }
+            if (ok_) packMX();
+            return;
+        }
         std::vector<_Float16> wh(nw);
         for (size_t i = 0; i < nw; ++i) wh[i] = (_Float16)w_[i];
         ok_ = hipMalloc(&w_dev_, sizeof(_Float16) * nw) == hipSuccess &&
@@ -1591,6 +1816,7 @@ public:
     }
     ~DsvtConv2dPlugin() override {
         if (w_dev_) (void)hipFree(w_dev_); if (b_dev_) (void)hipFree(b_dev_); if (wp_dev_) (void)hipFree(wp_dev_); if (zeros_dev_) (void)hipFree(zeros_dev_); if (wg_dev_) (void)hipFree(wg_dev_); if (chan_dev_) (void)hipFree(chan_dev_);
+        if (xscale_dev_) (void)hipFree(xscale_dev_);
     }
     const char* type() const override { return "DsvtConv2dPlugin"; }
     bool handlesBatch() const override { return true; }          // a stack of images is ONE launch: the persistent kernels walk image after image
@@ -1618,6 +1844,9 @@ public:
         a.KH = c_.KH; a.KW = c_.KW; a.stride = c_.stride; a.pad = c_.pad; a.up = c_.up; a.relu = c_.relu;
         a.split_out = c_.split_out ? c_.out_ld / 3 : 0;
         a.res_split = (c_.has_res && c_.split_res) ? a.res_ld / 3 : 0;
+        a.x8_out = c_.split_out == 2;
+        a.alias3 = c_.split_in == 1 ? c_.Cin / 3 * 2 : 0;
+        a.xscale = c_.split_in == 2 ? xscale_dev_ : nullptr;
         a.wide = !c_.out_f32 && c_.Cout % 16 == 0 && c_.out_ld % 8 == 0 && c_.out_coff % 8 == 0 && (!c_.has_res || a.res_ld % 8 == 0) &&
                  a.split_out % 8 == 0 && a.res_split % 8 == 0;
         a.nb = (inDesc && inDesc[0].dims.nbDims == 4 && inDesc[0].dims.d[0] > 1) ? inDesc[0].dims.d[0] : 1;
@@ -1643,6 +1872,7 @@ public:
                 }
             return rc;
         }
+        if (c_.split_in == 2) return launchConvHalo(a, wp_dev_, zeros_dev_, stream);
         if (groups_ > 0 && !a.split_out) {
             const int tilesX = cdiv(a.Wo, HTW), tilesY = cdiv(a.Ho, 8);
             hipLaunchKernelGGL(conv3x3_grouped_narrow_kernel, dim3(numCUs()), dim3(512), 0, stream, a, wg_dev_, chan_dev_, zeros_dev_, tilesX, tilesY, groups_);
@@ -1658,7 +1888,10 @@ public:
         if (wp_dev_ && haloEligible()) return launchConvHalo(a, wp_dev_, zeros_dev_, stream);
         return launchConv(a, KC(), stream);
     }
-    size_t serializationSize() const override { return 14 * sizeof(int) + sizeof(int) + sizeof(float) * (w_.size() + b_.size()) + ((c_.split_out || c_.split_res) ? 2 * sizeof(int) : 0); }
+    static constexpr int kTrailerMagic = 0x34585644;       // "DVX4": the four-int trailer {split_out, split_res, split_in, magic}
+    size_t serializationSize() const override {
+        return 14 * sizeof(int) + sizeof(int) + sizeof(float) * (w_.size() + b_.size()) + (c_.split_in ? 4 * sizeof(int) : (c_.split_out || c_.split_res) ? 2 * sizeof(int) : 0);
+    }
     void serialize(void* buf) const override {
         char* d = static_cast<char*>(buf);
         const int* ci = reinterpret_cast<const int*>(&c_);
@@ -1666,7 +1899,9 @@ public:
         wr<int>(d, b_.empty() ? 0 : 1);
         memcpy(d, w_.data(), sizeof(float) * w_.size()); d += sizeof(float) * w_.size();
         memcpy(d, b_.data(), sizeof(float) * b_.size()); d += sizeof(float) * b_.size();
-        if (c_.split_out || c_.split_res) { wr<int>(d, c_.split_out); wr<int>(d, c_.split_res); }      // (trailing, only when set: older blobs stay valid)
+        // trailing, only when set (older blobs stay valid); deserialize accepts exactly the three lengths: none, two ints, four ints ending in the magic word
+        if (c_.split_in) { wr<int>(d, c_.split_out); wr<int>(d, c_.split_res); wr<int>(d, c_.split_in); wr<int>(d, kTrailerMagic); }
+        else if (c_.split_out || c_.split_res) { wr<int>(d, c_.split_out); wr<int>(d, c_.split_res); }
     }
     Plugin* clone() const override { return new DsvtConv2dPlugin(c_, w_.data(), b_.empty() ? nullptr : b_.data()); }
 };
@@ -1678,7 +1913,11 @@ static Plugin* convNew(const ConvCfg& c, const float* w, const float* b) {
     if (c.up > 1 && (c.KH != 1 || c.KW != 1 || c.stride != 1 || c.Cout % CNB != 0)) return nullptr;   // pixel-shuffle chunks are whole workgroup columns
     if (!c.out_f32 && (c.out_ld % 4 != 0 || c.out_coff % 4 != 0)) return nullptr;
     if (c.split_out && (c.out_f32 || c.out_ld % 12 != 0 || c.out_ld / 3 < c.out_coff + c.Cout)) return nullptr;      // three planes of out_ld / 3 channels
+    if (c.split_out < 0 || c.split_out > 2 || c.split_in < 0 || c.split_in > 2) return nullptr;
+    if (c.split_out == 2 && ((c.out_ld / 3) % 32 != 0 || c.out_coff % 8 != 0)) return nullptr;       // the x8 plane is laid out in 32-channel groups
     if (c.split_res && !c.has_res) return nullptr;
+    if (c.split_in && c.Cin % 192 != 0) return nullptr;                                              // three planes of whole 64-channel phases
+    if (c.split_in == 2 && (c.KH != 3 || c.KW != 3 || c.stride != 1 || c.pad != 1 || c.up != 1 || c.Cout <= 32)) return nullptr;      // the layers conv_wide_kernel serves
     return new DsvtConv2dPlugin(c, w, b);
 }
 static Plugin* convCreate(const DsvtPluginFieldCollection* fc) {
@@ -1687,10 +1926,10 @@ static Plugin* convCreate(const DsvtPluginFieldCollection* fc) {
     c.KH = c.KW = fieldInt(fc, "kernel_size", 1); c.stride = fieldInt(fc, "stride", 1); c.pad = fieldInt(fc, "padding", 0);
     c.up = fieldInt(fc, "pixel_shuffle", 1); c.relu = fieldInt(fc, "relu", 0); c.has_res = fieldInt(fc, "has_residual", 0);
     c.out_ld = fieldInt(fc, "out_channel_stride", c.Cout); c.out_coff = fieldInt(fc, "out_channel_offset", 0); c.out_f32 = fieldInt(fc, "out_f32", 0);
-    c.split_out = fieldInt(fc, "split_output", 0) != 0; c.split_res = fieldInt(fc, "split_residual", 0) != 0;
+    c.split_out = fieldInt(fc, "split_output", 0); c.split_res = fieldInt(fc, "split_residual", 0) != 0; c.split_in = fieldInt(fc, "split_input", 0);
     const DsvtPluginField* w = findField(fc, "weight"); const DsvtPluginField* b = findField(fc, "bias");
     if (!w || !w->data || c.Cin <= 0 || c.Cout <= 0 || c.up < 1) return nullptr;
-    if ((long)w->length != (long)c.up * c.up * c.Cout * c.KH * c.KW * c.Cin) return nullptr;
+    if ((long)w->length != (long)c.up * c.up * c.Cout * c.KH * c.KW * (c.split_in == 2 ? c.Cin / 3 : c.Cin)) return nullptr;
     if (b && b->data && b->length != c.Cout) return nullptr;
     return convNew(c, static_cast<const float*>(w->data), (b && b->data) ? static_cast<const float*>(b->data) : nullptr);
 }
@@ -1701,12 +1940,24 @@ static Plugin* convDeser(const void* data, size_t len) {
     for (int i = 0; i < 14; ++i) ci[i] = rd<int>(d);
     int has_b = rd<int>(d);
     if (c.Cin <= 0 || c.Cout <= 0 || c.up < 1 || c.KH <= 0 || c.KW <= 0) return nullptr;
-    size_t nw = (size_t)c.up * c.up * c.Cout * c.KH * c.KW * c.Cin;
-    if (len < 15 * sizeof(int) + sizeof(float) * (nw + (has_b ? c.Cout : 0))) return nullptr;
-    std::vector<float> w(nw), b(has_b ? c.Cout : 0);
+    // the blob's length decides which trailer it carries: none, {split_out, split_res}, or {split_out, split_res, split_in, magic}; with
+    // split_in == 2 the weight rows hold Cin / 3 channels per tap.  Any other length is refused (trailing bytes are never guessed at).
+    const size_t nwFull = (size_t)c.up * c.up * c.Cout * c.KH * c.KW * c.Cin, nbias = has_b ? c.Cout : 0;
+    size_t nw = nwFull;
+    const size_t base = 15 * sizeof(int) + sizeof(float) * nbias;
+    if (len == base + sizeof(float) * nwFull) {
+    } else if (len == base + sizeof(float) * nwFull + 2 * sizeof(int)) {
+        const char* t = static_cast<const char*>(data) + len - 2 * sizeof(int); c.split_out = rd<int>(t); c.split_res = rd<int>(t);
+    } else {
+        if (len < base + 4 * sizeof(int)) return nullptr;
+        const char* t = static_cast<const char*>(data) + len - 4 * sizeof(int);
+        c.split_out = rd<int>(t); c.split_res = rd<int>(t); c.split_in = rd<int>(t);
+        if (rd<int>(t) != DsvtConv2dPlugin::kTrailerMagic || c.split_in < 1 || c.split_in > 2) return nullptr;
+        nw = c.split_in == 2 ? nwFull / 3 : nwFull;
+        if (len != base + sizeof(float) * nw + 4 * sizeof(int)) return nullptr;
+    }
+    std::vector<float> w(nw), b(nbias);
     memcpy(w.data(), d, sizeof(float) * nw); if (has_b) memcpy(b.data(), d + sizeof(float) * nw, sizeof(float) * c.Cout);
-    const size_t used = 15 * sizeof(int) + sizeof(float) * (nw + (has_b ? c.Cout : 0));
-    if (len >= used + 2 * sizeof(int)) { const char* t = static_cast<const char*>(data) + used; c.split_out = rd<int>(t); c.split_res = rd<int>(t); }
     return convNew(c, w.data(), has_b ? b.data() : nullptr);
 }
 static Creator g_convCreator{"DsvtConv2dPlugin",
@@ -1714,6 +1965,7 @@ static Creator g_convCreator{"DsvtConv2dPlugin",
      {"kernel_size", DSVT_FIELD_INT32}, {"stride", DSVT_FIELD_INT32}, {"padding", DSVT_FIELD_INT32}, {"pixel_shuffle", DSVT_FIELD_INT32},
      {"relu", DSVT_FIELD_INT32}, {"has_residual", DSVT_FIELD_INT32}, {"out_channel_stride", DSVT_FIELD_INT32},
      {"out_channel_offset", DSVT_FIELD_INT32}, {"out_f32", DSVT_FIELD_INT32}, {"split_output", DSVT_FIELD_INT32}, {"split_residual", DSVT_FIELD_INT32},
+     {"split_input", DSVT_FIELD_INT32},
      {"weight", DSVT_FIELD_FLOAT32}, {"bias", DSVT_FIELD_FLOAT32}},
     convCreate, convDeser, {}, {}};
 static Registrar g_convReg(&g_convCreator);

@@ -83,4 +83,16 @@ __device__ __forceinline__ void blockExclusiveScanK(uint32_t (&v)[K], uint32_t* 
     __syncthreads();
 }
 
+// ---- the "x8 plane" of a split-precision tensor (conv.hip ConvArgs::x8_out; written by the convolutions and by Map2Bev) ----
+// four values -> four OCP e4m3 bytes (round to nearest even; v_cvt_pk_fp8_f32 turns anything beyond the format's 448 into NaN, hence the clamp)
+__device__ __forceinline__ unsigned packE4m3(float a, float b, float c, float d) {
+    a = __builtin_fminf(__builtin_fmaxf(a, -448.f), 448.f); b = __builtin_fminf(__builtin_fmaxf(b, -448.f), 448.f);
+    c = __builtin_fminf(__builtin_fmaxf(c, -448.f), 448.f); d = __builtin_fminf(__builtin_fmaxf(d, -448.f), 448.f);
+    int p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    p = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
+    return (unsigned)p;
+}
+// byte offset, inside a pixel's x8 plane, of the lo8 byte of channel c (its hi8 byte is 16 further): [lo8 0..15 | hi8 0..15 | lo8 16..31 | hi8 16..31] per 32 channels
+__device__ __forceinline__ int x8Offset(int c) { return (c >> 5) * 64 + ((c >> 4) & 1) * 32 + (c & 15); }
+
 }  // namespace dsvt

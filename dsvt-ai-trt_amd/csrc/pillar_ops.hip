@@ -425,7 +425,7 @@ map2bev_kernel(const float4* __restrict__ feat, const uint4* __restrict__ coords
 typedef _Float16 mb_half4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256)
 map2bev_split_kernel(const float4* __restrict__ feat, const uint4* __restrict__ coords, const uint32_t* __restrict__ voxel_num,
-                     int G, int gx, int gy, int frames, mb_half4* __restrict__ bev)
+                     int G, int gx, int gy, int frames, mb_half4* __restrict__ bev, int x8)
 {
     size_t total = (size_t)(*voxel_num) * G;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -440,14 +440,20 @@ map2bev_split_kernel(const float4* __restrict__ feat, const uint4* __restrict__ 
             hi[k] = (_Float16)fminf(fmaxf(f[k], -65504.f), 65504.f);
             lo[k] = (_Float16)fminf(fmaxf(f[k] - (float)hi[k], -65504.f), 65504.f);
         }
-        mb_half4* o = bev + (((size_t)co.x * gy + co.z) * gx + co.w) * 3 * G + c;
-        o[0] = hi; o[G] = lo; o[2 * G] = hi;
+        mb_half4* cell = bev + (((size_t)co.x * gy + co.z) * gx + co.w) * 3 * G;
+        mb_half4* o = cell + c;
+        o[0] = hi; o[G] = lo;
+        if (x8) {       // third plane = the fp8 operands of the correction terms (conv.hip ConvArgs::x8_out): lo8 = e4m3(2^11 lo), hi8 = e4m3(v)
+            unsigned char* xp = reinterpret_cast<unsigned char*>(cell + 2 * G) + x8Offset(4 * c);
+            *reinterpret_cast<unsigned*>(xp) = packE4m3((f[0] - (float)hi[0]) * 2048.f, (f[1] - (float)hi[1]) * 2048.f, (f[2] - (float)hi[2]) * 2048.f, (f[3] - (float)hi[3]) * 2048.f);
+            *reinterpret_cast<unsigned*>(xp + 16) = packE4m3(f[0], f[1], f[2], f[3]);
+        } else o[2 * G] = hi;
     }
 }
 class Map2BevPlugin : public Plugin {
 public:
     int max_pillars_num_, channel_num_, gx_, gy_, frames_ = 1;      // frames_ > 1 (field "frames"): coords.x selects one of `frames` stacked BEV maps
-    int split_ = 0;                                                 // field "split_output": fp32 rows -> fp16 [hi | lo | hi] planes, 3 C channels per cell
+    int split_ = 0;                                                 // field "split_output": fp32 rows -> fp16 [hi | lo | hi] planes (1) or [hi | lo | x8] (2), 3 C channels per cell
     Map2BevPlugin(int mp, int c, int gx, int gy, int frames = 1, int split = 0) : max_pillars_num_(mp), channel_num_(c), gx_(gx), gy_(gy), frames_(frames), split_(split) {}
     const char* type() const override { return "Map2BevPlugin"; }
     int nbOutputs() const override { return 1; }
@@ -470,7 +476,7 @@ public:
             DSVT_CHECK(hipMemsetAsync(out[0], 0, (size_t)2 * gx_ * gy_ * 3 * channel_num_ * frames_, stream));
             hipLaunchKernelGGL(map2bev_split_kernel, dim3(2048), dim3(256), 0, stream, static_cast<const float4*>(in[0]),
                                static_cast<const uint4*>(in[1]), static_cast<const uint32_t*>(in[2]), channel_num_ / 4, gx_, gy_, frames_,
-                               static_cast<mb_half4*>(out[0]));
+                               static_cast<mb_half4*>(out[0]), split_ == 2 ? 1 : 0);
             return lastError();
         }
         const int esz = (inDesc && inDesc[0].type == DSVT_HALF) ? 2 : 4;
@@ -491,7 +497,8 @@ public:
     Plugin* clone() const override { return new Map2BevPlugin(max_pillars_num_, channel_num_, gx_, gy_, frames_, split_); }
 };
 static Plugin* mbNew(int mp, int c, int gx, int gy, int frames = 1, int split = 0) {
-    return (mp > 0 && c > 0 && c % 4 == 0 && gx > 0 && gy > 0 && frames >= 1) ? new Map2BevPlugin(mp, c, gx, gy, frames, split != 0) : nullptr;
+    if (split < 0 || split > 2 || (split == 2 && c % 32 != 0)) return nullptr;                 // 2: [hi | lo | x8], the x8 plane in 32-channel groups
+    return (mp > 0 && c > 0 && c % 4 == 0 && gx > 0 && gy > 0 && frames >= 1) ? new Map2BevPlugin(mp, c, gx, gy, frames, split) : nullptr;
 }
 static Plugin* mbCreate(const DsvtPluginFieldCollection* fc) {
     return mbNew(fieldInt(fc, "max_pillars_num"), fieldInt(fc, "channel_num"), fieldInt(fc, "grid_size_x"), fieldInt(fc, "grid_size_y"), fieldInt(fc, "frames", 1),

@@ -97,7 +97,7 @@ def fold_linear_bn(w, lin, bn, eps, bias=False):
 class DsvtPipeline:
     def __init__(self, weights, caps=None, blocks=4, with_head=True, ln_eps=0.0, head_dtype=torch.float32,
                  device="cuda:0", zero_fill=False, linear_compute=P.COMPUTE_F32, fused_mlp=None,
-                 device_nms=False, pos_table=None, fork_partition=None, frames=1):
+                 device_nms=False, pos_table=None, fork_partition=None, frames=1, head_mx=None):
         """linear_compute: COMPUTE_F32 = fp32 MFMA everywhere (parity mode, boxes within 1e-3 of the
         fp32 oracle); COMPUTE_F16 = fp16 MFMA operands with fp32 accumulate/epilogues (BASELINE
         configs[2] "fp16"); COMPUTE_SPLIT = split-precision fp16 MFMA (fp32 grade, fused frame path).  head_dtype: precision of the
@@ -107,6 +107,10 @@ class DsvtPipeline:
         all of them (rows = sum of the frames' pillars), one stacked BEV map per frame, the per-frame dense stage / decode / NMS through the C
         ABI's batched enqueue.  points [1, frames * caps.N, 4], n [frames] -> boxes [frames, 500, 9], count [frames].  caps.N stays the
         per-frame point capacity; the pillar / kept-point / window / set capacities are totals over the frames."""
+        # head_mx (fp32-grade head only; default: on in the split-precision frame, off in the exact-fp32 cross-check mode): the correction terms
+        # lo w_hi + hi w_lo of every head convolution run as OCP fp8 blocks of the scaled MFMA (csrc/conv.hip conv_wide_kernel<.., MX>): the
+        # activations travel as [hi | lo | x8] triples, boxes stay ~1e-4 from the fp32 oracle (1e-3 bar) at 2/3 of the matrix-pipe time
+        self.head_mx = (linear_compute == P.COMPUTE_SPLIT) if head_mx is None else bool(head_mx)
         self.caps = c = caps or Caps()
         self.frames = int(frames)
         self.split = split = linear_compute == P.COMPUTE_SPLIT
@@ -251,7 +255,8 @@ class DsvtPipeline:
             self.cat = torch.zeros((1, c.Nk, 192), dtype=torch.float32, device=self.device)
         if with_head:
             self.split_head = head_dtype == torch.float32
-            self.map2bev = P.add_map_2_bev_op(c.P, C, GX, GY, frames=self.frames, split_output=self.split_head)
+            self.head_mx = self.head_mx and self.split_head
+            self.map2bev = P.add_map_2_bev_op(c.P, C, GX, GY, frames=self.frames, split_output=(2 if self.head_mx else 1) if self.split_head else 0)
             self.filter = P.add_filter_box_by_score_op(TOP_K, X_MIN, X_MAX, Y_MIN, Y_MAX, Z_MIN, Z_MAX, VX, VY, VZ, SCORE_THR)
             self.nms = P.add_rotated_nms_op(TOP_K, NMS_THRESH) if device_nms else None
             self.hip_head = not self.split_head
@@ -313,13 +318,20 @@ class DsvtPipeline:
         is read as hi + lo (`split_residual`), the last layer writes fp32.  src/dsvt-ai-trt.cpp:1144-1468 in fp32 arithmetic."""
         cw, dw, sw = P.conv_weight_rows, P.deconv_weight_rows, P.split_weight_rows
         ops = self.sops = {}
+        mx = self.head_mx
 
         def conv(name, rows, bias, H, cin, cout, k, stride, relu, res=False, out_f32=False, plane=None, **kw):
             plane = cout if plane is None else plane
-            ops[name] = P.add_conv2d_op(sw(rows, k * k, cin), bias, H, H, 3 * cin, cout, k, stride, k // 2, relu=relu, has_residual=res,
-                                        split_residual=res, out_f32=out_f32, split_output=not out_f32,
+            # head_mx: the third plane of every tensor holds the fp8 operands (x8).  The 3 x 3 stride-1 layers with > 32 output channels (93 % of the
+            # stage's products) read [hi | x8] on the fp16 + fp8 K loop from the REAL fp32 rows (split_input = 2); the others keep the three-product
+            # walk over [w_hi | w_hi | w_lo] and read plane 0 where the third plane used to repeat it (split_input = 1)
+            wide = mx and k == 3 and stride == 1 and cout > 32 and not kw.get("pixel_shuffle")
+            ops[name] = P.add_conv2d_op(np.asarray(rows, np.float32) if wide else sw(rows, k * k, cin), bias, H, H, 3 * cin, cout, k, stride, k // 2,
+                                        relu=relu, has_residual=res, split_residual=res, out_f32=out_f32,
+                                        split_output=0 if out_f32 else (2 if mx else 1), split_input=(2 if wide else 1) if mx else 0,
                                         out_channel_stride=plane if out_f32 else 3 * plane, **kw)
             ops[name].split_in = True            # (bench.py's flop / byte accounting: 3 Cin operand channels carry Cin real ones)
+            ops[name].mx_in = bool(wide)
 
         def conv_bn(name, name_conv, name_bn, H, cin, cout, k, stride, relu, res=False):
             s_, sh = bn_fold(w, name_bn, 1e-3)

@@ -402,7 +402,7 @@ def add_map_2_bev_op(max_pillars_num, channel_num, grid_size_x, grid_size_y, fra
     split_output: fp32 rows in, the fp16 triple [hi | lo | hi] (3 C channels per cell) out -- the operand of the fp32-grade convolutions."""
     extra = dict(frames=int(frames)) if frames != 1 else {}
     if split_output:
-        extra["split_output"] = 1
+        extra["split_output"] = int(split_output)           # 2: the third plane holds the fp8 operands (x8) instead of repeating hi
     return Plugin("Map2BevPlugin", dict(extra, max_pillars_num=max_pillars_num, channel_num=channel_num,
                                         grid_size_x=grid_size_x, grid_size_y=grid_size_y), "map2bev_layer")
 
@@ -578,12 +578,15 @@ def add_split_half_op(channel_num, relu=False, has_residual=False):
 
 def add_conv2d_op(weight_rows, bias, in_height, in_width, in_channels, out_channels, kernel_size=1, stride=1, padding=0,
                   pixel_shuffle=1, relu=False, has_residual=False, out_channel_stride=None, out_channel_offset=0, out_f32=False,
-                  split_output=False, split_residual=False):
+                  split_output=0, split_residual=False, split_input=0):
     """NHWC fp16 implicit-GEMM convolution with fused bias / residual / ReLU / pixel-shuffle / concat offset
     (csrc/conv.hip): replaces the reference's addConvolutionNd / addDeconvolutionNd + addScale + ReLU + SUM
     groups (src/dsvt-ai-trt.cpp:149-246, 1144-1468).  Inputs: x [1,H,W,Cin] fp16 (, residual [1,Ho,Wo,C] fp16).
-    split_output: the result leaves as the fp16 triple [hi | lo | hi] (out_channel_stride = 3 x the plane width); split_residual: the
-    residual input is such a triple (value hi + lo)."""
+    split_output: 1 = the result leaves as the fp16 triple [hi | lo | hi] (out_channel_stride = 3 x the plane width), 2 = as [hi | lo | x8]
+    (third plane: the OCP-fp8 operands of the correction terms, csrc/conv.hip ConvArgs::x8_out); split_residual: the residual input is such
+    a triple (value hi + lo).  split_input (the input is a [hi | lo | x8] triple of in_channels / 3 real channels): 1 = weight_rows are
+    split_weight_rows(...) and the third plane's phases read plane 0; 2 = weight_rows are the REAL fp32 rows [R][9][in_channels / 3] and the
+    layer runs on the fp16 + fp8 K loop (3 x 3, stride 1, more than 32 output channels)."""
     fields = dict(in_height=in_height, in_width=in_width, in_channels=in_channels, out_channels=out_channels,
                   kernel_size=kernel_size, stride=stride, padding=padding, pixel_shuffle=pixel_shuffle, relu=int(bool(relu)),
                   has_residual=int(bool(has_residual)),
@@ -591,9 +594,11 @@ def add_conv2d_op(weight_rows, bias, in_height, in_width, in_channels, out_chann
                   out_channel_offset=out_channel_offset, out_f32=int(bool(out_f32)),
                   weight=np.asarray(weight_rows, np.float32).reshape(-1))
     if split_output:
-        fields["split_output"] = 1
+        fields["split_output"] = int(split_output)
     if split_residual:
         fields["split_residual"] = 1
+    if split_input:
+        fields["split_input"] = int(split_input)
     if bias is not None:
         fields["bias"] = np.asarray(bias, np.float32).reshape(-1)
     return Plugin("DsvtConv2dPlugin", fields, "conv2d_layer")

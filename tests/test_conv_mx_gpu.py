@@ -1,0 +1,197 @@
+"""The fp32-grade convolutions on the fp16 + fp8 K loop (round 4; csrc/conv.hip conv_wide_kernel<.., MX>, ConvArgs::x8_out / alias3).
+
+A split tensor [hi | lo | x8] carries, in its third plane, the OCP e4m3 operands of the two correction terms of
+a w = hi w_hi + lo w_hi + hi w_lo:  lo8 = e4m3(2^11 (a - hi)),  hi8 = e4m3(a),  per 32 channels 64 bytes
+[lo8 0..15 | hi8 0..15 | lo8 16..31 | hi8 16..31].  The reference layers are convBnLELU / convBn + SUM + ReLU of
+src/dsvt-ai-trt.cpp:149-246 in fp32; the tests compare with
+  * a float64 convolution of the UNROUNDED operands (the bar the boxes need: fp16-operand error / ~10), and
+  * a float64 EMULATION of the arithmetic (fp16 main product + the two fp8 products with the per-row weight exponent of
+    DsvtConv2dPlugin::packMX), which a wrong tap pairing, byte order or scale would miss by ~2^-12 -- 50 x the bound used."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def e4m3(t):
+    """decoded value of the OCP e4m3 byte the device writes: round to nearest even, saturated at +-448"""
+    return t.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+
+
+def e4m3_bytes(t):
+    return t.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+def make_triple(x):
+    """x [B,H,W,C] fp32 (CPU) -> fp16 [B,H,W,3C] = [hi | lo | x8]"""
+    C = x.shape[-1]
+    assert C % 32 == 0
+    hi = x.half()
+    d = x - hi.float()
+    lo = d.half()
+    lo8 = e4m3_bytes(d * 2048.0).reshape(*x.shape[:-1], C // 32, 2, 16)
+    hi8 = e4m3_bytes(x).reshape(*x.shape[:-1], C // 32, 2, 16)
+    x8 = torch.stack([lo8, hi8], dim=-2)                       # [.., group, half, kind, 16] -> bytes [lo 0..15 | hi 0..15 | lo 16..31 | hi 16..31]
+    x8 = x8.reshape(*x.shape[:-1], 2 * C).contiguous().view(torch.float16)
+    return torch.cat([hi, lo, x8], dim=-1).contiguous()
+
+
+def split_value(t3, C):
+    """[.., 3C] fp16 triple -> hi + lo in float64"""
+    return t3[..., :C].double() + t3[..., C:2 * C].double()
+
+
+def x8_of(t3, C):
+    return t3[..., 2 * C:].contiguous().view(torch.uint8)
+
+
+def assert_x8_plane(t3, C):
+    """the x8 plane of a device-written triple against its own fp16 planes: lo8 = e4m3(2^11 lo), hi8 = e4m3(hi + lo); bytes equal up to the
+    sign of zero, except where the fp16 rounding of lo moved the value across an e4m3 rounding boundary (rare, one code apart)"""
+    lo, v = t3[..., C:2 * C].float(), t3[..., :C].float() + t3[..., C:2 * C].float()
+    want = torch.stack([e4m3(lo * 2048.0).reshape(*lo.shape[:-1], C // 32, 2, 16), e4m3(v).reshape(*lo.shape[:-1], C // 32, 2, 16)], dim=-2)
+    have = x8_of(t3, C).view(torch.float8_e4m3fn).float().reshape(want.shape)
+    assert not torch.isnan(have).any()
+    d = (want - have).abs()
+    assert (d > 0.126 * torch.maximum(want.abs(), have.abs()) + 2.0 ** -9).sum().item() == 0
+    assert (d != 0).float().mean().item() < 5e-3
+
+
+def mx_emulation(x, w, b):
+    """float64 value of what the kernel computes (before residual / ReLU): fp16 main product + the two fp8 correction products"""
+    xh = x.half().float()
+    a_lo8, a_hi8 = e4m3((x - xh) * 2048.0).double() / 2048.0, e4m3(x).double()
+    wh = w.half().float()
+    mx = w.abs().amax(dim=(1, 2, 3))
+    e = torch.floor(torch.log2(torch.tensor(448.0) / mx)).clamp(-60, 60)
+    s = torch.pow(torch.tensor(2.0), e).reshape(-1, 1, 1, 1)
+    w_hi8 = e4m3(wh * s).double() / s.double()
+    w_lo8 = e4m3((w - wh) * s * 2048.0).double() / (s.double() * 2048.0)
+    y = F.conv2d(xh.double(), wh.double(), b.double(), 1, 1) + F.conv2d(a_lo8, w_hi8, None, 1, 1) + F.conv2d(a_hi8, w_lo8, None, 1, 1)
+    return y
+
+
+CASES = [
+    # H, W, cin, cout, res, relu, images
+    (52, 47, 128, 128, True, True, 1),        # basic-block conv2 + identity + ReLU: 8 rows x 64 channels, one row per wave (CT = 4, RW = 1)
+    (52, 47, 192, 128, False, True, 1),       # first BEV conv
+    (30, 33, 384, 64, False, True, 1),        # shared head conv (64 output channels: four channel tiles)
+    (30, 33, 64, 320, False, True, 1),        # head stems (three 128-channel chunks, the last one partial)
+    (37, 29, 256, 256, True, True, 2),        # third stage, two images
+    (468, 468, 128, 128, True, True, 1),      # 16-row x 128-channel items (CT = 8): the 468 x 468 layers
+    (234, 234, 128, 128, False, True, 1),     # 16-row x 64-channel items (CT = 4, RW = 2)
+    (150, 140, 192, 128, False, False, 2),    # CT = 8 with six phases, two images
+]
+
+
+@pytest.mark.parametrize("H,W,cin,cout,res,relu,B", CASES)
+def test_mx_conv_is_fp32_grade(pkg, H, W, cin, cout, res, relu, B):
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(H * 1000 + cin + cout)
+    x = torch.randn(B, cin, H, W, generator=g) * 3.0
+    x = torch.relu(x) if (H + cin) % 2 else x                  # (the network's tensors are post-ReLU: half zeros)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    w = w * torch.exp(torch.randn(cout, 1, 1, 1, generator=g))   # rows of different magnitude: the per-row exponent matters
+    b = torch.randn(cout, generator=g) * 0.1
+    r = torch.randn(B, cout, H, W, generator=g) if res else None
+    exact = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    emu = mx_emulation(x, w, b)
+    if res:
+        r3 = make_triple(nhwc(r))
+        rv = split_value(r3, cout).permute(0, 3, 1, 2)
+        exact, emu = exact + rv, emu + rv
+    if relu:
+        exact, emu = torch.relu(exact), torch.relu(emu)
+    op = P.add_conv2d_op(P.conv_weight_rows(w.numpy()), b.numpy(), H, W, 3 * cin, cout, 3, 1, 1, relu=relu, has_residual=res, split_residual=res,
+                         split_output=2, split_input=2, out_channel_stride=3 * cout)
+    args = [make_triple(nhwc(x)).to(DEV)] + ([r3.to(DEV)] if res else [])
+    y3 = op(*args)[0]
+    torch.cuda.synchronize()
+    y3 = y3.cpu()
+    got = split_value(y3, cout).permute(0, 3, 1, 2)
+    scale = exact.abs().max().item()
+    e_emu, e_exact = (got - emu).abs().max().item() / scale, (got - exact).abs().max().item() / scale
+    print(f"mx conv {H}x{W} {cin}->{cout}: vs emulation {e_emu:.2e}, vs exact fp64 {e_exact:.2e} of scale")
+    assert e_emu < 8e-6, (e_emu, e_exact)          # fp32 accumulation order over 9 cin products + the fp8 blocks' internal sums
+    assert e_exact < 1.5e-4, e_exact               # fp16 operands: ~1e-3; three fp16 products: ~1e-6
+    # the x8 plane of the result: the encoder's bytes for the value the planes hold (v - hi is exact, so only a double rounding
+    # through the fp16 lo plane can move a byte: rare, and then by one code)
+    assert_x8_plane(y3, cout)
+    again = op(*args)[0].cpu()
+    assert torch.equal(again.view(torch.int16), y3.view(torch.int16))
+
+
+@pytest.mark.parametrize("H,W,cin,cout,k,stride,res,relu,f32out", [
+    (52, 47, 128, 256, 3, 2, False, True, False),     # strided (gather kernel)
+    (52, 47, 128, 256, 1, 2, False, False, False),    # 1 x 1 downsample
+    (52, 47, 192, 128, 1, 1, False, False, False),    # 1 x 1 shortcut of the first block (halo kernel)
+    (25, 31, 320, 18, 3, 1, False, False, True),      # head outputs (narrow halo kernel, fp32 out)
+])
+def test_three_plane_kernels_read_plane_0_for_an_x8_third_plane(pkg, H, W, cin, cout, k, stride, res, relu, f32out):
+    """split_input = 1: the kernels that still walk [hi | lo | hi] with [w_hi | w_hi | w_lo] rows get the same bits from a [hi | lo | x8]
+    tensor (the third plane's phases read plane 0), and with split_output = 2 they write the x8 plane for their consumers."""
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(H * 1000 + cin + cout + k)
+    x = nhwc(torch.randn(1, cin, H, W, generator=g) * 3.0)
+    w = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g) * 0.1
+    rows = P.split_weight_rows(P.conv_weight_rows(w.numpy()), k * k, cin)
+    t_mx = make_triple(x)
+    t_old = torch.cat([t_mx[..., :2 * cin], t_mx[..., :cin]], dim=-1).contiguous()
+    kw = dict(relu=relu, out_f32=f32out, out_channel_stride=cout if f32out else 3 * cout)
+    old = P.add_conv2d_op(rows, b.numpy(), H, W, 3 * cin, cout, k, stride, k // 2, split_output=0 if f32out else 1, **kw)(t_old.to(DEV))[0].cpu()
+    new = P.add_conv2d_op(rows, b.numpy(), H, W, 3 * cin, cout, k, stride, k // 2, split_output=0 if f32out else 2, split_input=1, **kw)(t_mx.to(DEV))[0].cpu()
+    if f32out:
+        assert torch.equal(old, new)
+        return
+    assert torch.equal(old[..., :2 * cout].view(torch.int16), new[..., :2 * cout].view(torch.int16))
+    assert_x8_plane(new, cout)
+
+
+def test_map2bev_writes_the_x8_plane(pkg):
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n, C, GX, GY = 700, 192, 40, 40
+    feat = torch.randn(1, 1000, C, generator=g) * torch.exp(torch.randn(1, 1000, 1, generator=g) * 2)
+    cells = torch.randperm(GX * GY, generator=g)[:1000]
+    coords = torch.zeros(1, 1000, 4, dtype=torch.int32)
+    coords[0, :, 2] = (cells // GX).int(); coords[0, :, 3] = (cells % GX).int()
+    cnt = torch.tensor([n], dtype=torch.int32)
+    bev = P.add_map_2_bev_op(1000, C, GX, GY, split_output=2)(feat.to(DEV), coords.to(DEV), cnt.to(DEV))[0].cpu()
+    want = torch.zeros(1, GY, GX, C)
+    want[0, coords[0, :n, 2].long(), coords[0, :n, 3].long()] = feat[0, :n]
+    assert torch.equal(bev.view(torch.int16), make_triple(want).view(torch.int16))
+
+
+def test_mx_plugin_refuses_what_the_kernel_does_not_serve(pkg):
+    P = pkg.plugin
+    w = np.zeros((128, 9 * 128), np.float32)
+    for kw in (dict(kernel_size=1, padding=0), dict(stride=2), dict(pixel_shuffle=2, kernel_size=1, padding=0)):
+        args = dict(kernel_size=3, stride=1, padding=1)
+        args.update(kw)
+        with pytest.raises(Exception):
+            P.add_conv2d_op(w[:, :(args["kernel_size"] ** 2) * 128], None, 20, 20, 384, 128, split_input=2, split_output=2, out_channel_stride=384, **args)
+    with pytest.raises(Exception):      # 32 output channels: the narrow halo kernel's layer
+        P.add_conv2d_op(w[:32], None, 20, 20, 384, 32, 3, 1, 1, split_input=2, split_output=2, out_channel_stride=96)
+
+
+def test_mx_conv_blob_round_trip(pkg):
+    """serialize -> deserialize keeps split_input / split_output (four-int trailer ending in the magic word); a padded blob is refused"""
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(3)
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24
+    op = P.add_conv2d_op(P.conv_weight_rows(w.numpy()), None, 9, 11, 192, 64, 3, 1, 1, split_input=2, split_output=2, out_channel_stride=192)
+    x3 = make_triple(nhwc(torch.randn(1, 64, 9, 11, generator=g))).to(DEV)
+    y = op(x3)[0].cpu()
+    blob = op.serialize()
+    op2 = P.Plugin.deserialize("DsvtConv2dPlugin", blob)
+    assert torch.equal(op2(x3)[0].cpu().view(torch.int16), y.view(torch.int16))
+    with pytest.raises(Exception):
+        P.Plugin.deserialize("DsvtConv2dPlugin", blob + b"\0\0\0\0")
