@@ -56,7 +56,8 @@ struct ConvArgs {
     // v_mfma_scale_f32_16x16x128_f8f6f4 (2.4 x the fp16 rate, tools/ubench/mfma_mx.hip) instead of two more fp16 MFMAs per k-step.  The third plane of
     // a split tensor then holds the fp8 operands ("x8 plane"): per 32 channels 64 bytes [lo8 0..15 | hi8 0..15 | lo8 16..31 | hi8 16..31] with
     // lo8 = e4m3(2^11 (v - hi)), hi8 = e4m3(v), both saturated at +-448 (x8Store).
-    //   x8_out : the epilogue writes [hi | lo | x8] instead of [hi | lo | hi]
+    //   x8_out : 1 = the epilogue writes [hi | lo | x8] instead of [hi | lo | hi]; 2 = [hi | - | x8]: the lo plane is left untouched, for tensors that only
+    //            the fp16 + fp8 K loop reads (split_output = 3)
     //   alias3 : (kernels that still walk three fp16 planes) first channel of the third plane, whose phases read plane 0 instead; 0 = off
     //   xscale : (conv_wide_kernel<.., MX>) E8M0 scale byte per weight row: 127 - 11 - e with w_hi8 = e4m3(2^e w_hi), w_lo8 = e4m3(2^(e + 11) w_lo)
     int x8_out, alias3;
@@ -95,7 +96,8 @@ __device__ __forceinline__ void storeHalf8(const ConvArgs& a, const float (&v)[8
     if (SPL && a.split_out) {
         half8 hi, lo;
         splitPlanes<8>(v, hi, lo);
-        *reinterpret_cast<half8*>(o) = hi; *reinterpret_cast<half8*>(o + a.split_out) = lo;
+        *reinterpret_cast<half8*>(o) = hi;
+        if (a.x8_out != 2) *reinterpret_cast<half8*>(o + a.split_out) = lo;          // (x8_out 2: no consumer reads the lo plane -- a third of the store burst)
         if (a.x8_out) x8Store<8>(reinterpret_cast<unsigned char*>(static_cast<_Float16*>(a.out) + opix * a.out_ld + 2 * a.split_out), a.out_coff + co, v, hi);
         else *reinterpret_cast<half8*>(o + 2 * a.split_out) = hi;
     } else {
@@ -141,13 +143,15 @@ __device__ __forceinline__ void convStore(const ConvArgs& a, floatx4 acc, size_t
         splitPlanes<4>(v, hi, lo);
         unsigned char* xp = reinterpret_cast<unsigned char*>(static_cast<_Float16*>(a.out) + opix * a.out_ld + 2 * a.split_out);
         if (full) {
-            *reinterpret_cast<half4*>(o) = hi; *reinterpret_cast<half4*>(o + a.split_out) = lo;
+            *reinterpret_cast<half4*>(o) = hi;
+            if (a.x8_out != 2) *reinterpret_cast<half4*>(o + a.split_out) = lo;
             if (a.x8_out) x8Store<4>(xp, a.out_coff + co, v, hi);
             else *reinterpret_cast<half4*>(o + 2 * a.split_out) = hi;
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) if (co + i < a.Cout) {
-                o[i] = hi[i]; o[a.split_out + i] = lo[i];
+                o[i] = hi[i];
+                if (a.x8_out != 2) o[a.split_out + i] = lo[i];
                 if (a.x8_out) {
                     const int xo = x8Offset(a.out_coff + co + i);
                     xp[xo] = (unsigned char)packE4m3((v[i] - (float)hi[i]) * 2048.f, 0.f, 0.f, 0.f); xp[xo + 16] = (unsigned char)packE4m3(v[i], 0.f, 0.f, 0.f);
@@ -742,6 +746,32 @@ struct WideCfg {
 // 1 KB rows: bytes 0..15 and 16..31 of every lane), so a weight slab holds SPS / 2 cross steps.  Packed weights: DsvtConv2dPlugin::packMX.
 typedef int intx4 __attribute__((ext_vector_type(4)));
 typedef int intx8 __attribute__((ext_vector_type(8)));
+// tile engine of the MX instantiations (tools/ab_conv.sh builds variants from -D flags; A/B numbers in profiles/README.md, round 4): four-step
+// weight slabs (half the barriers: 7.70 vs 7.87 ms over the stage's layers), two slab buffers, four A fragments per fp16 batch, one per fp8 batch
+#ifndef MX_TRICKLE_MAIN
+#define MX_TRICKLE_MAIN 1
+#endif
+#ifndef MX_TRICKLE_CROSS
+#define MX_TRICKLE_CROSS 0
+#endif
+#ifndef MX_NWB
+#define MX_NWB 2
+#endif
+#ifndef MX_NWB4
+#define MX_NWB4 2
+#endif
+#ifndef MX_CH
+#define MX_CH 4
+#endif
+#ifndef WIDE_PFB
+#define WIDE_PFB 1
+#endif
+#ifndef MX_SPS
+#define MX_SPS 4
+#endif
+#ifndef MX_CHX
+#define MX_CHX 1
+#endif
 template <int OP>
 __device__ __forceinline__ floatx4 mfmaX8(const intx8& A, const intx8& B, const floatx4& c, int scaleA) {
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, c, 0, 0, OP, scaleA, 0, 127);          // fp8 x fp8; byte OP of scaleA; scale_b = 2^0
@@ -762,9 +792,9 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     constexpr int WT_HS = HS, WT_HBYTES = C::HBYTES, WT_WBYTES = C::WBYTES, WT_NPC = C::NPC, WT_ROWS = C::ROWS, PPW = C::PPW;
     constexpr int PPS = SPS == 2 ? (PPW + 2) / 3 : PPW;           // halo pieces a wave requests per slab
     constexpr int NRS = (PPW + PPS - 1) / PPS;                    // ... over this many slabs
-    constexpr int CH = CT > 4 ? 4 : CT;    // A fragments read per batch
+    constexpr int CH = CT > 4 ? (MX ? MX_CH : 4) : CT;  // A fragments read per batch
     constexpr int LEAD = NWB - 1;
-    constexpr bool TRICKLE = CT == 8 && NW == 8 && LEAD == 2 && !MX;     // requests spread over the slab (see the slab loop)
+    constexpr bool TRICKLE_K = CT == 8 && NW == 8 && LEAD >= 2;          // requests spread over the slab (see the slab loop)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WT_HBYTES + NWB * WT_WBYTES + 1024];      // halo[2] | wslab[NWB] | bias
     constexpr int BIAS_OFF = 2 * WT_HBYTES + NWB * WT_WBYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
@@ -836,15 +866,59 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
 #pragma unroll
     for (int i = 0; i < PPW; ++i)
         if (wave + NW * i < WT_NPC) haloRequest(wave + NW * i, y0, x0, 0, 0, bimg);
+    // PFA (NWB = 4: the slab THREE ahead is requested when a slab starts): the weights of slab s + 1 are published one slab early, so the first A
+    // fragments of the next slab are read BEFORE the barrier that ends the current one, like its first B fragments (whose halo phase is
+    // always published by then: requested in the first NRS slabs of the phase before) -- the first MFMAs after a barrier wait for no LDS read
+    constexpr bool PFB = WIDE_PFB != 0, PFA = PFB && LEAD >= 3;
     weightRequests(0, chunk, 0);
+    if (PFA) weightRequests(1, chunk, 1);
     slabBarrier(0);
-    if (LEAD == 2) weightRequests(1, chunk, 1);                   // (NSLAB >= 5; retired by the first slab-end wait)
+    if (LEAD >= 2) weightRequests(PFA ? 2 : 1, chunk, PFA ? 2 : 1);      // (NSLAB >= 5; retired by the first slab-end wait)
 
     const int wreq = (SPS * CT - wave + NW - 1) / NW;             // weight requests THIS wave issues per slab (what its counted wait leaves in flight)
     const int pb = ((RW * wave) * WT_HS + r) * 64;                // this lane's pixel of pixel tile 0, tap (0, 0)
     const int aoff = lane << 4;
     int wb = 0;
     floatx4 acc[CT][NM];
+    // fragment buffers (double buffered by hand inside a slab; the first fragments of a slab are loaded at the end of the slab before)
+    half8 Bf[2][NM], Af[2][CH];
+    constexpr int CHX = MX_CHX;                                   // (MX) channel tiles per batch of a cross step
+    intx8 Bx[MX ? NM : 1], Ax[2][CHX];
+    // B fragments of fp16 step t of the item (t = 9 NPM: step 0 of the next item -- phase 0, buffer 0: NPM is even)
+    auto loadB = [&](int t, half8 (&B)[NM]) {
+        const int ph = t / 9, tap = t - 9 * ph, ky = tap / 3, kx = tap - 3 * ky;
+        const unsigned char* hbp = smem + (ph & 1) * WT_HBYTES + (ky * WT_HS + kx) * 64 + pb + ((g ^ (((r + kx) >> 1) & 2)) << 4);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) B[m] = *reinterpret_cast<const half8*>(hbp + ((m >> 1) * WT_HS + (m & 1) * 16) * 64);
+    };
+    // A fragments of channel tiles c0 .. of step u of the slab in weight buffer wbuf
+    auto loadA = [&](int wbuf, int u, int c0, half8 (&A)[CH]) {
+        const unsigned char* wbp = smem + 2 * WT_HBYTES + wbuf * WT_WBYTES + (u * CT + c0) * 1024 + aoff;
+#pragma unroll
+        for (int ct = 0; ct < CH; ++ct) A[ct] = *reinterpret_cast<const half8*>(wbp + ct * 1024);
+    };
+    // (MX) B fragments of cross step x = (phase x / 5, tap pair x % 5) of the item
+    auto loadBx = [&](int x) {
+        const int q = x / 5, pr = x - 5 * q;
+        int tap = 2 * pr + (g >> 1); tap = tap > 8 ? 8 : tap;                                 // (tap 9: zero weights)
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;                                    // tap / 3 for 0 .. 8
+        const int slot = (g & 1) ^ (((r + kx) >> 1) & 2);
+        const unsigned char* hbp = smem + ((NPM + q) & 1) * WT_HBYTES + (ky * WT_HS + kx) * 64 + pb;
+#pragma unroll
+        for (int m = 0; m < (MX ? NM : 1); ++m) {
+            const unsigned char* pp = hbp + ((m >> 1) * WT_HS + (m & 1) * 16) * 64;
+            const intx4 lo = *reinterpret_cast<const intx4*>(pp + (slot << 4)), hi = *reinterpret_cast<const intx4*>(pp + ((slot ^ 2) << 4));
+            Bx[m] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    };
+    auto loadAx = [&](int wbuf, int u, int c0, intx8 (&A)[CHX]) {
+        const unsigned char* wbp = smem + 2 * WT_HBYTES + wbuf * WT_WBYTES + (u * CT + c0) * 2048 + aoff;
+#pragma unroll
+        for (int ct = 0; ct < CHX; ++ct) {
+            const intx4 lo = *reinterpret_cast<const intx4*>(wbp + ct * 2048), hi = *reinterpret_cast<const intx4*>(wbp + ct * 2048 + 1024);
+            A[ct] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    };
     for (;;) {
         int nitem = item + gridDim.x, ny0 = 0, nx0 = 0, nch = 0, nbimg = 0;
         const bool have_next = nitem < nitems;
@@ -855,6 +929,8 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
 #pragma unroll
             for (int m = 0; m < NM; ++m) acc[ct][m] = b4;
         }
+        if (PFB) loadB(0, Bf[0]);                                    // the item's first fragments (its first slabs were published while the item before ran)
+        if (PFA) loadA(wb, 0, 0, Af[0]);
         int xs[(CT + 3) / 4] = {};                                   // MX: scale byte of row (ct, r) in byte ct & 3 of xs[ct >> 2]
         if constexpr (MX) {
 #pragma unroll
@@ -862,8 +938,13 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         }
         // one slab; CROSS (compile time): a slab of the MX loop's fp8 steps (s >= NSA).  Two loops over this body, not one loop with a branch:
         // with both bodies in one loop hipcc spilled 141 registers of the accumulators into the MFMA stream
-        auto slab = [&](const int s, auto crossTag) {
+        // NEXT (compile time): what follows this slab -- 0: a slab of the same kind, 1: the first cross slab, 2: the end of the item (no
+        // prefetch: the epilogue comes first).  The last slab of each loop is peeled so that no fragment buffer is conditionally written
+        // inside a loop (hipcc then keeps it alive around the whole loop: 619 spilled registers).
+        auto slab = [&](const int s, auto crossTag, auto nextTag) {
             constexpr bool CROSS = decltype(crossTag)::value;
+            constexpr int NEXT = decltype(nextTag)::value;
+            constexpr bool TRICKLE = TRICKLE_K && (!MX || (CROSS ? MX_TRICKLE_CROSS : MX_TRICKLE_MAIN));
             // halo of phase P (the phase after the one this slab starts in): its buffer is free once phase P - 2 has ended, i.e.
             // from slab s0 = ceil(9 (P - 1) / SPS) on, and the first slab that touches phase P is floor(9 P / SPS) > s0 + NRS - 1.
             // Weights of the slab LEAD ahead; the halo requests of a slab come BEFORE its weight requests: with LEAD = 2 the slab-end
@@ -916,36 +997,17 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                 {
                     // a slab of cross steps: step x = (phase q, tap pair pr); batches of CHX channel tiles x NM pixel tiles; the B fragments of a step
                     // stay in ONE buffer (32 registers), the A fragments are double buffered
-                    constexpr int CHX = 1, BPX = CT / CHX, NBX = XPS * BPX;
-                    intx8 Bx[NM], Ax[2][CHX];
-                    auto loadBx = [&](int u) {
-                        const int x = XPS * (s - NSA) + u, q = x / 5, pr = x - 5 * q;
-                        int tap = 2 * pr + (g >> 1); tap = tap > 8 ? 8 : tap;                 // (tap 9: zero weights)
-                        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;                    // tap / 3 for 0 .. 8
-                        const int slot = (g & 1) ^ (((r + kx) >> 1) & 2);
-                        const unsigned char* hbp = smem + ((NPM + q) & 1) * WT_HBYTES + (ky * WT_HS + kx) * 64 + pb;
-#pragma unroll
-                        for (int m = 0; m < NM; ++m) {
-                            const unsigned char* pp = hbp + ((m >> 1) * WT_HS + (m & 1) * 16) * 64;
-                            const intx4 lo = *reinterpret_cast<const intx4*>(pp + (slot << 4)), hi = *reinterpret_cast<const intx4*>(pp + ((slot ^ 2) << 4));
-                            Bx[m] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                        }
-                    };
-                    auto loadAx = [&](int u, int c0, intx8 (&A)[CHX]) {
-                        const unsigned char* wbp = smem + 2 * WT_HBYTES + wb * WT_WBYTES + (u * CT + c0) * 2048 + aoff;
-#pragma unroll
-                        for (int ct = 0; ct < CHX; ++ct) {
-                            const intx4 lo = *reinterpret_cast<const intx4*>(wbp + ct * 2048), hi = *reinterpret_cast<const intx4*>(wbp + ct * 2048 + 1024);
-                            A[ct] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                        }
-                    };
-                    loadBx(0); loadAx(0, 0, Ax[0]);
+                    constexpr int BPX = CT / CHX, NBX = XPS * BPX;
+                    static_assert(NBX % 2 == 0, "the A buffer of the next slab's first batch");
+                    const int x0s = XPS * (s - NSA), wn = (wb + 1) % NWB;
+                    if (!PFB) loadBx(x0s);
+                    if (!PFA) loadAx(wb, 0, 0, Ax[0]);
 #pragma unroll
                     for (int b = 0; b < NBX; ++b) {
                         const int u = b / BPX, c0 = (b % BPX) * CHX;
-                        if (b + 1 < NBX) loadAx((b + 1) / BPX, ((b + 1) % BPX) * CHX, Ax[(b + 1) & 1]);
+                        if (b + 1 < NBX) loadAx(wb, (b + 1) / BPX, ((b + 1) % BPX) * CHX, Ax[(b + 1) & 1]);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (XPS * (s - NSA) + u < 5 * NPM) {
+                        if (x0s + u < 5 * NPM) {
 #pragma unroll
                             for (int ct = 0; ct < CHX; ++ct)
 #pragma unroll
@@ -953,7 +1015,8 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                                     acc[c0 + ct][m] = mfmaX8(c0 + ct, Ax[b & 1][ct], Bx[m], acc[c0 + ct][m], xs[(c0 + ct) >> 2]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
-                        if (b + 1 < NBX && (b + 1) % BPX == 0) loadBx((b + 1) / BPX);
+                        if (b + 1 < NBX && (b + 1) % BPX == 0) loadBx(x0s + (b + 1) / BPX);
+                        if (b + 1 == NBX && NEXT == 0 && PFB) { loadBx(x0s + XPS); if (PFA) loadAx(wn, 0, 0, Ax[0]); }      // the next slab's first fragments (the MFMAs above are still draining)
                         if (TRICKLE) {
 #pragma unroll
                             for (int j = 0; j < NREQ; ++j)
@@ -964,26 +1027,17 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                 }
             } else {
                 constexpr int BPS = CT / CH, NB = SPS * BPS;          // batches per step / per slab
-                half8 Bf[2][NM], Af[2][CH];
-                auto loadB = [&](int u, half8 (&B)[NM]) {
-                    const int step = SPS * s + u, ph = step / 9, tap = step - 9 * ph, ky = tap / 3, kx = tap - 3 * ky;
-                    const unsigned char* hbp = smem + (ph & 1) * WT_HBYTES + (ky * WT_HS + kx) * 64 + pb + ((g ^ (((r + kx) >> 1) & 2)) << 4);
-#pragma unroll
-                    for (int m = 0; m < NM; ++m) B[m] = *reinterpret_cast<const half8*>(hbp + ((m >> 1) * WT_HS + (m & 1) * 16) * 64);
-                };
-                auto loadA = [&](int u, int c0, half8 (&A)[CH]) {
-                    const unsigned char* wbp = smem + 2 * WT_HBYTES + wb * WT_WBYTES + (u * CT + c0) * 1024 + aoff;
-#pragma unroll
-                    for (int ct = 0; ct < CH; ++ct) A[ct] = *reinterpret_cast<const half8*>(wbp + ct * 1024);
-                };
-                loadB(0, Bf[0]); loadA(0, 0, Af[0]);
+                static_assert(NB % 2 == 0, "the A buffer of the next slab's first batch");
+                const int wn = (wb + 1) % NWB;
+                if (!PFB) loadB(SPS * s, Bf[0]);
+                if (!PFA) loadA(wb, 0, 0, Af[0]);
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     const int u = b / BPS, c0 = (b % BPS) * CH;
                     if (b + 1 < NB) {
                         const int un = (b + 1) / BPS, cn = ((b + 1) % BPS) * CH;
-                        if (cn == 0) loadB(un, Bf[un & 1]);
-                        loadA(un, cn, Af[(b + 1) & 1]);
+                        if (cn == 0) loadB(SPS * s + un, Bf[un & 1]);
+                        loadA(wb, un, cn, Af[(b + 1) & 1]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (SPS == 2 || SPS * s + u < NSTEP) {
@@ -994,6 +1048,10 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                                 acc[c0 + ct][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[b & 1][ct], Bf[u & 1][m], acc[c0 + ct][m], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    if (b + 1 == NB && PFB) {                        // the next slab's first fragments (the MFMAs above are still draining)
+                        if constexpr (NEXT == 1) { loadBx(0); if (PFA) loadAx(wn, 0, 0, Ax[0]); }
+                        else if constexpr (NEXT == 0) { loadB(SPS * (s + 1), Bf[0]); if (PFA) loadA(wn, 0, 0, Af[0]); }
+                    }
                     if (TRICKLE) {
 #pragma unroll
                         for (int j = 0; j < NREQ; ++j)
@@ -1004,19 +1062,22 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
             }
             if (TR && a.trace) {                                     // (wave-uniform; the wait and the barrier stamped apart)
                 mark();                                              // [5 s + 3] MFMAs issued
-                slabWait(LEAD == 2 && wIssued ? wreq : 0);
+                slabWait(LEAD >= 2 && wIssued ? wreq : 0);
                 mark();                                              // [5 s + 4] own requests landed
                 __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
                 mark();                                              // [5 s + 5] barrier passed
-            } else slabBarrier(LEAD == 2 && wIssued ? wreq : 0);
+            } else slabBarrier(LEAD >= 2 && wIssued ? wreq : 0);
             wb = (wb + 1) % NWB;
         };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
 #pragma unroll 1
-        for (int s = 0; s < NSA; ++s) slab(s, std::false_type{});
+        for (int s = 0; s < NSA - 1; ++s) slab(s, std::false_type{}, I0{});
         if constexpr (MX) {
+            slab(NSA - 1, std::false_type{}, I1{});
 #pragma unroll 1
-            for (int s = NSA; s < NSLAB; ++s) slab(s, std::true_type{});
-        }
+            for (int s = NSA; s < NSLAB - 1; ++s) slab(s, std::true_type{}, I0{});
+            slab(NSLAB - 1, std::true_type{}, I2{});
+        } else slab(NSA - 1, std::false_type{}, I2{});
         mark();
         // residual / ReLU / store (the bias is in the accumulators)
         if (!(dbg & 8)) {
@@ -1554,7 +1615,9 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
     const int tilesX = cdiv(a.Wo, HTW), nchunk = cdiv(a.CoutRows, CNB);
     const int NBI = a.nb;                                       // images: every item count below is per image x NBI
     const bool spl = a.split_out != 0 || a.res_split != 0;      // split-precision epilogue (its own instantiations: see ConvArgs)
-    const int ncu = numCUs();
+    static int ncuOverride = -1;                                // (ablation build: DSVT_CONV_NCU = persistent workgroups per launch)
+    if (ncuOverride < 0) ncuOverride = ablateEnv("DSVT_CONV_NCU", 0);
+    const int ncu = ncuOverride > 0 ? ncuOverride : numCUs();
     static int dbg = -1;                                        // timing ablations (wrong results): the -DDSVT_ABLATE build only, constant 0 in the product
     if (dbg < 0) dbg = ablateEnv("DSVT_CONV_DBG", 0);
     // 16-row tiles when they fill the CUs, else 8-row x 64-channel tiles (two workgroups per CU).  (Two channel
@@ -1571,12 +1634,12 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
         if (a.KH != 3 || ctWide < 4) return -3;
         const int nwide = cdiv(a.Ho, 16) * tilesX * nchunk * NBI;
         if (nwide >= ncu) {
-            if (ctWide == 8) DSVT_WIDE_MX(ncu, 512, nwide, nchunk, 8, 8, 36, 2, 3, 2);
-            else DSVT_WIDE_MX(ncu, 512, nwide, nchunk, 4, 8, 40, 4, 2, 2);
+            if (ctWide == 8) DSVT_WIDE_MX(ncu, 512, nwide, nchunk, 8, 8, 36, MX_SPS, MX_NWB, 2);
+            else DSVT_WIDE_MX(ncu, 512, nwide, nchunk, 4, 8, 40, 4, MX_NWB4, 2);
         }
         const int nch64 = cdiv(a.CoutRows, 64), nsmall = cdiv(a.Ho, 8) * tilesX * nch64 * NBI;
         const int n16 = cdiv(a.Ho, 16) * tilesX * nch64 * NBI;
-        if (n16 * 10 >= ncu * 9 && n16 <= ncu) DSVT_WIDE_MX(n16, 512, n16, nch64, 4, 8, 40, 4, 2, 2);
+        if (n16 * 10 >= ncu * 9 && n16 <= ncu) DSVT_WIDE_MX(n16, 512, n16, nch64, 4, 8, 40, 4, MX_NWB4, 2);
         DSVT_WIDE_MX(nsmall < 2 * ncu ? nsmall : 2 * ncu, 512, nsmall, nch64, 4, 8, 36, 4, 2, 1);
     }
 #undef DSVT_WIDE_MX
@@ -1639,7 +1702,7 @@ static int launchConv(const ConvArgs& a, int KC, hipStream_t stream) {
 // -------------------------------------------------------------------------------------
 struct ConvCfg {
     int H, W, Cin, Cout, KH, KW, stride, pad, up, relu, has_res, out_ld, out_coff, out_f32;
-    int split_out, split_res;      // split precision (fields "split_output" / "split_residual"): the output / the residual is an fp16 [hi | lo | hi] triple (see ConvArgs); split_out = 2: [hi | lo | x8]
+    int split_out, split_res;      // split precision (fields "split_output" / "split_residual"): the output / the residual is an fp16 [hi | lo | hi] triple (see ConvArgs); split_out = 2: [hi | lo | x8], 3: [hi | - | x8]
     int split_in;                  // field "split_input": the input is a split tensor [hi | lo | x8] (Cin = 3 C).  1: the weight rows are the host's [w_hi | w_hi | w_lo] and the phases
                                    // of the third plane read plane 0; 2: the weight rows are the REAL fp32 rows [R][9][C] and the layer runs on conv_wide_kernel<.., MX>
 };
@@ -1844,7 +1907,7 @@ public:
         a.KH = c_.KH; a.KW = c_.KW; a.stride = c_.stride; a.pad = c_.pad; a.up = c_.up; a.relu = c_.relu;
         a.split_out = c_.split_out ? c_.out_ld / 3 : 0;
         a.res_split = (c_.has_res && c_.split_res) ? a.res_ld / 3 : 0;
-        a.x8_out = c_.split_out == 2;
+        a.x8_out = c_.split_out == 2 ? 1 : c_.split_out == 3 ? 2 : 0;
         a.alias3 = c_.split_in == 1 ? c_.Cin / 3 * 2 : 0;
         a.xscale = c_.split_in == 2 ? xscale_dev_ : nullptr;
         a.wide = !c_.out_f32 && c_.Cout % 16 == 0 && c_.out_ld % 8 == 0 && c_.out_coff % 8 == 0 && (!c_.has_res || a.res_ld % 8 == 0) &&
@@ -1913,8 +1976,8 @@ static Plugin* convNew(const ConvCfg& c, const float* w, const float* b) {
     if (c.up > 1 && (c.KH != 1 || c.KW != 1 || c.stride != 1 || c.Cout % CNB != 0)) return nullptr;   // pixel-shuffle chunks are whole workgroup columns
     if (!c.out_f32 && (c.out_ld % 4 != 0 || c.out_coff % 4 != 0)) return nullptr;
     if (c.split_out && (c.out_f32 || c.out_ld % 12 != 0 || c.out_ld / 3 < c.out_coff + c.Cout)) return nullptr;      // three planes of out_ld / 3 channels
-    if (c.split_out < 0 || c.split_out > 2 || c.split_in < 0 || c.split_in > 2) return nullptr;
-    if (c.split_out == 2 && ((c.out_ld / 3) % 32 != 0 || c.out_coff % 8 != 0)) return nullptr;       // the x8 plane is laid out in 32-channel groups
+    if (c.split_out < 0 || c.split_out > 3 || c.split_in < 0 || c.split_in > 2) return nullptr;
+    if (c.split_out >= 2 && ((c.out_ld / 3) % 32 != 0 || c.out_coff % 8 != 0)) return nullptr;       // the x8 plane is laid out in 32-channel groups
     if (c.split_res && !c.has_res) return nullptr;
     if (c.split_in && c.Cin % 192 != 0) return nullptr;                                              // three planes of whole 64-channel phases
     if (c.split_in == 2 && (c.KH != 3 || c.KW != 3 || c.stride != 1 || c.pad != 1 || c.up != 1 || c.Cout <= 32)) return nullptr;      // the layers conv_wide_kernel serves

@@ -320,7 +320,8 @@ class DsvtPipeline:
         ops = self.sops = {}
         mx = self.head_mx
 
-        def conv(name, rows, bias, H, cin, cout, k, stride, relu, res=False, out_f32=False, plane=None, **kw):
+        def conv(name, rows, bias, H, cin, cout, k, stride, relu, res=False, out_f32=False, plane=None, lo=True, **kw):
+            # lo = False (head_mx only): every consumer of this tensor is a [hi | x8] layer and it is nobody's residual -- its lo plane is not written
             plane = cout if plane is None else plane
             # head_mx: the third plane of every tensor holds the fp8 operands (x8).  The 3 x 3 stride-1 layers with > 32 output channels (93 % of the
             # stage's products) read [hi | x8] on the fp16 + fp8 K loop from the REAL fp32 rows (split_input = 2); the others keep the three-product
@@ -328,14 +329,14 @@ class DsvtPipeline:
             wide = mx and k == 3 and stride == 1 and cout > 32 and not kw.get("pixel_shuffle")
             ops[name] = P.add_conv2d_op(np.asarray(rows, np.float32) if wide else sw(rows, k * k, cin), bias, H, H, 3 * cin, cout, k, stride, k // 2,
                                         relu=relu, has_residual=res, split_residual=res, out_f32=out_f32,
-                                        split_output=0 if out_f32 else (2 if mx else 1), split_input=(2 if wide else 1) if mx else 0,
+                                        split_output=0 if out_f32 else ((2 if lo else 3) if mx else 1), split_input=(2 if wide else 1) if mx else 0,
                                         out_channel_stride=plane if out_f32 else 3 * plane, **kw)
             ops[name].split_in = True            # (bench.py's flop / byte accounting: 3 Cin operand channels carry Cin real ones)
             ops[name].mx_in = bool(wide)
 
-        def conv_bn(name, name_conv, name_bn, H, cin, cout, k, stride, relu, res=False):
+        def conv_bn(name, name_conv, name_bn, H, cin, cout, k, stride, relu, res=False, lo=True):
             s_, sh = bn_fold(w, name_bn, 1e-3)
-            conv(name, cw(w[name_conv + ".weight"] * s_[:, None, None, None]), sh, H, cin, cout, k, stride, relu, res=res)
+            conv(name, cw(w[name_conv + ".weight"] * s_[:, None, None, None]), sh, H, cin, cout, k, stride, relu, res=res, lo=lo)
 
         H = GY
         for (i, cin, cout, stride, nb) in ((0, 192, 128, 1, 2), (1, 128, 128, 2, 3), (2, 128, 256, 2, 3)):
@@ -343,7 +344,7 @@ class DsvtPipeline:
                 p = f"module.backbone_2d.blocks.{i}.{j}"
                 st = stride if j == 0 else 1
                 ci = cin if j == 0 else cout
-                conv_bn(p + ".1", p + ".conv1", p + ".bn1", H, ci, cout, 3, st, True)
+                conv_bn(p + ".1", p + ".conv1", p + ".bn1", H, ci, cout, 3, st, True, lo=False)        # (read by conv2 only)
                 Ho = (H + 2 - 3) // st + 1
                 if j == 0:
                     conv_bn(p + ".d", p + ".downsample_layer.0", p + ".downsample_layer.1", H, ci, cout, 1, st, False)
@@ -353,8 +354,8 @@ class DsvtPipeline:
             p = f"module.backbone_2d.deblocks.{i}"
             s_, sh_ = bn_fold(w, p + ".1", 1e-3)
             conv(p, dw(w[p + ".0.weight"] * s_[None, :, None, None]), sh_, H, cout, 128, 1, 1, True, pixel_shuffle=k,
-                 plane=384, out_channel_offset=128 * i)
-        conv_bn("shared", "module.dense_head.shared_conv.0", "module.dense_head.shared_conv.1", GY, 384, 64, 3, 1, True)
+                 plane=384, out_channel_offset=128 * i, lo=False)                                       # (the concat buffer: read by the shared conv only)
+        conv_bn("shared", "module.dense_head.shared_conv.0", "module.dense_head.shared_conv.1", GY, 384, 64, 3, 1, True, lo=False)      # (read by the head stems only)
         names, outs = ["center", "center_z", "dim", "rot", "hm"], [2, 1, 3, 2, 10]          # iou head is dead (:1440-1452)
         W0, b0 = [], []
         for n in names:

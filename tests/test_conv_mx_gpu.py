@@ -195,3 +195,21 @@ def test_mx_conv_blob_round_trip(pkg):
     assert torch.equal(op2(x3)[0].cpu().view(torch.int16), y.view(torch.int16))
     with pytest.raises(Exception):
         P.Plugin.deserialize("DsvtConv2dPlugin", blob + b"\0\0\0\0")
+
+
+def test_split_output_3_leaves_the_lo_plane_alone(pkg):
+    """[hi | - | x8]: a tensor only the fp16 + fp8 K loop reads -- the hi and x8 planes are split_output = 2's, the lo plane keeps whatever it held"""
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(9)
+    H, W, cin, cout = 21, 37, 64, 128
+    w = torch.randn(cout, cin, 3, 3, generator=g) / 24
+    x3 = make_triple(nhwc(torch.randn(2, cin, H, W, generator=g))).to(DEV)
+    kw = dict(split_input=2, out_channel_stride=3 * cout, relu=True)
+    full = P.add_conv2d_op(P.conv_weight_rows(w.numpy()), None, H, W, 3 * cin, cout, 3, 1, 1, split_output=2, **kw)(x3)[0].cpu()
+    out = torch.full((2, H, W, 3 * cout), 7.0, dtype=torch.float16, device=DEV)
+    P.add_conv2d_op(P.conv_weight_rows(w.numpy()), None, H, W, 3 * cin, cout, 3, 1, 1, split_output=3, **kw)(x3, out=[out])
+    torch.cuda.synchronize()
+    out = out.cpu()
+    assert torch.equal(out[..., :cout].view(torch.int16), full[..., :cout].view(torch.int16))
+    assert torch.equal(out[..., 2 * cout:].view(torch.int16), full[..., 2 * cout:].view(torch.int16))
+    assert (out[..., cout:2 * cout] == 7.0).all()

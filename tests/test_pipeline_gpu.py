@@ -308,7 +308,7 @@ def test_detect_directory_writes_reference_txt(pkg, weights, tmp_path):
     done = pkg.detect.run_directory(cases.GOLDEN, str(out), weights, caps=pkg.pipeline.Caps.reference(), fp16=False, log=lambda *_: None)
     assert [d[0] for d in done] == ["000000", "000003", "000004"]
     c = pkg.pipeline.Caps.reference()
-    pipe = pkg.pipeline.DsvtPipeline(weights, caps=c, device_nms=True)
+    pipe = pkg.pipeline.DsvtPipeline(weights, caps=c, device_nms=True, linear_compute=pkg.plugin.COMPUTE_SPLIT)      # detect's fp32-grade mode
     for name, kept, ms in done:
         sec, rows = pkg.detect.read_txt(str(out / f"{name}.txt"))
         assert rows.shape == (kept, 9) and abs(sec - ms) < 1e-3
