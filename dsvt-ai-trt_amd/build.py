@@ -45,10 +45,8 @@ def _stale(target, deps):
 def build(force=False, verbose=False, ablate=False):
     """ablate=True: libdsvt_hip_ablate.so (-DDSVT_ABLATE: the DSVT_* trace / ablation / A-B switches of csrc/ are read from the environment).
     The product library reads none; tools/ load the other one through DSVT_HIP_LIB."""
-    global OUT, OBJ
-    if ablate:
-        OUT, OBJ = os.path.join(HERE, "libdsvt_hip_ablate.so"), os.path.join(HERE, "build_ablate")
-    os.makedirs(OBJ, exist_ok=True)
+    out, obj_dir = (os.path.join(HERE, "libdsvt_hip_ablate.so"), os.path.join(HERE, "build_ablate")) if ablate else (OUT, OBJ)
+    os.makedirs(obj_dir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "dsvt_plugin.h"))
     objs = []
@@ -57,7 +55,7 @@ def build(force=False, verbose=False, ablate=False):
         s = os.path.join(CSRC, src)
         if not os.path.exists(s):
             continue
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(obj_dir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
             cmd = [hipcc()] + COMMON + extra + (["-DDSVT_ABLATE"] if ablate else []) + ["-c", s, "-o", o]
@@ -70,12 +68,12 @@ def build(force=False, verbose=False, ablate=False):
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
         if verbose and out:
             print(out.decode(), file=sys.stderr)
-    if force or procs or _stale(OUT, objs):
-        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if force or procs or _stale(out, objs):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
         subprocess.check_call(cmd)
     if not ablate:
         build_host(force)
-    return OUT
+    return out
 
 
 HOST_SRC = os.path.join(HERE, "host", "dsvt_detect.cpp")

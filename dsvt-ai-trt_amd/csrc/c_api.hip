@@ -152,7 +152,9 @@ int32_t dsvtPluginEnqueue(DsvtPlugin* p, const DsvtPluginTensorDesc* inDesc, con
             // not configured (enqueue's signature, like TensorRT's, does not carry the number of inputs): a rank >= 3 first input with a
             // leading dimension > 1 can only be a batch, which cannot be served -- refused, not mis-sliced.  Rank-2 [rows, C] descriptors
             // and everything configured with B = 1 pass through as one enqueue.
-            if (p->nbInputs < 1 && inDesc && outDesc && inDesc[0].dims.nbDims >= 3 && inDesc[0].dims.d[0] > 1) return -2;
+            // Configured with a batch the loop above cannot serve (batch == -1: B > 1 frames in, but not every output a [B, ...] stack): refused too --
+            // a plugin that ignores the batch dimension would process frame 0 and report success.
+            if ((p->nbInputs < 1 || p->batch < 0) && inDesc && outDesc && inDesc[0].dims.nbDims >= 3 && inDesc[0].dims.d[0] > 1) return -2;
         }
         return p->impl->enqueue(inDesc, outDesc, inputs, outputs, ws, reinterpret_cast<hipStream_t>(stream));)
 }
@@ -169,7 +171,7 @@ int32_t dsvtPluginConfigurePlugin(DsvtPlugin* p, const DsvtPluginTensorDesc* in,
             p->batch = B;
             for (int k = 0; k < nbIn; ++k) p->inBatched[k] = in[k].dims.nbDims >= 1 && in[k].dims.d[0] == B && !p->impl->sharedInput(k);
             for (int k = 0; k < nbOut; ++k) p->outBatched[k] = 1;
-        }
+        } else if (in[0].dims.nbDims >= 3) p->batch = -1;        // a batch that cannot be sliced: enqueue refuses it
     }
     return 0;
 }

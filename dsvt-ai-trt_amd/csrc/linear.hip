@@ -1261,7 +1261,12 @@ static Plugin* linDeser(const void* data, size_t len) {
     memcpy(all.data(), d, need * sizeof(float));
     const float* w = all.data(); const float* b = has_b ? w + (size_t)c.K * c.N : nullptr;
     const float* g = w + (size_t)c.K * c.N + (has_b ? c.N : 0); const float* be = g + (size_t)c.n_ln * c.N;
-    { const size_t used = 13 * sizeof(int) + sizeof(float) + need * sizeof(float); if (len >= used + sizeof(int)) { const char* t = static_cast<const char*>(data) + used; c.a2_gather_wy = rd<int>(t); } }
+    {
+        const size_t used = 13 * sizeof(int) + sizeof(float) + need * sizeof(float);
+        const int extra = trailingInts(len, used, 1);
+        if (extra < 0) return nullptr;
+        if (extra >= 1) { const char* t = static_cast<const char*>(data) + used; c.a2_gather_wy = rd<int>(t); }
+    }
     if (has_pe) {                                  // stored as [w0 | w1 | b]; rebuild the [K][2] weight the constructor expects
         const float* pe = be + (size_t)c.n_ln * c.N;
         std::vector<float> pw(2 * (size_t)c.K);

@@ -756,8 +756,10 @@ static Plugin* mlpDeser(const void* data, size_t len) {
     const float* lg = q; q += (3 + hb) * MC; const float* lb = q;
     const size_t base = 2 * sizeof(int) + sizeof(float) + n * sizeof(float);
     int fr = 0, sp = 0;
-    if (len >= base + sizeof(int)) memcpy(&fr, d + n * sizeof(float), sizeof(int));
-    if (len >= base + 2 * sizeof(int)) memcpy(&sp, d + n * sizeof(float) + sizeof(int), sizeof(int));
+    const int extra = trailingInts(len, base, 2);
+    if (extra < 0) return nullptr;
+    if (extra >= 1) memcpy(&fr, d + n * sizeof(float), sizeof(int));
+    if (extra >= 2) memcpy(&sp, d + n * sizeof(float) + sizeof(int), sizeof(int));
     auto* pl = new DsvtEncoderMlpPlugin(max_rows, hb, eps, wo, w1, w2, bo, b1, b2, lg, lb, sp != 0);
     pl->frames_ = fr > 0 ? fr : 0;
     return pl;

@@ -473,11 +473,12 @@ static Plugin* gsCreate(const DsvtPluginFieldCollection* fc) {
     return gsNew(p);
 }
 static Plugin* gsDeser(const void* data, size_t len) {
-    if (len < 6 * sizeof(int)) return nullptr;
+    const int extra = trailingInts(len, 6 * sizeof(int), 1);
+    if (extra < 0) return nullptr;
     const char* d = static_cast<const char*>(data); GSParams p{};
     p.voxel_num_set = rd<int>(d); p.max_win_num = rd<int>(d); p.max_voxel_num_per_win = rd<int>(d);
     p.wx = rd<int>(d); p.wy = rd<int>(d); p.wz = rd<int>(d);
-    if (len >= 7 * sizeof(int)) p.max_set_num = rd<int>(d);
+    if (extra >= 1) p.max_set_num = rd<int>(d);
     return gsNew(p);
 }
 static Creator g_gsCreator{"GetSetPlugin",

@@ -214,11 +214,15 @@ pfn_kernel(PfnArgs a)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float v0 = x0[2 * s_][i], v1 = x0[2 * s_ + 1][i];
-                    h[i] = (_Float16)fminf(v0, 65504.f); h[4 + i] = (_Float16)fminf(v1, 65504.f);      // (x0 >= 0 after the ReLU)
-                    // (the residuals as fp32 values first; the hi parts come from the clamped, i.e. materialised, value: see attention.hip on hipcc's fused conversions)
-                    float d0 = v0 - (float)h[i], d1 = v1 - (float)h[4 + i];
-                    asm volatile("" : "+v"(d0), "+v"(d1));
-                    l[i] = (_Float16)d0; l[4 + i] = (_Float16)d1;
+                    if constexpr (SPLIT) {
+                        h[i] = (_Float16)fminf(v0, 65504.f); h[4 + i] = (_Float16)fminf(v1, 65504.f);      // (x0 >= 0 after the ReLU)
+                        // (the residuals as fp32 values first; the hi parts come from the clamped, i.e. materialised, value: see attention.hip on hipcc's fused conversions)
+                        float d0 = v0 - (float)h[i], d1 = v1 - (float)h[4 + i];
+                        asm volatile("" : "+v"(d0), "+v"(d1));
+                        l[i] = (_Float16)d0; l[4 + i] = (_Float16)d1;
+                    } else {                 // the fp16 frame: round 2's instruction stream (no clamp, no residuals)
+                        h[i] = (_Float16)v0; h[4 + i] = (_Float16)v1; l[i] = l[4 + i] = (_Float16)0.f;
+                    }
                 }
                 f1[s_] = half8{h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]};
                 f1l[s_] = half8{l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7]};
@@ -453,7 +457,9 @@ static Plugin* pfnDeser(const void* data, size_t len) {
     std::vector<float> all(n); memcpy(all.data(), d, n * sizeof(float));
     const float* q = all.data();
     int pack = 1, split = 0;
-    if (len >= 2 * sizeof(int) + n * sizeof(float)) { const char* t = d + n * sizeof(float); pack = rd<int>(t) != 0; if (len >= 3 * sizeof(int) + n * sizeof(float)) split = rd<int>(t) != 0; }
+    const int extra = trailingInts(len, sizeof(int) + n * sizeof(float), 2);
+    if (extra < 0) return nullptr;
+    if (extra >= 1) { const char* t = d + n * sizeof(float); pack = rd<int>(t) != 0; if (extra >= 2) split = rd<int>(t) != 0; }
     DsvtPillarFeatureNetPlugin* pl = new DsvtPillarFeatureNetPlugin(mp, q, q + PF_C0 * PF_IN, q + PF_C0 * PF_IN + PF_C0, q + PF_C0 * PF_IN + PF_C0 + (size_t)PF_C1 * PF_C1, split);
     pl->pack_ = pack;
     return pl;

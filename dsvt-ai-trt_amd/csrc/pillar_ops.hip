@@ -505,9 +505,10 @@ static Plugin* mbCreate(const DsvtPluginFieldCollection* fc) {
                  fieldInt(fc, "split_output", 0));
 }
 static Plugin* mbDeser(const void* data, size_t len) {
-    if (len < 4 * sizeof(int)) return nullptr;
+    const int extra = trailingInts(len, 4 * sizeof(int), 2);
+    if (extra < 0) return nullptr;
     const char* d = static_cast<const char*>(data); int mp = rd<int>(d), c = rd<int>(d), gx = rd<int>(d), gy = rd<int>(d);
-    const int frames = len >= 5 * sizeof(int) ? rd<int>(d) : 1, split = len >= 6 * sizeof(int) ? rd<int>(d) : 0;
+    const int frames = extra >= 1 ? rd<int>(d) : 1, split = extra >= 2 ? rd<int>(d) : 0;
     return mbNew(mp, c, gx, gy, frames, split);
 }
 static Creator g_mbCreator{"Map2BevPlugin",

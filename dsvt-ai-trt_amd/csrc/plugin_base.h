@@ -126,6 +126,14 @@ inline int lastError() { hipError_t e = hipGetLastError(); return e == hipSucces
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Optional trailing int fields of a serialized plugin (appended by later rounds, older blobs stay valid): how many of them a blob of `len`
+// bytes carries after its `base` bytes, or -1 when the length is none of base, base + 4, ... base + 4 maxInts -- a padded or truncated
+// buffer is refused instead of having stray bytes read as flags.
+inline int trailingInts(size_t len, size_t base, int maxInts) {
+    if (len < base || (len - base) % sizeof(int) != 0 || (len - base) / sizeof(int) > (size_t)maxInts) return -1;
+    return (int)((len - base) / sizeof(int));
+}
+
 // Ablation / trace / A-B switches.  The product library (libdsvt_hip.so) reads NO environment variable: ablateEnv() is the constant
 // default there, so no load, store or MFMA of a timed kernel can be skipped from outside.  `python dsvt-ai-trt_amd/build.py --ablate`
 // builds libdsvt_hip_ablate.so with -DDSVT_ABLATE for tools/ (trace_*.py, ablate_conv.sh, one_attn.py ...), where the switch is read.

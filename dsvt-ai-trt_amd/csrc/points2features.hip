@@ -624,8 +624,13 @@ public:
             DSVT_CHECK(hipMemsetAsync(coords, 0, sizeof(uint32_t) * (size_t)p_.max_pillars_num * 4, stream));
             DSVT_CHECK(hipMemsetAsync(pcnt, 0, sizeof(uint32_t) * (size_t)p_.max_pillars_num, stream));
         }
-        static bool lds_set = false;                                  // 48 KB of static LDS + up to 32 KB of histogram
-        if (!lds_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(p2f_partition), hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(uint32_t) * (kMaxBins + 1)); lds_set = true; }
+        // 48 KB of static LDS + up to 32 KB of histogram: the opt-in is issued once per DEVICE (a host with several detectors, one per GPU)
+        static bool lds_set[64] = {};
+        int devId = 0; (void)hipGetDevice(&devId);
+        if (devId < 0 || devId >= 64 || !lds_set[devId]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(p2f_partition), hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(uint32_t) * (kMaxBins + 1));
+            if (devId >= 0 && devId < 64) lds_set[devId] = true;
+        }
         hipLaunchKernelGGL(p2f_partition, dim3(pl.nblk), dim3(256), sizeof(uint32_t) * (pl.nbins + 1), stream, pts, n_ptr, p_, pl,
                            tab, part_pts, part_key, part_idx, scan_state, (int)stateWords());
         hipLaunchKernelGGL(p2f_bins, dim3(pl.nbins), dim3(kBT), 0, stream, p_, pl, tab, part_key, srt, scan_state,
@@ -689,7 +694,8 @@ static Plugin* p2fCreate(const DsvtPluginFieldCollection* fc) {                 
     return validP2F(p) ? new Points2FeaturesPlugin(p) : nullptr;
 }
 static Plugin* p2fDeserialize(const void* data, size_t len) {                                      // ctor :60-84
-    if (len < 9 * sizeof(float) + 9 * sizeof(int)) return nullptr;
+    const int extra = trailingInts(len, 9 * sizeof(float) + 9 * sizeof(int), 1);
+    if (extra < 0) return nullptr;
     const char* d = static_cast<const char*>(data);
     P2FParams p{};
     p.max_points_num = rd<int>(d); p.max_points_num_voxel_filter = rd<int>(d); p.max_pillars_num = rd<int>(d);
@@ -697,7 +703,7 @@ static Plugin* p2fDeserialize(const void* data, size_t len) {                   
     p.min_x = rd<float>(d); p.max_x = rd<float>(d); p.min_y = rd<float>(d); p.max_y = rd<float>(d);
     p.min_z = rd<float>(d); p.max_z = rd<float>(d); p.vx = rd<float>(d); p.vy = rd<float>(d); p.vz = rd<float>(d);
     p.gx = rd<int>(d); p.gy = rd<int>(d); p.gz = rd<int>(d);
-    p.frames = len >= 9 * sizeof(float) + 10 * sizeof(int) ? rd<int>(d) : 1;
+    p.frames = extra >= 1 ? rd<int>(d) : 1;
     return validP2F(p) ? new Points2FeaturesPlugin(p) : nullptr;
 }
 

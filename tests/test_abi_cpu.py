@@ -81,6 +81,15 @@ def test_serialisation_layouts_match_reference(pkg):
         assert op.clone().serialize() == blob
     with pytest.raises(ValueError):
         P.Plugin.deserialize("GetSetPlugin", b"\x00" * 8)          # truncated blob
+    # optional trailing fields are recognised by the blob's exact length: a padded buffer is refused, not read as flags
+    gs7 = P.add_get_set_op(800, 576, 36, 12, 12, 1, max_set_num=1200).serialize()
+    assert len(gs7) == 28 and P.Plugin.deserialize("GetSetPlugin", gs7).serialize() == gs7
+    mb6 = P.add_map_2_bev_op(10000, 192, 468, 468, frames=2, split_output=2).serialize()
+    assert mb6 == i32(10000, 192, 468, 468, 2, 2) and P.Plugin.deserialize("Map2BevPlugin", mb6).serialize() == mb6
+    for ptype, blob in (("GetSetPlugin", gs7 + b"\0" * 4), ("GetSetPlugin", gs7[:-2]), ("Map2BevPlugin", mb6 + b"\0" * 4),
+                        ("Points2FeaturesPlugin", vg.serialize() + b"\0" * 8)):
+        with pytest.raises(ValueError):
+            P.Plugin.deserialize(ptype, blob)
 
 
 def test_output_dimensions_and_types(pkg):
@@ -160,6 +169,12 @@ def test_configure_plugin_protocol(pkg):
     assert L.dsvtPluginConfigurePlugin(op._h, ind, 2, outd, 3) == -2
     assert L.dsvtPluginConfigurePlugin(None, ind, 2, outd, 1) == -1
     assert L.dsvtPluginConfigurePlugin(op._h, None, 2, outd, 1) == -1
+    # a batch of 2 frames whose output is NOT a [2, ...] stack cannot be sliced: enqueue refuses it (-2) instead of serving frame 0 only
+    import ctypes as C
+    bad = (P.PluginTensorDesc * 1)(P._desc((16, 8), P.DT_FLOAT))
+    assert L.dsvtPluginConfigurePlugin(op._h, ind, 2, bad, 1) == 0
+    ptrs_in, ptrs_out = (C.c_void_p * 2)(1, 1), (C.c_void_p * 1)(1)          # (never dereferenced: the shape check comes first)
+    assert L.dsvtPluginEnqueue(op._h, ind, bad, ptrs_in, ptrs_out, None, None) == -2
 
 
 def test_no_cpu_path(pkg):
