@@ -13,19 +13,24 @@ reference's own: one frame at a time).  Frame-batch data parallelism: every rank
 per-frame results are gathered to rank 0 with ONE collective inside the timed region.  Rank 0 prints one JSON line.
 
 Two precision modes are timed by a default run (N = 1):
-  value / ms_per_step / p50_ms   `--dtype f16`: fp16 MFMA operands, fp32 accumulate (BASELINE configs[2] "fp16").  Boxes sit 2e-3 .. 4e-3 from
-                the fp32 oracle: OUTSIDE north_star's 1e-3.
-  parity_mode   the same frames through the split-precision pipeline (every GEMM / convolution operand a (hi, lo) fp16 pair, three MFMAs per
-                product, fp32 tensors): the reference's fp32 arithmetic, boxes within 1e-3 of the oracle -- the mode that answers
-                north_star's joint target (>= 200 frames/s AND 1e-3).  Same timing protocol, its own roofline rows.
+  value / ms_per_step / p50_ms   `--dtype split` (default, round 4): the fp32-grade mode -- every DSVT GEMM on (hi, lo) fp16 operand pairs (three
+                v_mfma_f32_16x16x32_f16 per product), the 3 x 3 convolutions as one fp16 product + two e4m3 correction products on
+                v_mfma_scale_f32_16x16x128_f8f6f4, fp32 accumulate, fp32 tensors.  The reference's arithmetic is fp32 (include/params.h:332); boxes sit
+                within 1e-3 of the fp32 oracle (measured ~5e-5): the mode that answers north_star's joint target (>= 200 frames/s AND 1e-3).
+  fast_mode     the same frames through the fp16 pipeline (BASELINE configs[2] says "fp16"): 2.2 x the frames/s, boxes 2e-3 .. 4e-3 from the oracle on
+                z / size -- OUTSIDE the 1e-3 bar, so it is reported beside the headline, not as it.
   box_err_vs_oracle (inside cpu_baseline, where the oracle runs as the checker) the maximum box error of each mode on the bench frame.
 
-Timing: K steps are timed between barrier + synchronize on both sides.  When K steps take less than half a second the K-step loop is
-repeated (`repeats`); `value` is the median repeat.  The first repeat carries the roofline sample (its first forward() runs eagerly, alone,
-with HIP events around every launch): `value_with_sample` is that repeat, `value_without_sample` the median of the others.
+Timing: K steps per repeat, every repeat between two torch.cuda.synchronize() on every rank; R = max(3, min(15, ceil(300 / K))) repeats (a function
+of K only).  Collectives: one barrier before the first repeat, the result gather inside the LAST repeat (`gather_ms`), one barrier after it, ONE
+all-reduce (MAX) of the R per-repeat times; `value` = total frames / median over the repeats of the max-over-ranks time -- the same protocol for
+every N, so N = 8 / N = 1 compares like with like.  The roofline sample (one eager forward with HIP events around every launch) is a pre-pass
+outside every timed region.
 
 Extra objects in the line:
-  single_frame_mode  (N = 1) the same kernels with ONE frame per forward and one in flight -- the reference's own mode: frames/s and p50.
+  single_frame_mode  (N = 1) the same kernels with ONE frame per forward and one in flight -- the reference's own mode: frames/s and p50, both modes.
+  host_input_mode    (N = 1) the reference's own timed bracket (src/dsvt-ai-trt.cpp:1918-1956): upload from pinned host memory + the frame + download
+                of the final boxes, one frame at a time, host clock around each frame -- the PCIe-inclusive figure, never `value`.
   roofline      the hot path's kernel with the largest share of the frame: algorithmic bytes per launch / average launch
                 duration, measured with HIP events around every launch of the sampled forward, against the 8 TB/s HBM peak of gfx950.
   roofline_other_kernels  the other kernel families, incl. the scatter / gather stages north_star names (voxelizer chain, set partition,
@@ -58,8 +63,8 @@ PEAK_F16_MATRIX_TFLOPS = 2500.0     # same guide: "Peak BF16/FP16 MFMA ~2.5 PF d
 PEAK_HBM_GBS = 8000.0               # same guide: "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured float4 copy)
 N_POINTS = 180000
 # FETCH_SIZE / WRITE_SIZE passes (profiles/), by (mode, frames per forward())
-PMC_FILES = {("f16", 1): "r02_g_batch1_pmc_traffic.json", ("f16", 2): "r02_g_pmc_traffic.json", ("f16", 4): "r03_f16_pmc_traffic.json",
-             ("split", 4): "r03_split_pmc_traffic.json"}
+PMC_FILES = {("f16", 1): "r02_g_batch1_pmc_traffic.json", ("f16", 2): "r02_g_pmc_traffic.json", ("f16", 4): "r04_f16_pmc_traffic.json",
+             ("split", 4): "r04_split_pmc_traffic.json"}
 FRAME_POOL = 4                      # distinct synthetic clouds cycled through by the steps
 MIN_TIMED_S = 0.5                   # K steps shorter than this are repeated
 MAX_REPEATS = 15
@@ -257,61 +262,66 @@ class ModeRun:
             if not ok:
                 raise SystemExit(f"bench.py: the HIP-graph replay of a frame differs from its eager run ({self.mode})")
 
-    def timed(self, results, K, prof, sample):
-        """exactly K steps (K / FB forwards) between barrier + synchronize; returns (seconds (max over ranks), per-forward ms, sampled forwards)"""
+    def sample(self, results, prof):
+        """the roofline sample: ONE forward launched op by op, alone on the GPU, with HIP events around every launch (events cannot bracket
+        kernels inside a graph replay).  A pre-pass outside every timed region, for every N (round 3 put it inside the first repeat, which
+        a one-repeat N > 1 run then carried in its only region: scaling read 3-5 % low before any real effect)."""
+        torch.cuda.synchronize()
+        self.pkg.plugin.PROFILE = prof
+        with torch.cuda.stream(self.streams[0]):
+            self.run_frame(0, results[0:self.FB], eager=True)
+        torch.cuda.synchronize()
+        self.pkg.plugin.PROFILE = None
+        return 1
+
+    def timed(self, results, K, gather):
+        """exactly K steps (K / FB forwards), timed on THIS rank between two stream synchronisations; no collective inside unless `gather`
+        (the last repeat: the path's one collective, the result gather).  Returns (seconds, per-forward ms, gathered rows, gather ms)."""
         par, FB, NS = self.par, self.FB, self.NS
         KB = K // FB
         marks = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(KB)]
-        par.barrier(); torch.cuda.synchronize()
-        sampled = 0
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(KB):
-            # roofline sample: the FIRST forward of a sampled repeat is launched op by op, alone on the GPU, with HIP events around each
-            # launch (events cannot bracket kernels inside a graph replay); nothing is in flight yet, so it drains no other stream
-            ev = sample and prof is not None and (not self.use_graph or i == 0)
-            if ev and (self.use_graph or NS > 1):
-                torch.cuda.synchronize()
-            self.pkg.plugin.PROFILE = prof if ev else None
             with torch.cuda.stream(self.streams[i % NS]):
                 marks[i][0].record()
-                self.run_frame(i, results[i * FB:(i + 1) * FB], eager=ev)
+                self.run_frame(i, results[i * FB:(i + 1) * FB])
                 marks[i][1].record()
-            if ev and (self.use_graph or NS > 1):
-                torch.cuda.synchronize()
-            sampled += ev
         for s in self.streams:
             torch.cuda.current_stream().wait_stream(s)
-        gathered = par.gather_results(results, K * self.world, self.rank, self.world, force_collective=self.args.rccl_single)   # the one collective of the path
-        par.barrier(); torch.cuda.synchronize()
+        gathered, gather_ms = None, None
+        if gather:
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            gathered = par.gather_results(results, K * self.world, self.rank, self.world, force_collective=self.args.rccl_single)
+            torch.cuda.synchronize()
+            gather_ms = 1e3 * (time.perf_counter() - tg)
+        torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        self.pkg.plugin.PROFILE = None
-        dt = par.max_over_ranks(dt, self.dev)
         frame_ms = [marks[i][0].elapsed_time(marks[i][1]) for i in range(KB)]
-        return dt, frame_ms, sampled, gathered
+        return dt, frame_ms, gathered, gather_ms
 
-    def measure(self, results, K, prof):
-        """repeat the K-step loop until MIN_TIMED_S is covered; the first repeat carries the roofline sample"""
-        dt0, fm0, sampled, gathered = self.timed(results, K, prof, sample=True)
-        dts, fms = [dt0], []
-        R = 1 if dt0 >= MIN_TIMED_S else min(MAX_REPEATS, max(3, int(np.ceil(MIN_TIMED_S / dt0))))
-        if self.collective:
-            # ONE timed region when a communicator exists (N > 1, or --rccl-single): measured on this stack (ROCm 7.2, RCCL of torch 2.10), a
-            # third barrier / gather / barrier / all-reduce round interleaved with HIP-graph replays hangs (one stream) or faults (two) --
-            # `--rccl-single --repeats 3`; one or two rounds, round 2's protocol, are fine.  The N = 1 line without a communicator -- the
-            # one a short --steps makes noisy -- repeats.
-            R = 1
-        if self.args.repeats > 0:
-            R = self.args.repeats
-        for _ in range(1, R):
-            dt, frame_ms, _sm, g = self.timed(results, K, prof, sample=False)
+    def measure(self, results, K):
+        """R repeats of the K-step loop, the same R on every rank (it depends on K only).  Collectives: one barrier before the first repeat, the
+        result gather inside the LAST repeat, one barrier after it, then ONE all-reduce (MAX) of the R-vector of per-repeat times -- two
+        collective rounds however many repeats, because on this stack (ROCm 7.2, RCCL 2.26 of torch 2.10) a third barrier / gather / barrier /
+        all-reduce round interleaved with HIP-graph replays ends in "Memory access fault ... write access to a read-only page" (DESIGN 5).
+        Every repeat is bracketed by torch.cuda.synchronize() on both sides; value = median over the repeats of total frames / max-over-ranks time."""
+        R = self.args.repeats if self.args.repeats > 0 else max(3, min(MAX_REPEATS, -(-300 // K)))
+        self.par.barrier(); torch.cuda.synchronize()
+        dts, fms, gathered, gather_ms = [], [], None, None
+        for r in range(R):
+            last = r == R - 1
+            dt, frame_ms, g, gm = self.timed(results, K, gather=last)
             dts.append(dt); fms.extend(frame_ms)
-            gathered = g if g is not None else gathered
-        if not fms:
-            fms = fm0
-        return dts, fms, sampled, gathered
+            if last:
+                gathered, gather_ms = g, gm
+        self.par.barrier(); torch.cuda.synchronize()
+        dts = self.par.max_over_ranks_vec(dts, self.dev)
+        return dts, fms, gathered, gather_ms
 
 
-def roofline_rows(prof, sampled, counts, pool_len, FB, mode, n_points_per_launch):
+def roofline_rows(prof, sampled, counts, pool_len, FB, mode, n_points_per_launch, head_mx=False):
     """per plugin family: algorithmic work per launch (SURVEY 8d formulas) / measured launch duration"""
     f16, split = mode == "f16", mode == "split"
     pm = {}
@@ -320,9 +330,17 @@ def roofline_rows(prof, sampled, counts, pool_len, FB, mode, n_points_per_launch
     except Exception:
         pass
 
-    def pmc_traffic(substr):
-        ks = [k for k in pm if substr in k]
-        return round(pm[ks[0]]["traffic_mb_per_launch"] * 1e6) if ks else None
+    def pmc_traffic(substrs, chain):
+        """HBM bytes per plugin enqueue from the PMC passes, over ALL kernels of the family (round 3 took the first match).  chain: every kernel of
+        the family runs once per enqueue (voxelizer, set partition) -> the sum of their per-launch means; otherwise the enqueue launches ONE of
+        several instantiations (convolutions, linears) -> the launch-weighted mean."""
+        ks = [k for k in pm if any(x in k for x in substrs)]
+        if not ks:
+            return None
+        if chain:
+            return round(sum(pm[k]["traffic_mb_per_launch"] for k in ks) * 1e6)
+        n = sum(pm[k]["launches"] for k in ks)
+        return round(sum(pm[k]["traffic_mb_per_launch"] * pm[k]["launches"] for k in ks) / max(n, 1) * 1e6)
 
     def work(pl, c):
         """(flops, algorithmic HBM bytes) of one launch of plugin `pl` on a forward with counts c"""
@@ -378,25 +396,35 @@ def roofline_rows(prof, sampled, counts, pool_len, FB, mode, n_points_per_launch
                 "linear_f16_rows_kernel (QKV: all column chunks of a row tile per workgroup, v_mfma_f32_16x16x32_f16, weights by LDS-DMA)" if f16 else
                 "linear_f32_kernel (v_mfma_f32_16x16x4_f32)")
     sp_ = " <SPLIT>: (hi, lo) fp16 operand pairs, fp32 tensors" if split else ""
+    # matrix peak of one fp32-grade product: three fp16 MFMAs (2.5 PF / 3), or on the fp16 + fp8 K loop one fp16 MFMA + two e4m3 products at the
+    # 5 PF dense MX-fp8 rate with ten tap slots for nine taps: 2.5 PF / (1 + 2 (10 / 9) / 2)
+    PEAK_SPLIT3, PEAK_MX = PEAK_F16_MATRIX_TFLOPS / 3.0, PEAK_F16_MATRIX_TFLOPS / (1.0 + 10.0 / 9.0)
     meta = {"DsvtLinearPlugin": (qkv_name, "mfma" if mode == "f32" else "hbm", "linear_split_rows_kernel" if split else "linear_f16_resident_kernel" if resident_qkv else "linear_f16_rows_kernel" if f16 else "linear_f32_kernel<true>"),
             "DsvtEncoderMlpPlugin": ("encoder_mlp_stream_kernel (out-proj+LN -> FC1+GELU -> FC2+LN+LN, v_mfma_f32_16x16x32_f16, weights by LDS-DMA)" + sp_, "hbm", "encoder_mlp_stream_kernel"),
-            "DsvtSetAttentionPlugin": ("set_attention_f16_kernel (v_mfma_f32_16x16x32_f16)" if f16 else "set_attention_kernel (v_mfma_f32_16x16x4_f32, fp32 I/O)", "hbm",
-                                       "set_attention_f16_kernel" if f16 else "set_attention_kernel"),
+            "DsvtSetAttentionPlugin": ("set_attention_f16_kernel (v_mfma_f32_16x16x32_f16)" if f16 else
+                                       "set_attention_split_kernel ((hi, lo) images of Q, K, V^T in LDS, 3 x v_mfma_f32_16x16x32_f16 per product, fp32 I/O)" if split else
+                                       "set_attention_kernel (v_mfma_f32_16x16x4_f32, fp32 I/O)", "hbm",
+                                       "set_attention_f16_kernel" if f16 else "set_attention_split_kernel" if split else "set_attention_kernel("),
             "DsvtPosEmbedPlugin": ("posembed_batched_kernel (8 position-embedding MLPs, v_mfma_f32_16x16x32_f16)", "hbm", "posembed_batched_kernel"),
             "DsvtPillarFeatureNetPlugin": ("pfn_kernel (both PFN layers + scatter-max, v_mfma_f32_16x16x4_f32 + 16x16x32_f16; peak = the mix of the two matrix rates; the kernel is bound by the round trips of its 16-pillar groups, not by either)" + sp_, "mfma", "pfn_kernel"),
-            "DsvtConv2dPlugin": ("conv_wide_kernel / conv_halo_kernel / conv_f16_kernel (implicit GEMM, v_mfma_f32_16x16x32_f16)" + (" on [hi | lo | hi] x [w_hi | w_hi | w_lo]: three MFMAs per fp32-grade product" if split else ""), "mfma", "conv_wide_kernelILi8ELi8"),
-            "Points2FeaturesPlugin": ("p2f_partition -> p2f_bins -> p2f_pillar: the voxelizer, SURVEY 8a-1", "hbm", "p2f_"),
-            "DsvtSetPartitionPlugin": ("sp_count -> sp_scan -> sp_scatter -> sp_window (+ one memset): WindowPartition + GetSet of both window configurations, SURVEY 8a-3/4", "hbm", "sp_"),
+            "DsvtConv2dPlugin": ("conv_wide_kernel / conv_halo_kernel / conv_f16_kernel (implicit GEMM, v_mfma_f32_16x16x32_f16)" +
+                                 (" -- 3 x 3 stride-1 layers with > 32 output channels (93 % of the products) on the fp16 + fp8 K loop over [hi | x8]: one fp16 MFMA product + "
+                                  "two e4m3 correction products (v_mfma_scale_f32_16x16x128_f8f6f4) per fp32-grade product; the other layers walk [hi | lo | hi] x "
+                                  "[w_hi | w_hi | w_lo], three fp16 MFMAs per product; peak = the launch-weighted mix of the two" if (split and head_mx) else
+                                  " on [hi | lo | hi] x [w_hi | w_hi | w_lo]: three MFMAs per fp32-grade product" if split else ""), "mfma", "conv"),
+            "Points2FeaturesPlugin": ("p2f_partition -> p2f_bins -> p2f_pillar: the voxelizer, SURVEY 8a-1", "hbm", "dsvt::p2f_"),
+            "DsvtSetPartitionPlugin": ("sp_count -> sp_scan -> sp_scatter -> sp_window (+ one memset): WindowPartition + GetSet of both window configurations, SURVEY 8a-3/4", "hbm", ("dsvt::sp_", "sp_window")),
             "Map2BevPlugin": ("map2bev_kernel + the zero fill of the dense map (plugins/src/map2bev.cu:250-310)", "hbm", "map2bev")}
     rows_out = []
     for ptype, lst in prof.items():
         if not lst or ptype not in meta:
             continue
         per_frame = len(lst) // sampled
-        tot_ms = tot_fl = tot_by = 0.0
+        tot_ms = tot_fl = tot_by = tot_peak_s = 0.0
         for j, (e0, e1, pl) in enumerate(lst):
             fl, by = work(pl, counts[(j // per_frame) % pool_len])
             tot_ms += e0.elapsed_time(e1); tot_fl += fl; tot_by += by
+            tot_peak_s += fl / 1e12 / (PEAK_MX if getattr(pl, "mx_in", False) else PEAK_SPLIT3)       # (the split convolutions' matrix-peak time)
         n_l = len(lst)
         avg_ms = tot_ms / n_l
         tfl, gbs = tot_fl / n_l / (avg_ms * 1e-3) / 1e12, tot_by / n_l / (avg_ms * 1e-3) / 1e9
@@ -409,16 +437,22 @@ def roofline_rows(prof, sampled, counts, pool_len, FB, mode, n_points_per_launch
             # made a latency-bound kernel look MFMA-bound.)
             f32_part = 10.0 / (10.0 + 192.0)
             peak_tf = 1.0 / (f32_part / PEAK_F32_MATRIX_TFLOPS + (1.0 - f32_part) / (PEAK_F16_MATRIX_TFLOPS / (3 if split else 1)))
+        if split and ptype == "DsvtConv2dPlugin" and tot_peak_s > 0:
+            peak_tf = tot_fl / 1e12 / tot_peak_s
         r = dict(kernel=kname, bound=bound)
         if bound == "hbm":
             r.update(achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4))
             if tfl:
                 r["mfma_tflops"] = round(tfl, 2)
+                # north_star asks for the MFMA utilisation of the attention GEMMs against the gfx950 peak: algorithmic flops / the peak of the arithmetic
+                mp = PEAK_F32_MATRIX_TFLOPS if mode == "f32" else PEAK_SPLIT3 if split else PEAK_F16_MATRIX_TFLOPS
+                r["mfma_frac_of_peak"] = round(tfl / mp, 4); r["mfma_peak_tflops"] = round(mp, 1)
         else:
             r.update(achieved=round(tfl, 2), peak=round(peak_tf, 1), unit="TFLOP/s", frac=round(tfl / peak_tf, 4), hbm_gbs=round(gbs, 1))
-            if split and ptype == "DsvtConv2dPlugin":
+            if split and ptype == "DsvtConv2dPlugin" and not head_mx:
                 r["mfma_issue_tflops"] = round(3 * tfl, 1)
-        r.update(traffic=pmc_traffic(pmk), launches_per_frame=per_frame, sampled_frames=sampled, avg_launch_us=round(1e3 * avg_ms, 2),
+        chain = ptype in ("Points2FeaturesPlugin", "DsvtSetPartitionPlugin")
+        r.update(traffic=pmc_traffic([pmk] if isinstance(pmk, str) else list(pmk), chain), launches_per_frame=per_frame, sampled_frames=sampled, avg_launch_us=round(1e3 * avg_ms, 2),
                  ms_per_forward=round(tot_ms / sampled, 3), algorithmic_mb_per_launch=round(tot_by / n_l / 1e6, 2))
         if tot_fl:
             r["algorithmic_gflop_per_launch"] = round(tot_fl / n_l / 1e9, 3)
@@ -434,10 +468,11 @@ def main():
     ap.add_argument("--steps", type=int, default=240)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--points", type=int, default=N_POINTS)
-    ap.add_argument("--dtype", choices=["f32", "f16", "split"], default="f16",
-                    help="precision of the headline value.  f16: fp16 MFMA operands / fp16 dense head, fp32 accumulate + LayerNorm/softmax/decode "
-                         "(BASELINE configs[2]); split: (hi, lo) fp16 operand pairs, fp32 tensors (fp32 grade: boxes within 1e-3; also timed as "
-                         "`parity_mode` beside an f16 headline); f32: v_mfma_f32_16x16x4_f32 linears, the slow exact cross-check")
+    ap.add_argument("--dtype", choices=["f32", "f16", "split"], default="split",
+                    help="precision of the headline value.  split (default): (hi, lo) fp16 operand pairs on the DSVT GEMMs, fp16 + fp8 correction "
+                         "products in the convolutions, fp32 tensors -- fp32 grade, boxes within 1e-3 of the oracle (north_star's bar); f16: fp16 MFMA "
+                         "operands / fp16 dense head, fp32 accumulate (BASELINE configs[2] says fp16, but its boxes miss the 1e-3 bar on z / size: timed as "
+                         "`fast_mode` beside the headline); f32: v_mfma_f32_16x16x4_f32 linears, the slow exact cross-check")
     ap.add_argument("--streams", type=int, default=2,
                     help="forwards in flight per GPU: independent pipeline instances on separate HIP streams")
     ap.add_argument("--batch", type=int, default=4,
@@ -445,7 +480,7 @@ def main():
                          "(DsvtPipeline(frames=B)); a step is still one frame, --steps must be a multiple of B")
     ap.add_argument("--no-graph", action="store_true", help="launch every op from the host instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-parity-mode", action="store_true", help="skip the split-precision run that follows an f16 headline (N = 1 only)")
+    ap.add_argument("--no-parity-mode", "--no-fast-mode", dest="no_fast_mode", action="store_true", help="skip the run of the OTHER precision mode (fp16 beside a split headline) that follows the headline (N = 1 only)")
     ap.add_argument("--no-latency-mode", action="store_true", help="skip the single-frame-mode measurement (N = 1 only) that follows the timed region")
     ap.add_argument("--host-input", action="store_true", help="frames start in pinned host memory and are uploaded (n x 16 B) inside the timed region: the PCIe-inclusive rate quoted in DESIGN.md, never the headline value")
     ap.add_argument("--no-nms", action="store_true", help="stop at FilterBoxByScore (the reference engine's output) instead of the final boxes")
@@ -454,7 +489,7 @@ def main():
                                                                "really goes through RCCL (SURVEY 8e: exercising the collective on one device)")
     ap.add_argument("--share-gpu", action="store_true", help="N > visible GPUs: rank r uses GPU r mod visible (a launcher / RCCL dry run on one device; "
                                                              "the line is marked and is NOT a scaling number)")
-    ap.add_argument("--repeats", type=int, default=0, help="repeats of the K-step timed loop (0 = as many as cover half a second, at least 3 when one is shorter than that)")
+    ap.add_argument("--repeats", type=int, default=0, help="repeats of the K-step timed loop (0 = max(3, min(15, ceil(300 / K))): a function of K only, so every rank runs the same number)")
     ap.add_argument("--dump-rows", default=None, help="rank 0 saves the gathered result rows [K * N, 4501] of the headline mode as .npy (tests: the gather against single-process rows)")
     ap.add_argument("--no-whole-network-cpu", action="store_true", help="cpu_baseline skips the whole network on the CPU oracle (~10 s; also drops box_err_vs_oracle)")
     args = ap.parse_args()
@@ -534,7 +569,8 @@ def main():
         # communicator, as much as 23 frames), which is start-up cost, not a property of the frame path
         if world > 1 or args.rccl_single:
             par.gather_results(results, K * world, rank, world, force_collective=args.rccl_single)
-        dts, frame_ms, sampled, gathered = run.measure(results, K, prof)
+        sampled = run.sample(results, prof) if prof is not None else 0
+        dts, frame_ms, gathered, gather_ms = run.measure(results, K)
         if rank != 0:
             return None
         total = K * world
@@ -543,16 +579,15 @@ def main():
         if args.dump_rows and mode == args.dtype:
             np.save(args.dump_rows, gathered.cpu().numpy())
         med = float(np.median(dts))
-        rest = dts[1:] if (sampled and len(dts) > 1) else dts
         out = dict(value=round(total / med, 3), ms_per_step=round(1e3 * med / K, 4), p50_ms=round(float(np.median(frame_ms)), 4), repeats=len(dts),
                    repeat_values=[round(total / d, 1) for d in dts],
-                   value_with_sample=round(total / dts[0], 3) if sampled else None,
-                   value_without_sample=round(total / float(np.median(rest)), 3),
+                   gather_ms=None if gather_ms is None or not run.collective else round(gather_ms, 3),
+                   value_of_the_repeat_with_the_gather=round(total / dts[-1], 3),
                    graph_replay_equals_eager=run.replay_equals_eager, frame0=counts[0])
         out["_run"] = run
         if prof is not None and sampled:
             npl = sum(int(v) for v in pool[0][1].cpu())
-            rows = roofline_rows(prof, sampled, counts, len(pool), FB, mode, npl)
+            rows = roofline_rows(prof, sampled, counts, len(pool), FB, mode, npl, head_mx=bool(getattr(run.pipes[0], "head_mx", False)))
             # the headline roofline object = the hot path's kernel with the largest share of the frame
             hot = [x for x in rows if x[0] not in ("DsvtConv2dPlugin", "Points2FeaturesPlugin", "DsvtSetPartitionPlugin", "Map2BevPlugin")] or rows
             top = max(hot, key=lambda x: x[1]["ms_per_forward"])[1]
@@ -569,10 +604,14 @@ def main():
             "metric": "frames/sec (p50 per-frame ms in p50_ms), 180k-pt Waymo pillar DSVT",
             "value": head["value"], "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"], "p50_ms": head["p50_ms"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"f16": "f16", "split": "f16x3 (split-precision fp16 MFMA, fp32 grade)", "f32": "f32"}[args.dtype],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"f16": "f16 (fp16 MFMA operands, fp32 accumulate: boxes OUTSIDE the 1e-3 bar on z / size)",
+                      "split": "f16x3 + fp8 (fp32 grade: (hi, lo) fp16 operand pairs, three v_mfma_f32_16x16x32_f16 per product in the DSVT GEMMs; "
+                               "fp16 product + two e4m3 correction products on v_mfma_scale_f32_16x16x128_f8f6f4 in the 3 x 3 convolutions; fp32 accumulate; "
+                               "boxes within 1e-3 of the fp32 oracle: cpu_baseline.box_err_vs_oracle.split)", "f32": "f32"}[args.dtype],
             "data": "synthetic" + (" (uploaded from pinned host memory inside the timed region)" if args.host_input else ""),
-            "repeats": head["repeats"], "repeat_values": head["repeat_values"], "value_with_sample": head["value_with_sample"],
-            "value_without_sample": head["value_without_sample"],
+            "repeats": head["repeats"], "repeat_values": head["repeat_values"], "gather_ms": head["gather_ms"],
+            "value_of_the_repeat_with_the_gather": head["value_of_the_repeat_with_the_gather"],
             "config": {"workload": f"BASELINE configs[2]: lidar_like({args.points}, seed) Waymo-shaped cloud, 0.32 m pillars, "
                                    "468x468 BEV, full 4-block DSVT pillar backbone + BEV ResNet + CenterHead + top-K decode + "
                                    "FilterBoxByScore" + ("" if args.no_nms else " + rotated NMS (final boxes)") + "; seeded random weights (dsvt.wts is not shipped)",
@@ -585,8 +624,9 @@ def main():
                        "graph_replay_equals_eager": head["graph_replay_equals_eager"],
                        "launch": "hip-graph replay per forward" if not args.no_graph else "host launch per op",
                        "frames_in_flight": run.NS * FB, "frames_per_forward": FB,
-                       "timing": f"K = {K} steps per repeat between barrier + synchronize; value = median of `repeats` repeats; repeat 0 carries the roofline sample"
-                                 + ("; ONE repeat when a communicator exists (RCCL rounds interleaved with graph replays beyond two hang on this stack)" if run.collective else ""),
+                       "timing": f"K = {K} steps per repeat, each repeat between two torch.cuda.synchronize() on every rank; one barrier before the first repeat, "
+                                 "the result gather inside the LAST repeat (gather_ms), one barrier after it, ONE all-reduce (MAX) of the per-repeat times; "
+                                 "value = total frames / median over repeats of the max-over-ranks time; the roofline sample is a pre-pass outside every timed region",
                        "caps": dict(points=caps.N, pillars=caps.P, windows=caps.W, sets=caps.S, overflow_free=caps.overflow_free()),
                        "frame0": head["frame0"]},
             "roofline": head["roofline"],
@@ -611,22 +651,28 @@ def main():
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
             fb_rows(run, args.dtype)
-        if args.dtype == "f16" and not args.no_parity_mode and not args.host_input:
-            # north_star's joint target: >= 200 frames/s AND boxes within 1e-3.  Same frames, same protocol, split-precision kernels.
-            pm = run_mode("split")
+        other = {"split": "f16", "f16": "split"}.get(args.dtype)
+        if other and not args.no_fast_mode and not args.host_input:
+            # the OTHER precision mode on the same frames with the same protocol.  Beside the default (split) headline: `fast_mode`, the fp16 frame
+            # BASELINE configs[2] names -- 2.2 x the frames/s, but its boxes sit 2e-3 .. 4e-3 from the fp32 oracle on z / size, outside north_star's
+            # 1e-3 (cpu_baseline.box_err_vs_oracle.f16), so it is reported, not claimed.  Beside an f16 headline: `parity_mode`, as in rounds 1-3.
+            pm = run_mode(other)
             prun = pm.pop("_run")
             if not args.no_cpu_baseline:
-                fb_rows(prun, "split")
-            line["parity_mode"] = dict(
-                dtype="f16x3: every GEMM / convolution operand a (hi, lo) fp16 pair, three v_mfma_f32_16x16x32_f16 per product, fp32 accumulate, fp32 tensors "
-                      "between the DSVT kernels, [hi | lo | hi] fp16 triples between the convolutions (the reference's arithmetic is fp32: include/params.h:332)",
+                fb_rows(prun, other)
+            key = "fast_mode" if other == "f16" else "parity_mode"
+            line[key] = dict(
+                dtype=("f16: fp16 MFMA operands / fp16 BEV maps, fp32 accumulate + LayerNorm / softmax / box decode (BASELINE configs[2] 'fp16'; the reference's "
+                       "own arithmetic is fp32: include/params.h:332)" if other == "f16" else
+                       "f16x3 + fp8: the fp32-grade mode (see --dtype split)"),
                 value=pm["value"], unit="frames/s", ms_per_step=pm["ms_per_step"], p50_ms=pm["p50_ms"], repeats=pm["repeats"], repeat_values=pm["repeat_values"],
-                value_with_sample=pm["value_with_sample"], value_without_sample=pm["value_without_sample"], frames_per_forward=FB, frames_in_flight=prun.NS * FB,
+                frames_per_forward=FB, frames_in_flight=prun.NS * FB,
                 graph_replay_equals_eager=pm["graph_replay_equals_eager"], roofline=pm["roofline"], roofline_other_kernels=pm["roofline_other_kernels"],
-                note="boxes within 1e-3 of the fp32 oracle (cpu_baseline.box_err_vs_oracle.split; tests/test_split_kernels_gpu.py::test_boxes_split_mode): "
-                     "north_star's target is >= 200 frames/s AND 1e-3, which the f16 headline does not meet on z / size")
+                note=("OUT OF TOLERANCE: boxes 2e-3 (z) .. 3.5e-3 (size) from the fp32 oracle (cpu_baseline.box_err_vs_oracle.f16; every one of ~60 fp16 rounding "
+                      "sites adds ~4e-4, DESIGN 2) -- north_star's bar is 1e-3, which only the headline mode meets" if other == "f16" else
+                      "boxes within 1e-3 of the fp32 oracle (cpu_baseline.box_err_vs_oracle.split)"))
             del prun, pm
-        if FB > 1 and not args.no_latency_mode and args.dtype == "f16":
+        if FB > 1 and not args.no_latency_mode and args.dtype in ("f16", "split"):
             # the reference's own mode beside the headline: ONE frame per forward, one in flight (graph replay), same clouds --
             # what a caller who wants latency, not throughput, gets from the same kernels; measured after the timed region
             c1 = pkg.pipeline.Caps()
@@ -635,8 +681,10 @@ def main():
                 b1 = np.zeros((1, c1.N, 4), np.float32); b1[0, :cl.shape[0]] = cl
                 one.append((torch.from_numpy(b1).to(dev), torch.tensor([cl.shape[0]], dtype=torch.int32, device=dev)))
             line["single_frame_mode"] = {"frames_per_forward": 1, "frames_in_flight": 1,
-                                         "note": "same kernels, one frame at a time (the reference's mode); not the headline value"}
-            for tag, kw1 in (("f16", dict(linear_compute=pkg.plugin.COMPUTE_F16, head_dtype=torch.float16)), ("split", dict(linear_compute=pkg.plugin.COMPUTE_SPLIT))):
+                                         "note": "same kernels, one frame at a time (the reference's mode, src/dsvt-ai-trt.cpp:1884-1956; BASELINE.md: >= 200 frames/s, <= 5 ms p50); "
+                                                 "top-level value / p50_ms of this object = the split (fp32-grade) mode"}
+            KL = 64
+            for tag, kw1 in (("split", dict(linear_compute=pkg.plugin.COMPUTE_SPLIT)), ("f16", dict(linear_compute=pkg.plugin.COMPUTE_F16, head_dtype=torch.float16))):
                 p1 = pkg.pipeline.DsvtPipeline(weights, caps=c1, device=dev, device_nms=not args.no_nms, **kw1)
                 sin = (torch.zeros_like(one[0][0]), torch.zeros_like(one[0][1]))
                 for pts1, n1 in one[:2]:
@@ -644,7 +692,6 @@ def main():
                 torch.cuda.synchronize()
                 sin[0].copy_(one[0][0]); sin[1].copy_(one[0][1])
                 p1.capture(*sin)
-                KL = 64
                 ev1 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(KL)]
                 for i in range(-8, KL):
                     pts1, n1 = one[i % len(one)]
@@ -660,8 +707,30 @@ def main():
                 dl = time.perf_counter() - tl0
                 line["single_frame_mode"][tag] = {"frames": KL, "value": round(KL / dl, 1), "unit": "frames/s",
                                                   "p50_ms": round(float(np.median([a.elapsed_time(b) for a, b in ev1])), 4)}
+                if tag == "split":
+                    # the reference's timed bracket (src/dsvt-ai-trt.cpp:1918-1956): H2D of the frame + enqueue + D2H of the result + NMS, one frame at a
+                    # time, synchronously.  The points wait in pinned host memory (n x 16 bytes cross PCIe, not the zero-padded cap the reference
+                    # copies), the final boxes + count come back to pinned host memory; the host clock brackets each frame.  Never the headline value.
+                    hp = [(p_[0, :int(n_[0])].cpu().pin_memory(), n_.cpu().pin_memory(), int(n_[0])) for p_, n_ in one]
+                    gb, gc = p1.graph_out
+                    hb, hc = torch.empty(gb.shape, dtype=gb.dtype).pin_memory(), torch.empty(gc.shape, dtype=gc.dtype).pin_memory()
+                    lat = []
+                    for i in range(-8, KL):
+                        h_pts, h_n, k_ = hp[i % len(hp)]
+                        torch.cuda.synchronize(); th = time.perf_counter()
+                        sin[0][0, :k_].copy_(h_pts, non_blocking=True); sin[1].copy_(h_n, non_blocking=True)
+                        p1.replay()
+                        hb.copy_(gb, non_blocking=True); hc.copy_(gc, non_blocking=True)
+                        torch.cuda.synchronize()
+                        if i >= 0:
+                            lat.append(1e3 * (time.perf_counter() - th))
+                    line["host_input_mode"] = {"dtype": "split (fp32 grade)", "frames": KL, "value": round(1e3 * len(lat) / sum(lat), 1), "unit": "frames/s",
+                                               "p50_ms": round(float(np.median(lat)), 4), "pcie_bytes_per_frame": int(np.mean([h[2] for h in hp])) * 16 + 4 + gb.numel() * 4 + 4,
+                                               "note": "the reference's own bracket: upload of the frame's points from pinned host memory + graph replay (network + decode + "
+                                                       "FilterBoxByScore + device NMS) + download of the final boxes, one frame at a time, host clock around each frame "
+                                                       "(src/dsvt-ai-trt.cpp:1918-1956); the PCIe-inclusive figure, never `value`"}
                 del p1
-            line["single_frame_mode"].update(value=line["single_frame_mode"]["f16"]["value"], unit="frames/s", p50_ms=line["single_frame_mode"]["f16"]["p50_ms"])
+            line["single_frame_mode"].update(value=line["single_frame_mode"]["split"]["value"], unit="frames/s", p50_ms=line["single_frame_mode"]["split"]["p50_ms"])
         if not args.no_cpu_baseline:
             # the FilterBoxByScore rows of the pooled frames as the GPU produced them (the reference's D2H payload)
             frames = []

@@ -90,3 +90,12 @@ def max_over_ranks(value, device):
     t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t[0])
+
+
+def max_over_ranks_vec(values, device):
+    """element-wise maximum over the ranks of a list of floats: ONE all-reduce (bench.py: the per-repeat times of a run)"""
+    if not dist.is_initialized():
+        return list(values)
+    t = torch.tensor(list(values), dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t]

@@ -29,15 +29,25 @@ def test_bench_refuses_more_gpus_than_visible():
     assert "visible" in (r.stderr + r.stdout)
 
 
-def test_bench_single_rank_collective_line():
-    """bench.py --rccl-single: N = 1 with a size-1 RCCL communicator; the gather is inside the timed region and the line says so"""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--rccl-single",
-                        "--no-cpu-baseline", "--no-kernel-events"], capture_output=True, text=True, timeout=900)
+def _bench_line(extra, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-kernel-events",
+                        "--no-fast-mode", "--no-latency-mode"] + extra, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_single_rank_collective_line():
+    """bench.py --rccl-single: N = 1 with a size-1 RCCL communicator.  The timing protocol is the one an N > 1 run uses (round 4): R >= 3 repeats
+    with no collective between them, the gather inside the last repeat, one all-reduce of the R-vector -- so the line has repeats >= 3 and a
+    gather_ms, and its value agrees with the communicator-free N = 1 line (a one-repeat region with the roofline sample inside, round 3's
+    protocol, read 3-5 % low: the bias an N = 8 / N = 1 ratio would have carried)."""
+    line = _bench_line(["--rccl-single"])
     assert line["n_gpus"] == 1 and line["config"]["result_gather"] == "rccl gather (communicator of size 1)"
     assert line["config"]["graph_replay_equals_eager"] is True
-    assert line["value"] > 0
+    assert line["repeats"] >= 3 and len(line["repeat_values"]) == line["repeats"] and line["gather_ms"] is not None and line["gather_ms"] < 5.0
+    plain = _bench_line([])
+    assert plain["repeats"] == line["repeats"] and plain["gather_ms"] is None
+    assert abs(line["value"] / plain["value"] - 1.0) < 0.02, (line["value"], plain["value"], line["repeat_values"], plain["repeat_values"])
 
 
 def test_bench_two_ranks_sharing_the_gpu_gather_the_right_rows(pkg, tmp_path):
@@ -52,8 +62,8 @@ def test_bench_two_ranks_sharing_the_gpu_gather_the_right_rows(pkg, tmp_path):
     dump = str(tmp_path / "rows.npy")
     # (--no-graph: two PROCESSES replaying HIP graphs on one device fault on this stack -- "Memory access fault by GPU node", with one
     # stream or two, ROCm 7.2; host-launched kernels from two processes are fine.  Not a configuration the product runs in: one process per GPU.)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--no-graph", "--steps", "8", "--warmup", "2",
-           "--no-cpu-baseline", "--no-kernel-events", "--no-parity-mode", "--no-latency-mode", "--dump-rows", dump]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--no-graph", "--steps", "8", "--warmup", "2", "--dtype", "f16",
+           "--no-cpu-baseline", "--no-kernel-events", "--no-fast-mode", "--no-latency-mode", "--dump-rows", dump]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
     if r.returncode != 0 and "Memory access fault by GPU" in r.stderr:
         # two processes on ONE device: the platform's "Memory access fault" (with graph replays every time, with host launches seen once;
@@ -68,6 +78,7 @@ def test_bench_two_ranks_sharing_the_gpu_gather_the_right_rows(pkg, tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and "DRY RUN" in line["metric"] and "NOT a scaling number" in line["config"]["shared_gpu"]
+    assert line["repeats"] >= 3 and line["gather_ms"] is not None          # (the N > 1 protocol: repeats without a collective between them)
     assert line["config"]["result_gather"].startswith("gloo gather") and line["config"]["frames_per_forward"] == 4
     got = np.load(dump)
     assert got.shape == (16, 4501)
