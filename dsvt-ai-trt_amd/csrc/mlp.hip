@@ -135,7 +135,7 @@ struct MlpStreamArgs {
     const uint32_t* count; int max_rows; float eps;
     unsigned long long* trace;                       // debugging: per-workgroup phase timestamps, or nullptr
     int ncu;                                         // CUs of the device (tile plan, see the kernel)
-    int dbg;                                         // timing ablations (wrong results): 1 no LN1, 2 no GELU, 4 no final LNs, 8 no stores, 16 no MFMA
+    int dbg;                                         // timing ablations (wrong results): 1 no LN1, 2 no GELU, 4 no final LNs, 8 no stores, 16 (SPLIT) no correction-term MFMAs, 64 no weight DMA
     int sel, thr;                                    // 0: run; 1: run only when the row count is > thr; 2: only when it is <= thr (see enqueue)
 };
 
@@ -275,6 +275,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
             }
             return;
         }
+        if (a.dbg & 64) return;
 #pragma unroll
         for (int j = 0; j < (SR + NW - 1) / NW; ++j) {
             const int rw = wave + j * NW;
@@ -388,7 +389,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
 #pragma unroll
             for (int t = 0; t < PQT; ++t) {
                 const half8 wf = *reinterpret_cast<const half8*>(sl + (ks * PQT + t) * 1024);
-                if constexpr (SPLIT) {
+                if (SPLIT && !(a.dbg & 16)) {
                     const half8 wl = *reinterpret_cast<const half8*>(sl + LO + (ks * PQT + t) * 1024);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
@@ -439,7 +440,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
 #pragma unroll
             for (int t = 0; t < PQT; ++t) {
                 const half8 wf = *reinterpret_cast<const half8*>(slotA + (ks * PQT + t) * 1024);
-                if constexpr (SPLIT) {
+                if (SPLIT && !(a.dbg & 16)) {
                     const half8 wl = *reinterpret_cast<const half8*>(slotA + LO + (ks * PQT + t) * 1024);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
@@ -487,7 +488,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
 #pragma unroll
             for (int t = 0; t < MNT; ++t) {
                 const half8 wf = *reinterpret_cast<const half8*>(slotB + (sp * 12 + t) * 1024);
-                if constexpr (SPLIT) {
+                if (SPLIT && !(a.dbg & 16)) {
                     const half8 wl = *reinterpret_cast<const half8*>(slotB + LO + (sp * 12 + t) * 1024);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
@@ -657,6 +658,8 @@ public:
         if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }
         b.ncu = ncu;
         if (split_) {                  // one kernel for every row count: eight waves x 16 rows, one workgroup per CU (149 KB of LDS)
+            static int sdbg = -1; if (sdbg < 0) sdbg = ablateEnv("DSVT_MLP_DBG", 0);
+            b.dbg = sdbg;
             hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, 64, 3, true>), dim3(cdiv(max_rows_, MROWS)), dim3(512), 0, stream, b);
             return lastError();
         }
