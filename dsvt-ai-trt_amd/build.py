@@ -63,11 +63,11 @@ def build(force=False, verbose=False, ablate=False):
                 print(" ".join(cmd), file=sys.stderr)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, p in procs:
-        out, _ = p.communicate()
+        log, _ = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
-        if verbose and out:
-            print(out.decode(), file=sys.stderr)
+            raise RuntimeError(f"hipcc failed on {src}:\n{log.decode()}")
+        if verbose and log:
+            print(log.decode(), file=sys.stderr)
     if force or procs or _stale(out, objs):
         cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
         subprocess.check_call(cmd)

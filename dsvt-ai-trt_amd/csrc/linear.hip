@@ -1034,8 +1034,8 @@ int launchLinearF16Stream(const LinearArgs& a, const _Float16* Wp, hipStream_t s
     static int mt2 = -1;           // DSVT_STREAM_MT=2: 4 waves x 32 rows (<= 256 VGPRs); default 8 waves x 16 rows (<= 128 VGPRs, 4 waves/SIMD):
     if (mt2 < 0) mt2 = ablateEnv("DSVT_STREAM_MT", 1);      // 1.5 % faster with two frames in flight, slower alone
     const bool wide = mt2 == 2;
-#define DSVT_LS(AM) do { if (wide) hipLaunchKernelGGL((linear_f16_stream_kernel<AM, 2, 4>), grid, dim3(256), 0, stream, a, Wp); \
-                         else hipLaunchKernelGGL((linear_f16_stream_kernel<AM, 1, 8>), grid, dim3(512), 0, stream, a, Wp); } while (0)
+#define DSVT_LS(AM) do { if constexpr (kAblate) { if (wide) { hipLaunchKernelGGL((linear_f16_stream_kernel<AM, 2, 4>), grid, dim3(256), 0, stream, a, Wp); break; } } \
+                         hipLaunchKernelGGL((linear_f16_stream_kernel<AM, 1, 8>), grid, dim3(512), 0, stream, a, Wp); } while (0)
     if (amode == 2) DSVT_LS(2); else if (amode == 1) DSVT_LS(1); else DSVT_LS(0);
 #undef DSVT_LS
     return lastError();

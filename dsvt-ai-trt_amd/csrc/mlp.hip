@@ -695,13 +695,20 @@ public:
         b.dbg = dbg;
         static int ring = -1;          // DSVT_MLP_RING=6: the six-slot ring (measured: no gain, see the kernel's header)
         if (ring < 0) ring = ablateEnv("DSVT_MLP_RING", 3);
-        if (variant == 3 && ring == 6) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 10, 64, 6>), grid, dim3(640), 0, stream, b);
+        bool launched = false;
+        if constexpr (kAblate) {       // the measured-and-dropped variants: ablation build only (DSVT_MLP_VARIANT / DSVT_MLP_RING)
+            launched = true;
+            if (variant == 3 && ring == 6) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 10, 64, 6>), grid, dim3(640), 0, stream, b);
+            else if (variant == 2) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, 64, 3>), grid, dim3(512), 0, stream, b);
+            else if (variant == 4) hipLaunchKernelGGL((encoder_mlp_stream_kernel<2, 8, 64, 3>), dim3(cdiv(max_rows_, 256)), dim3(512), 0, stream, b);   // experiment
+            else launched = false;
+            // (variant 4, an experiment: ONE ring for 256 rows, eight waves in lockstep: 188 vs 155 us per four-frame launch for two independent <2,4> workgroups per CU.
+            // (The same with the upper four waves one stage behind the lower four, on a four-slot ring: 222 us.  What two independent workgroups
+            // overlap is not stage against stage -- both kinds are 48 MFMAs per wave -- but one's prologue and epilogue, 40 % of a
+            // workgroup's life, against the other's streaming loop: a lag of half a lifetime, which no ring in 160 KB can hold.))
+        }
+        if (launched) {}
         else if (variant == 3) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 10, 64, 3>), grid, dim3(640), 0, stream, b);
-        else if (variant == 2) hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, 64, 3>), grid, dim3(512), 0, stream, b);
-        else if (variant == 4) hipLaunchKernelGGL((encoder_mlp_stream_kernel<2, 8, 64, 3>), dim3(cdiv(max_rows_, 256)), dim3(512), 0, stream, b);   // experiment: ONE ring for 256 rows, eight waves in lockstep: 188 vs 155 us per four-frame launch for two independent <2,4> workgroups per CU.
-                                                                                   // (The same with the upper four waves one stage behind the lower four, on a four-slot ring: 222 us.  What two independent workgroups
-                                                                                   // overlap is not stage against stage -- both kinds are 48 MFMAs per wave -- but one's prologue and epilogue, 40 % of a
-                                                                                   // workgroup's life, against the other's streaming loop: a lag of half a lifetime, which no ring in 160 KB can hold.)
         else hipLaunchKernelGGL((encoder_mlp_stream_kernel<2, 4, 64, 3>), grid, dim3(256), 0, stream, b);
         if (tron) {
             (void)hipStreamSynchronize(stream);

@@ -139,8 +139,10 @@ inline int trailingInts(size_t len, size_t base, int maxInts) {
 // builds libdsvt_hip_ablate.so with -DDSVT_ABLATE for tools/ (trace_*.py, ablate_conv.sh, one_attn.py ...), where the switch is read.
 #ifdef DSVT_ABLATE
 inline int ablateEnv(const char* name, int def) { const char* e = getenv(name); return e ? atoi(e) : def; }
+constexpr bool kAblate = true;           // the kernel instantiations only an ablation switch can select are compiled
 #else
 inline int ablateEnv(const char*, int def) { return def; }
+constexpr bool kAblate = false;          // ... and are NOT part of the product library (`if constexpr (kAblate)` at their launch sites)
 #endif
 
 }  // namespace dsvt
