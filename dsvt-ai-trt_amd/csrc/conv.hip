@@ -61,6 +61,7 @@ struct ConvArgs {
     //   alias3 : (kernels that still walk three fp16 planes) first channel of the third plane, whose phases read plane 0 instead; 0 = off
     //   xscale : (conv_wide_kernel<.., MX>) E8M0 scale byte per weight row: 127 - 11 - e with w_hi8 = e4m3(2^e w_hi), w_lo8 = e4m3(2^(e + 11) w_lo)
     int x8_out, alias3;
+    int res_x8;                                  // the residual triple has no lo plane ([hi | - | x8]): its value is hi + 2^-11 lo8 (to 2^-15 relative)
     const unsigned char* xscale;
     unsigned long long* trace;                   // debugging (DSVT_CONV_TRACE=1, tools/trace_conv.py): s_memtime stamps of waves 0 and NW/2, or nullptr
 };
@@ -123,7 +124,12 @@ __device__ __forceinline__ void convStore(const ConvArgs& a, floatx4 acc, size_t
         const half4 rv = *reinterpret_cast<const half4*>(a.res + opix * a.res_ld + co);
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] += (float)rv[i];
-        if (SPL && a.res_split) {
+        if (SPL && a.res_split && a.res_x8) {
+            const unsigned w[1] = {*reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(a.res + opix * a.res_ld + 2 * a.res_split) + x8Offset(co))};
+            float lo[4]; x8DecodeLo<4>(w, lo);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += lo[i];
+        } else if (SPL && a.res_split) {
             const half4 rl = *reinterpret_cast<const half4*>(a.res + opix * a.res_ld + a.res_split + co);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] += (float)rl[i];
@@ -417,7 +423,13 @@ __device__ __forceinline__ void convStoreWide(const ConvArgs& a, floatx4 X, floa
         const half8 rv = *reinterpret_cast<const half8*>(a.res + opix * a.res_ld + co);
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += (float)rv[i];
-        if (SPL && a.res_split) {
+        if (SPL && a.res_split && a.res_x8) {
+            const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(a.res + opix * a.res_ld + 2 * a.res_split) + x8Offset(co));
+            const unsigned w[2] = {q.x, q.y};
+            float lo[8]; x8DecodeLo<8>(w, lo);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += lo[i];
+        } else if (SPL && a.res_split) {
             const half8 rl = *reinterpret_cast<const half8*>(a.res + opix * a.res_ld + a.res_split + co);
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] += (float)rl[i];
@@ -465,16 +477,60 @@ __device__ __forceinline__ void slabBarrier(int keep) {
     asm volatile("" ::: "memory");
 }
 
+// ---- the scaled MFMA of the fp16 + fp8 K loops (conv_wide_kernel<.., MX>, conv_halo_kernel<.., MX>): see the comment above conv_wide_kernel ----
+typedef int intx4 __attribute__((ext_vector_type(4)));
+typedef int intx8 __attribute__((ext_vector_type(8)));
+// tile engine of the MX instantiations (tools/ab_conv.sh builds variants from -D flags; A/B numbers in profiles/README.md, round 4): four-step
+// weight slabs (half the barriers: 7.70 vs 7.87 ms over the stage's layers), two slab buffers, four A fragments per fp16 batch, one per fp8 batch
+#ifndef MX_TRICKLE_MAIN
+#define MX_TRICKLE_MAIN 1
+#endif
+#ifndef MX_TRICKLE_CROSS
+#define MX_TRICKLE_CROSS 0
+#endif
+#ifndef MX_NWB
+#define MX_NWB 2
+#endif
+#ifndef MX_NWB4
+#define MX_NWB4 2
+#endif
+#ifndef MX_CH
+#define MX_CH 4
+#endif
+#ifndef WIDE_PFB
+#define WIDE_PFB 1
+#endif
+#ifndef MX_SPS
+#define MX_SPS 4
+#endif
+#ifndef MX_CHX
+#define MX_CHX 1
+#endif
+template <int OP>
+__device__ __forceinline__ floatx4 mfmaX8(const intx8& A, const intx8& B, const floatx4& c, int scaleA) {
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, c, 0, 0, OP, scaleA, 0, 127);          // fp8 x fp8; byte OP of scaleA; scale_b = 2^0
+}
+__device__ __forceinline__ floatx4 mfmaX8(int op, const intx8& A, const intx8& B, const floatx4& c, int scaleA) {      // (op is a constant after unrolling)
+    switch (op & 3) { case 0: return mfmaX8<0>(A, B, c, scaleA); case 1: return mfmaX8<1>(A, B, c, scaleA); case 2: return mfmaX8<2>(A, B, c, scaleA); default: return mfmaX8<3>(A, B, c, scaleA); }
+}
+
+
 // CTW = 16-channel tiles per workgroup: 8 (128 output channels; wave (pg, cg) = 64 pixels x 64 channels) or 4 / 2
 // (layers with <= 64 / <= 32 output channels: both waves of a row pair use the same channel tiles and split the four
 // pixel tiles; a 16 KB weight slab then holds 2 / 4 taps, so the barrier cadence stays at 16 fragment rows)
 // HB = halo buffers: 2 = the next halo streams in behind the weight slabs (one workgroup per CU);  1 = the halo is reloaded
 // between phases (exposed, but the LDS footprint lets TWO 4-wave workgroups share a CU: their barriers and their
 // LDS-read / MFMA phases are no longer in lockstep)
-template <int TH, int KS, int CTW, int HB, bool SPL = false>
+// MX (round 4, 1 x 1 layers with 128-channel chunks only): the input is a split tensor [hi | lo | x8] of C = Cin / 3 channels; C / 64 phases of the hi
+// plane (two fp16 k-steps each, as before) are followed by C / 64 phases of the x8 plane -- 128 bytes per pixel again: two 32-channel groups of
+// [lo8 0..15 | hi8 0..15 | lo8 16..31 | hi8 16..31] -- each ONE e4m3 K = 128 step: lane group g of the B operand reads chunks 4 (g >> 1) + (g & 1) and
+// + 2 of its pixel (group g >> 1, lo8 for even g, hi8 for odd g; conflict-free under the slot = chunk ^ (hx & 7) swizzle, enumerated), the A operand two
+// lane-linear 1 KB rows per channel tile with e4m3(2^e w_hi) / e4m3(2^(e + 11) w_lo) in the even / odd lane groups (DsvtConv2dPlugin::packMX1x1).
+template <int TH, int KS, int CTW, int HB, bool SPL = false, bool MX = false>
 __global__ void __launch_bounds__(64 * TH, 1)
 conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __restrict__ zeros, int tilesX, int nitems, int nchunk, int dbg)
 {
+    static_assert(!MX || (KS == 1 && CTW == 8 && SPL), "the fp16 + fp8 loop of this kernel serves the 1 x 1 layers");
     constexpr bool NARROW = CTW < 8;
     constexpr int HS = KS == 1 ? 32 : HHS;                          // LDS halo row stride in pixels (multiple of 8)
     constexpr int HH = TH + KS - 1, HWU = HTW + KS - 1, T = KS * KS, PAD = KS / 2;
@@ -496,7 +552,8 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     constexpr int BIAS_OFF = HB * HBYTES + NWB * WBYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
     const int pg = wave >> 1, cg = wave & 1;
-    const int NCC = a.Cin >> 6, NCT = NARROW ? CTW : nchunk * 8;
+    const int NPM = MX ? a.Cin / 192 : a.Cin >> 6;                    // 64-channel phases of fp16 k-steps (MX: of the hi plane; a.Cin = 3 C)
+    const int NCC = MX ? 2 * NPM : NPM, NCT = NARROW ? CTW : nchunk * 8;
     const int m0 = NARROW ? 2 * cg : 0, cgc = NARROW ? 0 : cg;       // first pixel tile / channel group of this wave
 
     // halo requests of this lane: request j of the wave covers LDS pixels 8(wave + j TH) .. +7; lane = (pixel, 16-byte slot)
@@ -524,7 +581,8 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         yy = (t / tilesX) * TH; xx = (t % tilesX) * HTW;
     };
     auto haloRequest = [&](int j, int cc, int hb) {                   // wave-uniform j: one LDS-DMA of 1 KB
-        const int c0 = (a.alias3 && cc * 64 >= a.alias3) ? cc * 64 - a.alias3 : cc * 64;          // (the phases of an x8 third plane read plane 0)
+        const int c0 = MX ? (cc >= NPM ? 128 * NPM + (cc - NPM) * 64 : cc * 64)                  // (MX: phase NPM + q = 128 bytes of the x8 plane, which starts at channel 2 C)
+                          : (a.alias3 && cc * 64 >= a.alias3) ? cc * 64 - a.alias3 : cc * 64;        // (the phases of an x8 third plane read plane 0)
         const _Float16* src = goff[j] >= 0 ? a.in + goff[j] + c0 : zeros;
         __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + hb * HBYTES + (wave + j * TH) * 1024), 16, 0, 0);
     };
@@ -533,7 +591,9 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         for (int j = 0; j < WPW; ++j) {
             const int u = wave + j * TH;
             if (WROWS % TH == 0 || u < WROWS) {
-                const size_t row = NARROW ? (size_t)q0 * CTW + u : (size_t)(q0 + (u >> 3)) * NCT + ch * 8 + (u & 7);
+                size_t row = NARROW ? (size_t)q0 * CTW + u : (size_t)(q0 + (u >> 3)) * NCT + ch * 8 + (u & 7);
+                if (MX && q0 >= 2 * NPM)                          // cross phase q0 / 2 - NPM: [NCT][2][1 KB] behind the fp16 rows
+                    row = (size_t)2 * NPM * NCT + ((size_t)(q0 / 2 - NPM) * NCT + ch * 8 + (u >> 1)) * 2 + (u & 1);
                 __builtin_amdgcn_global_load_lds((glds_src_t)(Wp + (row * 64 + lane) * 8), (glds_dst_t)(smem + HB * HBYTES + wb * WBYTES + u * 1024), 16, 0, 0);
             }
         }
@@ -579,8 +639,10 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     auto biasRequest = [&](int ch) {
         const int n0 = ch * CNB, sub = n0 / a.Cout, co = n0 - sub * a.Cout + lane * 4;
         const void* src = (biasInit && lane < 32 && co < a.Cout) ? static_cast<const void*>(a.bias + co) : static_cast<const void*>(zeros);
+        if (MX && lane >= 32 && lane < 40) src = a.xscale + n0 + (lane - 32) * 16;       // the chunk's scale bytes: LDS bytes 512 .. 639
         __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + BIAS_OFF), 16, 0, 0);
     };
+    int xs = 0;                                                     // MX: scale bytes of this wave's four channel tiles (row r)
 
     int item = blockIdx.x;
     if (item >= nitems) return;
@@ -625,6 +687,11 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                             const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + BIAS_OFF + (cgc * 64 + ct * 16 + 4 * g) * 4);      // zeros without a bias
 #pragma unroll
                             for (int m = 0; m < NM; ++m) acc[ct][m] = b4;
+                        }
+                        if constexpr (MX) {
+                            xs = 0;
+#pragma unroll
+                            for (int ct = 0; ct < CTP; ++ct) xs |= (int)smem[BIAS_OFF + 512 + (cgc * 4 + ct) * 16 + r] << (8 * ct);
                         }
                     }
                     // the slab LEAD ahead: (cc, grp + LEAD) or, past the end of this phase, (ncc, grp + LEAD - NG) of the next one
@@ -677,7 +744,29 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                                     acc[ct][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ct], B[m], acc[ct][m], 0, 0, 0);
                     }
                 };
-                if (dbg & 4) {} else if (ctn == CTP) slab(std::true_type{}); else slab(std::false_type{});
+                auto slabX = [&]() {                                 // (MX) one cross step: 16 scaled MFMAs per wave
+                    if constexpr (MX) {
+                        intx8 A[CTP], B[NM];
+                        const int c0 = 4 * (g >> 1) + (g & 1), s0 = (c0 ^ (r & 7)) << 4, s1 = ((c0 + 2) ^ (r & 7)) << 4;
+#pragma unroll
+                        for (int ct = 0; ct < CTP; ++ct) {
+                            const unsigned char* wr = wbp + (((cgc * 4 + ct) * 2) << 10);
+                            const intx4 lo = *reinterpret_cast<const intx4*>(wr), hi = *reinterpret_cast<const intx4*>(wr + 1024);
+                            A[ct] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+#pragma unroll
+                        for (int m = 0; m < NM; ++m) {
+                            const intx4 lo = *reinterpret_cast<const intx4*>(hbp + pbase[m] + s0), hi = *reinterpret_cast<const intx4*>(hbp + pbase[m] + s1);
+                            B[m] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+#pragma unroll
+                        for (int ct = 0; ct < CTP; ++ct)
+                            if (ct < ctn)
+#pragma unroll
+                                for (int m = 0; m < NM; ++m) acc[ct][m] = mfmaX8(ct, A[ct], B[m], acc[ct][m], xs);
+                    }
+                };
+                if (dbg & 4) {} else if (MX && cc >= NPM) slabX(); else if (ctn == CTP) slab(std::true_type{}); else slab(std::false_type{});
                 if (endOfSlab) {
                     // in issue order the queue holds: [W of the next slab] [halo reqs of the previous slab] [W issued at this slab's
                     // start] [halo reqs of this slab].  LEAD 1: retire everything but this slab's halo requests.  LEAD 2: retire the
@@ -744,42 +833,6 @@ struct WideCfg {
 // hi8) of row n, and the row's scale byte 127 - 11 - e undoes both factors (tap 9 of the fifth step: zero weights).  Per 32 channels and tile pair:
 // 9 fp16 + 5 fp8 MFMAs = 9 x 16 + 5 x 27 cycles of the pipe instead of 27 x 16.  A cross step's fragments are 2 KB per channel tile (two lane-linear
 // 1 KB rows: bytes 0..15 and 16..31 of every lane), so a weight slab holds SPS / 2 cross steps.  Packed weights: DsvtConv2dPlugin::packMX.
-typedef int intx4 __attribute__((ext_vector_type(4)));
-typedef int intx8 __attribute__((ext_vector_type(8)));
-// tile engine of the MX instantiations (tools/ab_conv.sh builds variants from -D flags; A/B numbers in profiles/README.md, round 4): four-step
-// weight slabs (half the barriers: 7.70 vs 7.87 ms over the stage's layers), two slab buffers, four A fragments per fp16 batch, one per fp8 batch
-#ifndef MX_TRICKLE_MAIN
-#define MX_TRICKLE_MAIN 1
-#endif
-#ifndef MX_TRICKLE_CROSS
-#define MX_TRICKLE_CROSS 0
-#endif
-#ifndef MX_NWB
-#define MX_NWB 2
-#endif
-#ifndef MX_NWB4
-#define MX_NWB4 2
-#endif
-#ifndef MX_CH
-#define MX_CH 4
-#endif
-#ifndef WIDE_PFB
-#define WIDE_PFB 1
-#endif
-#ifndef MX_SPS
-#define MX_SPS 4
-#endif
-#ifndef MX_CHX
-#define MX_CHX 1
-#endif
-template <int OP>
-__device__ __forceinline__ floatx4 mfmaX8(const intx8& A, const intx8& B, const floatx4& c, int scaleA) {
-    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, c, 0, 0, OP, scaleA, 0, 127);          // fp8 x fp8; byte OP of scaleA; scale_b = 2^0
-}
-__device__ __forceinline__ floatx4 mfmaX8(int op, const intx8& A, const intx8& B, const floatx4& c, int scaleA) {      // (op is a constant after unrolling)
-    switch (op & 3) { case 0: return mfmaX8<0>(A, B, c, scaleA); case 1: return mfmaX8<1>(A, B, c, scaleA); case 2: return mfmaX8<2>(A, B, c, scaleA); default: return mfmaX8<3>(A, B, c, scaleA); }
-}
-
 template <int CT, int NW, int HS, int SPS = (CT == 8 ? 2 : 4), int NWB = 3, int RW = 2, bool TR = false, bool SPL = false, bool MX = false>
 __global__ void __launch_bounds__(64 * NW, (NW * (RW == 1 ? 1 : 2) <= 8 && (NW == 4 || RW == 1)) ? 2 : 1)
 conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __restrict__ zeros, int tilesX, int nitems, int nchunk, int dbg)
@@ -1106,7 +1159,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                     // split precision: the residual is hi + lo (two planes), the result leaves as three planes; TWO blocks at a time (with four, the
                     // residual loads plus the hi / lo planes in flight spill 30 registers of the main loop's accumulators; with two, 10)
                     constexpr int RS = RB / 4 > 0 ? RB / 4 : 1;
-                    const bool splitRes = hasRes && a.res_split != 0;
+                    const bool splitRes = hasRes && a.res_split != 0, resX8 = splitRes && a.res_x8 != 0;
 #pragma unroll
                     for (int b0 = 0; b0 < NBLK; b0 += RS) {
                         half8 rh[RS], rl[RS];
@@ -1116,7 +1169,10 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                                 const int b = b0 + j, m = b / TP, tp = b % TP, co = cbase + tp * 32 + cg8;
                                 const bool ok = valid[m] && co < a.Cout && 2 * tp < ctn;
                                 rh[j] = *reinterpret_cast<const half8*>(a.res + (ok ? opix[m] * a.res_ld + co : 0));
-                                rl[j] = *reinterpret_cast<const half8*>(a.res + ((ok && splitRes) ? opix[m] * a.res_ld + a.res_split + co : 0));
+                                if (resX8) {           // 8 lo8 bytes of the x8 plane into the first half of rl[j]
+                                    const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(a.res + (ok ? opix[m] * a.res_ld + 2 * a.res_split : 0)) + (ok ? x8Offset(co) : 0));
+                                    rl[j] = __builtin_bit_cast(half8, make_uint4(q.x, q.y, 0u, 0u));
+                                } else rl[j] = *reinterpret_cast<const half8*>(a.res + ((ok && splitRes) ? opix[m] * a.res_ld + a.res_split + co : 0));
                             }
                         }
 #pragma unroll
@@ -1131,7 +1187,13 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                             }
                             if (!valid[m] || co >= a.Cout) continue;
                             float v[8] = {X[0], X[1], X[2], X[3], Y[0], Y[1], Y[2], Y[3]};
-                            if (hasRes) {
+                            if (hasRes && resX8) {
+                                const uint4 q = __builtin_bit_cast(uint4, rl[j]);
+                                const unsigned w[2] = {q.x, q.y};
+                                float lo[8]; x8DecodeLo<8>(w, lo);
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) v[i] += (float)rh[j][i] + lo[i];
+                            } else if (hasRes) {
 #pragma unroll
                                 for (int i = 0; i < 8; ++i) v[i] += splitRes ? (float)rh[j][i] + (float)rl[j][i] : (float)rh[j][i];
                             }
@@ -1630,6 +1692,12 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
 #define DSVT_WIDE_MX(GRID_, BLOCK_, NITEMS_, NCHUNK_, ...) do { \
         hipLaunchKernelGGL((conv_wide_kernel<__VA_ARGS__, false, true, true>), dim3(GRID_), dim3(BLOCK_), 0, stream, a, Wp, zeros, tilesX, NITEMS_, NCHUNK_, dbg); \
         return lastError(); } while (0)
+    if (a.xscale && a.KH == 1) {                                // 1 x 1 layers on the fp16 + fp8 K loop (packMX1x1 image)
+        if (ctWide != 8) return -3;
+        const int nit = cdiv(a.Ho, 8) * tilesX * nchunk * NBI;
+        hipLaunchKernelGGL((conv_halo_kernel<8, 1, 8, 2, true, true>), dim3(nit < ncu ? nit : ncu), dim3(512), 0, stream, a, Wp, zeros, tilesX, nit, nchunk, dbg);
+        return lastError();
+    }
     if (a.xscale) {                                             // split input [hi | lo | x8] on the fp16 + fp8 K loop (packMX image); same tile choices as below
         if (a.KH != 3 || ctWide < 4) return -3;
         const int nwide = cdiv(a.Ho, 16) * tilesX * nchunk * NBI;
@@ -1793,6 +1861,48 @@ public:
               hipMalloc(&xscale_dev_, sc.size()) == hipSuccess && hipMemcpy(xscale_dev_, sc.data(), sc.size(), hipMemcpyHostToDevice) == hipSuccess &&
               hipMalloc(&zeros_dev_, 256) == hipSuccess && hipMemset(zeros_dev_, 0, 256) == hipSuccess;
     }
+    // the same for a 1 x 1 layer on conv_halo_kernel<.., MX> (64-channel phases): [fp16 k-step q = 2 phase + ks][tile][lane (r, g)][8 halfs] <-
+    // fp16(W[tile 16 + r][64 phase + 32 ks + 8 g + j]), then [cross phase][tile][h][lane (r, g)][16 bytes] <- e4m3 of W_hi 2^e (g even) or W_lo 2^(e + 11)
+    // (g odd) at channel 64 phase + 32 (g >> 1) + 16 h + j
+    void packMX1x1() {
+        const ConvCfg& c = c_;
+        const int C = c.Cin / 3, NPM = C / 64, R = rows(), NCT = cdiv(R, CNB) * 8;
+        const size_t mainRows = (size_t)2 * NPM * NCT, crossRows = (size_t)NPM * NCT * 2;
+        std::vector<unsigned char> img((mainRows + crossRows + (size_t)2 * NCT) * 1024, 0);
+        std::vector<unsigned char> sc((size_t)NCT * 16, 127 - 11);
+        std::vector<int> ex(R, 0);
+        for (int n = 0; n < R; ++n) {
+            float mx = 0.f;
+            for (int i = 0; i < C; ++i) mx = std::fmax(mx, std::fabs(w_[(size_t)n * C + i]));
+            int e = mx > 0.f ? (int)std::floor(std::log2(448.f / mx)) : 0;
+            e = e < -60 ? -60 : e > 60 ? 60 : e;
+            ex[n] = e; sc[n] = (unsigned char)(127 - 11 - e);
+        }
+        _Float16* img16 = reinterpret_cast<_Float16*>(img.data());
+        for (int q = 0; q < 2 * NPM; ++q)
+            for (int tile = 0; tile < NCT; ++tile)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int n = tile * 16 + (lane & 15);
+                    if (n >= R) continue;
+                    const size_t dst = (((size_t)q * NCT + tile) * 64 + lane) * 8, src = (size_t)n * C + (q >> 1) * 64 + (q & 1) * 32 + (lane >> 4) * 8;
+                    for (int j = 0; j < 8; ++j) img16[dst + j] = (_Float16)w_[src + j];
+                }
+        for (int ph = 0; ph < NPM; ++ph)
+            for (int tile = 0; tile < NCT; ++tile)
+                for (int h = 0; h < 2; ++h)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int n = tile * 16 + (lane & 15), g = lane >> 4;
+                        if (n >= R) continue;
+                        const size_t dst = (mainRows + ((size_t)ph * NCT + tile) * 2 + h) * 1024 + (size_t)lane * 16, src = (size_t)n * C + ph * 64 + (g >> 1) * 32 + h * 16;
+                        for (int j = 0; j < 16; ++j) {
+                            const float wv = w_[src + j], hi = (float)(_Float16)wv;
+                            img[dst + j] = (g & 1) ? e4m3Encode(std::ldexp(wv - hi, ex[n] + 11)) : e4m3Encode(std::ldexp(hi, ex[n]));
+                        }
+                    }
+        ok_ = hipMalloc(&wp_dev_, img.size()) == hipSuccess && hipMemcpy(wp_dev_, img.data(), img.size(), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMalloc(&xscale_dev_, sc.size()) == hipSuccess && hipMemcpy(xscale_dev_, sc.data(), sc.size(), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMalloc(&zeros_dev_, 256) == hipSuccess && hipMemset(zeros_dev_, 0, 256) == hipSuccess;
+    }
     DsvtConv2dPlugin(const ConvCfg& c, const float* w, const float* b) : c_(c) {
         const size_t nw = (size_t)rows() * c.KH * c.KW * cinW();
         w_.assign(w, w + nw);
@@ -1804,7 +1914,7 @@ public:
                 ok_ = hipMalloc(&b_dev_, sizeof(float) * nb) == hipSuccess && hipMemset(b_dev_, 0, sizeof(float) * nb) == hipSuccess &&
                       hipMemcpy(b_dev_, b_.data(), sizeof(float) * c.Cout, hipMemcpyHostToDevice) == hipSuccess;
             }
-            if (ok_) packMX();
+            if (ok_) { if (c.KH == 1) packMX1x1(); else packMX(); }
             return;
         }
         std::vector<_Float16> wh(nw);
@@ -1907,6 +2017,7 @@ public:
         a.KH = c_.KH; a.KW = c_.KW; a.stride = c_.stride; a.pad = c_.pad; a.up = c_.up; a.relu = c_.relu;
         a.split_out = c_.split_out ? c_.out_ld / 3 : 0;
         a.res_split = (c_.has_res && c_.split_res) ? a.res_ld / 3 : 0;
+        a.res_x8 = c_.split_res == 2;
         a.x8_out = c_.split_out == 2 ? 1 : c_.split_out == 3 ? 2 : 0;
         a.alias3 = c_.split_in == 1 ? c_.Cin / 3 * 2 : 0;
         a.xscale = c_.split_in == 2 ? xscale_dev_ : nullptr;
@@ -1978,9 +2089,12 @@ static Plugin* convNew(const ConvCfg& c, const float* w, const float* b) {
     if (c.split_out && (c.out_f32 || c.out_ld % 12 != 0 || c.out_ld / 3 < c.out_coff + c.Cout)) return nullptr;      // three planes of out_ld / 3 channels
     if (c.split_out < 0 || c.split_out > 3 || c.split_in < 0 || c.split_in > 2) return nullptr;
     if (c.split_out >= 2 && ((c.out_ld / 3) % 32 != 0 || c.out_coff % 8 != 0)) return nullptr;       // the x8 plane is laid out in 32-channel groups
-    if (c.split_res && !c.has_res) return nullptr;
+    if ((c.split_res && !c.has_res) || c.split_res < 0 || c.split_res > 2) return nullptr;       // (2: the residual triple has no lo plane, its lo part comes from the x8 plane)
     if (c.split_in && c.Cin % 192 != 0) return nullptr;                                              // three planes of whole 64-channel phases
-    if (c.split_in == 2 && (c.KH != 3 || c.KW != 3 || c.stride != 1 || c.pad != 1 || c.up != 1 || c.Cout <= 32)) return nullptr;      // the layers conv_wide_kernel serves
+    // split_in 2: the layers the fp16 + fp8 K loops serve -- 3 x 3 stride 1 with more than 32 output channels (conv_wide_kernel) and 1 x 1 stride 1 with
+    // whole 128-row weight chunks, pixel shuffle included (conv_halo_kernel)
+    if (c.split_in == 2 && !((c.KH == 3 && c.KW == 3 && c.stride == 1 && c.pad == 1 && c.up == 1 && c.Cout > 32) ||
+                             (c.KH == 1 && c.KW == 1 && c.stride == 1 && c.pad == 0 && (c.up * c.up * c.Cout) % CNB == 0 && c.Cin % 192 == 0))) return nullptr;
     return new DsvtConv2dPlugin(c, w, b);
 }
 static Plugin* convCreate(const DsvtPluginFieldCollection* fc) {
@@ -1989,7 +2103,7 @@ static Plugin* convCreate(const DsvtPluginFieldCollection* fc) {
     c.KH = c.KW = fieldInt(fc, "kernel_size", 1); c.stride = fieldInt(fc, "stride", 1); c.pad = fieldInt(fc, "padding", 0);
     c.up = fieldInt(fc, "pixel_shuffle", 1); c.relu = fieldInt(fc, "relu", 0); c.has_res = fieldInt(fc, "has_residual", 0);
     c.out_ld = fieldInt(fc, "out_channel_stride", c.Cout); c.out_coff = fieldInt(fc, "out_channel_offset", 0); c.out_f32 = fieldInt(fc, "out_f32", 0);
-    c.split_out = fieldInt(fc, "split_output", 0); c.split_res = fieldInt(fc, "split_residual", 0) != 0; c.split_in = fieldInt(fc, "split_input", 0);
+    c.split_out = fieldInt(fc, "split_output", 0); c.split_res = fieldInt(fc, "split_residual", 0); c.split_in = fieldInt(fc, "split_input", 0);
     const DsvtPluginField* w = findField(fc, "weight"); const DsvtPluginField* b = findField(fc, "bias");
     if (!w || !w->data || c.Cin <= 0 || c.Cout <= 0 || c.up < 1) return nullptr;
     if ((long)w->length != (long)c.up * c.up * c.Cout * c.KH * c.KW * (c.split_in == 2 ? c.Cin / 3 : c.Cin)) return nullptr;

@@ -92,6 +92,15 @@ __device__ __forceinline__ unsigned packE4m3(float a, float b, float c, float d)
     p = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
     return (unsigned)p;
 }
+// the lo parts (v - hi, to four bits: e4m3 of 2^11 (v - hi)) of N (4 or 8) consecutive channels from their packed lo8 bytes
+template <int N>
+__device__ __forceinline__ void x8DecodeLo(const unsigned (&w)[N / 4], float (&lo)[N]) {
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+        const auto a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[i], false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[i], true);
+        lo[4 * i] = a[0] * (1.f / 2048.f); lo[4 * i + 1] = a[1] * (1.f / 2048.f); lo[4 * i + 2] = b[0] * (1.f / 2048.f); lo[4 * i + 3] = b[1] * (1.f / 2048.f);
+    }
+}
 // byte offset, inside a pixel's x8 plane, of the lo8 byte of channel c (its hi8 byte is 16 further): [lo8 0..15 | hi8 0..15 | lo8 16..31 | hi8 16..31] per 32 channels
 __device__ __forceinline__ int x8Offset(int c) { return (c >> 5) * 64 + ((c >> 4) & 1) * 32 + (c & 15); }
 

@@ -320,23 +320,26 @@ class DsvtPipeline:
         ops = self.sops = {}
         mx = self.head_mx
 
-        def conv(name, rows, bias, H, cin, cout, k, stride, relu, res=False, out_f32=False, plane=None, lo=True, **kw):
+        def conv(name, rows, bias, H, cin, cout, k, stride, relu, res=False, out_f32=False, plane=None, lo=True, res_lo=True, **kw):
             # lo = False (head_mx only): every consumer of this tensor is a [hi | x8] layer and it is nobody's residual -- its lo plane is not written
             plane = cout if plane is None else plane
             # head_mx: the third plane of every tensor holds the fp8 operands (x8).  The 3 x 3 stride-1 layers with > 32 output channels (93 % of the
             # stage's products) read [hi | x8] on the fp16 + fp8 K loop from the REAL fp32 rows (split_input = 2); the others keep the three-product
             # walk over [w_hi | w_hi | w_lo] and read plane 0 where the third plane used to repeat it (split_input = 1)
-            wide = mx and k == 3 and stride == 1 and cout > 32 and not kw.get("pixel_shuffle")
+            # (round 4, second step: the 1 x 1 stride-1 layers too -- shortcut of the first block and the three deblocks -- on conv_halo_kernel<.., MX>;
+            # res_lo = False: the residual tensor was written without its lo plane, whose part of the value comes from the x8 plane's lo8 bytes)
+            up2 = kw.get("pixel_shuffle", 1) ** 2
+            wide = mx and stride == 1 and ((k == 3 and cout > 32 and up2 == 1) or (k == 1 and (up2 * cout) % 128 == 0))
             ops[name] = P.add_conv2d_op(np.asarray(rows, np.float32) if wide else sw(rows, k * k, cin), bias, H, H, 3 * cin, cout, k, stride, k // 2,
-                                        relu=relu, has_residual=res, split_residual=res, out_f32=out_f32,
+                                        relu=relu, has_residual=res, split_residual=(1 if (res_lo or not mx) else 2) if res else 0, out_f32=out_f32,
                                         split_output=0 if out_f32 else ((2 if lo else 3) if mx else 1), split_input=(2 if wide else 1) if mx else 0,
                                         out_channel_stride=plane if out_f32 else 3 * plane, **kw)
             ops[name].split_in = True            # (bench.py's flop / byte accounting: 3 Cin operand channels carry Cin real ones)
             ops[name].mx_in = bool(wide)
 
-        def conv_bn(name, name_conv, name_bn, H, cin, cout, k, stride, relu, res=False, lo=True):
+        def conv_bn(name, name_conv, name_bn, H, cin, cout, k, stride, relu, res=False, lo=True, res_lo=True):
             s_, sh = bn_fold(w, name_bn, 1e-3)
-            conv(name, cw(w[name_conv + ".weight"] * s_[:, None, None, None]), sh, H, cin, cout, k, stride, relu, res=res, lo=lo)
+            conv(name, cw(w[name_conv + ".weight"] * s_[:, None, None, None]), sh, H, cin, cout, k, stride, relu, res=res, lo=lo, res_lo=res_lo)
 
         H = GY
         for (i, cin, cout, stride, nb) in ((0, 192, 128, 1, 2), (1, 128, 128, 2, 3), (2, 128, 256, 2, 3)):
@@ -346,6 +349,10 @@ class DsvtPipeline:
                 ci = cin if j == 0 else cout
                 conv_bn(p + ".1", p + ".conv1", p + ".bn1", H, ci, cout, 3, st, True, lo=False)        # (read by conv2 only)
                 Ho = (H + 2 - 3) // st + 1
+                # (Reading a residual's lo part from the x8 plane -- split_residual = 2, which would let these tensors drop their lo plane too -- is
+                # built and tested (tests/test_conv_mx_gpu.py) but NOT used: it carries a residual to 2^-15 instead of 2^-22, moved the worst yaw
+                # of the 180k-point frame from 8.4e-4 to 1.05e-3 (yaw = atan(sin / cos) of a short random-weight vector amplifies), and saves no
+                # read traffic -- lo8 and hi8 alternate in 16-byte chunks, so the same cache lines are fetched.)
                 if j == 0:
                     conv_bn(p + ".d", p + ".downsample_layer.0", p + ".downsample_layer.1", H, ci, cout, 1, st, False)
                 conv_bn(p + ".2", p + ".conv2", p + ".bn2", Ho, cout, cout, 3, 1, True, res=True)      # + identity, ReLU (:1165-1166)

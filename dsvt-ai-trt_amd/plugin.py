@@ -596,7 +596,7 @@ def add_conv2d_op(weight_rows, bias, in_height, in_width, in_channels, out_chann
     if split_output:
         fields["split_output"] = int(split_output)
     if split_residual:
-        fields["split_residual"] = 1
+        fields["split_residual"] = int(split_residual)     # 2: the residual triple has no lo plane, its lo part is read from the x8 plane (to 2^-15)
     if split_input:
         fields["split_input"] = int(split_input)
     if bias is not None:

@@ -173,11 +173,13 @@ def test_map2bev_writes_the_x8_plane(pkg):
 def test_mx_plugin_refuses_what_the_kernel_does_not_serve(pkg):
     P = pkg.plugin
     w = np.zeros((128, 9 * 128), np.float32)
-    for kw in (dict(kernel_size=1, padding=0), dict(stride=2), dict(pixel_shuffle=2, kernel_size=1, padding=0)):
+    for kw in (dict(kernel_size=1, padding=0, stride=2), dict(stride=2), dict(kernel_size=1, padding=1)):
         args = dict(kernel_size=3, stride=1, padding=1)
         args.update(kw)
         with pytest.raises(Exception):
             P.add_conv2d_op(w[:, :(args["kernel_size"] ** 2) * 128], None, 20, 20, 384, 128, split_input=2, split_output=2, out_channel_stride=384, **args)
+    with pytest.raises(Exception):      # a 1 x 1 layer whose weight rows are not whole 128-row chunks
+        P.add_conv2d_op(w[:64, :128], None, 20, 20, 384, 64, 1, 1, 0, split_input=2, split_output=2, out_channel_stride=192)
     with pytest.raises(Exception):      # 32 output channels: the narrow halo kernel's layer
         P.add_conv2d_op(w[:32], None, 20, 20, 384, 32, 3, 1, 1, split_input=2, split_output=2, out_channel_stride=96)
 
@@ -213,3 +215,78 @@ def test_split_output_3_leaves_the_lo_plane_alone(pkg):
     assert torch.equal(out[..., :cout].view(torch.int16), full[..., :cout].view(torch.int16))
     assert torch.equal(out[..., 2 * cout:].view(torch.int16), full[..., 2 * cout:].view(torch.int16))
     assert (out[..., cout:2 * cout] == 7.0).all()
+
+
+def mx_rows_emulation(x, rows, bias_rows):
+    """x [N, C] fp32, rows [R, C] fp32 -> float64 [N, R]: fp16 main product + the two e4m3 correction products, one exponent per weight row"""
+    xh = x.half().float()
+    a_lo8, a_hi8 = e4m3((x - xh) * 2048.0).double() / 2048.0, e4m3(x).double()
+    wh = rows.half().float()
+    e = torch.floor(torch.log2(torch.tensor(448.0) / rows.abs().amax(dim=1))).clamp(-60, 60)
+    sc = torch.pow(torch.tensor(2.0), e).reshape(-1, 1)
+    w_hi8 = e4m3(wh * sc).double() / sc.double()
+    w_lo8 = e4m3((rows - wh) * sc * 2048.0).double() / (sc.double() * 2048.0)
+    return xh.double() @ wh.double().T + a_lo8 @ w_hi8.T + a_hi8 @ w_lo8.T + bias_rows.double()
+
+
+@pytest.mark.parametrize("H,W,cin,cout,up,B", [
+    (52, 47, 192, 128, 1, 1),       # the 1 x 1 shortcut of the first block
+    (26, 23, 128, 128, 2, 1),       # second deblock: ConvTranspose 2 x 2 / 2 as a 1 x 1 layer with a pixel shuffle
+    (13, 11, 256, 128, 4, 2),       # third deblock, two images
+    (468, 468, 128, 128, 1, 1),     # first deblock at full size
+])
+def test_mx_1x1_layers_and_deblocks(pkg, H, W, cin, cout, up, B):
+    """1 x 1 layers of the fp32-grade dense stage on conv_halo_kernel<.., MX> (split_input = 2), deconvBnLELU included (stride == kernel ConvTranspose,
+    src/dsvt-ai-trt.cpp:217-246), written into a channel slice of the concat buffer with split_output = 3 ([hi | - | x8])"""
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(H * 100 + cin + up)
+    x = torch.relu(torch.randn(B, H, W, cin, generator=g) * 3.0)
+    w = torch.randn(cin, cout, up, up, generator=g) / np.sqrt(cin) * torch.exp(torch.randn(1, cout, 1, 1, generator=g))
+    b = torch.randn(cout, generator=g) * 0.1
+    rows = torch.from_numpy(P.deconv_weight_rows(w.numpy()))                     # [(dy, dx, co)][cin]
+    brow = b.repeat(up * up)
+    xf = x.reshape(-1, cin)
+    emu = torch.relu(mx_rows_emulation(xf, rows, brow))
+    exact = torch.relu(xf.double() @ rows.double().T + brow.double())
+    shuffle = lambda y: y.reshape(B, H, W, up, up, cout).permute(0, 1, 3, 2, 4, 5).reshape(B, H * up, W * up, cout)
+    emu, exact = shuffle(emu), shuffle(exact)
+    plane, off = 384, 128
+    op = P.add_conv2d_op(rows.numpy(), b.numpy(), H, W, 3 * cin, cout, 1, 1, 0, pixel_shuffle=up, relu=True, split_input=2, split_output=3,
+                         out_channel_stride=3 * plane, out_channel_offset=off)
+    cat = torch.full((B, H * up, W * up, 3 * plane), 7.0, dtype=torch.float16, device=DEV)
+    op(make_triple(x).to(DEV), out=[cat])
+    torch.cuda.synchronize()
+    cat = cat.cpu()
+    got = cat[..., off:off + cout].double()
+    lo8 = cat[..., 2 * plane:].contiguous().view(torch.uint8).reshape(B, H * up, W * up, plane // 32, 2, 2, 16)[..., 0, :]      # lo8 bytes [.., group, half, 16]
+    got = got + lo8.reshape(B, H * up, W * up, plane).view(torch.float8_e4m3fn).float()[..., off:off + cout].double() / 2048.0     # hi + the x8 plane's lo part (4 bits)
+    scale = exact.abs().max().item()
+    e_emu, e_exact = (got - emu).abs().max().item() / scale, (got - exact).abs().max().item() / scale
+    print(f"mx 1x1 {H}x{W} {cin}->{cout} up{up}: vs emulation {e_emu:.2e}, vs exact fp64 {e_exact:.2e} of scale")
+    assert e_emu < 4e-5 and e_exact < 1.5e-4, (e_emu, e_exact)        # (hi + lo8 / 2^11 carries the value to 2^-16: the lo plane is not written)
+    untouched = torch.ones(3 * plane, dtype=torch.bool)
+    untouched[off:off + cout] = False; untouched[2 * plane + off:2 * plane + off + cout] = False
+    assert (cat[..., untouched] == 7.0).all()
+
+
+@pytest.mark.parametrize("H,W,c,B", [(468, 468, 128, 1), (61, 45, 256, 2), (30, 33, 64, 1)])
+def test_residual_without_a_lo_plane_comes_from_the_x8_plane(pkg, H, W, c, B):
+    """split_residual = 2: the residual tensor is [hi | - | x8] (written with split_output = 3); its value is hi + 2^-11 lo8, i.e. the fp32 value
+    to 2^-15 relative.  The lo plane of the tensor handed in holds garbage that must not be read."""
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(H + c)
+    x = torch.relu(torch.randn(B, c, H, W, generator=g) * 3.0)
+    w = torch.randn(c, c, 3, 3, generator=g) / np.sqrt(c * 9)
+    r = torch.randn(B, c, H, W, generator=g) * 4.0
+    r3 = make_triple(nhwc(r))
+    lo8 = x8_of(r3, c).reshape(B, H, W, c // 32, 2, 2, 16)[..., 0, :].reshape(B, H, W, c).view(torch.float8_e4m3fn).float()
+    rv = (r3[..., :c].double() + lo8.double() / 2048.0).permute(0, 3, 1, 2)
+    emu = torch.relu(mx_emulation(x, w, torch.zeros(c)) + rv)
+    r3[..., c:2 * c] = 123.0                                                       # the lo plane nobody may read
+    op = P.add_conv2d_op(P.conv_weight_rows(w.numpy()), None, H, W, 3 * c, c, 3, 1, 1, relu=True, has_residual=True, split_residual=2,
+                         split_output=2, split_input=2, out_channel_stride=3 * c)
+    y3 = op(make_triple(nhwc(x)).to(DEV), r3.to(DEV))[0].cpu()
+    got = split_value(y3, c).permute(0, 3, 1, 2)
+    err = (got - emu).abs().max().item() / emu.abs().max().item()
+    assert err < 8e-6, err
+    assert ((rv - r.double()).abs() <= 2.0 ** -15 * r.double().abs() + 2.0 ** -20).all()      # what the x8 residual loses against the fp32 one: 2^-4 of lo <= 2^-11 |v|
