@@ -119,6 +119,11 @@ __device__ __forceinline__ void packFragsSplit(const floatx4 (&acc)[MNT], half8 
 // come through the same DMA queue into LDS (an ordinary global load with a DMA in flight makes hipcc wait vmcnt(0));
 // x is loaded in the prologue straight into the out-proj accumulator (acc = x, + bo after the barrier) and re-read for
 // LayerNorm 3 once nothing is in flight; no store is issued before the last stage has landed.
+#ifndef MLP_SPLIT_PQ
+#define MLP_SPLIT_PQ 64            // FC1 columns per piece in the split-precision kernel.  32 (24 KB stages, 78.8 KB of LDS: TWO workgroups per CU) was built and
+                                   // measured in round 4: correct, and SLOWER -- 337 vs 318 us per four-frame launch (twice the stages and barriers; the kernel is
+                                   // bound by its matrix work, not by occupancy: without the correction-term MFMAs 237 / 251 us)
+#endif
 constexpr int MP_FLOATS = 1280;                    // bo | ln1_g | ln1_b | b1 (384) | b2 | pad  -> five 1 KB DMA rows
 constexpr int MP_BO = 0, MP_G1 = 192, MP_B1LN = 384, MP_B1 = 576, MP_B2 = 960;
 
@@ -584,6 +589,7 @@ public:
           w2_(w2, w2 + MC * MF), bo_(bo, bo + MC), b1_(b1, b1 + MF), b2_(b2, b2 + MC),
           lg_(lg, lg + (3 + has_block_ln) * MC), lb_(lb, lb + (3 + has_block_ln) * MC) {
         lg_.resize(4 * MC, 1.f); lb_.resize(4 * MC, 0.f);
+        if (split_) pq_ = MLP_SPLIT_PQ;
         auto upF = [](const std::vector<float>& src, float** d) {
             return hipMalloc(d, sizeof(float) * src.size()) == hipSuccess &&
                    hipMemcpy(*d, src.data(), sizeof(float) * src.size(), hipMemcpyHostToDevice) == hipSuccess;
@@ -660,7 +666,7 @@ public:
         if (split_) {                  // one kernel for every row count: eight waves x 16 rows, one workgroup per CU (149 KB of LDS)
             static int sdbg = -1; if (sdbg < 0) sdbg = ablateEnv("DSVT_MLP_DBG", 0);
             b.dbg = sdbg;
-            hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, 64, 3, true>), dim3(cdiv(max_rows_, MROWS)), dim3(512), 0, stream, b);
+            hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, MLP_SPLIT_PQ, 3, true>), dim3(cdiv(max_rows_, MROWS)), dim3(512), 0, stream, b);
             return lastError();
         }
         // Kernel by row count.  Up to 2.5 x 128 rows per CU (one or two frames per launch): <1,10> elastic, ONE workgroup per CU at a time
