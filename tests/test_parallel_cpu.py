@@ -38,6 +38,9 @@ def _worker(rank, world, port, n_frames, q):
     out = par.gather_results(local, n_frames, r, w)
     t = par.max_over_ranks(float(r + 1), torch.device("cpu"))
     ok = abs(t - w) < 1e-9
+    # bench.py's timing protocol: the per-repeat times of every rank meet in ONE all-reduce (element-wise maximum)
+    tv = par.max_over_ranks_vec([1.0 + r, 5.0 - 2 * r, 0.25], torch.device("cpu"))
+    ok = ok and tv == [float(w), 5.0, 0.25]
     if r == 0:
         for f in range(n_frames):
             b, c = par.unpack_result(out[f])
@@ -78,7 +81,7 @@ def _single_rank_worker(backend, port, q):
     par.barrier()
     out = par.gather_results(local, 3, r, w, force_collective=True)
     ok = ok and out is not local and torch.equal(out.cpu(), local.cpu())
-    ok = ok and par.max_over_ranks(2.5, dev) == 2.5
+    ok = ok and par.max_over_ranks(2.5, dev) == 2.5 and par.max_over_ranks_vec([1.5, 0.5], dev) == [1.5, 0.5]
     q.put((0, bool(ok)))
     torch.distributed.destroy_process_group()
 
