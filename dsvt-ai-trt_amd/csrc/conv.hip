@@ -869,7 +869,8 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         const int chunk = (lane & 3) ^ ((hx >> 1) & 2);
         const int gy = yy - 1 + hy, gx = xx - 1 + hx;
         const bool ok = hx < HTW + 2 && hy < C::HH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        const int coff = (MX && ph >= NPM) ? 64 * NPM + (ph - NPM) * 32 : ph * 32;           // (MX: phase NPM + q = 64 bytes of the x8 plane, which starts at channel 2 C)
+        const int coff = MX ? (ph >= NPM ? 64 * NPM + (ph - NPM) * 32 : ph * 32)             // (MX: phase NPM + q = 64 bytes of the x8 plane, which starts at channel 2 C)
+                            : (a.alias3 && ph * 32 >= a.alias3) ? ph * 32 - a.alias3 : ph * 32;   // (three fp16 products over an x8 third plane: its phases read plane 0)
         const _Float16* src = ok ? a.in + (size_t)((bb * a.H + gy) * a.W + gx) * a.Cin + coff + chunk * 8 : zeros;
         __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + hb * WT_HBYTES + pc * 1024), 16, 0, 0);
     };

@@ -97,7 +97,7 @@ def fold_linear_bn(w, lin, bn, eps, bias=False):
 class DsvtPipeline:
     def __init__(self, weights, caps=None, blocks=4, with_head=True, ln_eps=0.0, head_dtype=torch.float32,
                  device="cuda:0", zero_fill=False, linear_compute=P.COMPUTE_F32, fused_mlp=None,
-                 device_nms=False, pos_table=None, fork_partition=None, frames=1, head_mx=None):
+                 device_nms=False, pos_table=None, fork_partition=None, frames=1, head_mx=None, head_mx_exclude=()):
         """linear_compute: COMPUTE_F32 = fp32 MFMA everywhere (parity mode, boxes within 1e-3 of the
         fp32 oracle); COMPUTE_F16 = fp16 MFMA operands with fp32 accumulate/epilogues (BASELINE
         configs[2] "fp16"); COMPUTE_SPLIT = split-precision fp16 MFMA (fp32 grade, fused frame path).  head_dtype: precision of the
@@ -111,6 +111,7 @@ class DsvtPipeline:
         # lo w_hi + hi w_lo of every head convolution run as OCP fp8 blocks of the scaled MFMA (csrc/conv.hip conv_wide_kernel<.., MX>): the
         # activations travel as [hi | lo | x8] triples, boxes stay ~1e-4 from the fp32 oracle (1e-3 bar) at 2/3 of the matrix-pipe time
         self.head_mx = (linear_compute == P.COMPUTE_SPLIT) if head_mx is None else bool(head_mx)
+        self.head_mx_exclude = tuple(head_mx_exclude)      # layer-name fragments that keep three fp16 products although head_mx is on (error attribution: tools/mx_box_sweep.py)
         self.caps = c = caps or Caps()
         self.frames = int(frames)
         self.split = split = linear_compute == P.COMPUTE_SPLIT
@@ -330,6 +331,8 @@ class DsvtPipeline:
             # res_lo = False: the residual tensor was written without its lo plane, whose part of the value comes from the x8 plane's lo8 bytes)
             up2 = kw.get("pixel_shuffle", 1) ** 2
             wide = mx and stride == 1 and ((k == 3 and cout > 32 and up2 == 1) or (k == 1 and (up2 * cout) % 128 == 0))
+            wide = wide and not any(x in name for x in self.head_mx_exclude)
+            lo = lo or bool(self.head_mx_exclude)            # (an excluded layer reads the lo plane of its input: every tensor keeps it then)
             ops[name] = P.add_conv2d_op(np.asarray(rows, np.float32) if wide else sw(rows, k * k, cin), bias, H, H, 3 * cin, cout, k, stride, k // 2,
                                         relu=relu, has_residual=res, split_residual=(1 if (res_lo or not mx) else 2) if res else 0, out_f32=out_f32,
                                         split_output=0 if out_f32 else ((2 if lo else 3) if mx else 1), split_input=(2 if wide else 1) if mx else 0,

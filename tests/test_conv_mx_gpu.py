@@ -133,6 +133,8 @@ def test_mx_conv_is_fp32_grade(pkg, H, W, cin, cout, res, relu, B):
     (52, 47, 128, 256, 1, 2, False, False, False),    # 1 x 1 downsample
     (52, 47, 192, 128, 1, 1, False, False, False),    # 1 x 1 shortcut of the first block (halo kernel)
     (25, 31, 320, 18, 3, 1, False, False, True),      # head outputs (narrow halo kernel, fp32 out)
+    (52, 47, 128, 128, 3, 1, False, True, False),     # a 3 x 3 stride-1 layer kept on three fp16 products (conv_wide_kernel, 64-channel chunks)
+    (150, 140, 64, 320, 3, 1, False, True, False),    # ... 128-channel chunks
 ])
 def test_three_plane_kernels_read_plane_0_for_an_x8_third_plane(pkg, H, W, cin, cout, k, stride, res, relu, f32out):
     """split_input = 1: the kernels that still walk [hi | lo | hi] with [w_hi | w_hi | w_lo] rows get the same bits from a [hi | lo | x8]

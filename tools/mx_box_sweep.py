@@ -12,7 +12,8 @@ NS = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 NP = int(sys.argv[2]) if len(sys.argv) > 2 else 180000
 caps = pkg.pipeline.Caps()
 w = pkg.synth.make_weights()
-pa = pkg.pipeline.DsvtPipeline(w, caps=caps, device=dev, linear_compute=P.COMPUTE_SPLIT)                       # head_mx on (default)
+EXC = tuple(x for x in os.environ.get("EXCLUDE", "").split(",") if x)        # EXCLUDE=shared,heads0: those layers keep three fp16 products
+pa = pkg.pipeline.DsvtPipeline(w, caps=caps, device=dev, linear_compute=P.COMPUTE_SPLIT, head_mx_exclude=EXC)                       # head_mx on (default)
 pb = pkg.pipeline.DsvtPipeline(w, caps=caps, device=dev, linear_compute=P.COMPUTE_SPLIT, head_mx=False)
 worst = {}
 for s in range(NS):
