@@ -119,6 +119,9 @@ __device__ __forceinline__ void packFragsSplit(const floatx4 (&acc)[MNT], half8 
 // come through the same DMA queue into LDS (an ordinary global load with a DMA in flight makes hipcc wait vmcnt(0));
 // x is loaded in the prologue straight into the out-proj accumulator (acc = x, + bo after the barrier) and re-read for
 // LayerNorm 3 once nothing is in flight; no store is issued before the last stage has landed.
+#ifndef MLP_SPLIT_ELASTIC
+#define MLP_SPLIT_ELASTIC 1            // ten-wave single-frame variant (spills ~60 registers and is still 18 us per layer faster than two rounds of eight-wave blocks)
+#endif
 #ifndef MLP_SPLIT_PQ
 #define MLP_SPLIT_PQ 64            // FC1 columns per piece in the split-precision kernel.  32 (24 KB stages, 78.8 KB of LDS: TWO workgroups per CU) was built and
                                    // measured in round 4: correct, and SLOWER -- 337 vs 318 us per four-frame launch (twice the stages and barriers; the kernel is
@@ -187,7 +190,7 @@ __device__ __forceinline__ void mlpLayerNormLds(floatx4 (&acc)[MNT], const float
 // same rows of w_lo (48 KB stages, three slots: 149 KB, one eight-wave workgroup per CU at <= 256 registers); s1 and h are split in
 // registers where the fp16 kernel rounds them; only the fp32 result is written.
 template <int MT, int NW, int PQ, int RS, bool SPLIT = false>
-__global__ void __launch_bounds__(64 * NW, (SPLIT ? 2 : MT == 1 ? 3 : 2))
+__global__ void __launch_bounds__(64 * NW, (SPLIT ? (NW == 10 ? 1 : 2) : MT == 1 ? 3 : 2))
 encoder_mlp_stream_kernel(MlpStreamArgs a)
 {
     constexpr int PQT = PQ / 16, PQS = PQ / 32, SRH = 6 * PQT, SR = SPLIT ? 2 * SRH : SRH, SB = SR * 1024, NWO = MC / PQ, NPIECE = MF / PQ;
@@ -272,7 +275,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
         }
         if (ELASTIC) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
+            for (int j = 0; j < (SR + 7) / 8; ++j) {         // (at least eight live waves)
                 const int rw = wave + j * nwa;
                 if (rw < SR)
                     __builtin_amdgcn_global_load_lds((mlp_gsrc_t)(a.Wp + ((size_t)s * SR + rw) * 512 + lane * 8),
@@ -280,7 +283,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
             }
             return;
         }
-        if (a.dbg & 64) return;
+        if (kAblate && (a.dbg & 64)) return;
 #pragma unroll
         for (int j = 0; j < (SR + NW - 1) / NW; ++j) {
             const int rw = wave + j * NW;
@@ -300,6 +303,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
             case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
             case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
             case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); break;
             case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); break;
             case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); break;
             case 9: asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory"); break;
@@ -394,7 +398,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
 #pragma unroll
             for (int t = 0; t < PQT; ++t) {
                 const half8 wf = *reinterpret_cast<const half8*>(sl + (ks * PQT + t) * 1024);
-                if (SPLIT && !(a.dbg & 16)) {
+                if (SPLIT && (!kAblate || !(a.dbg & 16))) {
                     const half8 wl = *reinterpret_cast<const half8*>(sl + LO + (ks * PQT + t) * 1024);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
@@ -445,7 +449,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
 #pragma unroll
             for (int t = 0; t < PQT; ++t) {
                 const half8 wf = *reinterpret_cast<const half8*>(slotA + (ks * PQT + t) * 1024);
-                if (SPLIT && !(a.dbg & 16)) {
+                if (SPLIT && (!kAblate || !(a.dbg & 16))) {
                     const half8 wl = *reinterpret_cast<const half8*>(slotA + LO + (ks * PQT + t) * 1024);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
@@ -493,7 +497,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
 #pragma unroll
             for (int t = 0; t < MNT; ++t) {
                 const half8 wf = *reinterpret_cast<const half8*>(slotB + (sp * 12 + t) * 1024);
-                if (SPLIT && !(a.dbg & 16)) {
+                if (SPLIT && (!kAblate || !(a.dbg & 16))) {
                     const half8 wl = *reinterpret_cast<const half8*>(slotB + LO + (sp * 12 + t) * 1024);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
@@ -666,6 +670,15 @@ public:
         if (split_) {                  // one kernel for every row count: eight waves x 16 rows, one workgroup per CU (149 KB of LDS)
             static int sdbg = -1; if (sdbg < 0) sdbg = ablateEnv("DSVT_MLP_DBG", 0);
             b.dbg = sdbg;
+#if MLP_SPLIT_ELASTIC
+            // one frame per launch: ten-wave blocks of which 8 .. 10 waves are live, so that ONE workgroup per CU covers the rows (a 34.4k-row frame =
+            // 256 workgroups of nine waves; fixed eight-wave workgroups are 269 = a second round of 13).  The 168-register budget of ten waves spills
+            // and the variant still wins at one frame, 89.9 against 107.8 us per launch; at two frames it loses (174 against 166 us) and is not used
+            if (frames_ > 0 ? frames_ <= 1 : max_rows_ <= 5 * ncu * MROWS / 4) {
+                hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 10, MLP_SPLIT_PQ, 3, true>), dim3(cdiv(max_rows_, MROWS)), dim3(640), 0, stream, b);
+                return lastError();
+            }
+#endif
             hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, MLP_SPLIT_PQ, 3, true>), dim3(cdiv(max_rows_, MROWS)), dim3(512), 0, stream, b);
             return lastError();
         }
