@@ -20,7 +20,9 @@ SOURCES = [
     ("attention.hip", []),
     ("conv.hip", []),
     ("mlp.hip", []),
-    ("pfn.hip", []),
+    # -fno-honor-nans: fmaxf() is llvm.maxnum, which without it costs THREE v_max_f32 (both operands canonicalised first); pfn_kernel is bound
+    # by VALU issue and its maxima run over MFMA sums of finite inputs
+    ("pfn.hip", ["-fno-honor-nans"]),
     ("decode.hip", []),
     ("nms.hip", ["-ffp-contract=off"]),
 ]

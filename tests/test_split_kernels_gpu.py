@@ -75,9 +75,11 @@ def test_split_operand_range(pkg):
     assert (got[0, 1:n].double().cpu() - ref[1:]).abs().max().item() < 2e-5 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("block_ln,MR,n", [(False, 8192, 5504), (True, 8192, 5504), (False, 8192, 1), (True, 8192, 17),
-                                             (True, 65536, 34483), (False, 196608, 137932), (True, 196608, 131072 + 33)])
-def test_encoder_mlp_split_against_reference_wiring(pkg, block_ln, MR, n):
+@pytest.mark.parametrize("block_ln,MR,n,frames", [(False, 8192, 5504, 0), (True, 8192, 5504, 0), (False, 8192, 1, 0), (True, 8192, 17, 0),
+                                                    (True, 65536, 34483, 0), (False, 196608, 137932, 0), (True, 196608, 131072 + 33, 0),
+                                                    # frames=1: the ten-wave elastic kernel with nine, ten and (two rounds) eight live waves
+                                                    (True, 65536, 34483, 1), (False, 65536, 40951, 1), (True, 65536, 47003, 1), (False, 65536, 3, 1)])
+def test_encoder_mlp_split_against_reference_wiring(pkg, block_ln, MR, n, frames):
     """src/dsvt-ai-trt.cpp:669-756 in fp64 on the fp32 operands, NO operand rounding anywhere: the split kernel must be within
     fp32-arithmetic distance (LayerNorm outputs are O(1): 2e-5 max, 1e-6 mean), 200x below the fp16 kernel's distance."""
     P = pkg.plugin
@@ -95,7 +97,7 @@ def test_encoder_mlp_split_against_reference_wiring(pkg, block_ln, MR, n):
     xb = np.zeros((MR, C), np.float32); xb[:n] = rng.standard_normal((n, C))
     mlp = P.add_encoder_mlp_op(w[lp + ".win_attn.self_attn.out_proj.weight"], w[lp + ".win_attn.self_attn.out_proj.bias"],
                                w[lp + ".win_attn.linear1.weight"], w[lp + ".win_attn.linear1.bias"],
-                               w[lp + ".win_attn.linear2.weight"], w[lp + ".win_attn.linear2.bias"], lns, MR, split_precision=True)
+                               w[lp + ".win_attn.linear2.weight"], w[lp + ".win_attn.linear2.bias"], lns, MR, split_precision=True, frames=frames)
     assert mlp.nb_outputs == 1
     args = [dev(att[None]), scalar(n), dev(x[None])] + ([dev(xb[None])] if block_ln else [])
     got, = mlp(*args)
