@@ -393,7 +393,7 @@ def roofline_rows(prof, sampled, counts, pool_len, FB, mode, n_points_per_launch
         return (0.0, 0.0)
 
     resident_qkv = f16 and FB >= 3          # (csrc/linear.hip: row capacity of three or more frames -> the resident-weights kernel)
-    qkv_name = ("linear_split_rows_kernel (QKV at fp32 grade: (hi, lo) fp16 operands, 3 x v_mfma_f32_16x16x32_f16 per product, weights by LDS-DMA)" if split else
+    qkv_name = ("linear_split_resident_kernel (QKV at fp32 grade: (hi, lo) fp16 operands, 3 x v_mfma_f32_16x16x32_f16 per product; a third of (w_hi, w_lo) resident in LDS per CU, waves walk 16-row tiles)" if split else
                 "linear_f16_resident_kernel (QKV: half of W_qkv resident in LDS per CU, waves walk 16-row tiles, v_mfma_f32_16x16x32_f16)" if resident_qkv else
                 "linear_f16_rows_kernel (QKV: all column chunks of a row tile per workgroup, v_mfma_f32_16x16x32_f16, weights by LDS-DMA)" if f16 else
                 "linear_f32_kernel (v_mfma_f32_16x16x4_f32)")
@@ -401,14 +401,14 @@ def roofline_rows(prof, sampled, counts, pool_len, FB, mode, n_points_per_launch
     # matrix peak of one fp32-grade product: three fp16 MFMAs (2.5 PF / 3), or on the fp16 + fp8 K loop one fp16 MFMA + two e4m3 products at the
     # 5 PF dense MX-fp8 rate with ten tap slots for nine taps: 2.5 PF / (1 + 2 (10 / 9) / 2)
     PEAK_SPLIT3, PEAK_MX = PEAK_F16_MATRIX_TFLOPS / 3.0, PEAK_F16_MATRIX_TFLOPS / (1.0 + 10.0 / 9.0)
-    meta = {"DsvtLinearPlugin": (qkv_name, "mfma" if mode == "f32" else "hbm", "linear_split_rows_kernel" if split else "linear_f16_resident_kernel" if resident_qkv else "linear_f16_rows_kernel" if f16 else "linear_f32_kernel<true>"),
+    meta = {"DsvtLinearPlugin": (qkv_name, "mfma" if mode == "f32" else "hbm", "linear_split_resident_kernel" if split else "linear_f16_resident_kernel" if resident_qkv else "linear_f16_rows_kernel" if f16 else "linear_f32_kernel<true>"),
             "DsvtEncoderMlpPlugin": ("encoder_mlp_stream_kernel (out-proj+LN -> FC1+GELU -> FC2+LN+LN, v_mfma_f32_16x16x32_f16, weights by LDS-DMA)" + sp_, "hbm", "encoder_mlp_stream_kernel"),
             "DsvtSetAttentionPlugin": ("set_attention_f16_kernel (v_mfma_f32_16x16x32_f16)" if f16 else
                                        "set_attention_split_kernel ((hi, lo) images of Q, K, V^T in LDS, 3 x v_mfma_f32_16x16x32_f16 per product, fp32 I/O)" if split else
                                        "set_attention_kernel (v_mfma_f32_16x16x4_f32, fp32 I/O)", "hbm",
                                        "set_attention_f16_kernel" if f16 else "set_attention_split_kernel" if split else "set_attention_kernel("),
             "DsvtPosEmbedPlugin": ("posembed_batched_kernel (8 position-embedding MLPs, v_mfma_f32_16x16x32_f16)", "hbm", "posembed_batched_kernel"),
-            "DsvtPillarFeatureNetPlugin": ("pfn_kernel (both PFN layers + scatter-max, v_mfma_f32_16x16x4_f32 + 16x16x32_f16; peak = the mix of the two matrix rates; the kernel is bound by the round trips of its 16-pillar groups, not by either)" + sp_, "mfma", "pfn_kernel"),
+            "DsvtPillarFeatureNetPlugin": ("pfn_kernel (both PFN layers + scatter-max, v_mfma_f32_16x16x4_f32 + 16x16x32_f16; peak = the mix of the two matrix rates; a wave owns a work-balanced group of up to 16 pillars; bound by dependent LDS / L2 round trips at two waves per SIMD, not by either)" + sp_, "mfma", "pfn_kernel"),
             "DsvtConv2dPlugin": ("conv_wide_kernel / conv_halo_kernel / conv_f16_kernel (implicit GEMM, v_mfma_f32_16x16x32_f16)" +
                                  (" -- 3 x 3 stride-1 layers with > 32 output channels (93 % of the products) on the fp16 + fp8 K loop over [hi | x8]: one fp16 MFMA product + "
                                   "two e4m3 correction products (v_mfma_scale_f32_16x16x128_f8f6f4) per fp32-grade product; the other layers walk [hi | lo | hi] x "

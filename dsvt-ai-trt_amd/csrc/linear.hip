@@ -980,6 +980,150 @@ linear_split_rows_kernel(LinearArgs a, const _Float16* __restrict__ Wp)
     }
 }
 
+// -------------------------------------------------------------------------------------
+// Split-precision QKV with the weights RESIDENT in LDS (round 4).  The kernel above streams all 442 KB of (w_hi, w_lo) through LDS for every
+// 128 rows -- at the ~25 GB/s a CU's LDS-DMA path delivers that is 17.7 us per workgroup where its MFMAs are 10 us, 184 us per four-frame
+// launch and, with 269 workgroups of a frame on 256 CUs, two rounds (76 us) for one frame.  Here a CU keeps a THIRD of the output columns --
+// four 48-column stages of w_hi + w_lo, 144 KB -- for the whole launch (workgroups cycle through the three thirds, so every activation row is
+// read by three workgroups of neighbouring CUs: from L2 after the first) and its eight waves walk the 16-row tiles independently, no barrier
+// after the prologue, like linear_f16_resident_kernel.  A third lies wholly inside or outside the "x + position" columns (add_cols a multiple
+// of 192), so a workgroup splits ONE operand per row tile (48 registers); the fp32 rows of the next tile are requested as soon as the current
+// tile's are split (their registers are dead by then) and land under its 216 MFMAs.
+constexpr int RSS_NW = 8, RSS_SPT = 4;
+template <bool TABLE>             // the A2 rows are gathered through the window cell (a2_c2d)
+__global__ void __launch_bounds__(64 * RSS_NW, 1)
+linear_split_resident_kernel(LinearArgs a, const _Float16* __restrict__ Wp, int dbg)      // dbg (ablation build): 1 no MFMA, 2 no stores, 4 rows not split, 8 rows loaded once
+{
+    __shared__ __attribute__((aligned(16))) unsigned char ring[RSS_SPT * SBYTES + 4096];   // four weight stages + the bias (<= 1024 floats)
+    const int M = rowLimit(a);
+    if (M <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+    // the three workgroups of a row stream on ONE XCD (workgroups go to the eight XCDs round-robin, each with its own L2): the rows the first of them
+    // fetches are L2 hits for the other two.  Per XCD the slots b / 8 = 0 .. 3 q - 1 form q streams; the slots left over form streams across XCDs
+    constexpr int ntype = 3;
+    const int q = (int)gridDim.x / 8 / ntype;                        // streams per XCD
+    const int xcd = (int)blockIdx.x % 8, sl = (int)blockIdx.x / 8;
+    const int nj = 8 * q + ((int)gridDim.x - 8 * q * ntype) / ntype;
+    int type, j;
+    if (sl < q * ntype) { type = sl % ntype; j = xcd * q + sl / ntype; }
+    else {
+        const int lo = (sl - q * ntype) * 8 + xcd;                    // leftover workgroups, in blockIdx order
+        type = lo % ntype; j = 8 * q + lo / ntype;
+        if (j >= nj) return;
+    }
+    for (int row = wave; row < RSS_SPT * SROWS; row += RSS_NW)
+        __builtin_amdgcn_global_load_lds((glds_src_t)(Wp + ((size_t)(type * RSS_SPT) * SROWS + row) * 512 + lane * 8), (glds_dst_t)(ring + row * 1024), 16, 0, 0);
+    if (wave < 4) {
+        const int f0 = wave * 256 + lane * 4;
+        const float* src = a.bias ? a.bias + (f0 + 3 < a.N ? f0 : 0) : reinterpret_cast<const float*>(Wp);       // (unused lanes: any valid address)
+        __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(ring + RSS_SPT * SBYTES + wave * 1024), 16, 0, 0);
+    }
+    const uint32_t bias_lds = (uint32_t)(uintptr_t)(glds_dst_t)(ring + RSS_SPT * SBYTES);
+    const int ntile = (M + 15) >> 4, step = nj * RSS_NW;
+    int tt = j * RSS_NW + wave;
+    const int nbase = type * RSS_SPT * SP_COLS;                        // first output column of this third
+    const bool add = nbase < a.add_cols;                              // the operand is x + A2 row (q, k) or x alone (v)
+    // the window cell of this lane's row of tile t (the position table's gather index); prefetches past the last tile re-read the last tile
+    auto cellOf = [&](int t) -> int2 {
+        t = t < ntile ? t : ntile - 1;
+        const int row = t * 16 + r, rc = row < M ? row : M - 1;
+        if (!TABLE) return make_int2(0, rc);
+        const int32_t* c = a.a2_c2d + (size_t)rc * 3;
+        return make_int2(c[0] * a.a2_wy + c[1], c[2]);      // (z * wy + y, x): a2_wy = 0 for the pillar model's 2-D tables
+    };
+    floatx4 xv[2 * NSTEP], pv[2 * NSTEP];
+    auto loadRows = [&](int t, int2 cell) {
+        t = t < ntile ? t : ntile - 1;
+        const int row = t * 16 + r, rc = row < M ? row : M - 1;
+        const float* px = static_cast<const float*>(a.A) + (size_t)rc * KS + g * 8;
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) { xv[2 * s] = *reinterpret_cast<const floatx4*>(px + s * 32); xv[2 * s + 1] = *reinterpret_cast<const floatx4*>(px + s * 32 + 4); }
+        if (add) {
+            const float* pp = static_cast<const float*>(a.A2) + (size_t)((TABLE ? cell.x * a.a2_wx : 0) + cell.y) * KS + g * 8;
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) { pv[2 * s] = *reinterpret_cast<const floatx4*>(pp + s * 32); pv[2 * s + 1] = *reinterpret_cast<const floatx4*>(pp + s * 32 + 4); }
+        }
+    };
+    const unsigned char* slot = ring + lane * 16;
+    if (tt >= ntile) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); return; }
+    loadRows(tt, cellOf(tt));
+    int2 cellN = cellOf(tt + step);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the weights (and the first rows) have landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    while (tt < ntile) {
+        const int row = tt * 16 + r;
+        half8 fh[NSTEP], fl[NSTEP];
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            if (kAblate && (dbg & 4)) { fh[s] = __builtin_bit_cast(half8, xv[2 * s]); fl[s] = __builtin_bit_cast(half8, xv[2 * s + 1]); continue; }
+            const HiLo8 f = add ? splitFrag(pv[2 * s] + xv[2 * s], pv[2 * s + 1] + xv[2 * s + 1])      // q = k = x + pos in fp32 (getValueByIndex.cu:299-301)
+                                : splitFrag(xv[2 * s], xv[2 * s + 1]);
+            fh[s] = f.hi; fl[s] = f.lo;
+        }
+        // the next tile's rows into the registers just split (in flight under this tile's MFMAs), the gather index of the one after
+        const int tn = tt + step;
+        asm volatile("" ::: "memory");
+        if (!kAblate || !(dbg & 8)) loadRows(tn, cellN);
+        cellN = cellOf(tn + step);
+        // 24 steps (stage h2 = 48 columns, k-step ks) of nine MFMAs; the six weight fragments of step i + 1 are read before the MFMAs of step i
+        half8 wq[2][6];
+        auto loadFr = [&](int i, half8 (&w)[6]) {
+            const unsigned char* sp = slot + (i / NSTEP) * SBYTES + (i % NSTEP) * 6 * 1024;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) w[t] = *reinterpret_cast<const half8*>(sp + t * 1024);
+        };
+        loadFr(0, wq[0]);
+#pragma unroll
+        for (int c = 0; c < RSS_SPT / 2; ++c) {                       // 96 columns at a time
+            floatx4 acc[6];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int ks = 0; ks < NSTEP; ++ks) {
+                    const int i = (2 * c + h) * NSTEP + ks;
+                    if (i + 1 < RSS_SPT * NSTEP) loadFr(i + 1, wq[(i + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const half8 (&w)[6] = wq[i & 1];
+                    if (kAblate && (dbg & 1)) { acc[3 * h][0] += (float)w[0][0] + (float)w[5][7] + (float)fh[ks][0] + (float)fl[ks][1]; continue; }
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) acc[3 * h + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[3 + t], fh[ks], acc[3 * h + t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) acc[3 * h + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[t], fl[ks], acc[3 * h + t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) acc[3 * h + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[t], fh[ks], acc[3 * h + t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const int n0 = nbase + c * 2 * SP_COLS;
+#pragma unroll
+            for (int t = 0; t < 6; t += 2) {
+                floatx4 X = acc[t], Y = acc[t + 1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(X[i]), __float_as_uint(Y[i]), false, false);
+                    X[i] = __uint_as_float(sw[0]); Y[i] = __uint_as_float(sw[1]);
+                }
+                const int col = n0 + t * 16 + (g & 1) * 16 + (g >> 1) * 8;       // the lane's eight columns after the swap are contiguous
+                if (a.bias) {
+                    const floatx4 b0 = *reinterpret_cast<const floatx4*>(ring + RSS_SPT * SBYTES + col * 4), b1 = *reinterpret_cast<const floatx4*>(ring + RSS_SPT * SBYTES + col * 4 + 16);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { X[i] += b0[i]; Y[i] += b1[i]; }
+                }
+                if (row < M && (!kAblate || !(dbg & 2) || X[0] == 1.2345f)) {
+                    float* o = a.out + (size_t)row * a.out_ld + col;
+                    *reinterpret_cast<float4*>(o) = make_float4(X[0], X[1], X[2], X[3]);
+                    *reinterpret_cast<float4*>(o + 4) = make_float4(Y[0], Y[1], Y[2], Y[3]);
+                }
+            }
+        }
+        tt = tn;
+    }
+    (void)bias_lds;
+}
+
 // stage image of the split kernel: stage s = output columns [48 s, 48 s + 48), row (ks, t) = w_hi of column tile t for t < 3, w_lo of tile t - 3 above
 static std::vector<_Float16> packStagesSplit(const float* W, int N) {
     std::vector<_Float16> out((size_t)(N / SP_COLS) * SROWS * 512);
@@ -996,6 +1140,17 @@ static std::vector<_Float16> packStagesSplit(const float* W, int N) {
 }
 
 static int launchLinearSplit(const LinearArgs& a, const _Float16* Wp, hipStream_t stream) {
+    static int resident = -1;      // DSVT_LINEAR_RESIDENT=0: the streamed kernel for every shape
+    if (resident < 0) resident = ablateEnv("DSVT_LINEAR_RESIDENT", 1);
+    if (resident && a.N == 3 * RSS_SPT * SP_COLS && (a.add_cols % (RSS_SPT * SP_COLS)) == 0) {
+        static int ncu = 0;
+        if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }
+        const int ng = ncu;                                             // (the kernel forms row streams of three workgroups per XCD; at most two workgroups idle)
+        static int dbg = -1; if (dbg < 0) dbg = ablateEnv("DSVT_QKV_DBG", 0);
+        if (a.a2_c2d) hipLaunchKernelGGL(linear_split_resident_kernel<true>, dim3(ng), dim3(64 * RSS_NW), 0, stream, a, Wp, dbg);
+        else hipLaunchKernelGGL(linear_split_resident_kernel<false>, dim3(ng), dim3(64 * RSS_NW), 0, stream, a, Wp, dbg);
+        return lastError();
+    }
     const dim3 grid(cdiv(a.max_rows, 16 * SP_NW)), block(64 * SP_NW);
     if (a.a2_c2d) hipLaunchKernelGGL(linear_split_rows_kernel<true>, grid, block, 0, stream, a, Wp);
     else hipLaunchKernelGGL(linear_split_rows_kernel<false>, grid, block, 0, stream, a, Wp);

@@ -1,6 +1,6 @@
 """Per-layer durations of the 3 x 3 stride-1 layers of the dense stage in the three arithmetic variants (HIP events over REPS launches,
 B images per launch):  f16 | split, three fp16 products over [hi | lo | hi] | split, fp16 + fp8 K loop over [hi | lo | x8].
-    python tools/bench_conv_mx.py [B] [variants: f16,split,mx]"""
+    python tools/bench_conv_mx.py [B] [variants: f16,split,mx]      ONLY=<indices of LAYERS, comma separated>: those layers only (PMC passes)"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,6 +15,8 @@ OCC = float(os.environ.get("OCC", "0.35"))          # fraction of non-zero pixel
 LAYERS = [  # H, cin, cout, residual, how many times in the network
     (468, 192, 128, False, 1), (468, 128, 128, True, 2), (468, 128, 128, False, 1), (234, 128, 128, True, 3), (234, 128, 128, False, 2),
     (117, 256, 256, True, 3), (117, 256, 256, False, 2), (468, 384, 64, False, 1), (468, 64, 320, False, 1)]
+if os.environ.get("ONLY"):
+    LAYERS = [LAYERS[int(i)] for i in os.environ["ONLY"].split(",")]
 rng = np.random.default_rng(0)
 tot = {v: 0.0 for v in variants}
 for H, cin, cout, res, cnt in LAYERS:
