@@ -144,6 +144,61 @@ def test_pillar_feature_net_split_against_oracle(pkg, oracle, frame, capname, n_
     assert again.serialize() == op.serialize() and torch.equal(again(feat, pidx, pcnt, Pn)[0], v)
 
 
+def _pfn_fp64(feat, counts, W0, b0, W1, b1):
+    """src/dsvt-ai-trt.cpp:565-589 in fp64 on the fp32 operands: x0 = ReLU(FC0 f), m = max over the pillar, x1 = ReLU(FC1 [x0 | m]), max over the pillar"""
+    f = feat.astype(np.float64)
+    x0 = np.maximum(f @ W0.astype(np.float64).T + b0, 0.0)
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    seg = np.repeat(np.arange(len(counts)), counts)
+    m = np.maximum.reduceat(x0, starts[:-1], axis=0)
+    x1 = np.maximum(np.concatenate([x0, m[seg]], axis=1) @ W1.astype(np.float64).T + b1, 0.0)
+    return np.maximum.reduceat(x1, starts[:-1], axis=0)
+
+
+@pytest.mark.parametrize("split", [True, False])
+@pytest.mark.parametrize("kind,P_", [("ones", 1), ("ones", 17), ("ones", 3000), ("full", 1), ("full", 16), ("full", 700), ("mixed", 5), ("mixed", 1023), ("mixed", 1025),
+                                      ("mixed", 20000), ("mixed", 60000), ("lumpy", 50000), ("huge", 9)])
+def test_pillar_feature_net_any_pillar_sizes(pkg, split, kind, P_):
+    """pfn_kernel cuts the pillars into groups of equal WORK (8 + points per pillar, 128 units per group) and finds a group's first pillar by searching the
+    row-start prefix: tables of every shape -- single points only (sixteen pillars per group), full 48-point pillars (two or three per group), runs of
+    dense pillars between sparse ones (the coarse samples of the search fall into very unequal intervals), launches on both sides of the ~47k pillars
+    where the search adds its probe round, one pillar, and pillars of more points than a group's budget (200: their groups have no other member and the
+    intervals between them hold no pillar at all).  fp64 restatement of the reference wiring on the same fp32 rows; 1e-5 of the scale in split precision,
+    1.5e-3 with fp16 operands."""
+    P = pkg.plugin
+    rng = np.random.default_rng(1000 * P_ + len(kind))
+    T = 48
+    if kind == "ones": counts = np.ones(P_, np.int64)
+    elif kind == "full": counts = np.full(P_, T, np.int64)
+    elif kind == "huge": counts = np.where(np.arange(P_) % 3 == 1, 200, rng.integers(1, 6, P_)).astype(np.int64)
+    elif kind == "lumpy":
+        counts = rng.integers(1, 3, P_).astype(np.int64)
+        for a_ in rng.integers(0, P_ - 400, 12): counts[a_:a_ + rng.integers(50, 400)] = rng.integers(30, T + 1)
+    else: counts = np.minimum(rng.geometric(0.25, P_), T).astype(np.int64)
+    Tcap = int(max(T, counts.max()))
+    Nk = int(counts.sum()); cap_p = P_ + 37; cap_n = Nk + 11
+    w = pkg.synth.make_weights(with_bev=False)
+    W0, b0 = pkg.pipeline.fold_linear_bn(w, "module.vfe.pfn_layers.0.linear", "module.vfe.pfn_layers.0.norm", 1e-5)
+    W1, b1 = pkg.pipeline.fold_linear_bn(w, "module.vfe.pfn_layers.1.linear", "module.vfe.pfn_layers.1.norm", 1e-5)
+    feat = np.zeros((1, cap_n, 10), np.float32)
+    feat[0, :Nk] = rng.standard_normal((Nk, 10)).astype(np.float32) * np.array([30, 30, 2, 0.3, 0.2, 0.2, 0.5, 0.1, 0.1, 1.0], np.float32)
+    starts = np.concatenate([[0], np.cumsum(counts)])[:-1]
+    pidx = np.zeros((1, cap_p, Tcap), np.int32); pcnt = np.zeros((1, cap_p, 1), np.int32)
+    pidx[0, :P_, 0] = starts                                       # (the fused kernel reads slot 0 = the pillar's first row; the rows of a pillar are consecutive)
+    pcnt[0, :P_, 0] = counts
+    op = P.add_pillar_feature_net_op(cap_p, W0, b0, W1, b1, split_precision=split)
+    out = op(dev(feat), dev(pidx), dev(pcnt), scalar(P_))
+    torch.cuda.synchronize()
+    got = host(out[0])[0]
+    ref = _pfn_fp64(feat[0, :Nk], counts, W0, b0, W1, b1)
+    scale = np.abs(ref).max()
+    err = np.abs(got[:P_] - ref).max()
+    assert err < (1e-5 if split else 1.5e-3) * scale, (err, scale)
+    assert not got[P_:].any()
+    if not split:
+        assert np.abs(host(out[1])[0, :P_].astype(np.float32) - got[:P_]).max() <= 2.0 ** -11 * scale * 1.01
+
+
 @pytest.mark.parametrize("frame", ["000000", "lidar180000"])
 def test_backbone_features_split_mode(pkg, oracle, frame):
     """voxel features after the four DSVT blocks, split-precision frame path against the fp32 oracle (2e-4: the bar of the exact-fp32 mode)"""
