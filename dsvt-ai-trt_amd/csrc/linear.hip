@@ -988,7 +988,12 @@ linear_split_rows_kernel(LinearArgs a, const _Float16* __restrict__ Wp)
 // read by three workgroups of neighbouring CUs: from L2 after the first) and its eight waves walk the 16-row tiles independently, no barrier
 // after the prologue, like linear_f16_resident_kernel.  A third lies wholly inside or outside the "x + position" columns (add_cols a multiple
 // of 192), so a workgroup splits ONE operand per row tile (48 registers); the fp32 rows of the next tile are requested as soon as the current
-// tile's are split (their registers are dead by then) and land under its 216 MFMAs.
+// tile's are split (their registers are dead by then) and land under its 216 MFMAs.  133 us per four-frame launch, 51 (one frame, the pipeline's tables) against
+// 184 / 76; DSVT_QKV_DBG ladder of the ablation build on tools/bench_qkv_split.py (dense position rows, 236 us): without stores 163, without the row loads 167,
+// without MFMAs 207, nothing but the fragment reads and the loop 62 -- the fragment reads (144 KB per tile and wave, ~110 B per cycle and CU) are the floor
+// under the 421 MB of fp32 traffic (3.2 TB/s mixed).  Walking PAIRS of row tiles per wave (k-step outermost, operands split one 32-channel slice at a time,
+// 96 accumulator registers: every fragment feeds six MFMAs) was built and is bit-identical: 1.17 ms per eight launches against 1.07 at four frames (the 24
+// stores of a pair leave in one burst), 0.39 against 0.41 at one -- not kept.
 constexpr int RSS_NW = 8, RSS_SPT = 4;
 template <bool TABLE>             // the A2 rows are gathered through the window cell (a2_c2d)
 __global__ void __launch_bounds__(64 * RSS_NW, 1)
