@@ -410,12 +410,14 @@ static Registrar g_geReg(&g_geCreator);
 // =====================================================================================
 __global__ void __launch_bounds__(256)
 map2bev_kernel(const float4* __restrict__ feat, const uint4* __restrict__ coords, const uint32_t* __restrict__ voxel_num,
-               int G, int gx, int gy, int frames, float4* __restrict__ bev)
+               int G, int gx, int gy, int frames, float4* __restrict__ bev, uint4* __restrict__ save_coords, uint32_t* __restrict__ save_num)
 {
     size_t total = (size_t)(*voxel_num) * G;
+    if (save_num && blockIdx.x == 0 && threadIdx.x == 0) *save_num = *voxel_num;      // (persistent_output: the cells the next call clears)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         size_t p = i / G; int c = (int)(i % G);
         uint4 co = coords[p];                                                        // map2bev.cu:259-261: y = .z, x = .w
+        if (save_coords && c == 0) save_coords[p] = co;
         if (co.x >= (uint32_t)frames) continue;                                      // (.x = frame index of a multi-frame voxelizer, 0 otherwise)
         bev[(((size_t)co.x * gy + co.z) * gx + co.w) * G + c] = feat[i];             // :264
     }
@@ -425,12 +427,14 @@ map2bev_kernel(const float4* __restrict__ feat, const uint4* __restrict__ coords
 typedef _Float16 mb_half4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256)
 map2bev_split_kernel(const float4* __restrict__ feat, const uint4* __restrict__ coords, const uint32_t* __restrict__ voxel_num,
-                     int G, int gx, int gy, int frames, mb_half4* __restrict__ bev, int x8)
+                     int G, int gx, int gy, int frames, mb_half4* __restrict__ bev, int x8, uint4* __restrict__ save_coords, uint32_t* __restrict__ save_num)
 {
     size_t total = (size_t)(*voxel_num) * G;
+    if (save_num && blockIdx.x == 0 && threadIdx.x == 0) *save_num = *voxel_num;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         size_t p = i / G; int c = (int)(i % G);
         uint4 co = coords[p];
+        if (save_coords && c == 0) save_coords[p] = co;
         if (co.x >= (uint32_t)frames) continue;
         const float4 v = feat[i];
         const float f[4] = {v.x, v.y, v.z, v.w};
@@ -450,11 +454,45 @@ map2bev_split_kernel(const float4* __restrict__ feat, const uint4* __restrict__ 
         } else o[2 * G] = hi;
     }
 }
+// persistent_output (round 4): the dense map is zero everywhere but at <= P cells, so when the caller keeps the SAME output buffer from call to call (this
+// pipeline's buffers are static) a call needs to zero only the cells the call before it wrote -- 40 MB per frame instead of the 126 / 252 / 504 MB fill
+// (fp16 / fp32 / triple map), which at four frames per launch was 133 of the plugin's 201 us.  The plugin remembers the coordinates it scattered (device
+// buffer) and the output address (host); any other address, and the first call, take the full fill.
+__global__ void __launch_bounds__(256)
+map2bev_clear_kernel(const uint4* __restrict__ prev_coords, const uint32_t* __restrict__ prev_num, int CH, int gx, int gy, int frames, uint4* __restrict__ bev)
+{
+    const size_t total = (size_t)(*prev_num) * CH;                                   // CH = 16-byte chunks per cell
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / CH; const int c = (int)(i % CH);
+        const uint4 co = prev_coords[p];
+        if (co.x >= (uint32_t)frames) continue;
+        bev[(((size_t)co.x * gy + co.z) * gx + co.w) * CH + c] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
 class Map2BevPlugin : public Plugin {
 public:
     int max_pillars_num_, channel_num_, gx_, gy_, frames_ = 1;      // frames_ > 1 (field "frames"): coords.x selects one of `frames` stacked BEV maps
     int split_ = 0;                                                 // field "split_output": fp32 rows -> fp16 [hi | lo | hi] planes (1) or [hi | lo | x8] (2), 3 C channels per cell
-    Map2BevPlugin(int mp, int c, int gx, int gy, int frames = 1, int split = 0) : max_pillars_num_(mp), channel_num_(c), gx_(gx), gy_(gy), frames_(frames), split_(split) {}
+    int persistent_ = 0;                                            // field "persistent_output": see map2bev_clear_kernel
+    uint4* prev_coords_ = nullptr; uint32_t* prev_num_ = nullptr; void* last_out_ = nullptr;
+    Map2BevPlugin(int mp, int c, int gx, int gy, int frames = 1, int split = 0, int persistent = 0)
+        : max_pillars_num_(mp), channel_num_(c), gx_(gx), gy_(gy), frames_(frames), split_(split), persistent_(persistent) {
+        if (persistent_) {
+            if (hipMalloc(&prev_coords_, sizeof(uint4) * (size_t)mp) != hipSuccess || hipMalloc(&prev_num_, sizeof(uint32_t)) != hipSuccess ||
+                hipMemset(prev_num_, 0, sizeof(uint32_t)) != hipSuccess) { persistent_ = 0; }
+        }
+    }
+    ~Map2BevPlugin() override { if (prev_coords_) (void)hipFree(prev_coords_); if (prev_num_) (void)hipFree(prev_num_); }
+    // zero the map: everything, or (same buffer as last time) the cells of the previous call
+    int clearMap(void* out, size_t bytes, int cellBytes, hipStream_t stream) {
+        if (persistent_ && out == last_out_) {
+            hipLaunchKernelGGL(map2bev_clear_kernel, dim3(1024), dim3(256), 0, stream, prev_coords_, prev_num_, cellBytes / 16, gx_, gy_, frames_, static_cast<uint4*>(out));
+            return lastError();
+        }
+        DSVT_CHECK(hipMemsetAsync(out, 0, bytes, stream));
+        last_out_ = persistent_ ? out : nullptr;
+        return 0;
+    }
     const char* type() const override { return "Map2BevPlugin"; }
     int nbOutputs() const override { return 1; }
     int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
@@ -473,43 +511,47 @@ public:
     int enqueue(const DsvtPluginTensorDesc* inDesc, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void*,
                 hipStream_t stream) override {
         if (split_) {
-            DSVT_CHECK(hipMemsetAsync(out[0], 0, (size_t)2 * gx_ * gy_ * 3 * channel_num_ * frames_, stream));
+            if (int rc = clearMap(out[0], (size_t)2 * gx_ * gy_ * 3 * channel_num_ * frames_, 2 * 3 * channel_num_, stream)) return rc;
             hipLaunchKernelGGL(map2bev_split_kernel, dim3(2048), dim3(256), 0, stream, static_cast<const float4*>(in[0]),
                                static_cast<const uint4*>(in[1]), static_cast<const uint32_t*>(in[2]), channel_num_ / 4, gx_, gy_, frames_,
-                               static_cast<mb_half4*>(out[0]), split_ == 2 ? 1 : 0);
+                               static_cast<mb_half4*>(out[0]), split_ == 2 ? 1 : 0, persistent_ ? prev_coords_ : nullptr, persistent_ ? prev_num_ : nullptr);
             return lastError();
         }
         const int esz = (inDesc && inDesc[0].type == DSVT_HALF) ? 2 : 4;
         if ((channel_num_ * esz) % 16 != 0) return -3;
         // the dense map must be zero wherever no pillar lands, so this fill is not optional (:303)
-        DSVT_CHECK(hipMemsetAsync(out[0], 0, (size_t)esz * gx_ * gy_ * channel_num_ * frames_, stream));
+        if (int rc = clearMap(out[0], (size_t)esz * gx_ * gy_ * channel_num_ * frames_, esz * channel_num_, stream)) return rc;
         hipLaunchKernelGGL(map2bev_kernel, dim3(2048), dim3(256), 0, stream, static_cast<const float4*>(in[0]),
                            static_cast<const uint4*>(in[1]), static_cast<const uint32_t*>(in[2]), channel_num_ * esz / 16, gx_, gy_, frames_,
-                           static_cast<float4*>(out[0]));
+                           static_cast<float4*>(out[0]), persistent_ ? prev_coords_ : nullptr, persistent_ ? prev_num_ : nullptr);
         return lastError();
     }
-    size_t serializationSize() const override { return (split_ ? 6 : frames_ > 1 ? 5 : 4) * sizeof(int); }
+    // trailing ints: [frames [split [persistent]]], each present when it or a later one is not the default
+    int nTrail() const { return persistent_ ? 3 : split_ ? 2 : frames_ > 1 ? 1 : 0; }
+    size_t serializationSize() const override { return (4 + nTrail()) * sizeof(int); }
     void serialize(void* b) const override {
         char* d = static_cast<char*>(b); wr<int>(d, max_pillars_num_); wr<int>(d, channel_num_); wr<int>(d, gx_); wr<int>(d, gy_);
-        if (frames_ > 1 || split_) wr<int>(d, frames_);
-        if (split_) wr<int>(d, split_);
+        if (nTrail() >= 1) wr<int>(d, frames_);
+        if (nTrail() >= 2) wr<int>(d, split_);
+        if (nTrail() >= 3) wr<int>(d, persistent_);
     }
-    Plugin* clone() const override { return new Map2BevPlugin(max_pillars_num_, channel_num_, gx_, gy_, frames_, split_); }
+    Plugin* clone() const override { return new Map2BevPlugin(max_pillars_num_, channel_num_, gx_, gy_, frames_, split_, persistent_); }
 };
-static Plugin* mbNew(int mp, int c, int gx, int gy, int frames = 1, int split = 0) {
+static Plugin* mbNew(int mp, int c, int gx, int gy, int frames = 1, int split = 0, int persistent = 0) {
     if (split < 0 || split > 2 || (split == 2 && c % 32 != 0)) return nullptr;                 // 2: [hi | lo | x8], the x8 plane in 32-channel groups
-    return (mp > 0 && c > 0 && c % 4 == 0 && gx > 0 && gy > 0 && frames >= 1) ? new Map2BevPlugin(mp, c, gx, gy, frames, split) : nullptr;
+    return (mp > 0 && c > 0 && c % 4 == 0 && gx > 0 && gy > 0 && frames >= 1) ? new Map2BevPlugin(mp, c, gx, gy, frames, split, persistent != 0) : nullptr;
 }
 static Plugin* mbCreate(const DsvtPluginFieldCollection* fc) {
     return mbNew(fieldInt(fc, "max_pillars_num"), fieldInt(fc, "channel_num"), fieldInt(fc, "grid_size_x"), fieldInt(fc, "grid_size_y"), fieldInt(fc, "frames", 1),
-                 fieldInt(fc, "split_output", 0));
+                 fieldInt(fc, "split_output", 0), fieldInt(fc, "persistent_output", 0));
 }
 static Plugin* mbDeser(const void* data, size_t len) {
-    const int extra = trailingInts(len, 4 * sizeof(int), 2);
+    const int extra = trailingInts(len, 4 * sizeof(int), 3);
     if (extra < 0) return nullptr;
     const char* d = static_cast<const char*>(data); int mp = rd<int>(d), c = rd<int>(d), gx = rd<int>(d), gy = rd<int>(d);
-    const int frames = extra >= 1 ? rd<int>(d) : 1, split = extra >= 2 ? rd<int>(d) : 0;
-    return mbNew(mp, c, gx, gy, frames, split);
+    const int frames = extra >= 1 ? rd<int>(d) : 1, split = extra >= 2 ? rd<int>(d) : 0, persistent = extra >= 3 ? rd<int>(d) : 0;
+    if (extra >= 3 && persistent != 1) return nullptr;               // (a seventh int is only ever written as 1: a zero-padded six-int blob is not a seven-int one)
+    return mbNew(mp, c, gx, gy, frames, split, persistent);
 }
 static Creator g_mbCreator{"Map2BevPlugin",
     {{"max_pillars_num", DSVT_FIELD_INT32}, {"channel_num", DSVT_FIELD_INT32}, {"grid_size_x", DSVT_FIELD_INT32}, {"grid_size_y", DSVT_FIELD_INT32}},

@@ -397,10 +397,14 @@ def add_get_value_by_index_op(max_win_num, voxel_num_set, channel_num, axis_id):
                                                 channel_num=channel_num, axis_id=axis_id), "get_value_by_index_layer")
 
 
-def add_map_2_bev_op(max_pillars_num, channel_num, grid_size_x, grid_size_y, frames=1, split_output=False):
+def add_map_2_bev_op(max_pillars_num, channel_num, grid_size_x, grid_size_y, frames=1, split_output=False, persistent_output=False):
     """plugin_helper.h:371-425.  Inputs: voxel_features, coors, valid_voxel_num.  frames > 1: coords.x selects one of `frames` stacked maps.
-    split_output: fp32 rows in, the fp16 triple [hi | lo | hi] (3 C channels per cell) out -- the operand of the fp32-grade convolutions."""
+    split_output: fp32 rows in, the fp16 triple [hi | lo | hi] (3 C channels per cell) out -- the operand of the fp32-grade convolutions.
+    persistent_output: the caller passes the SAME output buffer on every call and nobody else writes it: a call then zeroes only the cells the call
+    before it wrote instead of the whole map (another address, and the first call, take the full fill)."""
     extra = dict(frames=int(frames)) if frames != 1 else {}
+    if persistent_output:
+        extra["persistent_output"] = 1
     if split_output:
         extra["split_output"] = int(split_output)           # 2: the third plane holds the fp8 operands (x8) instead of repeating hi
     return Plugin("Map2BevPlugin", dict(extra, max_pillars_num=max_pillars_num, channel_num=channel_num,

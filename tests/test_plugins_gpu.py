@@ -366,6 +366,38 @@ def test_map2bev(pkg, oracle):
     assert np.array_equal(host(o[0])[0], O.map2bev(feat, vox["coords"], vox["P"], 468, 468))
 
 
+@pytest.mark.parametrize("split_output,frames", [(0, 1), (0, 3), (1, 1), (2, 2)])
+def test_map2bev_persistent_output_clears_what_the_last_call_wrote(pkg, split_output, frames):
+    """persistent_output: a call zeroes only the cells the call before it wrote into the SAME buffer.  Six calls with different pillar sets and counts (one of
+    them empty) on one set of input buffers (=> one cached output buffer), one call into another buffer in between (full fill, then incremental again on the
+    way back: the state of the plugin follows the buffer it wrote last); every result against the stateless plugin's, bit for bit; blob round trip."""
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(17 + split_output + frames)
+    MP, C, GX, GY = 1500, 64, 44, 40
+    feat = torch.zeros(1, MP, C, device=DEV); coords = torch.zeros(1, MP, 4, dtype=torch.int32, device=DEV); cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    op = P.add_map_2_bev_op(MP, C, GX, GY, frames=frames, split_output=split_output, persistent_output=True)
+    ref = P.add_map_2_bev_op(MP, C, GX, GY, frames=frames, split_output=split_output)
+    again = P.Plugin.deserialize("Map2BevPlugin", op.serialize())
+    assert again.serialize() == op.serialize() and len(op.serialize()) == 28 and len(ref.serialize()) == (24 if split_output else 20 if frames > 1 else 16)
+    other = None
+    for it, n in enumerate([900, 1500, 0, 37, 1200, 700, 1100]):
+        cells = torch.randperm(frames * GX * GY, generator=g)[:MP]
+        co = torch.zeros(1, MP, 4, dtype=torch.int32)
+        co[0, :, 0] = (cells // (GX * GY)).int(); co[0, :, 2] = ((cells % (GX * GY)) // GX).int(); co[0, :, 3] = (cells % GX).int()
+        co[0, 5::97, 0] = frames + 3                                  # pillars of no frame of this launch: skipped by the scatter AND by the clear
+        feat.copy_(torch.randn(1, MP, C, generator=g)); coords.copy_(co); cnt.fill_(n)
+        want = ref(feat, coords, cnt)[0].clone()
+        if it == 4:                                                   # another output address: the full fill, and the state moves with it
+            other = torch.full_like(want, 7)
+            got = op(feat, coords, cnt, out=[other])[0]
+        else:
+            got = op(feat, coords, cnt)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(got.view(torch.int16) if got.dtype == torch.float16 else got, want.view(torch.int16) if want.dtype == torch.float16 else want), it
+        g2 = again(feat, coords, cnt)[0]
+        assert torch.equal(g2.view(torch.int16) if g2.dtype == torch.float16 else g2, want.view(torch.int16) if want.dtype == torch.float16 else want), it
+
+
 def test_filter_box_by_score(pkg, oracle):
     P, O = pkg.plugin, oracle
     rng = np.random.default_rng(9)
