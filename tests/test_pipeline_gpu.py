@@ -130,10 +130,12 @@ def test_pipeline_is_deterministic(pkg, weights):
         assert torch.equal(a, b) and torch.equal(ca, cb)
 
 
-@pytest.mark.parametrize("mode", ["f16", "split"])
-def test_boxes_do_not_depend_on_stale_buffer_contents(pkg, weights, mode):
+@pytest.mark.parametrize("mode,persistent_bev", [("f16", False), ("split", False), ("split", True)])
+def test_boxes_do_not_depend_on_stale_buffer_contents(pkg, weights, mode, persistent_bev):
     """Uninitialised-read sanitiser: every plugin's outputs and workspace are overwritten with a byte pattern (zeros, 0xff = NaN / -1,
-    random) before a forward; the boxes are the same bits each time.  (TensorRT hands plugins uninitialised workspace and outputs.)"""
+    random) before a forward; the boxes are the same bits each time.  (TensorRT hands plugins uninitialised workspace and outputs.)
+    persistent_bev (the pipeline's default): Map2Bev's output is BY CONTRACT a buffer the plugin alone writes, call after call (it zeroes only the cells
+    its previous call wrote) -- that one buffer is left alone, every other one is overwritten as before."""
     P = pkg.plugin
     made, init = [], P.Plugin.__init__
     def tracking(self, *a, **k):
@@ -142,9 +144,11 @@ def test_boxes_do_not_depend_on_stale_buffer_contents(pkg, weights, mode):
     try:
         kw = dict(linear_compute=P.COMPUTE_SPLIT) if mode == "split" else dict(linear_compute=P.COMPUTE_F16, head_dtype=torch.float16)
         caps = pkg.pipeline.Caps()
-        pipe = pkg.pipeline.DsvtPipeline(weights, caps=caps, device=DEV, device_nms=True, **kw)
+        pipe = pkg.pipeline.DsvtPipeline(weights, caps=caps, device=DEV, device_nms=True, persistent_bev=persistent_bev, **kw)
     finally:
         P.Plugin.__init__ = init
+    if persistent_bev:
+        made = [pl for pl in made if pl.plugin_type != "Map2BevPlugin"]
     pts, n = cases.pad_points(pkg.synth.lidar_like(120000, 4), caps.N)
     p_d, n_d = torch.from_numpy(pts[None]).to(DEV), torch.tensor([n], dtype=torch.int32, device=DEV)
     b0, c0 = [t.clone() for t in pipe.forward(p_d, n_d)]
