@@ -169,6 +169,39 @@ def test_boxes_do_not_depend_on_stale_buffer_contents(pkg, weights, mode, persis
         assert torch.equal(c, c0) and torch.equal(b, b0), (kind, c.tolist(), c0.tolist())
 
 
+@pytest.mark.parametrize("mode,frames", [("split", 1), ("f16", 2)])
+def test_consecutive_forwards_do_not_see_each_others_bev_cells(pkg, weights, mode, frames):
+    """Map2Bev's persistent_output (the pipeline's default: a forward zeroes only the cells the forward before it wrote): a dense cloud, a sparse one,
+    an EMPTY frame and the dense one again through ONE captured graph (inputs refilled in place) give the bits of a stateless pipeline
+    (persistent_bev=False: whole-map fill per call) that sees each cloud alone."""
+    P = pkg.plugin
+    kw = dict(linear_compute=P.COMPUTE_SPLIT) if mode == "split" else dict(linear_compute=P.COMPUTE_F16, head_dtype=torch.float16)
+    caps = pkg.pipeline.Caps() if frames == 1 else pkg.pipeline.Caps.for_frames(frames)
+    pipe = pkg.pipeline.DsvtPipeline(weights, caps=caps, device=DEV, device_nms=True, frames=frames, **kw)
+    ref = pkg.pipeline.DsvtPipeline(weights, caps=caps, device=DEV, device_nms=True, frames=frames, persistent_bev=False, **kw)
+    seqs = [[180000, 150000], [30000, 7], [0, 0], [180000, 60000], [1, 120000]]
+    pts_d = torch.zeros((1, frames * caps.N, 4), device=DEV); n_d = torch.zeros(frames, dtype=torch.int32, device=DEV)
+    def fill(step, counts):
+        buf = np.zeros((1, frames * caps.N, 4), np.float32)
+        for f in range(frames):
+            if counts[f]:
+                p = pkg.synth.lidar_like(counts[f], 20 + 3 * step + f); buf[0, f * caps.N:f * caps.N + len(p)] = p
+        pts_d.copy_(torch.from_numpy(buf)); n_d.copy_(torch.tensor(counts[:frames], dtype=torch.int32))
+    fill(0, seqs[0])
+    pipe.capture(pts_d, n_d)
+    total = 0
+    for step, counts in enumerate(seqs):
+        fill(step, counts)
+        rows, cnt = pipe.replay()
+        torch.cuda.synchronize()
+        rows, cnt = rows.clone(), cnt.clone()
+        r2, c2 = ref.forward(pts_d, n_d)
+        torch.cuda.synchronize()
+        assert torch.equal(cnt, c2) and torch.equal(rows, r2), (step, cnt.tolist(), c2.tolist())
+        total += int(cnt.sum())
+    assert total > 100
+
+
 @pytest.mark.parametrize("mode,frames", [("f16", 4), ("split", 1), ("f16", 1)])
 def test_no_plugin_writes_outside_its_buffers(pkg, weights, mode, frames):
     """Guard-band sanitiser: every output and workspace of every plugin of the frame is allocated between two 4 KB bands of 0xA5 bytes
