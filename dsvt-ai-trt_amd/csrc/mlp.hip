@@ -119,6 +119,9 @@ __device__ __forceinline__ void packFragsSplit(const floatx4 (&acc)[MNT], half8 
 // come through the same DMA queue into LDS (an ordinary global load with a DMA in flight makes hipcc wait vmcnt(0));
 // x is loaded in the prologue straight into the out-proj accumulator (acc = x, + bo after the barrier) and re-read for
 // LayerNorm 3 once nothing is in flight; no store is issued before the last stage has landed.
+#ifndef MLP_SPLIT_PREFETCH
+#define MLP_SPLIT_PREFETCH 1          // fragment pairs of step s + 1 read under the MFMAs of step s (split kernel, one row tile per wave)
+#endif
 #ifndef MLP_SPLIT_ELASTIC
 #define MLP_SPLIT_ELASTIC 1            // ten-wave single-frame variant (spills ~60 registers and is still 18 us per layer faster than two rounds of eight-wave blocks)
 #endif
@@ -387,12 +390,49 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
         for (int mt = 0; mt < MT; ++mt) { acc[mt][t][0] += b.x; acc[mt][t][1] += b.y; acc[mt][t][2] += b.z; acc[mt][t][3] += b.w; }
     }
     const unsigned char* lbase = lds + lane * 16;
+    // (split precision, one row tile per wave) one pass of NS steps over a stage in LDS: step s reads NT (w_hi, w_lo) fragment pairs and issues 3 NT MFMAs; the
+    // pairs of step s + 1 are read BEFORE the MFMAs of step s (left to itself the step is "read eight fragments, wait ~300-500 cycles of LDS latency with
+    // eight waves reading, 192 cycles of MFMAs" -- the same finding as in linear_split_resident_kernel)
+    auto gemmSplit = [&](const unsigned char* slot, auto nsTag, auto ntTag, auto fragOff, auto opHi, auto opLo, auto accOf) {
+        constexpr int NS = decltype(nsTag)::value, NT = decltype(ntTag)::value;
+        half8 wq[2][2 * NT];
+        auto ld = [&](int s_, half8 (&w)[2 * NT]) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                w[t] = *reinterpret_cast<const half8*>(slot + fragOff(s_, t));
+                w[NT + t] = *reinterpret_cast<const half8*>(slot + LO + fragOff(s_, t));
+            }
+        };
+        ld(0, wq[0]);
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            if (s_ + 1 < NS) ld(s_ + 1, wq[(s_ + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const half8 oh = opHi(s_), ol = opLo(s_);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                floatx4& c = accOf(s_, t);
+                if (!kAblate || !(a.dbg & 16)) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[s_ & 1][NT + t], oh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[s_ & 1][t], ol, c, 0, 0, 0);
+                }
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[s_ & 1][t], oh, c, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    constexpr bool PREF = SPLIT && MT == 1 && NW == 8 && MLP_SPLIT_PREFETCH;          // (the ten-wave single-frame variant has 168 registers: 219 spilled with the second fragment set)
+    using std::integral_constant;
 
     // ---- stages 0 .. NWO-1: out-proj, PQ columns per stage ---------------------------------------------------------------
 #pragma unroll
     for (int h = 0; h < NWO; ++h) {
         request(h + D);                              // (NWO + D <= NST: the stages beyond the out-proj are W1 pieces / W2 slabs)
         const unsigned char* sl = lbase + (h % RS) * SB;
+        if constexpr (PREF) {
+            gemmSplit(sl, integral_constant<int, MNSTEP>{}, integral_constant<int, PQT>{}, [&](int ks, int t) { return (ks * PQT + t) * 1024; },
+                      [&](int ks) { return fa[0][ks]; }, [&](int ks) { return fal[0][ks]; }, [&](int, int t) -> floatx4& { return acc[0][h * PQT + t]; });
+        } else
 #pragma unroll
         for (int ks = 0; ks < MNSTEP; ++ks) {
 #pragma unroll
@@ -444,6 +484,10 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int t = 0; t < PQT; ++t) acc2[mt][t] = floatx4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (PREF) {
+            gemmSplit(slotA, integral_constant<int, MNSTEP>{}, integral_constant<int, PQT>{}, [&](int ks, int t) { return (ks * PQT + t) * 1024; },
+                      [&](int ks) { return fs1[0][ks]; }, [&](int ks) { return fs1l[0][ks]; }, [&](int, int t) -> floatx4& { return acc2[0][t]; });
+        } else
 #pragma unroll
         for (int ks = 0; ks < MNSTEP; ++ks) {
 #pragma unroll
@@ -492,6 +536,10 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
         stageEnd(stA);                               // W2 slab landed; everyone is done with the W1 piece
         if (stB + D < NST) request(stB + D);
         const unsigned char* slotB = lbase + (stB % RS) * SB;
+        if constexpr (PREF) {                        // steps of four column tiles: (32-column slice sp of the piece, tile group)
+            gemmSplit(slotB, integral_constant<int, PQS * 3>{}, integral_constant<int, 4>{}, [&](int s_, int t) { return ((s_ / 3) * 12 + (s_ % 3) * 4 + t) * 1024; },
+                      [&](int s_) { return fh[0][s_ / 3]; }, [&](int s_) { return fhl[0][s_ / 3]; }, [&](int s_, int t) -> floatx4& { return acc[0][(s_ % 3) * 4 + t]; });
+        } else
 #pragma unroll
         for (int sp = 0; sp < PQS; ++sp) {
 #pragma unroll
