@@ -245,6 +245,13 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
             if (base > 0 && rem > 0 && M - base * WGR <= MLP_SMALL_MAX) FULL = base;
             else if (rem > a.ncu && M - (base + a.ncu) * WGR <= MLP_SMALL_MAX) FULL = base + a.ncu;
         }
+        // split precision (one workgroup per CU: ncu of them are a round): four frames per launch are 1074 tiles = four rounds and 50 more, which as full
+        // workgroups are a fifth round on 50 CUs (51 us of the launch's 278); as 200 two-wave workgroups they are a round on 200 CUs that is bound by
+        // the weight stream alone
+        if (SPLIT && WGR == MROWS && (!kAblate || !(a.dbg & 32))) {
+            const int base = T / a.ncu * a.ncu, rem = T - base;
+            if (base > 0 && rem > 0 && M - base * WGR <= MLP_SMALL_MAX) FULL = base;
+        }
         small = (int)blockIdx.x >= FULL;
         m0 = blockIdx.x * WGR;
         if (small) {
@@ -727,7 +734,8 @@ public:
                 return lastError();
             }
 #endif
-            hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, MLP_SPLIT_PQ, 3, true>), dim3(cdiv(max_rows_, MROWS)), dim3(512), 0, stream, b);
+            // (+ the two-wave workgroups of a last partial round: at most MLP_SMALL_MAX rows of 32)
+            hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, MLP_SPLIT_PQ, 3, true>), dim3(cdiv(max_rows_, MROWS) + MLP_SMALL_MAX / (16 * MLP_SW)), dim3(512), 0, stream, b);
             return lastError();
         }
         // Kernel by row count.  Up to 2.5 x 128 rows per CU (one or two frames per launch): <1,10> elastic, ONE workgroup per CU at a time
