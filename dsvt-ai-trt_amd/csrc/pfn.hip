@@ -43,7 +43,7 @@ struct PfnArgs {
     const _Float16* w1b;               // fragment-ordered [3 k-steps][12 tiles][64 lanes][8], natural k; SPLIT: the same image of w_lo follows
     const float* b1;                   // [192]
     float* out; _Float16* out16;       // vfeat [P,192] + fp16 copy
-    unsigned long long* trace;         // ablation build: s_memtime stamps of wave 0 of workgroup 7 (tools/trace_pfn.py)
+    unsigned long long* trace;         // ablation build: s_memtime stamps of wave 0 of workgroup 7 (tools/bench_pfn.py)
     int dbg;                           // timing ablations of the ablation build (wrong results): 1 no point gather, 2 no layer-0 MFMA, 4 no layer-1 MFMA, 8 no stores, 16 no per-pillar GEMM, 32 no m maxima
     int pack;                          // 1: pillars with <= 4 points share tiles (default); 0: one pillar per tile (round-1 layout, A/B switch)
 };
