@@ -256,14 +256,31 @@ conv_f16_kernel(ConvArgs a_)
 
     uint4 wr[WPT];
     half8 cur[MT][KSTEPS], nxt[MT][KSTEPS];
+    // three fp16 products over an x8 third plane whose planes are ONE slab wide (the two stride-2 layers: C = KC = 128): the slab of the third plane
+    // gathers the very rows the tap's first slab gathered, so those fragments are kept (16 registers) instead of fetched again -- a third of the
+    // gathers of a kernel that waits for its gathers; the slab order, i.e. every sum, is unchanged
+    const bool keepHi = a.alias3 == 2 * KC && nck == 3;
+    half8 hiKeep[MT][KSTEPS];
     loadW(0, wr);
     loadA(0, cur);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) hiKeep[mt][ks] = cur[mt][ks];
     storeW(0, wr);
     __syncthreads();
     for (int s = 0; s < NS; ++s) {
         const int buf = s & 1;
         const bool more = s + 1 < NS;
-        if (more) { loadW(s + 1, wr); loadA(s + 1, nxt); }          // next slab's traffic is in flight during the MFMAs
+        if (more) {                                                  // next slab's traffic is in flight during the MFMAs
+            loadW(s + 1, wr);
+            if (keepHi && (s + 1) % 3 == 2) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int ks = 0; ks < KSTEPS; ++ks) nxt[mt][ks] = hiKeep[mt][ks];
+            } else loadA(s + 1, nxt);
+        }
         const _Float16* pw = &sW[buf][r * LDW + g * 8];
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks)
@@ -280,7 +297,10 @@ conv_f16_kernel(ConvArgs a_)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int ks = 0; ks < KSTEPS; ++ks) cur[mt][ks] = nxt[mt][ks];
+                for (int ks = 0; ks < KSTEPS; ++ks) {
+                    cur[mt][ks] = nxt[mt][ks];
+                    if (keepHi && (s + 1) % 3 == 0) hiKeep[mt][ks] = nxt[mt][ks];
+                }
         }
         __syncthreads();
     }
