@@ -1391,6 +1391,126 @@ conv3x3_grouped_narrow_kernel(ConvArgs a, const _Float16* __restrict__ Wg, const
     }
 }
 
+// The same layer at fp32 grade (round 4): three fp16 products over a split input [hi | lo | x8] of C real channels (a.Cin = 3 C; the weights are the
+// host's [w_hi | w_hi | w_lo] rows).  On the dense halo kernel the launch walks fifteen phases -- the third plane's re-read plane 0 -- of which every
+// output channel needs three: 2.27 GB fetched and 685 us per four frames (one frame 212 us).  Here a workgroup keeps ONE head's w_hi AND w_lo tiles
+// (36 KB) and per item streams that head's hi halo (buffer 0) and lo halo (buffer 1), 102 KB: the hi halo serves hi x w_hi and hi x w_lo, then the lo
+// halo lo x w_hi, and each buffer is refilled for the next item as soon as its products are done (the hi request leaves under the lo products, the
+// lo request under the next item's hi products).  Summation order per output: (hi w_hi, hi w_lo, lo w_hi) by tap -- the dense kernel's is (hi w_hi,
+// lo w_hi, hi w_lo): the same products, fp32 rounding apart (2e-6 of scale).
+__global__ void __launch_bounds__(512, 1)
+conv3x3_grouped_narrow_split_kernel(ConvArgs a, const _Float16* __restrict__ Wg, const int* __restrict__ chanTab, const _Float16* __restrict__ zeros,
+                                    int tilesX, int tilesY, int NCC)
+{
+    constexpr int TH = 8, HS = HHS, HH = TH + 2, HWU = HTW + 2, HBYTES = HH * HS * 128, NI = HH * HS / 8, HPW = (NI + TH - 1) / TH;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HBYTES + 36 * 1024];            // hi halo | lo halo | the head's w_hi, w_lo tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int pg = wave >> 1, m0 = 2 * (wave & 1);                      // rows 2 pg, 2 pg + 1; pixel tiles m0, m0 + 1 of the row pair's four
+    const int cc = (int)blockIdx.x % NCC, j = (int)blockIdx.x / NCC, nj = ((int)gridDim.x - cc + NCC - 1) / NCC;
+    const int ntile = a.nb * tilesY * tilesX;
+    if (j >= ntile) return;
+    const int C = a.Cin / 3;                                           // real channels: plane p starts at channel p C
+    for (int u = wave; u < 36; u += TH)
+        __builtin_amdgcn_global_load_lds((glds_src_t)(Wg + (((size_t)cc * 36 + u) * 64 + lane) * 8), (glds_dst_t)(smem + 2 * HBYTES + u * 1024), 16, 0, 0);
+    int ch[4]; float bs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ch[i] = chanTab[cc * 16 + 4 * g + i];
+        bs[i] = (ch[i] >= 0 && a.bias) ? a.bias[ch[i]] : 0.f;
+    }
+    int hpos[HPW], goff[HPW];
+#pragma unroll
+    for (int q = 0; q < HPW; ++q) {
+        const int lp = 8 * (wave + q * TH) + (lane >> 3), slot = lane & 7;
+        const int hy = lp / HS, hx = lp - hy * HS;
+        hpos[q] = (hy << 16) | (hx << 4) | (slot ^ (hx & 7));
+    }
+    auto decode = [&](int t, int& yy, int& xx, int& bb) {
+        const int per = tilesY * tilesX;
+        bb = t / per; t -= bb * per;
+        yy = (t / tilesX) * TH; xx = (t % tilesX) * HTW;
+    };
+    auto setup = [&](int yy, int xx, int bb) {
+#pragma unroll
+        for (int q = 0; q < HPW; ++q) {
+            const int hx = (hpos[q] >> 4) & 0xfff;
+            const int gy = yy - 1 + (hpos[q] >> 16), gx = xx - 1 + hx;
+            const bool ok = hx < HWU && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            goff[q] = ok ? ((bb * a.H + gy) * a.W + gx) * a.Cin + cc * 64 + (hpos[q] & 15) * 8 : -1;
+        }
+    };
+    auto haloRequests = [&](int plane) {                               // plane 0 (hi) -> buffer 0, plane 1 (lo) -> buffer 1; of the item `goff` describes
+#pragma unroll
+        for (int q = 0; q < HPW; ++q)
+            if (NI % TH == 0 || wave + q * TH < NI) {
+                const _Float16* src = goff[q] >= 0 ? a.in + goff[q] + plane * C : zeros;
+                __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + plane * HBYTES + (wave + q * TH) * 1024), 16, 0, 0);
+            }
+    };
+    int pbase[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) pbase[m] = ((2 * pg + ((m0 + m) >> 1)) * HS + ((m0 + m) & 1) * 16 + r) * 128;
+    int swz[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) swz[kx] = (g ^ ((r + kx) & 7)) << 4;
+    const unsigned char* wres = smem + 2 * HBYTES + (lane << 4);
+    // products of one halo buffer with one 18-row weight tile
+    auto products = [&](const unsigned char* hbp, const unsigned char* wt, floatx4 (&acc)[2]) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky, toff = (ky * HS + kx) * 128, sw = swz[kx];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const half8 A = *reinterpret_cast<const half8*>(wt + ((tap * 2 + ks) << 10));
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const half8 B = *reinterpret_cast<const half8*>(hbp + pbase[m] + toff + (sw ^ (ks << 6)));
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, acc[m], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    int t = j, y0, x0, bimg;
+    decode(t, y0, x0, bimg);
+    setup(y0, x0, bimg);
+    haloRequests(0); haloRequests(1);
+    slabBarrier(0);
+    for (;;) {
+        const int tn = t + nj;
+        const bool have_next = tn < ntile;
+        int ny0 = 0, nx0 = 0, nb_ = 0;
+        floatx4 acc[2] = {floatx4{bs[0], bs[1], bs[2], bs[3]}, floatx4{bs[0], bs[1], bs[2], bs[3]}};      // (the sums start from the bias, like the dense kernel's)
+        products(smem, wres, acc);                                    // hi x w_hi
+        products(smem, wres + 18 * 1024, acc);                        // hi x w_lo
+        // everyone is done with the hi halo: the next item's goes out now, under the lo products (the lo halo of THIS item has landed: it was
+        // requested an item ago -- or with the hi halo, for the first item -- and is awaited here)
+        slabBarrier(0);
+        if (have_next) { decode(tn, ny0, nx0, nb_); setup(ny0, nx0, nb_); haloRequests(0); }
+        products(smem + HBYTES, wres, acc);                           // lo x w_hi
+        // the stores, then (after everyone is done with the lo halo) the next item's lo request; its hi halo is awaited with the barrier below
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int oy = y0 + 2 * pg + ((m0 + m) >> 1), ox = x0 + ((m0 + m) & 1) * 16 + r;
+            if (!(oy < a.Ho && ox < a.Wo)) continue;
+            const size_t opix = (size_t)(bimg * a.Ho + oy) * a.Wo + ox;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (ch[i] < 0) continue;
+                float v = acc[m][i];
+                if (a.relu) v = fmaxf(v, 0.f);
+                if (a.out_f32) static_cast<float*>(a.out)[opix * a.out_ld + a.out_coff + ch[i]] = v;
+                else static_cast<_Float16*>(a.out)[opix * a.out_ld + a.out_coff + ch[i]] = (_Float16)v;
+            }
+        }
+        if (!have_next) break;
+        // (the hi halo of the next item has landed -- vmcnt(0) also waits for this wave's stores; then everyone is done with the lo halo)
+        slabBarrier(0);
+        haloRequests(1);
+        t = tn; y0 = ny0; x0 = nx0; bimg = nb_;
+    }
+}
+
 // -------------------------------------------------------------------------------------
 // 3 x 3 stride-1 layers with 64 INPUT channels and a multiple of 64 output channels (round 2): the CenterHead's five stems as one
 // 64 -> 320 layer.  On conv_wide_kernel<8, 4, 36, 2, 2> an 8-row x 32-pixel x 128-channel item streams 147 KB of weights beside 46 KB of
@@ -1818,7 +1938,7 @@ public:
     _Float16* w_dev_ = nullptr; float* b_dev_ = nullptr;
     _Float16* wp_dev_ = nullptr;         // fragment-packed copy for the halo kernel (stride-1 layers)
     _Float16* zeros_dev_ = nullptr;      // 256 zero bytes: LDS-DMA source of out-of-image halo pixels
-    _Float16* wg_dev_ = nullptr; int* chan_dev_ = nullptr; int groups_ = 0;      // block-diagonal narrow 3 x 3 layer: per-phase weight tiles + channel table
+    _Float16* wg_dev_ = nullptr; int* chan_dev_ = nullptr; int groups_ = 0; bool groups_split_ = false;      // block-diagonal narrow 3 x 3 layer: per-phase weight tiles + channel table (split: w_hi and w_lo tiles per group of a split input)
     unsigned char* xscale_dev_ = nullptr;                                        // split_in == 2: scale byte per weight row (wp_dev_ holds the packMX image)
     bool ok_ = false;
     int cinW() const { return c_.split_in == 2 ? c_.Cin / 3 : c_.Cin; }         // channels per tap of a weight row
@@ -1978,6 +2098,7 @@ public:
         if (on < 0) on = ablateEnv("DSVT_CONV_GROUPED", 1);
         const ConvCfg& c = c_;
         if (!on || c.KH != 3 || c.KW != 3 || c.stride != 1 || c.pad != 1 || c.up != 1 || c.has_res || c.Cin % 64 != 0 || c.Cin < 128 || c.Cout > 64) return;
+        if (c.split_in == 1) { packGroupedSplit(wh); return; }
         const int NCC = c.Cin / 64;
         std::vector<std::vector<int>> chans(NCC);
         for (int n = 0; n < c.Cout; ++n) {
@@ -2007,6 +2128,46 @@ public:
             hipMemcpy(wg_dev_, wg.data(), sizeof(_Float16) * wg.size(), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(chan_dev_, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) { ok_ = false; return; }
         groups_ = NCC;
+    }
+    // the same for three fp16 products over a split input [hi | lo | x8] (split_in = 1: rows [w_hi | w_hi | w_lo] over Cin = 3 C): every output channel
+    // reads ONE 64-channel group of each plane, the first two blocks of its row are equal; per group 18 fragment rows of w_hi and 18 of w_lo
+    void packGroupedSplit(const std::vector<_Float16>& wh) {
+        const ConvCfg& c = c_;
+        if (c.Cin % 192 != 0 || c.split_out != 0) return;
+        const int C = c.Cin / 3, NQ = C / 64;
+        std::vector<std::vector<int>> chans(NQ);
+        for (int n = 0; n < c.Cout; ++n) {
+            int phase = -1;
+            for (int tap = 0; tap < 9; ++tap)
+                for (int k = 0; k < c.Cin; ++k) {
+                    const float v = w_[((size_t)n * 9 + tap) * c.Cin + k];
+                    if (k < C && v != w_[((size_t)n * 9 + tap) * c.Cin + C + k]) return;      // (plane 1 must pair with the weights of plane 0)
+                    if (v != 0.f) {
+                        if (phase >= 0 && phase != (k % C) / 64) return;           // reads two groups: dense
+                        phase = (k % C) / 64;
+                    }
+                }
+            chans[phase < 0 ? 0 : phase].push_back(n);
+        }
+        for (auto& v : chans) if (v.size() > 16) return;
+        std::vector<_Float16> wg((size_t)NQ * 36 * 512, (_Float16)0.f);
+        std::vector<int> tab((size_t)NQ * 16, -1);
+        for (int cc = 0; cc < NQ; ++cc)
+            for (size_t i = 0; i < chans[cc].size(); ++i) {
+                const int n = chans[cc][i];
+                tab[cc * 16 + i] = n;
+                for (int pl = 0; pl < 2; ++pl)                                      // w_hi (block 0), w_lo (block 2)
+                    for (int tap = 0; tap < 9; ++tap)
+                        for (int ks = 0; ks < 2; ++ks)
+                            for (int gq = 0; gq < 4; ++gq)
+                                for (int jq = 0; jq < 8; ++jq)
+                                    wg[(((size_t)cc * 36 + pl * 18 + tap * 2 + ks) * 64 + gq * 16 + i) * 8 + jq] =
+                                        wh[((size_t)n * 9 + tap) * c.Cin + pl * 2 * C + cc * 64 + ks * 32 + gq * 8 + jq];
+            }
+        if (hipMalloc(&wg_dev_, sizeof(_Float16) * wg.size()) != hipSuccess || hipMalloc(&chan_dev_, sizeof(int) * tab.size()) != hipSuccess ||
+            hipMemcpy(wg_dev_, wg.data(), sizeof(_Float16) * wg.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(chan_dev_, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) { ok_ = false; return; }
+        groups_ = NQ; groups_split_ = true;
     }
     ~DsvtConv2dPlugin() override {
         if (w_dev_) (void)hipFree(w_dev_); if (b_dev_) (void)hipFree(b_dev_); if (wp_dev_) (void)hipFree(wp_dev_); if (zeros_dev_) (void)hipFree(zeros_dev_); if (wg_dev_) (void)hipFree(wg_dev_); if (chan_dev_) (void)hipFree(chan_dev_);
@@ -2070,7 +2231,8 @@ public:
         if (c_.split_in == 2) return launchConvHalo(a, wp_dev_, zeros_dev_, stream);
         if (groups_ > 0 && !a.split_out) {
             const int tilesX = cdiv(a.Wo, HTW), tilesY = cdiv(a.Ho, 8);
-            hipLaunchKernelGGL(conv3x3_grouped_narrow_kernel, dim3(numCUs()), dim3(512), 0, stream, a, wg_dev_, chan_dev_, zeros_dev_, tilesX, tilesY, groups_);
+            if (groups_split_) hipLaunchKernelGGL(conv3x3_grouped_narrow_split_kernel, dim3(numCUs()), dim3(512), 0, stream, a, wg_dev_, chan_dev_, zeros_dev_, tilesX, tilesY, groups_);
+            else hipLaunchKernelGGL(conv3x3_grouped_narrow_kernel, dim3(numCUs()), dim3(512), 0, stream, a, wg_dev_, chan_dev_, zeros_dev_, tilesX, tilesY, groups_);
             return lastError();
         }
         if (wp_dev_ && conv1x1ResidentEligible(a)) return launchConv1x1Resident(a, wp_dev_, stream);
