@@ -99,7 +99,8 @@ __device__ __forceinline__ void storeHalf8(const ConvArgs& a, const float (&v)[8
         splitPlanes<8>(v, hi, lo);
         *reinterpret_cast<half8*>(o) = hi;
         if (a.x8_out != 2) *reinterpret_cast<half8*>(o + a.split_out) = lo;          // (x8_out 2: no consumer reads the lo plane -- a third of the store burst)
-        if (a.x8_out) x8Store<8>(reinterpret_cast<unsigned char*>(static_cast<_Float16*>(a.out) + opix * a.out_ld + 2 * a.split_out), a.out_coff + co, v, hi);
+        if (a.x8_out == 3) {}                                                         // (x8_out 3: the tensor is only ever a residual -- hi + lo --: no third plane)
+        else if (a.x8_out) x8Store<8>(reinterpret_cast<unsigned char*>(static_cast<_Float16*>(a.out) + opix * a.out_ld + 2 * a.split_out), a.out_coff + co, v, hi);
         else *reinterpret_cast<half8*>(o + 2 * a.split_out) = hi;
     } else {
         half8 h;
@@ -151,14 +152,16 @@ __device__ __forceinline__ void convStore(const ConvArgs& a, floatx4 acc, size_t
         if (full) {
             *reinterpret_cast<half4*>(o) = hi;
             if (a.x8_out != 2) *reinterpret_cast<half4*>(o + a.split_out) = lo;
-            if (a.x8_out) x8Store<4>(xp, a.out_coff + co, v, hi);
+            if (a.x8_out == 3) {}
+            else if (a.x8_out) x8Store<4>(xp, a.out_coff + co, v, hi);
             else *reinterpret_cast<half4*>(o + 2 * a.split_out) = hi;
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) if (co + i < a.Cout) {
                 o[i] = hi[i];
                 if (a.x8_out != 2) o[a.split_out + i] = lo[i];
-                if (a.x8_out) {
+                if (a.x8_out == 3) {}
+                else if (a.x8_out) {
                     const int xo = x8Offset(a.out_coff + co + i);
                     xp[xo] = (unsigned char)packE4m3((v[i] - (float)hi[i]) * 2048.f, 0.f, 0.f, 0.f); xp[xo + 16] = (unsigned char)packE4m3(v[i], 0.f, 0.f, 0.f);
                 } else o[2 * a.split_out + i] = hi[i];
@@ -1911,7 +1914,7 @@ static int launchConv(const ConvArgs& a, int KC, hipStream_t stream) {
 // -------------------------------------------------------------------------------------
 struct ConvCfg {
     int H, W, Cin, Cout, KH, KW, stride, pad, up, relu, has_res, out_ld, out_coff, out_f32;
-    int split_out, split_res;      // split precision (fields "split_output" / "split_residual"): the output / the residual is an fp16 [hi | lo | hi] triple (see ConvArgs); split_out = 2: [hi | lo | x8], 3: [hi | - | x8]
+    int split_out, split_res;      // split precision (fields "split_output" / "split_residual"): the output / the residual is an fp16 [hi | lo | hi] triple (see ConvArgs); split_out = 2: [hi | lo | x8], 3: [hi | - | x8], 4: [hi | lo | -] (a tensor that is only ever a residual)
     int split_in;                  // field "split_input": the input is a split tensor [hi | lo | x8] (Cin = 3 C).  1: the weight rows are the host's [w_hi | w_hi | w_lo] and the phases
                                    // of the third plane read plane 0; 2: the weight rows are the REAL fp32 rows [R][9][C] and the layer runs on conv_wide_kernel<.., MX>
 };
@@ -2200,7 +2203,7 @@ public:
         a.split_out = c_.split_out ? c_.out_ld / 3 : 0;
         a.res_split = (c_.has_res && c_.split_res) ? a.res_ld / 3 : 0;
         a.res_x8 = c_.split_res == 2;
-        a.x8_out = c_.split_out == 2 ? 1 : c_.split_out == 3 ? 2 : 0;
+        a.x8_out = c_.split_out == 2 ? 1 : c_.split_out == 3 ? 2 : c_.split_out == 4 ? 3 : 0;
         a.alias3 = c_.split_in == 1 ? c_.Cin / 3 * 2 : 0;
         a.xscale = c_.split_in == 2 ? xscale_dev_ : nullptr;
         a.wide = !c_.out_f32 && c_.Cout % 16 == 0 && c_.out_ld % 8 == 0 && c_.out_coff % 8 == 0 && (!c_.has_res || a.res_ld % 8 == 0) &&
@@ -2270,7 +2273,7 @@ static Plugin* convNew(const ConvCfg& c, const float* w, const float* b) {
     if (c.up > 1 && (c.KH != 1 || c.KW != 1 || c.stride != 1 || c.Cout % CNB != 0)) return nullptr;   // pixel-shuffle chunks are whole workgroup columns
     if (!c.out_f32 && (c.out_ld % 4 != 0 || c.out_coff % 4 != 0)) return nullptr;
     if (c.split_out && (c.out_f32 || c.out_ld % 12 != 0 || c.out_ld / 3 < c.out_coff + c.Cout)) return nullptr;      // three planes of out_ld / 3 channels
-    if (c.split_out < 0 || c.split_out > 3 || c.split_in < 0 || c.split_in > 2) return nullptr;
+    if (c.split_out < 0 || c.split_out > 4 || c.split_in < 0 || c.split_in > 2) return nullptr;
     if (c.split_out >= 2 && ((c.out_ld / 3) % 32 != 0 || c.out_coff % 8 != 0)) return nullptr;       // the x8 plane is laid out in 32-channel groups
     if ((c.split_res && !c.has_res) || c.split_res < 0 || c.split_res > 2) return nullptr;       // (2: the residual triple has no lo plane, its lo part comes from the x8 plane)
     if (c.split_in && c.Cin % 192 != 0) return nullptr;                                              // three planes of whole 64-channel phases

@@ -324,7 +324,8 @@ class DsvtPipeline:
         ops = self.sops = {}
         mx = self.head_mx
 
-        def conv(name, rows, bias, H, cin, cout, k, stride, relu, res=False, out_f32=False, plane=None, lo=True, res_lo=True, **kw):
+        def conv(name, rows, bias, H, cin, cout, k, stride, relu, res=False, out_f32=False, plane=None, lo=True, res_lo=True, res_only=False, **kw):
+            # res_only (head_mx only): the tensor is only ever a residual (hi + lo): its third plane is not written (split_output = 4)
             # lo = False (head_mx only): every consumer of this tensor is a [hi | x8] layer and it is nobody's residual -- its lo plane is not written
             plane = cout if plane is None else plane
             # head_mx: the third plane of every tensor holds the fp8 operands (x8).  The 3 x 3 stride-1 layers with > 32 output channels (93 % of the
@@ -338,14 +339,14 @@ class DsvtPipeline:
             lo = lo or bool(self.head_mx_exclude)            # (an excluded layer reads the lo plane of its input: every tensor keeps it then)
             ops[name] = P.add_conv2d_op(np.asarray(rows, np.float32) if wide else sw(rows, k * k, cin), bias, H, H, 3 * cin, cout, k, stride, k // 2,
                                         relu=relu, has_residual=res, split_residual=(1 if (res_lo or not mx) else 2) if res else 0, out_f32=out_f32,
-                                        split_output=0 if out_f32 else ((2 if lo else 3) if mx else 1), split_input=(2 if wide else 1) if mx else 0,
+                                        split_output=0 if out_f32 else ((4 if res_only and not self.head_mx_exclude else 2 if lo else 3) if mx else 1), split_input=(2 if wide else 1) if mx else 0,
                                         out_channel_stride=plane if out_f32 else 3 * plane, **kw)
             ops[name].split_in = True            # (bench.py's flop / byte accounting: 3 Cin operand channels carry Cin real ones)
             ops[name].mx_in = bool(wide)
 
-        def conv_bn(name, name_conv, name_bn, H, cin, cout, k, stride, relu, res=False, lo=True, res_lo=True):
+        def conv_bn(name, name_conv, name_bn, H, cin, cout, k, stride, relu, res=False, lo=True, res_lo=True, res_only=False):
             s_, sh = bn_fold(w, name_bn, 1e-3)
-            conv(name, cw(w[name_conv + ".weight"] * s_[:, None, None, None]), sh, H, cin, cout, k, stride, relu, res=res, lo=lo, res_lo=res_lo)
+            conv(name, cw(w[name_conv + ".weight"] * s_[:, None, None, None]), sh, H, cin, cout, k, stride, relu, res=res, lo=lo, res_lo=res_lo, res_only=res_only)
 
         H = GY
         for (i, cin, cout, stride, nb) in ((0, 192, 128, 1, 2), (1, 128, 128, 2, 3), (2, 128, 256, 2, 3)):
@@ -360,7 +361,7 @@ class DsvtPipeline:
                 # of the 180k-point frame from 8.4e-4 to 1.05e-3 (yaw = atan(sin / cos) of a short random-weight vector amplifies), and saves no
                 # read traffic -- lo8 and hi8 alternate in 16-byte chunks, so the same cache lines are fetched.)
                 if j == 0:
-                    conv_bn(p + ".d", p + ".downsample_layer.0", p + ".downsample_layer.1", H, ci, cout, 1, st, False)
+                    conv_bn(p + ".d", p + ".downsample_layer.0", p + ".downsample_layer.1", H, ci, cout, 1, st, False, res_only=True)      # (conv2's residual, nothing else)
                 conv_bn(p + ".2", p + ".conv2", p + ".bn2", Ho, cout, cout, 3, 1, True, res=True)      # + identity, ReLU (:1165-1166)
                 H = Ho
             k = (1, 2, 4)[i]

@@ -587,7 +587,8 @@ def add_conv2d_op(weight_rows, bias, in_height, in_width, in_channels, out_chann
     (csrc/conv.hip): replaces the reference's addConvolutionNd / addDeconvolutionNd + addScale + ReLU + SUM
     groups (src/dsvt-ai-trt.cpp:149-246, 1144-1468).  Inputs: x [1,H,W,Cin] fp16 (, residual [1,Ho,Wo,C] fp16).
     split_output: 1 = the result leaves as the fp16 triple [hi | lo | hi] (out_channel_stride = 3 x the plane width), 2 = as [hi | lo | x8]
-    (third plane: the OCP-fp8 operands of the correction terms, csrc/conv.hip ConvArgs::x8_out); split_residual: the residual input is such
+    (third plane: the OCP-fp8 operands of the correction terms, csrc/conv.hip ConvArgs::x8_out), 3 = [hi | - | x8] (no lo plane: read by [hi | x8] layers only),
+    4 = [hi | lo | -] (no third plane: a tensor that is only ever a residual); split_residual: the residual input is such
     a triple (value hi + lo).  split_input (the input is a [hi | lo | x8] triple of in_channels / 3 real channels): 1 = weight_rows are
     split_weight_rows(...) and the third plane's phases read plane 0; 2 = weight_rows are the REAL fp32 rows [R][9][in_channels / 3] and the
     layer runs on the fp16 + fp8 K loop (3 x 3, stride 1, more than 32 output channels)."""

@@ -204,6 +204,25 @@ def test_block_diagonal_head_outputs_at_fp32_grade_on_the_grouped_split_kernel(p
     assert (got - ref_dense).abs().max().item() < 2e-6 * scale
 
 
+def test_split_output_4_writes_hi_and_lo_and_leaves_the_third_plane_alone(pkg):
+    """split_output = 4 (a tensor that is only ever a residual): the hi and lo planes are those of split_output = 2, the third plane keeps what the buffer held
+    (1 x 1 layer on the fp16 + fp8 loop, the first block's shortcut; and a 3 x 3 layer on three fp16 products)."""
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(41)
+    for k, cin, cout, si in ((1, 192, 128, 2), (3, 64, 128, 1)):
+        H, W = 37, 45
+        x = nhwc(torch.randn(1, cin, H, W, generator=g) * 2.0)
+        w = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k); b = torch.randn(cout, generator=g) * 0.1
+        rows = P.conv_weight_rows(w.numpy()) if si == 2 else P.split_weight_rows(P.conv_weight_rows(w.numpy()), k * k, cin)
+        t = make_triple(x).to(DEV)
+        mk = lambda so: P.add_conv2d_op(rows, b.numpy(), H, W, 3 * cin, cout, k, 1, k // 2, split_output=so, split_input=si, out_channel_stride=3 * cout)
+        full = mk(2)(t)[0].cpu()
+        buf = torch.full((1, H, W, 3 * cout), 7.0, dtype=torch.float16, device=DEV)
+        got = mk(4)(t, out=[buf])[0].cpu()
+        assert torch.equal(got[..., :2 * cout].view(torch.int16), full[..., :2 * cout].view(torch.int16))
+        assert (got[..., 2 * cout:] == 7.0).all()
+
+
 def test_mx_plugin_refuses_what_the_kernel_does_not_serve(pkg):
     P = pkg.plugin
     w = np.zeros((128, 9 * 128), np.float32)
