@@ -1771,6 +1771,145 @@ conv1x1_resident_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT, in
     }
 }
 
+// The same for the fp32-grade stage (round 4): the 1 x 1 stride-1 layers on the fp16 + fp8 K loop (packMX1x1 image, conv_halo_kernel<.., MX>'s arithmetic
+// in its order: C / 32 fp16 k-steps of the hi plane, then C / 64 e4m3 K = 128 steps of the x8 plane -- the same bits) with ONE 128-column stage resident per
+// CU: its fp16 rows (C / 32 KB per column tile) and cross rows (C / 32 KB again), C / 2 KB in all.  The halo kernel streamed, per 8 x 32-pixel x 128-column
+// item, the input tile (hi AND x8: 1 KB per pixel at C = 256) and 137 KB of weights through LDS: the 256 -> 16 x 128 deblock fetched the same 262 KB of
+// input sixteen times, 6 MB of LDS-DMA per CU and launch, 352 us per four frames for 0.5 GB of HBM traffic.  Here the waves walk 16-pixel tiles with their
+// rows (hi fragments + the two 16-byte x8 chunks per 64 channels) straight from global, next tile in flight under the current one; the workgroups of a
+// column group's sixteen (four) siblings that read the same pixels sit on one XCD.
+template <int KQ>                 // fp16 k-steps (C / 32): 4, 6, 8
+__global__ void __launch_bounds__(64 * C1_NW, 1)
+conv1x1_resident_mx_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT, int ngroup)
+{
+    constexpr int NPM = KQ / 2, CTG = 8;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KQ * CTG * 1024 + 1024];      // [fp16 k-step][tile] | [cross phase][tile][2] | bias (512 B) + scale bytes (128 B)
+    constexpr int CROSS_OFF = KQ * CTG * 1024, BIAS_OFF = 2 * KQ * CTG * 1024;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+    // workgroup -> (column group, row stream): the ngroup workgroups of a stream on one XCD (workgroups go to the XCDs round-robin)
+    const int nx = (int)gridDim.x / 8, xcd = (int)blockIdx.x % 8, sl = (int)blockIdx.x / 8;        // (the grid is a multiple of 8 ngroup)
+    const int type = sl % ngroup, j = xcd * (nx / ngroup) + sl / ngroup, nj = (int)gridDim.x / ngroup;
+    const unsigned char* Wb = reinterpret_cast<const unsigned char*>(Wp);
+    const size_t mainRows = (size_t)KQ * NCT;
+    for (int u = wave; u < KQ * CTG; u += C1_NW) {                    // fp16 rows: [q][NCT] -> [q][CTG]
+        const int q = u / CTG, t = u - q * CTG;
+        __builtin_amdgcn_global_load_lds((glds_src_t)(Wb + (((size_t)q * NCT + type * CTG + t) * 64 + lane) * 16), (glds_dst_t)(smem + u * 1024), 16, 0, 0);
+    }
+    for (int u = wave; u < NPM * CTG * 2; u += C1_NW) {               // cross rows: [ph][NCT][2] -> [ph][CTG][2]
+        const int ph = u / (CTG * 2), t2 = u - ph * CTG * 2;
+        __builtin_amdgcn_global_load_lds((glds_src_t)(Wb + ((mainRows + ((size_t)ph * NCT + type * CTG) * 2 + t2) * 64 + lane) * 16), (glds_dst_t)(smem + CROSS_OFF + u * 1024), 16, 0, 0);
+    }
+    const int n0 = type * 128, sub = n0 / a.Cout, dy = sub / a.up, dx = sub - dy * a.up, cbase = n0 - sub * a.Cout;
+    if (wave == 0) {                                                 // the stage's bias (128 floats) and scale bytes (128)
+        const void* src = lane < 32 ? (a.bias ? static_cast<const void*>(a.bias + cbase + lane * 4) : static_cast<const void*>(Wp))
+                                    : static_cast<const void*>(a.xscale + n0 + ((lane - 32) & 7) * 16);
+        __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + BIAS_OFF), 16, 0, 0);
+    }
+    const int HW = a.Ho * a.Wo, NPIX = a.nb * HW, ntile = (NPIX + 15) / 16, step = nj * C1_NW;      // OUTPUT pixels before the pixel shuffle = input pixels
+    const float invHW = 1.0f / (float)HW, invW = 1.0f / (float)a.Wo;
+    auto split = [&](int pc, int& b, int& y, int& xq) {
+        b = (int)(((float)pc + 0.5f) * invHW); b -= (b * HW > pc); b += ((b + 1) * HW <= pc);
+        const int rem = pc - b * HW;
+        y = (int)(((float)rem + 0.5f) * invW); y -= (y * a.Wo > rem); y += ((y + 1) * a.Wo <= rem);
+        xq = rem - y * a.Wo;
+    };
+    const int C = a.Cin / 3;
+    struct Rows { half8 h[KQ]; intx8 x[NPM]; };
+    auto loadRows = [&](int t, Rows& w) {
+        t = t < ntile ? t : ntile - 1;                               // (past the end: the last tile again, no branch around a load)
+        const int p = t * 16 + r, pc = p < NPIX ? p : NPIX - 1;
+        const _Float16* src = a.in + (size_t)pc * a.Cin;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) w.h[q] = *reinterpret_cast<const half8*>(src + q * 32 + g * 8);
+        // x8 plane: per 64 channels 128 bytes = two 32-channel groups of [lo8 0..15 | hi8 0..15 | lo8 16..31 | hi8 16..31]; lane group g: chunks 4 (g >> 1) + (g & 1), + 2
+        const unsigned char* xs_ = reinterpret_cast<const unsigned char*>(src + 2 * C) + (4 * (g >> 1) + (g & 1)) * 16;
+#pragma unroll
+        for (int ph = 0; ph < NPM; ++ph) {
+            const intx4 lo = *reinterpret_cast<const intx4*>(xs_ + ph * 128), hi = *reinterpret_cast<const intx4*>(xs_ + ph * 128 + 32);
+            w.x[ph] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    };
+    const unsigned char* slot = smem + lane * 16;
+    const int Wout = a.Wo * a.up;
+    int xsc[2] = {0, 0};                                             // scale byte of row (tile u, r) in byte u & 3 of xsc[u >> 2]
+    auto tile = [&](int t, const Rows& w) {
+        const int p = t * 16 + r;
+        const bool valid = p < NPIX;
+        int b, y, xq;
+        split(valid ? p : 0, b, y, xq);
+        floatx4 acc[CTG];
+#pragma unroll
+        for (int u = 0; u < CTG; ++u) {
+            const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + BIAS_OFF + (u * 16 + 4 * g) * 4);
+            acc[u] = a.bias ? b4 : floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+        // KQ fp16 steps (eight 1 KB fragments) then 2 NPM half-steps of the fp8 phases (four column tiles x 2 KB): eight 16-byte reads per step, those of
+        // step s + 1 issued before the MFMAs of step s (left alone hipcc hoists the reads of the whole tile: 500 spilled registers)
+        constexpr int NSTEP_ = KQ + 2 * NPM;
+        intx4 fb[2][8];
+        auto loadStep = [&](int s_, intx4 (&f)[8]) {
+            if (s_ < KQ) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) f[u] = *reinterpret_cast<const intx4*>(slot + (s_ * CTG + u) * 1024);
+            } else {
+                const int ph = (s_ - KQ) >> 1, u0 = ((s_ - KQ) & 1) * 4;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const intx4*>(slot + CROSS_OFF + (((ph * CTG + u0) * 2) + i) * 1024);
+            }
+        };
+        loadStep(0, fb[0]);
+#pragma unroll
+        for (int s_ = 0; s_ < NSTEP_; ++s_) {
+            if (s_ + 1 < NSTEP_) loadStep(s_ + 1, fb[(s_ + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const intx4 (&f)[8] = fb[s_ & 1];
+            if (s_ < KQ) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, f[u]), w.h[s_ < KQ ? s_ : 0], acc[u], 0, 0, 0);
+            } else {
+                const int ph = (s_ - KQ) >> 1, u0 = ((s_ - KQ) & 1) * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const intx8 A = __builtin_shufflevector(f[2 * i], f[2 * i + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[u0 + i] = mfmaX8(u0 + i, A, w.x[ph < NPM ? ph : 0], acc[u0 + i], xsc[(u0 + i) >> 2]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const size_t opix = (size_t)((b * a.Ho + y) * a.up + dy) * Wout + (xq * a.up + dx);
+#pragma unroll
+        for (int u = 0; u < CTG; u += 2) convStoreWide<false, true>(a, acc[u], acc[u + 1], valid, opix, cbase + u * 16, g);
+    };
+    int tt = j * C1_NW + wave;
+    Rows xa;
+    loadRows(tt, xa);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the weights (and the first rows) have landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < CTG; ++u) xsc[u >> 2] |= (int)smem[BIAS_OFF + 512 + u * 16 + r] << (8 * (u & 3));
+    if constexpr (KQ == 4) {                                          // (two sets of rows in flight: 2 x 32 registers)
+        Rows xb;
+        while (tt < ntile) {
+            const int tn = tt + step;
+            loadRows(tn, xb);
+            tile(tt, xa);
+            if (tn >= ntile) break;
+            tt = tn + step;
+            loadRows(tt, xa);
+            tile(tn, xb);
+        }
+    } else {
+        // the rows of a tile are 48 / 64 registers: a second set does not fit beside the accumulators, the fragment buffers and the split epilogue -- the wave
+        // that shares the SIMD covers the load
+        while (tt < ntile) {
+            tile(tt, xa);
+            tt += step;
+            if (tt < ntile) loadRows(tt, xa);
+        }
+    }
+}
+
 static int numCUs();
 static bool conv1x1ResidentShape(int KH, int KW, int stride, int pad, int Cin, int Cout, int rows) {
     static int on = -1;            // DSVT_CONV_1X1_RESIDENT=0: the halo / gather kernels for the 1 x 1 layers too
@@ -1838,6 +1977,19 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
         return lastError(); } while (0)
     if (a.xscale && a.KH == 1) {                                // 1 x 1 layers on the fp16 + fp8 K loop (packMX1x1 image)
         if (ctWide != 8) return -3;
+        static int res1 = -1;      // DSVT_CONV_1X1_RESIDENT=0: the halo kernel
+        if (res1 < 0) res1 = ablateEnv("DSVT_CONV_1X1_RESIDENT", 1);
+        const int C = a.Cin / 3, ngroup = a.CoutRows / 128;
+        // (C = 256 -- the 256 -> 16 x 128 deblock -- stays on the halo kernel: its rows are 64 registers, there is no second set in flight and hipcc
+        // spills 77 registers: 490 us against 352; DSVT_CONV_1X1_RESIDENT=2 in the ablation build runs it)
+        if (res1 && a.Cout == 128 && a.CoutRows % 128 == 0 && (C == 128 || C == 192 || (C == 256 && res1 == 2)) && a.wide && !a.res && !a.out_f32 && a.split_out && a.stride == 1 &&
+            (ngroup == 1 || ngroup == 4 || ngroup == 16) && ncu % (8 * ngroup) == 0) {
+            const int NCT = cdiv(a.CoutRows, CNB) * 8;
+            if (C == 128) hipLaunchKernelGGL((conv1x1_resident_mx_kernel<4>), dim3(ncu), dim3(64 * C1_NW), 0, stream, a, Wp, NCT, ngroup);
+            else if (C == 192) hipLaunchKernelGGL((conv1x1_resident_mx_kernel<6>), dim3(ncu), dim3(64 * C1_NW), 0, stream, a, Wp, NCT, ngroup);
+            else hipLaunchKernelGGL((conv1x1_resident_mx_kernel<8>), dim3(ncu), dim3(64 * C1_NW), 0, stream, a, Wp, NCT, ngroup);
+            return lastError();
+        }
         const int nit = cdiv(a.Ho, 8) * tilesX * nchunk * NBI;
         hipLaunchKernelGGL((conv_halo_kernel<8, 1, 8, 2, true, true>), dim3(nit < ncu ? nit : ncu), dim3(512), 0, stream, a, Wp, zeros, tilesX, nit, nchunk, dbg);
         return lastError();
