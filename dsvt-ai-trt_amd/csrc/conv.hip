@@ -1815,12 +1815,17 @@ conv1x1_resident_mx_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT,
     };
     const int C = a.Cin / 3;
     struct Rows { half8 h[KQ]; intx8 x[NPM]; };
-    auto loadRows = [&](int t, Rows& w) {
+    auto loadH = [&](int t, Rows& w) {
         t = t < ntile ? t : ntile - 1;                               // (past the end: the last tile again, no branch around a load)
         const int p = t * 16 + r, pc = p < NPIX ? p : NPIX - 1;
         const _Float16* src = a.in + (size_t)pc * a.Cin;
 #pragma unroll
         for (int q = 0; q < KQ; ++q) w.h[q] = *reinterpret_cast<const half8*>(src + q * 32 + g * 8);
+    };
+    auto loadX = [&](int t, Rows& w) {
+        t = t < ntile ? t : ntile - 1;
+        const int p = t * 16 + r, pc = p < NPIX ? p : NPIX - 1;
+        const _Float16* src = a.in + (size_t)pc * a.Cin;
         // x8 plane: per 64 channels 128 bytes = two 32-channel groups of [lo8 0..15 | hi8 0..15 | lo8 16..31 | hi8 16..31]; lane group g: chunks 4 (g >> 1) + (g & 1), + 2
         const unsigned char* xs_ = reinterpret_cast<const unsigned char*>(src + 2 * C) + (4 * (g >> 1) + (g & 1)) * 16;
 #pragma unroll
@@ -1829,18 +1834,23 @@ conv1x1_resident_mx_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT,
             w.x[ph] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
     };
-    const unsigned char* slot = smem + lane * 16;
+    auto loadRows = [&](int t, Rows& w) { loadH(t, w); loadX(t, w); };
     const int Wout = a.Wo * a.up;
     int xsc[2] = {0, 0};                                             // scale byte of row (tile u, r) in byte u & 3 of xsc[u >> 2]
-    auto tile = [&](int t, const Rows& w) {
+    auto tile = [&](int t, Rows& w, auto afterMain) {                 // afterMain(): called when the fp16 steps have been issued (the hi rows are dead)
         const int p = t * 16 + r;
         const bool valid = p < NPIX;
         int b, y, xq;
         split(valid ? p : 0, b, y, xq);
+        // (LDS addresses from an opaque copy of the lane offset: as loop invariants hipcc hoists the eight bias vectors -- 32 registers -- and every
+        // fragment address out of the tile loop and spills them)
+        int lo16 = lane * 16, g16 = g * 16;
+        asm volatile("" : "+v"(lo16), "+v"(g16));
+        const unsigned char* slot = smem + lo16;
         floatx4 acc[CTG];
 #pragma unroll
         for (int u = 0; u < CTG; ++u) {
-            const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + BIAS_OFF + (u * 16 + 4 * g) * 4);
+            const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + BIAS_OFF + u * 64 + g16);
             acc[u] = a.bias ? b4 : floatx4{0.f, 0.f, 0.f, 0.f};
         }
         // KQ fp16 steps (eight 1 KB fragments) then 2 NPM half-steps of the fp8 phases (four column tiles x 2 KB): eight 16-byte reads per step, those of
@@ -1861,6 +1871,7 @@ conv1x1_resident_mx_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT,
 #pragma unroll
         for (int s_ = 0; s_ < NSTEP_; ++s_) {
             if (s_ + 1 < NSTEP_) loadStep(s_ + 1, fb[(s_ + 1) & 1]);
+            if (s_ == KQ) afterMain();
             __builtin_amdgcn_sched_barrier(0);
             const intx4 (&f)[8] = fb[s_ & 1];
             if (s_ < KQ) {
@@ -1878,7 +1889,10 @@ conv1x1_resident_mx_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT,
         }
         const size_t opix = (size_t)((b * a.Ho + y) * a.up + dy) * Wout + (xq * a.up + dx);
 #pragma unroll
-        for (int u = 0; u < CTG; u += 2) convStoreWide<false, true>(a, acc[u], acc[u + 1], valid, opix, cbase + u * 16, g);
+        for (int u = 0; u < CTG; u += 2) {
+            convStoreWide<false, true>(a, acc[u], acc[u + 1], valid, opix, cbase + u * 16, g);
+            __builtin_amdgcn_sched_barrier(0);                          // (one pair of tiles at a time: the split / e4m3 encoding of all four pairs at once spills)
+        }
     };
     int tt = j * C1_NW + wave;
     Rows xa;
@@ -1893,17 +1907,19 @@ conv1x1_resident_mx_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT,
         while (tt < ntile) {
             const int tn = tt + step;
             loadRows(tn, xb);
-            tile(tt, xa);
+            tile(tt, xa, [] {});
             if (tn >= ntile) break;
             tt = tn + step;
             loadRows(tt, xa);
-            tile(tn, xb);
+            tile(tn, xb, [] {});
         }
     } else {
         // the rows of a tile are 48 / 64 registers: a second set does not fit beside the accumulators, the fragment buffers and the split epilogue -- the wave
-        // that shares the SIMD covers the load
+        // that shares the SIMD covers the load.  (Letting the two planes take turns -- the x8 chunks requested when a tile's fp16 steps start, the next
+        // tile's hi rows when they end -- was built: 304 vs 286 us at C = 192, and at C = 256 hipcc spills 107 registers either way: 490-690 us against
+        // the halo kernel's 352, which is why that layer stays there.)
         while (tt < ntile) {
-            tile(tt, xa);
+            tile(tt, xa, [] {});
             tt += step;
             if (tt < ntile) loadRows(tt, xa);
         }
