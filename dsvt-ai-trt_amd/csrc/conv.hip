@@ -1778,24 +1778,30 @@ conv1x1_resident_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT, in
 // input sixteen times, 6 MB of LDS-DMA per CU and launch, 352 us per four frames for 0.5 GB of HBM traffic.  Here the waves walk 16-pixel tiles with their
 // rows (hi fragments + the two 16-byte x8 chunks per 64 channels) straight from global, next tile in flight under the current one; the workgroups of a
 // column group's sixteen (four) siblings that read the same pixels sit on one XCD.
-template <int KQ>                 // fp16 k-steps (C / 32): 4, 6, 8
+// KQ = fp16 k-steps per PASS, NH = passes over a pixel tile (C = 32 KQ NH; accumulators kept between the passes of a tile).  A pass needs its rows in
+// registers -- 4 KQ for the hi fragments + 4 KQ for the x8 chunks -- and the NEXT pass's rows in flight, beside 32 accumulator and 64 fragment registers and the
+// split epilogue: <4, 1> for C = 128, <2, 3> for C = 192, <4, 2> for C = 256.  The one-pass forms of the larger layers were built first: <6, 1> with one set of
+// rows (a second spills): 256 us for the 192 -> 128 shortcut against 225; <8, 1>: 77-107 spilled registers in every arrangement tried (plain, or the two planes
+// taking turns), 490-690 us for the 256 -> 16 x 128 deblock against the halo kernel's 352 and the two-pass form's 215.  (Several passes sum per pass
+// [main, cross]: the same products as the halo kernel's [all main, all cross] in another fp32 order; <4, 1> is the halo kernel's order.)
+template <int KQ, int NH>
 __global__ void __launch_bounds__(64 * C1_NW, 1)
 conv1x1_resident_mx_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT, int ngroup)
 {
-    constexpr int NPM = KQ / 2, CTG = 8;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KQ * CTG * 1024 + 1024];      // [fp16 k-step][tile] | [cross phase][tile][2] | bias (512 B) + scale bytes (128 B)
-    constexpr int CROSS_OFF = KQ * CTG * 1024, BIAS_OFF = 2 * KQ * CTG * 1024;
+    constexpr int NPM = KQ / 2, CTG = 8, KQT = KQ * NH, NPT = NPM * NH;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KQT * CTG * 1024 + 1024];     // [fp16 k-step][tile] | [cross phase][tile][2] | bias (512 B) + scale bytes (128 B)
+    constexpr int CROSS_OFF = KQT * CTG * 1024, BIAS_OFF = 2 * KQT * CTG * 1024;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
     // workgroup -> (column group, row stream): the ngroup workgroups of a stream on one XCD (workgroups go to the XCDs round-robin)
     const int nx = (int)gridDim.x / 8, xcd = (int)blockIdx.x % 8, sl = (int)blockIdx.x / 8;        // (the grid is a multiple of 8 ngroup)
     const int type = sl % ngroup, j = xcd * (nx / ngroup) + sl / ngroup, nj = (int)gridDim.x / ngroup;
     const unsigned char* Wb = reinterpret_cast<const unsigned char*>(Wp);
-    const size_t mainRows = (size_t)KQ * NCT;
-    for (int u = wave; u < KQ * CTG; u += C1_NW) {                    // fp16 rows: [q][NCT] -> [q][CTG]
+    const size_t mainRows = (size_t)KQT * NCT;
+    for (int u = wave; u < KQT * CTG; u += C1_NW) {                   // fp16 rows: [q][NCT] -> [q][CTG]
         const int q = u / CTG, t = u - q * CTG;
         __builtin_amdgcn_global_load_lds((glds_src_t)(Wb + (((size_t)q * NCT + type * CTG + t) * 64 + lane) * 16), (glds_dst_t)(smem + u * 1024), 16, 0, 0);
     }
-    for (int u = wave; u < NPM * CTG * 2; u += C1_NW) {               // cross rows: [ph][NCT][2] -> [ph][CTG][2]
+    for (int u = wave; u < NPT * CTG * 2; u += C1_NW) {               // cross rows: [ph][NCT][2] -> [ph][CTG][2]
         const int ph = u / (CTG * 2), t2 = u - ph * CTG * 2;
         __builtin_amdgcn_global_load_lds((glds_src_t)(Wb + ((mainRows + ((size_t)ph * NCT + type * CTG) * 2 + t2) * 64 + lane) * 16), (glds_dst_t)(smem + CROSS_OFF + u * 1024), 16, 0, 0);
     }
@@ -1814,44 +1820,40 @@ conv1x1_resident_mx_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT,
         xq = rem - y * a.Wo;
     };
     const int C = a.Cin / 3;
+    const int tt0 = j * C1_NW + wave;
+    const int nunit = tt0 < ntile ? ((ntile - tt0 + step - 1) / step) * NH : 0;      // (tile, pass) units of this wave: unit v = tile tt0 + (v / NH) step, pass v % NH
     struct Rows { half8 h[KQ]; intx8 x[NPM]; };
-    auto loadH = [&](int t, Rows& w) {
-        t = t < ntile ? t : ntile - 1;                               // (past the end: the last tile again, no branch around a load)
+    auto loadRows = [&](int v, Rows& w) {
+        v = v < nunit ? v : nunit - 1;                               // (past the end: the last unit again, no branch around a load)
+        const int t = tt0 + (v / NH) * step, hp = v % NH;
         const int p = t * 16 + r, pc = p < NPIX ? p : NPIX - 1;
         const _Float16* src = a.in + (size_t)pc * a.Cin;
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) w.h[q] = *reinterpret_cast<const half8*>(src + q * 32 + g * 8);
-    };
-    auto loadX = [&](int t, Rows& w) {
-        t = t < ntile ? t : ntile - 1;
-        const int p = t * 16 + r, pc = p < NPIX ? p : NPIX - 1;
-        const _Float16* src = a.in + (size_t)pc * a.Cin;
+        for (int q = 0; q < KQ; ++q) w.h[q] = *reinterpret_cast<const half8*>(src + (hp * KQ + q) * 32 + g * 8);
         // x8 plane: per 64 channels 128 bytes = two 32-channel groups of [lo8 0..15 | hi8 0..15 | lo8 16..31 | hi8 16..31]; lane group g: chunks 4 (g >> 1) + (g & 1), + 2
-        const unsigned char* xs_ = reinterpret_cast<const unsigned char*>(src + 2 * C) + (4 * (g >> 1) + (g & 1)) * 16;
+        const unsigned char* xs_ = reinterpret_cast<const unsigned char*>(src + 2 * C) + hp * NPM * 128 + (4 * (g >> 1) + (g & 1)) * 16;
 #pragma unroll
         for (int ph = 0; ph < NPM; ++ph) {
             const intx4 lo = *reinterpret_cast<const intx4*>(xs_ + ph * 128), hi = *reinterpret_cast<const intx4*>(xs_ + ph * 128 + 32);
             w.x[ph] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
     };
-    auto loadRows = [&](int t, Rows& w) { loadH(t, w); loadX(t, w); };
     const int Wout = a.Wo * a.up;
     int xsc[2] = {0, 0};                                             // scale byte of row (tile u, r) in byte u & 3 of xsc[u >> 2]
-    auto tile = [&](int t, Rows& w, auto afterMain) {                 // afterMain(): called when the fp16 steps have been issued (the hi rows are dead)
-        const int p = t * 16 + r;
-        const bool valid = p < NPIX;
-        int b, y, xq;
-        split(valid ? p : 0, b, y, xq);
+    floatx4 acc[CTG];
+    auto unit = [&](int v, const Rows& w) {
+        const int t = tt0 + (v / NH) * step, hp = NH == 1 ? 0 : v % NH;
         // (LDS addresses from an opaque copy of the lane offset: as loop invariants hipcc hoists the eight bias vectors -- 32 registers -- and every
         // fragment address out of the tile loop and spills them)
         int lo16 = lane * 16, g16 = g * 16;
         asm volatile("" : "+v"(lo16), "+v"(g16));
         const unsigned char* slot = smem + lo16;
-        floatx4 acc[CTG];
+        if (hp == 0) {
 #pragma unroll
-        for (int u = 0; u < CTG; ++u) {
-            const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + BIAS_OFF + u * 64 + g16);
-            acc[u] = a.bias ? b4 : floatx4{0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < CTG; ++u) {
+                const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + BIAS_OFF + u * 64 + g16);
+                acc[u] = a.bias ? b4 : floatx4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         // KQ fp16 steps (eight 1 KB fragments) then 2 NPM half-steps of the fp8 phases (four column tiles x 2 KB): eight 16-byte reads per step, those of
         // step s + 1 issued before the MFMAs of step s (left alone hipcc hoists the reads of the whole tile: 500 spilled registers)
@@ -1860,9 +1862,9 @@ conv1x1_resident_mx_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT,
         auto loadStep = [&](int s_, intx4 (&f)[8]) {
             if (s_ < KQ) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) f[u] = *reinterpret_cast<const intx4*>(slot + (s_ * CTG + u) * 1024);
+                for (int u = 0; u < 8; ++u) f[u] = *reinterpret_cast<const intx4*>(slot + ((hp * KQ + s_) * CTG + u) * 1024);
             } else {
-                const int ph = (s_ - KQ) >> 1, u0 = ((s_ - KQ) & 1) * 4;
+                const int ph = hp * NPM + ((s_ - KQ) >> 1), u0 = ((s_ - KQ) & 1) * 4;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const intx4*>(slot + CROSS_OFF + (((ph * CTG + u0) * 2) + i) * 1024);
             }
@@ -1871,7 +1873,6 @@ conv1x1_resident_mx_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT,
 #pragma unroll
         for (int s_ = 0; s_ < NSTEP_; ++s_) {
             if (s_ + 1 < NSTEP_) loadStep(s_ + 1, fb[(s_ + 1) & 1]);
-            if (s_ == KQ) afterMain();
             __builtin_amdgcn_sched_barrier(0);
             const intx4 (&f)[8] = fb[s_ & 1];
             if (s_ < KQ) {
@@ -1887,41 +1888,39 @@ conv1x1_resident_mx_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT,
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        const size_t opix = (size_t)((b * a.Ho + y) * a.up + dy) * Wout + (xq * a.up + dx);
+        if (hp == NH - 1) {
+            const int p = t * 16 + r;
+            const bool valid = p < NPIX;
+            int b, y, xq;
+            split(valid ? p : 0, b, y, xq);
+            const size_t opix = (size_t)((b * a.Ho + y) * a.up + dy) * Wout + (xq * a.up + dx);
 #pragma unroll
-        for (int u = 0; u < CTG; u += 2) {
-            convStoreWide<false, true>(a, acc[u], acc[u + 1], valid, opix, cbase + u * 16, g);
-            __builtin_amdgcn_sched_barrier(0);                          // (one pair of tiles at a time: the split / e4m3 encoding of all four pairs at once spills)
+            for (int u = 0; u < CTG; u += 2) {
+                convStoreWide<false, true>(a, acc[u], acc[u + 1], valid, opix, cbase + u * 16, g);
+                __builtin_amdgcn_sched_barrier(0);                      // (one pair of tiles at a time)
+            }
         }
     };
-    int tt = j * C1_NW + wave;
     Rows xa;
-    loadRows(tt, xa);
+    if (nunit > 0) loadRows(0, xa);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the weights (and the first rows) have landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int u = 0; u < CTG; ++u) xsc[u >> 2] |= (int)smem[BIAS_OFF + 512 + u * 16 + r] << (8 * (u & 3));
-    if constexpr (KQ == 4) {                                          // (two sets of rows in flight: 2 x 32 registers)
+    if constexpr (KQ <= 4) {                                          // (two sets of rows in flight: 2 x 32 registers)
         Rows xb;
-        while (tt < ntile) {
-            const int tn = tt + step;
-            loadRows(tn, xb);
-            tile(tt, xa, [] {});
-            if (tn >= ntile) break;
-            tt = tn + step;
-            loadRows(tt, xa);
-            tile(tn, xb, [] {});
+        for (int v = 0; v < nunit; v += 2) {
+            loadRows(v + 1, xb);
+            unit(v, xa);
+            if (v + 1 >= nunit) break;
+            loadRows(v + 2, xa);
+            unit(v + 1, xb);
         }
-    } else {
-        // the rows of a tile are 48 / 64 registers: a second set does not fit beside the accumulators, the fragment buffers and the split epilogue -- the wave
-        // that shares the SIMD covers the load.  (Letting the two planes take turns -- the x8 chunks requested when a tile's fp16 steps start, the next
-        // tile's hi rows when they end -- was built: 304 vs 286 us at C = 192, and at C = 256 hipcc spills 107 registers either way: 490-690 us against
-        // the halo kernel's 352, which is why that layer stays there.)
-        while (tt < ntile) {
-            tile(tt, xa, [] {});
-            tt += step;
-            if (tt < ntile) loadRows(tt, xa);
+    } else {                                                          // (one set of rows: kept for A/B builds of the one-pass forms)
+        for (int v = 0; v < nunit; ++v) {
+            unit(v, xa);
+            if (v + 1 < nunit) loadRows(v + 1, xa);
         }
     }
 }
@@ -1996,14 +1995,12 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
         static int res1 = -1;      // DSVT_CONV_1X1_RESIDENT=0: the halo kernel
         if (res1 < 0) res1 = ablateEnv("DSVT_CONV_1X1_RESIDENT", 1);
         const int C = a.Cin / 3, ngroup = a.CoutRows / 128;
-        // (C = 256 -- the 256 -> 16 x 128 deblock -- stays on the halo kernel: its rows are 64 registers, there is no second set in flight and hipcc
-        // spills 77 registers: 490 us against 352; DSVT_CONV_1X1_RESIDENT=2 in the ablation build runs it)
-        if (res1 && a.Cout == 128 && a.CoutRows % 128 == 0 && (C == 128 || C == 192 || (C == 256 && res1 == 2)) && a.wide && !a.res && !a.out_f32 && a.split_out && a.stride == 1 &&
+        if (res1 && a.Cout == 128 && a.CoutRows % 128 == 0 && (C == 128 || C == 192 || C == 256) && a.wide && !a.res && !a.out_f32 && a.split_out && a.stride == 1 &&
             (ngroup == 1 || ngroup == 4 || ngroup == 16) && ncu % (8 * ngroup) == 0) {
             const int NCT = cdiv(a.CoutRows, CNB) * 8;
-            if (C == 128) hipLaunchKernelGGL((conv1x1_resident_mx_kernel<4>), dim3(ncu), dim3(64 * C1_NW), 0, stream, a, Wp, NCT, ngroup);
-            else if (C == 192) hipLaunchKernelGGL((conv1x1_resident_mx_kernel<6>), dim3(ncu), dim3(64 * C1_NW), 0, stream, a, Wp, NCT, ngroup);
-            else hipLaunchKernelGGL((conv1x1_resident_mx_kernel<8>), dim3(ncu), dim3(64 * C1_NW), 0, stream, a, Wp, NCT, ngroup);
+            if (C == 128) hipLaunchKernelGGL((conv1x1_resident_mx_kernel<4, 1>), dim3(ncu), dim3(64 * C1_NW), 0, stream, a, Wp, NCT, ngroup);
+            else if (C == 192) hipLaunchKernelGGL((conv1x1_resident_mx_kernel<2, 3>), dim3(ncu), dim3(64 * C1_NW), 0, stream, a, Wp, NCT, ngroup);
+            else hipLaunchKernelGGL((conv1x1_resident_mx_kernel<4, 2>), dim3(ncu), dim3(64 * C1_NW), 0, stream, a, Wp, NCT, ngroup);
             return lastError();
         }
         const int nit = cdiv(a.Ho, 8) * tilesX * nchunk * NBI;
