@@ -409,14 +409,14 @@ def roofline_rows(prof, sampled, counts, pool_len, FB, mode, n_points_per_launch
                                        "set_attention_f16_kernel" if f16 else "set_attention_split_kernel" if split else "set_attention_kernel("),
             "DsvtPosEmbedPlugin": ("posembed_batched_kernel (8 position-embedding MLPs, v_mfma_f32_16x16x32_f16)", "hbm", "posembed_batched_kernel"),
             "DsvtPillarFeatureNetPlugin": ("pfn_kernel (both PFN layers + scatter-max, v_mfma_f32_16x16x4_f32 + 16x16x32_f16; peak = the mix of the two matrix rates; a wave owns a work-balanced group of up to 16 pillars; bound by dependent LDS / L2 round trips at two waves per SIMD, not by either)" + sp_, "mfma", "pfn_kernel"),
-            "DsvtConv2dPlugin": ("conv_wide_kernel / conv_halo_kernel / conv_f16_kernel (implicit GEMM, v_mfma_f32_16x16x32_f16)" +
+            "DsvtConv2dPlugin": ("conv_wide_kernel / conv_halo_kernel / conv_f16_kernel / conv1x1_resident(_mx)_kernel / conv3x3_grouped_narrow(_split)_kernel (implicit GEMM, v_mfma_f32_16x16x32_f16)" +
                                  (" -- 3 x 3 stride-1 layers with > 32 output channels (93 % of the products) on the fp16 + fp8 K loop over [hi | x8]: one fp16 MFMA product + "
                                   "two e4m3 correction products (v_mfma_scale_f32_16x16x128_f8f6f4) per fp32-grade product; the other layers walk [hi | lo | hi] x "
                                   "[w_hi | w_hi | w_lo], three fp16 MFMAs per product; peak = the launch-weighted mix of the two" if (split and head_mx) else
                                   " on [hi | lo | hi] x [w_hi | w_hi | w_lo]: three MFMAs per fp32-grade product" if split else ""), "mfma", "conv"),
             "Points2FeaturesPlugin": ("p2f_partition -> p2f_bins -> p2f_pillar: the voxelizer, SURVEY 8a-1", "hbm", "dsvt::p2f_"),
             "DsvtSetPartitionPlugin": ("sp_count -> sp_scan -> sp_scatter -> sp_window (+ one memset): WindowPartition + GetSet of both window configurations, SURVEY 8a-3/4", "hbm", ("dsvt::sp_", "sp_window")),
-            "Map2BevPlugin": ("map2bev_kernel + the zero fill of the dense map (plugins/src/map2bev.cu:250-310)", "hbm", "map2bev")}
+            "Map2BevPlugin": ("map2bev_kernel + map2bev_clear_kernel: the scatter and the zeroing of the cells the previous call wrote (persistent_output; the stateless plugin fills the whole map, plugins/src/map2bev.cu:250-310)", "hbm", "map2bev")}
     rows_out = []
     for ptype, lst in prof.items():
         if not lst or ptype not in meta:
