@@ -325,7 +325,8 @@ class DsvtPipeline:
         mx = self.head_mx
 
         def conv(name, rows, bias, H, cin, cout, k, stride, relu, res=False, out_f32=False, plane=None, lo=True, res_lo=True, res_only=False, **kw):
-            # res_only (head_mx only): the tensor is only ever a residual (hi + lo): its third plane is not written (split_output = 4)
+            # res_only (head_mx only): no consumer reads the tensor's third plane -- it is only ever a residual, or the input of a three-product layer that
+            # takes hi and lo (and hi again from plane 0) --: not written (split_output = 4)
             # lo = False (head_mx only): every consumer of this tensor is a [hi | x8] layer and it is nobody's residual -- its lo plane is not written
             plane = cout if plane is None else plane
             # head_mx: the third plane of every tensor holds the fp8 operands (x8).  The 3 x 3 stride-1 layers with > 32 output channels (93 % of the
@@ -375,7 +376,7 @@ class DsvtPipeline:
         for n in names:
             s_, sh_ = bn_fold(w, f"module.dense_head.heads_list.0.{n}.0.1", 1e-3)
             W0.append(w[f"module.dense_head.heads_list.0.{n}.0.0.weight"] * s_[:, None, None, None]); b0.append(sh_)
-        conv("heads0", cw(np.concatenate(W0, 0)), np.concatenate(b0), GY, 64, 320, 3, 1, True)
+        conv("heads0", cw(np.concatenate(W0, 0)), np.concatenate(b0), GY, 64, 320, 3, 1, True, res_only=True)      # (read by heads1 only: three fp16 products over hi and lo, no x8)
         W1 = np.zeros((sum(outs), 320, 3, 3), np.float32); b1 = np.zeros((sum(outs),), np.float32)
         o = 0
         for k_, (n, no) in enumerate(zip(names, outs)):                                       # block-diagonal second convs
