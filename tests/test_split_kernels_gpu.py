@@ -54,6 +54,28 @@ def test_qkv_split_kernel_against_fp64_product(pkg, MR, n, table):
     assert again.serialize() == op.serialize()
 
 
+@pytest.mark.parametrize("N,add_cols,n", [(384, 192, 5504), (192, 0, 777), (960, 192, 130), (768, 768, 3001), (576, 0, 34483)])
+def test_split_linear_of_other_shapes_on_the_streamed_kernel(pkg, N, add_cols, n):
+    """The QKV shape (N = 576, add_cols a multiple of 192) runs on linear_split_resident_kernel; every other split-precision linear -- other widths, or a
+    position-added column range that is not whole thirds -- on linear_split_rows_kernel (all column chunks of a 128-row tile per workgroup, weights
+    streamed): the same 2e-6 of scale against the fp64 product."""
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(N + n)
+    C, MR = 192, 65536
+    x = torch.randn((1, MR, C), generator=g); pos = torch.randn((1, MR, C), generator=g) * 0.5
+    W = (torch.randn((N, C), generator=g) / np.sqrt(C)); b = torch.randn(N, generator=g) * 0.1
+    op = P.add_linear_op(W.numpy(), b.numpy(), MR, add_cols=add_cols, compute_type=P.COMPUTE_SPLIT)
+    cnt = torch.tensor([n], dtype=torch.int32, device=DEV)
+    got = (op(x.to(DEV), cnt, pos.to(DEV)) if add_cols else op(x.to(DEV), cnt))[0]
+    torch.cuda.synchronize()
+    Wd = W.double()
+    xs = (x[0, :n] + pos[0, :n]).double()
+    ref = torch.cat([xs @ Wd[:add_cols].T, x[0, :n].double() @ Wd[add_cols:].T], 1) + b.double()
+    err = (got[0, :n].double().cpu() - ref).abs()
+    assert err.max().item() < 2e-6 * ref.abs().max().item()
+    assert not got[0, n:].any()
+
+
 def test_split_operand_range(pkg):
     """operands far from 1: tiny weights (lo parts in the fp16 subnormal range: absolute step 2^-24, i.e. the split carries
     ~2^-18 of a 0.01-sized operand, not 2^-22) and activations beyond the fp16 range (hi saturates at 65504, no inf / NaN)."""
