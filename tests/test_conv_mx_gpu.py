@@ -287,9 +287,12 @@ def mx_rows_emulation(x, rows, bias_rows):
     (26, 23, 128, 128, 2, 1),       # second deblock: ConvTranspose 2 x 2 / 2 as a 1 x 1 layer with a pixel shuffle
     (13, 11, 256, 128, 4, 2),       # third deblock, two images
     (468, 468, 128, 128, 1, 1),     # first deblock at full size
+    (40, 37, 320, 128, 1, 1),       # channel counts conv1x1_resident_mx_kernel does not take (it serves C = 128 / 192 / 256): conv_halo_kernel<.., MX>
+    (33, 30, 64, 128, 2, 1),
 ])
 def test_mx_1x1_layers_and_deblocks(pkg, H, W, cin, cout, up, B):
-    """1 x 1 layers of the fp32-grade dense stage on conv_halo_kernel<.., MX> (split_input = 2), deconvBnLELU included (stride == kernel ConvTranspose,
+    """1 x 1 layers of the fp32-grade dense stage on the fp16 + fp8 K loop (split_input = 2: conv1x1_resident_mx_kernel in one, three and two passes for C = 128 /
+    192 / 256, conv_halo_kernel<.., MX> for other widths), deconvBnLELU included (stride == kernel ConvTranspose,
     src/dsvt-ai-trt.cpp:217-246), written into a channel slice of the concat buffer with split_output = 3 ([hi | - | x8])"""
     P = pkg.plugin
     g = torch.Generator(device="cpu").manual_seed(H * 100 + cin + up)
