@@ -25,15 +25,18 @@ __device__ __forceinline__ float waveMaxF(float v) {
     return v;
 }
 
-// inclusive scan across the 64 lanes of a wave
+// inclusive scan across the 64 lanes of a wave: six DPP adds -- row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then row_bcast15 into rows 1 and
+// 3 and row_bcast31 into rows 2 and 3 (lanes without a source add `old` = 0).  (Six __shfl_up steps are six ds_bpermute round trips through the
+// LDS crossbar, ~0.4 us of pure latency per scan: sp_scan's three workgroup scans were most of its 8 us.)
 __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v) {
-    const int lane = laneId();
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        uint32_t t = __shfl_up(v, o, kWave);
-        if (lane >= o) v += t;
-    }
-    return v;
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return (uint32_t)x;
 }
 
 // Exclusive scan of one uint32 per thread over a workgroup of NT threads (NT multiple of 64,
@@ -68,14 +71,11 @@ __device__ __forceinline__ void blockExclusiveScanK(uint32_t (&v)[K], uint32_t* 
 #pragma unroll
     for (int k = 0; k < K; ++k) { inc[k] = waveInclusiveScan(v[k]); if (lane == kWave - 1) smem[k * (NW + 1) + wave] = inc[k]; }
     __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const uint32_t w = lane < NW ? smem[k * (NW + 1) + lane] : 0;
-            const uint32_t wi = waveInclusiveScan(w);
-            if (lane < NW) smem[k * (NW + 1) + lane] = wi - w;
-            if (lane == NW - 1) smem[k * (NW + 1) + NW] = wi;
-        }
+    for (int k = wave; k < K; k += NW) {            // the wave totals of value k are scanned by wave k mod NW
+        const uint32_t w = lane < NW ? smem[k * (NW + 1) + lane] : 0;
+        const uint32_t wi = waveInclusiveScan(w);
+        if (lane < NW) smem[k * (NW + 1) + lane] = wi - w;
+        if (lane == NW - 1) smem[k * (NW + 1) + NW] = wi;
     }
     __syncthreads();
 #pragma unroll

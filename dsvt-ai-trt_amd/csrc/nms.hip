@@ -10,11 +10,11 @@
 // whose centres are farther apart than the two half diagonals (+ margin) skips it, which is exactly the
 // case where the reference finds no intersection point and no contained corner and returns 0.
 //
-//   nms_sort   one workgroup: stable order of the n <= 512 rows by descending score (bitonic, LDS)
+//   nms_sort   one wave per 64 rows: stable order of the n <= 512 rows by descending score (a row's place = the number of larger keys)
 //   nms_mask   one wave per (row j, 64-row word): bit i = IoU(i, j) >= thresh for i < j (ballot) -- the transposed mask
 //   nms_scan   mask in LDS; one wave sweeps 64 rows at a time (suppression by earlier blocks is a parallel test
-//              against their kept sets, the walk inside a block is register-only), then the kept rows are
-//              written in score order
+//              against their kept sets, inside a block the greedy walk is the fixed point of a triangular system,
+//              reached in a few whole-wave rounds), then the kept rows are written in score order
 // Outputs: rows [1, max_boxes, 9] (the input row of every kept box, i.e. x, y, z, l, w, h, rt, id,
 // score as helper.h:452-460 prints them), keep_idx [1, max_boxes] (input row numbers), count [1].
 #include "plugin_base.h"
@@ -129,36 +129,37 @@ __device__ float boxOverlap(const Bnd& a, const Bnd& b, const Trig& ta, const Tr
 }
 
 // ---- kernels -------------------------------------------------------------------------------
-__global__ void __launch_bounds__(512)
+// blockIdx.x = 64-row slice of the frame, blockIdx.y = frame of a stack; one wavefront
+__global__ void __launch_bounds__(64)
 nms_sort(const float* __restrict__ rows, const uint32_t* __restrict__ count, int max_boxes, uint32_t* __restrict__ order, float4* __restrict__ trig)
 {
     __shared__ unsigned long long sk[NMS_MAX];       // (score key << 32) | ~row : descending = score desc, row asc (stable)
-    const int t = threadIdx.x;
-    rows += (size_t)blockIdx.x * max_boxes * 9; count += blockIdx.x; order += (size_t)blockIdx.x * NMS_MAX; trig += (size_t)blockIdx.x * NMS_MAX;   // frame of a stack
+    const int lane = threadIdx.x, t = blockIdx.x * 64 + lane;
+    rows += (size_t)blockIdx.y * max_boxes * 9; count += blockIdx.y; order += (size_t)blockIdx.y * NMS_MAX; trig += (size_t)blockIdx.y * NMS_MAX;
     int n = (int)*count; if (n > max_boxes) n = max_boxes;
-    unsigned long long e = 0ull;
-    if (t < n) {
-        const uint32_t u = __float_as_uint(rows[(size_t)t * 9 + 8]);
+    if (blockIdx.x * 64 >= n) return;
+    auto keyOf = [&](int r) {
+        const uint32_t u = __float_as_uint(rows[(size_t)r * 9 + 8]);
         const uint32_t key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-        e = ((unsigned long long)key << 32) | (uint32_t)~(uint32_t)t;
-    }
-    sk[t] = e;
+        return ((unsigned long long)key << 32) | (uint32_t)~(uint32_t)r;
+    };
+    for (int j = lane; j < n; j += 64) sk[j] = keyOf(j);
     __syncthreads();
-    for (int k = 2; k <= NMS_MAX; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (t < NMS_MAX / 2) {
-                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
-                const bool desc = (lo & k) == 0;
-                const unsigned long long a = sk[lo], b = sk[hi];
-                if ((a < b) == desc && a != b) { sk[lo] = b; sk[hi] = a; }
-            }
-            __syncthreads();
-        }
+    // The keys are distinct (they carry the row number), so a row's place is the number of larger keys: n broadcast reads of LDS, no
+    // exchange network (the 512-thread bitonic sort this replaces was 45 barriers on ONE CU, 9.7 us; a slice per wavefront spreads the
+    // n^2 comparisons over n / 64 CUs).
     if (t < n) {
-        const uint32_t src = ~(uint32_t)sk[t];
-        order[t] = src;
-        const Trig tg = boxTrig(rows[(size_t)src * 9 + 6]);           // of SORTED row t
-        trig[t] = make_float4(tg.c, tg.s, tg.cn, tg.sn);
+        const unsigned long long e = sk[t];
+        int rank = 0;
+        const int n8 = n & ~7;
+        for (int j = 0; j < n8; j += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rank += sk[j + u] > e ? 1 : 0;
+        }
+        for (int j = n8; j < n; ++j) rank += sk[j] > e ? 1 : 0;
+        order[rank] = (uint32_t)t;
+        const Trig tg = boxTrig(rows[(size_t)t * 9 + 6]);             // trig[] is indexed by SORTED row
+        trig[rank] = make_float4(tg.c, tg.s, tg.cn, tg.sn);
     }
 }
 
@@ -219,8 +220,7 @@ nms_scan(const float* __restrict__ rows, const uint32_t* __restrict__ count, con
     if (t < 64) {
         // Greedy sweep (helper.h:260-281), 64 sorted rows at a time, one wave.  Lane = row j of the block.  Whether an
         // EARLIER block suppresses j is a parallel test of j's transposed mask words against the kept sets of those blocks;
-        // inside the block the walk is serial but register-only: row j is kept unless suppressed from outside or by a
-        // row kept earlier in this block (its own word of the block, fetched with v_readlane).
+        // inside the block row j is kept unless suppressed from outside or by a row kept earlier in this block (its own word of the block).
         unsigned long long ks[NMS_WORDS];            // kept set, wave-uniform
 #pragma unroll
         for (int w = 0; w < NMS_WORDS; ++w) ks[w] = 0ull;
@@ -236,18 +236,17 @@ nms_scan(const float* __restrict__ rows, const uint32_t* __restrict__ count, con
                     if (wi < w) pre |= sm[j * NMS_WORDS + wi] & ks[wi];
                 const unsigned long long own = lane < nb ? sm[j * NMS_WORDS + w] : 0ull;
                 const unsigned long long outside = __ballot(pre != 0ull || lane >= nb);
-                const uint32_t olo = (uint32_t)own, ohi = (uint32_t)(own >> 32);
-                uint32_t klo = 0, khi = 0;
-                const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)outside), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(outside >> 32));
-                for (int b = 0; b < 32; ++b) {
-                    const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)olo, b);
-                    if (!((xlo >> b) & 1u) && !(mlo & klo)) klo |= 1u << b;
+                // Inside the block row b is kept iff nothing outside suppresses it and no KEPT earlier row of the block does: a triangular system
+                // (own has bits below the lane only), so its fixed point is unique and is the serial walk's answer.  Iterate all 64 rows at once
+                // from "everything not suppressed from outside is kept": after t rounds rows 0 .. t - 1 are final, and real frames settle in two
+                // or three rounds (the 64-step readlane walk this replaces was 12 of the kernel's 18 us).
+                unsigned long long kw = ~outside;
+                for (int it = 0; it < 64; ++it) {
+                    const unsigned long long nk2 = __ballot((own & kw) == 0ull) & ~outside;
+                    if (nk2 == kw) break;
+                    kw = nk2;
                 }
-                for (int b = 0; b < 32; ++b) {
-                    const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)olo, b + 32), mhi = (uint32_t)__builtin_amdgcn_readlane((int)ohi, b + 32);
-                    if (!((xhi >> b) & 1u) && !(mlo & klo) && !(mhi & khi)) khi |= 1u << b;
-                }
-                ks[w] = ((unsigned long long)khi << 32) | klo;
+                ks[w] = kw;
             }
         }
 #pragma unroll
@@ -312,7 +311,7 @@ public:
         float4* trig = c.take<float4>((size_t)NMS_MAX * nb);
         const float* rows = static_cast<const float*>(in[0]);
         const uint32_t* count = static_cast<const uint32_t*>(in[1]);
-        hipLaunchKernelGGL(nms_sort, dim3(nb), dim3(512), 0, stream, rows, count, max_boxes_, order, trig);
+        hipLaunchKernelGGL(nms_sort, dim3(NMS_MAX / 64, nb), dim3(64), 0, stream, rows, count, max_boxes_, order, trig);
         hipLaunchKernelGGL(nms_mask, dim3(max_boxes_, cdiv(max_boxes_, 64), nb), dim3(64), 0, stream, rows, count, order, trig, max_boxes_, thresh_, mask);
         hipLaunchKernelGGL(nms_scan, dim3(nb), dim3(512), 0, stream, rows, count, order, mask, max_boxes_, static_cast<float*>(out[0]),
                            static_cast<int32_t*>(out[1]), static_cast<uint32_t*>(out[2]), zeroFill);

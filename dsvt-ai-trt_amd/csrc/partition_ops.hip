@@ -540,11 +540,12 @@ sp_count(const uint4* __restrict__ coords, const uint32_t* __restrict__ voxel_nu
 }
 
 // one workgroup per configuration
+template <int WPT>                                // slabs of 1024 windows per round (the host picks it from the dense grid's size)
 __global__ void __launch_bounds__(1024)
 sp_scan(const uint32_t* __restrict__ win_cnt, SPParams sp, uint32_t* __restrict__ win_seg, uint32_t* __restrict__ rank2win,
         uint32_t* __restrict__ set_base, uint32_t* __restrict__ win_num, SPOuts outs)
 {
-    __shared__ uint32_t smem[1024 / kWave + 1];
+    __shared__ uint32_t smem[2 * WPT * (1024 / kWave + 1)];
     const int k = blockIdx.x;
     const WPParams& p = sp.wp[k];
     const int dense = sp.dense_off[k + 1] - sp.dense_off[k];
@@ -552,38 +553,46 @@ sp_scan(const uint32_t* __restrict__ win_cnt, SPParams sp, uint32_t* __restrict_
     rank2win += (size_t)k * p.max_win_num; set_base += (size_t)k * p.max_win_num;
     const uint32_t L = (uint32_t)sp.voxel_num_set, Vw = (uint32_t)p.max_voxel_num_per_win;
     uint32_t carry_o = 0, carry_f = 0, carry_s = 0;
-    // eight consecutive windows per thread: an 8192-window chunk per round of three workgroup scans (a 6400-window configuration of four
-    // frames is ONE round, not seven: 32 -> 19 us with four windows per thread)
-    constexpr int WPT = 8;
+    // A round covers WPT slabs of 1024 windows (a frame's 3200 dense windows: one round of four slabs, four frames' 12,800: two rounds of
+    // eight): thread t holds window t of every slab, so every load and store of the round is
+    // lane-contiguous (the ranks of a slab's non-empty windows ascend with the lane too).  All slabs are scanned across the workgroup at
+    // once (one set of barriers for the 2 WPT rank / voxel-offset scans, one for the WPT set-base scans); the slab totals chain in registers.
+    // (Eight CONSECUTIVE windows per thread, the layout before, made every access 32 bytes apart from its neighbour's: 64 cache lines per
+    // wavefront instruction through ONE CU's memory pipeline -- 21 us per four-frame launch, 8 of them for a single frame's 3200 windows.)
     for (int b = 0; b < dense; b += 1024 * WPT) {
-        const int w0 = b + threadIdx.x * WPT;
-        uint32_t c[WPT], so = 0, sf = 0;
+        uint32_t c[WPT], v[2 * WPT], tot2[2 * WPT];
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) { c[i] = w0 + i < dense ? win_cnt[w0 + i] : 0; so += c[i] > 0 ? 1u : 0u; sf += c[i]; }
-        uint32_t tot;
-        uint32_t eo = blockExclusiveScan<1024>(so, smem, &tot) + carry_o; carry_o += tot;
-        uint32_t ef = blockExclusiveScan<1024>(sf, smem, &tot) + carry_f; carry_f += tot;
+        for (int i = 0; i < WPT; ++i) {
+            const int w = b + i * 1024 + (int)threadIdx.x;
+            c[i] = w < dense ? win_cnt[w] : 0u;
+            v[i] = c[i] > 0 ? 1u : 0u; v[WPT + i] = c[i];
+        }
+        blockExclusiveScanK<1024, 2 * WPT>(v, smem, tot2);
         // sets of a ranked window: ceil(min(c, Vw) / L) (getSet.cu:335 on the clamped count of windowPartition.cu:336-340); windows beyond
         // the window capacity get none
-        uint32_t ns[WPT], ss = 0, eoi = eo;
-        bool ranked[WPT];
+        uint32_t eo[WPT], ns[WPT], ts[WPT];
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
-            ranked[i] = c[i] > 0 && eoi < (uint32_t)p.max_win_num;
-            ns[i] = ranked[i] ? setsOf(c[i] > Vw ? Vw : c[i], L) : 0u;
-            ss += ns[i]; eoi += c[i] > 0 ? 1u : 0u;
+            eo[i] = v[i] + carry_o; v[WPT + i] += carry_f;                  // exclusive rank / voxel offset of window (i, t)
+            carry_o += tot2[i]; carry_f += tot2[WPT + i];
+            const bool ranked = c[i] > 0 && eo[i] < (uint32_t)p.max_win_num;
+            ns[i] = ranked ? setsOf(c[i] > Vw ? Vw : c[i], L) : 0u;
         }
-        uint32_t es = blockExclusiveScan<1024>(ss, smem, &tot) + carry_s; carry_s += tot;
+        uint32_t es[WPT];
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) es[i] = ns[i];
+        blockExclusiveScanK<1024, WPT>(es, smem, ts);
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
-            if (w0 + i < dense) {
-                win_seg[w0 + i] = ef;
-                if (ranked[i]) {
-                    rank2win[eo] = (uint32_t)(w0 + i);
-                    set_base[eo] = es + ns[i] <= (uint32_t)sp.max_set_num ? es : kNoneU;      // capacity guard the reference lacks (getSet.cu:337)
+            const int w = b + i * 1024 + (int)threadIdx.x;
+            const uint32_t e = es[i] + carry_s; carry_s += ts[i];
+            if (w < dense) {
+                win_seg[w] = v[WPT + i];
+                if (ns[i] > 0u) {                                                   // ranked (a non-empty window has at least one set)
+                    rank2win[eo[i]] = (uint32_t)w;
+                    set_base[eo[i]] = e + ns[i] <= (uint32_t)sp.max_set_num ? e : kNoneU;       // capacity guard the reference lacks (getSet.cu:337)
                 }
             }
-            eo += c[i] > 0 ? 1u : 0u; ef += c[i]; es += ns[i];
         }
     }
     if (threadIdx.x == 0) {
@@ -790,7 +799,10 @@ public:
                 DSVT_CHECK(hipMemsetAsync(o.mask[k], 0, sizeof(float) * e, stream));
             }
         hipLaunchKernelGGL(sp_count, dim3(cdiv(mp, 256), K), dim3(256), 0, stream, coords, voxel_num, sp_, win_cnt, vox_win, vox_slot);
-        hipLaunchKernelGGL(sp_scan, dim3(K), dim3(1024), 0, stream, win_cnt, sp_, win_seg, rank2win, set_base, win_num, o);
+        int dmax = 0;
+        for (int k = 0; k < K; ++k) dmax = std::max(dmax, sp_.dense_off[k + 1] - sp_.dense_off[k]);
+        if (dmax <= 4 * 1024) hipLaunchKernelGGL(sp_scan<4>, dim3(K), dim3(1024), 0, stream, win_cnt, sp_, win_seg, rank2win, set_base, win_num, o);
+        else hipLaunchKernelGGL(sp_scan<8>, dim3(K), dim3(1024), 0, stream, win_cnt, sp_, win_seg, rank2win, set_base, win_num, o);     // (sixteen slabs spill: 22 against 14 us for four frames)
         hipLaunchKernelGGL(sp_scatter, dim3(cdiv(mp, 256), K), dim3(256), 0, stream, voxel_num, sp_, vox_win, vox_slot, win_seg, sorted_vox);
         int capw = 2, ldsw = 0;
         for (int k = 0; k < K; ++k) {
