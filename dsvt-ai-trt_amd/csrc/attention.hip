@@ -138,7 +138,7 @@ set_attention_kernel(AttnArgs a)
                 float v = key < AL ? sc[t][u][i] + mk[t][i] : -INFINITY;
                 sc[t][u][i] = v; mx = fmaxf(mx, v);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, kWave)); mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+        mx = rows4Max(mx);
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
@@ -148,7 +148,7 @@ set_attention_kernel(AttnArgs a)
                 float e = key < AL ? expf(sc[t][u][i] - mx) : 0.f;
                 sc[t][u][i] = e; sum += e;
             }
-        sum += __shfl_xor(sum, 16, kWave); sum += __shfl_xor(sum, 32, kWave);
+        sum = rows4Sum(sum);
         float inv = 1.0f / sum;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
@@ -318,14 +318,14 @@ set_attention_f16_kernel(AttnArgs a)
         for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) { const float v = sc[t][u][i] + mk[t][i]; sc[t][u][i] = v; mx = fmaxf(mx, v); }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, kWave)); mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+        mx = rows4Max(mx);
         const float nm = -mx * kLog2e;
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) { const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[t][u][i], kLog2e, nm)); sc[t][u][i] = e; sum += e; }
-        sum += __shfl_xor(sum, 16, kWave); sum += __shfl_xor(sum, 32, kWave);
+        sum = rows4Sum(sum);
         const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
         for (int t = 0; t < 3; ++t)
@@ -489,13 +489,13 @@ set_attention_split_kernel(AttnArgs a)
         for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) { const float v = sc[t][u][i] + mk[t][i]; sc[t][u][i] = v; mx = fmaxf(mx, v); }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, kWave)); mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+        mx = rows4Max(mx);
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) { const float e = __builtin_amdgcn_exp2f((sc[t][u][i] - mx) * kLog2e); sc[t][u][i] = e; sum += e; }
-        sum += __shfl_xor(sum, 16, kWave); sum += __shfl_xor(sum, 32, kWave);
+        sum = rows4Sum(sum);
         const float inv = 1.0f / sum;
 #pragma unroll
         for (int t = 0; t < 3; ++t)

@@ -25,6 +25,22 @@ __device__ __forceinline__ float waveMaxF(float v) {
     return v;
 }
 
+// sum / maximum over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (the four rows of an MFMA accumulator column), in every lane: gfx950's
+// v_permlane16_swap / v_permlane32_swap exchange the rows inside the VALU (with both operands the same register, result[0] + result[1] is
+// "mine + my partner's" in every lane); __shfl_xor is a ds_bpermute round trip through the LDS crossbar each.  Same additions, same bits.
+__device__ __forceinline__ float rows4Sum(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float rows4Max(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 // inclusive scan across the 64 lanes of a wave: six DPP adds -- row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then row_bcast15 into rows 1 and
 // 3 and row_bcast31 into rows 2 and 3 (lanes without a source add `old` = 0).  (Six __shfl_up steps are six ds_bpermute round trips through the
 // LDS crossbar, ~0.4 us of pure latency per scan: sp_scan's three workgroup scans were most of its 8 us.)

@@ -54,8 +54,7 @@ __device__ __forceinline__ float geluFast(float x) {
 
 // sum over the 4 lane groups that share an activation row (lanes differing in bits 4..5)
 __device__ __forceinline__ float rowSum4(float v) {
-    v += __shfl_xor(v, 16, kWave); v += __shfl_xor(v, 32, kWave);
-    return v;
+    return rows4Sum(v);
 }
 
 // Epilogue shared by both kernels.  `acc[t]` = output columns n0 + 16t + 4g .. +3 of activation

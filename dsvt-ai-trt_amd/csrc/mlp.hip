@@ -49,8 +49,7 @@ __device__ __forceinline__ float mlpGelu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
 }
 __device__ __forceinline__ float rowSum4m(float v) {
-    v += __shfl_xor(v, 16, kWave); v += __shfl_xor(v, 32, kWave);
-    return v;
+    return rows4Sum(v);
 }
 // LayerNorm over the 192 values of a row spread as acc[12][4] over 4 lanes
 __device__ __forceinline__ void mlpLayerNorm(floatx4 (&acc)[MNT], const float* gm, const float* bt, int g, float eps) {

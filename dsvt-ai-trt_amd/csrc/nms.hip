@@ -143,8 +143,21 @@ nms_sort(const float* __restrict__ rows, const uint32_t* __restrict__ count, int
         const uint32_t key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
         return ((unsigned long long)key << 32) | (uint32_t)~(uint32_t)r;
     };
-    for (int j = lane; j < n; j += 64) sk[j] = keyOf(j);
+    bool desc = true;                                // rows already in the output order?  (FilterBoxByScore keeps the decode's descending order)
+    for (int j = lane; j < n; j += 64) {
+        const unsigned long long kj = keyOf(j);
+        sk[j] = kj;
+        if (j + 1 < n) desc = desc && kj > keyOf(j + 1);
+    }
     __syncthreads();
+    if (__ballot(!desc) == 0ull) {                   // the frame pipeline's case: the order is the identity, no comparisons
+        if (t < n) {
+            order[t] = (uint32_t)t;
+            const Trig tg = boxTrig(rows[(size_t)t * 9 + 6]);
+            trig[t] = make_float4(tg.c, tg.s, tg.cn, tg.sn);
+        }
+        return;
+    }
     // The keys are distinct (they carry the row number), so a row's place is the number of larger keys: n broadcast reads of LDS, no
     // exchange network (the 512-thread bitonic sort this replaces was 45 barriers on ONE CU, 9.7 us; a slice per wavefront spreads the
     // n^2 comparisons over n / 64 CUs).
