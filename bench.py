@@ -388,8 +388,10 @@ def roofline_rows(prof, sampled, counts, pool_len, FB, mode, n_points_per_launch
         if t == "DsvtSetPartitionPlugin":     # per window configuration: read 16 P; write 2 x 36 x 4 S (inds) + 2 x 36 x 4 S (mask) + 12 P (in-window coordinates)
             return (0.0, sum(16.0 * c["P"] + 2 * 2 * 36 * 4.0 * s_ + 12.0 * c["P"] for s_ in c["S"]))
         if t == "Map2BevPlugin":              # write GX GY C e (the dense map, zero fill included) + read P C e_in
-            e_out = 6 if f.get("split_output") else 2
-            return (0.0, FB * 468.0 * 468 * 192 * e_out + c["P"] * 192.0 * (4 if f.get("split_output") else 2))
+            e_out, e_in = (6, 4) if f.get("split_output") else (2, 2)
+            if f.get("persistent_output"):    # the map persists: write the P live cells + zero the P cells of the call before (no fill of the whole map)
+                return (0.0, c["P"] * 192.0 * (e_in + 2 * e_out))
+            return (0.0, FB * 468.0 * 468 * 192 * e_out + c["P"] * 192.0 * e_in)
         return (0.0, 0.0)
 
     resident_qkv = f16 and FB >= 3          # (csrc/linear.hip: row capacity of three or more frames -> the resident-weights kernel)
