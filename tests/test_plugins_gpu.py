@@ -699,6 +699,44 @@ def test_fused_set_partition_capacity_and_generic_order(pkg, oracle):
     assert int(host(wpo[3])[0]) > 0 and host(wpo[0])[0].max() < vox["P"]
 
 
+@pytest.mark.parametrize("F", [2, 3, 5])
+def test_fused_set_partition_of_several_frames_is_the_frames_one_after_the_other(pkg, oracle, F):
+    """DsvtSetPartitionPlugin(frames=F): coords.x = frame index, the dense window grid is F grids one after the other, so window ranks, voxel
+    segments and set bases continue from frame to frame.  Against the single-frame plugin (itself bit-exact against the oracle above) on
+    each frame: in-window coordinates concatenated, the sets of frame f appended after those of the frames before it with its pillar offset
+    added to every index, masks unchanged, counts summed.  F = 2: 6400 dense windows = one scan round of eight slabs; 3 and 5: two rounds
+    (the carries between rounds of sp_scan)."""
+    P, O = pkg.plugin, oracle
+    c = cases.caps("ref")
+    S1 = c["W"]
+    names = ["000000", "000003", "000004", "000003", "000000"][:F]
+    per, coords_all, offs = [], [], [0]
+    for f, name in enumerate(names):
+        pts, n = cases.load_frame(name, c["N"])
+        vox = O.points2features(pts, n, cases.p2f_cfg(c))
+        co = vox["coords"][:vox["P"]].copy()
+        po1 = P.add_set_partition_op(c["W"], c["Vw"], 36, S1, c["P"], cases.GRID, cases.WINS)(dev(vox["coords"][None]), scalar(vox["P"]))
+        torch.cuda.synchronize()
+        per.append([host(t) for t in po1])
+        co[:, 0] = f
+        coords_all.append(co); offs.append(offs[-1] + vox["P"])
+    Pt = offs[-1]
+    buf = np.zeros((F * c["P"], 4), vox["coords"].dtype); buf[:Pt] = np.concatenate(coords_all, 0)
+    po = P.add_set_partition_op(F * c["W"], c["Vw"], 36, F * S1, F * c["P"], cases.GRID, cases.WINS, frames=F)(dev(buf[None]), scalar(Pt))
+    torch.cuda.synchronize()
+    for k in range(2):
+        c2d, inds, mask, S = [host(t) for t in po[4 * k:4 * k + 4]]
+        s_off = 0
+        for f in range(F):
+            c2d1, inds1, mask1, S1f = per[f][4 * k:4 * k + 4]
+            nf, sf = offs[f + 1] - offs[f], int(S1f[0])
+            assert np.array_equal(c2d[0, offs[f]:offs[f + 1]], c2d1[0, :nf]), (k, f)
+            assert np.array_equal(inds[0, :, s_off:s_off + sf], inds1[0, :, :sf] + offs[f]), (k, f)
+            assert np.array_equal(mask[0, :, s_off:s_off + sf], mask1[0, :, :sf]), (k, f)
+            s_off += sf
+        assert int(S[0]) == s_off
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_integer_path_fuzz_against_oracle(pkg, oracle, seed):
     """Randomised clouds and CAPACITIES through Points2Features, the per-configuration WindowPartition / GetSet plugins and the fused
