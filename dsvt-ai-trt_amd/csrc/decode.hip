@@ -89,24 +89,20 @@ topk_hist(const float* __restrict__ head, TopKParams p, uint32_t* __restrict__ h
         if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
 
-// bin of the K-th largest key: the largest B with count(bins >= B) >= K; *above = count(bins > B).  256 threads x 16 bins.
+// bin of the K-th largest key: the largest B with count(bins >= B) >= K; *above = count(bins > B).  256 threads x 16 bins, thread t owning
+// bins 16 (255 - t) ..: an EXCLUSIVE scan over t is then the count above a thread's bins (one workgroup scan on DPP adds; a one-thread walk
+// over 256 partials in LDS was ~5 us at the head of every workgroup of topk_collect).
 __device__ __forceinline__ int thresholdBin(const uint32_t* __restrict__ hist, int K, uint32_t* sh /* 258 */, uint32_t* above_out) {
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, b0 = (255 - t) * 16;
     uint32_t local[16], sum = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { local[i] = hist[t * 16 + i]; sum += local[i]; }
-    sh[t] = sum;
-    __syncthreads();
-    if (t == 0) {                                    // suffix sums over 256 partials
-        uint32_t run = 0;
-        for (int i = 255; i >= 0; --i) { const uint32_t v = sh[i]; sh[i] = run; run += v; }   // sh[i] = count above thread i's bins
-        sh[256] = 0xffffffffu; sh[257] = 0;
-    }
-    __syncthreads();
-    uint32_t above = sh[t];
+    for (int i = 0; i < 16; ++i) { local[i] = hist[b0 + i]; sum += local[i]; }
+    if (t == 0) { sh[256] = 0xffffffffu; sh[257] = 0; }
+    uint32_t tot;
+    uint32_t above = blockExclusiveScan<256>(sum, sh, &tot);       // (ends with a barrier: sh[256 ..] are published too)
     if (above < (uint32_t)K && above + sum >= (uint32_t)K) {
         for (int i = 15; i >= 0; --i) {
-            if (above + local[i] >= (uint32_t)K) { sh[256] = (uint32_t)(t * 16 + i); sh[257] = above; break; }
+            if (above + local[i] >= (uint32_t)K) { sh[256] = (uint32_t)(b0 + i); sh[257] = above; break; }
             above += local[i];
         }
     }
