@@ -671,7 +671,7 @@ sp_window(const uint4* __restrict__ coords, SPParams sp, const uint32_t* __restr
 {
     extern __shared__ uint32_t lds[];
     __shared__ unsigned long long bits[17];
-    __shared__ uint32_t smem[NT / kWave + 1];
+    __shared__ uint32_t smem[2 * (NT / kWave + 1)];
     const int k = blockIdx.y;
     const WPParams& p = sp.wp[k];
     const uint32_t r = blockIdx.x;
@@ -722,10 +722,10 @@ sp_window(const uint4* __restrict__ coords, SPParams sp, const uint32_t* __restr
     uint32_t cy = 0, cx = 0;
     for (uint32_t b = 0; b < vol; b += blockDim.x) {
         const uint32_t i = b + threadIdx.x;
-        uint32_t tot;
         const uint32_t vy = i < vol ? ty[i] : kNoneU, vx = i < vol ? tx[i] : kNoneU;
-        const uint32_t ey = blockExclusiveScan<NT>(vy != kNoneU ? 1u : 0u, smem, &tot) + cy; cy += tot;
-        const uint32_t ex = blockExclusiveScan<NT>(vx != kNoneU ? 1u : 0u, smem, &tot) + cx; cx += tot;
+        uint32_t e2[2] = {vy != kNoneU ? 1u : 0u, vx != kNoneU ? 1u : 0u}, tot2[2];
+        blockExclusiveScanK<NT, 2>(e2, smem, tot2);                                      // both tables behind one set of barriers
+        const uint32_t ey = e2[0] + cy, ex = e2[1] + cx; cy += tot2[0]; cx += tot2[1];
         if (vy != kNoneU && ey < Vw) sy[ey] = vy;
         if (vx != kNoneU && ex < Vw) sx[ex] = vx;
     }
