@@ -110,9 +110,16 @@ def test_two_processes_time_sharing_the_device_are_reproducible():
     at run time = 400 bytes of scratch per lane, and with two processes on the device about 1 iteration in 100 kept or dropped one box
     differently (inputs identical, RotatedNmsPlugin's outputs not).  The arrays are in LDS now and the kernel has no scratch."""
     env = dict(os.environ, SECONDS="12")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "dbg_two_proc.py"), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                              text=True, env=env) for r in range(2)]
-    outs = [p.communicate(timeout=900)[0] for p in procs]
+
+    def run():
+        ps = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "dbg_two_proc.py"), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               text=True, env=env) for r in range(2)]
+        return ps, [p.communicate(timeout=900)[0] for p in ps]
+    procs, outs = run()
+    # (the platform's "Memory access fault" of two processes on ONE device -- see the test above: one retry for that message only.  A run
+    # that ENDS and reports differing iterations is never retried: that is the finding this test exists for.)
+    if any(p.returncode != 0 and "Memory access fault by GPU" in o for p, o in zip(procs, outs)):
+        procs, outs = run()
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-2000:]
         last = [l for l in o.splitlines() if l.startswith("rank")][-1]
