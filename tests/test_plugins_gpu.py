@@ -554,6 +554,27 @@ def test_rotated_nms_matches_host_nms(pkg, oracle, n, spread, seed):
         assert 1 < k < n                             # the case does exercise suppression
 
 
+@pytest.mark.parametrize("n,shuffle", [(500, False), (500, True), (129, False)])
+def test_rotated_nms_on_a_chain_of_boxes(pkg, oracle, n, shuffle):
+    """The worst case of nms_scan's fixed-point sweep: a chain in which every box overlaps only its two neighbours and the scores descend
+    along it, so row j's fate depends on row j - 1's, whose fate depends on row j - 2's ... -- the in-block system needs all 64 rounds (real
+    frames settle in two or three).  The greedy answer keeps every second box; same rows, same order as nms_cpu (helper.h:257-283)."""
+    P = pkg.plugin
+    rng = np.random.default_rng(7)
+    b = np.zeros((500, 9), np.float32)
+    b[:n, 0] = 1.5 * np.arange(n) - 300.0; b[:n, 1] = 3.0                     # 2 x 2 boxes 1.5 apart along x: IoU 1 / 7 with a neighbour, 0 beyond
+    b[:n, 3] = 2.0; b[:n, 4] = 2.0; b[:n, 5] = 1.5; b[:n, 7] = rng.integers(0, 10, n)
+    b[:n, 8] = np.linspace(0.95, 0.2, n).astype(np.float32)
+    if shuffle:
+        b[:n] = b[rng.permutation(n)]
+    rows, keep = oracle.nms_cpu(b, n, 0.01)
+    assert len(keep) == (n + 1) // 2
+    out, idx, cnt = P.add_rotated_nms_op(500, 0.01)(dev(b[None]), scalar(n))
+    torch.cuda.synchronize()
+    k = int(cnt.cpu()[0])
+    assert k == len(keep) and np.array_equal(host(idx)[0, :k], keep) and np.array_equal(host(out)[0, :k], rows)
+
+
 def test_fused_pillar_feature_net_equals_plugin_chain(pkg, oracle):
     """DsvtPillarFeatureNetPlugin (one launch, no per-point activation in memory) == the reference
     wiring FC0+BN+ReLU -> TorchScatterMax -> concat -> FC1+BN+ReLU -> TorchScatterMax on the fp32 plugins.  Layer 0 is fp32
