@@ -49,7 +49,11 @@ __device__ __forceinline__ float mlpGelu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
 }
 __device__ __forceinline__ float rowSum4m(float v) {
-    return rows4Sum(v);
+    // (not rows4Sum(): the function returns the same bits -- tools/ubench/rows4_check.hip -- but inside THIS kernel hipcc then contracts / orders the
+    // LayerNorm arithmetic around it differently and 7 % of the outputs move by an ulp or two: the same 2.2e-6 / 1.5e-7 from float64, no faster, and the
+    // committed box sweeps (profiles/r04_mx_box_sweep.txt) would no longer be this library's bits)
+    v += __shfl_xor(v, 16, kWave); v += __shfl_xor(v, 32, kWave);
+    return v;
 }
 // LayerNorm over the 192 values of a row spread as acc[12][4] over 4 lanes
 __device__ __forceinline__ void mlpLayerNorm(floatx4 (&acc)[MNT], const float* gm, const float* bt, int g, float eps) {
@@ -658,10 +662,34 @@ public:
         // (split precision: a stage holds its SRH fragment rows twice, w_hi = fp16(w) then w_lo = fp16(w - w_hi))
         const int PQ = pq_, PQT = PQ / 16, PQS = PQ / 32, SRH = 6 * PQT, SR = split_ ? 2 * SRH : SRH, NWO = MC / PQ, NPIECE = MF / PQ;
         std::vector<_Float16> wp((size_t)(NWO + 2 * NPIECE) * SR * 512);
-        auto put = [&](int stage, int rowi, int lane, int j, float v) {
+        // (ablate build, DSVT_MLP_LO8=1: w_lo rounded to what an e4m3 byte + a power-of-two scale per weight row would hold -- the accuracy half of
+        // "stream w_lo at half rate", measured before any kernel is written for it: tools/mx_box_sweep.py)
+        const bool lo8 = split_ && ablateEnv("DSVT_MLP_LO8", 0) != 0;
+        auto rowScales = [&](const std::vector<float>& W, int rows, int cols) {
+            std::vector<float> sc(rows, 1.f);
+            for (int n = 0; n < rows; ++n) {
+                float mx = 0.f;
+                for (int k = 0; k < cols; ++k) { const float v = W[(size_t)n * cols + k]; mx = std::max(mx, std::fabs(v - (float)(_Float16)v)); }
+                if (mx > 0.f) sc[n] = std::ldexp(1.f, (int)std::floor(std::log2(224.f / mx)));
+            }
+            return sc;
+        };
+        std::vector<float> sco, sc1, sc2;
+        if (lo8) { sco = rowScales(wo_, MC, MC); sc1 = rowScales(w1_, MF, MC); sc2 = rowScales(w2_, MC, MF); }
+        auto e4m3 = [](float x) {
+            const float a = std::fabs(x);
+            if (a == 0.f) return 0.f;
+            int e; (void)std::frexp(a, &e);
+            const int E = std::max(e - 1, -6);
+            const float q = std::ldexp(1.f, E - 3);
+            return std::copysign(std::min(std::nearbyint(a / q) * q, 448.f), x);
+        };
+        auto put = [&](int stage, int rowi, int lane, int j, float v, float sc = 0.f) {
             const _Float16 hi = (_Float16)v;
             wp[(((size_t)stage * SR + rowi) * 64 + lane) * 8 + j] = hi;
-            if (split_) wp[(((size_t)stage * SR + SRH + rowi) * 64 + lane) * 8 + j] = (_Float16)(v - (float)hi);
+            float lo = v - (float)hi;
+            if (lo8 && sc > 0.f) lo = e4m3(lo * sc) / sc;
+            if (split_) wp[(((size_t)stage * SR + SRH + rowi) * 64 + lane) * 8 + j] = (_Float16)lo;
         };
         for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j) {
@@ -669,14 +697,14 @@ public:
                 for (int h = 0; h < NWO; ++h)
                     for (int ks = 0; ks < 6; ++ks)
                         for (int t = 0; t < PQT; ++t)
-                            put(h, ks * PQT + t, lane, j, wo_[(size_t)(PQ * h + 16 * t + r) * MC + 32 * ks + 8 * g + j]);
+                            put(h, ks * PQT + t, lane, j, wo_[(size_t)(PQ * h + 16 * t + r) * MC + 32 * ks + 8 * g + j], lo8 ? sco[PQ * h + 16 * t + r] : 0.f);
                 for (int q = 0; q < NPIECE; ++q) {
                     for (int ks = 0; ks < 6; ++ks)
                         for (int t = 0; t < PQT; ++t)
-                            put(NWO + 2 * q, ks * PQT + t, lane, j, w1_[(size_t)(PQ * q + 16 * t + r) * MC + permuteK(32 * ks + 8 * g + j)]);
+                            put(NWO + 2 * q, ks * PQT + t, lane, j, w1_[(size_t)(PQ * q + 16 * t + r) * MC + permuteK(32 * ks + 8 * g + j)], lo8 ? sc1[PQ * q + 16 * t + r] : 0.f);
                     for (int sp = 0; sp < PQS; ++sp)
                         for (int t = 0; t < 12; ++t)
-                            put(NWO + 2 * q + 1, sp * 12 + t, lane, j, w2_[(size_t)(16 * t + r) * MF + permuteK(PQ * q + 32 * sp + 8 * g + j)]);
+                            put(NWO + 2 * q + 1, sp * 12 + t, lane, j, w2_[(size_t)(16 * t + r) * MF + permuteK(PQ * q + 32 * sp + 8 * g + j)], lo8 ? sc2[16 * t + r] : 0.f);
                 }
             }
         std::vector<float> prm(MP_FLOATS, 0.f);

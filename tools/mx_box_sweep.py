@@ -13,7 +13,10 @@ NP = int(sys.argv[2]) if len(sys.argv) > 2 else 180000
 caps = pkg.pipeline.Caps()
 w = pkg.synth.make_weights()
 EXC = tuple(x for x in os.environ.get("EXCLUDE", "").split(",") if x)        # EXCLUDE=shared,heads0: those layers keep three fp16 products
+# MLP_LO8=1 (ablate build: DSVT_HIP_LIB=dsvt-ai-trt_amd/libdsvt_hip_ablate.so): the encoder MLPs of the FIRST pipeline get w_lo rounded to e4m3 + a row scale
+if os.environ.get("MLP_LO8"): os.environ["DSVT_MLP_LO8"] = "1"
 pa = pkg.pipeline.DsvtPipeline(w, caps=caps, device=dev, linear_compute=P.COMPUTE_SPLIT, head_mx_exclude=EXC)                       # head_mx on (default)
+os.environ.pop("DSVT_MLP_LO8", None)
 pb = pkg.pipeline.DsvtPipeline(w, caps=caps, device=dev, linear_compute=P.COMPUTE_SPLIT, head_mx=False)
 worst = {}
 for s in range(NS):
