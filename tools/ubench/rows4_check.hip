@@ -1,5 +1,5 @@
 // rows4Sum / rows4Max (csrc/device_utils.h: v_permlane16_swap + v_permlane32_swap) against the __shfl_xor(16) / __shfl_xor(32) form they replaced: bit for bit, in every lane.
-//   hipcc --offload-arch=gfx950 -O3 -I../../dsvt-ai-trt_amd/csrc -I../../include rows4_check.hip -o rows4_check && ./rows4_check
+//   hipcc --offload-arch=gfx950 -O3 -I../../dsvt-ai-trt_amd/csrc -I../../include rows4_check.hip -o rows4_check.bin && ./rows4_check.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
