@@ -1960,11 +1960,7 @@ static int launchConv1x1Resident(const ConvArgs& a, const _Float16* Wp, hipStrea
 // 16-channel tiles per workgroup of the halo kernel (and of its packed weights)
 static int haloChannelTiles(int coutRows) { return coutRows <= 32 ? 2 : coutRows <= 64 ? 4 : 8; }
 
-static int numCUs() {
-    static int n = 0;
-    if (!n) { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); n = hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }
-    return n;
-}
+static int numCUs() { return deviceCUs(); }
 
 // Experiments that stay documented but are not product code (round 3: the ablation / tuning switches that used to be read from the
 // environment inside these launchers are gone; measurements in profiles/README.md): 4-row halo tiles (5-10 % faster alone, 4 % slower

@@ -7,6 +7,16 @@ namespace dsvt {
 
 constexpr int kWave = 64;   // CDNA wavefront width
 
+// compute units of the CURRENT device (host side; cached per device ordinal: a process may drive several devices, and a partitioned or
+// smaller part must not inherit the first device's count)
+inline int deviceCUs() {
+    static int n[64] = {0};
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
+    if (!n[d]) { hipDeviceProp_t p; n[d] = hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0 ? p.multiProcessorCount : 256; }
+    return n[d];
+}
+
 __device__ __forceinline__ int laneId() { return threadIdx.x & (kWave - 1); }
 
 template <class T> __device__ __forceinline__ T waveSum(T v) {

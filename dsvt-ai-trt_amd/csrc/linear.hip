@@ -1146,9 +1146,10 @@ static std::vector<_Float16> packStagesSplit(const float* W, int N) {
 static int launchLinearSplit(const LinearArgs& a, const _Float16* Wp, hipStream_t stream) {
     static int resident = -1;      // DSVT_LINEAR_RESIDENT=0: the streamed kernel for every shape
     if (resident < 0) resident = ablateEnv("DSVT_LINEAR_RESIDENT", 1);
-    if (resident && a.N == 3 * RSS_SPT * SP_COLS && (a.add_cols % (RSS_SPT * SP_COLS)) == 0) {
-        static int ncu = 0;
-        if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }
+    const int ncu = deviceCUs();
+    // (the resident kernel forms row streams of three workgroups; a device -- or partition -- with fewer than three CUs would form none and
+    // leave the output unwritten: it takes the streamed kernel)
+    if (resident && ncu >= 3 && a.N == 3 * RSS_SPT * SP_COLS && (a.add_cols % (RSS_SPT * SP_COLS)) == 0) {
         const int ng = ncu;                                             // (the kernel forms row streams of three workgroups per XCD; at most two workgroups idle)
         static int dbg = -1; if (dbg < 0) dbg = ablateEnv("DSVT_QKV_DBG", 0);
         if (a.a2_c2d) hipLaunchKernelGGL(linear_split_resident_kernel<true>, dim3(ng), dim3(64 * RSS_NW), 0, stream, a, Wp, dbg);
@@ -1162,8 +1163,7 @@ static int launchLinearSplit(const LinearArgs& a, const _Float16* Wp, hipStream_
 }
 
 static int launchLinearF16Resident(const LinearArgs& a, const _Float16* Wp, hipStream_t stream) {
-    static int ncu = 0;
-    if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }
+    const int ncu = deviceCUs();
     const int ntype = a.N / (96 * RS_SPT);
     if (a.a2_c2d) hipLaunchKernelGGL(linear_f16_resident_kernel<true>, dim3(ncu / ntype * ntype), dim3(64 * RS_NW), 0, stream, a, Wp);
     else hipLaunchKernelGGL(linear_f16_resident_kernel<false>, dim3(ncu / ntype * ntype), dim3(64 * RS_NW), 0, stream, a, Wp);
@@ -1171,8 +1171,7 @@ static int launchLinearF16Resident(const LinearArgs& a, const _Float16* Wp, hipS
 }
 
 int launchLinearF16Rows(const LinearArgs& a, const _Float16* Wp, hipStream_t stream) {
-    static int ncu = 0;
-    if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }
+    const int ncu = deviceCUs();
     hipLaunchKernelGGL(linear_f16_rows_kernel, dim3(cdiv(a.max_rows, 128)), dim3(64 * RW_NW), 0, stream, a, Wp, ncu);
     return lastError();
 }

@@ -746,8 +746,7 @@ public:
             DSVT_CHECK(hipMemsetAsync(out[0], 0, sizeof(float) * (size_t)max_rows_ * MC, stream));
             if (!split_) DSVT_CHECK(hipMemsetAsync(out[1], 0, sizeof(_Float16) * (size_t)max_rows_ * MC, stream));
         }
-        static int ncu = 0;
-        if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }
+        const int ncu = deviceCUs();
         b.ncu = ncu;
         if (split_) {                  // one kernel for every row count: eight waves x 16 rows, one workgroup per CU (149 KB of LDS)
             static int sdbg = -1; if (sdbg < 0) sdbg = ablateEnv("DSVT_MLP_DBG", 0);

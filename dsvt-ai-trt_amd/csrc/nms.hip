@@ -5,10 +5,19 @@
 // and drop every later box whose rotated-rectangle IoU with it is >= NMS_THRESH (0.01, class
 // agnostic; params.h:334).  box_overlap (helper.h:166-255) clips the two rectangles by collecting
 // edge intersections + contained corners, ordering them by atan2 around their centroid and summing
-// the fan triangles.  The arithmetic below is that code line by line in fp32 (cos / sin / atan2 in
-// double like the host's, the file is built with -ffp-contract=off); the only shortcut is that a pair
-// whose centres are farther apart than the two half diagonals (+ margin) skips it, which is exactly the
-// case where the reference finds no intersection point and no contained corner and returns 0.
+// the fan triangles.  The arithmetic below is that code line by line in fp32 (the file is built with
+// -ffp-contract=off); the only shortcut is that a pair whose centres are farther apart than the two half
+// diagonals (+ margin) skips it, which is exactly the case where the reference finds no intersection point
+// and no contained corner and returns 0.
+// Trigonometry: helper.h calls cos / sin / atan2 / fabs on floats under libstdc++, i.e. the FLOAT overloads
+// (cosf, sinf, atan2f of the host's libm: helper.h:117-118, 194-195, 236-237).  glibc's float functions are
+// not correctly rounded (and not one function: ifunc picks an FMA build where the CPU has it), and the device
+// library's are a different algorithm again, so "the same bits as the host" does not exist for these values.
+// The kernel uses the CORRECTLY ROUNDED float of each -- (float)cos((double)x) etc. --, which is what glibc's
+// cosf / sinf return for ~98.7 % of inputs and what the device's own cosf / sinf return less often
+// (tools/nms_trig_rates.py prints both rates on the box).  oracle/dsvt_oracle.c restates both arithmetics:
+// orc_nms_cpu (the reference's overloads) and orc_nms_cpu_cr (this file's); the GPU tests pin the kernel to
+// the second bit for bit and tests/test_host_post_cpu.py + the tool bound how often the two keep lists differ.
 //
 //   nms_sort   one wave per 64 rows: stable order of the n <= 512 rows by descending score (a row's place = the number of larger keys)
 //   nms_mask   one wave per (row j, 64-row word): bit i = IoU(i, j) >= thresh for i < j (ballot) -- the transposed mask
@@ -37,7 +46,7 @@ __device__ __forceinline__ Bnd rowToBox(const float* o) {            // src/dsvt
 __device__ __forceinline__ float crossf(F2 p1, F2 p2, F2 p0) { return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y); }   // :109-111
 
 // The four trigonometric values box_overlap / check_box2d derive from a box's yaw (helper.h:115-116, 190-193: cos / sin of rt and of
-// -rt, in double like the host, narrowed to float).  They depend on the box alone, so they are computed once per box (nms_sort) instead
+// -rt, each correctly rounded to float -- see the header).  They depend on the box alone, so they are computed once per box (nms_sort) instead
 // of once per PAIR (the host does the latter); the values, and with them every IoU, are the same bits.
 struct Trig { float c, s, cn, sn; };                                  // cos(rt), sin(rt), cos(-rt), sin(-rt)
 __device__ __forceinline__ Trig boxTrig(float rt) {
@@ -82,7 +91,7 @@ __device__ __forceinline__ void rotateAround(F2 c, float ac, float as, F2& p) { 
 // lane l at [k * 64 + l]), not in a private array: a private array indexed at run time is scratch memory (400 bytes per lane here), and
 // this was the only kernel of the frame with any (under two processes time-sharing the device its result was not
 // reproducible run to run).
-__device__ float boxOverlap(const Bnd& a, const Bnd& b, const Trig& ta, const Trig& tb, F2* __restrict__ cp, double* __restrict__ ang) {   // :166-255
+__device__ float boxOverlap(const Bnd& a, const Bnd& b, const Trig& ta, const Trig& tb, F2* __restrict__ cp, float* __restrict__ ang) {   // :166-255
     constexpr int L = 64;                                            // column stride
     const float a_dx = a.w / 2, b_dx = b.w / 2, a_dy = a.l / 2, b_dy = b.l / 2;
     F2 ac[5], bc[5], pc = {0.f, 0.f};                  // the host's cross_points[16] cannot hold the 16 + 8 worst case either: 24 here
@@ -108,11 +117,11 @@ __device__ float boxOverlap(const Bnd& a, const Bnd& b, const Trig& ta, const Tr
     }
     if (cnt == 0) return 0.f;                                        // reference: 0/0 centroid, empty fan, area 0
     pc.x /= cnt; pc.y /= cnt;
-    // the host recomputes atan2 inside every comparison; same values
-    for (int i = 0; i < cnt; ++i) { const F2 q = cp[i * L]; ang[i * L] = atan2((double)(q.y - pc.y), (double)(q.x - pc.x)); }
+    // the host recomputes atan2 inside every comparison (float overload: helper.h:236-237); same values, correctly rounded to float here
+    for (int i = 0; i < cnt; ++i) { const F2 q = cp[i * L]; ang[i * L] = (float)atan2((double)(q.y - pc.y), (double)(q.x - pc.x)); }
     for (int j = 0; j < cnt - 1; ++j)
         for (int i = 0; i < cnt - j - 1; ++i) {
-            const double a0 = ang[i * L], a1 = ang[(i + 1) * L];
+            const float a0 = ang[i * L], a1 = ang[(i + 1) * L];
             if (a0 > a1) {
                 const F2 t = cp[i * L]; cp[i * L] = cp[(i + 1) * L]; cp[(i + 1) * L] = t;
                 ang[i * L] = a1; ang[(i + 1) * L] = a0;
@@ -125,7 +134,7 @@ __device__ float boxOverlap(const Bnd& a, const Bnd& b, const Trig& ta, const Tr
         const F2 u = {ck.x - c0.x, ck.y - c0.y}, v = {cn.x - c0.x, cn.y - c0.y};
         area += (u.x * v.y - u.y * v.x);
     }
-    return (float)(fabs((double)area) / 2.0);
+    return (float)(fabsf(area) / 2.0);                               // :254: fabs(float), then the double division
 }
 
 // ---- kernels -------------------------------------------------------------------------------
@@ -185,7 +194,7 @@ nms_mask(const float* __restrict__ rows, const uint32_t* __restrict__ count, con
     maskT += (size_t)blockIdx.z * NMS_MAX * NMS_WORDS;                                                  // blockIdx.z = frame of a stack
     int n = (int)*count; if (n > max_boxes) n = max_boxes;
     __shared__ F2 s_cp[24 * 64];
-    __shared__ double s_ang[24 * 64];
+    __shared__ float s_ang[24 * 64];
     const int j = blockIdx.x, wi = blockIdx.y, lane = threadIdx.x, i = wi * 64 + lane;
     if (j >= n) return;
     bool sup = false;

@@ -498,11 +498,7 @@ pfn_kernel(PfnArgs a)
   }
 }
 
-static int pfnCUs() {
-    static int n = 0;
-    if (!n) { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); n = hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }
-    return n;
-}
+static int pfnCUs() { return deviceCUs(); }
 
 static inline int pfnPermuteK(int p) {       // see mlp.hip: position p of a permuted weight row holds column k(p)
     const int s = p / 32, q = p % 32, g = q / 8, j = q % 8;

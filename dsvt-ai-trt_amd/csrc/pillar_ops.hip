@@ -410,10 +410,12 @@ static Registrar g_geReg(&g_geCreator);
 // =====================================================================================
 __global__ void __launch_bounds__(256)
 map2bev_kernel(const float4* __restrict__ feat, const uint4* __restrict__ coords, const uint32_t* __restrict__ voxel_num,
-               int G, int gx, int gy, int frames, float4* __restrict__ bev, uint4* __restrict__ save_coords, uint32_t* __restrict__ save_num)
+               int G, int gx, int gy, int frames, float4* __restrict__ bev, uint4* __restrict__ save_coords, unsigned long long* __restrict__ save_state)
 {
     size_t total = (size_t)(*voxel_num) * G;
-    if (save_num && blockIdx.x == 0 && threadIdx.x == 0) *save_num = *voxel_num;      // (persistent_output: the cells the next call clears)
+    if (save_state && blockIdx.x == 0 && threadIdx.x == 0) {                          // (persistent_output: which cells of WHICH buffer the next call may clear)
+        save_state[0] = *voxel_num; save_state[1] = reinterpret_cast<unsigned long long>(bev);
+    }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         size_t p = i / G; int c = (int)(i % G);
         uint4 co = coords[p];                                                        // map2bev.cu:259-261: y = .z, x = .w
@@ -427,10 +429,10 @@ map2bev_kernel(const float4* __restrict__ feat, const uint4* __restrict__ coords
 typedef _Float16 mb_half4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256)
 map2bev_split_kernel(const float4* __restrict__ feat, const uint4* __restrict__ coords, const uint32_t* __restrict__ voxel_num,
-                     int G, int gx, int gy, int frames, mb_half4* __restrict__ bev, int x8, uint4* __restrict__ save_coords, uint32_t* __restrict__ save_num)
+                     int G, int gx, int gy, int frames, mb_half4* __restrict__ bev, int x8, uint4* __restrict__ save_coords, unsigned long long* __restrict__ save_state)
 {
     size_t total = (size_t)(*voxel_num) * G;
-    if (save_num && blockIdx.x == 0 && threadIdx.x == 0) *save_num = *voxel_num;
+    if (save_state && blockIdx.x == 0 && threadIdx.x == 0) { save_state[0] = *voxel_num; save_state[1] = reinterpret_cast<unsigned long long>(bev); }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         size_t p = i / G; int c = (int)(i % G);
         uint4 co = coords[p];
@@ -456,13 +458,23 @@ map2bev_split_kernel(const float4* __restrict__ feat, const uint4* __restrict__ 
 }
 // persistent_output (round 4): the dense map is zero everywhere but at <= P cells, so when the caller keeps the SAME output buffer from call to call (this
 // pipeline's buffers are static) a call needs to zero only the cells the call before it wrote -- 40 MB per frame instead of the 126 / 252 / 504 MB fill
-// (fp16 / fp32 / triple map), which at four frames per launch was 133 of the plugin's 201 us.  The plugin remembers the coordinates it scattered (device
-// buffer) and the output address (host); any other address, and the first call, take the full fill.
+// (fp16 / fp32 / triple map), which at four frames per launch was 133 of the plugin's 201 us.  Contract of the opt-in field: between two calls nobody
+// but this plugin writes the buffer.  Whether the incremental clear applies is decided ON THE DEVICE, at execution time (round 5; until then the host
+// compared the output address at ENQUEUE time, which is wrong as soon as enqueue order and execution order differ -- a call recorded under stream capture
+// but not run yet, then an eager call: the eager call would have cleared "the previous cells" of a map nobody ever zeroed): the scatter kernel leaves
+// {cell count, address of the map it filled} in `state`, and the clear kernel takes the short path only if that address is the one it was handed;
+// otherwise (first call, another buffer) it zeroes the whole map itself.
 __global__ void __launch_bounds__(256)
-map2bev_clear_kernel(const uint4* __restrict__ prev_coords, const uint32_t* __restrict__ prev_num, int CH, int gx, int gy, int frames, uint4* __restrict__ bev)
+map2bev_clear_kernel(const uint4* __restrict__ prev_coords, const unsigned long long* __restrict__ state, int CH, int gx, int gy, int frames,
+                     uint4* __restrict__ bev, size_t whole)                          // CH = 16-byte chunks per cell, whole = 16-byte chunks of the map
 {
-    const size_t total = (size_t)(*prev_num) * CH;                                   // CH = 16-byte chunks per cell
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    if (state[1] != reinterpret_cast<unsigned long long>(bev)) {                      // (uniform over the grid)
+        for (size_t i = tid; i < whole; i += nth) bev[i] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    const size_t total = (size_t)state[0] * CH;
+    for (size_t i = tid; i < total; i += nth) {
         const size_t p = i / CH; const int c = (int)(i % CH);
         const uint4 co = prev_coords[p];
         if (co.x >= (uint32_t)frames) continue;
@@ -474,25 +486,27 @@ public:
     int max_pillars_num_, channel_num_, gx_, gy_, frames_ = 1;      // frames_ > 1 (field "frames"): coords.x selects one of `frames` stacked BEV maps
     int split_ = 0;                                                 // field "split_output": fp32 rows -> fp16 [hi | lo | hi] planes (1) or [hi | lo | x8] (2), 3 C channels per cell
     int persistent_ = 0;                                            // field "persistent_output": see map2bev_clear_kernel
-    uint4* prev_coords_ = nullptr; uint32_t* prev_num_ = nullptr; void* last_out_ = nullptr;
+    uint4* prev_coords_ = nullptr; unsigned long long* prev_state_ = nullptr;      // device: the cells of the last EXECUTED call, {count, address of its map}
     Map2BevPlugin(int mp, int c, int gx, int gy, int frames = 1, int split = 0, int persistent = 0)
         : max_pillars_num_(mp), channel_num_(c), gx_(gx), gy_(gy), frames_(frames), split_(split), persistent_(persistent) {
         if (persistent_) {
-            if (hipMalloc(&prev_coords_, sizeof(uint4) * (size_t)mp) != hipSuccess || hipMalloc(&prev_num_, sizeof(uint32_t)) != hipSuccess ||
-                hipMemset(prev_num_, 0, sizeof(uint32_t)) != hipSuccess) { persistent_ = 0; }
+            if (hipMalloc(&prev_coords_, sizeof(uint4) * (size_t)mp) != hipSuccess || hipMalloc(&prev_state_, 2 * sizeof(unsigned long long)) != hipSuccess ||
+                hipMemset(prev_state_, 0, 2 * sizeof(unsigned long long)) != hipSuccess) { persistent_ = 0; }
         }
     }
-    ~Map2BevPlugin() override { if (prev_coords_) (void)hipFree(prev_coords_); if (prev_num_) (void)hipFree(prev_num_); }
-    // zero the map: everything, or (same buffer as last time) the cells of the previous call
+    ~Map2BevPlugin() override { if (prev_coords_) (void)hipFree(prev_coords_); if (prev_state_) (void)hipFree(prev_state_); }
+    // zero the map: everything, or (persistent_output, and the device state says this buffer holds the previous call's cells and nothing else) those cells
     int clearMap(void* out, size_t bytes, int cellBytes, hipStream_t stream) {
-        if (persistent_ && out == last_out_) {
-            hipLaunchKernelGGL(map2bev_clear_kernel, dim3(1024), dim3(256), 0, stream, prev_coords_, prev_num_, cellBytes / 16, gx_, gy_, frames_, static_cast<uint4*>(out));
+        if (persistent_ && cellBytes % 16 == 0 && bytes % 16 == 0) {
+            hipLaunchKernelGGL(map2bev_clear_kernel, dim3(2048), dim3(256), 0, stream, prev_coords_, prev_state_, cellBytes / 16, gx_, gy_, frames_,
+                               static_cast<uint4*>(out), bytes / 16);
             return lastError();
         }
         DSVT_CHECK(hipMemsetAsync(out, 0, bytes, stream));
-        last_out_ = persistent_ ? out : nullptr;
         return 0;
     }
+    // (the scatter kernels record their cells only when the clear kernel can use them)
+    bool saves(int cellBytes) const { return persistent_ && cellBytes % 16 == 0; }
     const char* type() const override { return "Map2BevPlugin"; }
     int nbOutputs() const override { return 1; }
     int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
@@ -514,7 +528,7 @@ public:
             if (int rc = clearMap(out[0], (size_t)2 * gx_ * gy_ * 3 * channel_num_ * frames_, 2 * 3 * channel_num_, stream)) return rc;
             hipLaunchKernelGGL(map2bev_split_kernel, dim3(2048), dim3(256), 0, stream, static_cast<const float4*>(in[0]),
                                static_cast<const uint4*>(in[1]), static_cast<const uint32_t*>(in[2]), channel_num_ / 4, gx_, gy_, frames_,
-                               static_cast<mb_half4*>(out[0]), split_ == 2 ? 1 : 0, persistent_ ? prev_coords_ : nullptr, persistent_ ? prev_num_ : nullptr);
+                               static_cast<mb_half4*>(out[0]), split_ == 2 ? 1 : 0, saves(6 * channel_num_) ? prev_coords_ : nullptr, saves(6 * channel_num_) ? prev_state_ : nullptr);
             return lastError();
         }
         const int esz = (inDesc && inDesc[0].type == DSVT_HALF) ? 2 : 4;
@@ -523,7 +537,7 @@ public:
         if (int rc = clearMap(out[0], (size_t)esz * gx_ * gy_ * channel_num_ * frames_, esz * channel_num_, stream)) return rc;
         hipLaunchKernelGGL(map2bev_kernel, dim3(2048), dim3(256), 0, stream, static_cast<const float4*>(in[0]),
                            static_cast<const uint4*>(in[1]), static_cast<const uint32_t*>(in[2]), channel_num_ * esz / 16, gx_, gy_, frames_,
-                           static_cast<float4*>(out[0]), persistent_ ? prev_coords_ : nullptr, persistent_ ? prev_num_ : nullptr);
+                           static_cast<float4*>(out[0]), persistent_ ? prev_coords_ : nullptr, persistent_ ? prev_state_ : nullptr);
         return lastError();
     }
     // trailing ints: [frames [split [persistent]]], each present when it or a later one is not the default

@@ -521,7 +521,7 @@ class DsvtPipeline:
         launch, which removes the ~150 per-op host launches from the frame's critical path."""
         # warm-up on the CURRENT stream: warming up on a side stream (the usual PyTorch recipe) makes the
         # second replay fault on ROCm 7.2 ("write access to a read-only page"), also for graphs that hold
-        # nothing but this library's kernels -- see tools/graph_test2.py
+        # nothing but this library's kernels -- see tools/dbg_graph_capture2.py
         for _ in range(warmup):
             self.forward(points, n)
         torch.cuda.synchronize(self.device)

@@ -477,13 +477,28 @@ static const float ORC_THRESH = 1e-8f;                                          
 static inline float orc_cross(orc_f2 p1, orc_f2 p2, orc_f2 p0)                     /* :109-111 */
 { return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y); }
 
-static inline int orc_check_box2d(const orc_bndbox* box, orc_f2 p)                 /* :113-123 */
+/* Which libm functions the reference calls.  helper.h is C++ and includes <math.h> / <iostream> under libstdc++, whose <cmath>
+ * declares the float overloads  float cos(float), sin(float), atan2(float, float), fabs(float)  in the global namespace; every
+ * argument at helper.h:117-118 (cos / sin of -box.rt), :122 (fabs(rot_x)), :143 (fabs(s5 - s1)), :194-195 (cos / sin of the yaw)
+ * and :236-237 (atan2 of two float differences) is a float, so overload resolution picks cosf / sinf / atan2f / fabsf (g++ 11:
+ * typeid(cos(-box.rt)) is float).  Only :254 `fabs(area) / 2.0` widens: fabsf, then a double division, then the float return.
+ * ORC_TRIG_REF restates exactly that (the platform libm's float functions).  ORC_TRIG_CR is the arithmetic csrc/nms.hip runs on
+ * the device: each of those values correctly rounded to float through the double function, (float)cos((double)x) -- the device
+ * math library's own cosf / sinf / atan2f are further from glibc's than that (tools/nms_trig_rates.py measures all three), and
+ * glibc's float functions are themselves not one function (ifunc picks an FMA build on CPUs that have it).  The two modes differ
+ * in the last bit of ~1 % of the trigonometric values; tests/test_host_post_cpu.py bounds how often a keep list differs. */
+enum { ORC_TRIG_REF = 0, ORC_TRIG_CR = 1 };
+static inline float orc_cos(float x, int m) { return m == ORC_TRIG_REF ? cosf(x) : (float)cos((double)x); }
+static inline float orc_sin(float x, int m) { return m == ORC_TRIG_REF ? sinf(x) : (float)sin((double)x); }
+static inline float orc_atan2(float y, float x, int m) { return m == ORC_TRIG_REF ? atan2f(y, x) : (float)atan2((double)y, (double)x); }
+
+static inline int orc_check_box2d(const orc_bndbox* box, orc_f2 p, int m)          /* :113-123 */
 {
     const float MARGIN = 1e-2f;
-    float angle_cos = (float)cos(-box->rt), angle_sin = (float)sin(-box->rt);
+    float angle_cos = orc_cos(-box->rt, m), angle_sin = orc_sin(-box->rt, m);
     float rot_x = (p.x - box->x) * angle_cos + (p.y - box->y) * (-angle_sin);
     float rot_y = (p.x - box->x) * angle_sin + (p.y - box->y) * angle_cos;
-    return (fabs(rot_x) < box->w / 2 + MARGIN && fabs(rot_y) < box->l / 2 + MARGIN);
+    return (fabsf(rot_x) < box->w / 2 + MARGIN && fabsf(rot_y) < box->l / 2 + MARGIN);
 }
 
 static inline float fminf2(float a, float b) { return a < b ? a : b; }
@@ -498,7 +513,7 @@ static int orc_intersection(orc_f2 p1, orc_f2 p0, orc_f2 q1, orc_f2 q0, orc_f2* 
     float s3 = orc_cross(p0, q1, q0), s4 = orc_cross(q1, p1, q0);
     if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0;
     float s5 = orc_cross(q1, p1, p0);
-    if (fabs(s5 - s1) > ORC_THRESH) {
+    if (fabsf(s5 - s1) > ORC_THRESH) {
         ans->x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
         ans->y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
     } else {
@@ -518,17 +533,18 @@ static inline void orc_rotate(orc_f2 c, float ac, float as, orc_f2* p)          
     p->x = nx; p->y = ny;
 }
 
-static float orc_box_overlap(const orc_bndbox* a, const orc_bndbox* b)             /* :166-255 */
+static float orc_box_overlap(const orc_bndbox* a, const orc_bndbox* b, int m)      /* :166-255 */
 {
     float a_dx = a->w / 2, b_dx = b->w / 2, a_dy = a->l / 2, b_dy = b->l / 2;
-    orc_f2 ac[5], bc[5], cp[16], pc = {0, 0}, ca = {a->x, a->y}, cb = {b->x, b->y};
+    orc_f2 ac[5], bc[5], cp[24], pc = {0, 0}, ca = {a->x, a->y}, cb = {b->x, b->y};   /* the reference's cross_points[16] (:183) cannot hold the
+                                                                                        16 + 8 worst case; 24 here, as in csrc/nms.hip */
     int cnt = 0;
     ac[0] = (orc_f2){a->x - a_dx, a->y - a_dy}; ac[1] = (orc_f2){a->x + a_dx, a->y - a_dy};
     ac[2] = (orc_f2){a->x + a_dx, a->y + a_dy}; ac[3] = (orc_f2){a->x - a_dx, a->y + a_dy};
     bc[0] = (orc_f2){b->x - b_dx, b->y - b_dy}; bc[1] = (orc_f2){b->x + b_dx, b->y - b_dy};
     bc[2] = (orc_f2){b->x + b_dx, b->y + b_dy}; bc[3] = (orc_f2){b->x - b_dx, b->y + b_dy};
-    float a_cos = (float)cos(a->rt), a_sin = (float)sin(a->rt);
-    float b_cos = (float)cos(b->rt), b_sin = (float)sin(b->rt);
+    float a_cos = orc_cos(a->rt, m), a_sin = orc_sin(a->rt, m);                    /* :194-195 */
+    float b_cos = orc_cos(b->rt, m), b_sin = orc_sin(b->rt, m);
     for (int k = 0; k < 4; k++) { orc_rotate(ca, a_cos, a_sin, &ac[k]); orc_rotate(cb, b_cos, b_sin, &bc[k]); }
     ac[4] = ac[0]; bc[4] = bc[0];
     for (int i = 0; i < 4; i++)
@@ -537,13 +553,13 @@ static float orc_box_overlap(const orc_bndbox* a, const orc_bndbox* b)          
                 pc.x += cp[cnt].x; pc.y += cp[cnt].y; cnt++;
             }
     for (int k = 0; k < 4; k++) {
-        if (orc_check_box2d(a, bc[k])) { pc.x += bc[k].x; pc.y += bc[k].y; cp[cnt++] = bc[k]; }
-        if (orc_check_box2d(b, ac[k])) { pc.x += ac[k].x; pc.y += ac[k].y; cp[cnt++] = ac[k]; }
+        if (orc_check_box2d(a, bc[k], m)) { pc.x += bc[k].x; pc.y += bc[k].y; cp[cnt++] = bc[k]; }
+        if (orc_check_box2d(b, ac[k], m)) { pc.x += ac[k].x; pc.y += ac[k].y; cp[cnt++] = ac[k]; }
     }
     pc.x /= cnt; pc.y /= cnt;
     for (int j = 0; j < cnt - 1; j++)
         for (int i = 0; i < cnt - j - 1; i++)
-            if (atan2(cp[i].y - pc.y, cp[i].x - pc.x) > atan2(cp[i + 1].y - pc.y, cp[i + 1].x - pc.x)) {
+            if (orc_atan2(cp[i].y - pc.y, cp[i].x - pc.x, m) > orc_atan2(cp[i + 1].y - pc.y, cp[i + 1].x - pc.x, m)) {   /* :236-237 */
                 orc_f2 t = cp[i]; cp[i] = cp[i + 1]; cp[i + 1] = t;
             }
     float area = 0;
@@ -551,14 +567,21 @@ static float orc_box_overlap(const orc_bndbox* a, const orc_bndbox* b)          
         orc_f2 u = {cp[k].x - cp[0].x, cp[k].y - cp[0].y}, v = {cp[k + 1].x - cp[0].x, cp[k + 1].y - cp[0].y};
         area += (u.x * v.y - u.y * v.x);
     }
-    return (float)(fabs(area) / 2.0);
+    return (float)(fabsf(area) / 2.0);                                             /* :254: fabs(float) -> float, / 2.0 in double */
 }
+
+static orc_bndbox orc_row_to_box(const float* o)            /* save_result, helper.h:470-481: dim0 -> l, dim1 -> w */
+{ return (orc_bndbox){o[0], o[1], o[2], o[4], o[3], o[5], o[6], (int)o[7], o[8]}; }
 
 ORC_API float orc_box_overlap_rows(const float* a9, const float* b9)
 {
-    orc_bndbox a = {a9[0], a9[1], a9[2], a9[4], a9[3], a9[5], a9[6], (int)a9[7], a9[8]};
-    orc_bndbox b = {b9[0], b9[1], b9[2], b9[4], b9[3], b9[5], b9[6], (int)b9[7], b9[8]};
-    return orc_box_overlap(&a, &b);
+    orc_bndbox a = orc_row_to_box(a9), b = orc_row_to_box(b9);
+    return orc_box_overlap(&a, &b, ORC_TRIG_REF);
+}
+ORC_API float orc_box_overlap_rows_cr(const float* a9, const float* b9)
+{
+    orc_bndbox a = orc_row_to_box(a9), b = orc_row_to_box(b9);
+    return orc_box_overlap(&a, &b, ORC_TRIG_CR);
 }
 
 /* save_result (helper.h:470-481: dim0->l, dim1->w) + nms_cpu (helper.h:257-283).
@@ -566,13 +589,13 @@ ORC_API float orc_box_overlap_rows(const float* a9, const float* b9)
  * order (stable), which is one of the orders the reference may produce.
  * out_rows: 9 floats per kept box as save_txt prints them: x,y,z,l,w,h,rt,id,score
  * (helper.h:452-460).  keep_idx: input row of each kept box. */
-ORC_API int orc_nms_cpu(const float* boxes9, int n, float nms_thresh, float* out_rows, int32_t* keep_idx)
+static int orc_nms_impl(const float* boxes9, int n, float nms_thresh, float* out_rows, int32_t* keep_idx, int m)
 {
     orc_bndbox* bb = (orc_bndbox*)malloc((size_t)(n ? n : 1) * sizeof(orc_bndbox));
     int32_t* order = (int32_t*)malloc((size_t)(n ? n : 1) * sizeof(int32_t));
     for (int i = 0; i < n; i++) {
         const float* o = boxes9 + (size_t)i * 9;
-        bb[i] = (orc_bndbox){o[0], o[1], o[2], o[4], o[3], o[5], o[6], (int)o[7], o[8]};
+        bb[i] = orc_row_to_box(o);
         order[i] = i;
     }
     for (int i = 1; i < n; i++) {              /* stable insertion sort, score descending */
@@ -593,11 +616,28 @@ ORC_API int orc_nms_cpu(const float* boxes9, int n, float nms_thresh, float* out
             if (sup[j]) continue;
             const orc_bndbox* bj = &bb[order[j]];
             float sa = bi->w * bi->l, sb = bj->w * bj->l;
-            float so = orc_box_overlap(bi, bj);
+            float so = orc_box_overlap(bi, bj, m);
             float iou = so / fmaxf(sa + sb - so, ORC_THRESH);
             if (iou >= nms_thresh) sup[j] = 1;
         }
     }
     free(bb); free(order); free(sup);
     return kept;
+}
+
+/* the reference's host NMS: the platform libm's float functions where helper.h gets the float overloads */
+ORC_API int orc_nms_cpu(const float* boxes9, int n, float nms_thresh, float* out_rows, int32_t* keep_idx)
+{ return orc_nms_impl(boxes9, n, nms_thresh, out_rows, keep_idx, ORC_TRIG_REF); }
+
+/* the same walk with every trigonometric value correctly rounded through the double function: the arithmetic of csrc/nms.hip */
+ORC_API int orc_nms_cpu_cr(const float* boxes9, int n, float nms_thresh, float* out_rows, int32_t* keep_idx)
+{ return orc_nms_impl(boxes9, n, nms_thresh, out_rows, keep_idx, ORC_TRIG_CR); }
+
+/* the trigonometric values themselves, both ways (tools/nms_trig_rates.py, tests/test_host_post_cpu.py): mode 0 = the platform libm's
+ * float functions (what helper.h calls), mode 1 = correctly rounded through the double functions (what csrc/nms.hip computes) */
+ORC_API void orc_trig_values(const float* x, const float* y, int n, int mode, float* out_cos, float* out_sin, float* out_atan2)
+{
+    for (int i = 0; i < n; i++) {
+        out_cos[i] = orc_cos(x[i], mode); out_sin[i] = orc_sin(x[i], mode); out_atan2[i] = orc_atan2(y[i], x[i], mode);
+    }
 }

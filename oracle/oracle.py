@@ -32,6 +32,7 @@ def lib():
     if _LIB is None:
         _LIB = C.CDLL(build())
         _LIB.orc_box_overlap_rows.restype = C.c_float
+        _LIB.orc_box_overlap_rows_cr.restype = C.c_float
     return _LIB
 
 
@@ -195,19 +196,30 @@ def filter_box_by_score(scores, classes, xs, ys, center, center_z, angle, dim, c
     return out, int(n.value)
 
 
-def nms_cpu(boxes9, n, nms_thresh=0.01):
+def nms_cpu(boxes9, n, nms_thresh=0.01, trig="ref"):
     """save_result + nms_cpu (include/helper.h:257-283, 470-481).  Returns (rows, keep_idx):
-    rows are x,y,z,l,w,h,rt,id,score as save_txt prints them."""
+    rows are x,y,z,l,w,h,rt,id,score as save_txt prints them.
+    trig = "ref": cosf / sinf / atan2f of the platform libm, the float overloads helper.h resolves to (the reference's arithmetic);
+    trig = "cr": each of those values correctly rounded through the double function -- the arithmetic of csrc/nms.hip."""
     boxes9 = np.ascontiguousarray(boxes9[:n], np.float32)
     out = np.empty((max(n, 1), 9), np.float32)
     keep = np.empty((max(n, 1),), np.int32)
-    k = lib().orc_nms_cpu(_p(boxes9), n, C.c_float(nms_thresh), _p(out), _p(keep))
+    fn = {"ref": lib().orc_nms_cpu, "cr": lib().orc_nms_cpu_cr}[trig]
+    k = fn(_p(boxes9), n, C.c_float(nms_thresh), _p(out), _p(keep))
     return out[:k].copy(), keep[:k].copy()
 
 
-def box_overlap(a9, b9):
-    return float(lib().orc_box_overlap_rows(_p(np.ascontiguousarray(a9, np.float32)),
-                                            _p(np.ascontiguousarray(b9, np.float32))))
+def box_overlap(a9, b9, trig="ref"):
+    fn = {"ref": lib().orc_box_overlap_rows, "cr": lib().orc_box_overlap_rows_cr}[trig]
+    return float(fn(_p(np.ascontiguousarray(a9, np.float32)), _p(np.ascontiguousarray(b9, np.float32))))
+
+
+def trig_values(x, y, trig="ref"):
+    """cos(x), sin(x), atan2(y, x) as floats: "ref" = cosf / sinf / atan2f of the platform libm, "cr" = correctly rounded through double"""
+    x = np.ascontiguousarray(x, np.float32); y = np.ascontiguousarray(y, np.float32)
+    c, s_, a = (np.empty_like(x) for _ in range(3))
+    lib().orc_trig_values(_p(x), _p(y), len(x), {"ref": 0, "cr": 1}[trig], _p(c), _p(s_), _p(a))
+    return c, s_, a
 
 
 # ---- fingerprints of SURVEY.md section 8(a): FNV-1a 64 over little-endian uint32 stream ----

@@ -5,8 +5,8 @@ import numpy as np
 def match_boxes(got, n_got, exp, n_exp, tol=1e-3, thr=0.3, thr_band=1e-4):
     """Box rows are only ordered by candidate rank, and two candidates whose scores differ by
     ~1e-6 may swap; so rows are matched by (class, nearest centre) instead of by index.
-    Returns (max abs difference over matched rows, number of unmatched rows that are not within
-    `thr_band` of the score threshold)."""
+    Returns (max abs difference over ALL NINE columns of the matched rows -- x, y, z, the three sizes, yaw, class, score --, number of
+    unmatched rows that are not within `thr_band` of the score threshold)."""
     got, exp = got[:n_got], exp[:n_exp]
     worst, unmatched = 0.0, 0
     used = np.zeros(n_got, bool)
@@ -20,7 +20,9 @@ def match_boxes(got, n_got, exp, n_exp, tol=1e-3, thr=0.3, thr_band=1e-4):
             unmatched += abs(e[8] - thr) > thr_band
             continue
         used[j] = True
-        worst = max(worst, float(np.abs(got[j] - e).max()))
+        d = np.abs(got[j] - e)
+        d[6] = min(d[6], abs(np.pi - d[6]))       # yaw = atan(sin / cos) (src/dsvt-ai-trt.cpp:1668-1669) lives in (-pi/2, pi/2): its two ends are one heading
+        worst = max(worst, float(d.max()))
     for j in np.nonzero(~used)[0]:
         unmatched += abs(got[j, 8] - thr) > thr_band
     return worst, int(unmatched)

@@ -1,6 +1,7 @@
 """Random small shapes through the convolution kernels that keep their weights resident in LDS (round 2): the 1 x 1 streaming GEMM
 (stride 1 / 2, pixel shuffle), the 64-input-channel 3 x 3 kernel and the block-diagonal narrow 3 x 3 kernel -- images smaller than a
-tile, ragged right / bottom tiles, stacks of images -- against PyTorch on the same fp16 operands."""
+tile, ragged right / bottom tiles, stacks of images -- against PyTorch's fp32 CPU convolution on the same fp16 operands (the reference is computed
+on the host: until round 4 it ran on the GPU, i.e. MIOpen checked these kernels)."""
 import numpy as np
 import pytest
 import torch
@@ -30,11 +31,11 @@ def test_fuzz_conv1x1_resident(pkg, H, W, B, seed):
     b = (torch.randn(cout, generator=g) * 0.1)
     if up > 1:
         w = torch.randn(cin, cout, up, up, generator=g) / np.sqrt(cin)
-        ref = torch.relu(F.conv_transpose2d(x.float(), w.half().float().to(DEV), b.to(DEV), stride=up))
+        ref = torch.relu(F.conv_transpose2d(x.float().cpu(), w.half().float(), b, stride=up)).to(DEV)
         op = P.add_conv2d_op(P.deconv_weight_rows(w.numpy()), b.numpy(), H, W, cin, cout, 1, 1, 0, pixel_shuffle=up, relu=True)
     else:
         w = torch.randn(cout, cin, 1, 1, generator=g) / np.sqrt(cin)
-        ref = torch.relu(F.conv2d(x.float(), w.half().float().to(DEV), b.to(DEV), stride))
+        ref = torch.relu(F.conv2d(x.float().cpu(), w.half().float(), b, stride)).to(DEV)
         op = P.add_conv2d_op(P.conv_weight_rows(w.numpy()), b.numpy(), H, W, cin, cout, 1, stride, 0, relu=True)
     got = op(_nhwc(x))[0]
     torch.cuda.synchronize()
@@ -51,7 +52,7 @@ def test_fuzz_conv3x3_c64_resident(pkg, H, W, B, seed):
     x = torch.randn(B, 64, H, W, generator=g).half().to(DEV)
     w = torch.randn(cout, 64, 3, 3, generator=g) / 24.0
     b = torch.randn(cout, generator=g) * 0.1
-    ref = torch.relu(F.conv2d(x.float(), w.half().float().to(DEV), b.to(DEV), 1, 1))
+    ref = torch.relu(F.conv2d(x.float().cpu(), w.half().float(), b, 1, 1)).to(DEV)
     got = P.add_conv2d_op(P.conv_weight_rows(w.numpy()), b.numpy(), H, W, 64, cout, 3, 1, 1, relu=True)(_nhwc(x))[0]
     torch.cuda.synchronize()
     assert (got.permute(0, 3, 1, 2).float() - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
@@ -74,7 +75,7 @@ def test_fuzz_block_diagonal_narrow_conv(pkg, H, W, B, seed):
         n0 += n
     b = torch.randn(cout, generator=g) * 0.1
     x = torch.randn(B, cin, H, W, generator=g).half().to(DEV)
-    ref = F.conv2d(x.float(), w.half().float().to(DEV), b.to(DEV), 1, 1)
+    ref = F.conv2d(x.float().cpu(), w.half().float(), b, 1, 1).to(DEV)
     got = P.add_conv2d_op(P.conv_weight_rows(w.numpy()), b.numpy(), H, W, cin, cout, 3, 1, 1, out_f32=True)(_nhwc(x))[0]
     torch.cuda.synchronize()
     assert got.dtype == torch.float32
@@ -94,7 +95,7 @@ def test_fuzz_conv3x3_wide_kernels_with_residual(pkg, H, W, B, seed):
     w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
     b = torch.randn(cout, generator=g) * 0.1
     r = torch.randn(B, cout, H, W, generator=g).half().to(DEV)
-    ref = torch.relu(F.conv2d(x.float(), w.half().float().to(DEV), b.to(DEV), 1, 1) + r.float())
+    ref = torch.relu(F.conv2d(x.float().cpu(), w.half().float(), b, 1, 1) + r.float().cpu()).to(DEV)
     got = P.add_conv2d_op(P.conv_weight_rows(w.numpy()), b.numpy(), H, W, cin, cout, 3, 1, 1, relu=True, has_residual=True)(_nhwc(x), _nhwc(r))[0]
     torch.cuda.synchronize()
     assert (got.permute(0, 3, 1, 2).float() - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())

@@ -11,10 +11,13 @@ DEV = "cuda:0"
 
 
 def _ref(x, w, b, stride, pad, res=None, relu=False):
-    y = F.conv2d(x.float(), w.float(), b, stride, pad)
+    """the reference convolution on the CPU (PyTorch fp32, the arithmetic oracle/dense_ref.py restates the TensorRT layers with); the result
+    goes back to the device only to be subtracted there.  (Until round 4 this ran F.conv2d on the GPU, i.e. MIOpen checked our kernels.)"""
+    dev = x.device
+    y = F.conv2d(x.float().cpu(), w.float().cpu(), None if b is None else b.float().cpu(), stride, pad)
     if res is not None:
-        y = y + res.float()
-    return torch.relu(y) if relu else y
+        y = y + res.float().cpu()
+    return (torch.relu(y) if relu else y).to(dev)
 
 
 def nhwc(t):      # NCHW tensor -> contiguous [1,H,W,C]
@@ -80,7 +83,7 @@ def test_deconv_pixel_shuffle_and_concat(pkg, k, cin):
     x = torch.randn(1, cin, H, W, generator=g).half().to(DEV)
     w = (torch.randn(cin, cout, k, k, generator=g) / np.sqrt(cin)).half().to(DEV)
     b = (torch.randn(cout, generator=g) * 0.1).to(DEV)
-    ref = torch.relu(F.conv_transpose2d(x.float(), w.float(), b, stride=k))
+    ref = torch.relu(F.conv_transpose2d(x.float().cpu(), w.float().cpu(), b.cpu(), stride=k)).to(DEV)      # (CPU reference)
     op = P.add_conv2d_op(P.deconv_weight_rows(w.float().cpu().numpy()), b.cpu().numpy(), H, W, cin, cout, 1, 1, 0,
                          pixel_shuffle=k, relu=True, out_channel_stride=total, out_channel_offset=off)
     buf = torch.full((1, H * k, W * k, total), 7.0, dtype=torch.float16, device=DEV)

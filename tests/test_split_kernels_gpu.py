@@ -256,6 +256,105 @@ def test_boxes_split_mode(pkg, oracle, frame):
     assert unmatched == 0 and worst < 1e-3, (worst, unmatched)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# The configuration bench.py TIMES, under test: the headline mode x four frames per forward x HIP-graph replay x two
+# pipelines on two streams, and the whole box row -- all nine columns, yaw included -- against the fp32 oracle on clouds that include the
+# ill-conditioned one of the 24-cloud sweep (seed 21: a box whose rot vector is ~1 % of the head's scale, profiles/r04_mx_box_sweep.txt).
+# ---------------------------------------------------------------------------------------------------------------------
+_ORACLE_BOXES = {}
+
+
+def _oracle_boxes(pkg, seed):
+    """FilterBoxByScore rows of lidar_like(180000, seed) on the fp32 CPU oracle (cached per session: ~10 s each on the GPU box's host cores)"""
+    if seed not in _ORACLE_BOXES:
+        from oracle import dense_ref as D
+        from tests.test_pipeline_gpu import _oracle_cfg
+        caps = pkg.pipeline.Caps()
+        pts, n = cases.pad_points(pkg.synth.lidar_like(180000, seed), caps.N)
+        _ORACLE_BOXES[seed] = D.forward(pts, n, pkg.synth.make_weights(), _oracle_cfg(caps))
+    return _ORACLE_BOXES[seed]
+
+
+def test_boxes_split_mode_four_frames_graph(pkg, oracle):
+    """DsvtPipeline(COMPUTE_SPLIT, frames=4) as bench.py runs it: (a) each frame's FilterBoxByScore rows are the BITS of the frames=1 split pipeline's --
+    eager, replayed from a HIP graph, and replayed by two pipelines on two streams at once (the four-frame launches pick other kernel instantiations:
+    eight-wave MLP + two-wave tail round, the resident QKV's row streams, image stacks in the convolutions); (b) every one of the nine box columns
+    of every frame is within 1e-3 of dense_ref.forward."""
+    from tests.parity import match_boxes
+    P = pkg.plugin
+    w = pkg.synth.make_weights()
+    seeds = [21, 1, 9, 3]
+    clouds = [pkg.synth.lidar_like(180000, s) for s in seeds]
+    one = pkg.pipeline.DsvtPipeline(w, caps=pkg.pipeline.Caps(), device=DEV, linear_compute=P.COMPUTE_SPLIT)
+    singles = []
+    for p in clouds:
+        pts, n = cases.pad_points(p, one.caps.N)
+        r, c = one.forward(torch.from_numpy(pts[None]).to(DEV), torch.tensor([n], dtype=torch.int32, device=DEV))
+        torch.cuda.synchronize()
+        singles.append((r[0].clone(), int(c[0])))
+    del one
+    caps4 = pkg.pipeline.Caps.for_frames(4)
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+    pipes = [pkg.pipeline.DsvtPipeline(w, caps=caps4, device=DEV, linear_compute=P.COMPUTE_SPLIT, frames=4) for _ in range(2)]
+    orders = [(0, 1, 2, 3), (2, 3, 1, 0)]                     # the two pipelines see the clouds in different slots
+
+    def inputs(order):
+        buf = np.zeros((1, 4 * caps4.N, 4), np.float32)
+        for slot, k in enumerate(order):
+            buf[0, slot * caps4.N:slot * caps4.N + clouds[k].shape[0]] = clouds[k]
+        return torch.from_numpy(buf).to(DEV), torch.tensor([clouds[k].shape[0] for k in order], dtype=torch.int32, device=DEV)
+
+    def check(rows, cnt, order, what):
+        assert rows.shape == (4, 500, 9) and cnt.shape == (4,)
+        for slot, k in enumerate(order):
+            assert int(cnt[slot]) == singles[k][1] and singles[k][1] > 0, (what, slot)
+            assert torch.equal(rows[slot], singles[k][0]), (what, slot, float((rows[slot] - singles[k][0]).abs().max()))
+
+    ins = [inputs(o) for o in orders]
+    rows, cnt = pipes[0].forward(*ins[0])                     # eager
+    torch.cuda.synchronize()
+    check(rows, cnt, orders[0], "eager")
+    outs = []
+    for s in range(2):                                        # capture on each pipeline's own stream
+        with torch.cuda.stream(streams[s]):
+            outs.append(pipes[s].capture(*ins[s]))
+            torch.cuda.synchronize()
+    for rep in range(3):                                      # both graphs in flight at once, three rounds
+        for s in range(2):
+            with torch.cuda.stream(streams[s]):
+                pipes[s].replay()
+        torch.cuda.synchronize()
+        for s in range(2):
+            check(outs[s][0], outs[s][1], orders[s], f"two-stream replay {rep}")
+    # (b) all nine columns against the fp32 oracle
+    for slot, k in enumerate(orders[0]):
+        eb, ec = _oracle_boxes(pkg, seeds[k])
+        worst, unmatched = match_boxes(outs[0][0][slot].cpu().numpy(), int(outs[0][1][slot]), eb, ec)
+        print("four-frame graph replay, seed", seeds[k], "max|diff| over nine columns", worst, "unmatched", unmatched)
+        assert unmatched == 0 and worst < 1e-3, (seeds[k], worst, unmatched)
+
+
+def test_boxes_split_mode_eight_clouds_all_nine_columns(pkg, oracle):
+    """an 8-seed slice of tools/head_variant_sweep.py as a test: the headline mode's rows against the fp32 ORACLE on eight 180k-point clouds, the sweep's
+    worst yaw cases among them (seeds 21, 9, 3, 1); the bar is 1e-3 on every column, and HALF of it on the worst cloud is asserted as the margin a
+    later kernel tweak may use up (a 1-ulp change elsewhere moved the fp8 head's worst yaw from 1.7e-3 to 2.0e-3)."""
+    from tests.parity import match_boxes
+    P = pkg.plugin
+    w = pkg.synth.make_weights()
+    pipe = pkg.pipeline.DsvtPipeline(w, caps=pkg.pipeline.Caps(), device=DEV, linear_compute=P.COMPUTE_SPLIT)
+    worst_all = 0.0
+    for seed in (21, 9, 3, 1, 0, 7, 16, 23):
+        pts, n = cases.pad_points(pkg.synth.lidar_like(180000, seed), pipe.caps.N)
+        r, c = pipe.forward(torch.from_numpy(pts[None]).to(DEV), torch.tensor([n], dtype=torch.int32, device=DEV))
+        torch.cuda.synchronize()
+        eb, ec = _oracle_boxes(pkg, seed)
+        worst, unmatched = match_boxes(r[0].cpu().numpy(), int(c[0]), eb, ec)
+        print("seed", seed, "max|diff| over nine columns", worst, "unmatched", unmatched)
+        assert unmatched == 0 and worst < 1e-3, (seed, worst, unmatched)
+        worst_all = max(worst_all, worst)
+    assert worst_all < 5e-4, worst_all
+
+
 # =====================================================================================================================
 # set_attention_split_kernel (DsvtSetAttentionPlugin split_precision) vs GetValueByIndex -> multHeadAttention core -> MapSetFeature2Voxel
 # =====================================================================================================================
