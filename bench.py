@@ -12,16 +12,19 @@ frames on each GPU per batch) on each of two streams (`--streams`) are the defau
 reference's own: one frame at a time).  Frame-batch data parallelism: every rank processes K frames of its own (weak scaling) and the
 per-frame results are gathered to rank 0 with ONE collective inside the timed region.  Rank 0 prints one JSON line.
 
-Two precision modes are timed by a default run (N = 1):
-  value / ms_per_step / p50_ms   `--dtype split` (default, round 4): the fp32-grade mode -- every DSVT GEMM on (hi, lo) fp16 operand pairs (three
-                v_mfma_f32_16x16x32_f16 per product), the 3 x 3 convolutions as one fp16 product + two e4m3 correction products on
-                v_mfma_scale_f32_16x16x128_f8f6f4, fp32 accumulate, fp32 tensors.  The reference's arithmetic is fp32 (include/params.h:332); boxes sit
-                within 1e-3 of the fp32 oracle (measured ~5e-5): the mode that answers north_star's joint target (>= 200 frames/s AND 1e-3).
+Three precision modes are timed by a default run (N = 1):
+  value / ms_per_step / p50_ms   `--dtype split` (default): the fp32-grade mode -- every GEMM and convolution on (hi, lo) fp16 operand pairs (three
+                v_mfma_f32_16x16x32_f16 per product), fp32 accumulate, fp32 tensors in the DSVT stage.  The reference's arithmetic is fp32
+                (include/params.h:332); ALL NINE box columns (yaw included) sit within 1e-3 of the fp32 oracle on every check cloud (measured ~1e-4 worst):
+                the mode that answers north_star's joint target (>= 200 frames/s AND 1e-3).  Round 4's headline ran the convolutions' correction products
+                on the fp8 scaled MFMA: its yaw tail crosses 1e-3 on ill-conditioned boxes, so since round 5 it is `fp8_head_mode` below, not `value`.
   fast_mode     the same frames through the fp16 pipeline (BASELINE configs[2] says "fp16"): 2.2 x the frames/s, boxes 2e-3 .. 4e-3 from the oracle on
                 z / size -- OUTSIDE the 1e-3 bar, so it is reported beside the headline, not as it.
-  exact_head_mode  the fp32-grade frame with three fp16 products in the convolutions as well (round 3's arithmetic): every box column incl. yaw within
-                1.5e-5 of the oracle, 12-14 % fewer frames/s -- what the headline's fp8 correction terms trade.
-  box_err_vs_oracle (inside cpu_baseline, where the oracle runs as the checker) the maximum box error of each mode on the bench frame.
+  fp8_head_mode  the fp32-grade frame with one fp16 product + two e4m3 correction products (v_mfma_scale_f32_16x16x128_f8f6f4) in the convolutions
+                (`DsvtPipeline(head_mx=True)`): ~20 % more frames/s, centres / sizes / scores ~1e-4, yaw above 1e-3 on single boxes -- reported, not claimed.
+  box_err_vs_oracle (inside cpu_baseline, where the oracle runs as the checker) the WORST box error of each mode over eight check clouds
+                (seeds 21, 9, 3, 1, 0, 7, 16, 23), per column and over all nine, run through the timed pipelines.
+  targets       which operating point meets which bar (>= 200 frames/s; <= 5 ms p50 per frame), and whether one point meets both.
 
 Timing: K steps per repeat, every repeat between two torch.cuda.synchronize() on every rank; R = max(3, min(15, ceil(300 / K))) repeats (a function
 of K only).  Collectives: one barrier before the first repeat, the result gather inside the LAST repeat (`gather_ms`), one barrier after it, ONE
@@ -33,8 +36,9 @@ Extra objects in the line:
   single_frame_mode  (N = 1) the same kernels with ONE frame per forward and one in flight -- the reference's own mode: frames/s and p50, both modes.
   host_input_mode    (N = 1) the reference's own timed bracket (src/dsvt-ai-trt.cpp:1918-1956): upload from pinned host memory + the frame + download
                 of the final boxes, one frame at a time, host clock around each frame -- the PCIe-inclusive figure, never `value`.
-  roofline      the hot path's kernel with the largest share of the frame: algorithmic bytes per launch / average launch
-                duration, measured with HIP events around every launch of the sampled forward, against the 8 TB/s HBM peak of gfx950.
+  roofline      the kernel family with the LARGEST share of the frame (the convolutions): algorithmic flops (bytes) per launch / average launch
+                duration, measured with HIP events around every launch of the sampled forward, against the dense fp16 MFMA peak (8 TB/s HBM peak).
+  roofline_hot_path  the same object for the largest of SURVEY 8(a)'s own rows (the DSVT stage: encoder MLP / QKV / set attention / PFN).
   roofline_other_kernels  the other kernel families, incl. the scatter / gather stages north_star names (voxelizer chain, set partition,
                 Map2Bev) priced with SURVEY 8(d)'s algorithmic bytes.
   cpu_baseline  SURVEY 8(d): the reference's HOST path -- loadData + save_result + nms_cpu (include/helper.h:28-72, 257-283, 470-481;
@@ -105,11 +109,12 @@ def box_errors(got, n_got, exp, n_exp):
                 max_xyz_size_score=float(max(m[:6].max(), m[8])), matched=round(matched / max(n_exp, 1), 4), boxes=int(n_got), oracle_boxes=int(n_exp))
 
 
-def cpu_baseline(caps, frames, n_parallel_frames=32, whole_network=None, mode_rows=None):
+def cpu_baseline(caps, frames, n_parallel_frames=32, whole_network=None, mode_rows=None, check_clouds=None):
     """SURVEY 8(d).  frames: [(points [n,4] float32 numpy, FilterBoxByScore rows [500,9] float32 numpy from the GPU, count)].
     value = frames/s of the reference's host path, ONE thread: loadData (read the .bin, size check, zero-pad to the cap) +
     save_result + nms_cpu on the GPU's own rows.  whole_network = (weights,): the whole network of frame 0 on the CPU oracle;
-    mode_rows = {mode: (rows, count)} FilterBoxByScore rows of frame 0 per precision mode -> box_err_vs_oracle."""
+    check_clouds = [(seed, points)], mode_rows = {mode: [(rows, count) per check cloud]}: FilterBoxByScore rows of every precision mode on the CHECK clouds
+    (run through the timed pipelines) -> box_err_vs_oracle = the worst error per column over all of them against the oracle's rows."""
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
@@ -169,11 +174,29 @@ def cpu_baseline(caps, frames, n_parallel_frames=32, whole_network=None, mode_ro
         out["whole_network_port"] = dict(value=round(1.0 / t_frame, 4), unit="frames/s", frame_ms=round(1e3 * t_frame, 1),
                                          note=f"the whole network of frame 0 in fp32 on the CPU oracle, dense layers on {torch.get_num_threads()} "
                                               "torch threads, plugin restatement on 1 core", boxes=int(cnt))
-        if mode_rows:
-            # the oracle as the CHECKER of the timed modes: FilterBoxByScore rows of frame 0 (before NMS, like the reference engine's output)
-            out["box_err_vs_oracle"] = {m: box_errors(r, c, boxes, int(cnt)) for m, (r, c) in mode_rows.items()}
-            out["box_err_vs_oracle"]["note"] = ("max abs error of the FilterBoxByScore rows of pool frame 0 against the fp32 CPU oracle, rows matched by class + "
-                                                "nearest centre; north_star's bar: centres / sizes / scores within 1e-3")
+        if mode_rows and check_clouds:
+            # the oracle as the CHECKER of the timed modes: FilterBoxByScore rows (before NMS, like the reference engine's output) of every check
+            # cloud -- the 24-cloud sweep's ill-conditioned one (seed 21) among them --, worst error per column over all of them
+            errs = {m: [] for m in mode_rows}
+            for ci, (seed, cp) in enumerate(check_clouds):
+                pc = np.zeros((caps.N, 4), np.float32); pc[:cp.shape[0]] = cp
+                ob, oc = D.forward(pc, cp.shape[0], weights, cfg)
+                for m, rows in mode_rows.items():
+                    errs[m].append(box_errors(rows[ci][0], rows[ci][1], ob, int(oc)))
+            cols = ("xy", "z", "size", "yaw", "score", "max_xyz_size_score")
+            out["box_err_vs_oracle"] = {}
+            for m, es in errs.items():
+                es_ = [e for e in es if e]
+                w_ = {k: max(e[k] for e in es_) for k in cols} if es_ else None
+                if w_:
+                    w_.update(all_nine_columns=max(w_["max_xyz_size_score"], w_["yaw"]), matched=min(e["matched"] for e in es_), clouds=len(es_),
+                              per_cloud_worst=[round(max(e["max_xyz_size_score"], e["yaw"]), 7) for e in es_])
+                out["box_err_vs_oracle"][m] = w_
+            out["box_err_vs_oracle"]["seeds"] = [sd for sd, _ in check_clouds]
+            out["box_err_vs_oracle"]["note"] = ("WORST absolute error per column over the check clouds (lidar_like(points, seed) for the listed seeds, run through the timed "
+                                                "pipelines: same kernels, same frames per forward) of the FilterBoxByScore rows against the fp32 CPU oracle, rows matched by "
+                                                "class + nearest centre; all_nine_columns = max over x, y, z, the sizes, yaw, score (the class matches by construction); "
+                                                "north_star's bar: centres / sizes / scores within 1e-3 -- the headline mode holds it on all nine")
     for p_ in paths:
         os.remove(p_)
     os.rmdir(tmp)
@@ -204,7 +227,7 @@ class ModeRun:
         self.NS = NS = max(1, args.streams)
         self.use_graph = not args.no_graph
         kw = {"f16": dict(linear_compute=P.COMPUTE_F16, head_dtype=torch.float16), "split": dict(linear_compute=P.COMPUTE_SPLIT),
-              "split3": dict(linear_compute=P.COMPUTE_SPLIT, head_mx=False), "f32": dict(linear_compute=P.COMPUTE_F32)}[mode]
+              "splitmx": dict(linear_compute=P.COMPUTE_SPLIT, head_mx=True), "f32": dict(linear_compute=P.COMPUTE_F32)}[mode]
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
         self.pipes = [pkg.pipeline.DsvtPipeline(weights, caps=caps, device=dev, device_nms=not args.no_nms, frames=FB, **kw) for _ in range(NS)]
         self.static_in = [(torch.zeros_like(pool[0][0]), torch.zeros_like(pool[0][1])) for _ in range(NS)]
@@ -325,10 +348,10 @@ class ModeRun:
 
 def roofline_rows(prof, sampled, counts, pool_len, FB, mode, n_points_per_launch, head_mx=False):
     """per plugin family: algorithmic work per launch (SURVEY 8d formulas) / measured launch duration"""
-    f16, split = mode == "f16", mode in ("split", "split3")
+    f16, split = mode == "f16", mode in ("split", "splitmx")
     pm = {}
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", PMC_FILES[(mode, FB)]))) if mode != "split3" else {}
+        pm = json.load(open(os.path.join(ROOT, "profiles", PMC_FILES[(mode, FB)])))
     except Exception:
         pass
 
@@ -364,9 +387,13 @@ def roofline_rows(prof, sampled, counts, pool_len, FB, mode, n_points_per_launch
             per_row = 192 * ((4 + 4 + 4 * f.get("has_block_norm", 0) + 4) if sp else (2 + 4 + 4 * f.get("has_block_norm", 0) + 4 + 2))
             return (2.0 * rows * (192 * 192 + 2 * 192 * 384), rows * per_row + (4 if sp else 2) * (192 * 192 + 2 * 192 * 384))
         if t == "DsvtSetAttentionPlugin":
+            # io_half: 1 = fp16 rows, 0 / 2 = fp32 rows (2 = the split-precision kernel; round 4 priced those at 2 bytes).  Algorithmic bytes = every
+            # voxel's q, k, v row in ONCE and its output row out once (P x 3C + P x C values): two thirds of the S x 36 slots repeat voxels of the same
+            # window, and the PMC fetch of the kernel IS P x 576 x 4 B (profiles/r04_split_pmc_traffic.json) -- the slot formula S x 36 x 3C counted
+            # every repeat as HBM traffic (kept as slot_gather_mb in the row)
             S = c["S"][0 if pl.win == 0 else 1]
-            esz = 2 if f.get("io_half") else 4
-            return (4.0 * 36 * 36 * 192 * S, S * 36 * 192 * esz * 3 + c["P"] * 192 * esz)
+            esz = 2 if f.get("io_half") == 1 else 4
+            return (4.0 * 36 * 36 * 192 * S, c["P"] * 192 * esz * 3 + c["P"] * 192 * esz)
         if t == "DsvtPosEmbedPlugin":
             L = f["num_layers"]
             return (2.0 * L * c["P"] * (2 * 192 + 192 * 192), c["P"] * 16 + L * (c["P"] * 192 * 2 + 2 * 192 * 192))
@@ -452,7 +479,12 @@ def roofline_rows(prof, sampled, counts, pool_len, FB, mode, n_points_per_launch
                 mp = PEAK_F32_MATRIX_TFLOPS if mode == "f32" else PEAK_SPLIT3 if split else PEAK_F16_MATRIX_TFLOPS
                 r["mfma_frac_of_peak"] = round(tfl / mp, 4); r["mfma_peak_tflops"] = round(mp, 1)
         else:
-            r.update(achieved=round(tfl, 2), peak=round(peak_tf, 1), unit="TFLOP/s", frac=round(tfl / peak_tf, 4), hbm_gbs=round(gbs, 1))
+            # peak = the guide's dense peak of the matrix instruction the kernel issues (fp16: 2.5 PF; fp32 matrix: 157 TF); achieved = ALGORITHMIC flops
+            # (2 M N K of the fp32-grade product) per second.  A split-precision product is three fp16 MFMAs (or fp16 + two fp8), so the rate the matrix
+            # pipe is asked for is 3 x that: frac_of_arithmetic_peak prices the achieved rate against the peak OF THAT ARITHMETIC (dense peak / 3, ...)
+            dense = PEAK_F32_MATRIX_TFLOPS if mode == "f32" else PEAK_F16_MATRIX_TFLOPS
+            r.update(achieved=round(tfl, 2), peak=dense, unit="TFLOP/s", frac=round(tfl / dense, 4), hbm_gbs=round(gbs, 1),
+                     peak_of_the_arithmetic=round(peak_tf, 1), frac_of_arithmetic_peak=round(tfl / peak_tf, 4))
             if split and ptype == "DsvtConv2dPlugin" and not head_mx:
                 r["mfma_issue_tflops"] = round(3 * tfl, 1)
         chain = ptype in ("Points2FeaturesPlugin", "DsvtSetPartitionPlugin")
@@ -462,6 +494,9 @@ def roofline_rows(prof, sampled, counts, pool_len, FB, mode, n_points_per_launch
             r["algorithmic_gflop_per_launch"] = round(tot_fl / n_l / 1e9, 3)
         if r["traffic"] is not None:
             r["traffic_source"] = "profiles/" + PMC_FILES[(mode, FB)]
+        if ptype == "DsvtSetAttentionPlugin":        # the slot formula of rounds 1-4 (every slot's q, k, v row counted as HBM traffic), for comparison
+            esz_ = 2 if lst[0][2].fields.get("io_half") == 1 else 4
+            r["slot_gather_mb"] = round(sum(counts[(j // per_frame) % pool_len]["S"][0 if pl.win == 0 else 1] * 36 * 192 * esz_ * 3 for j, (_, _, pl) in enumerate(lst)) / n_l / 1e6, 2)
         rows_out.append((ptype, r))
     return rows_out
 
@@ -495,6 +530,7 @@ def main():
                                                              "the line is marked and is NOT a scaling number)")
     ap.add_argument("--repeats", type=int, default=0, help="repeats of the K-step timed loop (0 = max(3, min(15, ceil(300 / K))): a function of K only, so every rank runs the same number)")
     ap.add_argument("--dump-rows", default=None, help="rank 0 saves the gathered result rows [K * N, 4501] of the headline mode as .npy (tests: the gather against single-process rows)")
+    ap.add_argument("--oracle-clouds", type=int, default=8, help="how many 180k-point clouds the timed modes' boxes are checked on against the CPU oracle (~10 s of host time each on the GPU box; cpu_baseline.box_err_vs_oracle = the worst over them)")
     ap.add_argument("--no-whole-network-cpu", action="store_true", help="cpu_baseline skips the whole network on the CPU oracle (~10 s; also drops box_err_vs_oracle)")
     args = ap.parse_args()
     # the product library reads no environment switch (csrc/plugin_base.h ablateEnv), and a timed run must not load another build either
@@ -592,13 +628,18 @@ def main():
         if prof is not None and sampled:
             npl = sum(int(v) for v in pool[0][1].cpu())
             rows = roofline_rows(prof, sampled, counts, len(pool), FB, mode, npl, head_mx=bool(getattr(run.pipes[0], "head_mx", False)))
-            # the headline roofline object = the hot path's kernel with the largest share of the frame
+            # the headline roofline object = the kernel family with the LARGEST share of the frame, whichever it is (round 4 left the convolutions
+            # out of the candidates although they are two thirds of the frame); roofline_hot_path = the largest of SURVEY 8(a)'s own rows (the DSVT stage)
+            tot = sum(x[1]["ms_per_forward"] for x in rows)
+            for _, r_ in rows:
+                r_["share_of_sampled_forward"] = round(r_["ms_per_forward"] / max(tot, 1e-9), 4)
+            top = max(rows, key=lambda x: x[1]["ms_per_forward"])[1]
             hot = [x for x in rows if x[0] not in ("DsvtConv2dPlugin", "Points2FeaturesPlugin", "DsvtSetPartitionPlugin", "Map2BevPlugin")] or rows
-            top = max(hot, key=lambda x: x[1]["ms_per_forward"])[1]
             out["roofline"] = top
+            out["roofline_hot_path"] = max(hot, key=lambda x: x[1]["ms_per_forward"])[1]
             out["roofline_other_kernels"] = [r for _, r in rows if r is not top]
         else:
-            out["roofline"], out["roofline_other_kernels"] = None, []
+            out["roofline"], out["roofline_hot_path"], out["roofline_other_kernels"] = None, None, []
         return out
 
     head = run_mode(args.dtype)
@@ -610,9 +651,9 @@ def main():
             "ms_per_step": head["ms_per_step"], "p50_ms": head["p50_ms"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f16": "f16 (fp16 MFMA operands, fp32 accumulate: boxes OUTSIDE the 1e-3 bar on z / size)",
-                      "split": "f16x3 + fp8 (fp32 grade: (hi, lo) fp16 operand pairs, three v_mfma_f32_16x16x32_f16 per product in the DSVT GEMMs; "
-                               "fp16 product + two e4m3 correction products on v_mfma_scale_f32_16x16x128_f8f6f4 in the 3 x 3 convolutions; fp32 accumulate; "
-                               "boxes within 1e-3 of the fp32 oracle: cpu_baseline.box_err_vs_oracle.split)", "f32": "f32"}[args.dtype],
+                      "split": "f16x3 (fp32 grade: every GEMM / convolution operand a (hi, lo) fp16 pair, three v_mfma_f32_16x16x32_f16 per product, fp32 "
+                               "accumulate, fp32 tensors in the DSVT stage; all nine box columns within 1e-3 of the fp32 oracle: cpu_baseline.box_err_vs_oracle.split)",
+                      "f32": "f32"}[args.dtype],
             "data": "synthetic" + (" (uploaded from pinned host memory inside the timed region)" if args.host_input else ""),
             "repeats": head["repeats"], "repeat_values": head["repeat_values"], "gather_ms": head["gather_ms"],
             "value_of_the_repeat_with_the_gather": head["value_of_the_repeat_with_the_gather"],
@@ -634,6 +675,7 @@ def main():
                        "caps": dict(points=caps.N, pillars=caps.P, windows=caps.W, sets=caps.S, overflow_free=caps.overflow_free()),
                        "frame0": head["frame0"]},
             "roofline": head["roofline"],
+            "roofline_hot_path": head["roofline_hot_path"],
             "roofline_other_kernels": head["roofline_other_kernels"],
         }
         if shared:
@@ -641,16 +683,29 @@ def main():
                                             "n_gpus counts ranks, the ranks time-share the device")
             line["metric"] += " [DRY RUN: ranks share a device]"
     mode_rows = {}
+    # the clouds every timed mode is CHECKED on against the CPU oracle (cpu_baseline.box_err_vs_oracle): eight seeds, the 24-cloud sweep's worst yaw
+    # cases among them (21, 9, 3, 1: profiles/r04_mx_box_sweep.txt), run through the timed pipelines themselves (FB frames per forward)
+    CHECK_SEEDS = [21, 9, 3, 1, 0, 7, 16, 23][:max(1, args.oracle_clouds)] if args.oracle_clouds > 0 else []
+    check_clouds = [(sd, pkg.synth.lidar_like(args.points, seed=sd)) for sd in CHECK_SEEDS] if (rank == 0 and world == 1 and not args.no_cpu_baseline) else []
 
     def fb_rows(run_, tag):
-        """FilterBoxByScore rows (before NMS: the reference engine's output) of pool frame 0 in this mode"""
+        """FilterBoxByScore rows (before NMS: the reference engine's output) of the check clouds in this mode, through the timed pipeline"""
+        if not check_clouds:
+            return
         pipe = run_.pipes[0]
         nms_op, pipe.nms = pipe.nms, None
-        fb = pipe.forward(*pool[0])
-        torch.cuda.synchronize()
-        mode_rows[tag] = (fb[0][0].cpu().numpy().copy(), int(fb[1][0]))
+        rows_ = []
+        for j in range(0, len(check_clouds), FB):
+            buf = np.zeros((1, FB * caps.N, 4), np.float32); ns = [0] * FB
+            grp = check_clouds[j:j + FB]
+            for f, (_, cp) in enumerate(grp):
+                buf[0, f * caps.N:f * caps.N + cp.shape[0]] = cp; ns[f] = cp.shape[0]
+            fb = pipe.forward(torch.from_numpy(buf).to(dev), torch.tensor(ns, dtype=torch.int32, device=dev))
+            torch.cuda.synchronize()
+            for f in range(len(grp)):
+                rows_.append((fb[0][f].cpu().numpy().copy(), int(fb[1][f])))
+        mode_rows[tag] = rows_
         pipe.nms = nms_op
-        return fb
 
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
@@ -668,7 +723,7 @@ def main():
             line[key] = dict(
                 dtype=("f16: fp16 MFMA operands / fp16 BEV maps, fp32 accumulate + LayerNorm / softmax / box decode (BASELINE configs[2] 'fp16'; the reference's "
                        "own arithmetic is fp32: include/params.h:332)" if other == "f16" else
-                       "f16x3 + fp8: the fp32-grade mode (see --dtype split)"),
+                       "f16x3: the fp32-grade mode (see --dtype split)"),
                 value=pm["value"], unit="frames/s", ms_per_step=pm["ms_per_step"], p50_ms=pm["p50_ms"], repeats=pm["repeats"], repeat_values=pm["repeat_values"],
                 frames_per_forward=FB, frames_in_flight=prun.NS * FB,
                 graph_replay_equals_eager=pm["graph_replay_equals_eager"], roofline=pm["roofline"], roofline_other_kernels=pm["roofline_other_kernels"],
@@ -677,17 +732,19 @@ def main():
                       "boxes within 1e-3 of the fp32 oracle (cpu_baseline.box_err_vs_oracle.split)"))
             del prun, pm
         if args.dtype == "split" and not args.no_fast_mode and not args.host_input:
-            # the same fp32-grade frame with THREE fp16 products in every convolution too (round 3's arithmetic, `DsvtPipeline(head_mx=False)`): every box
-            # column, yaw included, within 1.5e-5 of the oracle -- what the fp8 correction terms of the headline trade (centres / sizes / scores 5e-5 ..
-            # 1e-4; the yaw = atan(sin / cos) of the random-weight rot head's short vectors up to ~1e-3 on single boxes) for 14 % more frames/s
-            em = run_mode("split3")
+            # round 4's headline, now reported beside it: the fp32-grade frame with the convolutions' two correction products on the fp8 scaled MFMA
+            # (`DsvtPipeline(head_mx=True)`): ~20 % more frames/s, centres / sizes / scores ~1e-4 from the oracle, but the yaw of boxes with a short rot
+            # vector lands above 1e-3 on about one cloud in thirty (tools/head_variant_sweep.py) -- a nine-column 1e-3 bar rejects it, so it is not `value`
+            em = run_mode("splitmx")
             erun = em.pop("_run")
             if not args.no_cpu_baseline:
-                fb_rows(erun, "split3")
-            line["exact_head_mode"] = dict(dtype="f16x3 everywhere: (hi, lo) fp16 operand pairs, three v_mfma_f32_16x16x32_f16 per product in the convolutions too",
-                                           value=em["value"], unit="frames/s", ms_per_step=em["ms_per_step"], p50_ms=em["p50_ms"], repeats=em["repeats"],
-                                           repeat_values=em["repeat_values"], graph_replay_equals_eager=em["graph_replay_equals_eager"],
-                                           note="cpu_baseline.box_err_vs_oracle.split3: every column incl. yaw within ~1.5e-5")
+                fb_rows(erun, "splitmx")
+            line["fp8_head_mode"] = dict(dtype="f16x3 in the DSVT stage; fp16 product + two e4m3 correction products (v_mfma_scale_f32_16x16x128_f8f6f4) in the 3 x 3 and 1 x 1 "
+                                               "stride-1 convolutions (DsvtPipeline(head_mx=True))",
+                                         value=em["value"], unit="frames/s", ms_per_step=em["ms_per_step"], p50_ms=em["p50_ms"], repeats=em["repeats"],
+                                         repeat_values=em["repeat_values"], graph_replay_equals_eager=em["graph_replay_equals_eager"],
+                                         note="NOT CLAIMED: cpu_baseline.box_err_vs_oracle.splitmx -- centres / sizes / scores ~1e-4, yaw above 1e-3 on the worst "
+                                              "box of the check clouds")
             del erun, em
         if FB > 1 and not args.no_latency_mode and args.dtype in ("f16", "split"):
             # the reference's own mode beside the headline: ONE frame per forward, one in flight (graph replay), same clouds --
@@ -748,6 +805,22 @@ def main():
                                                        "(src/dsvt-ai-trt.cpp:1918-1956); the PCIe-inclusive figure, never `value`"}
                 del p1
             line["single_frame_mode"].update(value=line["single_frame_mode"]["split"]["value"], unit="frames/s", p50_ms=line["single_frame_mode"]["split"]["p50_ms"])
+        # which operating point meets which bar (>= 200 frames/s and <= 5 ms p50 per frame; north_star: boxes within 1e-3), in ONE place:
+        # the headline (FB frames per forward x NS streams) is the throughput point -- its p50 is per FORWARD of FB frames with NS in flight, not a frame
+        # latency --, single_frame_mode is the latency point; `both_at_one_operating_point` says whether one of them meets both bars by itself
+        sf = line.get("single_frame_mode", {}).get(args.dtype if args.dtype in ("split", "f16") else "split")
+        hl_ok = line["value"] >= 200.0
+        line["targets"] = {
+            "bars": ">= 200 frames/s on one MI355X, <= 5 ms p50 per frame, boxes within 1e-3 of the fp32 oracle (all nine columns: cpu_baseline.box_err_vs_oracle)",
+            "throughput_point": {"mode": f"{args.dtype}, {FB} frames per forward x {run.NS} streams", "frames_per_s": line["value"], "meets_200_frames_per_s": bool(hl_ok),
+                                 "p50_ms_per_forward": line["p50_ms"], "frame_latency_ms": round(line["p50_ms"], 3),
+                                 "meets_5_ms_p50": bool(line["p50_ms"] <= 5.0)},
+            "latency_point": None if not sf else {"mode": f"{args.dtype}, one frame per forward, one in flight", "frames_per_s": sf["value"], "p50_ms": sf["p50_ms"],
+                                                  "meets_200_frames_per_s": bool(sf["value"] >= 200.0), "meets_5_ms_p50": bool(sf["p50_ms"] <= 5.0)},
+        }
+        line["targets"]["both_at_one_operating_point"] = (
+            "latency_point" if sf and sf["value"] >= 200.0 and sf["p50_ms"] <= 5.0 else
+            "throughput_point" if hl_ok and line["p50_ms"] <= 5.0 else "neither: throughput and latency bars are met at different operating points" if (hl_ok and sf and sf["p50_ms"] <= 5.0) else "neither")
         if not args.no_cpu_baseline:
             # the FilterBoxByScore rows of the pooled frames as the GPU produced them (the reference's D2H payload)
             frames = []
@@ -761,7 +834,7 @@ def main():
                     frames.append((pts[0, f * caps.N:f * caps.N + k].cpu().numpy(), fb[0][f].cpu().numpy().copy(), int(fb[1][f])))
             pipe.nms = nms_op
             c_one = pkg.pipeline.Caps()              # (the oracle runs ONE frame: per-frame capacities)
-            line["cpu_baseline"] = cpu_baseline(c_one, frames, whole_network=None if args.no_whole_network_cpu else (weights,), mode_rows=mode_rows)
+            line["cpu_baseline"] = cpu_baseline(c_one, frames, whole_network=None if args.no_whole_network_cpu else (weights,), mode_rows=mode_rows, check_clouds=check_clouds)
         else:
             line["cpu_baseline"] = None
     elif rank == 0:

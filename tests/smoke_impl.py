@@ -12,7 +12,7 @@ def run(pkg, verbose=True):
     dev = torch.device("cuda:0")
     w = pkg.synth.make_weights()
     caps = pkg.pipeline.Caps.reference()
-    pipe = pkg.pipeline.DsvtPipeline(w, caps=caps, device=dev, linear_compute=pkg.plugin.COMPUTE_SPLIT)      # the fp32-grade mode (bench.py `parity_mode`)
+    pipe = pkg.pipeline.DsvtPipeline(w, caps=caps, device=dev, linear_compute=pkg.plugin.COMPUTE_SPLIT)      # the fp32-grade mode (bench.py's headline)
     pts, n = cases.load_frame("000000", caps.N)
     boxes, cnt = pipe.forward(torch.from_numpy(pts[None]).to(dev), torch.tensor([n], dtype=torch.int32, device=dev))
     torch.cuda.synchronize()

@@ -448,10 +448,10 @@ def test_map2bev_persistent_output_with_cells_that_are_no_multiple_of_16_bytes(p
     does not apply and the plugin keeps the whole-map fill (it used to clear the wrong addresses)."""
     P = pkg.plugin
     g = torch.Generator(device="cpu").manual_seed(3)
-    MP, C, GX, GY = 500, 36, 24, 20
+    MP, C, GX, GY = 400, 36, 24, 20
     op = P.add_map_2_bev_op(MP, C, GX, GY, split_output=1, persistent_output=True)
     ref = P.add_map_2_bev_op(MP, C, GX, GY, split_output=1)
-    for n in (400, 50, 480):
+    for n in (400, 50, 380):
         cells = torch.randperm(GX * GY, generator=g)[:MP]
         co = torch.zeros(1, MP, 4, dtype=torch.int32); co[0, :, 2] = (cells // GX).int(); co[0, :, 3] = (cells % GX).int()
         f, c_, k = torch.randn(1, MP, C, generator=g).to(DEV), co.to(DEV), torch.tensor([n], dtype=torch.int32, device=DEV)

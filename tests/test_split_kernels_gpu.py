@@ -241,7 +241,7 @@ def test_backbone_features_split_mode(pkg, oracle, frame):
 
 @pytest.mark.parametrize("frame", ["000000", "000004", "lidar180000", "lidar60000s3"])
 def test_boxes_split_mode(pkg, oracle, frame):
-    """the split-precision frame (what bench.py reports as `parity_mode`) against the fp32 oracle at the north-star tolerance"""
+    """the split-precision frame (bench.py's headline mode) against the fp32 oracle at the north-star tolerance, all nine columns"""
     from oracle import dense_ref as D
     from tests.parity import match_boxes
     from tests.test_pipeline_gpu import _frame_and_caps, _oracle_cfg, _run
@@ -353,6 +353,26 @@ def test_boxes_split_mode_eight_clouds_all_nine_columns(pkg, oracle):
         assert unmatched == 0 and worst < 1e-3, (seed, worst, unmatched)
         worst_all = max(worst_all, worst)
     assert worst_all < 5e-4, worst_all
+
+
+@pytest.mark.parametrize("frame,seed", [("000000", None), ("lidar", 0), ("lidar", 21)])
+def test_boxes_fp8_head_variant(pkg, oracle, frame, seed):
+    """DsvtPipeline(head_mx=True), the opt-in fast variant of the fp32-grade frame (round 4's headline; bench.py `fp8_head_mode`): the two correction
+    products of the head convolutions on the fp8 scaled MFMA.  Centres / sizes / scores stay ~1e-4 from the fp32 oracle (asserted at 3e-4); its yaw does
+    NOT hold 1e-3 on boxes with a short rot vector (seed 21: 1.7e-3) -- asserted only at 5e-3, which is why the variant is not the default."""
+    from oracle import dense_ref as D
+    from tests.test_pipeline_gpu import _frame_and_caps, _oracle_cfg, _run, _box_errors
+    w = pkg.synth.make_weights()
+    caps, pts, n = _frame_and_caps(pkg, frame if seed is None else f"lidar180000s{seed}")
+    pipe = pkg.pipeline.DsvtPipeline(w, caps=caps, device=DEV, linear_compute=pkg.plugin.COMPUTE_SPLIT, head_mx=True)
+    assert pipe.head_mx
+    boxes, cnt = _run(pkg, pipe, pts, n)
+    torch.cuda.synchronize()
+    eb, ec = _oracle_boxes(pkg, seed) if seed is not None else D.forward(pts, n, w, _oracle_cfg(caps))
+    err, frac = _box_errors(boxes[0].cpu().numpy(), int(cnt[0]), eb, ec)
+    print("fp8-head box errors per field", frame, seed, err, "matched", frac)
+    assert frac == 1.0 and int(cnt[0]) == ec
+    assert max(err[:6].max(), err[8]) < 3e-4 and err[6] < 5e-3, err
 
 
 # =====================================================================================================================
