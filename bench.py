@@ -203,6 +203,34 @@ def cpu_baseline(caps, frames, n_parallel_frames=32, whole_network=None, mode_ro
     return out
 
 
+def cpp_host_mode(pkg, weights, clouds, repeat=12):
+    """the reference's `-d` loop in C++ above the C ABI (dsvt-ai-trt_amd/host/dsvt_detect.cpp; nothing but include/dsvt_plugin.h + the HIP runtime), in the
+    headline precision, on the bench clouds written as .bin files: per frame the upload of n x 16 bytes from pinned memory + one HIP-graph launch + the
+    download of the final boxes, host clock around it (src/dsvt-ai-trt.cpp:1918-1956) -- one frame at a time and four frames per forward"""
+    import re, shutil, subprocess, tempfile
+    exe = os.path.join(G.PKG_DIR, "dsvt_detect")
+    if not os.path.exists(exe):
+        return {"error": "dsvt_detect is not built"}
+    tmp = tempfile.mkdtemp(prefix="dsvt_cpp_")
+    try:
+        wts = os.path.join(tmp, "dsvt.wts"); data = os.path.join(tmp, "data"); os.makedirs(data)
+        pkg.synth.write_wts(wts, weights)
+        for i, cl in enumerate(clouds):
+            cl.astype(np.float32).tofile(os.path.join(data, f"{i:06d}.bin"))
+        out = {"binary": "dsvt-ai-trt_amd/dsvt_detect --fp32 (default): f16x3 everywhere, the headline's arithmetic; boxes bit-identical to the Python host "
+                         "(tests/test_host_executor_gpu.py)", "clouds": len(clouds), "repeat": repeat}
+        for key, extra in (("one_frame_per_forward", []), ("four_frames_per_forward", ["--frames", "4"])):
+            o = os.path.join(tmp, "out_" + key); os.makedirs(o)
+            r = subprocess.run([exe, "--wts", wts, "--data", data, "--out", o, "--repeat", str(repeat)] + extra, capture_output=True, text=True, timeout=600)
+            m = re.search(r"([0-9.]+) ms per frame, ([0-9.]+) frames/s", r.stdout)
+            out[key] = ({"ms_per_frame": float(m.group(1)), "value": float(m.group(2)), "unit": "frames/s"} if (r.returncode == 0 and m)
+                        else {"error": (r.stdout + r.stderr)[-300:]})
+        out["note"] = "PCIe upload / download and the host's launch inside every figure; one forward in flight (the reference's loop is synchronous)"
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def spawn_ranks(n, share_gpu):
     """`python bench.py --gpus N` outside torchrun: launch the N ranks (one process per GPU) and relay rank 0's JSON line"""
     import socket
@@ -530,6 +558,7 @@ def main():
                                                              "the line is marked and is NOT a scaling number)")
     ap.add_argument("--repeats", type=int, default=0, help="repeats of the K-step timed loop (0 = max(3, min(15, ceil(300 / K))): a function of K only, so every rank runs the same number)")
     ap.add_argument("--dump-rows", default=None, help="rank 0 saves the gathered result rows [K * N, 4501] of the headline mode as .npy (tests: the gather against single-process rows)")
+    ap.add_argument("--no-cpp-host", action="store_true", help="skip cpp_host_mode (the C++ host dsvt_detect on the same clouds: writes an ~80 MB .wts file, ~25 s)")
     ap.add_argument("--oracle-clouds", type=int, default=8, help="how many 180k-point clouds the timed modes' boxes are checked on against the CPU oracle (~10 s of host time each on the GPU box; cpu_baseline.box_err_vs_oracle = the worst over them)")
     ap.add_argument("--no-whole-network-cpu", action="store_true", help="cpu_baseline skips the whole network on the CPU oracle (~10 s; also drops box_err_vs_oracle)")
     args = ap.parse_args()
@@ -821,6 +850,8 @@ def main():
         line["targets"]["both_at_one_operating_point"] = (
             "latency_point" if sf and sf["value"] >= 200.0 and sf["p50_ms"] <= 5.0 else
             "throughput_point" if hl_ok and line["p50_ms"] <= 5.0 else "neither: throughput and latency bars are met at different operating points" if (hl_ok and sf and sf["p50_ms"] <= 5.0) else "neither")
+        if not args.no_cpp_host and not args.host_input and args.dtype == "split":
+            line["cpp_host_mode"] = cpp_host_mode(pkg, weights, clouds[:FRAME_POOL])
         if not args.no_cpu_baseline:
             # the FilterBoxByScore rows of the pooled frames as the GPU produced them (the reference's D2H payload)
             frames = []
