@@ -439,9 +439,10 @@ struct Engine {
         if (!plane) plane = cout;
         const int up2 = shuffle * shuffle;
         const bool wide = mx() && stride == 1 && ((k == 3 && cout > 32 && up2 == 1) || (k == 1 && (up2 * cout) % 128 == 0));
-        const int splitOut = f32out ? 0 : (mx() ? (resOnly ? 4 : lo ? 2 : 3) : 1);
+        // three fp16 products (default): [hi | lo | -] out (4), the third plane's phases of the input alias plane 0 (split_input 1) -- pipeline.py conv()
+        const int splitOut = f32out ? 0 : (mx() ? (resOnly ? 4 : lo ? 2 : 3) : 4);
         return convOp(wide ? rows : splitRows(rows, k * k, cin), bias, Hh, 3 * cin, cout, k, stride, k / 2, shuffle, relu, res, f32out ? plane : 3 * plane, ooff, f32out,
-                      splitOut, res ? 1 : 0, mx() ? (wide ? 2 : 1) : 0);
+                      splitOut, res ? 1 : 0, mx() ? (wide ? 2 : 1) : 1);
     }
     Op convBnSplit(const WeightMap& w, const std::string& cv, const std::string& bn, int Hh, int cin, int cout, int k, int stride, bool relu, bool res,
                    bool lo = true, bool resOnly = false) {

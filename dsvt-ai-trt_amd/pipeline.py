@@ -330,6 +330,9 @@ class DsvtPipeline:
         mx = self.head_mx
 
         def conv(name, rows, bias, H, cin, cout, k, stride, relu, res=False, out_f32=False, plane=None, lo=True, res_lo=True, res_only=False, **kw):
+            # three fp16 products everywhere (head_mx off, the default): every layer reads its input as [hi | lo | (plane 0 again)] (split_input = 1: the
+            # third plane's phases alias plane 0 -- an L2 hit instead of a third HBM plane) and writes [hi | lo | -] (split_output = 4): a third of the
+            # activation bytes of round 3's [hi | lo | hi] triples never moves, and the block-diagonal 320 -> 18 output layer takes the grouped kernel
             # res_only (head_mx only): no consumer reads the tensor's third plane -- it is only ever a residual, or the input of a three-product layer that
             # takes hi and lo (and hi again from plane 0) --: not written (split_output = 4)
             # lo = False (head_mx only): every consumer of this tensor is a [hi | x8] layer and it is nobody's residual -- its lo plane is not written
@@ -345,7 +348,7 @@ class DsvtPipeline:
             lo = lo or bool(self.head_mx_exclude)            # (an excluded layer reads the lo plane of its input: every tensor keeps it then)
             ops[name] = P.add_conv2d_op(np.asarray(rows, np.float32) if wide else sw(rows, k * k, cin), bias, H, H, 3 * cin, cout, k, stride, k // 2,
                                         relu=relu, has_residual=res, split_residual=(1 if (res_lo or not mx) else 2) if res else 0, out_f32=out_f32,
-                                        split_output=0 if out_f32 else ((4 if res_only and not self.head_mx_exclude else 2 if lo else 3) if mx else 1), split_input=(2 if wide else 1) if mx else 0,
+                                        split_output=0 if out_f32 else ((4 if res_only and not self.head_mx_exclude else 2 if lo else 3) if mx else 4), split_input=(2 if wide else 1) if mx else 1,
                                         out_channel_stride=plane if out_f32 else 3 * plane, **kw)
             ops[name].split_in = True            # (bench.py's flop / byte accounting: 3 Cin operand channels carry Cin real ones)
             ops[name].mx_in = bool(wide)
