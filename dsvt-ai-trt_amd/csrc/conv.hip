@@ -879,7 +879,10 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     const int NSTEP = NPM * 9, NSA = (NSTEP + SPS - 1) / SPS;     // (SPS = 4: the last fp16 slab may be partial; the packed weights end in a zero slab)
     const int NSLAB = NSA + (MX ? (5 * NPM + XPS - 1) / XPS : 0);
     const int NCT = a.CoutRows <= 64 ? 4 : (a.CoutRows + 127) / 128 * 8;      // 16-channel tiles per k-step of the packed weights
-
+    // (Round 5 built a "split-native" phase walk for the three-product head -- per 32 channels q the phases (hi_q, w_hi), (hi_q AGAIN, w_lo) reading the halo the
+    // first one left in LDS, (lo_q, w_hi): a third of the halo requests gone, same weights / MFMAs / fragment reads -- correct (tests pass) and SLOWER:
+    // 11.15 vs 10.58 ms of convolutions per four-frame forward, 276 vs 285 frames/s.  Like round 4's re-ordered head-output kernel: a phase without halo
+    // requests does not run faster, the bytes of the aliased plane -- an L2 hit -- were not what the kernel waits for.  The plain plane-order walk stays.)
     const int perImg = nitems / a.nb;                             // items of one image (items walk image after image)
     auto decode = [&](int it, int& yy, int& xx, int& ch, int& bb) {
         bb = it / perImg; it -= bb * perImg;
@@ -1925,6 +1928,123 @@ conv1x1_resident_mx_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT,
     }
 }
 
+// The 1 x 1 stride-1 layers of the fp32-grade stage on THREE fp16 products (round 5: the default head), same scheme: one 128-column stage of w_hi AND w_lo
+// resident per CU (C / 2 KB), the waves walk 16-pixel tiles with their hi and lo rows straight from global (plane 0 and plane 1 of the [hi | lo | -] triple:
+// the third plane is never read), per k-step 8 w_hi fragments -> 16 MFMAs (w_hi x hi, w_hi x lo), then 8 w_lo fragments -> 8 MFMAs (w_lo x hi).  The halo
+// kernel walked 3 C / 64 phases per 8 x 32-pixel x 128-column item -- the hi plane through LDS twice, 8.4 C bytes of weights per column for every item --:
+// 318-418 us per four-frame launch on these byte-bound layers (1.45 ms for the four of them).  Weights come from the halo kernel's fragment image of the
+// host's [w_hi | w_hi | w_lo] rows: k-step q of plane 0 = w_hi, k-step 2 C / 32 + q = w_lo.  Summation order per k-step (hi w_hi, lo w_hi, hi w_lo) instead of
+// per plane: 2^-22-grade either way (tests/test_conv_gpu.py::test_split_precision_1x1_resident).
+template <int KQ, int NH>
+__global__ void __launch_bounds__(64 * C1_NW, 1)
+conv1x1_resident_split_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int NCT, int ngroup)
+{
+    constexpr int CTG = 8, KQT = KQ * NH;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KQT * CTG * 1024 + 1024];     // w_hi [k-step][tile] | w_lo [k-step][tile] | bias (512 B)
+    constexpr int LO_OFF = KQT * CTG * 1024, BIAS_OFF = 2 * KQT * CTG * 1024;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+    // workgroup -> (column group, row stream): the ngroup workgroups of a stream on one XCD (workgroups go to the XCDs round-robin)
+    const int nx = (int)gridDim.x / 8, xcd = (int)blockIdx.x % 8, sl = (int)blockIdx.x / 8;        // (the grid is a multiple of 8 ngroup)
+    const int type = sl % ngroup, j = xcd * (nx / ngroup) + sl / ngroup, nj = (int)gridDim.x / ngroup;
+    for (int u = wave; u < 2 * KQT * CTG; u += C1_NW) {               // rows [q][NCT] of plane 0 (w_hi) and of plane 2 (w_lo) -> [q][CTG]
+        const int pl = u / (KQT * CTG), v = u - pl * KQT * CTG, q = v / CTG, t = v - q * CTG;
+        __builtin_amdgcn_global_load_lds((glds_src_t)(Wp + (((size_t)(pl * 2 * KQT + q) * NCT + type * CTG + t) * 64 + lane) * 8), (glds_dst_t)(smem + u * 1024), 16, 0, 0);
+    }
+    const int n0 = type * 128, sub = n0 / a.Cout, dy = sub / a.up, dx = sub - dy * a.up, cbase = n0 - sub * a.Cout;
+    if (wave == 0) {                                                 // the stage's bias (128 floats)
+        const void* src = (a.bias && lane < 32) ? static_cast<const void*>(a.bias + cbase + lane * 4) : static_cast<const void*>(Wp);
+        __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + BIAS_OFF), 16, 0, 0);
+    }
+    const int HW = a.Ho * a.Wo, NPIX = a.nb * HW, ntile = (NPIX + 15) / 16, step = nj * C1_NW;      // OUTPUT pixels before the pixel shuffle = input pixels
+    const float invHW = 1.0f / (float)HW, invW = 1.0f / (float)a.Wo;
+    auto split = [&](int pc, int& b, int& y, int& xq) {
+        b = (int)(((float)pc + 0.5f) * invHW); b -= (b * HW > pc); b += ((b + 1) * HW <= pc);
+        const int rem = pc - b * HW;
+        y = (int)(((float)rem + 0.5f) * invW); y -= (y * a.Wo > rem); y += ((y + 1) * a.Wo <= rem);
+        xq = rem - y * a.Wo;
+    };
+    const int C = a.Cin / 3;
+    const int tt0 = j * C1_NW + wave;
+    const int nunit = tt0 < ntile ? ((ntile - tt0 + step - 1) / step) * NH : 0;      // (tile, pass) units of this wave: unit v = tile tt0 + (v / NH) step, pass v % NH
+    struct Rows { half8 h[KQ]; half8 l[KQ]; };
+    auto loadRows = [&](int v, Rows& w) {
+        v = v < nunit ? v : nunit - 1;                               // (past the end: the last unit again, no branch around a load)
+        const int t = tt0 + (v / NH) * step, hp = v % NH;
+        const int p = t * 16 + r, pc = p < NPIX ? p : NPIX - 1;
+        const _Float16* src = a.in + (size_t)pc * a.Cin + hp * KQ * 32 + g * 8;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) { w.h[q] = *reinterpret_cast<const half8*>(src + q * 32); w.l[q] = *reinterpret_cast<const half8*>(src + C + q * 32); }
+    };
+    const int Wout = a.Wo * a.up;
+    floatx4 acc[CTG];
+    auto unit = [&](int v, const Rows& w) {
+        const int t = tt0 + (v / NH) * step, hp = NH == 1 ? 0 : v % NH;
+        // (LDS addresses from an opaque copy of the lane offset: see conv1x1_resident_mx_kernel)
+        int lo16 = lane * 16, g16 = g * 16;
+        asm volatile("" : "+v"(lo16), "+v"(g16));
+        const unsigned char* slot = smem + lo16;
+        if (hp == 0) {
+#pragma unroll
+            for (int u = 0; u < CTG; ++u) {
+                const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + BIAS_OFF + u * 64 + g16);
+                acc[u] = a.bias ? b4 : floatx4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        // 2 KQ half-steps: even = the eight w_hi fragments of k-step s (sixteen MFMAs: x hi, x lo), odd = the eight w_lo fragments (eight MFMAs: x hi);
+        // the reads of half-step i + 1 are issued before the MFMAs of half-step i
+        constexpr int NHS = 2 * KQ;
+        intx4 fb[2][8];
+        auto loadHalf = [&](int i, intx4 (&f)[8]) {
+            const int s_ = i >> 1, off = (i & 1) ? LO_OFF : 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) f[u] = *reinterpret_cast<const intx4*>(slot + off + ((hp * KQ + s_) * CTG + u) * 1024);
+        };
+        loadHalf(0, fb[0]);
+#pragma unroll
+        for (int i = 0; i < NHS; ++i) {
+            if (i + 1 < NHS) loadHalf(i + 1, fb[(i + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const intx4 (&f)[8] = fb[i & 1];
+            const int s_ = i >> 1;
+            if ((i & 1) == 0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, f[u]), w.h[s_], acc[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, f[u]), w.l[s_], acc[u], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, f[u]), w.h[s_], acc[u], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (hp == NH - 1) {
+            const int p = t * 16 + r;
+            const bool valid = p < NPIX;
+            int b, y, xq;
+            split(valid ? p : 0, b, y, xq);
+            const size_t opix = (size_t)((b * a.Ho + y) * a.up + dy) * Wout + (xq * a.up + dx);
+#pragma unroll
+            for (int u = 0; u < CTG; u += 2) {
+                convStoreWide<false, true>(a, acc[u], acc[u + 1], valid, opix, cbase + u * 16, g);
+                __builtin_amdgcn_sched_barrier(0);                      // (one pair of tiles at a time)
+            }
+        }
+    };
+    Rows xa;
+    if (nunit > 0) loadRows(0, xa);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the weights (and the first rows) have landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    Rows xb;                                                          // (two sets of rows in flight: 2 x 8 KQ registers)
+    for (int v = 0; v < nunit; v += 2) {
+        loadRows(v + 1, xb);
+        unit(v, xa);
+        if (v + 1 >= nunit) break;
+        loadRows(v + 2, xa);
+        unit(v + 1, xb);
+    }
+}
+
 static int numCUs();
 static bool conv1x1ResidentShape(int KH, int KW, int stride, int pad, int Cin, int Cout, int rows) {
     static int on = -1;            // DSVT_CONV_1X1_RESIDENT=0: the halo / gather kernels for the 1 x 1 layers too
@@ -2002,6 +2122,19 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
         const int nit = cdiv(a.Ho, 8) * tilesX * nchunk * NBI;
         hipLaunchKernelGGL((conv_halo_kernel<8, 1, 8, 2, true, true>), dim3(nit < ncu ? nit : ncu), dim3(512), 0, stream, a, Wp, zeros, tilesX, nit, nchunk, dbg);
         return lastError();
+    }
+    if (!a.xscale && a.alias3 && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0) {      // 1 x 1 stride-1 layers on three fp16 products over [hi | lo | -]
+        static int res1s = -1;     // DSVT_CONV_1X1_RESIDENT=0: the halo kernel
+        if (res1s < 0) res1s = ablateEnv("DSVT_CONV_1X1_RESIDENT", 1);
+        const int C = a.Cin / 3, ngroup = a.CoutRows / 128;
+        if (res1s && ctWide == 8 && a.Cout == 128 && a.CoutRows % 128 == 0 && (C == 128 || C == 192 || C == 256) && a.wide && !a.res && !a.out_f32 && a.split_out &&
+            (ngroup == 1 || ngroup == 4 || ngroup == 16) && ncu % (8 * ngroup) == 0) {
+            const int NCT = cdiv(a.CoutRows, CNB) * 8;
+            if (C == 128) hipLaunchKernelGGL((conv1x1_resident_split_kernel<4, 1>), dim3(ncu), dim3(64 * C1_NW), 0, stream, a, Wp, NCT, ngroup);
+            else if (C == 192) hipLaunchKernelGGL((conv1x1_resident_split_kernel<2, 3>), dim3(ncu), dim3(64 * C1_NW), 0, stream, a, Wp, NCT, ngroup);
+            else hipLaunchKernelGGL((conv1x1_resident_split_kernel<4, 2>), dim3(ncu), dim3(64 * C1_NW), 0, stream, a, Wp, NCT, ngroup);
+            return lastError();
+        }
     }
     if (a.xscale) {                                             // split input [hi | lo | x8] on the fp16 + fp8 K loop (packMX image); same tile choices as below
         if (a.KH != 3 || ctWide < 4) return -3;

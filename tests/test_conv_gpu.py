@@ -256,3 +256,71 @@ def test_block_diagonal_narrow_conv_on_the_grouped_kernel(pkg, H, W, B):
     assert torch.equal(got, ref_dense), float((got - ref_dense).abs().max())
     ref = _ref(x, w.half().to(DEV), b.to(DEV), 1, 1)
     assert (got.permute(0, 3, 1, 2) - ref).abs().max().item() < 1e-3 * ref.abs().max().item()
+
+
+def _hi_lo_junk(x):
+    """x [B,H,W,C] fp32 (CPU) -> fp16 [B,H,W,3C] = [hi | lo | NaN]: the third plane must never be read (split_input = 1 aliases it to plane 0)"""
+    hi = x.half(); lo = (x - hi.float()).half()
+    return torch.cat([hi, lo, torch.full_like(hi, float("nan"))], dim=-1).contiguous()
+
+
+@pytest.mark.parametrize("H,W,cin,cout,k,stride,up,res,relu,B", [
+    (52, 47, 192, 128, 1, 1, 1, False, False, 1),     # the 1 x 1 shortcut of the first block: conv1x1_resident_split_kernel<2, 3>
+    (468, 468, 128, 128, 1, 1, 1, False, True, 1),    # first deblock at full size: <4, 1>
+    (26, 23, 128, 128, 1, 1, 2, False, True, 2),      # second deblock: 2 x 2 pixel shuffle, two images
+    (13, 11, 256, 128, 1, 1, 4, False, True, 2),      # third deblock: <4, 2>, sixteen column groups
+    (40, 37, 320, 128, 1, 1, 1, False, True, 1),      # a width the resident kernel does not take: the halo kernel
+    (468, 468, 128, 128, 3, 1, 1, True, True, 1),     # 16-row x 128-channel items, residual
+    (150, 140, 192, 128, 3, 1, 1, False, True, 2),    # six channel groups, two images
+    (61, 45, 256, 256, 3, 1, 1, True, True, 1),       # 8-row x 64-channel items (four-step slabs)
+    (234, 234, 128, 128, 3, 1, 1, False, True, 1),    # 16-row x 64-channel items
+    (150, 140, 384, 64, 3, 1, 1, False, True, 1),     # shared head convolution (64 output channels)
+    (150, 140, 64, 320, 3, 1, 1, False, True, 1),     # head stems (two channel groups: the shortest walk)
+    (52, 47, 128, 256, 3, 2, 1, False, True, 1),      # strided entry (gather kernel)
+])
+def test_three_product_layers_over_hi_lo_planes(pkg, H, W, cin, cout, k, stride, up, res, relu, B):
+    """The dense stage of the default (three-product) head as pipeline.py wires it since round 5: input [hi | lo | -] with split_input = 1 (the third
+    plane's phases alias plane 0; here it holds NaNs), output [hi | lo | -] with split_output = 4 (third plane untouched), residual hi + lo -- against a
+    float64 convolution of the unrounded operands (5e-6 of scale: fp32 summation-order level; src/dsvt-ai-trt.cpp:149-246 in fp32).  Covers
+    conv_wide_kernel / conv_halo_kernel / conv_f16_kernel with the aliased third plane and conv1x1_resident_split_kernel."""
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(H * 1000 + cin + cout + k + up)
+    x = torch.randn(B, H, W, cin, generator=g) * 3.0
+    x = torch.relu(x) if (H + cin) % 2 else x
+    if up > 1:
+        w = torch.randn(cin, cout, up, up, generator=g) / np.sqrt(cin)
+        rows = P.deconv_weight_rows(w.numpy())
+        ref = F.conv_transpose2d(x.permute(0, 3, 1, 2).double(), w.double(), None, stride=up)
+    else:
+        w = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+        rows = P.conv_weight_rows(w.numpy())
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, stride, k // 2)
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = ref + b.double()[None, :, None, None]
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    r = torch.randn(B, Ho, Wo, cout, generator=g) if res else None
+    if res:
+        r3 = _hi_lo_junk(r)
+        ref = ref + (r3[..., :cout].double() + r3[..., cout:2 * cout].double()).permute(0, 3, 1, 2)
+    if relu:
+        ref = torch.relu(ref)
+    plane, off = (384, 128) if up > 1 else (cout, 0)
+    op = P.add_conv2d_op(P.split_weight_rows(rows, k * k, cin), b.numpy(), H, W, 3 * cin, cout, k, stride, k // 2, pixel_shuffle=up, relu=relu, has_residual=res,
+                         split_residual=1 if res else 0, split_input=1, split_output=4, out_channel_stride=3 * plane, out_channel_offset=off)
+    out = torch.full((B, Ho, Wo, 3 * plane), 7.0, dtype=torch.float16, device=DEV)
+    args = [_hi_lo_junk(x).to(DEV)] + ([r3.to(DEV)] if res else [])
+    op(*args, out=[out])
+    torch.cuda.synchronize()
+    o = out.cpu()
+    got = (o[..., off:off + cout].double() + o[..., plane + off:plane + off + cout].double()).permute(0, 3, 1, 2)
+    assert not torch.isnan(got).any()
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item() / scale
+    print(f"three-product {H}x{W} {cin}->{cout} k{k} s{stride} up{up}: {err:.2e} of scale")
+    assert err < 5e-6, err
+    untouched = torch.ones(3 * plane, dtype=torch.bool)
+    untouched[off:off + cout] = False; untouched[plane + off:plane + off + cout] = False
+    assert (o[..., untouched] == 7.0).all()                       # the third plane (and the neighbours of a concat slice) are left alone
+    again = torch.full_like(out, 7.0)
+    op(*args, out=[again]); torch.cuda.synchronize()
+    assert torch.equal(again.view(torch.int16), out.view(torch.int16))
