@@ -27,8 +27,9 @@ Three precision modes are timed by a default run (N = 1):
   targets       which operating point meets which bar (>= 200 frames/s; <= 5 ms p50 per frame), and whether one point meets both.
 
 Timing: K steps per repeat, every repeat between two torch.cuda.synchronize() on every rank; R = max(3, min(15, ceil(300 / K))) repeats (a function
-of K only).  Collectives: one barrier before the first repeat, the result gather inside the LAST repeat (`gather_ms`), one barrier after it, ONE
-all-reduce (MAX) of the R per-repeat times; `value` = total frames / median over the repeats of the max-over-ranks time -- the same protocol for
+of K only).  Collectives: one all-gather of the ranks' device identities at start-up (n_gpus = DISTINCT devices, checked), one barrier before the first
+repeat, the result gather inside the LAST repeat (`gather_ms`; rank 0 checks its own rows in the gathered tensor bit for bit), one barrier after it, ONE
+all-gather of the R per-repeat times (`repeat_values_per_rank`); `value` = total frames / median over the repeats of the max-over-ranks time -- the same protocol for
 every N, so N = 8 / N = 1 compares like with like.  The roofline sample (one eager forward with HIP events around every launch) is a pre-pass
 outside every timed region.
 
@@ -356,7 +357,7 @@ class ModeRun:
 
     def measure(self, results, K):
         """R repeats of the K-step loop, the same R on every rank (it depends on K only).  Collectives: one barrier before the first repeat, the
-        result gather inside the LAST repeat, one barrier after it, then ONE all-reduce (MAX) of the R-vector of per-repeat times -- two
+        result gather inside the LAST repeat, one barrier after it, then ONE all-gather of the R-vector of per-repeat times (the maximum over the ranks is taken on the host) -- two
         collective rounds however many repeats, because on this stack (ROCm 7.2, RCCL 2.26 of torch 2.10) a third barrier / gather / barrier /
         all-reduce round interleaved with HIP-graph replays ends in "Memory access fault ... write access to a read-only page" (DESIGN 5).
         Every repeat is bracketed by torch.cuda.synchronize() on both sides; value = median over the repeats of total frames / max-over-ranks time."""
@@ -370,7 +371,9 @@ class ModeRun:
             if last:
                 gathered, gather_ms = g, gm
         self.par.barrier(); torch.cuda.synchronize()
-        dts = self.par.max_over_ranks_vec(dts, self.dev)
+        per_rank = self.par.all_ranks_vec(dts, self.dev)                 # ONE all-gather: [world][R]
+        dts = [max(pr[i] for pr in per_rank) for i in range(len(dts))]
+        self.per_rank_dts = per_rank
         return dts, fms, gathered, gather_ms
 
 
@@ -592,6 +595,14 @@ def main():
     par = pkg.parallel
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
+    # n_gpus must be the number of DISTINCT physical devices that took part: every rank's device identity (UUID / PCI address) meets in one
+    # all-gather BEFORE any HIP graph exists; a job whose ranks doubled up on a device (a wrong HIP_VISIBLE_DEVICES / LOCAL_RANK mapping) is refused
+    # unless it is the declared dry run (--share-gpu)
+    dev_ids = par.gather_device_identities(dev)
+    n_distinct = len({d for d, _ in dev_ids})
+    if n_distinct != world and not shared:
+        raise SystemExit(f"bench.py: {world} ranks on {n_distinct} distinct device(s) {sorted({d for d, _ in dev_ids})}: n_gpus would not be the GPUs that ran "
+                         "(use --share-gpu for a declared dry run)")
 
     FB = max(1, args.batch) if args.dtype in ("f16", "split") else 1          # (the exact-fp32 cross-check mode has no multi-frame path)
     if args.host_input:
@@ -643,8 +654,13 @@ def main():
         if rank != 0:
             return None
         total = K * world
-        if world > 1:
+        own_ok = None
+        if world > 1 or args.rccl_single:
             assert gathered is not None and gathered.shape[0] == total
+            # the gather, checked where it can be: rank 0's own shard sits in the gathered tensor bit for bit, in global frame order f -> rank f mod N
+            own_ok = par.own_rows_match(gathered, results, total, rank, world)
+            if not own_ok:
+                raise SystemExit("bench.py: the gathered result rows of rank 0's own shard differ from its local rows")
         if args.dump_rows and mode == args.dtype:
             np.save(args.dump_rows, gathered.cpu().numpy())
         med = float(np.median(dts))
@@ -652,7 +668,8 @@ def main():
                    repeat_values=[round(total / d, 1) for d in dts],
                    gather_ms=None if gather_ms is None or not run.collective else round(gather_ms, 3),
                    value_of_the_repeat_with_the_gather=round(total / dts[-1], 3),
-                   graph_replay_equals_eager=run.replay_equals_eager, frame0=counts[0])
+                   graph_replay_equals_eager=run.replay_equals_eager, frame0=counts[0], gather_own_rows_bit_identical=own_ok,
+                   repeat_values_per_rank=[[round(K / d, 1) for d in pr] for pr in getattr(run, "per_rank_dts", [])] if world > 1 else None)
         out["_run"] = run
         if prof is not None and sampled:
             npl = sum(int(v) for v in pool[0][1].cpu())
@@ -686,6 +703,7 @@ def main():
             "data": "synthetic" + (" (uploaded from pinned host memory inside the timed region)" if args.host_input else ""),
             "repeats": head["repeats"], "repeat_values": head["repeat_values"], "gather_ms": head["gather_ms"],
             "value_of_the_repeat_with_the_gather": head["value_of_the_repeat_with_the_gather"],
+            "repeat_values_per_rank": head["repeat_values_per_rank"],
             "config": {"workload": f"BASELINE configs[2]: lidar_like({args.points}, seed) Waymo-shaped cloud, 0.32 m pillars, "
                                    "468x468 BEV, full 4-block DSVT pillar backbone + BEV ResNet + CenterHead + top-K decode + "
                                    "FilterBoxByScore" + ("" if args.no_nms else " + rotated NMS (final boxes)") + "; seeded random weights (dsvt.wts is not shipped)",
@@ -696,10 +714,12 @@ def main():
                                          "rccl gather" if world > 1 else "rccl gather (communicator of size 1)" if args.rccl_single
                                          else "none (single process)"),
                        "graph_replay_equals_eager": head["graph_replay_equals_eager"],
+                       "gather_own_rows_bit_identical": head["gather_own_rows_bit_identical"],
+                       "devices": {"ranks": world, "distinct": n_distinct, "identities_md5": [d for d, _ in dev_ids]},
                        "launch": "hip-graph replay per forward" if not args.no_graph else "host launch per op",
                        "frames_in_flight": run.NS * FB, "frames_per_forward": FB,
                        "timing": f"K = {K} steps per repeat, each repeat between two torch.cuda.synchronize() on every rank; one barrier before the first repeat, "
-                                 "the result gather inside the LAST repeat (gather_ms), one barrier after it, ONE all-reduce (MAX) of the per-repeat times; "
+                                 "the result gather inside the LAST repeat (gather_ms), one barrier after it, ONE all-gather of the per-repeat times (max over ranks on the host); "
                                  "value = total frames / median over repeats of the max-over-ranks time; the roofline sample is a pre-pass outside every timed region",
                        "caps": dict(points=caps.N, pillars=caps.P, windows=caps.W, sets=caps.S, overflow_free=caps.overflow_free()),
                        "frame0": head["frame0"]},
@@ -871,7 +891,13 @@ def main():
     elif rank == 0:
         line["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(line))
+        # the JSON line is the LAST thing on stdout: whatever native libraries left in C stdio buffers (RCCL's version banner) goes out first
+        try:
+            import ctypes
+            sys.stdout.flush(); ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

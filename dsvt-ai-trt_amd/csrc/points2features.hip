@@ -40,6 +40,10 @@ struct P2FParams {
     float vx, vy, vz;
     int gx, gy, gz;
     int frames;       // >= 1: the points tensor holds `frames` slabs of max_points_num rows with one count each (see the plugin class)
+    int pid_slots;    // optional field "point_id_slots" (default max_num_points_per_voxel = the reference's table): how many slots of a pillar's row of the
+                      // [P, T] point-id table (output 1) are written.  The rows of a pillar are consecutive, so a consumer that walks them needs slot 0 (the
+                      // pillar's first row) and the count: the fused pillar feature net reads nothing else, and the other 47 slots were 26 MB of stores per
+                      // four-frame launch that no kernel of the frame pipeline ever read (round 4 PMC: 155 MB of p2f_pillar's 198 MB)
 };
 
 constexpr uint32_t kNone = 0xffffffffu;
@@ -224,7 +228,7 @@ __device__ __forceinline__ void p2fPillarWave(uint32_t pid, uint32_t seg, uint32
     }
     const int ni = (int)kept;
     cx = cx / ni; cy = cy / ni; cz = cz / ni;
-    if (lane < (int)T) pidx[(size_t)pid * T + lane] = lane < (int)kept ? ptoff + lane : 0u;   // :829-830
+    if (lane < p.pid_slots) pidx[(size_t)pid * T + lane] = lane < (int)kept ? ptoff + lane : 0u;   // :829-830 (pid_slots = T unless the caller asked for fewer)
     if (lane < (int)kept) p2fWriteFeat(feat + (size_t)(ptoff + lane) * p.feature_num, q, cx, cy, cz, p);
 }
 
@@ -540,7 +544,7 @@ p2f_pillar(P2FParams p, int dbg, const uint32_t* __restrict__ pillar_num, const 
     const int ni = (int)kept;
     cx = cx / ni; cy = cy / ni; cz = cz / ni;
     if (!P2F_DBG(128))
-    for (uint32_t e = (uint32_t)sl; e < T; e += 16u) pidx[(size_t)pid * T + e] = e < kept ? ptoff + e : 0u;   // :829-830
+    for (uint32_t e = (uint32_t)sl; e < (uint32_t)p.pid_slots; e += 16u) pidx[(size_t)pid * T + e] = e < kept ? ptoff + e : 0u;   // :829-830
     if (sl < (int)kept && !P2F_DBG(64)) p2fWriteFeat(feat + (size_t)(ptoff + sl) * p.feature_num, q, cx, cy, cz, p);
     if (P2F_DBG(64) && cx + q.x == 123.f) feat[0] = cx;       // (keeps the arithmetic alive)
 }
@@ -650,8 +654,9 @@ public:
         }
         return lastError();
     }
-    // the reference's 18 words (:1033-1036); one more only for a multi-frame plugin
-    size_t serializationSize() const override { return 9 * sizeof(float) + (p_.frames > 1 ? 10 : 9) * sizeof(int); }
+    // the reference's 18 words (:1033-1036); trailing ints [frames [point_id_slots]], each present when it or a later one is not the default
+    int nTrail() const { return p_.pid_slots != p_.max_num_points_per_voxel ? 2 : p_.frames > 1 ? 1 : 0; }
+    size_t serializationSize() const override { return 9 * sizeof(float) + (9 + nTrail()) * sizeof(int); }
     void serialize(void* buffer) const override {                                                  // :1038-1060
         char* d = static_cast<char*>(buffer);
         wr<int>(d, p_.max_points_num); wr<int>(d, p_.max_points_num_voxel_filter); wr<int>(d, p_.max_pillars_num);
@@ -659,7 +664,8 @@ public:
         wr<float>(d, p_.min_x); wr<float>(d, p_.max_x); wr<float>(d, p_.min_y); wr<float>(d, p_.max_y);
         wr<float>(d, p_.min_z); wr<float>(d, p_.max_z); wr<float>(d, p_.vx); wr<float>(d, p_.vy); wr<float>(d, p_.vz);
         wr<int>(d, p_.gx); wr<int>(d, p_.gy); wr<int>(d, p_.gz);
-        if (p_.frames > 1) wr<int>(d, p_.frames);
+        if (nTrail() >= 1) wr<int>(d, p_.frames);
+        if (nTrail() >= 2) wr<int>(d, p_.pid_slots);
     }
     Plugin* clone() const override { return new Points2FeaturesPlugin(p_); }
 };
@@ -671,6 +677,7 @@ static bool validP2F(const P2FParams& p) {
     if (p.max_num_points_per_voxel <= 0 || p.max_num_points_per_voxel > kWave) return no("max_num_points_per_voxel must be in 1 .. 64 (one wavefront lane per kept point)");
     if (p.gx <= 0 || p.gy <= 0 || p.gz <= 0 || p.frames < 1) return no("grid_size and frames must be positive");
     if (!(p.vx > 0 && p.vy > 0 && p.vz > 0)) return no("voxel_size must be positive");
+    if (p.pid_slots < 1 || p.pid_slots > p.max_num_points_per_voxel) return no("point_id_slots must be in 1 .. max_num_points_per_voxel");
     if ((long)p.gx * p.gy * p.gz * p.frames >= (1l << 30)) return no("grid cells x frames must stay below 2^30 (the look-back word holds a 30-bit pillar count)");
     if (((long)p.max_points_num + kBlk) * p.frames >= (1l << 31)) return no("(max_points_num + 2048) x frames must stay below 2^31 (32-bit row indices and slot numbers)");
     return true;
@@ -691,10 +698,11 @@ static Plugin* p2fCreate(const DsvtPluginFieldCollection* fc) {                 
     p.min_x = r[0]; p.max_x = r[3]; p.min_y = r[1]; p.max_y = r[4]; p.min_z = r[2]; p.max_z = r[5];
     p.vx = v[0]; p.vy = v[1]; p.vz = v[2]; p.gx = g[0]; p.gy = g[1]; p.gz = g[2];
     p.frames = fieldInt(fc, "frames", 1);       // not a reference field: see the class comment
+    p.pid_slots = fieldInt(fc, "point_id_slots", p.max_num_points_per_voxel);      // not a reference field: see P2FParams
     return validP2F(p) ? new Points2FeaturesPlugin(p) : nullptr;
 }
 static Plugin* p2fDeserialize(const void* data, size_t len) {                                      // ctor :60-84
-    const int extra = trailingInts(len, 9 * sizeof(float) + 9 * sizeof(int), 1);
+    const int extra = trailingInts(len, 9 * sizeof(float) + 9 * sizeof(int), 2);
     if (extra < 0) return nullptr;
     const char* d = static_cast<const char*>(data);
     P2FParams p{};
@@ -704,6 +712,7 @@ static Plugin* p2fDeserialize(const void* data, size_t len) {                   
     p.min_z = rd<float>(d); p.max_z = rd<float>(d); p.vx = rd<float>(d); p.vy = rd<float>(d); p.vz = rd<float>(d);
     p.gx = rd<int>(d); p.gy = rd<int>(d); p.gz = rd<int>(d);
     p.frames = extra >= 1 ? rd<int>(d) : 1;
+    p.pid_slots = extra >= 2 ? rd<int>(d) : p.max_num_points_per_voxel;
     return validP2F(p) ? new Points2FeaturesPlugin(p) : nullptr;
 }
 

@@ -245,6 +245,7 @@ struct Engine {
                        .i("feature_num", 10).i("max_num_points_per_voxel", 48).fl("point_cloud_range", Vec{X_MIN, Y_MIN, Z_MIN, X_MAX, Y_MAX, Z_MAX})
                        .fl("voxel_size", Vec{VX, VY, VZ}).i("grid_size", {GX, GY, GZ});
             if (frames != 1) f.i("frames", frames);
+            f.i("point_id_slots", 1);                                // (the fused pillar feature net reads slot 0 of the [P, 48] table: pipeline.py)
             voxelizer = Op("Points2FeaturesPlugin", f, "voxelGeneratorlayer", false);
         }
         {   // PFN: FC (no bias) + BN1d(1e-5) + ReLU twice, TorchScatterMax twice (:565-589), BN folded

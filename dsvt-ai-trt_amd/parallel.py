@@ -99,3 +99,52 @@ def max_over_ranks_vec(values, device):
     t = torch.tensor(list(values), dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return [float(v) for v in t]
+
+
+def all_ranks_vec(values, device):
+    """every rank's list of floats on every rank: ONE all-gather (bench.py: the per-repeat times of a run -- the maximum over the ranks is the job's
+    time of a repeat, the per-rank values say which rank was slow).  Returns [world][len(values)]."""
+    if not dist.is_initialized():
+        return [list(values)]
+    dev = "cpu" if dist.get_backend() == "gloo" else device
+    t = torch.tensor(list(values), dtype=torch.float64, device=dev)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(v) for v in o] for o in out]
+
+
+def device_identity(device):
+    """16 bytes that name the physical GPU of this rank: its UUID where the runtime reports one, else PCI bus / device / domain, else name + index"""
+    import hashlib
+    import socket
+    p = torch.cuda.get_device_properties(device)
+    ident = None
+    for attr in ("uuid", "pci_bus_id"):
+        v = getattr(p, attr, None)
+        if v is not None and str(v) not in ("", "None"):
+            ident = f"{attr}:{v}"
+            break
+    if ident is None:
+        ident = f"name:{p.name}:index:{torch.device(device).index}"
+    if not ident.startswith("uuid"):
+        ident = socket.gethostname() + "/" + ident + f"/{getattr(p, 'pci_device_id', '')}/{getattr(p, 'pci_domain_id', '')}"
+    return hashlib.md5(ident.encode()).digest(), ident
+
+
+def gather_device_identities(device):
+    """[(md5 hex, text)] of every rank's device, on every rank: one all-gather of 16 bytes, to be called BEFORE any HIP graph exists (bench.py:
+    n_gpus must be the number of DISTINCT devices that took part, not the number of processes)"""
+    digest, text = device_identity(device)
+    if not dist.is_initialized():
+        return [(digest.hex(), text)]
+    dev = "cpu" if dist.get_backend() == "gloo" else device
+    t = torch.tensor(list(digest), dtype=torch.uint8, device=dev)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [(bytes(o.cpu().tolist()).hex(), text if i == dist.get_rank() else "") for i, o in enumerate(out)]
+
+
+def own_rows_match(gathered, local, n_frames, rank, world):
+    """rank `dst`'s check of the gather: the rows of its own shard in the gathered tensor are its local rows, bit for bit"""
+    ids = shard_frames(n_frames, rank, world)
+    return bool(torch.equal(gathered[ids].view(torch.int32), local[:len(ids)].view(torch.int32)))

@@ -148,8 +148,9 @@ class DsvtPipeline:
         h_in = dict(input_half=True) if f16 else {}
         o16 = dict(output_mode=P.OUT_F16) if f16 else {}
         oboth = dict(output_mode=P.OUT_BOTH) if f16 else {}
+        # (fused frame path: the pillar feature net reads slot 0 of the [P, 48] point-id table -- a pillar's rows are consecutive -- and nobody reads the rest)
         self.voxelizer = zf(P.add_voxel_generator(c.N, c.Nk, c.P, 4, 10, 48, X_MIN, X_MAX, Y_MIN, Y_MAX, Z_MIN, Z_MAX,
-                                                  VX, VY, VZ, GX, GY, GZ, frames=self.frames))
+                                                  VX, VY, VZ, GX, GY, GZ, frames=self.frames, point_id_slots=1 if (fast and not zero_fill) else None))
         # PFN: FC (no bias) + BN1d(1e-5) + ReLU, BN folded into the FC           (:268-286, :577, :587)
         W0, b0 = fold_linear_bn(w, "module.vfe.pfn_layers.0.linear", "module.vfe.pfn_layers.0.norm", 1e-5)
         W1, b1 = fold_linear_bn(w, "module.vfe.pfn_layers.1.linear", "module.vfe.pfn_layers.1.norm", 1e-5)

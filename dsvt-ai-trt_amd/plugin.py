@@ -340,11 +340,15 @@ class Plugin:
 # --------------------------------------------------------------------------------------
 def add_voxel_generator(max_points_num, max_points_num_voxel_filter, max_pillars_num, point_feature_num,
                         feature_num, max_num_points_per_voxel, x_min, x_max, y_min, y_max, z_min, z_max,
-                        voxel_size_x, voxel_size_y, voxel_size_z, grid_size_x, grid_size_y, grid_size_z, frames=1):
+                        voxel_size_x, voxel_size_y, voxel_size_z, grid_size_x, grid_size_y, grid_size_z, frames=1, point_id_slots=None):
     """plugin_helper.h:15-123.  Inputs at call time: points[1,N,4] f32, points_size[1] i32.
     frames > 1 (not in the reference): points [1, frames * N, 4] (frame f = rows f * N ...), points_size [frames]; the frames' pillars are
-    concatenated (ascending (frame, cell)), coords = (frame, z, y, x), max_pillars_num / max_points_num_voxel_filter bound the totals."""
+    concatenated (ascending (frame, cell)), coords = (frame, z, y, x), max_pillars_num / max_points_num_voxel_filter bound the totals.
+    point_id_slots (not in the reference): how many slots of each row of the [P, 48] point-id table are written (default: all); a pillar's rows are
+    consecutive, so the fused pillar feature net needs slot 0 only and the frame pipeline passes 1."""
     extra = dict(frames=int(frames)) if frames != 1 else {}
+    if point_id_slots is not None and int(point_id_slots) != max_num_points_per_voxel:
+        extra["point_id_slots"] = int(point_id_slots)
     return Plugin("Points2FeaturesPlugin", dict(extra, 
         max_points_num=max_points_num, max_points_num_voxel_filter=max_points_num_voxel_filter,
         max_pillars_num=max_pillars_num, point_feature_num=point_feature_num, feature_num=feature_num,

@@ -41,6 +41,13 @@ def _worker(rank, world, port, n_frames, q):
     # bench.py's timing protocol: the per-repeat times of every rank meet in ONE all-reduce (element-wise maximum)
     tv = par.max_over_ranks_vec([1.0 + r, 5.0 - 2 * r, 0.25], torch.device("cpu"))
     ok = ok and tv == [float(w), 5.0, 0.25]
+    # ... and since round 5 in ONE all-gather that keeps the per-rank values (which rank was slow)
+    av = par.all_ranks_vec([1.0 + r, 5.0 - 2 * r], torch.device("cpu"))
+    ok = ok and av == [[1.0 + k, 5.0 - 2 * k] for k in range(w)]
+    if r == 0:
+        ok = ok and par.own_rows_match(out, local, n_frames, r, w)
+        bad = out.clone(); bad[0, 7] += 1.0
+        ok = ok and not par.own_rows_match(bad, local, n_frames, r, w)
     if r == 0:
         for f in range(n_frames):
             b, c = par.unpack_result(out[f])

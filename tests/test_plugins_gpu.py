@@ -63,6 +63,35 @@ def test_points2features_frames(pkg, oracle, frame, capname):
     check_voxelizer(outs, ref)
 
 
+def test_points2features_point_id_slots(pkg, oracle):
+    """optional field point_id_slots = 1 (what the fused frame pipeline passes: the pillar feature net walks a pillar's consecutive rows from slot 0):
+    slot 0 of every pillar's row of the [P, 48] table is the reference's, the other 47 slots are not written, every other output is unchanged;
+    blob round trip; out-of-range values are refused."""
+    P = pkg.plugin
+    c = cases.caps("waymo")
+    pts, n = cases.pad_points(pkg.synth.lidar_like(180000, 0), c["N"])
+    ref = oracle.points2features(pts, n, cases.p2f_cfg(c))
+    args = (c["N"], c["Nk"], c["P"], 4, 10, 48, -74.88, 74.88, -74.88, 74.88, -5.0, 3.0, 0.32, 0.32, 8.0, 468, 468, 1)
+    op = P.add_voxel_generator(*args, point_id_slots=1).set_zero_fill(False)       # (the reference's whole-output memsets would hide what the kernels write)
+    pidx0 = torch.full((1, c["P"], 48), 0x7fffffff, dtype=torch.int32, device=DEV)
+    full = op(dev(pts[None]), scalar(n))
+    outs = list(full)
+    op.enqueue([dev(pts[None]), scalar(n)], [outs[0], pidx0] + outs[2:], torch.empty(op.get_workspace_size(
+        [P._desc((1, c["N"], 4), 0), P._desc((1,), 3)], [P._desc(tuple(o.shape), P._dt_code(o)) for o in outs]), dtype=torch.uint8, device=DEV))
+    torch.cuda.synchronize()
+    feat, _, coords, pcnt, Pn, Nk = [host(o) for o in outs]
+    pi = host(pidx0)[0]
+    assert int(Pn[0]) == ref["P"] and np.array_equal(coords[0], ref["coords"]) and np.array_equal(pcnt[0], ref["pcnt"]) and np.array_equal(feat[0], ref["feat"])
+    assert np.array_equal(pi[:ref["P"], 0], ref["pidx"][:ref["P"], 0])
+    assert (pi[:, 1:] == 0x7fffffff).all() and (pi[ref["P"]:, 0] == 0x7fffffff).all()
+    blob = op.serialize()
+    assert len(blob) == 9 * 4 + 11 * 4 and P.Plugin.deserialize("Points2FeaturesPlugin", blob).serialize() == blob
+    assert len(P.add_voxel_generator(*args, point_id_slots=48).serialize()) == 72        # the default is the reference's blob
+    for bad in (0, 49):
+        with pytest.raises(ValueError):
+            P.add_voxel_generator(*args, point_id_slots=bad)
+
+
 @pytest.mark.parametrize("n_pts,capname", [(60000, "mid"), (180000, "waymo"), (300000, None)])
 def test_points2features_synthetic(pkg, oracle, n_pts, capname):
     c = cases.caps(capname) if capname else dict(N=327680, Nk=327680, P=65536, W=4096, Vw=576)
