@@ -2169,7 +2169,21 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
             //    of 0.375; LDS only holds 8-row tiles then, four waves of two rows): correct (boxes within 1e-5) and 364 registers without a
             //    spill, but 860-1054 us per 468 x 468 128 -> 128 layer against 831-954 for the plain kernel walking the [hi | lo | hi] triple.
             if (ctWide == 8) DSVT_WIDE(ncu, 512, nwide, nchunk, 8, 8, 36, 2, 3, 2);
-            else DSVT_WIDE(ncu, 512, nwide, nchunk, 4, 8, 40, 4, 2, 2);
+            else {
+                // 64 output channels (the shared 384 -> 64 head convolution): a 16-row item's accumulators are half a wave's budget (64 of 128 registers), so
+                // THREE rows per wave -- 24 x 32-pixel items, 96 accumulator registers, 26 x 36-pixel halo phases (59 KB each) beside two 16 KB weight slabs:
+                // the weight stream per output pixel falls by a third and the halo overhead from 18 / 16 to 26 / 24 (round 5; DSVT_CONV_RW3=0: 16-row items)
+                // Measured (tools/bench_conv_mx.py, 468 x 468 384 -> 64, three products): four frames 1367 vs 1516 us (1200 items = 4.7 rounds of 256 against
+                // 1800 = 7.03), ONE frame 497 vs 397 us (300 items = a second round for 44 of them) -- so the item height follows the round count: a 24-row
+                // row costs ~0.92 of a 16-row one.  Split-precision instantiation only (the fp16 one spills 42 registers at three rows per wave).
+                static int rw3 = -1; if (rw3 < 0) rw3 = ablateEnv("DSVT_CONV_RW3", 1);
+                const int n24 = cdiv(a.Ho, 24) * tilesX * nchunk * NBI;
+                if (rw3 && spl && n24 >= ncu && cdiv(n24, ncu) * 24 * 92 < cdiv(nwide, ncu) * 16 * 100) {
+                    hipLaunchKernelGGL((conv_wide_kernel<4, 8, 36, 4, 2, 3, false, true>), dim3(ncu), dim3(512), 0, stream, a, Wp, zeros, tilesX, n24, nchunk, dbg);
+                    return lastError();
+                }
+                DSVT_WIDE(ncu, 512, nwide, nchunk, 4, 8, 40, 4, 2, 2);
+            }
         }
         const int nch64 = cdiv(a.CoutRows, 64), nsmall = cdiv(a.Ho, 8) * tilesX * nch64 * NBI;
         // 16-row x 64-channel items on eight waves when they nearly fill the CUs (234x234x128: 240 items, one per CU, 40 LDS-DMA

@@ -324,3 +324,32 @@ def test_three_product_layers_over_hi_lo_planes(pkg, H, W, cin, cout, k, stride,
     again = torch.full_like(out, 7.0)
     op(*args, out=[again]); torch.cuda.synchronize()
     assert torch.equal(again.view(torch.int16), out.view(torch.int16))
+
+
+def test_shared_head_conv_on_24_row_items_equals_its_16_row_form(pkg):
+    """The 64-output-channel three-product layer (shared 384 -> 64 head convolution) picks its item height by the round count: four 468 x 468 images take
+    24-row items (three rows per wave: conv_wide_kernel<4, 8, 36, 4, 2, 3>), one image 16-row ones.  Both walk the same K order, so the stack's images
+    must be the BITS of the single-image launches; and image 0 is checked against a float64 convolution on a crop."""
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(77)
+    H, cin, cout, B = 468, 384, 64, 4
+    w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    x = torch.relu(torch.randn(B, H, H, cin, generator=g))
+    x3 = _hi_lo_junk(x).to(DEV)
+    kw = dict(relu=True, split_input=1, split_output=4, out_channel_stride=3 * cout)
+    rows = P.split_weight_rows(P.conv_weight_rows(w.numpy()), 9, cin)
+    many = P.add_conv2d_op(rows, b.numpy(), H, H, 3 * cin, cout, 3, 1, 1, **kw)
+    one = P.add_conv2d_op(rows, b.numpy(), H, H, 3 * cin, cout, 3, 1, 1, **kw)
+    out = many(x3)[0]
+    torch.cuda.synchronize()
+    for i in range(B):
+        ref = one(x3[i:i + 1].contiguous())[0]
+        torch.cuda.synchronize()
+        assert torch.equal(out[i][..., :2 * cout].view(torch.int16), ref[0][..., :2 * cout].view(torch.int16)), i
+    # a 40 x 468 band of image 0 (rows 200 .. 239: item boundaries of both heights inside) against float64
+    y0, y1 = 200, 240
+    crop = x[0:1, y0 - 1:y1 + 1].permute(0, 3, 1, 2).double()
+    ref = torch.relu(F.conv2d(crop, w.double(), b.double(), 1, (0, 1)))[0].permute(1, 2, 0)
+    got = (out[0, y0:y1, :, :cout].double() + out[0, y0:y1, :, cout:2 * cout].double()).cpu()
+    assert (got - ref).abs().max().item() < 5e-6 * ref.abs().max().item()

@@ -1,5 +1,6 @@
 """Per-layer durations of the 3 x 3 stride-1 layers of the dense stage in the three arithmetic variants (HIP events over REPS launches,
-B images per launch):  f16 | split, three fp16 products over [hi | lo | hi] | split, fp16 + fp8 K loop over [hi | lo | x8].
+B images per launch):  f16 | split, three fp16 products over [hi | lo | hi] | split4, the same over [hi | lo | -] with the third plane aliased to plane 0
+(round 5's default head wiring: split_input = 1, split_output = 4) | mx, fp16 + fp8 K loop over [hi | lo | x8].
     python tools/bench_conv_mx.py [B] [variants: f16,split,mx]      ONLY=<indices of LAYERS, comma separated>: those layers only (PMC passes)"""
 import os, sys
 import numpy as np, torch
@@ -31,7 +32,7 @@ for H, cin, cout, res, cnt in LAYERS:
         else:
             rows = P.conv_weight_rows(w) if v == "mx" else P.split_weight_rows(P.conv_weight_rows(w), 9, cin)
             op = P.add_conv2d_op(rows, b, H, H, 3 * cin, cout, 3, 1, 1, relu=True, has_residual=res, split_residual=res,
-                                 split_output=2 if v == "mx" else 1, split_input=2 if v == "mx" else 0, out_channel_stride=3 * cout)
+                                 split_output={"mx": 2, "split4": 4}.get(v, 1), split_input={"mx": 2, "split4": 1}.get(v, 0), out_channel_stride=3 * cout)
             x = (torch.randn(B, H, H, 3 * cin, device=dev) * 0.5).to(torch.float16)      # (any bit pattern is a valid operand; NaN-free fp8 bytes not required for timing)
             x[..., 2 * cin:] = torch.randint(0, 120, (B, H, H, cin), device=dev, dtype=torch.int16).view(torch.float16) if v == "mx" else x[..., :cin]
             r = (torch.randn(B, H, H, 3 * cout, device=dev) * 0.5).to(torch.float16)
