@@ -71,7 +71,8 @@ PEAK_HBM_GBS = 8000.0               # same guide: "HBM3E peak BW 8.0 TB/s spec" 
 N_POINTS = 180000
 # FETCH_SIZE / WRITE_SIZE passes (profiles/), by (mode, frames per forward())
 PMC_FILES = {("f16", 1): "r02_g_batch1_pmc_traffic.json", ("f16", 2): "r02_g_pmc_traffic.json", ("f16", 4): "r04_f16_pmc_traffic.json",
-             ("split", 4): "r04_split_pmc_traffic.json"}
+             ("split", 4): "r05_split_pmc_traffic.json", ("split", 1): "r05_split_batch1_pmc_traffic.json",
+             ("splitmx", 4): "r04_split_pmc_traffic.json"}          # (round 4's split frame had the fp8 head: today's `splitmx`)
 FRAME_POOL = 4                      # distinct synthetic clouds cycled through by the steps
 MIN_TIMED_S = 0.5                   # K steps shorter than this are repeated
 MAX_REPEATS = 15
