@@ -2157,6 +2157,15 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
             const int n8 = cdiv(a.Ho, 8) * tilesX * nchunk * NBI, grid = n8 < 2 * ncu ? n8 : 2 * ncu;
             DSVT_WIDE(grid, 256, n8, nchunk, 8, 4, 36, 2, 2, 2);
         }
+        {   // three-product layers whose channel count leaves half of the last 128-channel chunk empty (the 64 -> 320 head stems: 2.5 chunks -> a sixth of the
+            // MFMAs wasted, and a short K -- six phases -- that streams 432 KB of weights per item): 64-channel chunks on 24-row items (see the 64-channel rule below)
+            static int hct4 = -1; if (hct4 < 0) hct4 = ablateEnv("DSVT_CONV_HEADS_CT4", 1);
+            const int nch64h = cdiv(a.CoutRows, 64), n24h = cdiv(a.Ho, 24) * tilesX * nch64h * NBI;
+            if (hct4 && spl && ctWide == 8 && a.CoutRows % 128 == 64 && n24h >= ncu) {
+                hipLaunchKernelGGL((conv_wide_kernel<4, 8, 36, 4, 2, 3, false, true>), dim3(ncu), dim3(512), 0, stream, a, Wp, zeros, tilesX, n24h, nch64h, dbg);
+                return lastError();
+            }
+        }
         if (nwide >= ncu) {
             // halo row stride 36 pixels, not 40: 134,144 B of LDS instead of 142,336 (room for the OTHER frame's 23 KB attention workgroups)
             // Round-3 experiments, measured and dropped (one wave per SIMD loses both times -- a lone wave cannot hide its own LDS-DMA issue,
