@@ -631,12 +631,12 @@ public:
         for (size_t i = 0; i < (size_t)C * C; ++i) wis[i] = wis[i] / scale;
         for (int i = 0; i < C; ++i) bis[i] = bis[i] / scale;
         auto up = [](const std::vector<float>& h, float** d) {
-            if (hipMalloc(d, sizeof(float) * h.size()) != hipSuccess) return false;
+            if (dsvtMalloc(d, sizeof(float) * h.size()) != hipSuccess) return false;
             return hipMemcpy(*d, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice) == hipSuccess;
         };
         ok_ = up(wis, &wi_dev_) && up(bis, &bi_dev_) && up(wo_, &wo_dev_) && up(bo_, &bo_dev_);
     }
-    ~MultiHeadAttentionPlugin() override { for (float* p : {wi_dev_, bi_dev_, wo_dev_, bo_dev_}) if (p) (void)hipFree(p); }
+    ~MultiHeadAttentionPlugin() override { for (float* p : {wi_dev_, bi_dev_, wo_dev_, bo_dev_}) if (p) (void)dsvtFree(p); }
     const char* type() const override { return "MultiHeadAttentionPlugin"; }
     int nbOutputs() const override { return 1; }
     int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {

@@ -1,7 +1,44 @@
 // c_api.hip -- extern "C" surface of libdsvt_hip.so (declared in include/dsvt_plugin.h).
 #include "plugin_base.h"
+#include <mutex>
+#include <unordered_map>
 
 namespace dsvt {
+
+// ---- the plugins' own device memory (dsvtSetGpuAllocator) ----------------------------------------------------------------
+namespace {
+struct GpuAllocator { DsvtGpuAllocFn alloc = nullptr; DsvtGpuFreeFn free_ = nullptr; void* user = nullptr; };
+std::mutex& allocMu() { static std::mutex m; return m; }
+GpuAllocator& gpuAllocator() { static GpuAllocator a; return a; }
+std::unordered_map<void*, GpuAllocator>& hostedBlocks() { static std::unordered_map<void*, GpuAllocator> m; return m; }     // blocks that came from a host allocator
+}  // namespace
+void setGpuAllocator(DsvtGpuAllocFn alloc, DsvtGpuFreeFn free_, void* user) {
+    std::lock_guard<std::mutex> lk(allocMu());
+    GpuAllocator& a = gpuAllocator();
+    if (alloc && free_) { a.alloc = alloc; a.free_ = free_; a.user = user; } else a = GpuAllocator{};
+}
+hipError_t deviceMallocBytes(void** p, size_t bytes) {
+    GpuAllocator a;
+    { std::lock_guard<std::mutex> lk(allocMu()); a = gpuAllocator(); }
+    if (!a.alloc) return hipMalloc(p, bytes);
+    void* q = a.alloc(bytes ? bytes : 1, a.user);
+    if (!q) { *p = nullptr; return hipErrorOutOfMemory; }
+    { std::lock_guard<std::mutex> lk(allocMu()); hostedBlocks()[q] = a; }
+    *p = q;
+    return hipSuccess;
+}
+hipError_t deviceFreeBytes(void* p) {
+    if (!p) return hipSuccess;
+    GpuAllocator a;
+    {
+        std::lock_guard<std::mutex> lk(allocMu());
+        auto it = hostedBlocks().find(p);
+        if (it == hostedBlocks().end()) return hipFree(p);
+        a = it->second; hostedBlocks().erase(it);
+    }
+    a.free_(p, a.user);
+    return hipSuccess;
+}
 std::vector<Creator*>& registry() {
     static std::vector<Creator*> r;
     return r;
@@ -199,6 +236,8 @@ void dsvtPluginDestroy(DsvtPlugin* p) {
     delete p;
 }
 void dsvtPluginSetZeroFill(DsvtPlugin* p, int32_t enable) { if (p) p->impl->zeroFill = enable != 0; }
+void dsvtSetGpuAllocator(DsvtGpuAllocFn alloc, DsvtGpuFreeFn free_, void* user) { dsvt::setGpuAllocator(alloc, free_, user); }
+
 const char* dsvtGetBuildInfo(void) { return "libdsvt_hip gfx950 (CDNA4) hand-written HIP, built " __DATE__; }
 
 }  // extern "C"

@@ -2318,9 +2318,9 @@ public:
                             img[dst + j] = (g & 1) ? e4m3Encode(std::ldexp(wv - hi, ex[n] + 11)) : e4m3Encode(std::ldexp(hi, ex[n]));
                         }
                     }
-        ok_ = hipMalloc(&wp_dev_, img.size()) == hipSuccess && hipMemcpy(wp_dev_, img.data(), img.size(), hipMemcpyHostToDevice) == hipSuccess &&
-              hipMalloc(&xscale_dev_, sc.size()) == hipSuccess && hipMemcpy(xscale_dev_, sc.data(), sc.size(), hipMemcpyHostToDevice) == hipSuccess &&
-              hipMalloc(&zeros_dev_, 256) == hipSuccess && hipMemset(zeros_dev_, 0, 256) == hipSuccess;
+        ok_ = dsvtMalloc(&wp_dev_, img.size()) == hipSuccess && hipMemcpy(wp_dev_, img.data(), img.size(), hipMemcpyHostToDevice) == hipSuccess &&
+              dsvtMalloc(&xscale_dev_, sc.size()) == hipSuccess && hipMemcpy(xscale_dev_, sc.data(), sc.size(), hipMemcpyHostToDevice) == hipSuccess &&
+              dsvtMalloc(&zeros_dev_, 256) == hipSuccess && hipMemset(zeros_dev_, 0, 256) == hipSuccess;
     }
     // the same for a 1 x 1 layer on conv_halo_kernel<.., MX> (64-channel phases): [fp16 k-step q = 2 phase + ks][tile][lane (r, g)][8 halfs] <-
     // fp16(W[tile 16 + r][64 phase + 32 ks + 8 g + j]), then [cross phase][tile][h][lane (r, g)][16 bytes] <- e4m3 of W_hi 2^e (g even) or W_lo 2^(e + 11)
@@ -2360,9 +2360,9 @@ public:
                             img[dst + j] = (g & 1) ? e4m3Encode(std::ldexp(wv - hi, ex[n] + 11)) : e4m3Encode(std::ldexp(hi, ex[n]));
                         }
                     }
-        ok_ = hipMalloc(&wp_dev_, img.size()) == hipSuccess && hipMemcpy(wp_dev_, img.data(), img.size(), hipMemcpyHostToDevice) == hipSuccess &&
-              hipMalloc(&xscale_dev_, sc.size()) == hipSuccess && hipMemcpy(xscale_dev_, sc.data(), sc.size(), hipMemcpyHostToDevice) == hipSuccess &&
-              hipMalloc(&zeros_dev_, 256) == hipSuccess && hipMemset(zeros_dev_, 0, 256) == hipSuccess;
+        ok_ = dsvtMalloc(&wp_dev_, img.size()) == hipSuccess && hipMemcpy(wp_dev_, img.data(), img.size(), hipMemcpyHostToDevice) == hipSuccess &&
+              dsvtMalloc(&xscale_dev_, sc.size()) == hipSuccess && hipMemcpy(xscale_dev_, sc.data(), sc.size(), hipMemcpyHostToDevice) == hipSuccess &&
+              dsvtMalloc(&zeros_dev_, 256) == hipSuccess && hipMemset(zeros_dev_, 0, 256) == hipSuccess;
     }
     DsvtConv2dPlugin(const ConvCfg& c, const float* w, const float* b) : c_(c) {
         const size_t nw = (size_t)rows() * c.KH * c.KW * cinW();
@@ -2372,7 +2372,7 @@ public:
             ok_ = true;
             if (b) {
                 const size_t nb = ((size_t)c.Cout + 3) / 4 * 4;
-                ok_ = hipMalloc(&b_dev_, sizeof(float) * nb) == hipSuccess && hipMemset(b_dev_, 0, sizeof(float) * nb) == hipSuccess &&
+                ok_ = dsvtMalloc(&b_dev_, sizeof(float) * nb) == hipSuccess && hipMemset(b_dev_, 0, sizeof(float) * nb) == hipSuccess &&
                       hipMemcpy(b_dev_, b_.data(), sizeof(float) * c.Cout, hipMemcpyHostToDevice) == hipSuccess;
             }
             if (ok_) { if (c.KH == 1) packMX1x1(); else packMX(); }
@@ -2380,11 +2380,11 @@ public:
         }
         std::vector<_Float16> wh(nw);
         for (size_t i = 0; i < nw; ++i) wh[i] = (_Float16)w_[i];
-        ok_ = hipMalloc(&w_dev_, sizeof(_Float16) * nw) == hipSuccess &&
+        ok_ = dsvtMalloc(&w_dev_, sizeof(_Float16) * nw) == hipSuccess &&
               hipMemcpy(w_dev_, wh.data(), sizeof(_Float16) * nw, hipMemcpyHostToDevice) == hipSuccess;
         if (ok_ && b) {                      // zero padded to whole float4s: the halo kernels fetch the bias as 16-byte LDS-DMA lanes
             const size_t nb = ((size_t)c.Cout + 3) / 4 * 4;
-            ok_ = hipMalloc(&b_dev_, sizeof(float) * nb) == hipSuccess && hipMemset(b_dev_, 0, sizeof(float) * nb) == hipSuccess &&
+            ok_ = dsvtMalloc(&b_dev_, sizeof(float) * nb) == hipSuccess && hipMemset(b_dev_, 0, sizeof(float) * nb) == hipSuccess &&
                   hipMemcpy(b_dev_, b_.data(), sizeof(float) * c.Cout, hipMemcpyHostToDevice) == hipSuccess;
         }
         if (ok_ && (haloEligible() || conv1x1ResidentShape(c.KH, c.KW, c.stride, c.pad, c.Cin, c.Cout, rows()))) {
@@ -2404,9 +2404,9 @@ public:
                                 const size_t src = ((size_t)n * T + tap) * c.Cin + cc * 64 + ks * 32 + (lane >> 4) * 8;
                                 for (int j = 0; j < 8; ++j) wp[dst + j] = wh[src + j];
                             }
-            ok_ = hipMalloc(&wp_dev_, sizeof(_Float16) * wp.size()) == hipSuccess &&
+            ok_ = dsvtMalloc(&wp_dev_, sizeof(_Float16) * wp.size()) == hipSuccess &&
                   hipMemcpy(wp_dev_, wp.data(), sizeof(_Float16) * wp.size(), hipMemcpyHostToDevice) == hipSuccess &&
-                  hipMalloc(&zeros_dev_, 256) == hipSuccess && hipMemset(zeros_dev_, 0, 256) == hipSuccess;
+                  dsvtMalloc(&zeros_dev_, 256) == hipSuccess && hipMemset(zeros_dev_, 0, 256) == hipSuccess;
         }
         if (ok_ && zeros_dev_) packGrouped(wh);
     }
@@ -2444,7 +2444,7 @@ public:
                             for (int jq = 0; jq < 8; ++jq)
                                 wg[(((size_t)cc * 18 + tap * 2 + ks) * 64 + gq * 16 + i) * 8 + jq] = wh[((size_t)n * 9 + tap) * c.Cin + cc * 64 + ks * 32 + gq * 8 + jq];
             }
-        if (hipMalloc(&wg_dev_, sizeof(_Float16) * wg.size()) != hipSuccess || hipMalloc(&chan_dev_, sizeof(int) * tab.size()) != hipSuccess ||
+        if (dsvtMalloc(&wg_dev_, sizeof(_Float16) * wg.size()) != hipSuccess || dsvtMalloc(&chan_dev_, sizeof(int) * tab.size()) != hipSuccess ||
             hipMemcpy(wg_dev_, wg.data(), sizeof(_Float16) * wg.size(), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(chan_dev_, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) { ok_ = false; return; }
         groups_ = NCC;
@@ -2484,14 +2484,14 @@ public:
                                     wg[(((size_t)cc * 36 + pl * 18 + tap * 2 + ks) * 64 + gq * 16 + i) * 8 + jq] =
                                         wh[((size_t)n * 9 + tap) * c.Cin + pl * 2 * C + cc * 64 + ks * 32 + gq * 8 + jq];
             }
-        if (hipMalloc(&wg_dev_, sizeof(_Float16) * wg.size()) != hipSuccess || hipMalloc(&chan_dev_, sizeof(int) * tab.size()) != hipSuccess ||
+        if (dsvtMalloc(&wg_dev_, sizeof(_Float16) * wg.size()) != hipSuccess || dsvtMalloc(&chan_dev_, sizeof(int) * tab.size()) != hipSuccess ||
             hipMemcpy(wg_dev_, wg.data(), sizeof(_Float16) * wg.size(), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(chan_dev_, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) { ok_ = false; return; }
         groups_ = NQ; groups_split_ = true;
     }
     ~DsvtConv2dPlugin() override {
-        if (w_dev_) (void)hipFree(w_dev_); if (b_dev_) (void)hipFree(b_dev_); if (wp_dev_) (void)hipFree(wp_dev_); if (zeros_dev_) (void)hipFree(zeros_dev_); if (wg_dev_) (void)hipFree(wg_dev_); if (chan_dev_) (void)hipFree(chan_dev_);
-        if (xscale_dev_) (void)hipFree(xscale_dev_);
+        if (w_dev_) (void)dsvtFree(w_dev_); if (b_dev_) (void)dsvtFree(b_dev_); if (wp_dev_) (void)dsvtFree(wp_dev_); if (zeros_dev_) (void)dsvtFree(zeros_dev_); if (wg_dev_) (void)dsvtFree(wg_dev_); if (chan_dev_) (void)dsvtFree(chan_dev_);
+        if (xscale_dev_) (void)dsvtFree(xscale_dev_);
     }
     const char* type() const override { return "DsvtConv2dPlugin"; }
     bool handlesBatch() const override { return true; }          // a stack of images is ONE launch: the persistent kernels walk image after image
@@ -2532,7 +2532,7 @@ public:
         if (tron && wp_dev_ && haloEligible()) {
             static unsigned long long* tr = nullptr;
             const size_t n = (size_t)4096 * 2 * CONV_TRACE_N;
-            if (!tr && hipMalloc(&tr, n * 8) != hipSuccess) return -3;
+            if (!tr && dsvtMalloc(&tr, n * 8) != hipSuccess) return -3;
             (void)hipMemsetAsync(tr, 0, n * 8, stream);
             a.trace = tr;
             const int rc = launchConvHalo(a, wp_dev_, zeros_dev_, stream);

@@ -1260,32 +1260,32 @@ public:
         if (c.n_ln) { g_.assign(g, g + (size_t)c.n_ln * c.N); be_.assign(be, be + (size_t)c.n_ln * c.N); }
         auto up = [](const std::vector<float>& h, float** d) {
             if (h.empty()) { *d = nullptr; return true; }
-            if (hipMalloc(d, sizeof(float) * h.size()) != hipSuccess) return false;
+            if (dsvtMalloc(d, sizeof(float) * h.size()) != hipSuccess) return false;
             return hipMemcpy(*d, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice) == hipSuccess;
         };
         ok_ = up(w_, &w_dev_) && up(b_, &b_dev_) && up(g_, &g_dev_) && up(be_, &be_dev_) && up(pe_, &pe_dev_);
         if (ok_ && useF16()) {
             std::vector<_Float16> wh(w_.size());
             for (size_t i = 0; i < w_.size(); ++i) wh[i] = (_Float16)w_[i];
-            ok_ = hipMalloc(&wh_dev_, sizeof(_Float16) * wh.size()) == hipSuccess &&
+            ok_ = dsvtMalloc(&wh_dev_, sizeof(_Float16) * wh.size()) == hipSuccess &&
                   hipMemcpy(wh_dev_, wh.data(), sizeof(_Float16) * wh.size(), hipMemcpyHostToDevice) == hipSuccess;
         }
         if (ok_ && c_.compute_type == 2) {
             const std::vector<_Float16> wp = packStagesSplit(w_.data(), c_.N);
-            ok_ = hipMalloc(&wps_dev_, sizeof(_Float16) * wp.size()) == hipSuccess &&
+            ok_ = dsvtMalloc(&wps_dev_, sizeof(_Float16) * wp.size()) == hipSuccess &&
                   hipMemcpy(wps_dev_, wp.data(), sizeof(_Float16) * wp.size(), hipMemcpyHostToDevice) == hipSuccess;
         }
         if (ok_ && useStream()) {
             const std::vector<_Float16> wp = packStages(w_.data(), c_.N);
-            ok_ = hipMalloc(&wp_dev_, sizeof(_Float16) * wp.size()) == hipSuccess &&
+            ok_ = dsvtMalloc(&wp_dev_, sizeof(_Float16) * wp.size()) == hipSuccess &&
                   hipMemcpy(wp_dev_, wp.data(), sizeof(_Float16) * wp.size(), hipMemcpyHostToDevice) == hipSuccess;
         }
     }
     ~DsvtLinearPlugin() override {
-        for (float* p : {w_dev_, b_dev_, g_dev_, be_dev_, pe_dev_}) if (p) (void)hipFree(p);
-        if (wh_dev_) (void)hipFree(wh_dev_);
-        if (wp_dev_) (void)hipFree(wp_dev_);
-        if (wps_dev_) (void)hipFree(wps_dev_);
+        for (float* p : {w_dev_, b_dev_, g_dev_, be_dev_, pe_dev_}) if (p) (void)dsvtFree(p);
+        if (wh_dev_) (void)dsvtFree(wh_dev_);
+        if (wp_dev_) (void)dsvtFree(wp_dev_);
+        if (wps_dev_) (void)dsvtFree(wps_dev_);
     }
     const char* type() const override { return "DsvtLinearPlugin"; }
     int nbOutputs() const override { return c_.output_mode == OUT_BOTH ? 2 : 1; }
@@ -1365,7 +1365,7 @@ public:
     }
     Plugin* clone() const override {
         DsvtLinearPlugin* p = new DsvtLinearPlugin(c_, w_.data(), b_.empty() ? nullptr : b_.data(), g_.data(), be_.data());
-        if (!pe_.empty()) { p->pe_ = pe_; p->ok_ = p->ok_ && hipMalloc(&p->pe_dev_, sizeof(float) * pe_.size()) == hipSuccess &&
+        if (!pe_.empty()) { p->pe_ = pe_; p->ok_ = p->ok_ && dsvtMalloc(&p->pe_dev_, sizeof(float) * pe_.size()) == hipSuccess &&
                             hipMemcpy(p->pe_dev_, pe_.data(), sizeof(float) * pe_.size(), hipMemcpyHostToDevice) == hipSuccess; }
         return p;
     }
@@ -1465,11 +1465,11 @@ public:
             }
         std::vector<_Float16> wp;
         for (int l = 0; l < L; ++l) { const std::vector<_Float16> one = packStages(w_.data() + (size_t)l * KS * KS, KS); wp.insert(wp.end(), one.begin(), one.end()); }
-        ok_ = hipMalloc(&pe_dev_, sizeof(float) * pe.size()) == hipSuccess && hipMemcpy(pe_dev_, pe.data(), sizeof(float) * pe.size(), hipMemcpyHostToDevice) == hipSuccess &&
-              hipMalloc(&b_dev_, sizeof(float) * b_.size()) == hipSuccess && hipMemcpy(b_dev_, b_.data(), sizeof(float) * b_.size(), hipMemcpyHostToDevice) == hipSuccess &&
-              hipMalloc(&wp_dev_, sizeof(_Float16) * wp.size()) == hipSuccess && hipMemcpy(wp_dev_, wp.data(), sizeof(_Float16) * wp.size(), hipMemcpyHostToDevice) == hipSuccess;
+        ok_ = dsvtMalloc(&pe_dev_, sizeof(float) * pe.size()) == hipSuccess && hipMemcpy(pe_dev_, pe.data(), sizeof(float) * pe.size(), hipMemcpyHostToDevice) == hipSuccess &&
+              dsvtMalloc(&b_dev_, sizeof(float) * b_.size()) == hipSuccess && hipMemcpy(b_dev_, b_.data(), sizeof(float) * b_.size(), hipMemcpyHostToDevice) == hipSuccess &&
+              dsvtMalloc(&wp_dev_, sizeof(_Float16) * wp.size()) == hipSuccess && hipMemcpy(wp_dev_, wp.data(), sizeof(_Float16) * wp.size(), hipMemcpyHostToDevice) == hipSuccess;
     }
-    ~DsvtPosEmbedPlugin() override { if (pe_dev_) (void)hipFree(pe_dev_); if (b_dev_) (void)hipFree(b_dev_); if (wp_dev_) (void)hipFree(wp_dev_); }
+    ~DsvtPosEmbedPlugin() override { if (pe_dev_) (void)dsvtFree(pe_dev_); if (b_dev_) (void)dsvtFree(b_dev_); if (wp_dev_) (void)dsvtFree(wp_dev_); }
     int nInputs() const { int m = 0; for (int v : src_) m = v > m ? v : m; return m + 2; }
     const char* type() const override { return "DsvtPosEmbedPlugin"; }
     int nbOutputs() const override { return L_; }

@@ -653,7 +653,7 @@ public:
         lg_.resize(4 * MC, 1.f); lb_.resize(4 * MC, 0.f);
         if (split_) pq_ = MLP_SPLIT_PQ;
         auto upF = [](const std::vector<float>& src, float** d) {
-            return hipMalloc(d, sizeof(float) * src.size()) == hipSuccess &&
+            return dsvtMalloc(d, sizeof(float) * src.size()) == hipSuccess &&
                    hipMemcpy(*d, src.data(), sizeof(float) * src.size(), hipMemcpyHostToDevice) == hipSuccess;
         };
         ok_ = upF(lg_, &lg_dev_) && upF(lb_, &lb_dev_);
@@ -710,12 +710,12 @@ public:
         std::vector<float> prm(MP_FLOATS, 0.f);
         for (int i = 0; i < MC; ++i) { prm[MP_BO + i] = bo_[i]; prm[MP_G1 + i] = lg_[i]; prm[MP_B1LN + i] = lb_[i]; prm[MP_B2 + i] = b2_[i]; }
         for (int i = 0; i < MF; ++i) prm[MP_B1 + i] = b1_[i];
-        ok_ = hipMalloc(&wp_dev_, sizeof(_Float16) * wp.size()) == hipSuccess &&
+        ok_ = dsvtMalloc(&wp_dev_, sizeof(_Float16) * wp.size()) == hipSuccess &&
               hipMemcpy(wp_dev_, wp.data(), sizeof(_Float16) * wp.size(), hipMemcpyHostToDevice) == hipSuccess && upF(prm, &prm_dev_);
     }
     ~DsvtEncoderMlpPlugin() override {
         for (void* p : {(void*)lg_dev_, (void*)lb_dev_, (void*)wp_dev_, (void*)prm_dev_})
-            if (p) (void)hipFree(p);
+            if (p) (void)dsvtFree(p);
     }
     const char* type() const override { return "DsvtEncoderMlpPlugin"; }
     int nbOutputs() const override { return split_ ? 1 : 2; }

@@ -534,15 +534,15 @@ public:
                         if (split_) { wa[img + d] = (_Float16)(va - (float)wa[d]); wb[img + d] = (_Float16)(vb - (float)wb[d]); }
                     }
         auto upF = [](const std::vector<float>& h, float** d) {
-            return hipMalloc(d, sizeof(float) * h.size()) == hipSuccess && hipMemcpy(*d, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice) == hipSuccess;
+            return dsvtMalloc(d, sizeof(float) * h.size()) == hipSuccess && hipMemcpy(*d, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice) == hipSuccess;
         };
         auto upH = [](const std::vector<_Float16>& h, _Float16** d) {
-            return hipMalloc(d, sizeof(_Float16) * h.size()) == hipSuccess && hipMemcpy(*d, h.data(), sizeof(_Float16) * h.size(), hipMemcpyHostToDevice) == hipSuccess;
+            return dsvtMalloc(d, sizeof(_Float16) * h.size()) == hipSuccess && hipMemcpy(*d, h.data(), sizeof(_Float16) * h.size(), hipMemcpyHostToDevice) == hipSuccess;
         };
         ok_ = upF(w0p, &w0_dev_) && upF(b0_, &b0_dev_) && upF(b1_, &b1_dev_) && upH(wa, &w1a_dev_) && upH(wb, &w1b_dev_);
     }
     ~DsvtPillarFeatureNetPlugin() override {
-        for (void* p : {(void*)w0_dev_, (void*)b0_dev_, (void*)b1_dev_, (void*)w1a_dev_, (void*)w1b_dev_}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)w0_dev_, (void*)b0_dev_, (void*)b1_dev_, (void*)w1a_dev_, (void*)w1b_dev_}) if (p) (void)dsvtFree(p);
     }
     const char* type() const override { return "DsvtPillarFeatureNetPlugin"; }
     int nbOutputs() const override { return split_ ? 1 : 2; }

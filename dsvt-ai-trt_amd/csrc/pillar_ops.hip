@@ -285,13 +285,13 @@ public:
     LayerNormPlugin(int mp, int c, int ws, float eps, const float* g, const float* b)
         : max_pillars_num_(mp), channel_num_(c), weights_size_(ws), eps_(eps), gamma_(g, g + ws), beta_(b, b + ws) {
         // the plugin owns its device weights (layerNorm.cu:150-155)
-        if (hipMalloc(&gamma_dev_, sizeof(float) * ws) != hipSuccess || hipMalloc(&beta_dev_, sizeof(float) * ws) != hipSuccess) {
+        if (dsvtMalloc(&gamma_dev_, sizeof(float) * ws) != hipSuccess || dsvtMalloc(&beta_dev_, sizeof(float) * ws) != hipSuccess) {
             gamma_dev_ = beta_dev_ = nullptr; return;
         }
         (void)hipMemcpy(gamma_dev_, gamma_.data(), sizeof(float) * ws, hipMemcpyHostToDevice);
         (void)hipMemcpy(beta_dev_, beta_.data(), sizeof(float) * ws, hipMemcpyHostToDevice);
     }
-    ~LayerNormPlugin() override { if (gamma_dev_) (void)hipFree(gamma_dev_); if (beta_dev_) (void)hipFree(beta_dev_); }    // :432-444
+    ~LayerNormPlugin() override { if (gamma_dev_) (void)dsvtFree(gamma_dev_); if (beta_dev_) (void)dsvtFree(beta_dev_); }    // :432-444
     const char* type() const override { return "LayerNormPlugin"; }
     int nbOutputs() const override { return 1; }
     int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
@@ -490,11 +490,11 @@ public:
     Map2BevPlugin(int mp, int c, int gx, int gy, int frames = 1, int split = 0, int persistent = 0)
         : max_pillars_num_(mp), channel_num_(c), gx_(gx), gy_(gy), frames_(frames), split_(split), persistent_(persistent) {
         if (persistent_) {
-            if (hipMalloc(&prev_coords_, sizeof(uint4) * (size_t)mp) != hipSuccess || hipMalloc(&prev_state_, 2 * sizeof(unsigned long long)) != hipSuccess ||
+            if (dsvtMalloc(&prev_coords_, sizeof(uint4) * (size_t)mp) != hipSuccess || dsvtMalloc(&prev_state_, 2 * sizeof(unsigned long long)) != hipSuccess ||
                 hipMemset(prev_state_, 0, 2 * sizeof(unsigned long long)) != hipSuccess) { persistent_ = 0; }
         }
     }
-    ~Map2BevPlugin() override { if (prev_coords_) (void)hipFree(prev_coords_); if (prev_state_) (void)hipFree(prev_state_); }
+    ~Map2BevPlugin() override { if (prev_coords_) (void)dsvtFree(prev_coords_); if (prev_state_) (void)dsvtFree(prev_state_); }
     // zero the map: everything, or (persistent_output, and the device state says this buffer holds the previous call's cells and nothing else) those cells
     int clearMap(void* out, size_t bytes, int cellBytes, hipStream_t stream) {
         if (persistent_ && cellBytes % 16 == 0 && bytes % 16 == 0) {

@@ -29,6 +29,13 @@ struct WsCarver {
     }
 };
 
+// device memory of the plugins' own state: hipMalloc / hipFree unless the host installed an allocator (include/dsvt_plugin.h dsvtSetGpuAllocator)
+void setGpuAllocator(DsvtGpuAllocFn alloc, DsvtGpuFreeFn free_, void* user);      // c_api.hip
+hipError_t deviceMallocBytes(void** p, size_t bytes);
+hipError_t deviceFreeBytes(void* p);
+template <class T> inline hipError_t dsvtMalloc(T** p, size_t bytes) { return deviceMallocBytes(reinterpret_cast<void**>(p), bytes); }
+inline hipError_t dsvtFree(void* p) { return deviceFreeBytes(p); }
+
 struct FieldDef { const char* name; DsvtPluginFieldType type; };
 
 class Plugin {

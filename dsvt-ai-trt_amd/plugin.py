@@ -84,6 +84,8 @@ def _load():
     lib.dsvtGetBuildInfo.restype = C.c_char_p
     lib.dsvtGetLastCreateError.restype = C.c_char_p
     lib.dsvtGetLastCreateError.argtypes = []
+    lib.dsvtSetGpuAllocator.restype = None
+    lib.dsvtSetGpuAllocator.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     return lib
 
 
@@ -116,7 +118,25 @@ EXPORTED_SYMBOLS = [
     "dsvtPluginGetOutputDimensions", "dsvtPluginGetOutputDataType", "dsvtPluginSupportsFormatCombination",
     "dsvtPluginGetWorkspaceSize", "dsvtPluginConfigurePlugin", "dsvtPluginEnqueue", "dsvtPluginGetSerializationSize",
     "dsvtPluginSerialize", "dsvtPluginClone", "dsvtPluginDestroy", "dsvtPluginSetZeroFill", "dsvtGetBuildInfo", "dsvtGetLastCreateError",
+    "dsvtSetGpuAllocator",
 ]
+
+
+GPU_ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
+GPU_FREE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+_gpu_allocator = None          # (keeps the ctypes callbacks alive)
+
+
+def set_gpu_allocator(alloc=None, free=None):
+    """nvinfer1::IGpuAllocator for the plugins' OWN device memory (packed weights, tables): alloc(bytes) -> address (0 = failure), free(address).
+    None, None restores hipMalloc / hipFree.  Tensors and workspaces stay the caller's."""
+    global _gpu_allocator
+    if alloc is None or free is None:
+        LIB.dsvtSetGpuAllocator(None, None, None); _gpu_allocator = None
+        return
+    a = GPU_ALLOC_FN(lambda n, _u: alloc(n)); f = GPU_FREE_FN(lambda p_, _u: free(p_))
+    _gpu_allocator = (a, f)
+    LIB.dsvtSetGpuAllocator(a, f, None)
 
 
 def plugin_types():

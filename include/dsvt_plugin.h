@@ -206,6 +206,16 @@ void dsvtPluginDestroy(DsvtPlugin* p);
  * 0 because every consumer honours the device-side counts. */
 void dsvtPluginSetZeroFill(DsvtPlugin* p, int32_t enable);
 
+/* Device memory of the plugins' OWN state (packed weights, tables, LayerNorm parameters): the reference allocates it with cudaMalloc in the plugin
+ * constructor (plugins/src/layerNorm.cu:150-155) and TensorRT lets a host replace the allocator of an engine's memory through nvinfer1::IGpuAllocator
+ * (IBuilder::setGpuAllocator / IRuntime::setGpuAllocator).  Same idea: after dsvtSetGpuAllocator(alloc, free, user) every plugin created or deserialized
+ * takes its device memory from alloc(bytes, user) (NULL = failure; 256-byte alignment expected) and returns it through free(ptr, user); NULL, NULL
+ * restores hipMalloc / hipFree.  Memory is always released by the allocator it came from.  Tensors and workspaces stay the caller's, as in the
+ * reference.  (tests/test_guard_pages_gpu.py puts unmapped guard pages around these buffers too.) */
+typedef void* (*DsvtGpuAllocFn)(size_t bytes, void* user);
+typedef void (*DsvtGpuFreeFn)(void* ptr, void* user);
+void dsvtSetGpuAllocator(DsvtGpuAllocFn alloc, DsvtGpuFreeFn free_, void* user);
+
 /* Library build info ("gfx950 ...") */
 const char* dsvtGetBuildInfo(void);
 

@@ -11,6 +11,19 @@ if os.environ.get("DSVT_GUARD_OFF", "0") == "0":
     torch.cuda.memory.change_current_allocator(alloc)
 import __graft_entry__ as G
 pkg = G.load_package(); P = pkg.plugin
+if os.environ.get("DSVT_GUARD_OFF", "0") == "0" and os.environ.get("DSVT_GUARD_PLUGINS", "1") != "0":
+    # the torch allocator only covers TENSORS.  The plugins' own device memory (packed weights incl. their "+ slack" rows, position /
+    # scale tables, LayerNorm parameters, Map2Bev's coordinate list, the convolutions' zero rows) comes from the same guard allocator through
+    # dsvtSetGpuAllocator (the C ABI's IGpuAllocator): an LDS-DMA or prefetch that runs past the end of one of THOSE buffers dies on its guard page too
+    import ctypes as C
+    ga = C.CDLL(so)
+    ga.guard_malloc.restype = C.c_void_p; ga.guard_malloc.argtypes = [C.c_ssize_t, C.c_int, C.c_void_p]
+    ga.guard_free.restype = None; ga.guard_free.argtypes = [C.c_void_p, C.c_ssize_t, C.c_int, C.c_void_p]
+    n_plugin_blocks = [0]
+    def _alloc(n):
+        n_plugin_blocks[0] += 1
+        return ga.guard_malloc(n, 0, None)
+    P.set_gpu_allocator(_alloc, lambda p_: ga.guard_free(p_, 0, 0, None))
 trace = os.environ.get("DSVT_GUARD_TRACE", "0") != "0"
 if trace:        # name the plugin whose launch faults: synchronise after every enqueue
     call = P.Plugin.__call__
@@ -58,4 +71,4 @@ for mode in modes:
             import zlib
             print(f"mode {mode} frames {FB} cloud {j}: boxes {[int(c) for c in cnt]} crc {zlib.crc32(boxes.cpu().numpy().tobytes()):08x}", flush=True)
         del pipe
-print("GUARD-OK", flush=True)
+print("GUARD-OK", "plugin-owned blocks behind guard pages:", n_plugin_blocks[0] if "n_plugin_blocks" in dir() else 0, flush=True)

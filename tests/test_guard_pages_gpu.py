@@ -6,6 +6,8 @@ that side of ANY buffer -- inputs, outputs, workspaces, the pipeline's own tenso
 instead of landing unnoticed in a neighbouring block of the caching allocator (which is all test_no_plugin_writes_outside_its_buffers'
 0xA5 bands can see, and only for writes).  The children run the reference frames and the 180k-point cloud eagerly, one and four frames
 per forward, in the fp16 and the split-precision (fp32-grade) modes, once with the end of every buffer on a guard and once with its start.
+Since round 5 the plugins' own device memory (packed weights and their slack rows, tables, LayerNorm parameters ...) comes from the same allocator
+through the C ABI's dsvtSetGpuAllocator, so a prefetch or LDS-DMA past the end of one of those buffers is caught as well.
 A freed range is never mapped again (a use after free faults too; re-mapping a translated address is not safe on this stack: DESIGN 5)."""
 import os
 import subprocess
@@ -44,3 +46,5 @@ def test_no_kernel_of_the_frame_touches_memory_outside_its_buffers(mode, front):
     _build()
     r = _child([mode, "1,4"], env={"DSVT_GUARD_FRONT": str(front)})
     assert r.returncode == 0 and "GUARD-OK" in r.stdout, (r.stdout[-600:], r.stderr[-1200:])
+    # (round 5) the plugins' OWN device memory -- packed weights, tables, parameters -- sat behind guard pages too (dsvtSetGpuAllocator)
+    assert int(r.stdout.strip().splitlines()[-1].rsplit(":", 1)[1]) > 100, r.stdout[-300:]
