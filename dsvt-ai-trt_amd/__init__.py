@@ -11,6 +11,7 @@ CPU or PyTorch fallback for the product path.
 from . import plugin          # noqa: F401  (loads libdsvt_hip.so or raises)
 from . import synth           # noqa: F401
 from . import pipeline        # noqa: F401
+from . import pipeline3d      # noqa: F401
 from . import parallel        # noqa: F401
 from . import hostio          # noqa: F401
 from . import detect          # noqa: F401

@@ -25,6 +25,7 @@ SOURCES = [
     ("pfn.hip", ["-fno-honor-nans"]),
     ("decode.hip", []),
     ("nms.hip", ["-ffp-contract=off"]),
+    ("voxel_pool.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math",
           "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]

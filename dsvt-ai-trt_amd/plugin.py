@@ -491,6 +491,29 @@ def add_pillar_feature_net_op(max_pillars_num, weight0, bias0, weight1, bias1, p
         bias1=np.asarray(bias1, np.float32).reshape(-1), pack_small_pillars=int(bool(pack_small_pillars))), "pillar_feature_net_layer")
 
 
+def add_voxel_pool_op(max_voxel_num, max_pooled_num, sparse_shape, stride, frames=1):
+    """Stage reduction of a 3-D voxel DSVT, integer half (csrc/voxel_pool.hip; no reference counterpart: SURVEY 8f-4).  sparse_shape / stride: (x, y, z).
+    Inputs: coords [1,P,4] (b, z, y, x), count [1].  Outputs: pooled coords [1,P2,4] in ascending pooled-cell order, the child table [1,P2,pool_volume]
+    (input row per slot (x % sx) sy sz + (y % sy) sz + z % sz, -1 = empty), every voxel's pooled row [1,P,1], P2 [1], P2 x pool_volume [1]."""
+    f = dict(max_voxel_num=int(max_voxel_num), max_pooled_num=int(max_pooled_num), sparse_shape=[int(v) for v in sparse_shape], stride=[int(v) for v in stride])
+    if frames != 1:
+        f["frames"] = int(frames)
+    return Plugin("DsvtVoxelPoolPlugin", f, "voxel_pool_layer")
+
+
+def add_pool_gather_op(max_pooled_num, pool_volume, channel_num, pos_embedding):
+    """x [1,P,C], child table, P2 -> src [1,P2,C] = max over the pool_volume slots (empty slots count as zero rows), key input [1,P2*pv,C] = x + pos_embedding[slot],
+    value input [1,P2*pv,C] = x (csrc/voxel_pool.hip; upstream DSVT's prepool tensor)"""
+    return Plugin("DsvtPoolGatherPlugin", dict(max_pooled_num=int(max_pooled_num), pool_volume=int(pool_volume), channel_num=int(channel_num),
+                                               pos_embedding=np.asarray(pos_embedding, np.float32).reshape(-1)), "pool_gather_layer")
+
+
+def add_pool_attention_core_op(max_pooled_num, pool_volume, channel_num, num_heads):
+    """q [1,P2,C] (already scaled by 1 / sqrt(head_dim)), k, v [1,P2*pv,C], child table, P2 -> softmax over the non-empty slots, per head: [1,P2,C]"""
+    return Plugin("DsvtPoolAttentionCorePlugin", dict(max_pooled_num=int(max_pooled_num), pool_volume=int(pool_volume), channel_num=int(channel_num),
+                                                      num_heads=int(num_heads)), "pool_attention_core_layer")
+
+
 def add_rotated_nms_op(max_boxes=500, nms_thresh=0.01):
     """nms_cpu (include/helper.h:257-283) on the device.  Inputs: FilterBoxByScorePlugin's rows [1,K,9] and count [1].
     Outputs: kept rows [1,K,9] in score order, their input row numbers [1,K], count [1]."""

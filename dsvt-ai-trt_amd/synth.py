@@ -200,3 +200,33 @@ def read_wts(path):
             raw = bytes.fromhex("".join(parts[2:2 + n]))
             out[name] = np.frombuffer(raw, ">f4").astype(np.float32)
     return out
+
+
+def make_weights_3d(seed=4321, stages=2, pool_volumes=(4,)):
+    """Seeded random weights of a multi-stage 3-D voxel DSVT backbone (upstream DSVT's tensor names where the reference has none):
+    the pillar feature net, per stage one DSVT block (two encoder layers) with position-embedding MLPs over (x, y, z) in-window coordinates, and between
+    stages the attention-style stage reduction (in-proj / out-proj of an 8-head attention, a [pool_volume, C] position embedding, a LayerNorm)."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    C = C_MODEL
+    w["module.vfe.pfn_layers.0.linear.weight"] = _lin(rng, 96, 10); _bn(rng, w, "module.vfe.pfn_layers.0.norm", 96)
+    w["module.vfe.pfn_layers.1.linear.weight"] = _lin(rng, C, C); _bn(rng, w, "module.vfe.pfn_layers.1.norm", C)
+    for s_ in range(stages):
+        for l in range(2):
+            p = f"module.backbone_3d.input_layer.posembed_layers.{s_}.0.{l}.position_embedding_head"
+            w[p + ".0.weight"] = _lin(rng, C, 3); w[p + ".0.bias"] = _bias(rng, C); _bn(rng, w, p + ".1", C)
+            w[p + ".3.weight"] = _lin(rng, C, C); w[p + ".3.bias"] = _bias(rng, C)
+            p = f"module.backbone_3d.stage_{s_}.0.encoder_list.{l}"
+            w[p + ".win_attn.self_attn.in_proj_weight"] = _lin(rng, 3 * C, C); w[p + ".win_attn.self_attn.in_proj_bias"] = _bias(rng, 3 * C)
+            w[p + ".win_attn.self_attn.out_proj.weight"] = _lin(rng, C, C); w[p + ".win_attn.self_attn.out_proj.bias"] = _bias(rng, C)
+            w[p + ".win_attn.linear1.weight"] = _lin(rng, C_FFN, C); w[p + ".win_attn.linear1.bias"] = _bias(rng, C_FFN)
+            w[p + ".win_attn.linear2.weight"] = _lin(rng, C, C_FFN); w[p + ".win_attn.linear2.bias"] = _bias(rng, C)
+            _ln(rng, w, p + ".win_attn.norm1", C); _ln(rng, w, p + ".win_attn.norm2", C); _ln(rng, w, p + ".norm", C)
+        _ln(rng, w, f"module.backbone_3d.residual_norm_stage_{s_}.0", C)
+        if s_ + 1 < stages:
+            p = f"module.backbone_3d.stage_{s_}_reduction"
+            w[p + ".self_attn.in_proj_weight"] = _lin(rng, 3 * C, C); w[p + ".self_attn.in_proj_bias"] = _bias(rng, 3 * C)
+            w[p + ".self_attn.out_proj.weight"] = _lin(rng, C, C); w[p + ".self_attn.out_proj.bias"] = _bias(rng, C)
+            w[p + ".pos_embedding"] = (rng.standard_normal((pool_volumes[s_], C)) * 0.5).astype(np.float32)     # (upstream initialises at std 0.01; 0.5 makes a wrong slot order visible)
+            _ln(rng, w, p + ".norm", C)
+    return w

@@ -142,7 +142,8 @@ def dsvt_layer(x, x_pos, gs, axis, P, w, prefix, cfg):
     return O.layer_norm(s2 + x, P, w[prefix + ".norm.weight"], w[prefix + ".norm.bias"], cfg.ln_eps)                 # :691-697
 
 
-def dsvt_blocks(st, w, cfg, nblocks=None, trace=None):
+def dsvt_blocks(st, w, cfg, nblocks=None, trace=None, stage=0):
+    """stage: which stage's weights (`stage_{stage}` / `residual_norm_stage_{stage}`); the reference has stage 0 only (src/dsvt-ai-trt.cpp:653-756)"""
     x = st["vfeat"].copy()
     P = st["P"]
     x[P:] = 0
@@ -150,11 +151,11 @@ def dsvt_blocks(st, w, cfg, nblocks=None, trace=None):
         xb = x
         gs = st["gss"][b % 2]
         for l in range(2):
-            x = dsvt_layer(x, st["pe"][(b, l)], gs, l, P, w, f"module.backbone_3d.stage_0.{b}.encoder_list.{l}", cfg)
+            x = dsvt_layer(x, st["pe"][(b, l)], gs, l, P, w, f"module.backbone_3d.stage_{stage}.{b}.encoder_list.{l}", cfg)
             if trace is not None:
                 trace[(b, l)] = x.copy()
-        x = O.layer_norm(x + xb, P, w[f"module.backbone_3d.residual_norm_stage_0.{b}.weight"],
-                         w[f"module.backbone_3d.residual_norm_stage_0.{b}.bias"], cfg.ln_eps)       # :750-756
+        x = O.layer_norm(x + xb, P, w[f"module.backbone_3d.residual_norm_stage_{stage}.{b}.weight"],
+                         w[f"module.backbone_3d.residual_norm_stage_{stage}.{b}.bias"], cfg.ln_eps)       # :750-756
         if trace is not None:
             trace[(b, "res")] = x.copy()
     return x
@@ -233,3 +234,98 @@ def forward(points, n, w, cfg, trace=None):
     if trace is not None:
         trace["state"], trace["x"], trace["heads"], trace["pp"] = st, x, heads, pp
     return boxes, cnt
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# stage reduction of a multi-stage 3-D voxel DSVT.  NOT in the reference (its voxel z index is forced to 0,
+# plugins/src/points2Features.cu:689-690,755): this restates UPSTREAM DSVT's published semantics (DSVTInputLayer pooling indices +
+# Stage_ReductionAtt_Block: MaxPool1d query, nn.MultiheadAttention(query, prepool + pos_embedding, prepool, key_padding_mask), residual,
+# LayerNorm) and is PARITY-UNPINNED: nothing the reference holds can confirm it.
+# ---------------------------------------------------------------------------------------------------------------------
+def pool_partition(coords, P, sparse_shape, stride):
+    """coords [.., 4] (b, z, y, x) of the P voxels of a stage (any order) -> (pooled coords [P2, 4] ascending by pooled cell key (b, z, y, x),
+    child table [P2, pool_volume] (input row or -1), parent [P]).  Slot of a child: (x % sx) sy sz + (y % sy) sz + z % sz (upstream's voxel_index_in_win)."""
+    gx, gy, gz = sparse_shape; sx, sy, sz = stride
+    c = np.asarray(coords[:P], np.int64)
+    px, py, pz = -(-gx // sx), -(-gy // sy), -(-gz // sz)
+    z2, y2, x2 = c[:, 1] // sz, c[:, 2] // sy, c[:, 3] // sx
+    key = ((c[:, 0] * pz + z2) * py + y2) * px + x2
+    uniq, parent = np.unique(key, return_inverse=True)
+    pv = sx * sy * sz
+    slot = ((c[:, 3] % sx) * sy + (c[:, 2] % sy)) * sz + (c[:, 1] % sz)
+    table = np.full((len(uniq), pv), -1, np.int32)
+    table[parent, slot] = np.arange(P, dtype=np.int32)
+    coords2 = np.zeros((len(uniq), 4), np.int32)
+    coords2[:, 3] = uniq % px; coords2[:, 2] = (uniq // px) % py; coords2[:, 1] = (uniq // (px * py)) % pz; coords2[:, 0] = uniq // (px * py * pz)
+    return coords2, table, parent.astype(np.int32)
+
+
+def stage_reduction_att(x, table, w, prefix, num_heads=8, eps=1e-5):
+    """x [P, C] voxel features, table [P2, pv] -> pooled features [P2, C] (Stage_ReductionAtt_Block.forward)"""
+    xt = T(np.asarray(x, np.float32))
+    tb = torch.from_numpy(np.asarray(table, np.int64))
+    P2, pv = tb.shape
+    C = xt.shape[1]
+    pre = torch.zeros((P2, pv, C), dtype=torch.float32)
+    valid = tb >= 0
+    pre[valid] = xt[tb[valid]]
+    src = pre.max(dim=1).values                                              # MaxPool1d(pool_volume): the zero rows of empty slots take part
+    key = pre + T(w[prefix + ".pos_embedding"])[None]
+    wi, bi = T(w[prefix + ".self_attn.in_proj_weight"]), T(w[prefix + ".self_attn.in_proj_bias"])
+    hd = C // num_heads
+    q = (F.linear(src, wi[:C], bi[:C]) / float(np.sqrt(hd))).reshape(P2, num_heads, hd)
+    k = F.linear(key, wi[C:2 * C], bi[C:2 * C]).reshape(P2, pv, num_heads, hd)
+    v = F.linear(pre, wi[2 * C:], bi[2 * C:]).reshape(P2, pv, num_heads, hd)
+    sc = torch.einsum("phd,pjhd->phj", q, k)
+    sc = sc.masked_fill(~valid[:, None, :], float("-inf"))
+    a = torch.softmax(sc, dim=-1)
+    ctx = torch.einsum("phj,pjhd->phd", a, v).reshape(P2, C)
+    out = F.linear(ctx, T(w[prefix + ".self_attn.out_proj.weight"]), T(w[prefix + ".self_attn.out_proj.bias"]))
+    y = F.layer_norm(src + out, (C,), T(w[prefix + ".norm.weight"]), T(w[prefix + ".norm.bias"]), eps)
+    return np_(y)
+
+
+def backbone_3d(points, n, w, grid, voxel_size, windows, strides, max_points, max_voxels, max_win, max_sets, trace=None):
+    """The multi-stage 3-D voxel backbone dsvt-ai-trt_amd/pipeline3d.py builds, on the CPU: z-aware Points2Features + PFN (restated reference kernels),
+    per stage WindowPartition / GetSet / one DSVT block (restated reference kernels and layers) with a position-embedding MLP over (x, y, z), and
+    between stages pool_partition + stage_reduction_att (upstream semantics, parity-unpinned).  Returns (features [P_last, C], coords [P_last, 4])."""
+    MP = max_voxels
+    p2f = dict(max_points_num=max_points, max_points_num_voxel_filter=max_points, max_pillars_num=MP, point_feature_num=4, feature_num=10,
+               max_num_points_per_voxel=48, point_cloud_range=[-74.88, -74.88, -5.0, 74.88, 74.88, 3.0], voxel_size=list(voxel_size), grid_size=list(grid))
+    v = O.points2features(points, n, p2f)
+    P, Nk = v["P"], v["Nk"]
+    x0 = fc_bn_relu(T(v["feat"][:Nk]), w, "module.vfe.pfn_layers.0.linear", "module.vfe.pfn_layers.0.norm")
+    x0p = np.zeros((max_points, 96), np.float32); x0p[:Nk] = np_(x0)
+    mp0, _ = O.scatter_max(x0p, v["pidx"], v["pcnt"], P, max_points, MP, 96)
+    x1 = fc_bn_relu(torch.cat([x0, T(mp0[:Nk])], 1), w, "module.vfe.pfn_layers.1.linear", "module.vfe.pfn_layers.1.norm")
+    x1p = np.zeros((max_points, 192), np.float32); x1p[:Nk] = np_(x1)
+    _, x = O.scatter_max(x1p, v["pidx"], v["pcnt"], P, max_points, MP, 192)
+    coords = v["coords"].astype(np.int32)
+    g = tuple(grid)
+    cfg = OracleCfg(max_pillars=MP, blocks=1)
+    for s_, win in enumerate(windows):
+        wx, wy, wz = win
+        wcfg = dict(max_win_num=max_win, max_voxel_num_per_win=wx * wy * wz, sparse_shape=list(g), win_shape=list(win), shift_list=[0, 0, 0], max_pillars_num=MP)
+        wp = O.window_partition(coords.view(np.uint32) if coords.dtype != np.uint32 else coords, P, wcfg)
+        gs = O.get_set(wp["gidx"], wp["cinw"], wp["vcnt"], wp["W"], dict(max_win_num=max_sets, max_voxel_num_per_win=wx * wy * wz, voxel_num_set=36, win_shape=list(win)))
+        c2d = wp["c2d"][:P].astype(np.float32)                                 # (z, y, x) inside the window
+        xyz = np.stack([c2d[:, 2] - wx / 2, c2d[:, 1] - wy / 2, c2d[:, 0] - wz / 2], 1).astype(np.float32)
+        pe = {}
+        for l in range(2):
+            full = np.zeros((MP, 192), np.float32)
+            full[:P] = np_(posembed(T(xyz), w, f"module.backbone_3d.input_layer.posembed_layers.{s_}.0.{l}.position_embedding_head"))
+            pe[(0, l)] = full
+        xin = np.zeros((MP, 192), np.float32); xin[:P] = x[:P]
+        x = dsvt_blocks(dict(vfeat=xin, P=P, gss=[gs, gs], pe=pe), w, cfg, nblocks=1, stage=s_)
+        if trace is not None:
+            trace[("block", s_)] = (x[:P].copy(), dict(S=gs["S"], W=wp["W"], inds=gs["inds"], c2d=wp["c2d"]))
+        if s_ < len(strides):
+            coords2, table, parent = pool_partition(coords, P, g, strides[s_])
+            x = stage_reduction_att(x[:P], table, w, f"module.backbone_3d.stage_{s_}_reduction")
+            if trace is not None:
+                trace[("pool", s_)] = (x.copy(), coords2.copy(), table.copy(), parent.copy())
+            P = len(coords2)
+            coords = np.zeros((MP, 4), np.int32); coords[:P] = coords2
+            sx, sy, sz = strides[s_]
+            g = (-(-g[0] // sx), -(-g[1] // sy), -(-g[2] // sz))
+    return x[:P], coords[:P]

@@ -87,3 +87,26 @@ def test_nms_float_overloads_against_correctly_rounded_trig(oracle):
         k0 = oracle.nms_cpu(b, 150, 0.01, trig="ref")[1]; k1 = oracle.nms_cpu(b, 150, 0.01, trig="cr")[1]
         differ += not np.array_equal(k0, k1)
     assert differ <= 1, differ
+
+
+def test_pool_partition_properties():
+    """oracle/dense_ref.pool_partition (the checker of DsvtVoxelPoolPlugin; upstream DSVT's stage-reduction indices, no reference counterpart): every voxel is
+    the child of exactly one pooled voxel, in the slot its in-pool coordinates name; pooled voxels ascend by (b, z, y, x); an identity stride changes nothing"""
+    from oracle import dense_ref as D
+    rng = np.random.default_rng(3)
+    g = (40, 36, 16)
+    cells = rng.choice(g[0] * g[1] * g[2], 5000, replace=False)
+    coords = np.zeros((6000, 4), np.int32)
+    coords[:5000, 3] = cells % g[0]; coords[:5000, 2] = (cells // g[0]) % g[1]; coords[:5000, 1] = cells // (g[0] * g[1])
+    for stride in ((1, 1, 4), (2, 2, 2), (4, 3, 1)):
+        c2, tab, par = D.pool_partition(coords, 5000, g, stride)
+        sx, sy, sz = stride
+        assert tab.shape == (len(c2), sx * sy * sz) and (tab >= 0).sum() == 5000 and len(set(tab[tab >= 0].tolist())) == 5000
+        key = (c2[:, 1].astype(np.int64) * 1000 + c2[:, 2]) * 1000 + c2[:, 3]
+        assert np.all(np.diff(key) > 0)
+        for i in rng.integers(0, 5000, 200):
+            z, y, x = coords[i, 1:]
+            r = par[i]
+            assert tuple(c2[r, 1:]) == (z // sz, y // sy, x // sx) and tab[r, ((x % sx) * sy + (y % sy)) * sz + z % sz] == i
+    c2, tab, par = D.pool_partition(coords[rng.permutation(5000)], 5000, g, (1, 1, 1))
+    assert len(c2) == 5000 and tab.shape == (5000, 1)
