@@ -1185,6 +1185,9 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                 if constexpr (SPL) {
                     // split precision: the residual is hi + lo (two planes), the result leaves as three planes; TWO blocks at a time (with four, the
                     // residual loads plus the hi / lo planes in flight spill 30 registers of the main loop's accumulators; with two, 10)
+                    // (Round 5 software-pipelined this loop -- round k + 1's residual rows requested before round k is added and stored --: no gain on the
+                    // residual layers (953 / 947 vs 964 / 950 us at 468 x 468, tools/conv_layers.py) and 34 spilled registers that cost the layers WITHOUT a residual
+                    // 5 %.  The 160 us a residual costs such a layer are not eight exposed latencies, they are 448 MB read by all CUs at once at item end.)
                     constexpr int RS = RB / 4 > 0 ? RB / 4 : 1;
                     const bool splitRes = hasRes && a.res_split != 0, resX8 = splitRes && a.res_x8 != 0;
 #pragma unroll
