@@ -12,8 +12,10 @@
 //   DsvtVoxelPoolPlugin          integer: pooled coordinates in canonical (ascending pooled cell key) order, the [P2, pool_volume] child table,
 //                                every voxel's pooled row, the counts P2 and P2 x pool_volume -- an occupancy bitmap of the pooled grid, one
 //                                single-workgroup popcount scan, one ranking pass: no sort, no dense table of rows (219 KB of bitmap at 468 x 468 x 8)
-//   DsvtPoolGatherPlugin         x [P, C], child table -> src [P2, C], key input [P2 pv, C] = x + pos, value input [P2 pv, C]
-//   DsvtPoolAttentionCorePlugin  q [P2, C], k, v [P2 pv, C], child table -> softmax(q k^T / masked) v per head: one wavefront per pooled voxel
+//   DsvtPoolGatherPlugin         x [P, C], child table -> src [P2, C] (the max query) and the key input [P, C] = x + pos_embedding[slot of the voxel], per INPUT voxel:
+//                                upstream materialises a [P2, pool_volume, C] tensor and projects all of it; the empty slots' keys and values are masked out of the
+//                                softmax anyway, so K and V are projected for the P real voxels only (a third of the rows at stride (1, 1, 4)) -- the value input is x itself
+//   DsvtPoolAttentionCorePlugin  q [P2, C], k, v [P, C], child table -> softmax(q k^T over the pool's children) v per head: one wavefront per pooled voxel
 #include "plugin_base.h"
 #include "device_utils.h"
 
@@ -184,7 +186,7 @@ static Registrar g_vpReg(&g_vpCreator);
 // =====================================================================================================================
 __global__ void __launch_bounds__(256)
 pool_gather_kernel(const float4* __restrict__ x, const int32_t* __restrict__ pool_inds, const uint32_t* __restrict__ pooled_num, const float4* __restrict__ pos,
-                   int pv, int G, int max_pooled, float4* __restrict__ src, float4* __restrict__ kin, float4* __restrict__ vin)
+                   int pv, int G, int max_pooled, float4* __restrict__ src, float4* __restrict__ kin)
 {
     const uint32_t n = min(*pooled_num, (uint32_t)max_pooled);
     const size_t total = (size_t)n * G;
@@ -194,10 +196,11 @@ pool_gather_kernel(const float4* __restrict__ x, const int32_t* __restrict__ poo
         for (int j = 0; j < pv; ++j) {
             const int32_t row = pool_inds[r * pv + j];
             const float4 v = row >= 0 ? x[(size_t)row * G + c] : make_float4(0.f, 0.f, 0.f, 0.f);      // empty slot = the zero row of upstream's preholder tensor
-            const float4 pe = pos[(size_t)j * G + c];
             m = make_float4(fmaxf(m.x, v.x), fmaxf(m.y, v.y), fmaxf(m.z, v.z), fmaxf(m.w, v.w));
-            kin[(r * pv + j) * G + c] = make_float4(v.x + pe.x, v.y + pe.y, v.z + pe.z, v.w + pe.w);
-            vin[(r * pv + j) * G + c] = v;
+            if (row >= 0) {                                                                // key input of child `row` (every voxel is the child of exactly one pool)
+                const float4 pe = pos[(size_t)j * G + c];
+                kin[(size_t)row * G + c] = make_float4(v.x + pe.x, v.y + pe.y, v.z + pe.z, v.w + pe.w);
+            }
         }
         src[i] = m;
     }
@@ -205,29 +208,30 @@ pool_gather_kernel(const float4* __restrict__ x, const int32_t* __restrict__ poo
 
 class DsvtPoolGatherPlugin : public Plugin {
 public:
-    int max_pooled_, pv_, C_; std::vector<float> pos_; float* pos_dev_ = nullptr; bool ok_ = true;
+    int max_pooled_, pv_, C_;      // (output 1 has the row capacity of input 0: one key-input row per input voxel)
+    std::vector<float> pos_; float* pos_dev_ = nullptr; bool ok_ = true;
     DsvtPoolGatherPlugin(int mp, int pv, int c, const float* pos) : max_pooled_(mp), pv_(pv), C_(c), pos_(pos, pos + (size_t)pv * c) {
         ok_ = dsvtMalloc(&pos_dev_, sizeof(float) * pos_.size()) == hipSuccess && hipMemcpy(pos_dev_, pos_.data(), sizeof(float) * pos_.size(), hipMemcpyHostToDevice) == hipSuccess;
     }
     ~DsvtPoolGatherPlugin() override { if (pos_dev_) (void)dsvtFree(pos_dev_); }
     const char* type() const override { return "DsvtPoolGatherPlugin"; }
-    int nbOutputs() const override { return 3; }
+    int nbOutputs() const override { return 2; }
     int outputDims(int i, const DsvtDims* in, int, DsvtDims* out) const override {
-        if (i < 0 || i > 2) return -1;
-        *out = dims3(in[0].d[0], i == 0 ? max_pooled_ : max_pooled_ * pv_, C_); return 0;
+        if (i < 0 || i > 1) return -1;
+        *out = dims3(in[0].d[0], i == 0 ? max_pooled_ : in[0].d[1], C_); return 0;
     }
     int outputType(int, const int32_t*, int) const override { return DSVT_FLOAT; }
-    bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int, int) const override { return (pos == 1 || pos == 2) ? vpI32(io[pos]) : pos >= 0 && pos <= 5 && vpF32(io[pos]); }
+    bool supportsFormat(int pos, const DsvtPluginTensorDesc* io, int, int) const override { return (pos == 1 || pos == 2) ? vpI32(io[pos]) : pos >= 0 && pos <= 4 && vpF32(io[pos]); }
     size_t workspaceSize(const DsvtPluginTensorDesc*, int, const DsvtPluginTensorDesc*, int) const override { return 0; }
-    int enqueue(const DsvtPluginTensorDesc*, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void*, hipStream_t stream) override {
+    int enqueue(const DsvtPluginTensorDesc* inDesc, const DsvtPluginTensorDesc*, const void* const* in, void* const* out, void*, hipStream_t stream) override {
         if (!ok_) return static_cast<int>(hipErrorOutOfMemory);
         if (zeroFill) {
             DSVT_CHECK(hipMemsetAsync(out[0], 0, sizeof(float) * (size_t)max_pooled_ * C_, stream));
-            for (int i = 1; i < 3; ++i) DSVT_CHECK(hipMemsetAsync(out[i], 0, sizeof(float) * (size_t)max_pooled_ * pv_ * C_, stream));
+            if (inDesc) DSVT_CHECK(hipMemsetAsync(out[1], 0, sizeof(float) * (size_t)inDesc[0].dims.d[1] * C_, stream));
         }
         hipLaunchKernelGGL(pool_gather_kernel, dim3(2048), dim3(256), 0, stream, static_cast<const float4*>(in[0]), static_cast<const int32_t*>(in[1]),
                            static_cast<const uint32_t*>(in[2]), reinterpret_cast<const float4*>(pos_dev_), pv_, C_ / 4, max_pooled_,
-                           static_cast<float4*>(out[0]), static_cast<float4*>(out[1]), static_cast<float4*>(out[2]));
+                           static_cast<float4*>(out[0]), static_cast<float4*>(out[1]));
         return lastError();
     }
     size_t serializationSize() const override { return 3 * sizeof(int) + sizeof(float) * pos_.size(); }
@@ -258,7 +262,7 @@ static Creator g_pgCreator{"DsvtPoolGatherPlugin",
 static Registrar g_pgReg(&g_pgCreator);
 
 // =====================================================================================================================
-// DsvtPoolAttentionCorePlugin: one query, pool_volume keys, H heads per pooled voxel -- one wavefront per voxel, lane l owns channels
+// DsvtPoolAttentionCorePlugin: one query, <= pool_volume keys (the children's rows of k / v, through the child table), H heads per pooled voxel -- one wavefront per voxel, lane l owns channels
 // (C / 64) l .. : a head's dot product is a reduction over the 64 / H consecutive lanes that hold its channels
 // =====================================================================================================================
 template <int CPL>      // channels per lane (C = 64 CPL)
@@ -280,8 +284,9 @@ pool_attention_kernel(const float* __restrict__ q, const float* __restrict__ k, 
         // with key_padding_mask: masked keys get -inf, i.e. weight 0)
         for (int pass = 0; pass < 2; ++pass)
             for (int j = 0; j < pv; ++j) {
-                if (pool_inds[(size_t)r * pv + j] < 0) continue;                      // (wave-uniform)
-                const float* kr = k + ((size_t)r * pv + j) * C + lane * CPL;
+                const int32_t row = pool_inds[(size_t)r * pv + j];
+                if (row < 0) continue;                                                 // (wave-uniform) an empty slot: masked out of the softmax
+                const float* kr = k + (size_t)row * C + lane * CPL;
                 float s = 0.f;
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) s += qv[c] * kr[c];
@@ -290,7 +295,7 @@ pool_attention_kernel(const float* __restrict__ q, const float* __restrict__ k, 
                 else {
                     const float e = expf(s - mx);
                     den += e;
-                    const float* vr = v + ((size_t)r * pv + j) * C + lane * CPL;
+                    const float* vr = v + (size_t)row * C + lane * CPL;
 #pragma unroll
                     for (int c = 0; c < CPL; ++c) acc[c] += e * vr[c];
                 }

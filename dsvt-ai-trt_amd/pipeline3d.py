@@ -13,7 +13,7 @@ oracle/; features against oracle/dense_ref.py's restatement of the same publishe
     stage s = 0 ..:
         WindowPartition(window_s) -> GetSet(36)
         2 x [ QKV linear with the stage's position table | set attention | out-proj + LN, FFN + LN + LN (+ block LN) ]
-        s < last: DsvtVoxelPool(stride_s) -> DsvtPoolGather -> Q / K / V linears -> DsvtPoolAttentionCore -> out-proj + residual + LayerNorm
+        s < last: DsvtVoxelPool(stride_s) -> DsvtPoolGather -> Q (pooled rows) / K / V (input rows) linears -> DsvtPoolAttentionCore -> out-proj + residual + LayerNorm
 Every op is enqueued on the current stream; counts stay on the device.  Arithmetic: the fp32-grade split precision of the pillar frame ((hi, lo) fp16 operand
 pairs, three MFMAs per product) in every GEMM but the stage reduction's out-projection, whose residual + LayerNorm epilogue lives on the exact-fp32 linear."""
 import math
@@ -82,8 +82,8 @@ class Dsvt3dBackbone:
                 st["pool"] = P.add_voxel_pool_op(MP, MP, g, (sx, sy, sz))
                 st["gather"] = P.add_pool_gather_op(MP, pv, C, w[rp + ".pos_embedding"])
                 st["q"] = P.add_linear_op(wi[:C], bi[:C], MP, compute_type=ct)
-                st["k"] = P.add_linear_op(wi[C:2 * C], bi[C:2 * C], MP * pv, compute_type=ct)
-                st["v"] = P.add_linear_op(wi[2 * C:], bi[2 * C:], MP * pv, compute_type=ct)
+                st["k"] = P.add_linear_op(wi[C:2 * C], bi[C:2 * C], MP, compute_type=ct)       # (K and V per INPUT voxel: empty slots are masked out of the softmax anyway)
+                st["v"] = P.add_linear_op(wi[2 * C:], bi[2 * C:], MP, compute_type=ct)
                 st["core"] = P.add_pool_attention_core_op(MP, pv, C, H)
                 st["o"] = P.add_linear_op(w[rp + ".self_attn.out_proj.weight"], w[rp + ".self_attn.out_proj.bias"], MP,      # (exact fp32: the LayerNorm epilogue)
                                           layer_norms=[(w[rp + ".norm.weight"], w[rp + ".norm.bias"])], ln_eps=reduction_eps)
@@ -103,10 +103,10 @@ class Dsvt3dBackbone:
 
     def reduce(self, st, x, coords, Pn):
         coords2, table, parent, P2, rows = st["pool"](coords, Pn)
-        src, kin, vin = st["gather"](x, table, P2)
+        src, kin = st["gather"](x, table, P2)
         q = st["q"](src, P2)[0]
-        k = st["k"](kin, rows)[0]
-        v = st["v"](vin, rows)[0]
+        k = st["k"](kin, Pn)[0]
+        v = st["v"](x, Pn)[0]
         ctx = st["core"](q, k, v, table, P2)[0]
         y = st["o"](ctx, P2, src)[0]
         return y, coords2, P2, dict(table=table, parent=parent)

@@ -502,14 +502,14 @@ def add_voxel_pool_op(max_voxel_num, max_pooled_num, sparse_shape, stride, frame
 
 
 def add_pool_gather_op(max_pooled_num, pool_volume, channel_num, pos_embedding):
-    """x [1,P,C], child table, P2 -> src [1,P2,C] = max over the pool_volume slots (empty slots count as zero rows), key input [1,P2*pv,C] = x + pos_embedding[slot],
-    value input [1,P2*pv,C] = x (csrc/voxel_pool.hip; upstream DSVT's prepool tensor)"""
+    """x [1,P,C], child table, P2 -> src [1,P2,C] = max over the pool_volume slots (empty slots count as zero rows) and the key input [1,P,C] =
+    x + pos_embedding[slot of the voxel in its pool] per INPUT voxel (the value input is x itself; csrc/voxel_pool.hip)"""
     return Plugin("DsvtPoolGatherPlugin", dict(max_pooled_num=int(max_pooled_num), pool_volume=int(pool_volume), channel_num=int(channel_num),
                                                pos_embedding=np.asarray(pos_embedding, np.float32).reshape(-1)), "pool_gather_layer")
 
 
 def add_pool_attention_core_op(max_pooled_num, pool_volume, channel_num, num_heads):
-    """q [1,P2,C] (already scaled by 1 / sqrt(head_dim)), k, v [1,P2*pv,C], child table, P2 -> softmax over the non-empty slots, per head: [1,P2,C]"""
+    """q [1,P2,C] (already scaled by 1 / sqrt(head_dim)), k, v [1,P,C] (per input voxel), child table, P2 -> softmax over the pool's children, per head: [1,P2,C]"""
     return Plugin("DsvtPoolAttentionCorePlugin", dict(max_pooled_num=int(max_pooled_num), pool_volume=int(pool_volume), channel_num=int(channel_num),
                                                       num_heads=int(num_heads)), "pool_attention_core_layer")
 

@@ -187,10 +187,10 @@ def test_stage_reduction_attention_against_oracle(pkg, oracle, grid3d, stride, s
     scale = np.float32(np.sqrt(C / 8))
     wi, bi = w["red.self_attn.in_proj_weight"].copy(), w["red.self_attn.in_proj_bias"].copy()
     wi[:C] /= scale; bi[:C] /= scale
-    src, kin, vin = P.add_pool_gather_op(MP, pv, C, w["red.pos_embedding"])(x, table, P2)
+    src, kin = P.add_pool_gather_op(MP, pv, C, w["red.pos_embedding"])(x, table, P2)
     q = P.add_linear_op(wi[:C], bi[:C], MP, compute_type=ct)(src, P2)[0]
-    k = P.add_linear_op(wi[C:2 * C], bi[C:2 * C], MP * pv, compute_type=ct)(kin, rows)[0]
-    v = P.add_linear_op(wi[2 * C:], bi[2 * C:], MP * pv, compute_type=ct)(vin, rows)[0]
+    k = P.add_linear_op(wi[C:2 * C], bi[C:2 * C], MP, compute_type=ct)(kin, g["Pn"])[0]           # K / V per INPUT voxel (the empty slots are masked anyway)
+    v = P.add_linear_op(wi[2 * C:], bi[2 * C:], MP, compute_type=ct)(x, g["Pn"])[0]
     ctx = P.add_pool_attention_core_op(MP, pv, C, 8)(q, k, v, table, P2)[0]
     y = P.add_linear_op(w["red.self_attn.out_proj.weight"], w["red.self_attn.out_proj.bias"], MP, layer_norms=[(w["red.norm.weight"], w["red.norm.bias"])], ln_eps=1e-5)(ctx, P2, src)[0]
     torch.cuda.synchronize()
