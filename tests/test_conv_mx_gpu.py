@@ -155,7 +155,13 @@ def test_three_plane_kernels_read_plane_0_for_an_x8_third_plane(pkg, H, W, cin, 
         # output where the dense walk of `old` sums (hi w_hi, lo w_hi, hi w_lo): the same products in another fp32 order)
         assert (old - new).abs().max().item() <= 2e-6 * old.abs().max().item()
         return
-    assert torch.equal(old[..., :2 * cout].view(torch.int16), new[..., :2 * cout].view(torch.int16))
+    if k == 1 and stride == 1:
+        # (round 5: split_input = 1 puts the 1 x 1 stride-1 layers on conv1x1_resident_split_kernel, which sums per k-step (hi w_hi, lo w_hi, hi w_lo) where the
+        # halo kernel of `old` sums plane by plane: the same products in another fp32 order)
+        vo = old[..., :cout].double() + old[..., cout:2 * cout].double(); vn = new[..., :cout].double() + new[..., cout:2 * cout].double()
+        assert (vo - vn).abs().max().item() <= 2e-6 * vo.abs().max().item()
+    else:
+        assert torch.equal(old[..., :2 * cout].view(torch.int16), new[..., :2 * cout].view(torch.int16))
     assert_x8_plane(new, cout)
 
 
