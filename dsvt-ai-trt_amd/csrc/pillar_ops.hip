@@ -449,11 +449,11 @@ map2bev_split_kernel(const float4* __restrict__ feat, const uint4* __restrict__ 
         mb_half4* cell = bev + (((size_t)co.x * gy + co.z) * gx + co.w) * 3 * G;
         mb_half4* o = cell + c;
         o[0] = hi; o[G] = lo;
-        if (x8) {       // third plane = the fp8 operands of the correction terms (conv.hip ConvArgs::x8_out): lo8 = e4m3(2^11 lo), hi8 = e4m3(v)
+        if (x8 > 0) {       // third plane = the fp8 operands of the correction terms (conv.hip ConvArgs::x8_out): lo8 = e4m3(2^11 lo), hi8 = e4m3(v)
             unsigned char* xp = reinterpret_cast<unsigned char*>(cell + 2 * G) + x8Offset(4 * c);
             *reinterpret_cast<unsigned*>(xp) = packE4m3((f[0] - (float)hi[0]) * 2048.f, (f[1] - (float)hi[1]) * 2048.f, (f[2] - (float)hi[2]) * 2048.f, (f[3] - (float)hi[3]) * 2048.f);
             *reinterpret_cast<unsigned*>(xp + 16) = packE4m3(f[0], f[1], f[2], f[3]);
-        } else o[2 * G] = hi;
+        } else if (x8 == 0) o[2 * G] = hi;          // (x8 < 0: [hi | lo | -], the third plane is left alone -- its readers alias plane 0: split_output 3)
     }
 }
 // persistent_output (round 4): the dense map is zero everywhere but at <= P cells, so when the caller keeps the SAME output buffer from call to call (this
@@ -484,7 +484,7 @@ map2bev_clear_kernel(const uint4* __restrict__ prev_coords, const unsigned long 
 class Map2BevPlugin : public Plugin {
 public:
     int max_pillars_num_, channel_num_, gx_, gy_, frames_ = 1;      // frames_ > 1 (field "frames"): coords.x selects one of `frames` stacked BEV maps
-    int split_ = 0;                                                 // field "split_output": fp32 rows -> fp16 [hi | lo | hi] planes (1) or [hi | lo | x8] (2), 3 C channels per cell
+    int split_ = 0;                                                 // field "split_output": fp32 rows -> fp16 [hi | lo | hi] planes (1), [hi | lo | x8] (2) or [hi | lo | -] (3: the third plane is not written), 3 C channels per cell
     int persistent_ = 0;                                            // field "persistent_output": see map2bev_clear_kernel
     uint4* prev_coords_ = nullptr; unsigned long long* prev_state_ = nullptr;      // device: the cells of the last EXECUTED call, {count, address of its map}
     Map2BevPlugin(int mp, int c, int gx, int gy, int frames = 1, int split = 0, int persistent = 0)
@@ -528,7 +528,7 @@ public:
             if (int rc = clearMap(out[0], (size_t)2 * gx_ * gy_ * 3 * channel_num_ * frames_, 2 * 3 * channel_num_, stream)) return rc;
             hipLaunchKernelGGL(map2bev_split_kernel, dim3(2048), dim3(256), 0, stream, static_cast<const float4*>(in[0]),
                                static_cast<const uint4*>(in[1]), static_cast<const uint32_t*>(in[2]), channel_num_ / 4, gx_, gy_, frames_,
-                               static_cast<mb_half4*>(out[0]), split_ == 2 ? 1 : 0, saves(6 * channel_num_) ? prev_coords_ : nullptr, saves(6 * channel_num_) ? prev_state_ : nullptr);
+                               static_cast<mb_half4*>(out[0]), split_ == 2 ? 1 : split_ == 3 ? -1 : 0, saves(6 * channel_num_) ? prev_coords_ : nullptr, saves(6 * channel_num_) ? prev_state_ : nullptr);
             return lastError();
         }
         const int esz = (inDesc && inDesc[0].type == DSVT_HALF) ? 2 : 4;
@@ -552,7 +552,7 @@ public:
     Plugin* clone() const override { return new Map2BevPlugin(max_pillars_num_, channel_num_, gx_, gy_, frames_, split_, persistent_); }
 };
 static Plugin* mbNew(int mp, int c, int gx, int gy, int frames = 1, int split = 0, int persistent = 0) {
-    if (split < 0 || split > 2 || (split == 2 && c % 32 != 0)) return nullptr;                 // 2: [hi | lo | x8], the x8 plane in 32-channel groups
+    if (split < 0 || split > 3 || (split == 2 && c % 32 != 0)) return nullptr;                 // 2: [hi | lo | x8], the x8 plane in 32-channel groups; 3: [hi | lo | -] (third plane untouched)
     return (mp > 0 && c > 0 && c % 4 == 0 && gx > 0 && gy > 0 && frames >= 1) ? new Map2BevPlugin(mp, c, gx, gy, frames, split, persistent != 0) : nullptr;
 }
 static Plugin* mbCreate(const DsvtPluginFieldCollection* fc) {

@@ -453,7 +453,7 @@ struct Engine {
     void buildHeadSplit(const WeightMap& w) {
         { Fields f; f.i("max_pillars_num", c.P).i("channel_num", C).i("grid_size_x", GX).i("grid_size_y", GY);
           if (frames != 1) f.i("frames", frames);
-          f.i("persistent_output", 1).i("split_output", mx() ? 2 : 1); map2bev = Op("Map2BevPlugin", f, "map2bev_layer"); }
+          f.i("persistent_output", 1).i("split_output", mx() ? 2 : 3); map2bev = Op("Map2BevPlugin", f, "map2bev_layer"); }
         const int blk[3][4] = {{192, 128, 1, 2}, {128, 128, 2, 3}, {128, 256, 2, 3}};
         int Hh = GY;
         for (int i = 0; i < 3; ++i) {

@@ -265,7 +265,7 @@ class DsvtPipeline:
         if with_head:
             self.split_head = head_dtype == torch.float32
             self.head_mx = self.head_mx and self.split_head
-            self.map2bev = P.add_map_2_bev_op(c.P, C, GX, GY, frames=self.frames, split_output=(2 if self.head_mx else 1) if self.split_head else 0,
+            self.map2bev = P.add_map_2_bev_op(c.P, C, GX, GY, frames=self.frames, split_output=(2 if self.head_mx else 3) if self.split_head else 0,      # (3: [hi | lo | -] -- every consumer aliases the third plane to plane 0)
                                                 persistent_output=persistent_bev)
             self.filter = P.add_filter_box_by_score_op(TOP_K, X_MIN, X_MAX, Y_MIN, Y_MAX, Z_MIN, Z_MAX, VX, VY, VZ, SCORE_THR)
             self.nms = P.add_rotated_nms_op(TOP_K, NMS_THRESH) if device_nms else None

@@ -430,7 +430,7 @@ def add_map_2_bev_op(max_pillars_num, channel_num, grid_size_x, grid_size_y, fra
     if persistent_output:
         extra["persistent_output"] = 1
     if split_output:
-        extra["split_output"] = int(split_output)           # 2: the third plane holds the fp8 operands (x8) instead of repeating hi
+        extra["split_output"] = int(split_output)           # 2: the third plane holds the fp8 operands (x8) instead of repeating hi; 3: it is not written at all
     return Plugin("Map2BevPlugin", dict(extra, max_pillars_num=max_pillars_num, channel_num=channel_num,
                                         grid_size_x=grid_size_x, grid_size_y=grid_size_y), "map2bev_layer")
 

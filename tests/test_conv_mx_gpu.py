@@ -178,6 +178,9 @@ def test_map2bev_writes_the_x8_plane(pkg):
     want = torch.zeros(1, GY, GX, C)
     want[0, coords[0, :n, 2].long(), coords[0, :n, 3].long()] = feat[0, :n]
     assert torch.equal(bev.view(torch.int16), make_triple(want).view(torch.int16))
+    # split_output = 3 (round 5, the default head's map): [hi | lo | -], the third plane stays as the fill left it (zeros)
+    bev3 = P.add_map_2_bev_op(1000, C, GX, GY, split_output=3)(feat.to(DEV), coords.to(DEV), cnt.to(DEV))[0].cpu()
+    assert torch.equal(bev3[..., :2 * C].view(torch.int16), bev[..., :2 * C].view(torch.int16)) and not bev3[..., 2 * C:].any()
 
 
 @pytest.mark.parametrize("H,W,B", [(468, 468, 1), (61, 45, 3), (7, 5, 2)])

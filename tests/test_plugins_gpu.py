@@ -395,7 +395,7 @@ def test_map2bev(pkg, oracle):
     assert np.array_equal(host(o[0])[0], O.map2bev(feat, vox["coords"], vox["P"], 468, 468))
 
 
-@pytest.mark.parametrize("split_output,frames", [(0, 1), (0, 3), (1, 1), (2, 2)])
+@pytest.mark.parametrize("split_output,frames", [(0, 1), (0, 3), (1, 1), (2, 2), (3, 1)])
 def test_map2bev_persistent_output_clears_what_the_last_call_wrote(pkg, split_output, frames):
     """persistent_output: a call zeroes only the cells the call before it wrote into the SAME buffer.  Six calls with different pillar sets and counts (one of
     them empty) on one set of input buffers (=> one cached output buffer), one call into another buffer in between (full fill, then incremental again on the
