@@ -883,6 +883,10 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     // first one left in LDS, (lo_q, w_hi): a third of the halo requests gone, same weights / MFMAs / fragment reads -- correct (tests pass) and SLOWER:
     // 11.15 vs 10.58 ms of convolutions per four-frame forward, 276 vs 285 frames/s.  Like round 4's re-ordered head-output kernel: a phase without halo
     // requests does not run faster, the bytes of the aliased plane -- an L2 hit -- were not what the kernel waits for.  The plain plane-order walk stays.)
+    // (Also round 5: the CT = 8 instantiations hold 256 registers with 34-46 spilled, and the hoisted lane shares of the trickled requests are reloaded from scratch
+    // inside the slab loop -- each reload waits with vmcnt(0), i.e. for every request in flight.  A loop without any scratch access (wave index in an SGPR, lane shares
+    // recomputed per request) was built: same results, 4-5 % SLOWER on the three-product 128-channel layers, neutral on the fp16 frame:
+    // profiles/r05_conv_dead_ends.txt.  The waits are not what this kernel loses time to.)
     const int perImg = nitems / a.nb;                             // items of one image (items walk image after image)
     auto decode = [&](int it, int& yy, int& xx, int& ch, int& bb) {
         bb = it / perImg; it -= bb * perImg;
