@@ -227,7 +227,18 @@ def cpp_host_mode(pkg, weights, clouds, repeat=12):
             m = re.search(r"([0-9.]+) ms per frame, ([0-9.]+) frames/s", r.stdout)
             out[key] = ({"ms_per_frame": float(m.group(1)), "value": float(m.group(2)), "unit": "frames/s"} if (r.returncode == 0 and m)
                         else {"error": (r.stdout + r.stderr)[-300:]})
-        out["note"] = "PCIe upload / download and the host's launch inside every figure; one forward in flight (the reference's loop is synchronous)"
+        # --in-flight 2: two engines on two streams, groups round-robin (the copies of one group under the forward of the other); sixteen files = the clouds four times
+        data2 = os.path.join(tmp, "data16"); os.makedirs(data2)
+        for j in range(16):
+            os.symlink(os.path.join(data, f"{j % len(clouds):06d}.bin"), os.path.join(data2, f"{j:06d}.bin"))
+        for key, extra in (("one_frame_per_forward_two_in_flight", ["--in-flight", "2"]), ("four_frames_per_forward_two_in_flight", ["--frames", "4", "--in-flight", "2"])):
+            o = os.path.join(tmp, "out_" + key); os.makedirs(o)
+            r = subprocess.run([exe, "--wts", wts, "--data", data2, "--out", o, "--repeat", "4"] + extra, capture_output=True, text=True, timeout=600)
+            m = re.search(r"([0-9.]+) ms per frame, ([0-9.]+) frames/s", r.stdout)
+            out[key] = ({"ms_per_frame": float(m.group(1)), "value": float(m.group(2)), "unit": "frames/s"} if (r.returncode == 0 and m)
+                        else {"error": (r.stdout + r.stderr)[-300:]})
+        out["note"] = ("PCIe upload / download and the host's launch inside every figure; the first two: one forward in flight (the reference's loop is synchronous), host clock around each group; "
+                       "*_two_in_flight: dsvt_detect --in-flight 2, wall clock of a whole pass over sixteen files (host copy into pinned memory inside too)")
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -547,8 +547,89 @@ static void saveTxt(const std::string& path, const float* rows, int k, double ms
     fclose(fh);
 }
 
+
+// --in-flight K (K > 1): K engines on K streams, the groups of `frames` frames go to them round-robin -- the upload of one group and the download of another's boxes
+// run under a third's forward.  The reference's loop (src/dsvt-ai-trt.cpp:1884-1970) is synchronous; this is the same forward per group (same kernels, same boxes: every
+// engine is the engine of the synchronous loop), only the waiting is taken out.  Timed: the LAST pass over the directory, wall clock from the first host copy to the last
+// download (frames cached in host memory after the first pass; the .txt files are written after the clock stops).
+static int runPipelined(const WeightMap& w, const Caps& caps, Mode mode, int frames, int inflight, bool graph, bool raw, int repeat,
+                        const std::string& data, const std::string& out, const std::vector<std::string>& files) {
+    struct Slot {
+        hipStream_t s = nullptr; std::unique_ptr<Engine> eng; hipGraphExec_t exec = nullptr;
+        float* hpts = nullptr; int* hcnt = nullptr; float* hrows = nullptr; int* hkept = nullptr;
+        long group = -1;                                                          // the group in flight on this slot, -1 = none
+    };
+    std::vector<Slot> slots(inflight);
+    for (Slot& sl : slots) {
+        HIP_OK(hipStreamCreate(&sl.s));
+        sl.eng.reset(new Engine(w, caps, sl.s, mode, frames));
+        for (int k = 0; k < 2; ++k) sl.eng->enqueue(sl.s);                        // warm-up on empty frames (sizes every buffer)
+        HIP_OK(hipStreamSynchronize(sl.s));
+        if (graph) {
+            hipGraph_t g;
+            HIP_OK(hipStreamBeginCapture(sl.s, hipStreamCaptureModeThreadLocal));
+            sl.eng->enqueue(sl.s);
+            HIP_OK(hipStreamEndCapture(sl.s, &g));
+            HIP_OK(hipGraphInstantiate(&sl.exec, g, nullptr, nullptr, 0));
+        }
+        HIP_OK(hipHostMalloc(&sl.hpts, (size_t)frames * caps.N * 16)); HIP_OK(hipHostMalloc(&sl.hcnt, 4 * frames));
+        HIP_OK(hipHostMalloc(&sl.hrows, (size_t)frames * TOP_K * 9 * 4)); HIP_OK(hipHostMalloc(&sl.hkept, 4 * frames));
+    }
+    const size_t nfile = files.size(), ngroup = (nfile + frames - 1) / frames;
+    std::vector<std::vector<float>> cache(nfile); std::vector<int> npts(nfile, 0);
+    std::vector<std::vector<float>> rows(nfile); std::vector<int> kept(nfile, 0);
+    auto collect = [&](Slot& sl) {                                                // wait for the slot's group and keep its boxes
+        if (sl.group < 0) return;
+        HIP_OK(hipStreamSynchronize(sl.s));
+        const size_t f0 = (size_t)sl.group * frames;
+        for (int f = 0; f < frames && f0 + f < nfile; ++f) {
+            kept[f0 + f] = sl.hkept[f];
+            rows[f0 + f].assign(sl.hrows + (size_t)f * TOP_K * 9, sl.hrows + (size_t)f * TOP_K * 9 + (size_t)sl.hkept[f] * 9);
+        }
+        sl.group = -1;
+    };
+    double lastMs = 0;
+    for (int r = 0; r < repeat; ++r) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (size_t g = 0; g < ngroup; ++g) {
+            Slot& sl = slots[g % inflight];
+            collect(sl);
+            const size_t f0 = g * frames;
+            const int nf = (int)std::min<size_t>(frames, nfile - f0);
+            for (int f = 0; f < frames; ++f) sl.hcnt[f] = 0;
+            for (int f = 0; f < nf; ++f) {
+                if (cache[f0 + f].empty()) cache[f0 + f] = loadBin(data + "/" + files[f0 + f], caps.N, npts[f0 + f]);
+                memcpy(sl.hpts + (size_t)f * caps.N * 4, cache[f0 + f].data(), (size_t)npts[f0 + f] * 16); sl.hcnt[f] = npts[f0 + f];
+                HIP_OK(hipMemcpyAsync((char*)sl.eng->points.ptr + (size_t)f * caps.N * 16, sl.hpts + (size_t)f * caps.N * 4, (size_t)sl.hcnt[f] * 16, hipMemcpyHostToDevice, sl.s));
+            }
+            HIP_OK(hipMemcpyAsync(sl.eng->count.ptr, sl.hcnt, 4 * frames, hipMemcpyHostToDevice, sl.s));
+            if (graph) HIP_OK(hipGraphLaunch(sl.exec, sl.s)); else sl.eng->enqueue(sl.s);
+            HIP_OK(hipMemcpyAsync(sl.hkept, sl.eng->result[2].ptr, 4 * frames, hipMemcpyDeviceToHost, sl.s));
+            HIP_OK(hipMemcpyAsync(sl.hrows, sl.eng->result[0].ptr, (size_t)frames * TOP_K * 9 * 4, hipMemcpyDeviceToHost, sl.s));
+            sl.group = (long)g;
+        }
+        for (Slot& sl : slots) collect(sl);
+        lastMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    for (size_t i = 0; i < nfile; ++i) {
+        const std::string stem = files[i].substr(0, files[i].size() - 4);
+        saveTxt(out + "/" + stem + ".txt", rows[i].data(), kept[i], lastMs / nfile);
+        if (raw) {
+            FILE* fh = fopen((out + "/" + stem + ".rows").c_str(), "wb");
+            if (!fh) die("cannot write raw rows");
+            fwrite(&kept[i], 4, 1, fh); fwrite(rows[i].data(), 4, (size_t)kept[i] * 9, fh); fclose(fh);
+        }
+        printf("%s: %d points -> %d boxes, %.3f ms (its share of the pipelined pass)\n", stem.c_str(), npts[i], kept[i], lastMs / nfile);
+    }
+    printf("dsvt_detect: %zu frames, %s, %d frame(s) per forward, %s, %d forwards in flight: %.3f ms per frame, %.1f frames/s (host copy + upload + forward + download of the final boxes, "
+           "wall clock of the last pass%s)\n",
+           nfile, mode == MODE_F16 ? "fp16" : mode == MODE_SPLIT ? "fp32 grade (f16x3)" : "fp32 grade with fp8 head corrections", frames, graph ? "HIP graph" : "host launches", inflight,
+           lastMs / std::max<size_t>(nfile, 1), 1e3 * nfile / std::max(lastMs, 1e-9), repeat > 1 ? ", frames cached in host memory" : ", disk reads inside");
+    return 0;
+}
+
 int main(int argc, char** argv) {
-    std::string wts, data, out; bool refCaps = false, graph = true, raw = false; int repeat = 1, frames = 1; Mode mode = MODE_SPLIT;
+    std::string wts, data, out; bool refCaps = false, graph = true, raw = false; int repeat = 1, frames = 1, inflight = 1; Mode mode = MODE_SPLIT;
     for (int a = 1; a < argc; ++a) {
         const std::string s = argv[a];
         if (s == "--wts" && a + 1 < argc) wts = argv[++a];
@@ -562,10 +643,12 @@ int main(int argc, char** argv) {
         else if (s == "--fp16") mode = MODE_F16;
         else if (s == "--frames" && a + 1 < argc) frames = atoi(argv[++a]);
         else if (s == "--repeat" && a + 1 < argc) repeat = atoi(argv[++a]);
-        else die("usage: dsvt_detect --wts F --data DIR --out DIR [--fp32 | --fp8-head | --fp16] [--frames N] [--ref-caps] [--no-graph] [--dump-raw] [--repeat N]");
+        else if (s == "--in-flight" && a + 1 < argc) inflight = atoi(argv[++a]);
+        else die("usage: dsvt_detect --wts F --data DIR --out DIR [--fp32 | --fp8-head | --fp16] [--frames N] [--in-flight K] [--ref-caps] [--no-graph] [--dump-raw] [--repeat N]");
     }
     if (wts.empty() || data.empty() || out.empty()) die("--wts, --data and --out are required (the reference's dsvt.wts is not shipped)");
     if (frames < 1 || frames > 16) die("--frames must be 1 .. 16");
+    if (inflight < 1 || inflight > 4) die("--in-flight must be 1 .. 4");
     if (refCaps && frames != 1) die("--ref-caps is the reference's one-frame configuration (its kernels only ever read frame 0's counts)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) die("no GPU visible (there is no CPU path)");
@@ -580,8 +663,9 @@ int main(int argc, char** argv) {
     if (files.empty()) die("no .bin frames under " + data);
     std::sort(files.begin(), files.end());
 
-    hipStream_t s; HIP_OK(hipStreamCreate(&s));
     const WeightMap w = loadWeights(wts);
+    if (inflight > 1) return runPipelined(w, caps, mode, frames, inflight, graph, raw, repeat, data, out, files);
+    hipStream_t s; HIP_OK(hipStreamCreate(&s));
     Engine eng(w, caps, s, mode, frames);
     // warm-up on empty frames (sizes every buffer), then record the forward into a HIP graph
     for (int k = 0; k < 2; ++k) eng.enqueue(s);

@@ -108,6 +108,28 @@ def test_cpp_host_four_frames_per_forward(pkg, wts_file, tmp_path):
         assert kc == k and k > 0 and np.array_equal(rc.view(np.uint32), rows.view(np.uint32)), i
 
 
+def test_cpp_host_two_forwards_in_flight(pkg, wts_file, tmp_path):
+    """dsvt_detect --in-flight 2 (two engines on two streams, groups round-robin: the copies of one group under the forward of the other): ten clouds in groups of four
+    (two full groups + a partial one, so a slot is reused) and in groups of one -- every frame's rows are the bits the synchronous loop writes"""
+    data = tmp_path / "data"; data.mkdir()
+    for i in range(10):
+        pkg.synth.lidar_like(180000 if i % 3 else 90000, 50 + i).tofile(data / f"{i:06d}.bin")
+    outs = {}
+    for tag, extra in (("sync4", ["--frames", "4"]), ("pipe4", ["--frames", "4", "--in-flight", "2", "--repeat", "3"]), ("pipe1", ["--in-flight", "3", "--repeat", "2"])):
+        out = tmp_path / tag; out.mkdir()
+        r = subprocess.run([EXE, "--wts", wts_file, "--data", str(data), "--out", str(out), "--dump-raw"] + extra, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        print(tag, r.stdout.strip().splitlines()[-1])
+        outs[tag] = [_read_rows(str(out / f"{i:06d}.rows")) for i in range(10)]
+        assert all(os.path.exists(out / f"{i:06d}.txt") for i in range(10))
+    for i in range(10):
+        k, rows = outs["sync4"][i]
+        assert k > 0
+        for tag in ("pipe4", "pipe1"):
+            kc, rc = outs[tag][i]
+            assert kc == k and np.array_equal(rc.view(np.uint32), rows.view(np.uint32)), (tag, i)
+
+
 def test_cpp_host_fails_loudly(wts_file, tmp_path):
     r = subprocess.run([EXE, "--wts", wts_file, "--data", str(tmp_path), "--out", str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "no .bin frames" in r.stderr
