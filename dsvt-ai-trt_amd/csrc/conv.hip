@@ -505,6 +505,21 @@ typedef int intx4 __attribute__((ext_vector_type(4)));
 typedef int intx8 __attribute__((ext_vector_type(8)));
 // tile engine of the MX instantiations (tools/ab_conv.sh builds variants from -D flags; A/B numbers in profiles/README.md, round 4): four-step
 // weight slabs (half the barriers: 7.70 vs 7.87 ms over the stage's layers), two slab buffers, four A fragments per fp16 batch, one per fp8 batch
+#ifndef WIDE_TRICKLE4_NUM
+#define WIDE_TRICKLE4_NUM 4
+#endif
+#ifndef WIDE_TRICKLE_CT4
+#define WIDE_TRICKLE_CT4 1
+#endif
+#ifndef WIDE_TRICKLE1
+#define WIDE_TRICKLE1 1
+#endif
+#ifndef WIDE_TRICKLE1_NUM
+#define WIDE_TRICKLE1_NUM 4
+#endif
+#ifndef WIDE_SPS4_DEFAULT
+#define WIDE_SPS4_DEFAULT 1
+#endif
 #ifndef MX_TRICKLE_MAIN
 #define MX_TRICKLE_MAIN 1
 #endif
@@ -870,7 +885,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     constexpr int NRS = (PPW + PPS - 1) / PPS;                    // ... over this many slabs
     constexpr int CH = CT > 4 ? (MX ? MX_CH : 4) : CT;  // A fragments read per batch
     constexpr int LEAD = NWB - 1;
-    constexpr bool TRICKLE_K = CT == 8 && NW == 8 && LEAD >= 2;          // requests spread over the slab (see the slab loop)
+    constexpr bool TRICKLE_K = (CT == 8 || (WIDE_TRICKLE_CT4 && !MX && LEAD == 1)) && NW == 8 && (LEAD >= 2 || (WIDE_TRICKLE1 && !MX));          // requests spread over the slab (see the slab loop)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WT_HBYTES + NWB * WT_WBYTES + 1024];      // halo[2] | wslab[NWB] | bias
     constexpr int BIAS_OFF = 2 * WT_HBYTES + NWB * WT_WBYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
@@ -1038,6 +1053,10 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
             // with the matrix pipe idle), so request j goes out after the MFMAs of batch j * NB / NREQ, when the wave would wait
             // for the pipe anyway: 88 -> 84 us (128 -> 128 channels), 123 -> 115 us (192 -> 128).  (Neutral to harmful on the
             // 64-channel variants, whose slabs hold four steps: 384 -> 64 channels 125 -> 144 us.)
+            // Round 5 (late): with four-step slabs in TWO buffers (LEAD = 1: the next slab's weights must have landed at this slab's end) the requests are spread over the
+            // FIRST HALF of the slab's batches (WIDE_TRICKLE1_NUM / WIDE_TRICKLE4_NUM eighths): three-product dense stage 9.72 -> 9.40 ms per four frames (128 -> 128 at
+            // 468 x 468 760 -> 733 us, shared 384 -> 64 1150 -> 1085, 64 -> 320 stems 1080 -> 1045); spread over 5/8 already loses, over 3/4 or the whole slab the wait is exposed
+            // (922 us / 1245 us).  The fp8 loops keep their requests at the slab start.
             int hP = (SPS * s) / 9 + 1, hk = s - (9 * (hP - 1) + SPS - 1) / SPS;
             if constexpr (CROSS) {                                    // cross phase q0 = five steps: the same rule on its own step count
                 const int q0 = (XPS * (s - NSA)) / 5;
@@ -1139,7 +1158,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
                     if (TRICKLE) {
 #pragma unroll
                         for (int j = 0; j < NREQ; ++j)
-                            if (j * NB / NREQ == b) request(j);
+                            if (j * (LEAD >= 2 ? NB : NB * (CT == 8 ? WIDE_TRICKLE1_NUM : WIDE_TRICKLE4_NUM) / 8) / NREQ == b) request(j);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -2184,8 +2203,14 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
             //    w_lo rows in LDS, three MFMAs per fragment pair: a third less halo / weight traffic and 0.25 fragment reads per MFMA instead
             //    of 0.375; LDS only holds 8-row tiles then, four waves of two rows): correct (boxes within 1e-5) and 364 registers without a
             //    spill, but 860-1054 us per 468 x 468 128 -> 128 layer against 831-954 for the plain kernel walking the [hi | lo | hi] triple.
-            if (ctWide == 8) DSVT_WIDE(ncu, 512, nwide, nchunk, 8, 8, 36, 2, 3, 2);
-            else {
+            if (ctWide == 8) {
+                // round 5, late: FOUR-step slabs in two buffers instead of two-step slabs in three -- half the workgroup barriers and counted waits per item, requests
+                // at the slab start (no trickle: LEAD = 1).  Four frames per launch: three-product 128 -> 128 at 468 x 468 780 -> 760 us, with a residual 940 -> 877, dense
+                // stage 9.95 -> 9.67 ms; fp16 frame 315 -> 308 / 367 -> 347 us, dense stage 4.00 -> 3.91 ms; one frame 2.98 -> 2.93 ms (WIDE_SPS4_DEFAULT / DSVT_CONV_SPS4=0: the two-step kernel)
+                static int sps4 = -1; if (sps4 < 0) sps4 = ablateEnv("DSVT_CONV_SPS4", WIDE_SPS4_DEFAULT);
+                if (sps4) DSVT_WIDE(ncu, 512, nwide, nchunk, 8, 8, 36, 4, 2, 2);
+                DSVT_WIDE(ncu, 512, nwide, nchunk, 8, 8, 36, 2, 3, 2);
+            } else {
                 // 64 output channels (the shared 384 -> 64 head convolution): a 16-row item's accumulators are half a wave's budget (64 of 128 registers), so
                 // THREE rows per wave -- 24 x 32-pixel items, 96 accumulator registers, 26 x 36-pixel halo phases (59 KB each) beside two 16 KB weight slabs:
                 // the weight stream per output pixel falls by a third and the halo overhead from 18 / 16 to 26 / 24 (round 5; DSVT_CONV_RW3=0: 16-row items)
