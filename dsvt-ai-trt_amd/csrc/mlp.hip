@@ -196,7 +196,7 @@ __device__ __forceinline__ void mlpLayerNormLds(floatx4 (&acc)[MNT], const float
 // same rows of w_lo (48 KB stages, three slots: 149 KB, one eight-wave workgroup per CU at <= 256 registers); s1 and h are split in
 // registers where the fp16 kernel rounds them; only the fp32 result is written.
 template <int MT, int NW, int PQ, int RS, bool SPLIT = false>
-__global__ void __launch_bounds__(64 * NW, (SPLIT ? (NW == 10 ? 1 : 2) : MT == 1 ? 3 : 2))
+__global__ void __launch_bounds__(64 * NW, (SPLIT ? (NW == 10 || NW == 4 ? 1 : 2) : MT == 1 ? 3 : 2))
 encoder_mlp_stream_kernel(MlpStreamArgs a)
 {
     constexpr int PQT = PQ / 16, PQS = PQ / 32, SRH = 6 * PQT, SR = SPLIT ? 2 * SRH : SRH, SB = SR * 1024, NWO = MC / PQ, NPIECE = MF / PQ;
@@ -207,7 +207,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
     constexpr bool LN_IN_RING = RS == 3;
     constexpr int LNP = LN_IN_RING ? 0 : 8 * MC * 4;
     constexpr bool ELASTIC = MT == 1 && NW == 10;   // 8 .. 10 waves of 16 rows are live, chosen from the row count (see below)
-    static_assert(12 * PQS == SRH && (ELASTIC || (SR % NW == 0 && (NRW == 3 || NRW == 6))), "uniform request count per wave");
+    static_assert(12 * PQS == SRH && (ELASTIC || (SR % NW == 0 && (NRW == 3 || NRW == 6 || NRW == 12))), "uniform request count per wave");
     __shared__ __attribute__((aligned(16))) unsigned char lds[RS * SB + MP_FLOATS * 4 + LNP];     // RS = 3: 78,848 B; RS = 6: 158,720 B (one workgroup per CU)
     const uint32_t cnt = *a.count;
     const int M = (int)(cnt < (uint32_t)a.max_rows ? cnt : (uint32_t)a.max_rows);
@@ -431,6 +431,40 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    // (one wave per SIMD, MT row tiles per wave -- the DSVT_MLP_SPLIT_VARIANT experiments) the same pass with NT fragment pairs per step feeding 3 NT MT MFMAs
+    auto gemmSplitM = [&](const unsigned char* slot, auto nsTag, auto ntTag, auto fragOff, auto opHi, auto opLo, auto accOf) {
+        constexpr int NS = decltype(nsTag)::value, NT = decltype(ntTag)::value;
+        half8 wq[2][2 * NT];
+        auto ld = [&](int s_, half8 (&w)[2 * NT]) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                w[t] = *reinterpret_cast<const half8*>(slot + fragOff(s_, t));
+                w[NT + t] = *reinterpret_cast<const half8*>(slot + LO + fragOff(s_, t));
+            }
+        };
+        ld(0, wq[0]);
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            if (s_ + 1 < NS) ld(s_ + 1, wq[(s_ + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            // the three products of an accumulator are a dependent chain: with one wave per SIMD nobody fills its bubbles, so the NT MT accumulators of the step
+            // take product 1, then product 2, then product 3 (the order of a row's sums does not change)
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        floatx4& c = accOf(s_, t, mt);
+                        if (pr == 0 && (!kAblate || !(a.dbg & 16))) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[s_ & 1][NT + t], opHi(s_, mt), c, 0, 0, 0);
+                        if (pr == 1 && (!kAblate || !(a.dbg & 16))) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[s_ & 1][t], opLo(s_, mt), c, 0, 0, 0);
+                        if (pr == 2) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[s_ & 1][t], opHi(s_, mt), c, 0, 0, 0);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    constexpr bool PREFM = SPLIT && MT > 1 && NW == 4 && MLP_SPLIT_PREFETCH;
+    constexpr int NTM = 2;                           // fragment pairs per step of gemmSplitM (two buffers of 2 NTM fragments: 32 registers)
     constexpr bool PREF = SPLIT && MT == 1 && NW == 8 && MLP_SPLIT_PREFETCH;          // (the ten-wave single-frame variant has 168 registers: 219 spilled with the second fragment set)
     using std::integral_constant;
 
@@ -442,6 +476,11 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
         if constexpr (PREF) {
             gemmSplit(sl, integral_constant<int, MNSTEP>{}, integral_constant<int, PQT>{}, [&](int ks, int t) { return (ks * PQT + t) * 1024; },
                       [&](int ks) { return fa[0][ks]; }, [&](int ks) { return fal[0][ks]; }, [&](int, int t) -> floatx4& { return acc[0][h * PQT + t]; });
+        } else if constexpr (PREFM) {
+            constexpr int TG = PQT / NTM;
+            gemmSplitM(sl, integral_constant<int, MNSTEP * TG>{}, integral_constant<int, NTM>{}, [&](int s_, int t) { return ((s_ / TG) * PQT + (s_ % TG) * NTM + t) * 1024; },
+                       [&](int s_, int mt) { return fa[mt][s_ / TG]; }, [&](int s_, int mt) { return fal[mt][s_ / TG]; },
+                       [&](int s_, int t, int mt) -> floatx4& { return acc[mt][h * PQT + (s_ % TG) * NTM + t]; });
         } else
 #pragma unroll
         for (int ks = 0; ks < MNSTEP; ++ks) {
@@ -497,6 +536,11 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
         if constexpr (PREF) {
             gemmSplit(slotA, integral_constant<int, MNSTEP>{}, integral_constant<int, PQT>{}, [&](int ks, int t) { return (ks * PQT + t) * 1024; },
                       [&](int ks) { return fs1[0][ks]; }, [&](int ks) { return fs1l[0][ks]; }, [&](int, int t) -> floatx4& { return acc2[0][t]; });
+        } else if constexpr (PREFM) {
+            constexpr int TG = PQT / NTM;
+            gemmSplitM(slotA, integral_constant<int, MNSTEP * TG>{}, integral_constant<int, NTM>{}, [&](int s_, int t) { return ((s_ / TG) * PQT + (s_ % TG) * NTM + t) * 1024; },
+                       [&](int s_, int mt) { return fs1[mt][s_ / TG]; }, [&](int s_, int mt) { return fs1l[mt][s_ / TG]; },
+                       [&](int s_, int t, int mt) -> floatx4& { return acc2[mt][(s_ % TG) * NTM + t]; });
         } else
 #pragma unroll
         for (int ks = 0; ks < MNSTEP; ++ks) {
@@ -549,6 +593,11 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
         if constexpr (PREF) {                        // steps of four column tiles: (32-column slice sp of the piece, tile group)
             gemmSplit(slotB, integral_constant<int, PQS * 3>{}, integral_constant<int, 4>{}, [&](int s_, int t) { return ((s_ / 3) * 12 + (s_ % 3) * 4 + t) * 1024; },
                       [&](int s_) { return fh[0][s_ / 3]; }, [&](int s_) { return fhl[0][s_ / 3]; }, [&](int s_, int t) -> floatx4& { return acc[0][(s_ % 3) * 4 + t]; });
+        } else if constexpr (PREFM) {
+            constexpr int TG = MNT / NTM;
+            gemmSplitM(slotB, integral_constant<int, PQS * TG>{}, integral_constant<int, NTM>{}, [&](int s_, int t) { return ((s_ / TG) * 12 + (s_ % TG) * NTM + t) * 1024; },
+                       [&](int s_, int mt) { return fh[mt][s_ / TG]; }, [&](int s_, int mt) { return fhl[mt][s_ / TG]; },
+                       [&](int s_, int t, int mt) -> floatx4& { return acc[mt][(s_ % TG) * NTM + t]; });
         } else
 #pragma unroll
         for (int sp = 0; sp < PQS; ++sp) {
@@ -760,6 +809,34 @@ public:
                 return lastError();
             }
 #endif
+            // Round 5, review item 5 ("32-row tiles to halve the fragment reads"): the eight-wave kernel holds 250 registers at ONE 16-row tile per wave, so more rows
+            // per fragment read means one wave per SIMD at up to 512 registers.  Built as <3, 4> (four waves x 48 rows = 192 rows per weight stream: 256 + 252
+            // registers, no spill; a third of the fragment reads, two thirds of the weight bytes per row), <2, 4> and <4, 4> (227 spilled registers), with the
+            // fragment pairs of step s + 1 read under the MFMAs of step s and the three products of an accumulator issued a step apart (gemmSplitM).  Measured
+            // (tools/mlp_split_variants.py, four frames = 137k rows per launch, us): <1, 8> shipped 250-256, <3, 4> 253-260, <2, 4> 288-290, <4, 4> 440.  Outputs agree with
+            // the shipped kernel up to hipcc's fma contraction of the LayerNorm / GELU arithmetic (1.6 % of the values by one ulp; without gemmSplitM bit for bit).
+            // Why no gain (s_memtime stamps of a <3, 4> workgroup, DSVT_MLP_TRACE): 188k cycles per 192 rows of which the MFMAs are 52k; the prologue (att + x rows
+            // of every CU at once: 10 B / cycle / CU, the HBM burst) is 29k and the epilogue 31k with nothing to run under them (149 KB of LDS: one workgroup per
+            // CU), and inside the streaming loop a stage of 216 MFMAs (3.5k cycles) takes 5.7k (FC1 + GELU + split) / 8.7k (FC2): with ONE wave per SIMD
+            // nothing fills the GELU / split / LayerNorm VALU blocks, the barrier skew or the request issue.  The ablation ladder of both kernels (DSVT_MLP_DBG): no weight
+            // stream -10 .. -17 us (the L2 -> LDS stream is NOT what bounds either), no correction MFMAs -30 (<1, 8>) / -55 (<3, 4>), no LayerNorm / GELU -14 / -23, no stores
+            // -19 / -14, all of them 166 / 148 us left.  <1, 8> per 128 rows: 46k cycles of LDS fragment reads (8 waves x 737 KB at 128 B / cycle) + 35k of MFMAs
+            // in 108k; <3, 4>: 23k + 52k in 188k -- the headroom is in <3, 4>, behind hand-interleaved VALU / MFMA streams (sched_group_barrier); not built this round.
+            if constexpr (kAblate) {   // experiments (DSVT_MLP_SPLIT_VARIANT): one wave per SIMD at up to 512 registers, MT 16-row tiles per wave
+                static int sv = -1; if (sv < 0) sv = ablateEnv("DSVT_MLP_SPLIT_VARIANT", 0);
+                static unsigned long long* tr = nullptr; static int tron = -1;         // per-workgroup phase stamps (tools/mlp_split_variants.py)
+                if (tron < 0) { tron = ablateEnv("DSVT_MLP_TRACE", 0) ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 32 * 2048); }
+                b.trace = tr;
+                struct Dump { hipStream_t st; unsigned long long* tr; int on; ~Dump() {
+                    if (!on) return;
+                    (void)hipStreamSynchronize(st);
+                    for (int w : {0, 200, 700}) { fprintf(stderr, "[mlp trace wg%d]", w); for (int i = 1; i < 32; ++i) fprintf(stderr, " %lld", (long long)(tr[w * 32 + i] - tr[w * 32])); fprintf(stderr, "\n"); }
+                } } dump{stream, tr, tron};
+                if (sv == 0) { hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, MLP_SPLIT_PQ, 3, true>), dim3(cdiv(max_rows_, MROWS) + MLP_SMALL_MAX / (16 * MLP_SW)), dim3(512), 0, stream, b); return lastError(); }
+                if (sv == 3) { hipLaunchKernelGGL((encoder_mlp_stream_kernel<3, 4, MLP_SPLIT_PQ, 3, true>), dim3(cdiv(max_rows_, 192)), dim3(256), 0, stream, b); return lastError(); }
+                if (sv == 4) { hipLaunchKernelGGL((encoder_mlp_stream_kernel<4, 4, MLP_SPLIT_PQ, 3, true>), dim3(cdiv(max_rows_, 256)), dim3(256), 0, stream, b); return lastError(); }
+                if (sv == 2) { hipLaunchKernelGGL((encoder_mlp_stream_kernel<2, 4, MLP_SPLIT_PQ, 3, true>), dim3(cdiv(max_rows_, 128) + MLP_SMALL_MAX / (32 * MLP_SW)), dim3(256), 0, stream, b); return lastError(); }
+            }
             // (+ the two-wave workgroups of a last partial round: at most MLP_SMALL_MAX rows of 32)
             hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, MLP_SPLIT_PQ, 3, true>), dim3(cdiv(max_rows_, MROWS) + MLP_SMALL_MAX / (16 * MLP_SW)), dim3(512), 0, stream, b);
             return lastError();
