@@ -481,6 +481,7 @@ p2f_bins(P2FParams p, P2FPlan pl, const uint16_t* __restrict__ tab, const uint32
     }
 }
 
+constexpr uint32_t kPillarChunk = 64;            // consecutive (virtual) workgroups of p2f_pillar that share an XCD
 // ---- 3. pillar rows ----------------------------------------------------------------------------------------------------
 // A wavefront owns FOUR pillars.  Pillars hold 4.8 points on average, so when all four have <= 16 points (the common case) each takes
 // a 16-lane group: same ranking, same sequential fp32 sums, a quarter of the wavefronts.  A pillar with more points gets the whole
@@ -497,7 +498,16 @@ p2f_pillar(P2FParams p, int dbg, const uint32_t* __restrict__ pillar_num, const 
     // so the records are loaded beside the count, not behind it: wavefront j of a group of S takes pillars base + j + {0, S, 2S, 3S} of
     // the group's 4S, S = a sixteenth of the capacity (the dense region of a frame is ~9000 pillars wide).
     const uint32_t S = ((uint32_t)p.max_pillars_num + 15u) / 16u;
-    const uint32_t gw = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    // XCD-aware (round 5): workgroups go to the eight XCDs round-robin (workgroup b -> XCD b % 8), and the 64-byte lines of the partitioned points hold the
+    // points of FOUR slots of one (block, bin) piece, i.e. of neighbouring pillars.  With workgroup b on pillars 4 b .. each line was fetched into several
+    // L2s; chunks of kPillarChunk consecutive workgroups (256 consecutive pillars of each of the four groups) now share an XCD: virtual workgroup
+    // ((s / CH) * 8 + x) * CH + s % CH for x = b % 8, s = b / 8 (the grid is padded to a multiple of 8 CH).
+    uint32_t vb = blockIdx.x;
+    // PMC, four frames per launch (tools/pmc_fetch_kernel.sh, FETCH_SIZE as counted / x 2 per the guide): 48.8 / 97.7 MB with the plain mapping (DSVT_P2F_DBG=512),
+    // chunks of 16 workgroups 39.3 / 78.5, of 64 28.5 / 57.0 (kept: the launch 0.7 us shorter), of 256 15.2 / 30.4 (the launch 1.5 us LONGER: the last chunks of a
+    // frame's pillars leave XCDs idle); writes 31 MB either way.  Algorithmic bytes of the launch: 43.6 MB.
+    if (!P2F_DBG(512)) { const uint32_t CH = P2F_DBG(1024) ? 16u : P2F_DBG(2048) ? 256u : kPillarChunk, x = vb & 7u, s_ = vb >> 3; vb = ((s_ / CH) * 8u + x) * CH + s_ % CH; }
+    const uint32_t gw = vb * (blockDim.x / kWave) + threadIdx.x / kWave;
     const uint32_t pid0 = (gw / S) * (4u * S) + (gw % S), pid = pid0 + (uint32_t)sub * S;
     const uint4 rc0 = pid < (uint32_t)p.max_pillars_num ? pil_rec[pid] : make_uint4(0u, 0u, 0u, 0u);     // (stale beyond the count: masked below)
     const uint32_t P = *pillar_num;
@@ -639,7 +649,7 @@ public:
                            tab, part_pts, part_key, part_idx, scan_state, (int)stateWords());
         hipLaunchKernelGGL(p2f_bins, dim3(pl.nbins), dim3(kBT), 0, stream, p_, pl, tab, part_key, srt, scan_state,
                            pil_rec, coords, pcnt, pillar_num, point_num);
-        hipLaunchKernelGGL(p2f_pillar, dim3(cdiv(cdiv(p_.max_pillars_num, 16), 4) * 4), dim3(256), 0, stream,     // four groups of S = cap / 16 wavefronts
+        hipLaunchKernelGGL(p2f_pillar, dim3(cdiv(cdiv(cdiv(p_.max_pillars_num, 16), 4) * 4, 8 * 256) * 8 * 256), dim3(256), 0, stream,     // four groups of S = cap / 16 wavefronts (padded to whole XCD chunks)
                            p_, pl.dbg, pillar_num, srt, part_pts, part_idx,
                            pil_rec, feat, pidx);
         if (tron) {
