@@ -683,6 +683,7 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     int xs = 0;                                                     // MX: scale bytes of this wave's four channel tiles (row r)
 
     int item = blockIdx.x;
+    if (kAblate && (dbg & 16) && (gridDim.x & 7u) == 0u) item = (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));      // XCD-aware item walk (measured, not kept): see conv_wide_kernel
     if (item >= nitems) return;
     int y0, x0, chunk, bimg;
     decode(item, y0, x0, chunk, bimg);
@@ -949,7 +950,15 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + BIAS_OFF), 16, 0, 0);
     };
 
+    // An XCD-aware item walk, measured and NOT kept (round 5; ablation build, DSVT_CONV_DBG=16).  Workgroups go to the eight XCDs round-robin (workgroup b -> XCD b % 8) and
+    // consecutive items are the channel chunks of one tile, then its right neighbour -- the same halo pixels -- so with item = b the chunks of a tile (five for the 64 -> 320
+    // head stems) sit on different XCDs and every L2 fetches the tile's halo itself.  With XCD x walking items x G / 8 .. (x + 1) G / 8 - 1 of every round of G, FETCH_SIZE of
+    // the 64-channel-chunk launches (shared 384 -> 64, 64 -> 320 stems) HALVES (1438 -> 754 MB as counted, per four-frame launch; the 128-channel layers 147 -> 138), the
+    // dense stage alone does not move (9.42-9.46 against 9.42-9.45 ms, tools/conv_layers.py) and the two-stream frame gets SLOWER: 296.4 / 296.5 against 300.5 / 301.0
+    // frames/s (tools/two_stream_fps.py, four alternating runs in one box).  These kernels do not wait for their L2 misses, and 32 neighbouring items per XCD start and
+    // end their phases together.  The plain walk stays.
     int item = blockIdx.x;
+    if (kAblate && (dbg & 16) && (gridDim.x & 7u) == 0u) item = (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
     if (item >= nitems) return;
     int nmark = 0;
     const bool tracing = TR && a.trace != nullptr && (wave == 0 || wave == NW / 2);      // (TR: the instrumented instantiation, tools/trace_conv.py)
