@@ -274,7 +274,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
     const int nreq = (SR - wave + nwa - 1) / nwa;    // weight rows this wave requests per stage (elastic: 3 or 2)
     const float* prm = reinterpret_cast<const float*>(lds + RS * SB);
     int nmark = 0;
-    auto mark = [&]() { if (a.trace && tid == 0 && nmark < 32) a.trace[blockIdx.x * 32 + nmark] = clock64(); ++nmark; };
+    auto mark = [&]() { if (a.trace && tid == 0 && nmark < 64) a.trace[blockIdx.x * 64 + nmark] = clock64(); ++nmark; };
     mark();
     auto request = [&](int s) {
         if (small) {                                 // (MLP_SW waves share the SR rows)
@@ -588,6 +588,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
         }
         mark();
         stageEnd(stA);                               // W2 slab landed; everyone is done with the W1 piece
+        if (kAblate) mark();
         if (stB + D < NST) request(stB + D);
         const unsigned char* slotB = lbase + (stB % RS) * SB;
         if constexpr (PREF) {                        // steps of four column tiles: (32-column slice sp of the piece, tile group)
@@ -619,6 +620,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
         }
         mark();
         if (stB + 1 < NST) stageEnd(stB);            // next W1 piece landed; everyone is done with the W2 slab
+        if (kAblate) mark();
     }
     mark();
     // ---- s2 = LN2(s1 + f + b2) (already summed); x' = LN3(s2 + x); [x' = LN4(x' + xb)]: nothing in flight any more ------
@@ -825,12 +827,12 @@ public:
             if constexpr (kAblate) {   // experiments (DSVT_MLP_SPLIT_VARIANT): one wave per SIMD at up to 512 registers, MT 16-row tiles per wave
                 static int sv = -1; if (sv < 0) sv = ablateEnv("DSVT_MLP_SPLIT_VARIANT", 0);
                 static unsigned long long* tr = nullptr; static int tron = -1;         // per-workgroup phase stamps (tools/mlp_split_variants.py)
-                if (tron < 0) { tron = ablateEnv("DSVT_MLP_TRACE", 0) ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 32 * 2048); }
+                if (tron < 0) { tron = ablateEnv("DSVT_MLP_TRACE", 0) ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 64 * 2048); }
                 b.trace = tr;
                 struct Dump { hipStream_t st; unsigned long long* tr; int on; ~Dump() {
                     if (!on) return;
                     (void)hipStreamSynchronize(st);
-                    for (int w : {0, 200, 700}) { fprintf(stderr, "[mlp trace wg%d]", w); for (int i = 1; i < 32; ++i) fprintf(stderr, " %lld", (long long)(tr[w * 32 + i] - tr[w * 32])); fprintf(stderr, "\n"); }
+                    for (int w : {0, 200, 700}) { fprintf(stderr, "[mlp trace wg%d]", w); for (int i = 1; i < 40; ++i) fprintf(stderr, " %lld", (long long)(tr[w * 64 + i] - tr[w * 64])); fprintf(stderr, "\n"); }
                 } } dump{stream, tr, tron};
                 if (sv == 0) { hipLaunchKernelGGL((encoder_mlp_stream_kernel<1, 8, MLP_SPLIT_PQ, 3, true>), dim3(cdiv(max_rows_, MROWS) + MLP_SMALL_MAX / (16 * MLP_SW)), dim3(512), 0, stream, b); return lastError(); }
                 if (sv == 3) { hipLaunchKernelGGL((encoder_mlp_stream_kernel<3, 4, MLP_SPLIT_PQ, 3, true>), dim3(cdiv(max_rows_, 192)), dim3(256), 0, stream, b); return lastError(); }
@@ -867,7 +869,7 @@ public:
         const int gfull = cdiv(max_rows_, MROWS);                               // (covers the elastic variant too: >= 128 rows per workgroup)
         const dim3 grid(gfull + cdiv(MLP_SMALL_MAX, srows));                    // full workgroups of the whole rounds + the small ones of the remainder (the rest exit at once)
         static unsigned long long* tr = nullptr; static int tron = -1;         // tools/trace_mlp.py
-        if (tron < 0) { tron = ablateEnv("DSVT_MLP_TRACE", 0) ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 32 * 1024); }
+        if (tron < 0) { tron = ablateEnv("DSVT_MLP_TRACE", 0) ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 64 * 1024); }
         b.trace = tr;
         static int dbg = -1; if (dbg < 0) dbg = ablateEnv("DSVT_MLP_DBG", 0);
         b.dbg = dbg;
@@ -890,7 +892,7 @@ public:
         else hipLaunchKernelGGL((encoder_mlp_stream_kernel<2, 4, 64, 3>), grid, dim3(256), 0, stream, b);
         if (tron) {
             (void)hipStreamSynchronize(stream);
-            for (int w : {0, 200}) { fprintf(stderr, "[mlp trace wg%d]", w); for (int i = 1; i < 32; ++i) fprintf(stderr, " %lld", (long long)(tr[w * 32 + i] - tr[w * 32])); fprintf(stderr, "\n"); }
+            for (int w : {0, 200}) { fprintf(stderr, "[mlp trace wg%d]", w); for (int i = 1; i < 40; ++i) fprintf(stderr, " %lld", (long long)(tr[w * 64 + i] - tr[w * 64])); fprintf(stderr, "\n"); }
         }
         return lastError();
     }
