@@ -2217,6 +2217,9 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
                 // at the slab start (no trickle: LEAD = 1).  Four frames per launch: three-product 128 -> 128 at 468 x 468 780 -> 760 us, with a residual 940 -> 877, dense
                 // stage 9.95 -> 9.67 ms; fp16 frame 315 -> 308 / 367 -> 347 us, dense stage 4.00 -> 3.91 ms; one frame 2.98 -> 2.93 ms (WIDE_SPS4_DEFAULT / DSVT_CONV_SPS4=0: the two-step kernel)
                 static int sps4 = -1; if (sps4 < 0) sps4 = ablateEnv("DSVT_CONV_SPS4", WIDE_SPS4_DEFAULT);
+                if constexpr (kAblate) {     // the instrumented instantiation of the three-product kernel (DSVT_CONV_TRACE=1, tools/trace_conv_split.py)
+                    if (a.trace && spl && sps4) { hipLaunchKernelGGL((conv_wide_kernel<8, 8, 36, 4, 2, 2, true, true>), dim3(ncu), dim3(512), 0, stream, a, Wp, zeros, tilesX, nwide, nchunk, dbg); return lastError(); }
+                }
                 if (sps4) DSVT_WIDE(ncu, 512, nwide, nchunk, 8, 8, 36, 4, 2, 2);
                 DSVT_WIDE(ncu, 512, nwide, nchunk, 8, 8, 36, 2, 3, 2);
             } else {
