@@ -850,6 +850,9 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
 // channels, 4 waves, 78 KB of LDS: two independent workgroups per CU) serves the 234x234 and 117x117 layers, which have
 // too few 16-row x 128-channel items for 256 CUs (117x117x256: 240 items of four waves instead of 120 of eight).
 // HS = halo row stride in pixels (>= 34; HS * 64 B is a multiple of 256 B, so the bank pattern is that of one row).
+#ifndef WIDE_REQ_V2
+#define WIDE_REQ_V2 0
+#endif
 template <int CT, int NW, int HS, int SPS, int RW>
 struct WideCfg {
     static constexpr int ROWS = RW * NW, HH = ROWS + 2;
@@ -872,6 +875,16 @@ struct WideCfg {
 // hi8) of row n, and the row's scale byte 127 - 11 - e undoes both factors (tap 9 of the fifth step: zero weights).  Per 32 channels and tile pair:
 // 9 fp16 + 5 fp8 MFMAs = 9 x 16 + 5 x 27 cycles of the pipe instead of 27 x 16.  A cross step's fragments are 2 KB per channel tile (two lane-linear
 // 1 KB rows: bytes 0..15 and 16..31 of every lane), so a weight slab holds SPS / 2 cross steps.  Packed weights: DsvtConv2dPlugin::packMX.
+// What bounds the slab loop (round 5, late; profiles/r05_conv_issue_bound.txt): INSTRUCTION ISSUE.  The loop body of <8, 8, 36, 4, 2, 2, SPL> is 1159 instructions per wave for its 128
+// MFMAs (494 VALU, 455 SALU, 60 ds_read_b128, 35 branches, 21 s_waitcnt, 11 LDS-DMA requests, 76 v_mov_b64 of loop-carried fragment registers, 44 SGPR spill moves): a wave
+// issues one instruction per ~4 cycles, i.e. >= 4636 cycles per slab where the SIMD's matrix pipe needs 4096 for both waves' MFMAs.  s_memtime stamps (tools/trace_conv_split.py):
+// the older wave of a SIMD finishes a slab's instruction stream in 4390 cycles, its partner in 5580 (+ 370 for the requests to land, + 160 at the barrier); the DMA wait and the
+// barrier skew are 6 % of an item, the epilogue 8 %, the 27 slabs 70 %.  The address arithmetic of a halo request is ~45 instructions inside three nested exec-mask branches
+// (hipcc turns the short-circuit validity test into control flow).  Tried on this finding: (a) wave index in an SGPR + a branch-free request (WIDE_REQ_V2=1): 1433 instructions
+// per slab (more SALU), not run; (b) no "step < NSTEP" guard around the MFMA batches of layers whose steps are whole slabs (eight scalar branches per slab gone): the merged
+// blocks raise the register pressure and hipcc spills INSIDE the loop (58 scratch accesses per slab instead of 11): 1088 against 731 us per 468 x 468 128 -> 128 layer.  At 256
+// registers with 34 spilled every change of the source moves the allocation; the next step for this kernel is its slab loop in assembly (per-slab descriptors precomputed in LDS,
+// row-aligned halo pieces through a buffer descriptor so that out-of-image lanes need no arithmetic: ~700 instructions per slab), not another C++ variant.
 template <int CT, int NW, int HS, int SPS = (CT == 8 ? 2 : 4), int NWB = 3, int RW = 2, bool TR = false, bool SPL = false, bool MX = false>
 __global__ void __launch_bounds__(64 * NW, (NW * (RW == 1 ? 1 : 2) <= 8 && (NW == 4 || RW == 1)) ? 2 : 1)
 conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __restrict__ zeros, int tilesX, int nitems, int nchunk, int dbg)
@@ -889,7 +902,11 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     constexpr bool TRICKLE_K = (CT == 8 || (WIDE_TRICKLE_CT4 && !MX && LEAD == 1)) && NW == 8 && (LEAD >= 2 || (WIDE_TRICKLE1 && !MX));          // requests spread over the slab (see the slab loop)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WT_HBYTES + NWB * WT_WBYTES + 1024];      // halo[2] | wslab[NWB] | bias
     constexpr int BIAS_OFF = 2 * WT_HBYTES + NWB * WT_WBYTES;
+#if WIDE_REQ_V2
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, g = lane >> 4;     // (wave index in an SGPR: the request bookkeeping is scalar)
+#else
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+#endif
     const int NPM = MX ? a.Cin / 96 : a.Cin >> 5;                 // 32-channel phases of fp16 k-steps (MX: of the hi plane; a.Cin = 3 C)
     const int NP = MX ? 2 * NPM : NPM;                            // halo phases (even)
     const int NSTEP = NPM * 9, NSA = (NSTEP + SPS - 1) / SPS;     // (SPS = 4: the last fp16 slab may be partial; the packed weights end in a zero slab)
@@ -914,10 +931,18 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         const int lp = pc * 16 + (lane >> 2), hy = lp / WT_HS, hx = lp - hy * WT_HS;
         const int chunk = (lane & 3) ^ ((hx >> 1) & 2);
         const int gy = yy - 1 + hy, gx = xx - 1 + hx;
-        const bool ok = hx < HTW + 2 && hy < C::HH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         const int coff = MX ? (ph >= NPM ? 64 * NPM + (ph - NPM) * 32 : ph * 32)             // (MX: phase NPM + q = 64 bytes of the x8 plane, which starts at channel 2 C)
                             : (a.alias3 && ph * 32 >= a.alias3) ? ph * 32 - a.alias3 : ph * 32;   // (three fp16 products over an x8 third plane: its phases read plane 0)
+#if WIDE_REQ_V2
+        // branch-free: the address of every lane is formed (never dereferenced when the pixel is outside the image or the halo), then selected.  With the short-circuit
+        // form hipcc wrapped the address arithmetic in three nested exec-mask branches per request, each with an s_waitcnt lgkmcnt(0) that also drains the fragment reads
+        const unsigned ok = (unsigned)(hx < HTW + 2) & (unsigned)(hy < C::HH) & (unsigned)((unsigned)gy < (unsigned)a.H) & (unsigned)((unsigned)gx < (unsigned)a.W);
+        const long off = (long)((bb * a.H + gy) * a.W + gx) * a.Cin + (coff + chunk * 8);
+        const _Float16* src = ok ? a.in + off : zeros;
+#else
+        const bool ok = hx < HTW + 2 && hy < C::HH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         const _Float16* src = ok ? a.in + (size_t)((bb * a.H + gy) * a.W + gx) * a.Cin + coff + chunk * 8 : zeros;
+#endif
         __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(smem + hb * WT_HBYTES + pc * 1024), 16, 0, 0);
     };
     // the 16 fragment rows of slab sl (steps SPS sl ...) of chunk ch -> buffer wb
