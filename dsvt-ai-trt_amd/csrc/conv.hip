@@ -902,7 +902,7 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     constexpr bool TRICKLE_K = (CT == 8 || (WIDE_TRICKLE_CT4 && !MX && LEAD == 1)) && NW == 8 && (LEAD >= 2 || (WIDE_TRICKLE1 && !MX));          // requests spread over the slab (see the slab loop)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WT_HBYTES + NWB * WT_WBYTES + 1024];      // halo[2] | wslab[NWB] | bias
     constexpr int BIAS_OFF = 2 * WT_HBYTES + NWB * WT_WBYTES;
-#if WIDE_REQ_V2
+#if WIDE_REQ_V2 == 1
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, g = lane >> 4;     // (wave index in an SGPR: the request bookkeeping is scalar)
 #else
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
