@@ -853,6 +853,9 @@ conv_halo_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
 #ifndef WIDE_REQ_V2
 #define WIDE_REQ_V2 0
 #endif
+#ifndef WIDE_REQ_V3
+#define WIDE_REQ_V3 0
+#endif
 template <int CT, int NW, int HS, int SPS, int RW>
 struct WideCfg {
     static constexpr int ROWS = RW * NW, HH = ROWS + 2;
@@ -900,8 +903,14 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
     constexpr int CH = CT > 4 ? (MX ? MX_CH : 4) : CT;  // A fragments read per batch
     constexpr int LEAD = NWB - 1;
     constexpr bool TRICKLE_K = (CT == 8 || (WIDE_TRICKLE_CT4 && !MX && LEAD == 1)) && NW == 8 && (LEAD >= 2 || (WIDE_TRICKLE1 && !MX));          // requests spread over the slab (see the slab loop)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WT_HBYTES + NWB * WT_WBYTES + 1024];      // halo[2] | wslab[NWB] | bias
+    // WIDE_REQ_V3 (round 5, late): a halo request's per-lane arithmetic from two kernel-invariant LDS tables -- byte offset of (piece, lane)'s 16 bytes within the tile
+    // [NPC][64] u32, (hy, hx) of its pixel [NPC][16] u16 -- and the request itself as buffer_load_dwordx4 ... lds through ONE descriptor over the input tensor with the
+    // offset of an invalid lane set out of range (the hardware returns zeros): ~12 vector instructions per request instead of ~45 in three exec-mask branches
+    constexpr int TBL_BYTES = WT_NPC * 64 * 4 + WT_NPC * 16 * 2;
+    constexpr bool REQ3 = WIDE_REQ_V3 != 0 && !MX && 2 * WT_HBYTES + NWB * WT_WBYTES + 1024 + TBL_BYTES <= 160 * 1024;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WT_HBYTES + NWB * WT_WBYTES + 1024 + (REQ3 ? TBL_BYTES : 0)];      // halo[2] | wslab[NWB] | bias (| request tables)
     constexpr int BIAS_OFF = 2 * WT_HBYTES + NWB * WT_WBYTES;
+    constexpr int TOFF_OFF = BIAS_OFF + 1024, THYX_OFF = TOFF_OFF + WT_NPC * 64 * 4;
 #if WIDE_REQ_V2 == 1
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, g = lane >> 4;     // (wave index in an SGPR: the request bookkeeping is scalar)
 #else
@@ -927,7 +936,34 @@ conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __
         yy = (t / tilesX) * WT_ROWS; xx = (t % tilesX) * HTW;
     };
     // piece pc of the halo of phase ph at tile origin (yy, xx) of image bb -> buffer hb
+    const __amdgpu_buffer_rsrc_t inRsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.in), 0, (int)((size_t)a.nb * a.H * a.W * a.Cin * 2), 0x00020000);
+    if constexpr (REQ3) {
+        // this wave's pieces only: a wave reads back what it wrote (no workgroup barrier needed)
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int pc = wave + NW * i;
+            if (pc < WT_NPC) {
+                const int lp = pc * 16 + (lane >> 2), hy = lp / WT_HS, hx = lp - hy * WT_HS;
+                const int chunk = (lane & 3) ^ ((hx >> 1) & 2);
+                const bool in = hx < HTW + 2 && hy < C::HH;
+                // (padding pixels of the 36-pixel rows / beyond the last halo row are never read by a fragment: they fetch the tile's first pixel)
+                *reinterpret_cast<uint32_t*>(smem + TOFF_OFF + (pc * 64 + lane) * 4) = in ? (uint32_t)(((hy * a.W + hx) * a.Cin + chunk * 8) * 2) : 0u;
+                if ((lane & 3) == 0) *reinterpret_cast<unsigned short*>(smem + THYX_OFF + lp * 2) = in ? (unsigned short)(hy << 8 | hx) : (unsigned short)0x0101;
+            }
+        }
+    }
     auto haloRequest = [&](int pc, int yy, int xx, int ph, int hb, int bb) {
+        if constexpr (REQ3) {
+            const uint32_t toff = *reinterpret_cast<const uint32_t*>(smem + TOFF_OFF + (pc * 64 + lane) * 4);
+            const uint32_t hyx = *reinterpret_cast<const unsigned short*>(smem + THYX_OFF + (pc * 16 + (lane >> 2)) * 2);
+            const int gy = yy - 1 + (int)(hyx >> 8), gx = xx - 1 + (int)(hyx & 255u);
+            const unsigned ok = (unsigned)((unsigned)gy < (unsigned)a.H) & (unsigned)((unsigned)gx < (unsigned)a.W);
+            const int coff = (a.alias3 && ph * 32 >= a.alias3) ? ph * 32 - a.alias3 : ph * 32;
+            const uint32_t sbase = (uint32_t)((((bb * a.H + yy - 1) * a.W + xx - 1) * a.Cin + coff) * 2);          // (wraps for yy = 0 / xx = 0: the sum below is exact mod 2^32 for every valid lane)
+            const uint32_t voff = ok ? toff + sbase : 0xFFFFFFF0u;                                           // (>= num_records: the tensor holds < 2^31 elements, checked by the plugin)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(inRsrc, (glds_dst_t)(smem + hb * WT_HBYTES + pc * 1024), 16, (int)voff, 0, 0, 0);
+            return;
+        }
         const int lp = pc * 16 + (lane >> 2), hy = lp / WT_HS, hx = lp - hy * WT_HS;
         const int chunk = (lane & 3) ^ ((hx >> 1) & 2);
         const int gy = yy - 1 + hy, gx = xx - 1 + hx;
