@@ -878,16 +878,15 @@ struct WideCfg {
 // hi8) of row n, and the row's scale byte 127 - 11 - e undoes both factors (tap 9 of the fifth step: zero weights).  Per 32 channels and tile pair:
 // 9 fp16 + 5 fp8 MFMAs = 9 x 16 + 5 x 27 cycles of the pipe instead of 27 x 16.  A cross step's fragments are 2 KB per channel tile (two lane-linear
 // 1 KB rows: bytes 0..15 and 16..31 of every lane), so a weight slab holds SPS / 2 cross steps.  Packed weights: DsvtConv2dPlugin::packMX.
-// What bounds the slab loop (round 5, late; profiles/r05_conv_issue_bound.txt): INSTRUCTION ISSUE.  The loop body of <8, 8, 36, 4, 2, 2, SPL> is 1159 instructions per wave for its 128
-// MFMAs (494 VALU, 455 SALU, 60 ds_read_b128, 35 branches, 21 s_waitcnt, 11 LDS-DMA requests, 76 v_mov_b64 of loop-carried fragment registers, 44 SGPR spill moves): a wave
-// issues one instruction per ~4 cycles, i.e. >= 4636 cycles per slab where the SIMD's matrix pipe needs 4096 for both waves' MFMAs.  s_memtime stamps (tools/trace_conv_split.py):
-// the older wave of a SIMD finishes a slab's instruction stream in 4390 cycles, its partner in 5580 (+ 370 for the requests to land, + 160 at the barrier); the DMA wait and the
-// barrier skew are 6 % of an item, the epilogue 8 %, the 27 slabs 70 %.  The address arithmetic of a halo request is ~45 instructions inside three nested exec-mask branches
-// (hipcc turns the short-circuit validity test into control flow).  Tried on this finding: (a) wave index in an SGPR + a branch-free request (WIDE_REQ_V2=1): 1433 instructions
-// per slab (more SALU), not run; (b) no "step < NSTEP" guard around the MFMA batches of layers whose steps are whole slabs (eight scalar branches per slab gone): the merged
-// blocks raise the register pressure and hipcc spills INSIDE the loop (58 scratch accesses per slab instead of 11): 1088 against 731 us per 468 x 468 128 -> 128 layer.  At 256
-// registers with 34 spilled every change of the source moves the allocation; the next step for this kernel is its slab loop in assembly (per-slab descriptors precomputed in LDS,
-// row-aligned halo pieces through a buffer descriptor so that out-of-image lanes need no arithmetic: ~700 instructions per slab), not another C++ variant.
+// What bounds the slab loop (round 5, late; profiles/r05_conv_issue_bound.txt): the ALTERNATION of its two instruction kinds.  The inner loop of <8, 8, 36, 4, 2, 2, SPL> is 830 instructions per
+// wave and slab -- 128 MFMAs in eight back-to-back blocks of 16 (256 matrix-pipe cycles each), and between them eight blocks of ~88 others (308 VALU, 335 SALU of slab schedule and addresses,
+// 48 ds_read_b128, 32 branches, 11 LDS-DMA requests; no scratch access inside the loop).  The sched_barrier fences and the branches around every request keep hipcc from placing the others
+// UNDER the MFMAs, so a wave alone needs 8 x (256 + ~290) = 4390 cycles per slab (s_memtime stamps, tools/trace_conv_split.py: exactly the wave that has priority), its partner 5580, + 370
+// for the requests to land, + 160 at the barrier: 6100 where the pipe needs 4096.  DMA wait and barrier skew are 6 % of an item, the epilogue 8 %, the 27 slabs 70 %.  Variants measured on
+// this (switches in the source, off): WIDE_REQ_V2 = 1 (wave index in an SGPR, branch-free validity test: 763 instructions) -1 % on the dense stage (-3.5 % without a residual, +3 % with);
+// WIDE_REQ_V3 = 1 (request arithmetic from LDS tables + buffer descriptor: 727) -1 .. -1.8 %; no "step < NSTEP" guard around the MFMA batches: hipcc spills INSIDE the loop (22 scratch
+// accesses per slab) and a layer takes 1088 instead of 731 us.  Fewer instructions buy little; they have to issue under the MFMAs of the same wave, i.e. the slab body as ONE straight-line
+// region (descriptors precomputed in LDS, predicated requests) behind sched_group_barrier pipelines or in assembly: DESIGN.md section 6.
 template <int CT, int NW, int HS, int SPS = (CT == 8 ? 2 : 4), int NWB = 3, int RW = 2, bool TR = false, bool SPL = false, bool MX = false>
 __global__ void __launch_bounds__(64 * NW, (NW * (RW == 1 ? 1 : 2) <= 8 && (NW == 4 || RW == 1)) ? 2 : 1)
 conv_wide_kernel(ConvArgs a, const _Float16* __restrict__ Wp, const _Float16* __restrict__ zeros, int tilesX, int nitems, int nchunk, int dbg)
