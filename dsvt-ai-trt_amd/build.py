@@ -19,6 +19,7 @@ SOURCES = [
     ("linear.hip", []),
     ("attention.hip", []),
     ("conv.hip", []),
+    ("conv_rows.hip", []),
     ("mlp.hip", []),
     # -fno-honor-nans: fmaxf() is llvm.maxnum, which without it costs THREE v_max_f32 (both operands canonicalised first); pfn_kernel is bound
     # by VALU issue and its maxima run over MFMA sums of finite inputs

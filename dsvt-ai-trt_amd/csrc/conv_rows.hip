@@ -1,0 +1,317 @@
+// conv_rows.hip -- conv_rows_kernel: the 3 x 3 stride-1 layers with 128-channel output chunks (the BEV ResNet blocks, src/dsvt-ai-trt.cpp:1144-1351) in the
+// fp32-grade frame, with a slab loop the matrix pipe can be kept busy under.
+//
+// Round 5 measured what conv_wide_kernel<8, 8, 36, 4, 2, 2, SPL> (39 % of the frame in one symbol) loses time to (profiles/r05_conv_issue_bound.txt): its slab --
+// four (phase, tap) steps = 128 MFMAs per wave -- carries ~700 OTHER instructions per wave (request addresses of ~45 instructions each, the schedule of which
+// halo phase / weight slab goes where, exec-mask branches around every request), alternating in blocks with the MFMAs; an in-order wave cannot issue them under
+// its own MFMAs and the two waves of a SIMD overlap each other's blocks only by chance: 6100 cycles per slab where the matrix pipe needs 4096.  Variants that
+// shortened the other blocks by 8-14 % bought 1-3 %.  This kernel removes the other instructions instead of shortening them, by choosing the slab so that its
+// schedule is a compile-time constant:
+//
+//   * same tile as conv_wide_kernel<8, 8, ..>: 16 rows x 32 pixels x 128 channels per workgroup, eight waves of two rows, 128 accumulator registers, the K loop
+//     walks 32-channel phases of the [hi | lo | hi] input (a halo pixel = 64 B of LDS, chunk c of halo column hx in slot c ^ ((hx >> 1) & 2)), the packed
+//     weights of DsvtConv2dPlugin::packHalo unchanged, the (phase, tap) steps in the same order: every accumulator sees the same sequence of MFMAs as in
+//     conv_wide_kernel, so the results are BIT-IDENTICAL (tests/test_conv_gpu.py::test_rows_kernel_equals_wide_kernel);
+//   * a slab = the THREE taps of one kernel row ky of one phase (96 MFMAs per wave, 24 KB of weights): a phase is exactly three slabs, slab s lives in weight
+//     buffer s mod 3 = ky and halo buffer = phase parity, so with the loop body = two phases = six slabs, every LDS address of every fragment read is a
+//     per-lane base register + an immediate, and every slab issues the same requests: the weights of slab s + 2 (three 1 KB rows per wave) and, in the
+//     ky = 0 / 1 slabs, three / two of the wave's five halo pieces of the NEXT phase (34-pixel halo rows: 18 x 34 pixels = 39 pieces, five per wave);
+//   * a request = s_mov m0 + one buffer_load_dwordx4 ... lds: the per-lane byte offsets of the wave's five halo pieces (validity folded in: a lane outside
+//     the image carries an offset beyond num_records and the hardware writes the zeros) are computed ONCE PER ITEM into five registers, the phase / plane
+//     and the weight row travel in the scalar offset; no branch, no per-request address arithmetic;
+//   * no conditional request: the last phase of an item requests the first phase / slabs of the NEXT item (a workgroup without a next item re-requests its own:
+//     the bytes land in buffers nobody reads again).
+// What is left per slab and wave beside the 96 MFMAs: 36 ds_read_b128, 3-6 requests, a dozen scalar instructions, one s_waitcnt + s_barrier.
+#include "plugin_base.h"
+#include "device_utils.h"
+#include "conv_args.h"
+#include <type_traits>
+
+namespace dsvt {
+
+constexpr int RK_TW = 32;                          // tile width in pixels
+constexpr int RK_HS = RK_TW + 2;                   // halo row stride in pixels (a fragment read touches ONE halo row: its bank pattern does not depend on the stride)
+constexpr int RK_ROWS = 16, RK_HH = RK_ROWS + 2;
+constexpr int RK_NW = 8;
+constexpr int RK_PPW = 5;                          // halo pieces (1 KB = 16 pixels) per wave and phase: 18 x 34 = 612 pixels = 38.25 pieces
+constexpr int RK_NPC = RK_NW * RK_PPW;             // 40 KB per halo buffer (piece 39 is padding: its lanes carry out-of-range offsets)
+constexpr int RK_HBYTES = RK_NPC * 1024;
+constexpr int RK_WBYTES = 3 * 8 * 1024;            // three taps x eight 16-channel tiles
+constexpr int RK_WOFF = 2 * RK_HBYTES, RK_BIAS = RK_WOFF + 3 * RK_WBYTES, RK_SMEM = RK_BIAS + 1024;
+static_assert(RK_HH * RK_HS <= RK_NPC * 16 && RK_SMEM <= 160 * 1024, "LDS budget");
+constexpr uint32_t RK_OOB = 0xFFFFFFF0u;           // byte offset of a lane whose halo pixel lies outside the image (>= num_records: the request writes zeros)
+
+template <bool SPL>
+__global__ void __launch_bounds__(64 * RK_NW, 1)
+conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int nitems, int nchunk)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RK_SMEM];          // halo[2] | wslab[3] | bias
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, g = lane >> 4;
+    const int NP = a.Cin >> 5;                                                     // 32-channel phases (even: checked by the launcher)
+    const int NCT = (a.CoutRows + 127) / 128 * 8;                                  // 16-channel tiles per k-step of the packed weights
+    const int perImg = nitems / a.nb;
+    auto decode = [&](int it, int& yy, int& xx, int& ch, int& bb) {
+        bb = it / perImg; it -= bb * perImg;
+        ch = it % nchunk; const int t = it / nchunk;
+        yy = (t / tilesX) * RK_ROWS; xx = (t % tilesX) * RK_TW;
+    };
+    const __amdgpu_buffer_rsrc_t inRsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.in), 0, (int)((size_t)a.nb * a.H * a.W * a.Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wRsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Wp), 0, 0x7FFFFFF0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bRsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias ? a.Cout * 4 : 0, 0x00020000);
+
+    // byte offsets of this lane's 16 bytes of the wave's five halo pieces of the tile at (yy, xx) of image bb, phase 0
+    uint32_t hv[RK_PPW];
+    auto haloOffsets = [&](int yy, int xx, int bb) {
+#pragma unroll
+        for (int i = 0; i < RK_PPW; ++i) {
+            const int lp = (wave + RK_NW * i) * 16 + (lane >> 2), hy = lp / RK_HS, hx = lp - hy * RK_HS;
+            const int chunk = (lane & 3) ^ ((hx >> 1) & 2);
+            const int gy = yy - 1 + hy, gx = xx - 1 + hx;
+            const bool ok = hy < RK_HH && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            hv[i] = ok ? (uint32_t)((((bb * a.H + gy) * a.W + gx) * a.Cin + chunk * 8) * 2) : RK_OOB;
+        }
+    };
+    // byte offset (scalar) of the 32 channels of phase ph within a pixel: the phases of the third plane of [hi | lo | hi] read plane 0 (alias3, see ConvArgs)
+    auto phaseOff = [&](int ph) { const int c = ph * 32; return (uint32_t)(((a.alias3 && c >= a.alias3) ? c - a.alias3 : c) * 2); };
+    auto haloRequest = [&](int i, int buf, uint32_t soff) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(inRsrc, (glds_dst_t)(smem + buf * RK_HBYTES + (wave + RK_NW * i) * 1024), 16, (int)hv[i], (int)soff, 0, 0);
+    };
+    // weight rows of slab (ph, ky) of chunk ch: tap 3 ky + j, channel tile `wave` -> row (2 ((ph >> 1) 9 + tap) + (ph & 1)) NCT + 8 ch + wave of the packed image
+    const uint32_t wv = (uint32_t)tid * 16u;                                       // (wave * 1024 + lane * 16)
+    const uint32_t wstep = (uint32_t)(2 * NCT * 1024);
+    auto weightBase = [&](int ph, int ky, int ch) { return (uint32_t)(((2 * ((ph >> 1) * 9 + 3 * ky) + (ph & 1)) * NCT + ch * 8) * 1024); };
+    auto weightRequest = [&](uint32_t base, int buf, int j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wRsrc, (glds_dst_t)(smem + RK_WOFF + buf * RK_WBYTES + (j * 8 + wave) * 1024), 16, (int)wv, (int)(base + j * wstep), 0, 0);
+    };
+    auto weightRequests = [&](uint32_t base, int buf) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) weightRequest(base, buf, j);
+    };
+    // the chunk's bias (128 floats, zeros beyond Cout / without a bias: out-of-range lanes) as one LDS-DMA piece: the accumulators start from it
+    auto biasRequest = [&](int ch) {
+        const int co = ch * 128 + lane * 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(bRsrc, (glds_dst_t)(smem + RK_BIAS), 16, (int)((lane < 32 && co < a.Cout) ? (uint32_t)co * 4u : RK_OOB), 0, 0, 0);
+    };
+
+    int item = blockIdx.x;
+    if (item >= nitems) return;
+    int y0, x0, chunk, bimg;
+    decode(item, y0, x0, chunk, bimg);
+    haloOffsets(y0, x0, bimg);
+    if (wave == 0) biasRequest(chunk);
+#pragma unroll
+    for (int i = 0; i < RK_PPW; ++i) haloRequest(i, 0, phaseOff(0));
+    weightRequests(weightBase(0, 0, chunk), 0);
+    weightRequests(weightBase(0, 1, chunk), 1);
+    slabBarrier(0);
+
+    // fragment addresses: per-lane bases + immediates
+    const int pb = ((2 * wave) * RK_HS + r) * 64;
+    int vB[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) vB[kx] = pb + kx * 64 + ((g ^ (((r + kx) >> 1) & 2)) << 4);
+    int vA[3];                                                                     // (one base per weight buffer: the immediates stay below 64 KB)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) vA[i] = RK_WOFF + i * RK_WBYTES + (lane << 4);
+    // (opaque to the optimizer: left visible, hipcc re-associates base + immediate into one constant per access, which no longer fits the 16-bit offset field,
+    // and keeps 72 address registers alive around the loop -- 200 spilled registers, each reload an s_waitcnt vmcnt(0) in the middle of the LDS-DMA stream)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { asm volatile("" : "+v"(vA[i])); asm volatile("" : "+v"(vB[i])); }
+
+    floatx4 acc[8][4];
+    half8 Bf[2][4], Af[2][4];
+    auto loadB = [&](int par, int ky, int kx, half8 (&B)[4]) {                    // (par, ky, kx: constants after inlining)
+        const unsigned char* p = smem + vB[kx] + (par * RK_HBYTES + ky * RK_HS * 64);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) B[m] = *reinterpret_cast<const half8*>(p + ((m >> 1) * RK_HS + (m & 1) * 16) * 64);
+    };
+    auto loadA = [&](int buf, int u, int c0, half8 (&A)[4]) {
+        const unsigned char* p = smem + vA[buf] + (u * 8 + c0) * 1024;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) A[ct] = *reinterpret_cast<const half8*>(p + ct * 1024);
+    };
+
+    loadB(0, 0, 0, Bf[0]);
+    for (;;) {
+        int nitem = item + gridDim.x, ny0, nx0, nch, nbimg;
+        const bool have_next = nitem < nitems;
+        if (!have_next) nitem = item;                              // (no next item: the end-of-item requests fetch this item's first phase again, into buffers nobody reads)
+        decode(nitem, ny0, nx0, nch, nbimg);
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+            const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + RK_BIAS + (ct * 16 + 4 * g) * 4);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[ct][m] = b4;
+        }
+
+        // one slab: kernel row KY of phase P (parity PAR)
+        // TAIL: P is the item's last phase (the halo / weights requested now belong to the next item); compile-time: the last two phases are peeled
+        auto slab = [&](const int P, auto kyTag, auto parTag, auto tailTag) {
+            constexpr int KY = decltype(kyTag)::value, PAR = decltype(parTag)::value;
+            constexpr bool tail = decltype(tailTag)::value;
+            // --- requests: halo pieces of phase P + 1 (ky = 0: three, ky = 1: two), then the weights of slab s + 2 (three): one request per batch of MFMAs
+            const uint32_t hso = tail ? phaseOff(0) : phaseOff(P + 1);
+            if (KY == 2 && tail && wave == 0) biasRequest(nch);   // (before the weights: retired with the older requests)
+            constexpr bool wnext = tail && KY != 0;               // the slab two ahead is slab 0 / 1 of the next item
+            const uint32_t wbase = weightBase(wnext ? 0 : (KY == 0 ? P : P + 1), (KY + 2) % 3, wnext ? nch : chunk);
+            constexpr int NH = KY == 0 ? 3 : KY == 1 ? 2 : 0;      // halo requests of this slab
+            auto request = [&](int j) {                            // j = 0 .. NH + 2 (a constant after unrolling)
+                if (j < NH) haloRequest((KY == 0 ? 0 : 3) + j, PAR ^ 1, hso);
+                else if (j < NH + 3) weightRequest(wbase, (KY + 2) % 3, j - NH);
+            };
+            // --- 3 steps x 2 batches of 16 MFMAs; the fragments of batch b + 1 are read before the MFMAs of batch b
+            loadA(KY, 0, 0, Af[0]);
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const int u = b >> 1, c0 = (b & 1) * 4, t = PAR + KY + u;         // t & 1: the B buffer of step (P, KY, u)
+                if (b + 1 < 6) {
+                    if (((b + 1) & 1) == 0) loadB(PAR, KY, u + 1, Bf[(t + 1) & 1]);
+                    loadA(KY, (b + 1) >> 1, ((b + 1) & 1) * 4, Af[(b + 1) & 1]);
+                } else {                                           // the next slab's first B fragments (its halo phase was published a slab ago at the latest); the item's
+                    if (KY == 2) loadB(PAR ^ 1, 0, 0, Bf[(t + 1) & 1]); else loadB(PAR, KY + 1, 0, Bf[(t + 1) & 1]);      // last slab reads the NEXT item's: they wait in Bf[0] through the epilogue
+                }
+                request(b);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        acc[c0 + ct][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[b & 1][ct], Bf[t & 1][m], acc[c0 + ct][m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            slabBarrier(3);                                        // everything but this slab's three weight requests has landed
+        };
+        using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+        using NT = std::false_type; using TL = std::true_type;
+#pragma unroll 1
+        for (int P = 0; P < NP - 2; P += 2) {
+            slab(P, K0{}, K0{}, NT{}); slab(P, K1{}, K0{}, NT{}); slab(P, K2{}, K0{}, NT{});
+            slab(P + 1, K0{}, K1{}, NT{}); slab(P + 1, K1{}, K1{}, NT{}); slab(P + 1, K2{}, K1{}, NT{});
+        }
+        slab(NP - 2, K0{}, K0{}, NT{}); slab(NP - 2, K1{}, K0{}, NT{}); slab(NP - 2, K2{}, K0{}, NT{});
+        haloOffsets(ny0, nx0, nbimg);                              // (this item's halo phases have all been requested: the last phase requests the next item's first)
+        slab(NP - 1, K0{}, K1{}, TL{}); slab(NP - 1, K1{}, K1{}, TL{}); slab(NP - 1, K2{}, K1{}, TL{});
+
+        // residual / ReLU / store (the bias is in the accumulators): conv_wide_kernel's epilogue for a.wide layers
+        {
+            const int n0 = chunk * 128;
+            int ctn = (a.CoutRows - n0 + 15) / 16; ctn = ctn > 8 ? 8 : ctn;
+            constexpr int TP = 4, NBLK = 4 * TP;                  // blocks b = (pixel tile m, channel-tile pair tp)
+            const int cg8 = (g & 1) * 16 + (g >> 1) * 8;
+            bool valid[4]; size_t opix[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int oy = y0 + 2 * wave + (m >> 1), ox = x0 + (m & 1) * 16 + r;
+                valid[m] = oy < a.Ho && ox < a.Wo;
+                opix[m] = valid[m] ? (size_t)(bimg * a.Ho + oy) * a.Wo + ox : 0;
+            }
+            const bool hasRes = a.res != nullptr;
+            if constexpr (SPL) {
+                constexpr int RS = 2;
+                const bool splitRes = hasRes && a.res_split != 0, resX8 = splitRes && a.res_x8 != 0;
+#pragma unroll
+                for (int b0 = 0; b0 < NBLK; b0 += RS) {
+                    half8 rh[RS], rl[RS];
+                    if (hasRes) {
+#pragma unroll
+                        for (int j = 0; j < RS; ++j) {
+                            const int b = b0 + j, m = b / TP, tp = b % TP, co = n0 + tp * 32 + cg8;
+                            const bool ok = valid[m] && co < a.Cout && 2 * tp < ctn;
+                            rh[j] = *reinterpret_cast<const half8*>(a.res + (ok ? opix[m] * a.res_ld + co : 0));
+                            if (resX8) {
+                                const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(a.res + (ok ? opix[m] * a.res_ld + 2 * a.res_split : 0)) + (ok ? x8Offset(co) : 0));
+                                rl[j] = __builtin_bit_cast(half8, make_uint4(q.x, q.y, 0u, 0u));
+                            } else rl[j] = *reinterpret_cast<const half8*>(a.res + ((ok && splitRes) ? opix[m] * a.res_ld + a.res_split + co : 0));
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < RS; ++j) {
+                        const int b = b0 + j, m = b / TP, tp = b % TP, co = n0 + tp * 32 + cg8;
+                        if (2 * tp >= ctn) continue;
+                        floatx4 X = acc[2 * tp][m], Y = acc[2 * tp + 1][m];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(X[i]), __float_as_uint(Y[i]), false, false);
+                            X[i] = __uint_as_float(sw[0]); Y[i] = __uint_as_float(sw[1]);
+                        }
+                        if (!valid[m] || co >= a.Cout) continue;
+                        float v[8] = {X[0], X[1], X[2], X[3], Y[0], Y[1], Y[2], Y[3]};
+                        if (hasRes && resX8) {
+                            const uint4 q = __builtin_bit_cast(uint4, rl[j]);
+                            const unsigned w[2] = {q.x, q.y};
+                            float lo[8]; x8DecodeLo<8>(w, lo);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) v[i] += (float)rh[j][i] + lo[i];
+                        } else if (hasRes) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) v[i] += splitRes ? (float)rh[j][i] + (float)rl[j][i] : (float)rh[j][i];
+                        }
+                        if (a.relu) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+                        }
+                        storeHalf8<true>(a, v, opix[m], co);
+                    }
+                }
+            } else {
+                constexpr int RB = 8;
+#pragma unroll
+                for (int b0 = 0; b0 < NBLK; b0 += RB) {
+                    half8 rv[RB];
+                    if (hasRes) {
+#pragma unroll
+                        for (int j = 0; j < RB; ++j) {
+                            const int b = b0 + j, m = b / TP, tp = b % TP, co = n0 + tp * 32 + cg8;
+                            const bool ok = valid[m] && co < a.Cout && 2 * tp < ctn;
+                            rv[j] = *reinterpret_cast<const half8*>(a.res + (ok ? opix[m] * a.res_ld + co : 0));
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < RB; ++j) {
+                        const int b = b0 + j, m = b / TP, tp = b % TP, co = n0 + tp * 32 + cg8;
+                        if (2 * tp >= ctn) continue;
+                        floatx4 X = acc[2 * tp][m], Y = acc[2 * tp + 1][m];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(X[i]), __float_as_uint(Y[i]), false, false);
+                            X[i] = __uint_as_float(sw[0]); Y[i] = __uint_as_float(sw[1]);
+                        }
+                        if (!valid[m] || co >= a.Cout) continue;
+                        float v[8] = {X[0], X[1], X[2], X[3], Y[0], Y[1], Y[2], Y[3]};
+                        if (hasRes) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) v[i] += (float)rv[j][i];
+                        }
+                        half8 h;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) h[i] = (_Float16)(a.relu ? fmaxf(v[i], 0.f) : v[i]);
+                        *reinterpret_cast<half8*>(static_cast<_Float16*>(a.out) + opix[m] * a.out_ld + a.out_coff + co) = h;
+                    }
+                }
+            }
+        }
+        if (!have_next) break;
+        item = nitem; y0 = ny0; x0 = nx0; chunk = nch; bimg = nbimg;
+    }
+}
+
+// the layers this kernel takes: 3 x 3, stride 1, pad 1, no pixel shuffle, 16-byte epilogue accesses legal, an even number of 32-channel phases, whole-chip grids
+bool convRowsEligible(const ConvArgs& a, int ncu) {
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.up != 1 || !a.wide || a.out_f32 || a.xscale) return false;
+    if (a.CoutRows != a.Cout || a.CoutRows <= 64 || a.Cin % 64 != 0 || a.Cin < 64) return false;
+    if (a.Ho != a.H || a.Wo != a.W) return false;
+    if ((size_t)a.nb * a.H * a.W * a.Cin * 2 >= 0xF0000000ull) return false;           // (byte offsets in 32 bits, RK_OOB beyond num_records)
+    const int nwide = cdiv(a.Ho, RK_ROWS) * cdiv(a.Wo, RK_TW) * cdiv(a.CoutRows, 128) * a.nb;
+    return nwide >= ncu;
+}
+
+int launchConvRows(const ConvArgs& a, const _Float16* Wp, int ncu, hipStream_t stream) {
+    const int tilesX = cdiv(a.Wo, RK_TW), nchunk = cdiv(a.CoutRows, 128);
+    const int nitems = cdiv(a.Ho, RK_ROWS) * tilesX * nchunk * a.nb;
+    const bool spl = a.split_out != 0 || a.res_split != 0;
+    if (spl) hipLaunchKernelGGL(conv_rows_kernel<true>, dim3(ncu), dim3(64 * RK_NW), 0, stream, a, Wp, tilesX, nitems, nchunk);
+    else hipLaunchKernelGGL(conv_rows_kernel<false>, dim3(ncu), dim3(64 * RK_NW), 0, stream, a, Wp, tilesX, nitems, nchunk);
+    return lastError();
+}
+
+}  // namespace dsvt

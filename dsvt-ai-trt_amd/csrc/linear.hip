@@ -1184,7 +1184,7 @@ int launchLinearF16Stream(const LinearArgs& a, const _Float16* Wp, hipStream_t s
         (a.add_cols % BN) == 0 && a.N <= 1024 && !a.trace) {
         static int resident = -1;  // DSVT_LINEAR_RESIDENT=0: the streamed whole-row kernel for every shape; 2: the resident one whatever the row capacity
         if (resident < 0) resident = ablateEnv("DSVT_LINEAR_RESIDENT", 1);
-        if (resident && a.N == 96 * RS_SPT * 2 && (a.add_cols % 96) == 0 && (a.max_rows >= 3 * 65536 || resident == 2)) return launchLinearF16Resident(a, Wp, stream);
+        if (resident && a.N == 96 * RS_SPT * 2 && (a.add_cols % 96) == 0 && (a.max_rows >= 3 * 65536 || resident == 2) && deviceCUs() >= a.N / (96 * RS_SPT)) return launchLinearF16Resident(a, Wp, stream);   // (fewer CUs than column types: the rows kernel, not an empty grid)
         return launchLinearF16Rows(a, Wp, stream);
     }
     dim3 grid(cdiv(a.max_rows, BM16), a.N / BN);

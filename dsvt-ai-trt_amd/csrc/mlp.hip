@@ -37,6 +37,7 @@ constexpr int MC = 192, MF = 384;                 // d_model, FFN width (include
 constexpr int MNT = MC / 16;                      // 12 column tiles
 constexpr int MNSTEP = MC / 32;                   // 6 k-steps per 192-wide slab
 constexpr int MROWS = 128;
+constexpr int kMlpTraceBlocks = 4096;    // workgroups the DSVT_MLP_TRACE buffer holds (64 stamps each); later workgroups do not stamp
 constexpr int MLP_SMALL_MAX = 8192;        // rows beyond one tile per CU that are cut into small workgroups
 constexpr int MLP_SW = 2;                  // waves of a small workgroup, 32 rows each (round 2, one frame on this kernel: two waves 53.6 vs one 50.1 us; round 3, the tail
                                            // after two whole rounds at four frames: 1.25 vs 1.27 ms per eight launches, three waves 1.27-1.30)
@@ -274,7 +275,7 @@ encoder_mlp_stream_kernel(MlpStreamArgs a)
     const int nreq = (SR - wave + nwa - 1) / nwa;    // weight rows this wave requests per stage (elastic: 3 or 2)
     const float* prm = reinterpret_cast<const float*>(lds + RS * SB);
     int nmark = 0;
-    auto mark = [&]() { if (a.trace && tid == 0 && nmark < 64) a.trace[blockIdx.x * 64 + nmark] = clock64(); ++nmark; };
+    auto mark = [&]() { if (a.trace && tid == 0 && nmark < 64 && blockIdx.x < kMlpTraceBlocks) a.trace[blockIdx.x * 64 + nmark] = clock64(); ++nmark; };   // (the trace buffer holds kMlpTraceBlocks workgroups: a four-frame launch has more)
     mark();
     auto request = [&](int s) {
         if (small) {                                 // (MLP_SW waves share the SR rows)
@@ -827,7 +828,7 @@ public:
             if constexpr (kAblate) {   // experiments (DSVT_MLP_SPLIT_VARIANT): one wave per SIMD at up to 512 registers, MT 16-row tiles per wave
                 static int sv = -1; if (sv < 0) sv = ablateEnv("DSVT_MLP_SPLIT_VARIANT", 0);
                 static unsigned long long* tr = nullptr; static int tron = -1;         // per-workgroup phase stamps (tools/mlp_split_variants.py)
-                if (tron < 0) { tron = ablateEnv("DSVT_MLP_TRACE", 0) ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 64 * 2048); }
+                if (tron < 0) { tron = ablateEnv("DSVT_MLP_TRACE", 0) ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 64 * kMlpTraceBlocks); }
                 b.trace = tr;
                 struct Dump { hipStream_t st; unsigned long long* tr; int on; ~Dump() {
                     if (!on) return;
@@ -869,7 +870,7 @@ public:
         const int gfull = cdiv(max_rows_, MROWS);                               // (covers the elastic variant too: >= 128 rows per workgroup)
         const dim3 grid(gfull + cdiv(MLP_SMALL_MAX, srows));                    // full workgroups of the whole rounds + the small ones of the remainder (the rest exit at once)
         static unsigned long long* tr = nullptr; static int tron = -1;         // tools/trace_mlp.py
-        if (tron < 0) { tron = ablateEnv("DSVT_MLP_TRACE", 0) ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 64 * 1024); }
+        if (tron < 0) { tron = ablateEnv("DSVT_MLP_TRACE", 0) ? 1 : 0; if (tron) (void)hipMallocManaged(&tr, 8 * 64 * kMlpTraceBlocks); }
         b.trace = tr;
         static int dbg = -1; if (dbg < 0) dbg = ablateEnv("DSVT_MLP_DBG", 0);
         b.dbg = dbg;

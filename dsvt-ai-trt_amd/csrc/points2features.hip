@@ -649,7 +649,12 @@ public:
                            tab, part_pts, part_key, part_idx, scan_state, (int)stateWords());
         hipLaunchKernelGGL(p2f_bins, dim3(pl.nbins), dim3(kBT), 0, stream, p_, pl, tab, part_key, srt, scan_state,
                            pil_rec, coords, pcnt, pillar_num, point_num);
-        hipLaunchKernelGGL(p2f_pillar, dim3(cdiv(cdiv(cdiv(p_.max_pillars_num, 16), 4) * 4, 8 * 256) * 8 * 256), dim3(256), 0, stream,     // four groups of S = cap / 16 wavefronts (padded to whole XCD chunks)
+        #ifdef DSVT_ABLATE
+        constexpr int kPillarPad = 8 * 256;                     // (the ablation build's largest chunk, DSVT_P2F_DBG=2048)
+#else
+        constexpr int kPillarPad = 8 * (int)kPillarChunk;
+#endif
+        hipLaunchKernelGGL(p2f_pillar, dim3(cdiv(cdiv(cdiv(p_.max_pillars_num, 16), 4) * 4, kPillarPad) * kPillarPad), dim3(256), 0, stream,     // four groups of S = cap / 16 wavefronts (padded to whole XCD chunks)
                            p_, pl.dbg, pillar_num, srt, part_pts, part_idx,
                            pil_rec, feat, pidx);
         if (tron) {

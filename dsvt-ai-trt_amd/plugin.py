@@ -124,7 +124,9 @@ EXPORTED_SYMBOLS = [
 
 GPU_ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 GPU_FREE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
-_gpu_allocator = None          # (keeps the ctypes callbacks alive)
+_gpu_allocator = None          # the pair installed now
+_gpu_allocator_thunks = []     # EVERY pair ever installed, never cleared: the library keeps the raw function pointers per outstanding block (c_api.hip deviceFreeBytes:
+                               # "memory is always released by the allocator it came from"), so a thunk may be called long after it was replaced or reset
 
 
 def set_gpu_allocator(alloc=None, free=None):
@@ -135,7 +137,7 @@ def set_gpu_allocator(alloc=None, free=None):
         LIB.dsvtSetGpuAllocator(None, None, None); _gpu_allocator = None
         return
     a = GPU_ALLOC_FN(lambda n, _u: alloc(n)); f = GPU_FREE_FN(lambda p_, _u: free(p_))
-    _gpu_allocator = (a, f)
+    _gpu_allocator = (a, f); _gpu_allocator_thunks.append((a, f))
     LIB.dsvtSetGpuAllocator(a, f, None)
 
 
@@ -629,7 +631,7 @@ def add_split_half_op(channel_num, relu=False, has_residual=False):
 
 def add_conv2d_op(weight_rows, bias, in_height, in_width, in_channels, out_channels, kernel_size=1, stride=1, padding=0,
                   pixel_shuffle=1, relu=False, has_residual=False, out_channel_stride=None, out_channel_offset=0, out_f32=False,
-                  split_output=0, split_residual=False, split_input=0):
+                  split_output=0, split_residual=False, split_input=0, kernel_variant=0):
     """NHWC fp16 implicit-GEMM convolution with fused bias / residual / ReLU / pixel-shuffle / concat offset
     (csrc/conv.hip): replaces the reference's addConvolutionNd / addDeconvolutionNd + addScale + ReLU + SUM
     groups (src/dsvt-ai-trt.cpp:149-246, 1144-1468).  Inputs: x [1,H,W,Cin] fp16 (, residual [1,Ho,Wo,C] fp16).
@@ -638,7 +640,8 @@ def add_conv2d_op(weight_rows, bias, in_height, in_width, in_channels, out_chann
     4 = [hi | lo | -] (no third plane: a tensor that is only ever a residual); split_residual: the residual input is such
     a triple (value hi + lo).  split_input (the input is a [hi | lo | x8] triple of in_channels / 3 real channels): 1 = weight_rows are
     split_weight_rows(...) and the third plane's phases read plane 0; 2 = weight_rows are the REAL fp32 rows [R][9][in_channels / 3] and the
-    layer runs on the fp16 + fp8 K loop (3 x 3, stride 1, more than 32 output channels)."""
+    layer runs on the fp16 + fp8 K loop (3 x 3, stride 1, more than 32 output channels).  kernel_variant (a test knob, not serialized): 1 = the layer
+    never takes conv_rows_kernel (csrc/conv_rows.hip), i.e. runs on round 5's conv_wide_kernel -- the two must agree bit for bit."""
     fields = dict(in_height=in_height, in_width=in_width, in_channels=in_channels, out_channels=out_channels,
                   kernel_size=kernel_size, stride=stride, padding=padding, pixel_shuffle=pixel_shuffle, relu=int(bool(relu)),
                   has_residual=int(bool(has_residual)),
@@ -651,6 +654,8 @@ def add_conv2d_op(weight_rows, bias, in_height, in_width, in_channels, out_chann
         fields["split_residual"] = int(split_residual)     # 2: the residual triple has no lo plane, its lo part is read from the x8 plane (to 2^-15)
     if split_input:
         fields["split_input"] = int(split_input)
+    if kernel_variant:
+        fields["kernel_variant"] = int(kernel_variant)
     if bias is not None:
         fields["bias"] = np.asarray(bias, np.float32).reshape(-1)
     return Plugin("DsvtConv2dPlugin", fields, "conv2d_layer")

@@ -50,3 +50,15 @@ def pad_points(p, max_points):
     out = np.zeros((max_points, 4), np.float32)
     out[:p.shape[0]] = p
     return out, p.shape[0]
+
+
+def sample_rows(n, seed=0, full_below=24576):
+    """Rows on which a per-row fp64 reference is evaluated when the tensor is large (the row-wise kernels -- linears, the encoder MLP -- compute every
+    row independently, and the fp64 restatement of 138k rows cost 7 s per case on the GPU box's host cores): None (= all rows) below `full_below`;
+    otherwise the first and last 512 rows, ONE row of every 16-row MFMA tile (so a wrong wave tile anywhere is always hit) and 2048 random rows."""
+    if n <= full_below:
+        return None
+    rng = np.random.default_rng(seed + n)
+    tiles = np.arange(0, n, 16)
+    per_tile = np.minimum(tiles + rng.integers(0, 16, tiles.shape[0]), n - 1)
+    return np.unique(np.concatenate([np.arange(512), np.arange(n - 512, n), per_tile, rng.integers(0, n, 2048)]))

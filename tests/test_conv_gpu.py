@@ -353,3 +353,42 @@ def test_shared_head_conv_on_24_row_items_equals_its_16_row_form(pkg):
     ref = torch.relu(F.conv2d(crop, w.double(), b.double(), 1, (0, 1)))[0].permute(1, 2, 0)
     got = (out[0, y0:y1, :, :cout].double() + out[0, y0:y1, :, cout:2 * cout].double()).cpu()
     assert (got - ref).abs().max().item() < 5e-6 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("H,W,cin,cout,res,B,split_out", [
+    (468, 468, 128, 128, False, 1, 4),     # the BEV ResNet layer (14 of the frame's launches): 450 items on 256 CUs, the last round partial
+    (468, 468, 128, 128, True, 2, 4),      # ... with a residual, two images: items walk image after image
+    (468, 468, 192, 128, False, 1, 1),     # the first block's entry: 18 phases; [hi | lo | hi] output
+    (150, 140, 128, 256, True, 4, 4),      # two channel chunks per tile, image edges inside the last tile column / row
+    (117, 117, 256, 256, False, 4, 4),     # the third stage at four frames: exactly 256 items
+    (200, 190, 64, 320, False, 2, 4),      # six phases, a half-empty last channel chunk (ctn = 4)
+])
+def test_rows_kernel_equals_wide_kernel(pkg, H, W, cin, cout, res, B, split_out):
+    """conv_rows_kernel (round 6, csrc/conv_rows.hip: ky-row slabs, requests through buffer descriptors, 34-pixel halo rows) against round 5's
+    conv_wide_kernel<8, 8, 36, 4, 2, 2, SPL> on the same three-product layer: both walk the (phase, tap) steps in the same order into the same accumulators,
+    so every output bit must agree (kernel_variant = 1 keeps a layer on the round-5 kernel); and against a float64 convolution (5e-6 of scale)."""
+    P = pkg.plugin
+    g = torch.Generator(device="cpu").manual_seed(H * 7 + cin + cout + B)
+    x = torch.relu(torch.randn(B, H, W, cin, generator=g) * 3.0)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    rows = P.split_weight_rows(P.conv_weight_rows(w.numpy()), 9, cin)
+    r3 = _hi_lo_junk(torch.randn(B, H, W, cout, generator=g)) if res else None
+    outs = []
+    for variant in (0, 1):
+        op = P.add_conv2d_op(rows, b.numpy(), H, W, 3 * cin, cout, 3, 1, 1, relu=True, has_residual=res, split_residual=1 if res else 0, split_input=1,
+                             split_output=split_out, out_channel_stride=3 * cout, kernel_variant=variant)
+        out = torch.full((B, H, W, 3 * cout), 7.0, dtype=torch.float16, device=DEV)
+        args = [_hi_lo_junk(x).to(DEV)] + ([r3.to(DEV)] if res else [])
+        op(*args, out=[out])
+        op(*args, out=[out])                                          # (a second launch into the same buffers: nothing carried over)
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), int((outs[0].view(torch.int16) != outs[1].view(torch.int16)).sum())
+    ref = F.conv2d(x[:1].permute(0, 3, 1, 2).double(), w.double(), b.double(), 1, 1)
+    if res:
+        ref = ref + (r3[:1, ..., :cout].double() + r3[:1, ..., cout:2 * cout].double()).permute(0, 3, 1, 2)
+    ref = torch.relu(ref)
+    o = outs[0][:1]
+    got = (o[..., :cout].double() + o[..., cout:2 * cout].double()).permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() < 5e-6 * ref.abs().max().item()

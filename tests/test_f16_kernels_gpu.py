@@ -135,11 +135,11 @@ def test_set_attention_f16_set_cap_overflow_leaves_zeros(pkg, oracle):
 # =====================================================================================================================
 # encoder_mlp_stream_kernel (DsvtEncoderMlpPlugin) vs the reference wiring src/dsvt-ai-trt.cpp:669-756
 # =====================================================================================================================
-def _mlp_reference(att16, x, xb, w, lp, block, n, mimic_roundings=True, round_weights=True):
+def _mlp_reference(att16, x, xb, w, lp, block, n, mimic_roundings=True, round_weights=True, rows=None):
     """fp64 restatement of  s1 = LN1(att Wo^T + bo + x); h = GELU(s1 W1^T + b1); y = LN3(LN2(s1 + h W2^T + b2) + x)
     (; y = LN4(y + xb)) with eps = 0 LayerNorms (layerNorm.cu:261-402 semantics: biased variance) and the tanh GELU of
     gelu.cu:201-250, on fp16-rounded weights; mimic_roundings: the two operand roundings the kernel performs (s1 and h are
-    MFMA operands of the next GEMM) are restated."""
+    MFMA operands of the next GEMM) are restated.  rows: evaluate these rows only (cases.sample_rows; every row is independent)."""
     f = lambda k: w[lp + k].astype(np.float64)
     h16 = (lambda k: r16(w[lp + k]).astype(np.float64)) if round_weights else f
 
@@ -148,7 +148,8 @@ def _mlp_reference(att16, x, xb, w, lp, block, n, mimic_roundings=True, round_we
         mu = v.mean(1, keepdims=True); var = ((v - mu) ** 2).mean(1, keepdims=True)
         return (v - mu) / np.sqrt(var) * g + b
 
-    a = att16[:n].astype(np.float64); x_ = x[:n].astype(np.float64)
+    sel = slice(0, n) if rows is None else rows
+    a = att16[sel].astype(np.float64); x_ = x[sel].astype(np.float64)
     s1 = ln(a @ h16(".win_attn.self_attn.out_proj.weight").T + f(".win_attn.self_attn.out_proj.bias") + x_, lp + ".win_attn.norm1")
     s1_op = r16(s1).astype(np.float64) if mimic_roundings else s1
     u = s1_op @ h16(".win_attn.linear1.weight").T + f(".win_attn.linear1.bias")
@@ -157,7 +158,7 @@ def _mlp_reference(att16, x, xb, w, lp, block, n, mimic_roundings=True, round_we
     s2 = ln(s1 + h_op @ h16(".win_attn.linear2.weight").T + f(".win_attn.linear2.bias"), lp + ".win_attn.norm2")
     y = ln(s2 + x_, lp + ".norm")
     if block is not None:
-        y = ln(y + xb[:n].astype(np.float64), f"module.backbone_3d.residual_norm_stage_0.{block}")
+        y = ln(y + xb[sel].astype(np.float64), f"module.backbone_3d.residual_norm_stage_0.{block}")
     return y
 
 
@@ -193,15 +194,18 @@ def test_encoder_mlp_f16_against_reference_wiring(pkg, oracle, block_ln, MR, n):
     got, got_h = mlp(*args)
     torch.cuda.synchronize()
     g = host(got)[0]
-    ref = _mlp_reference(att16, x, xb, w, lp, b_ if block_ln else None, n)
-    err = np.abs(g[:n] - ref)
+    rows = cases.sample_rows(n)                                      # large cases: the fp64 reference on a tile-covering sample of the rows
+    sel = slice(0, n) if rows is None else rows
+    ref = _mlp_reference(att16, x, xb, w, lp, b_ if block_ln else None, n, rows=rows)
+    assert np.isfinite(g[:n]).all()
+    err = np.abs(g[sel] - ref)
     # one fp16 ulp flip of an operand element (the kernel rounds an fp32-accumulated value, the reference an fp64 one) moves a
     # LayerNorm-ed O(1) output by ~3e-5; everything else is fp32 summation order
     assert err.max() < 5e-4, err.max()
     assert err.mean() < 2e-5, err.mean()
     # against the arithmetic WITHOUT the internal operand roundings: fp16-sized
-    ref0 = _mlp_reference(att16, x, xb, w, lp, b_ if block_ln else None, n, mimic_roundings=False)
-    assert np.abs(g[:n] - ref0).max() < 4e-3 and np.abs(g[:n] - ref0).mean() < 3e-4
+    ref0 = _mlp_reference(att16, x, xb, w, lp, b_ if block_ln else None, n, mimic_roundings=False, rows=rows)
+    assert np.abs(g[sel] - ref0).max() < 4e-3 and np.abs(g[sel] - ref0).mean() < 3e-4
     assert not g[n:].any()
     gh = got_h[0, :n].float().cpu().numpy()
     assert np.abs(gh - g[:n]).max() <= 2.0 ** -11 * np.abs(g[:n]).max() * 1.01           # the fp16 copy is the same value, rounded

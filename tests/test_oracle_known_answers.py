@@ -97,3 +97,25 @@ def test_point_order_invariance(oracle):
         assert O.pillar_key_fingerprint(vox["coords"], vox["P"], 468) == FP_000000["pillars"]
         (wp, gs), _ = _partition(O, vox, c)
         assert O.set_fingerprint(gs["inds"][0], gs["mask"][0], gs["S"], vox["coords"], 468) == FP_000000["w12a0"]
+
+
+def test_golden_boxes_are_current(pkg):
+    """tests/golden/oracle_boxes.npz (the committed FilterBoxByScore rows of dense_ref.forward the GPU box tests compare against, tools/make_golden.py):
+    every key of tests/golden_oracle.KEYS is present and was made from exactly the cloud, weights and caps the tests feed the GPU (the loader refuses
+    anything else), and the entry of reference frame 000000 is RE-DERIVED here from the live oracle.  The rows come from torch's CPU convolutions, whose
+    summation order depends on the host (ISA, thread count): 2e-5 on O(1..75) values, against the tests' 1e-3 bar."""
+    from tests import golden_oracle as GO
+    w = pkg.synth.make_weights()
+    for key in GO.KEYS:
+        caps, pts, n = GO.frame_inputs(pkg, key)
+        rows, cnt = GO.forward(key, pts, n, w, caps)                       # raises on a missing or stale entry
+        assert rows.shape == (500, 9) and 0 < cnt <= 500 and not rows[cnt:].any()
+        assert (rows[:cnt, 8] >= 0.3).all()                                # FilterBoxByScore's threshold (filterBoxByScore.cu:266-326)
+    caps, pts, n = GO.frame_inputs(pkg, "000000")
+    rows, cnt = GO.forward("000000", pts, n, w, caps)
+    live_rows, live_cnt = GO.live(pts, n, w, caps)
+    assert live_cnt == cnt
+    assert np.abs(live_rows[:cnt] - rows[:cnt]).max() < 2e-5
+    # a wrong cloud under a right key is refused, not served
+    with pytest.raises(AssertionError):
+        GO.forward("000000", pts, n - 1, w, caps)

@@ -103,12 +103,12 @@ def test_config1_60k_cloud_one_block_fp32(pkg, oracle, weights):
 def test_boxes_reference_frames(pkg, oracle, weights, frame):
     """fp32 mode of the HIP path against the oracle at the north-star tolerance, on reference frames and on the bench frame
     (BASELINE configs[2] size: 180k points, 34.5k pillars, 1714 / 1158 sets)."""
-    from oracle import dense_ref as D
+    from tests import golden_oracle as GO
     caps, pts, n = _frame_and_caps(pkg, frame)
     pipe = pkg.pipeline.DsvtPipeline(weights, caps=caps, device=DEV)
     boxes, cnt = _run(pkg, pipe, pts, n)
     torch.cuda.synchronize()
-    eb, ec = D.forward(pts, n, weights, _oracle_cfg(caps))
+    eb, ec = GO.forward(frame, pts, n, weights, caps)          # dense_ref.forward's rows for this cloud (tests/golden/oracle_boxes.npz, tools/make_golden.py)
     assert 0 < ec <= 500 and (ec < 500 or frame.startswith("lidar"))      # the score threshold actually filters the reference frames
     worst, unmatched = match_boxes(boxes[0].cpu().numpy(), int(cnt[0]), eb, ec)
     assert unmatched == 0 and worst < 1e-3, (worst, unmatched)     # north-star tolerance: 1e-3 fp32
@@ -264,14 +264,14 @@ def test_boxes_f16_mode(pkg, oracle, weights, frame):
     bench frame itself (lidar_like(180000, 0)).  The reference's own fp16 build (TensorRT kFP16, include/params.h:332) is not
     reproducible, so this mode is judged against the fp32 oracle with the fp16-sized bounds F16_TOL derived above.  The yaw is atan(sin/cos) of two
     raw head outputs (src/dsvt-ai-trt.cpp:1668-1669): ill-conditioned when cos ~ 0, so its bound is loose."""
-    from oracle import dense_ref as D
+    from tests import golden_oracle as GO
     caps, pts, n = _frame_and_caps(pkg, frame)
     pipe = pkg.pipeline.DsvtPipeline(weights, caps=caps, device=DEV, linear_compute=pkg.plugin.COMPUTE_F16,
                                      head_dtype=torch.float16)
     assert pipe.hip_head
     boxes, cnt = _run(pkg, pipe, pts, n)
     torch.cuda.synchronize()
-    eb, ec = D.forward(pts, n, weights, _oracle_cfg(caps))
+    eb, ec = GO.forward(frame, pts, n, weights, caps)
     err, frac = _box_errors(boxes[0].cpu().numpy(), int(cnt[0]), eb, ec)
     print("f16 box errors per field", frame, err, "matched", frac, "counts", int(cnt[0]), ec)
     assert frac >= 0.99

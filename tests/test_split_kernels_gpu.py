@@ -125,8 +125,10 @@ def test_encoder_mlp_split_against_reference_wiring(pkg, block_ln, MR, n, frames
     got, = mlp(*args)
     torch.cuda.synchronize()
     g = host(got)[0]
-    ref = _mlp_reference(att, x, xb, w, lp, b_ if block_ln else None, n, mimic_roundings=False, round_weights=False)
-    err = np.abs(g[:n] - ref)
+    rows = cases.sample_rows(n)                                      # large cases: the fp64 reference on a tile-covering sample of the rows
+    ref = _mlp_reference(att, x, xb, w, lp, b_ if block_ln else None, n, mimic_roundings=False, round_weights=False, rows=rows)
+    assert np.isfinite(g[:n]).all()
+    err = np.abs(g[slice(0, n) if rows is None else rows] - ref)
     assert err.max() < 2e-5, err.max()
     assert err.mean() < 1.5e-6, err.mean()
     assert not g[n:].any()
@@ -242,15 +244,15 @@ def test_backbone_features_split_mode(pkg, oracle, frame):
 @pytest.mark.parametrize("frame", ["000000", "000004", "lidar180000", "lidar60000s3"])
 def test_boxes_split_mode(pkg, oracle, frame):
     """the split-precision frame (bench.py's headline mode) against the fp32 oracle at the north-star tolerance, all nine columns"""
-    from oracle import dense_ref as D
+    from tests import golden_oracle as GO
     from tests.parity import match_boxes
-    from tests.test_pipeline_gpu import _frame_and_caps, _oracle_cfg, _run
+    from tests.test_pipeline_gpu import _frame_and_caps, _run
     w = pkg.synth.make_weights()
     caps, pts, n = _frame_and_caps(pkg, frame)
     pipe = pkg.pipeline.DsvtPipeline(w, caps=caps, device=DEV, linear_compute=pkg.plugin.COMPUTE_SPLIT)
     boxes, cnt = _run(pkg, pipe, pts, n)
     torch.cuda.synchronize()
-    eb, ec = D.forward(pts, n, w, _oracle_cfg(caps))
+    eb, ec = GO.forward(frame, pts, n, w, caps)
     worst, unmatched = match_boxes(boxes[0].cpu().numpy(), int(cnt[0]), eb, ec)
     print("split-mode boxes", frame, "max|diff|", worst, "unmatched", unmatched, "count", int(cnt[0]), ec)
     assert unmatched == 0 and worst < 1e-3, (worst, unmatched)
@@ -262,16 +264,22 @@ def test_boxes_split_mode(pkg, oracle, frame):
 # ill-conditioned one of the 24-cloud sweep (seed 21: a box whose rot vector is ~1 % of the head's scale, profiles/r04_mx_box_sweep.txt).
 # ---------------------------------------------------------------------------------------------------------------------
 _ORACLE_BOXES = {}
+_WEIGHTS = []
+
+
+def _weights(pkg):
+    if not _WEIGHTS:
+        _WEIGHTS.append(pkg.synth.make_weights())
+    return _WEIGHTS[0]
 
 
 def _oracle_boxes(pkg, seed):
-    """FilterBoxByScore rows of lidar_like(180000, seed) on the fp32 CPU oracle (cached per session: ~10 s each on the GPU box's host cores)"""
+    """FilterBoxByScore rows of lidar_like(180000, seed) on the fp32 CPU oracle: the committed fixture (tests/golden_oracle.py; ~10 s each when run live)"""
     if seed not in _ORACLE_BOXES:
-        from oracle import dense_ref as D
-        from tests.test_pipeline_gpu import _oracle_cfg
+        from tests import golden_oracle as GO
         caps = pkg.pipeline.Caps()
         pts, n = cases.pad_points(pkg.synth.lidar_like(180000, seed), caps.N)
-        _ORACLE_BOXES[seed] = D.forward(pts, n, pkg.synth.make_weights(), _oracle_cfg(caps))
+        _ORACLE_BOXES[seed] = GO.forward(f"lidar180000s{seed}", pts, n, _weights(pkg), caps)
     return _ORACLE_BOXES[seed]
 
 
@@ -360,15 +368,15 @@ def test_boxes_fp8_head_variant(pkg, oracle, frame, seed):
     """DsvtPipeline(head_mx=True), the opt-in fast variant of the fp32-grade frame (round 4's headline; bench.py `fp8_head_mode`): the two correction
     products of the head convolutions on the fp8 scaled MFMA.  Centres / sizes / scores stay ~1e-4 from the fp32 oracle (asserted at 3e-4); its yaw does
     NOT hold 1e-3 on boxes with a short rot vector (seed 21: 1.7e-3) -- asserted only at 5e-3, which is why the variant is not the default."""
-    from oracle import dense_ref as D
-    from tests.test_pipeline_gpu import _frame_and_caps, _oracle_cfg, _run, _box_errors
+    from tests import golden_oracle as GO
+    from tests.test_pipeline_gpu import _frame_and_caps, _run, _box_errors
     w = pkg.synth.make_weights()
     caps, pts, n = _frame_and_caps(pkg, frame if seed is None else f"lidar180000s{seed}")
     pipe = pkg.pipeline.DsvtPipeline(w, caps=caps, device=DEV, linear_compute=pkg.plugin.COMPUTE_SPLIT, head_mx=True)
     assert pipe.head_mx
     boxes, cnt = _run(pkg, pipe, pts, n)
     torch.cuda.synchronize()
-    eb, ec = _oracle_boxes(pkg, seed) if seed is not None else D.forward(pts, n, w, _oracle_cfg(caps))
+    eb, ec = _oracle_boxes(pkg, seed) if seed is not None else GO.forward(frame, pts, n, w, caps)
     err, frac = _box_errors(boxes[0].cpu().numpy(), int(cnt[0]), eb, ec)
     print("fp8-head box errors per field", frame, seed, err, "matched", frac)
     assert frac == 1.0 and int(cnt[0]) == ec
