@@ -2165,7 +2165,7 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
             if (ctWide == 8) {
                 // round 6: the ky-row-slab kernel (conv_rows.hip) for the three-product layers -- same tile, same MFMA order, bit-identical results
                 static int rowsOn = -1; if (rowsOn < 0) rowsOn = ablateEnv("DSVT_CONV_ROWS", 1);
-                if (rowsOn && spl && a.variant != 1 && !a.trace && convRowsEligible(a, ncu)) return launchConvRows(a, Wp, ncu, stream);
+                if (rowsOn && spl && a.variant != 1 && convRowsEligible(a, ncu)) return launchConvRows(a, Wp, ncu, stream);
                 // round 5, late: FOUR-step slabs in two buffers instead of two-step slabs in three -- half the workgroup barriers and counted waits per item, requests
                 // at the slab start (no trickle: LEAD = 1).  Four frames per launch: three-product 128 -> 128 at 468 x 468 780 -> 760 us, with a residual 940 -> 877, dense
                 // stage 9.95 -> 9.67 ms; fp16 frame 315 -> 308 / 367 -> 347 us, dense stage 4.00 -> 3.91 ms; one frame 2.98 -> 2.93 ms (WIDE_SPS4_DEFAULT / DSVT_CONV_SPS4=0: the two-step kernel)

@@ -46,7 +46,7 @@ struct ConvArgs {
     unsigned long long* trace;                   // debugging (DSVT_CONV_TRACE=1, tools/trace_conv.py): s_memtime stamps of waves 0 and NW/2, or nullptr
     int variant;                                 // plugin field "kernel_variant": 0 = the launcher's choice; 1 = never conv_rows_kernel (tests: the round-5 kernel of the same layer, bit for bit)
 };
-constexpr int CONV_TRACE_N = 256;               // stamps per traced wave
+constexpr int CONV_TRACE_N = 512;               // stamps per traced wave
 
 
 // hi / lo planes of N consecutive channels (saturated: |v| beyond the fp16 range gives +-65504, not inf)

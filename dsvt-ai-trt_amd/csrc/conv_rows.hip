@@ -41,12 +41,31 @@ constexpr int RK_WOFF = 2 * RK_HBYTES, RK_BIAS = RK_WOFF + 3 * RK_WBYTES, RK_SME
 static_assert(RK_HH * RK_HS <= RK_NPC * 16 && RK_SMEM <= 160 * 1024, "LDS budget");
 constexpr uint32_t RK_OOB = 0xFFFFFFF0u;           // byte offset of a lane whose halo pixel lies outside the image (>= num_records: the request writes zeros)
 
-template <bool SPL>
+// RK_HALO_IN_KY0 = 1: all five halo pieces of the next phase are requested in the phase's FIRST slab and its slab-end wait leaves them in flight (they have two
+// slabs to land: a halo line that misses the L2 takes ~900 cycles, a slab of MFMAs ~3000 per SIMD); 0: three in the first slab, two in the second, each
+// waited for at its own slab end
+#ifndef RK_HALO_IN_KY0
+#define RK_HALO_IN_KY0 0
+#endif
+#ifndef RK_STAGGER
+#define RK_STAGGER 0
+#endif
+#ifndef RK_SETPRIO
+#define RK_SETPRIO 0
+#endif
+// TR: the instrumented instantiation (ablation build, DSVT_CONV_TRACE=1, tools/trace_conv_rows.py): s_memtime stamps of waves 0 and 4 -- per slab [start, MFMAs
+// issued, own requests landed, barrier passed], per item [K loop done, epilogue done]
+// ABL: timing ablations (instantiated in the -DDSVT_ABLATE build only, DSVT_CONV_DBG; wrong results): 1 = no halo requests, 2 = no weight requests, 4 = no epilogue,
+// 8 = no fragment reads
+// EPI: the epilogue's flavour as a compile-time constant (the generic SPL epilogue with every residual / output-plane variant unrolled sixteen times is 35 KB of
+// code, more than half of the 64 KB instruction cache): 0 = generic; 1 = no residual, output [hi | lo | -] (split_output = 4); 2 = [hi | lo] residual, output [hi | lo | -]
+template <bool SPL, bool TR = false, int ABL = 0, int EPI = 0>
 __global__ void __launch_bounds__(64 * RK_NW, 1)
 conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int nitems, int nchunk)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[RK_SMEM];          // halo[2] | wslab[3] | bias
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, g = lane >> 4;
+    const bool upper = wave >= RK_NW / 2;                                          // (RK_STAGGER) the second wave of its SIMD
     const int NP = a.Cin >> 5;                                                     // 32-channel phases (even: checked by the launcher)
     const int NCT = (a.CoutRows + 127) / 128 * 8;                                  // 16-channel tiles per k-step of the packed weights
     const int perImg = nitems / a.nb;
@@ -95,6 +114,17 @@ conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int ni
 
     int item = blockIdx.x;
     if (item >= nitems) return;
+#if RK_SETPRIO
+    if (upper) __builtin_amdgcn_s_setprio(1);                     // (MI355X_MICROARCH "Two waves per SIMD" item 4: static priority for the younger half)
+#endif
+    int nmark = 0;
+    const bool tracing = TR && a.trace != nullptr && (wave == 0 || wave == RK_NW / 2);
+    auto mark = [&]() {
+        if constexpr (TR) {
+            if (tracing) { if (lane == 0 && nmark < CONV_TRACE_N) a.trace[(size_t)(blockIdx.x * 2 + (wave != 0)) * CONV_TRACE_N + nmark] = clock64(); ++nmark; }
+        }
+    };
+    mark();
     int y0, x0, chunk, bimg;
     decode(item, y0, x0, chunk, bimg);
     haloOffsets(y0, x0, bimg);
@@ -121,11 +151,21 @@ conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int ni
     floatx4 acc[8][4];
     half8 Bf[2][4], Af[2][4];
     auto loadB = [&](int par, int ky, int kx, half8 (&B)[4]) {                    // (par, ky, kx: constants after inlining)
+        if (ABL & 8) return;
         const unsigned char* p = smem + vB[kx] + (par * RK_HBYTES + ky * RK_HS * 64);
 #pragma unroll
         for (int m = 0; m < 4; ++m) B[m] = *reinterpret_cast<const half8*>(p + ((m >> 1) * RK_HS + (m & 1) * 16) * 64);
     };
+    auto loadB1 = [&](int par, int ky, int kx, int m, half8 (&B)[4]) {
+        if (ABL & 8) return;
+        B[m] = *reinterpret_cast<const half8*>(smem + vB[kx] + (par * RK_HBYTES + ky * RK_HS * 64) + ((m >> 1) * RK_HS + (m & 1) * 16) * 64);
+    };
+    auto loadA1 = [&](int buf, int u, int c0, int ct, half8 (&A)[4]) {
+        if (ABL & 8) return;
+        A[ct] = *reinterpret_cast<const half8*>(smem + vA[buf] + (u * 8 + c0 + ct) * 1024);
+    };
     auto loadA = [&](int buf, int u, int c0, half8 (&A)[4]) {
+        if (ABL & 8) return;
         const unsigned char* p = smem + vA[buf] + (u * 8 + c0) * 1024;
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) A[ct] = *reinterpret_cast<const half8*>(p + ct * 1024);
@@ -146,54 +186,77 @@ conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int ni
 
         // one slab: kernel row KY of phase P (parity PAR)
         // TAIL: P is the item's last phase (the halo / weights requested now belong to the next item); compile-time: the last two phases are peeled
-        auto slab = [&](const int P, auto kyTag, auto parTag, auto tailTag) {
+        auto slab = [&](const int P, auto kyTag, auto parTag, auto tailTag, auto upTag) {
             constexpr int KY = decltype(kyTag)::value, PAR = decltype(parTag)::value;
             constexpr bool tail = decltype(tailTag)::value;
+            constexpr bool UP = decltype(upTag)::value;            // (RK_STAGGER) this wave is the second of its SIMD: the whole K loop exists twice
             // --- requests: halo pieces of phase P + 1 (ky = 0: three, ky = 1: two), then the weights of slab s + 2 (three): one request per batch of MFMAs
             const uint32_t hso = tail ? phaseOff(0) : phaseOff(P + 1);
             if (KY == 2 && tail && wave == 0) biasRequest(nch);   // (before the weights: retired with the older requests)
             constexpr bool wnext = tail && KY != 0;               // the slab two ahead is slab 0 / 1 of the next item
             const uint32_t wbase = weightBase(wnext ? 0 : (KY == 0 ? P : P + 1), (KY + 2) % 3, wnext ? nch : chunk);
-            constexpr int NH = KY == 0 ? 3 : KY == 1 ? 2 : 0;      // halo requests of this slab
-            auto request = [&](int j) {                            // j = 0 .. NH + 2 (a constant after unrolling)
-                if (j < NH) haloRequest((KY == 0 ? 0 : 3) + j, PAR ^ 1, hso);
-                else if (j < NH + 3) weightRequest(wbase, (KY + 2) % 3, j - NH);
+            constexpr int NH = RK_HALO_IN_KY0 ? (KY == 0 ? RK_PPW : 0) : (KY == 0 ? 3 : KY == 1 ? 2 : 0);      // halo requests of this slab
+            constexpr int NREQ = NH + 3;
+            auto request = [&](int j) {                            // j = 0 .. NREQ - 1 (a constant after unrolling)
+                if (j < NH) { if (!(ABL & 1)) haloRequest((KY == 0 ? 0 : 3) + j, PAR ^ 1, hso); }
+                else if (j < NREQ) { if (!(ABL & 2)) weightRequest(wbase, (KY + 2) % 3, j - NH); }
             };
+            mark();
             // --- 3 steps x 2 batches of 16 MFMAs; the fragments of batch b + 1 are read before the MFMAs of batch b
+            // Fragment reads and requests are spread over the batch instead of issued as a burst before it (RK_SPREAD): eight waves leave the barrier together, and a
+            // burst of eight ds_read_b128 per wave at every batch boundary is 256 LDS cycles during which no wave issues an MFMA (without any fragment read the layer
+            // takes 525 instead of 685 us, tools/abl_conv_rows.sh).  Group g of a batch = the four MFMAs of channel tile g; before it: fragment g of the next batch's A
+            // (and B) tiles.  The requests of a batch go out before group 0 (waves 0-3) or group 2 (their SIMD partners 4-7: RK_STAGGER).
             loadA(KY, 0, 0, Af[0]);
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
                 const int u = b >> 1, c0 = (b & 1) * 4, t = PAR + KY + u;         // t & 1: the B buffer of step (P, KY, u)
-                if (b + 1 < 6) {
-                    if (((b + 1) & 1) == 0) loadB(PAR, KY, u + 1, Bf[(t + 1) & 1]);
-                    loadA(KY, (b + 1) >> 1, ((b + 1) & 1) * 4, Af[(b + 1) & 1]);
-                } else {                                           // the next slab's first B fragments (its halo phase was published a slab ago at the latest); the item's
-                    if (KY == 2) loadB(PAR ^ 1, 0, 0, Bf[(t + 1) & 1]); else loadB(PAR, KY + 1, 0, Bf[(t + 1) & 1]);      // last slab reads the NEXT item's: they wait in Bf[0] through the epilogue
-                }
-                request(b);
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
+                for (int gq = 0; gq < 4; ++gq) {
+                    if (b + 1 < 6) {
+                        if (((b + 1) & 1) == 0) loadB1(PAR, KY, u + 1, gq, Bf[(t + 1) & 1]);
+                        loadA1(KY, (b + 1) >> 1, ((b + 1) & 1) * 4, gq, Af[(b + 1) & 1]);
+                    } else {                                       // the next slab's first B fragments (its halo phase was published a slab ago at the latest); the item's
+                        if (KY == 2) loadB1(PAR ^ 1, 0, 0, gq, Bf[(t + 1) & 1]); else loadB1(PAR, KY + 1, 0, gq, Bf[(t + 1) & 1]);      // last slab reads the NEXT item's: they wait in Bf[0] through the epilogue
+                    }
+                    if (gq == ((RK_STAGGER && UP) ? 2 : 0)) {
+#pragma unroll
+                        for (int j = 0; j < NREQ; ++j)             // request j goes out with batch j * 6 / NREQ (the weights last)
+                            if ((j * 6) / NREQ == b) request(j);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
-                        acc[c0 + ct][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[b & 1][ct], Bf[t & 1][m], acc[c0 + ct][m], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                        acc[c0 + gq][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[b & 1][gq], Bf[t & 1][m], acc[c0 + gq][m], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            slabBarrier(3);                                        // everything but this slab's three weight requests has landed
+            // everything but this slab's three weight requests (RK_HALO_IN_KY0: and the five halo requests of a first slab) has landed
+            constexpr int KEEP = (RK_HALO_IN_KY0 && KY == 0) ? RK_PPW + 3 : 3;
+            if constexpr (TR) {
+                mark();
+                slabWait(KEEP);
+                mark();
+                __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+                mark();
+            } else slabBarrier(KEEP);
         };
         using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
         using NT = std::false_type; using TL = std::true_type;
+        auto kloop = [&](auto up) {
 #pragma unroll 1
-        for (int P = 0; P < NP - 2; P += 2) {
-            slab(P, K0{}, K0{}, NT{}); slab(P, K1{}, K0{}, NT{}); slab(P, K2{}, K0{}, NT{});
-            slab(P + 1, K0{}, K1{}, NT{}); slab(P + 1, K1{}, K1{}, NT{}); slab(P + 1, K2{}, K1{}, NT{});
-        }
-        slab(NP - 2, K0{}, K0{}, NT{}); slab(NP - 2, K1{}, K0{}, NT{}); slab(NP - 2, K2{}, K0{}, NT{});
-        haloOffsets(ny0, nx0, nbimg);                              // (this item's halo phases have all been requested: the last phase requests the next item's first)
-        slab(NP - 1, K0{}, K1{}, TL{}); slab(NP - 1, K1{}, K1{}, TL{}); slab(NP - 1, K2{}, K1{}, TL{});
-
+            for (int P = 0; P < NP - 2; P += 2) {
+                slab(P, K0{}, K0{}, NT{}, up); slab(P, K1{}, K0{}, NT{}, up); slab(P, K2{}, K0{}, NT{}, up);
+                slab(P + 1, K0{}, K1{}, NT{}, up); slab(P + 1, K1{}, K1{}, NT{}, up); slab(P + 1, K2{}, K1{}, NT{}, up);
+            }
+            slab(NP - 2, K0{}, K0{}, NT{}, up); slab(NP - 2, K1{}, K0{}, NT{}, up); slab(NP - 2, K2{}, K0{}, NT{}, up);
+            haloOffsets(ny0, nx0, nbimg);                          // (this item's halo phases have all been requested: the last phase requests the next item's first)
+            slab(NP - 1, K0{}, K1{}, TL{}, up); slab(NP - 1, K1{}, K1{}, TL{}, up); slab(NP - 1, K2{}, K1{}, TL{}, up);
+        };
+        if (RK_STAGGER && upper) kloop(std::true_type{}); else kloop(std::false_type{});
+        mark();
         // residual / ReLU / store (the bias is in the accumulators): conv_wide_kernel's epilogue for a.wide layers
-        {
+        if (!(ABL & 4)) {
             const int n0 = chunk * 128;
             int ctn = (a.CoutRows - n0 + 15) / 16; ctn = ctn > 8 ? 8 : ctn;
             constexpr int TP = 4, NBLK = 4 * TP;                  // blocks b = (pixel tile m, channel-tile pair tp)
@@ -205,10 +268,10 @@ conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int ni
                 valid[m] = oy < a.Ho && ox < a.Wo;
                 opix[m] = valid[m] ? (size_t)(bimg * a.Ho + oy) * a.Wo + ox : 0;
             }
-            const bool hasRes = a.res != nullptr;
+            const bool hasRes = EPI == 0 ? a.res != nullptr : EPI == 2;
             if constexpr (SPL) {
                 constexpr int RS = 2;
-                const bool splitRes = hasRes && a.res_split != 0, resX8 = splitRes && a.res_x8 != 0;
+                const bool splitRes = EPI == 0 ? (hasRes && a.res_split != 0) : EPI == 2, resX8 = EPI == 0 && splitRes && a.res_x8 != 0;
 #pragma unroll
                 for (int b0 = 0; b0 < NBLK; b0 += RS) {
                     half8 rh[RS], rl[RS];
@@ -250,7 +313,14 @@ conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int ni
 #pragma unroll
                             for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
                         }
-                        storeHalf8<true>(a, v, opix[m], co);
+                        if constexpr (EPI == 0) storeHalf8<true>(a, v, opix[m], co);
+                        else {                                     // [hi | lo | -]: two 16-byte stores
+                            _Float16* o = static_cast<_Float16*>(a.out) + opix[m] * a.out_ld + a.out_coff + co;
+                            half8 hi, lo;
+                            splitPlanes<8>(v, hi, lo);
+                            *reinterpret_cast<half8*>(o) = hi;
+                            *reinterpret_cast<half8*>(o + a.split_out) = lo;
+                        }
                     }
                 }
             } else {
@@ -290,6 +360,7 @@ conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int ni
                 }
             }
         }
+        mark();
         if (!have_next) break;
         item = nitem; y0 = ny0; x0 = nx0; chunk = nch; bimg = nbimg;
     }
@@ -309,6 +380,15 @@ int launchConvRows(const ConvArgs& a, const _Float16* Wp, int ncu, hipStream_t s
     const int tilesX = cdiv(a.Wo, RK_TW), nchunk = cdiv(a.CoutRows, 128);
     const int nitems = cdiv(a.Ho, RK_ROWS) * tilesX * nchunk * a.nb;
     const bool spl = a.split_out != 0 || a.res_split != 0;
+    if constexpr (kAblate) {
+        static int dbg = -1; if (dbg < 0) dbg = ablateEnv("DSVT_CONV_DBG", 0);
+        if (a.trace && spl) { hipLaunchKernelGGL((conv_rows_kernel<true, true>), dim3(ncu), dim3(64 * RK_NW), 0, stream, a, Wp, tilesX, nitems, nchunk); return lastError(); }
+#define RK_ABL(N_) if (spl && dbg == N_) { hipLaunchKernelGGL((conv_rows_kernel<true, false, N_>), dim3(ncu), dim3(64 * RK_NW), 0, stream, a, Wp, tilesX, nitems, nchunk); return lastError(); }
+        RK_ABL(1) RK_ABL(2) RK_ABL(3) RK_ABL(4) RK_ABL(7) RK_ABL(8) RK_ABL(15)
+#undef RK_ABL
+    }
+    if (spl && a.split_out && a.x8_out == 3 && !a.res) { hipLaunchKernelGGL((conv_rows_kernel<true, false, 0, 1>), dim3(ncu), dim3(64 * RK_NW), 0, stream, a, Wp, tilesX, nitems, nchunk); return lastError(); }
+    if (spl && a.split_out && a.x8_out == 3 && a.res && a.res_split && !a.res_x8) { hipLaunchKernelGGL((conv_rows_kernel<true, false, 0, 2>), dim3(ncu), dim3(64 * RK_NW), 0, stream, a, Wp, tilesX, nitems, nchunk); return lastError(); }
     if (spl) hipLaunchKernelGGL(conv_rows_kernel<true>, dim3(ncu), dim3(64 * RK_NW), 0, stream, a, Wp, tilesX, nitems, nchunk);
     else hipLaunchKernelGGL(conv_rows_kernel<false>, dim3(ncu), dim3(64 * RK_NW), 0, stream, a, Wp, tilesX, nitems, nchunk);
     return lastError();
