@@ -28,9 +28,11 @@ Three precision modes are timed by a default run (N = 1):
 
 Timing: K steps per repeat, every repeat between two torch.cuda.synchronize() on every rank; R = max(3, min(15, ceil(300 / K))) repeats (a function
 of K only).  Collectives: one all-gather of the ranks' device identities at start-up (n_gpus = DISTINCT devices, checked), one barrier before the first
-repeat, the result gather inside the LAST repeat (`gather_ms`; rank 0 checks its own rows in the gathered tensor bit for bit), one barrier after it, ONE
+repeat, the RESULT GATHER AFTER EVERY BATCH (one forward per stream on every rank = frames_in_flight frames per rank; `--gather-every-batch`, the default
+whenever a communicator exists: N > 1 and `--rccl-single`) inside every repeat -- the product loop of BASELINE configs[3], buffers allocated once (round 5
+gathered once, in the last repeat: `--gather-once`) --, rank 0 checks its own rows in the gathered tensor bit for bit, one barrier after the last repeat, ONE
 all-gather of the R per-repeat times (`repeat_values_per_rank`); `value` = total frames / median over the repeats of the max-over-ranks time -- the same protocol for
-every N, so N = 8 / N = 1 compares like with like.  The roofline sample (one eager forward with HIP events around every launch) is a pre-pass
+every N, so N = 8 / N = 1 compares like with like (a communicator-free N = 1 run has no collective to time: `gathers_per_repeat` says which it was).  The roofline sample (one eager forward with HIP events around every launch) is a pre-pass
 outside every timed region.
 
 Extra objects in the line:
@@ -275,6 +277,9 @@ class ModeRun:
         self.scratch = [torch.zeros((FB, par.ROW), dtype=torch.float32, device=dev) for _ in range(NS)]
         self.replay_equals_eager = None
         self.collective = world > 1 or args.rccl_single
+        # --gather-every-batch: the buffers of the per-batch gather exist before any graph is captured
+        self.batch_buffers = par.GatherBuffers(self.NS * FB * world, rank, world, dev, staged=(torch.distributed.is_initialized() and torch.distributed.get_backend() == "gloo")) if (self.collective and args.gather_every_batch) else None
+        self.gathered_all = torch.zeros((args.steps * world, par.ROW), dtype=torch.float32, device=dev) if (self.batch_buffers is not None and rank == 0) else None
 
     def pack(self, boxes, cnt, rows):
         """boxes [FB,500,9], cnt [FB] -> FB rows of the result buffer (two device ops, no host sync)"""
@@ -301,6 +306,13 @@ class ModeRun:
 
     def prepare(self):
         a = self.args
+        # every pipeline's FIRST forward runs on the process's current stream, before its side stream sees any work.  Round 6 (tools/bisect_gather_fault.sh,
+        # DESIGN 5): with a communicator alive, pipelines whose first forward ran on a side stream (capture()'s warm-up) fault at the first two-stream graph
+        # replay ("illegal memory access" / "write access to a read-only page"), with or without a collective in the loop; one eager forward on the
+        # current stream first and thirty batches with a gather after each run clean.  Not understood below that level (the library holds no per-stream state).
+        for s in range(self.NS):
+            self.run_frame(s, self.scratch[s], eager=True)
+        torch.cuda.synchronize()
         for s in range(self.NS):
             with torch.cuda.stream(self.streams[s]):
                 for i in range(max(a.warmup, 1)):
@@ -348,14 +360,30 @@ class ModeRun:
         marks = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(KB)]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        every = self.collective and self.args.gather_every_batch
+        gathered, gather_ms = None, None
         for i in range(KB):
             with torch.cuda.stream(self.streams[i % NS]):
                 marks[i][0].record()
                 self.run_frame(i, results[i * FB:(i + 1) * FB])
                 marks[i][1].record()
+            if every and (i + 1) % NS == 0:
+                # the product loop of BASELINE configs[3] (src/dsvt-ai-trt.cpp:1884-1970: a result per frame, every frame): the rows of this batch -- one forward
+                # per stream on every rank -- meet on rank 0 before the next batch's rows exist; static buffers (parallel.GatherBuffers), no allocation
+                b = (i + 1) // NS - 1
+                for s in self.streams:
+                    torch.cuda.current_stream().wait_stream(s)
+                g = par.gather_results(results[b * NS * FB:(b + 1) * NS * FB], NS * FB * self.world, self.rank, self.world, force_collective=self.args.rccl_single,
+                                       buffers=self.batch_buffers)
+                if g is not None:
+                    self.gathered_all[b * NS * FB * self.world:(b + 1) * NS * FB * self.world].copy_(g)
         for s in self.streams:
             torch.cuda.current_stream().wait_stream(s)
-        gathered, gather_ms = None, None
+        if every:
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            frame_ms = [marks[i][0].elapsed_time(marks[i][1]) for i in range(KB)]
+            return dt, frame_ms, (self.gathered_all if self.rank == 0 else None), None
         if gather:
             torch.cuda.synchronize()
             tg = time.perf_counter()
@@ -571,12 +599,18 @@ def main():
                                                                "really goes through RCCL (SURVEY 8e: exercising the collective on one device)")
     ap.add_argument("--share-gpu", action="store_true", help="N > visible GPUs: rank r uses GPU r mod visible (a launcher / RCCL dry run on one device; "
                                                              "the line is marked and is NOT a scaling number)")
+    ap.add_argument("--gather-every-batch", dest="gather_every_batch", action="store_true", default=None,
+                    help="the result gather runs after EVERY batch (one forward per stream on every rank) inside every repeat, with buffers allocated once -- the product loop of "
+                         "BASELINE configs[3]; default for N > 1 and with --rccl-single.  --gather-once: round 5's protocol (the gather inside the last repeat only)")
+    ap.add_argument("--gather-once", dest="gather_every_batch", action="store_false")
     ap.add_argument("--repeats", type=int, default=0, help="repeats of the K-step timed loop (0 = max(3, min(15, ceil(300 / K))): a function of K only, so every rank runs the same number)")
     ap.add_argument("--dump-rows", default=None, help="rank 0 saves the gathered result rows [K * N, 4501] of the headline mode as .npy (tests: the gather against single-process rows)")
     ap.add_argument("--no-cpp-host", action="store_true", help="skip cpp_host_mode (the C++ host dsvt_detect on the same clouds: writes an ~80 MB .wts file, ~25 s)")
     ap.add_argument("--oracle-clouds", type=int, default=8, help="how many 180k-point clouds the timed modes' boxes are checked on against the CPU oracle (~10 s of host time each on the GPU box; cpu_baseline.box_err_vs_oracle = the worst over them)")
     ap.add_argument("--no-whole-network-cpu", action="store_true", help="cpu_baseline skips the whole network on the CPU oracle (~10 s; also drops box_err_vs_oracle)")
     args = ap.parse_args()
+    if args.gather_every_batch is None:
+        args.gather_every_batch = args.gpus > 1 or args.rccl_single
     # the product library reads no environment switch (csrc/plugin_base.h ablateEnv), and a timed run must not load another build either
     stray = sorted(k for k in os.environ if k.startswith("DSVT_"))
     if stray:
@@ -661,6 +695,8 @@ def main():
         # communicator, as much as 23 frames), which is start-up cost, not a property of the frame path
         if world > 1 or args.rccl_single:
             par.gather_results(results, K * world, rank, world, force_collective=args.rccl_single)
+            if run.batch_buffers is not None:
+                par.gather_results(results[:run.NS * FB], run.NS * FB * world, rank, world, force_collective=args.rccl_single, buffers=run.batch_buffers)
         sampled = run.sample(results, prof) if prof is not None else 0
         dts, frame_ms, gathered, gather_ms = run.measure(results, K)
         if rank != 0:
@@ -680,6 +716,7 @@ def main():
                    repeat_values=[round(total / d, 1) for d in dts],
                    gather_ms=None if gather_ms is None or not run.collective else round(gather_ms, 3),
                    value_of_the_repeat_with_the_gather=round(total / dts[-1], 3),
+                   gathers_per_repeat=(K // (FB * run.NS)) if (run.collective and args.gather_every_batch) else (1 if run.collective else 0),
                    graph_replay_equals_eager=run.replay_equals_eager, frame0=counts[0], gather_own_rows_bit_identical=own_ok,
                    repeat_values_per_rank=[[round(K / d, 1) for d in pr] for pr in getattr(run, "per_rank_dts", [])] if world > 1 else None)
         out["_run"] = run
@@ -715,6 +752,7 @@ def main():
             "data": "synthetic" + (" (uploaded from pinned host memory inside the timed region)" if args.host_input else ""),
             "repeats": head["repeats"], "repeat_values": head["repeat_values"], "gather_ms": head["gather_ms"],
             "value_of_the_repeat_with_the_gather": head["value_of_the_repeat_with_the_gather"],
+            "gathers_per_repeat": head["gathers_per_repeat"],
             "repeat_values_per_rank": head["repeat_values_per_rank"],
             "config": {"workload": f"BASELINE configs[2]: lidar_like({args.points}, seed) Waymo-shaped cloud, 0.32 m pillars, "
                                    "468x468 BEV, full 4-block DSVT pillar backbone + BEV ResNet + CenterHead + top-K decode + "
@@ -730,9 +768,11 @@ def main():
                        "devices": {"ranks": world, "distinct": n_distinct, "identities_md5": [d for d, _ in dev_ids]},
                        "launch": "hip-graph replay per forward" if not args.no_graph else "host launch per op",
                        "frames_in_flight": run.NS * FB, "frames_per_forward": FB,
-                       "timing": f"K = {K} steps per repeat, each repeat between two torch.cuda.synchronize() on every rank; one barrier before the first repeat, "
-                                 "the result gather inside the LAST repeat (gather_ms), one barrier after it, ONE all-gather of the per-repeat times (max over ranks on the host); "
-                                 "value = total frames / median over repeats of the max-over-ranks time; the roofline sample is a pre-pass outside every timed region",
+                       "timing": (f"K = {K} steps per repeat, each repeat between two torch.cuda.synchronize() on every rank; one barrier before the first repeat, " +
+                                  ("the result gather after EVERY batch of frames_in_flight frames per rank inside every repeat (static buffers, rank 0 checks its own rows of the last repeat bit for bit), "
+                                   if (run.collective and args.gather_every_batch) else "the result gather inside the LAST repeat (gather_ms), ") +
+                                  "one barrier after the last repeat, ONE all-gather of the per-repeat times (max over ranks on the host); "
+                                  "value = total frames / median over repeats of the max-over-ranks time; the roofline sample is a pre-pass outside every timed region"),
                        "caps": dict(points=caps.N, pillars=caps.P, windows=caps.W, sets=caps.S, overflow_free=caps.overflow_free()),
                        "frame0": head["frame0"]},
             "roofline": head["roofline"],

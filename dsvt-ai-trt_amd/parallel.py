@@ -54,17 +54,52 @@ def unpack_result(row):
     return row[:ROW - 1].reshape(500, 9), int(round(float(row[ROW - 1])))
 
 
-def gather_results(local, n_frames, rank, world, dst=0, force_collective=False):
+class GatherBuffers:
+    """The tensors one result gather needs, allocated ONCE (before any HIP graph is captured) and reused by every call: the padded send rows, on `dst` the
+    per-rank receive buffers and the output in global frame order.  gather_results() without them allocates all three through the caching allocator on
+    every call -- while captured graphs are alive that is the one ingredient of the steady-state loop (a gather after every batch, the loop shape of
+    src/dsvt-ai-trt.cpp:1884-1970) that differs from the pattern known to run, so the product loop does not do it."""
+
+    def __init__(self, n_frames, rank, world, device, dtype=torch.float32, dst=0, staged=False):
+        self.n_frames, self.rank, self.world, self.dst = n_frames, rank, world, dst
+        per = (n_frames + world - 1) // world
+        gdev = torch.device("cpu") if staged else torch.device(device)
+        self.pad = torch.zeros((per, ROW), dtype=dtype, device=gdev)
+        self.bufs = [torch.empty_like(self.pad) for _ in range(world)] if rank == dst else None
+        self.flat = torch.empty((world * per, ROW), dtype=dtype, device=gdev)          # (all-gather form: every rank receives every rank's rows)
+        self.out = torch.empty((n_frames, ROW), dtype=dtype, device=device) if rank == dst else None
+        self.ids = [torch.tensor(shard_frames(n_frames, r, world), dtype=torch.long, device=device) for r in range(world)] if rank == dst else None
+
+
+def gather_results(local, n_frames, rank, world, dst=0, force_collective=False, buffers=None, collective="gather"):
     """local: [frames_of_this_rank, ROW].  Returns on `dst` a [n_frames, ROW] tensor in global frame
     order (None elsewhere).  One gather for the whole batch; ranks may own a different number of
     frames, so rows are padded to the maximum.  A single process skips the collective unless
-    force_collective (needs init(single_rank_group=True))."""
+    force_collective (needs init(single_rank_group=True)).  buffers: a GatherBuffers made for the same (n_frames, rank, world): no allocation in the call
+    (the returned tensor is buffers.out, overwritten by the next call)."""
     if world == 1 and not (force_collective and dist.is_initialized()):
         return local
     per = (n_frames + world - 1) // world
     # gloo gathers host tensors only: device rows are staged through the host (the CPU tests, and bench.py --share-gpu, where RCCL
     # refuses two ranks on one device: "Duplicate GPU detected"); with nccl (= RCCL) the rows never leave the devices
     stage = local.is_cuda and dist.get_backend() == "gloo"
+    if buffers is not None:
+        assert (buffers.n_frames, buffers.rank, buffers.world, buffers.dst) == (n_frames, rank, world, dst)
+        assert buffers.pad.is_cuda == (local.is_cuda and not stage), "GatherBuffers(staged=...) does not match the backend"
+        buffers.pad[:local.shape[0]].copy_(local)
+        if collective == "all_gather":
+            dist.all_gather_into_tensor(buffers.flat, buffers.pad)
+            recv = [buffers.flat[r * per:(r + 1) * per] for r in range(world)]
+        else:
+            dist.gather(buffers.pad, buffers.bufs, dst=dst)
+            recv = buffers.bufs
+        if rank != dst:
+            return None
+        for r in range(world):
+            k = buffers.ids[r].shape[0]
+            if k:
+                buffers.out.index_copy_(0, buffers.ids[r], recv[r][:k].to(buffers.out.device, non_blocking=False))
+        return buffers.out
     gdev = torch.device("cpu") if stage else local.device
     pad = torch.zeros((per, ROW), dtype=local.dtype, device=gdev)
     pad[:local.shape[0]].copy_(local)

@@ -48,6 +48,15 @@ def _worker(rank, world, port, n_frames, q):
         ok = ok and par.own_rows_match(out, local, n_frames, r, w)
         bad = out.clone(); bad[0, 7] += 1.0
         ok = ok and not par.own_rows_match(bad, local, n_frames, r, w)
+    # the product loop's form (round 6): buffers allocated once (parallel.GatherBuffers), a gather after every batch -- three batches whose rows differ --,
+    # through dist.gather and through the all-gather form; every call returns the same rows as the allocating call
+    gb = par.GatherBuffers(n_frames, r, w, torch.device("cpu"))
+    for coll in ("gather", "all_gather"):
+        for batch in range(3):
+            shifted = local + float(batch)
+            got = par.gather_results(shifted, n_frames, r, w, buffers=gb, collective=coll)
+            ref = par.gather_results(shifted, n_frames, r, w)
+            ok = ok and ((got is None and ref is None) if r != 0 else (got is gb.out and torch.equal(got, ref)))
     if r == 0:
         for f in range(n_frames):
             b, c = par.unpack_result(out[f])

@@ -127,3 +127,24 @@ def test_two_processes_time_sharing_the_device_are_reproducible():
         assert p.returncode == 0, o[-2000:]
         last = [l for l in o.splitlines() if l.startswith("rank")][-1]
         assert last.endswith("iterations differing per stream: none"), o[-2000:]
+
+
+def _gather_loop(args, timeout=600):
+    env = dict(os.environ, MASTER_PORT=str(29600 + os.getpid() % 300))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gather_loop_worker.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_gather_after_every_batch_rccl_single():
+    """The steady-state loop of BASELINE configs[3] on one rank (missing 2): headline-mode pipelines (split precision, four frames per
+    forward) on two streams, HIP-graph replay, and a result gather through a size-1 RCCL communicator after EVERY batch of eight frames, thirty batches,
+    gather buffers allocated once before capture (parallel.GatherBuffers) -- the loop shape of src/dsvt-ai-trt.cpp:1884-1970 (a result per frame, every
+    frame).  Every batch's gathered rows are the bits of the first batch's (same clouds).  Round 5 only ever gathered once per run."""
+    res = _gather_loop(["30", "static"])
+    assert res["ok"] and res["batches"] == 30 and all(c > 0 for c in res["counts"]), res
+    # ... and with bench.py's other ingredients around every gather (barrier before and after, an all-gather of the times, frames uploaded from pinned memory,
+    # events around every forward): the interleaving round 4 saw fault.  (What made it fault is the order of the pipelines' first forwards, not any of these:
+    # tools/bisect_gather_fault.sh, profiles/r06_gather_fault_bisect.txt, DESIGN 5.)
+    res = _gather_loop(["30", "static", "barriers", "allreduce", "pinned", "events"])
+    assert res["ok"], res
