@@ -113,7 +113,7 @@ def box_errors(got, n_got, exp, n_exp):
                 max_xyz_size_score=float(max(m[:6].max(), m[8])), matched=round(matched / max(n_exp, 1), 4), boxes=int(n_got), oracle_boxes=int(n_exp))
 
 
-def cpu_baseline(caps, frames, n_parallel_frames=32, whole_network=None, mode_rows=None, check_clouds=None):
+def cpu_baseline(caps, frames, n_parallel_frames=32, whole_network=None, mode_rows=None, check_clouds=None, n_points_key=N_POINTS, live_seed=0):
     """SURVEY 8(d).  frames: [(points [n,4] float32 numpy, FilterBoxByScore rows [500,9] float32 numpy from the GPU, count)].
     value = frames/s of the reference's host path, ONE thread: loadData (read the .bin, size check, zero-pad to the cap) +
     save_result + nms_cpu on the GPU's own rows.  whole_network = (weights,): the whole network of frame 0 on the CPU oracle;
@@ -182,9 +182,20 @@ def cpu_baseline(caps, frames, n_parallel_frames=32, whole_network=None, mode_ro
             # the oracle as the CHECKER of the timed modes: FilterBoxByScore rows (before NMS, like the reference engine's output) of every check
             # cloud -- the 24-cloud sweep's ill-conditioned one (seed 21) among them --, worst error per column over all of them
             errs = {m: [] for m in mode_rows}
+            from tests import golden_oracle as GO
+            src = {"golden": 0, "live": 0}
             for ci, (seed, cp) in enumerate(check_clouds):
                 pc = np.zeros((caps.N, 4), np.float32); pc[:cp.shape[0]] = cp
-                ob, oc = D.forward(pc, cp.shape[0], weights, cfg)
+                # the oracle's rows for this cloud: the committed fixture (tests/golden/oracle_boxes.npz: made by tools/make_golden.py from the live oracle, refused when
+                # its recorded inputs differ from these points / weights / caps); a cloud without a fixture runs the live oracle (~10 s)
+                try:
+                    ob, oc = GO.forward(f"lidar{n_points_key}s{seed}", pc, cp.shape[0], weights, caps); src["golden"] += 1
+                except (KeyError, FileNotFoundError):
+                    ob, oc = D.forward(pc, cp.shape[0], weights, cfg); src["live"] += 1
+                if seed == live_seed:          # frame 0 ran on the LIVE oracle above: the fixture of the same cloud must be its rows
+                    e_ = box_errors(np.asarray(ob), int(oc), np.asarray(boxes), int(cnt))       # (rows matched by class + centre: two candidates whose scores differ by 1e-7 may swap ranks between hosts)
+                    out["whole_network_port"]["golden_fixture_vs_live_oracle"] = None if e_ is None else dict(max_abs_all_nine_columns=max(e_["max_xyz_size_score"], e_["yaw"]), matched=e_["matched"],
+                                                                                                               rows=(int(oc), int(cnt)))
                 for m, rows in mode_rows.items():
                     errs[m].append(box_errors(rows[ci][0], rows[ci][1], ob, int(oc)))
             cols = ("xy", "z", "size", "yaw", "score", "max_xyz_size_score")
@@ -197,6 +208,7 @@ def cpu_baseline(caps, frames, n_parallel_frames=32, whole_network=None, mode_ro
                               per_cloud_worst=[round(max(e["max_xyz_size_score"], e["yaw"]), 7) for e in es_])
                 out["box_err_vs_oracle"][m] = w_
             out["box_err_vs_oracle"]["seeds"] = [sd for sd, _ in check_clouds]
+            out["box_err_vs_oracle"]["oracle_rows_from"] = src
             out["box_err_vs_oracle"]["note"] = ("WORST absolute error per column over the check clouds (lidar_like(points, seed) for the listed seeds, run through the timed "
                                                 "pipelines: same kernels, same frames per forward) of the FilterBoxByScore rows against the fp32 CPU oracle, rows matched by "
                                                 "class + nearest centre; all_nine_columns = max over x, y, z, the sizes, yaw, score (the class matches by construction); "
@@ -244,6 +256,84 @@ def cpp_host_mode(pkg, weights, clouds, repeat=12):
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def other_configs(pkg, weights, dev):
+    """The single-GPU configurations of BASELINE.json besides the one `value` is quoted on, timed in the same driver run (missing 4):
+      configs[1]  lidar_like(60000, 0): voxelize + WindowPartition_0 + GetSet_0 + ONE DSVT block, fp32 (v_mfma_f32_16x16x4_f32), HIP-graph replay: ms per cloud, and the
+                  set-attention kernel priced against the fp32-matrix peak (parity: tests/test_pipeline_gpu.py::test_config1_60k_cloud_one_block_fp32)
+      configs[4]  lidar_like(300000, 0): the two-stage 3-D voxel backbone (pipeline3d.Dsvt3dBackbone, 468 x 468 x 32 -> 468 x 468 x 8), HIP-graph replay: ms per
+                  cloud, and the voxelizer / partition launches priced in GB/s (parity: tests/test_voxel3d_gpu.py)"""
+    P = pkg.plugin
+    out = {}
+
+    def replay_ms(fwd, ins, reps=24):
+        sin = tuple(torch.zeros_like(t) for t in ins[0])
+        for t, v in zip(sin, ins[0]):
+            t.copy_(v)
+        for _ in range(3):
+            fwd(*sin)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fwd(*sin)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(reps):
+            for t, v in zip(sin, ins[i % len(ins)]):
+                t.copy_(v)
+            g.replay()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    def plugin_rows(fwd, ins):
+        P.PROFILE = {k: [] for k in P.plugin_types()}
+        fwd(*ins); torch.cuda.synchronize()
+        prof, P.PROFILE = P.PROFILE, None
+        return {k: (sum(e0.elapsed_time(e1) for e0, e1, _ in v) * 1e3, len(v)) for k, v in prof.items() if v}
+
+    # configs[1]
+    caps = pkg.pipeline.Caps(65536, 65536, 32768, 2048, 576)
+    pipe = pkg.pipeline.DsvtPipeline(weights, caps=caps, blocks=1, with_head=False, device=dev, linear_compute=P.COMPUTE_F32)
+    ins = []
+    for sd in range(2):
+        p = pkg.synth.lidar_like(60000, sd); buf = np.zeros((1, caps.N, 4), np.float32); buf[0, :len(p)] = p
+        ins.append((torch.from_numpy(buf).to(dev), torch.tensor([len(p)], dtype=torch.int32, device=dev)))
+    fwd = lambda pts, n: pipe.backbone(pipe.voxel_stage(pts, n))
+    st = pipe.voxel_stage(*ins[0]); torch.cuda.synchronize()
+    Pn, Nk, S = int(st["P"][0]), int(st["Nk"][0]), [int(g[2][0]) for g in st["gss"]]
+    ms = replay_ms(fwd, ins)
+    rows = plugin_rows(fwd, ins[0])
+    att_us, att_n = rows.get("DsvtSetAttentionPlugin", (0.0, 0))
+    att_fl = sum(4.0 * 36 * 36 * 192 * S[l % len(S)] for l in range(att_n))                      # QK^T + AV of every set, both layers (layer l on window configuration l)
+    out["configs[1]"] = dict(workload="lidar_like(60000, 0): voxelize + WindowPartition_0 + GetSet_0 + one DSVT block (two encoder layers), fp32 (COMPUTE_F32: v_mfma_f32_16x16x4_f32), HIP-graph replay",
+                             ms_per_cloud=round(ms, 4), clouds_per_s=round(1e3 / ms, 1), counts=dict(P=Pn, Nk=Nk, S=S),
+                             set_attention=dict(kernel="set_attention_kernel (v_mfma_f32_16x16x4_f32, fp32 I/O)", launches=att_n, us_per_launch=round(att_us / max(att_n, 1), 2),
+                                                achieved=round(att_fl / max(att_us, 1e-9) / 1e6, 3), peak=PEAK_F32_MATRIX_TFLOPS, unit="TFLOP/s",
+                                                frac=round(att_fl / max(att_us, 1e-9) / 1e6 / PEAK_F32_MATRIX_TFLOPS, 4),
+                                                hbm_gbs=round(att_n * Pn * 192 * 4 * 4 / max(att_us, 1e-9) / 1e3, 1),
+                                                note="algorithmic flops = 4 x 36 x 36 x 192 per set (QK^T + AV); bound by HBM / latency at this size, not by the fp32 matrix pipe"),
+                             plugin_us={k: round(v[0], 1) for k, v in sorted(rows.items(), key=lambda kv: -kv[1][0])})
+    del pipe
+    # configs[4]
+    net = pkg.pipeline3d.Dsvt3dBackbone(pkg.synth.make_weights_3d(), device=dev)
+    ins = []
+    for sd in range(2):
+        p = pkg.synth.lidar_like(300000, sd); buf = np.zeros((1, net.N, 4), np.float32); buf[0, :len(p)] = p
+        ins.append((torch.from_numpy(buf).to(dev), torch.tensor([len(p)], dtype=torch.int32, device=dev)))
+    x, coords, Pl = net.forward(*ins[0]); torch.cuda.synchronize()
+    ms = replay_ms(net.forward, ins)
+    rows = plugin_rows(net.forward, ins[0])
+    npts = int(ins[0][1][0])
+    p2f_us = rows.get("Points2FeaturesPlugin", (0.0, 0))[0]
+    out["configs[4]"] = dict(workload="lidar_like(300000, 0): two-stage 3-D voxel DSVT backbone (468 x 468 x 32 voxels -> block over 12 x 12 x 32 windows -> pooling by (1, 1, 4) -> block over "
+                                      "12 x 12 x 8 windows), split precision, HIP-graph replay",
+                             ms_per_cloud=round(ms, 4), clouds_per_s=round(1e3 / ms, 1), voxels_last_stage=int(Pl[0]),
+                             voxelizer=dict(us=round(p2f_us, 1), algorithmic_mb=round((16.0 * npts + 44.0 * npts) / 1e6, 2), gbs=round((16.0 * npts + 44.0 * npts) / max(p2f_us, 1e-9) / 1e3, 1),
+                                            peak=PEAK_HBM_GBS, note="16 N bytes read + 44 Nk written (Nk <= N: upper bound on the bytes, so on the GB/s)"),
+                             plugin_us={k: round(v[0], 1) for k, v in sorted(rows.items(), key=lambda kv: -kv[1][0])})
+    return out
 
 
 def spawn_ranks(n, share_gpu):
@@ -605,6 +695,7 @@ def main():
     ap.add_argument("--gather-once", dest="gather_every_batch", action="store_false")
     ap.add_argument("--repeats", type=int, default=0, help="repeats of the K-step timed loop (0 = max(3, min(15, ceil(300 / K))): a function of K only, so every rank runs the same number)")
     ap.add_argument("--dump-rows", default=None, help="rank 0 saves the gathered result rows [K * N, 4501] of the headline mode as .npy (tests: the gather against single-process rows)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip other_configs (BASELINE configs[1] and configs[4] timed beside the headline, ~10 s)")
     ap.add_argument("--no-cpp-host", action="store_true", help="skip cpp_host_mode (the C++ host dsvt_detect on the same clouds: writes an ~80 MB .wts file, ~25 s)")
     ap.add_argument("--oracle-clouds", type=int, default=8, help="how many 180k-point clouds the timed modes' boxes are checked on against the CPU oracle (~10 s of host time each on the GPU box; cpu_baseline.box_err_vs_oracle = the worst over them)")
     ap.add_argument("--no-whole-network-cpu", action="store_true", help="cpu_baseline skips the whole network on the CPU oracle (~10 s; also drops box_err_vs_oracle)")
@@ -922,6 +1013,11 @@ def main():
         line["targets"]["both_at_one_operating_point"] = (
             "latency_point" if sf and sf["value"] >= 200.0 and sf["p50_ms"] <= 5.0 else
             "throughput_point" if hl_ok and line["p50_ms"] <= 5.0 else "neither: throughput and latency bars are met at different operating points" if (hl_ok and sf and sf["p50_ms"] <= 5.0) else "neither")
+        if not args.no_other_configs and not args.host_input:
+            try:
+                line["other_configs"] = other_configs(pkg, weights, dev)
+            except Exception as e:                                   # (never lose the headline line to a side measurement)
+                line["other_configs"] = {"error": repr(e)[:300]}
         if not args.no_cpp_host and not args.host_input and args.dtype == "split":
             line["cpp_host_mode"] = cpp_host_mode(pkg, weights, clouds[:FRAME_POOL])
         if not args.no_cpu_baseline:
@@ -937,7 +1033,8 @@ def main():
                     frames.append((pts[0, f * caps.N:f * caps.N + k].cpu().numpy(), fb[0][f].cpu().numpy().copy(), int(fb[1][f])))
             pipe.nms = nms_op
             c_one = pkg.pipeline.Caps()              # (the oracle runs ONE frame: per-frame capacities)
-            line["cpu_baseline"] = cpu_baseline(c_one, frames, whole_network=None if args.no_whole_network_cpu else (weights,), mode_rows=mode_rows, check_clouds=check_clouds)
+            line["cpu_baseline"] = cpu_baseline(c_one, frames, whole_network=None if args.no_whole_network_cpu else (weights,), mode_rows=mode_rows, check_clouds=check_clouds,
+                                                n_points_key=args.points, live_seed=0)
         else:
             line["cpu_baseline"] = None
     elif rank == 0:

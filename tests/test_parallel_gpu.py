@@ -31,7 +31,7 @@ def test_bench_refuses_more_gpus_than_visible():
 
 def _bench_line(extra, timeout=900):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-kernel-events",
-                        "--no-fast-mode", "--no-latency-mode"] + extra, capture_output=True, text=True, timeout=timeout)
+                        "--no-fast-mode", "--no-latency-mode", "--no-other-configs", "--no-cpp-host"] + extra, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
@@ -63,7 +63,7 @@ def test_bench_two_ranks_sharing_the_gpu_gather_the_right_rows(pkg, tmp_path):
     # (--no-graph: two PROCESSES replaying HIP graphs on one device fault on this stack -- "Memory access fault by GPU node", with one
     # stream or two, ROCm 7.2; host-launched kernels from two processes are fine.  Not a configuration the product runs in: one process per GPU.)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--no-graph", "--steps", "8", "--warmup", "2", "--dtype", "f16",
-           "--no-cpu-baseline", "--no-kernel-events", "--no-fast-mode", "--no-latency-mode", "--dump-rows", dump]
+           "--no-cpu-baseline", "--no-kernel-events", "--no-fast-mode", "--no-latency-mode", "--no-other-configs", "--no-cpp-host", "--dump-rows", dump]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
     if r.returncode != 0 and "Memory access fault by GPU" in r.stderr:
         # two processes on ONE device: the platform's "Memory access fault" (with graph replays every time, with host launches seen once;
