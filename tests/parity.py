@@ -21,7 +21,10 @@ def match_boxes(got, n_got, exp, n_exp, tol=1e-3, thr=0.3, thr_band=1e-4):
             continue
         used[j] = True
         d = np.abs(got[j] - e)
-        d[6] = min(d[6], abs(np.pi - d[6]))       # yaw = atan(sin / cos) (src/dsvt-ai-trt.cpp:1668-1669) lives in (-pi/2, pi/2): its two ends are one heading
+        # yaw = atan(sin / cos) (src/dsvt-ai-trt.cpp:1668-1669) lives in (-pi/2, pi/2): its two ends are one heading.  The wrap applies ONLY there -- both yaws within
+        # 0.02 of +-pi/2 --, so a sign / flip error anywhere else still scores as the ~pi it is
+        if min(abs(got[j][6]), abs(e[6])) > np.pi / 2 - 0.02:
+            d[6] = min(d[6], abs(np.pi - d[6]))
         worst = max(worst, float(d.max()))
     for j in np.nonzero(~used)[0]:
         unmatched += abs(got[j, 8] - thr) > thr_band

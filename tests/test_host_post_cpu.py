@@ -110,3 +110,21 @@ def test_pool_partition_properties():
             assert tuple(c2[r, 1:]) == (z // sz, y // sy, x // sx) and tab[r, ((x % sx) * sy + (y % sy)) * sz + z % sz] == i
     c2, tab, par = D.pool_partition(coords[rng.permutation(5000)], 5000, g, (1, 1, 1))
     assert len(c2) == 5000 and tab.shape == (5000, 1)
+
+
+def test_nms_keep_decisions_at_the_threshold():
+    """csrc/nms.hip rounds cos / sin / atan2 correctly through the double functions (oracle trig="cr"), the reference's host NMS gets glibc's float overloads
+    (include/helper.h:117-118,194-195,236-237; trig="ref").  Random box sets never showed a differing keep list (profiles/r05_nms_trig_rates.txt) because random pairs sit
+    nowhere near the threshold; here the pairs are BUILT onto it (tools/nms_threshold_adversaries.py: centre distance bisected to the last float whose reference IoU is
+    still >= 0.01, then its float neighbours on both sides).  The difference is observable and small: some decisions flip, well under 1 % of the threshold points, and only
+    where the two IoUs straddle 0.01 within 1e-6 -- the figure INTEGRATION.md section 3 quotes."""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("adv", os.path.join(root, "tools", "nms_threshold_adversaries.py"))
+    adv = importlib.util.module_from_spec(spec); spec.loader.exec_module(adv)
+    r = adv.adversaries(pairs=1500, steps=8, seed=0)
+    assert r["pairs"] == 1500 and r["points"] == 1500 * 17
+    assert r["differing_points"] <= 0.01 * r["points"], r                      # < 1 % of the points AT the threshold
+    assert r["pairs_with_a_differing_decision"] <= 0.02 * r["pairs"], r
+    for iou_ref, iou_cr in r["examples"]:
+        assert abs(iou_ref - 0.01) < 1e-6 and abs(iou_cr - 0.01) < 1e-6 and (iou_ref >= np.float32(0.01)) != (iou_cr >= np.float32(0.01))

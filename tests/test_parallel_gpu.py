@@ -44,10 +44,14 @@ def test_bench_single_rank_collective_line():
     line = _bench_line(["--rccl-single"])
     assert line["n_gpus"] == 1 and line["config"]["result_gather"] == "rccl gather (communicator of size 1)"
     assert line["config"]["graph_replay_equals_eager"] is True
-    assert line["repeats"] >= 3 and len(line["repeat_values"]) == line["repeats"] and line["gather_ms"] is not None and line["gather_ms"] < 5.0
+    # round 6: with a communicator the gather runs after EVERY forward inside every repeat (the product loop of configs[3]): 20 steps = 5 forwards of four frames
+    assert line["repeats"] >= 3 and len(line["repeat_values"]) == line["repeats"] and line["gathers_per_repeat"] == 5
+    assert line["config"]["gather_own_rows_bit_identical"] is True
     plain = _bench_line([])
-    assert plain["repeats"] == line["repeats"] and plain["gather_ms"] is None
-    assert abs(line["value"] / plain["value"] - 1.0) < 0.02, (line["value"], plain["value"], line["repeat_values"], plain["repeat_values"])
+    assert plain["repeats"] == line["repeats"] and plain["gather_ms"] is None and plain["gathers_per_repeat"] == 0
+    assert abs(line["value"] / plain["value"] - 1.0) < 0.03, (line["value"], plain["value"], line["repeat_values"], plain["repeat_values"])
+    once = _bench_line(["--rccl-single", "--gather-once"])                 # round 5's protocol stays available: one gather, in the last repeat, timed by itself
+    assert once["gathers_per_repeat"] == 1 and once["gather_ms"] is not None and once["gather_ms"] < 5.0
 
 
 def test_bench_two_ranks_sharing_the_gpu_gather_the_right_rows(pkg, tmp_path):
@@ -81,7 +85,7 @@ def test_bench_two_ranks_sharing_the_gpu_gather_the_right_rows(pkg, tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and "DRY RUN" in line["metric"] and "NOT a scaling number" in line["config"]["shared_gpu"]
-    assert line["repeats"] >= 3 and line["gather_ms"] is not None          # (the N > 1 protocol: repeats without a collective between them)
+    assert line["repeats"] >= 3 and line["gathers_per_repeat"] == 2        # (the N > 1 protocol: the gather after every forward of four frames per rank, inside every repeat)
     assert line["config"]["result_gather"].startswith("gloo gather") and line["config"]["frames_per_forward"] == 4
     got = np.load(dump)
     assert got.shape == (16, 4501)
