@@ -90,7 +90,7 @@ def build_host(force=False):
     hdr = os.path.join(HERE, "..", "include", "dsvt_plugin.h")
     if force or _stale(HOST_EXE, [HOST_SRC, hdr, OUT]):
         subprocess.check_call([hipcc(), "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-I", os.path.join(HERE, "..", "include"),
-                               HOST_SRC, "-o", HOST_EXE, "-L", HERE, "-l:libdsvt_hip.so", "-Wl,-rpath,$ORIGIN"])
+                               HOST_SRC, "-o", HOST_EXE, "-L", HERE, "-l:libdsvt_hip.so", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"])
     return HOST_EXE
 
 

@@ -20,7 +20,9 @@
 // (dsvt-ai-trt_amd/pipeline.py) does them: compiled with -ffp-contract=off, the two hosts hand bit-identical fields to the plugins and
 // produce bit-identical boxes (tests/test_host_executor_gpu.py).
 //
-//   dsvt_detect --wts dsvt.wts --data DIR --out DIR [--fp32 | --fp8-head | --fp16] [--frames N] [--ref-caps] [--no-graph] [--dump-raw] [--repeat N]
+//   * --gpus N               frame-batch data parallelism over the N devices of a node inside this process: file j of a batch of N x frames on device j mod N, one
+//                            RCCL gather of the result rows to device 0 per batch (runMultiGpu; --rccl-gather: the same path on one device, communicator of size 1)
+//   dsvt_detect --wts dsvt.wts --data DIR --out DIR [--fp32 | --fp8-head | --fp16] [--frames N] [--in-flight K] [--gpus N] [--rccl-gather] [--ref-caps] [--no-graph] [--dump-raw] [--repeat N]
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -36,6 +38,8 @@
 #include <sstream>
 #include <string>
 #include <vector>
+
+#include <rccl/rccl.h>
 
 #include "dsvt_plugin.h"
 
@@ -628,8 +632,109 @@ static int runPipelined(const WeightMap& w, const Caps& caps, Mode mode, int fra
     return 0;
 }
 
+// --gpus N (round 6; BASELINE configs[3] from the C++ host): frame-batch data parallelism inside ONE process -- an engine, a stream and a HIP graph per device, a batch =
+// N x `frames` consecutive files, file j of the batch on device j mod N (slot j / N of that device's forward), and ONE collective per batch: the result rows and kept
+// counts of every device gathered to device 0 with ncclGather (RCCL over xGMI; grouped, one thread drives all devices), from where they go to the host and into the
+// .txt files.  The reference binds one device (cudaSetDevice(DEVICE), src/dsvt-ai-trt.cpp:1783; include/params.h:333) and has nothing to gather; the loop shape -- a
+// result per frame, every frame -- is its -d loop (:1884-1970).  --rccl-gather forces this path with N = 1 (a communicator of size 1: how a one-GPU box runs it).
+#define NCCL_OK(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { \
+    fprintf(stderr, "%s:%d: %s -> %s\n", __FILE__, __LINE__, #expr, ncclGetErrorString(r_)); exit(2); } } while (0)
+static int runMultiGpu(const WeightMap& w, const Caps& caps, Mode mode, int frames, int ngpu, bool graph, bool raw, int repeat,
+                       const std::string& data, const std::string& out, const std::vector<std::string>& files) {
+    struct Dev {
+        hipStream_t s = nullptr; std::unique_ptr<Engine> eng; hipGraphExec_t exec = nullptr;
+        float* hpts = nullptr; int* hcnt = nullptr;
+    };
+    std::vector<Dev> devs(ngpu);
+    std::vector<int> ids(ngpu); for (int d = 0; d < ngpu; ++d) ids[d] = d;
+    std::vector<ncclComm_t> comms(ngpu);
+    NCCL_OK(ncclCommInitAll(comms.data(), ngpu, ids.data()));
+    const size_t rowFloats = (size_t)frames * TOP_K * 9;
+    float* gRows = nullptr; int* gKept = nullptr; float* hRows = nullptr; int* hKept = nullptr;
+    for (int d = 0; d < ngpu; ++d) {
+        Dev& dv = devs[d];
+        HIP_OK(hipSetDevice(d));
+        HIP_OK(hipStreamCreate(&dv.s));
+        dv.eng.reset(new Engine(w, caps, dv.s, mode, frames));
+        for (int k = 0; k < 2; ++k) dv.eng->enqueue(dv.s);                        // warm-up on empty frames (sizes every buffer)
+        HIP_OK(hipStreamSynchronize(dv.s));
+        if (graph) {
+            hipGraph_t g;
+            HIP_OK(hipStreamBeginCapture(dv.s, hipStreamCaptureModeThreadLocal));
+            dv.eng->enqueue(dv.s);
+            HIP_OK(hipStreamEndCapture(dv.s, &g));
+            HIP_OK(hipGraphInstantiate(&dv.exec, g, nullptr, nullptr, 0));
+        }
+        HIP_OK(hipHostMalloc(&dv.hpts, (size_t)frames * caps.N * 16)); HIP_OK(hipHostMalloc(&dv.hcnt, 4 * frames));
+        if (d == 0) {                                                             // the gather's receive buffers, allocated once
+            HIP_OK(hipMalloc(&gRows, (size_t)ngpu * rowFloats * 4)); HIP_OK(hipMalloc(&gKept, (size_t)ngpu * frames * 4));
+            HIP_OK(hipHostMalloc(&hRows, (size_t)ngpu * rowFloats * 4)); HIP_OK(hipHostMalloc(&hKept, (size_t)ngpu * frames * 4));
+        }
+    }
+    const size_t nfile = files.size(), per = (size_t)frames * ngpu, nbatch = (nfile + per - 1) / per;
+    std::vector<std::vector<float>> cache(nfile); std::vector<int> npts(nfile, 0);
+    std::vector<std::vector<float>> rows(nfile); std::vector<int> kept(nfile, 0);
+    double lastMs = 0;
+    for (int r = 0; r < repeat; ++r) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (size_t b = 0; b < nbatch; ++b) {
+            const size_t f0 = b * per;
+            for (int d = 0; d < ngpu; ++d) {
+                Dev& dv = devs[d];
+                HIP_OK(hipSetDevice(d));
+                for (int sl = 0; sl < frames; ++sl) {
+                    const size_t f = f0 + (size_t)sl * ngpu + d;                  // file j = sl * N + d of the batch: device j mod N, slot j / N
+                    dv.hcnt[sl] = 0;
+                    if (f >= nfile) continue;
+                    if (cache[f].empty()) cache[f] = loadBin(data + "/" + files[f], caps.N, npts[f]);
+                    memcpy(dv.hpts + (size_t)sl * caps.N * 4, cache[f].data(), (size_t)npts[f] * 16); dv.hcnt[sl] = npts[f];
+                    HIP_OK(hipMemcpyAsync((char*)dv.eng->points.ptr + (size_t)sl * caps.N * 16, dv.hpts + (size_t)sl * caps.N * 4, (size_t)npts[f] * 16, hipMemcpyHostToDevice, dv.s));
+                }
+                HIP_OK(hipMemcpyAsync(dv.eng->count.ptr, dv.hcnt, 4 * frames, hipMemcpyHostToDevice, dv.s));
+                if (graph) HIP_OK(hipGraphLaunch(dv.exec, dv.s)); else dv.eng->enqueue(dv.s);
+            }
+            // the one collective of the batch: rows [frames, 500, 9] and kept [frames] of every device -> device 0, rank-major
+            NCCL_OK(ncclGroupStart());
+            for (int d = 0; d < ngpu; ++d) {
+                NCCL_OK(ncclGather(devs[d].eng->result[0].ptr, gRows, rowFloats, ncclFloat, 0, comms[d], devs[d].s));
+                NCCL_OK(ncclGather(devs[d].eng->result[2].ptr, gKept, (size_t)frames, ncclInt32, 0, comms[d], devs[d].s));
+            }
+            NCCL_OK(ncclGroupEnd());
+            HIP_OK(hipSetDevice(0));
+            HIP_OK(hipMemcpyAsync(hKept, gKept, (size_t)ngpu * frames * 4, hipMemcpyDeviceToHost, devs[0].s));
+            HIP_OK(hipMemcpyAsync(hRows, gRows, (size_t)ngpu * rowFloats * 4, hipMemcpyDeviceToHost, devs[0].s));
+            for (int d = ngpu - 1; d >= 0; --d) { HIP_OK(hipSetDevice(d)); HIP_OK(hipStreamSynchronize(devs[d].s)); }      // (device 0 last: the downloads)
+            for (int d = 0; d < ngpu; ++d)
+                for (int sl = 0; sl < frames; ++sl) {
+                    const size_t f = f0 + (size_t)sl * ngpu + d;
+                    if (f >= nfile) continue;
+                    kept[f] = hKept[(size_t)d * frames + sl];
+                    const float* src = hRows + ((size_t)d * frames + sl) * TOP_K * 9;
+                    rows[f].assign(src, src + (size_t)kept[f] * 9);
+                }
+        }
+        lastMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    for (size_t i = 0; i < nfile; ++i) {
+        const std::string stem = files[i].substr(0, files[i].size() - 4);
+        saveTxt(out + "/" + stem + ".txt", rows[i].data(), kept[i], lastMs / nfile);
+        if (raw) {
+            FILE* fh = fopen((out + "/" + stem + ".rows").c_str(), "wb");
+            if (!fh) die("cannot write raw rows");
+            fwrite(&kept[i], 4, 1, fh); fwrite(rows[i].data(), 4, (size_t)kept[i] * 9, fh); fclose(fh);
+        }
+        printf("%s: %d points -> %d boxes, %.3f ms (its share of the pass), device %d\n", stem.c_str(), npts[i], kept[i], lastMs / nfile, (int)((i % per) % ngpu));
+    }
+    printf("dsvt_detect: %zu frames on %d GPU(s), %s, %d frame(s) per forward, %s, one RCCL gather per batch of %zu frames: %.3f ms per frame, %.1f frames/s (host copy + upload + forward + "
+           "gather to device 0 + download of the final boxes, wall clock of the last pass%s)\n",
+           nfile, ngpu, mode == MODE_F16 ? "fp16" : mode == MODE_SPLIT ? "fp32 grade (f16x3)" : "fp32 grade with fp8 head corrections", frames, graph ? "HIP graph" : "host launches", per,
+           lastMs / std::max<size_t>(nfile, 1), 1e3 * nfile / std::max(lastMs, 1e-9), repeat > 1 ? ", frames cached in host memory" : ", disk reads inside");
+    for (int d = 0; d < ngpu; ++d) ncclCommDestroy(comms[d]);
+    return 0;
+}
+
 int main(int argc, char** argv) {
-    std::string wts, data, out; bool refCaps = false, graph = true, raw = false; int repeat = 1, frames = 1, inflight = 1; Mode mode = MODE_SPLIT;
+    std::string wts, data, out; bool refCaps = false, graph = true, raw = false, rcclGather = false; int repeat = 1, frames = 1, inflight = 1, gpus = 1; Mode mode = MODE_SPLIT;
     for (int a = 1; a < argc; ++a) {
         const std::string s = argv[a];
         if (s == "--wts" && a + 1 < argc) wts = argv[++a];
@@ -644,7 +749,9 @@ int main(int argc, char** argv) {
         else if (s == "--frames" && a + 1 < argc) frames = atoi(argv[++a]);
         else if (s == "--repeat" && a + 1 < argc) repeat = atoi(argv[++a]);
         else if (s == "--in-flight" && a + 1 < argc) inflight = atoi(argv[++a]);
-        else die("usage: dsvt_detect --wts F --data DIR --out DIR [--fp32 | --fp8-head | --fp16] [--frames N] [--in-flight K] [--ref-caps] [--no-graph] [--dump-raw] [--repeat N]");
+        else if (s == "--gpus" && a + 1 < argc) gpus = atoi(argv[++a]);
+        else if (s == "--rccl-gather") rcclGather = true;
+        else die("usage: dsvt_detect --wts F --data DIR --out DIR [--fp32 | --fp8-head | --fp16] [--frames N] [--in-flight K] [--gpus N] [--rccl-gather] [--ref-caps] [--no-graph] [--dump-raw] [--repeat N]");
     }
     if (wts.empty() || data.empty() || out.empty()) die("--wts, --data and --out are required (the reference's dsvt.wts is not shipped)");
     if (frames < 1 || frames > 16) die("--frames must be 1 .. 16");
@@ -652,6 +759,9 @@ int main(int argc, char** argv) {
     if (refCaps && frames != 1) die("--ref-caps is the reference's one-frame configuration (its kernels only ever read frame 0's counts)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) die("no GPU visible (there is no CPU path)");
+    if (gpus < 1 || gpus > 64) die("--gpus must be 1 .. 64");
+    if (gpus > ndev) die("--gpus " + std::to_string(gpus) + ": only " + std::to_string(ndev) + " GPU(s) visible (one engine per DEVICE: devices are never shared)");
+    if ((gpus > 1 || rcclGather) && inflight > 1) die("--gpus / --rccl-gather and --in-flight are separate loops");
     HIP_OK(hipSetDevice(0));                                                       // cudaSetDevice(DEVICE) :1783
     Caps caps = capsForFrames(frames);
     if (refCaps) { caps.N = 50000; caps.Nk = 30000; caps.P = 10000; caps.W = 800; caps.Vw = 576; caps.S = 800; }      // params.h:24-27,68-69
@@ -664,6 +774,7 @@ int main(int argc, char** argv) {
     std::sort(files.begin(), files.end());
 
     const WeightMap w = loadWeights(wts);
+    if (gpus > 1 || rcclGather) return runMultiGpu(w, caps, mode, frames, gpus, graph, raw, repeat, data, out, files);
     if (inflight > 1) return runPipelined(w, caps, mode, frames, inflight, graph, raw, repeat, data, out, files);
     hipStream_t s; HIP_OK(hipStreamCreate(&s));
     Engine eng(w, caps, s, mode, frames);

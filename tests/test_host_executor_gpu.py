@@ -135,3 +135,27 @@ def test_cpp_host_fails_loudly(wts_file, tmp_path):
     assert r.returncode != 0 and "no .bin frames" in r.stderr
     r = subprocess.run([EXE, "--wts", str(tmp_path / "missing.wts"), "--data", cases.GOLDEN, "--out", str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "cannot open" in r.stderr
+
+
+def test_cpp_host_multi_gpu_path_on_one_device(pkg, wts_file, tmp_path):
+    """dsvt_detect --gpus N (round 6): frame-batch data parallelism inside the C++ host -- an engine per device, file j of a batch on device j mod N, ONE RCCL gather of
+    the result rows to device 0 per batch (the loop shape of BASELINE configs[3]; the reference binds one device, src/dsvt-ai-trt.cpp:1783).  A gpurun box has one GPU:
+    --rccl-gather runs that path with a communicator of size 1, four frames per forward, the gather after every batch -- and must write the same BITS as the plain
+    loop for every file (six clouds of different sizes: a partial last batch).  --gpus 2 on a one-GPU box must fail loudly, never share a device."""
+    data = tmp_path / "data"; data.mkdir()
+    for i in range(6):
+        pkg.synth.lidar_like(180000 if i % 3 else 90000, 70 + i).tofile(data / f"{i:06d}.bin")
+    outs = {}
+    for tag, extra in (("plain", []), ("gather", ["--rccl-gather"]), ("gather_no_graph", ["--rccl-gather", "--no-graph"])):
+        o = tmp_path / tag; o.mkdir()
+        r = subprocess.run([EXE, "--wts", wts_file, "--data", str(data), "--out", str(o), "--frames", "4", "--dump-raw", "--repeat", "3"] + extra, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        if extra:
+            assert "one RCCL gather per batch of 4 frames" in r.stdout
+        outs[tag] = [_read_rows(str(o / f"{i:06d}.rows")) for i in range(6)]
+    for tag in ("gather", "gather_no_graph"):
+        for (k0, r0), (k1, r1) in zip(outs["plain"], outs[tag]):
+            assert k0 == k1 and k0 > 0 and np.array_equal(r0.view(np.uint32), r1.view(np.uint32)), tag
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([EXE, "--wts", wts_file, "--data", str(data), "--out", str(tmp_path / "plain"), "--gpus", "2"], capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "visible" in r.stderr and "frames/s" not in r.stdout
