@@ -2147,6 +2147,8 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
             static int hct4 = -1; if (hct4 < 0) hct4 = ablateEnv("DSVT_CONV_HEADS_CT4", 1);
             const int nch64h = cdiv(a.CoutRows, 64), n24h = cdiv(a.Ho, 24) * tilesX * nch64h * NBI;
             if (hct4 && spl && ctWide == 8 && a.CoutRows % 128 == 64 && n24h >= ncu) {
+                static int rows64h = -1; if (rows64h < 0) rows64h = ablateEnv("DSVT_CONV_ROWS", 1);           // round 6: the same items on conv_rows_kernel<4, 3> (conv_rows.hip)
+                if (rows64h && a.variant != 1 && !a.trace && convRows64Eligible(a, ncu)) return launchConvRows64(a, Wp, ncu, stream);
                 hipLaunchKernelGGL((conv_wide_kernel<4, 8, 36, 4, 2, 3, false, true>), dim3(ncu), dim3(512), 0, stream, a, Wp, zeros, tilesX, n24h, nch64h, dbg);
                 return lastError();
             }
@@ -2185,6 +2187,8 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
                 static int rw3 = -1; if (rw3 < 0) rw3 = ablateEnv("DSVT_CONV_RW3", 1);
                 const int n24 = cdiv(a.Ho, 24) * tilesX * nchunk * NBI;
                 if (rw3 && spl && n24 >= ncu && cdiv(n24, ncu) * 24 * 92 < cdiv(nwide, ncu) * 16 * 100) {
+                    static int rows64 = -1; if (rows64 < 0) rows64 = ablateEnv("DSVT_CONV_ROWS", 1);         // round 6: the same items on conv_rows_kernel<4, 3>
+                    if (rows64 && a.variant != 1 && !a.trace && convRows64Eligible(a, ncu)) return launchConvRows64(a, Wp, ncu, stream);
                     hipLaunchKernelGGL((conv_wide_kernel<4, 8, 36, 4, 2, 3, false, true>), dim3(ncu), dim3(512), 0, stream, a, Wp, zeros, tilesX, n24, nchunk, dbg);
                     return lastError();
                 }

@@ -124,5 +124,7 @@ __device__ __forceinline__ void slabBarrier(int keep) {
 // layer is not one of its shapes (the caller falls back to conv_wide_kernel)
 bool convRowsEligible(const ConvArgs& a, int ncu);
 int launchConvRows(const ConvArgs& a, const _Float16* Wp, int ncu, hipStream_t stream);
+bool convRows64Eligible(const ConvArgs& a, int ncu);          // (64-channel chunks on 24-row items)
+int launchConvRows64(const ConvArgs& a, const _Float16* Wp, int ncu, hipStream_t stream);
 
 }  // namespace dsvt

@@ -31,14 +31,24 @@ namespace dsvt {
 
 constexpr int RK_TW = 32;                          // tile width in pixels
 constexpr int RK_HS = RK_TW + 2;                   // halo row stride in pixels (a fragment read touches ONE halo row: its bank pattern does not depend on the stride)
-constexpr int RK_ROWS = 16, RK_HH = RK_ROWS + 2;
 constexpr int RK_NW = 8;
-constexpr int RK_PPW = 5;                          // halo pieces (1 KB = 16 pixels) per wave and phase: 18 x 34 = 612 pixels = 38.25 pieces
-constexpr int RK_NPC = RK_NW * RK_PPW;             // 40 KB per halo buffer (piece 39 is padding: its lanes carry out-of-range offsets)
-constexpr int RK_HBYTES = RK_NPC * 1024;
-constexpr int RK_WBYTES = 3 * 8 * 1024;            // three taps x eight 16-channel tiles
-constexpr int RK_WOFF = 2 * RK_HBYTES, RK_BIAS = RK_WOFF + 3 * RK_WBYTES, RK_SMEM = RK_BIAS + 1024;
-static_assert(RK_HH * RK_HS <= RK_NPC * 16 && RK_SMEM <= 160 * 1024, "LDS budget");
+// CT = 16-channel tiles per workgroup, RW = tile rows per wave.  <8, 2>: 16 rows x 32 pixels x 128 channels (128 accumulator registers; halo 18 x 34 pixels = 39 pieces
+// of 1 KB, five per wave; 24 KB weight slabs) -- the BEV ResNet layers.  <4, 3>: 24 rows x 32 pixels x 64 channels (96 accumulator registers; halo 26 x 34 = 56 pieces,
+// seven per wave; 12 KB weight slabs: twelve rows, so waves 0-3 request two and waves 4-7 one) -- the layers with 64-channel chunks (the shared 384 -> 64 head
+// convolution, the 64 -> 320 head stems), whose item height round 5 chose for the weight stream per output pixel (conv_wide_kernel<4, 8, 36, 4, 2, 3>).
+template <int CT, int RW>
+struct RowsCfg {
+    static constexpr int ROWS = 8 * RW, HH = ROWS + 2, NM = 2 * RW;
+    static constexpr int PPW = (HH * RK_HS + 16 * RK_NW - 1) / (16 * RK_NW);   // halo pieces (1 KB = 16 pixels) per wave and phase
+    static constexpr int NPC = RK_NW * PPW, HBYTES = NPC * 1024;               // (pieces beyond the halo are padding: their lanes carry out-of-range offsets)
+    static constexpr int WBYTES = 3 * CT * 1024;                               // three taps x CT 16-channel tiles
+    static constexpr int WOFF = 2 * HBYTES, BIAS = WOFF + 3 * WBYTES, SMEM = BIAS + 1024;
+    static constexpr int BPS = CT / 4, NB = 3 * BPS;                           // batches (four channel tiles x NM pixel tiles of MFMAs) per step / per slab
+    static constexpr int RPW = (3 * CT + RK_NW - 1) / RK_NW;                   // weight-request slots per wave and slab
+    static constexpr bool WUNI = (3 * CT) % RK_NW == 0;                        // every wave fills every slot
+    static constexpr bool BIGH = HBYTES + (2 * RK_HS + 2) * 64 + ((RW - 1) * RK_HS + 16) * 64 + 64 > 65535;   // the second halo buffer lies beyond a 16-bit offset: a base per buffer
+    static_assert(CT % 4 == 0 && SMEM <= 160 * 1024, "LDS budget");
+};
 constexpr uint32_t RK_OOB = 0xFFFFFFF0u;           // byte offset of a lane whose halo pixel lies outside the image (>= num_records: the request writes zeros)
 
 // RK_HALO_IN_KY0 = 1: all five halo pieces of the next phase are requested in the phase's FIRST slab and its slab-end wait leaves them in flight (they have two
@@ -59,15 +69,18 @@ constexpr uint32_t RK_OOB = 0xFFFFFFF0u;           // byte offset of a lane whos
 // 8 = no fragment reads
 // EPI: the epilogue's flavour as a compile-time constant (the generic SPL epilogue with every residual / output-plane variant unrolled sixteen times is 35 KB of
 // code, more than half of the 64 KB instruction cache): 0 = generic; 1 = no residual, output [hi | lo | -] (split_output = 4); 2 = [hi | lo] residual, output [hi | lo | -]
-template <bool SPL, bool TR = false, int ABL = 0, int EPI = 0>
+template <int CT, int RW, bool SPL, bool TR = false, int ABL = 0, int EPI = 0>
 __global__ void __launch_bounds__(64 * RK_NW, 1)
 conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int nitems, int nchunk)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[RK_SMEM];          // halo[2] | wslab[3] | bias
+    using C = RowsCfg<CT, RW>;
+    constexpr int RK_ROWS = C::ROWS, RK_HH = C::HH, NM = C::NM, RK_PPW = C::PPW, RK_HBYTES = C::HBYTES, RK_WBYTES = C::WBYTES, RK_WOFF = C::WOFF, RK_BIAS = C::BIAS;
+    constexpr int BPS = C::BPS, NB = C::NB, RPW = C::RPW;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[C::SMEM];          // halo[2] | wslab[3] | bias
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, g = lane >> 4;
     const bool upper = wave >= RK_NW / 2;                                          // (RK_STAGGER) the second wave of its SIMD
     const int NP = a.Cin >> 5;                                                     // 32-channel phases (even: checked by the launcher)
-    const int NCT = (a.CoutRows + 127) / 128 * 8;                                  // 16-channel tiles per k-step of the packed weights
+    const int NCT = a.CoutRows <= 64 ? 4 : (a.CoutRows + 127) / 128 * 8;           // 16-channel tiles per k-step of the packed weights (DsvtConv2dPlugin::packHalo)
     const int perImg = nitems / a.nb;
     auto decode = [&](int it, int& yy, int& xx, int& ch, int& bb) {
         bb = it / perImg; it -= bb * perImg;
@@ -96,20 +109,24 @@ conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int ni
         __builtin_amdgcn_raw_ptr_buffer_load_lds(inRsrc, (glds_dst_t)(smem + buf * RK_HBYTES + (wave + RK_NW * i) * 1024), 16, (int)hv[i], (int)soff, 0, 0);
     };
     // weight rows of slab (ph, ky) of chunk ch: tap 3 ky + j, channel tile `wave` -> row (2 ((ph >> 1) 9 + tap) + (ph & 1)) NCT + 8 ch + wave of the packed image
-    const uint32_t wv = (uint32_t)tid * 16u;                                       // (wave * 1024 + lane * 16)
+    // slot j of wave w is row u = w + 8 j of the slab's 3 CT rows: tap u / CT, channel tile u % CT (scalars)
+    const uint32_t wv = (uint32_t)lane * 16u;
     const uint32_t wstep = (uint32_t)(2 * NCT * 1024);
-    auto weightBase = [&](int ph, int ky, int ch) { return (uint32_t)(((2 * ((ph >> 1) * 9 + 3 * ky) + (ph & 1)) * NCT + ch * 8) * 1024); };
+    auto weightBase = [&](int ph, int ky, int ch) { return (uint32_t)(((2 * ((ph >> 1) * 9 + 3 * ky) + (ph & 1)) * NCT + ch * CT) * 1024); };
     auto weightRequest = [&](uint32_t base, int buf, int j) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wRsrc, (glds_dst_t)(smem + RK_WOFF + buf * RK_WBYTES + (j * 8 + wave) * 1024), 16, (int)wv, (int)(base + j * wstep), 0, 0);
+        const int u = wave + RK_NW * j;
+        if (!C::WUNI && u >= 3 * CT) return;                                       // (wave-uniform)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wRsrc, (glds_dst_t)(smem + RK_WOFF + buf * RK_WBYTES + u * 1024), 16, (int)wv, (int)(base + (u / CT) * wstep + (u % CT) * 1024), 0, 0);
     };
     auto weightRequests = [&](uint32_t base, int buf) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) weightRequest(base, buf, j);
+        for (int j = 0; j < RPW; ++j) weightRequest(base, buf, j);
     };
+    const int wreq = C::WUNI ? RPW : ((wave + RK_NW * (RPW - 1) < 3 * CT) ? RPW : RPW - 1);      // requests this wave issues per slab = what its slab-end wait leaves in flight
     // the chunk's bias (128 floats, zeros beyond Cout / without a bias: out-of-range lanes) as one LDS-DMA piece: the accumulators start from it
     auto biasRequest = [&](int ch) {
-        const int co = ch * 128 + lane * 4;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(bRsrc, (glds_dst_t)(smem + RK_BIAS), 16, (int)((lane < 32 && co < a.Cout) ? (uint32_t)co * 4u : RK_OOB), 0, 0, 0);
+        const int co = ch * CT * 16 + lane * 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(bRsrc, (glds_dst_t)(smem + RK_BIAS), 16, (int)((lane < CT * 4 && co < a.Cout) ? (uint32_t)co * 4u : RK_OOB), 0, 0, 0);
     };
 
     int item = blockIdx.x;
@@ -136,37 +153,38 @@ conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int ni
     slabBarrier(0);
 
     // fragment addresses: per-lane bases + immediates
-    const int pb = ((2 * wave) * RK_HS + r) * 64;
-    int vB[3];
+    const int pb = ((RW * wave) * RK_HS + r) * 64;
+    constexpr int NVB = C::BIGH ? 2 : 1;                                           // (BIGH: one set of bases per halo buffer)
+    int vB[NVB][3];
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) vB[kx] = pb + kx * 64 + ((g ^ (((r + kx) >> 1) & 2)) << 4);
+    for (int pp = 0; pp < NVB; ++pp)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) vB[pp][kx] = pp * RK_HBYTES + pb + kx * 64 + ((g ^ (((r + kx) >> 1) & 2)) << 4);
     int vA[3];                                                                     // (one base per weight buffer: the immediates stay below 64 KB)
 #pragma unroll
     for (int i = 0; i < 3; ++i) vA[i] = RK_WOFF + i * RK_WBYTES + (lane << 4);
     // (opaque to the optimizer: left visible, hipcc re-associates base + immediate into one constant per access, which no longer fits the 16-bit offset field,
     // and keeps 72 address registers alive around the loop -- 200 spilled registers, each reload an s_waitcnt vmcnt(0) in the middle of the LDS-DMA stream)
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { asm volatile("" : "+v"(vA[i])); asm volatile("" : "+v"(vB[i])); }
+    for (int i = 0; i < 3; ++i) { asm volatile("" : "+v"(vA[i])); asm volatile("" : "+v"(vB[0][i])); if (C::BIGH) asm volatile("" : "+v"(vB[NVB - 1][i])); }
 
-    floatx4 acc[8][4];
-    half8 Bf[2][4], Af[2][4];
-    auto loadB = [&](int par, int ky, int kx, half8 (&B)[4]) {                    // (par, ky, kx: constants after inlining)
+    floatx4 acc[CT][NM];
+    half8 Bf[2][NM], Af[2][4];
+    auto loadB1 = [&](int par, int ky, int kx, int m, half8 (&B)[NM]) {            // (par, ky, kx, m: constants after inlining)
         if (ABL & 8) return;
-        const unsigned char* p = smem + vB[kx] + (par * RK_HBYTES + ky * RK_HS * 64);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) B[m] = *reinterpret_cast<const half8*>(p + ((m >> 1) * RK_HS + (m & 1) * 16) * 64);
+        B[m] = *reinterpret_cast<const half8*>(smem + vB[C::BIGH ? par : 0][kx] + ((C::BIGH ? 0 : par * RK_HBYTES) + ky * RK_HS * 64) + ((m >> 1) * RK_HS + (m & 1) * 16) * 64);
     };
-    auto loadB1 = [&](int par, int ky, int kx, int m, half8 (&B)[4]) {
-        if (ABL & 8) return;
-        B[m] = *reinterpret_cast<const half8*>(smem + vB[kx] + (par * RK_HBYTES + ky * RK_HS * 64) + ((m >> 1) * RK_HS + (m & 1) * 16) * 64);
+    auto loadB = [&](int par, int ky, int kx, half8 (&B)[NM]) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) loadB1(par, ky, kx, m, B);
     };
     auto loadA1 = [&](int buf, int u, int c0, int ct, half8 (&A)[4]) {
         if (ABL & 8) return;
-        A[ct] = *reinterpret_cast<const half8*>(smem + vA[buf] + (u * 8 + c0 + ct) * 1024);
+        A[ct] = *reinterpret_cast<const half8*>(smem + vA[buf] + (u * CT + c0 + ct) * 1024);
     };
     auto loadA = [&](int buf, int u, int c0, half8 (&A)[4]) {
         if (ABL & 8) return;
-        const unsigned char* p = smem + vA[buf] + (u * 8 + c0) * 1024;
+        const unsigned char* p = smem + vA[buf] + (u * CT + c0) * 1024;
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) A[ct] = *reinterpret_cast<const half8*>(p + ct * 1024);
     };
@@ -178,10 +196,10 @@ conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int ni
         if (!have_next) nitem = item;                              // (no next item: the end-of-item requests fetch this item's first phase again, into buffers nobody reads)
         decode(nitem, ny0, nx0, nch, nbimg);
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct) {
+        for (int ct = 0; ct < CT; ++ct) {
             const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + RK_BIAS + (ct * 16 + 4 * g) * 4);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[ct][m] = b4;
+            for (int m = 0; m < NM; ++m) acc[ct][m] = b4;
         }
 
         // one slab: kernel row KY of phase P (parity PAR)
@@ -195,10 +213,12 @@ conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int ni
             if (KY == 2 && tail && wave == 0) biasRequest(nch);   // (before the weights: retired with the older requests)
             constexpr bool wnext = tail && KY != 0;               // the slab two ahead is slab 0 / 1 of the next item
             const uint32_t wbase = weightBase(wnext ? 0 : (KY == 0 ? P : P + 1), (KY + 2) % 3, wnext ? nch : chunk);
-            constexpr int NH = RK_HALO_IN_KY0 ? (KY == 0 ? RK_PPW : 0) : (KY == 0 ? 3 : KY == 1 ? 2 : 0);      // halo requests of this slab
-            constexpr int NREQ = NH + 3;
+            constexpr int NH0 = (RK_PPW + 1) / 2;                  // (five pieces: three in the first slab, two in the second; seven: four and three)
+            constexpr int NH = RK_HALO_IN_KY0 ? (KY == 0 ? RK_PPW : 0) : (KY == 0 ? NH0 : KY == 1 ? RK_PPW - NH0 : 0);      // halo requests of this slab
+            constexpr int NREQ = NH + RPW;
+            constexpr int NPOS = NB == 6 ? 6 : 4 * NB;             // where a request may go: before a batch (six batches per slab) or before any group of four / six MFMAs (three)
             auto request = [&](int j) {                            // j = 0 .. NREQ - 1 (a constant after unrolling)
-                if (j < NH) { if (!(ABL & 1)) haloRequest((KY == 0 ? 0 : 3) + j, PAR ^ 1, hso); }
+                if (j < NH) { if (!(ABL & 1)) haloRequest((KY == 0 ? 0 : NH0) + j, PAR ^ 1, hso); }
                 else if (j < NREQ) { if (!(ABL & 2)) weightRequest(wbase, (KY + 2) % 3, j - NH); }
             };
             mark();
@@ -209,30 +229,34 @@ conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int ni
             // (and B) tiles.  The requests of a batch go out before group 0 (waves 0-3) or group 2 (their SIMD partners 4-7: RK_STAGGER).
             loadA(KY, 0, 0, Af[0]);
 #pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                const int u = b >> 1, c0 = (b & 1) * 4, t = PAR + KY + u;         // t & 1: the B buffer of step (P, KY, u)
+            for (int b = 0; b < NB; ++b) {
+                const int u = b / BPS, c0 = (b % BPS) * 4, t = PAR + KY + u;      // t & 1: the B buffer of step (P, KY, u)
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
-                    if (b + 1 < 6) {
-                        if (((b + 1) & 1) == 0) loadB1(PAR, KY, u + 1, gq, Bf[(t + 1) & 1]);
-                        loadA1(KY, (b + 1) >> 1, ((b + 1) & 1) * 4, gq, Af[(b + 1) & 1]);
-                    } else {                                       // the next slab's first B fragments (its halo phase was published a slab ago at the latest); the item's
-                        if (KY == 2) loadB1(PAR ^ 1, 0, 0, gq, Bf[(t + 1) & 1]); else loadB1(PAR, KY + 1, 0, gq, Bf[(t + 1) & 1]);      // last slab reads the NEXT item's: they wait in Bf[0] through the epilogue
-                    }
-                    if (gq == ((RK_STAGGER && UP) ? 2 : 0)) {
+                    if (b + 1 < NB) {
+                        if ((b + 1) % BPS == 0) {
 #pragma unroll
-                        for (int j = 0; j < NREQ; ++j)             // request j goes out with batch j * 6 / NREQ (the weights last)
-                            if ((j * 6) / NREQ == b) request(j);
+                            for (int m = gq; m < NM; m += 4) loadB1(PAR, KY, u + 1, m, Bf[(t + 1) & 1]);
+                        }
+                        loadA1(KY, (b + 1) / BPS, ((b + 1) % BPS) * 4, gq, Af[(b + 1) & 1]);
+                    } else {                                       // the next slab's first B fragments (its halo phase was published a slab ago at the latest); the item's
+#pragma unroll
+                        for (int m = gq; m < NM; m += 4) {         // last slab reads the NEXT item's: they wait in Bf[0] through the epilogue
+                            if (KY == 2) loadB1(PAR ^ 1, 0, 0, m, Bf[(t + 1) & 1]); else loadB1(PAR, KY + 1, 0, m, Bf[(t + 1) & 1]);
+                        }
                     }
+#pragma unroll
+                    for (int j = 0; j < NREQ; ++j)                 // request j goes out at position j * NPOS / NREQ of the slab (the weights last)
+                        if ((NB == 6 ? (gq == ((RK_STAGGER && UP) ? 2 : 0) && (j * NPOS) / NREQ == b) : (j * NPOS) / NREQ == b * 4 + gq)) request(j);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int m = 0; m < 4; ++m)
+                    for (int m = 0; m < NM; ++m)
                         acc[c0 + gq][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[b & 1][gq], Bf[t & 1][m], acc[c0 + gq][m], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             // everything but this slab's three weight requests (RK_HALO_IN_KY0: and the five halo requests of a first slab) has landed
-            constexpr int KEEP = (RK_HALO_IN_KY0 && KY == 0) ? RK_PPW + 3 : 3;
+            const int KEEP = ((RK_HALO_IN_KY0 && KY == 0) ? RK_PPW : 0) + wreq;
             if constexpr (TR) {
                 mark();
                 slabWait(KEEP);
@@ -257,14 +281,14 @@ conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int ni
         mark();
         // residual / ReLU / store (the bias is in the accumulators): conv_wide_kernel's epilogue for a.wide layers
         if (!(ABL & 4)) {
-            const int n0 = chunk * 128;
-            int ctn = (a.CoutRows - n0 + 15) / 16; ctn = ctn > 8 ? 8 : ctn;
-            constexpr int TP = 4, NBLK = 4 * TP;                  // blocks b = (pixel tile m, channel-tile pair tp)
+            const int n0 = chunk * CT * 16;
+            int ctn = (a.CoutRows - n0 + 15) / 16; ctn = ctn > CT ? CT : ctn;
+            constexpr int TP = CT / 2, NBLK = NM * TP;            // blocks b = (pixel tile m, channel-tile pair tp)
             const int cg8 = (g & 1) * 16 + (g >> 1) * 8;
-            bool valid[4]; size_t opix[4];
+            bool valid[NM]; size_t opix[NM];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int oy = y0 + 2 * wave + (m >> 1), ox = x0 + (m & 1) * 16 + r;
+            for (int m = 0; m < NM; ++m) {
+                const int oy = y0 + RW * wave + (m >> 1), ox = x0 + (m & 1) * 16 + r;
                 valid[m] = oy < a.Ho && ox < a.Wo;
                 opix[m] = valid[m] ? (size_t)(bimg * a.Ho + oy) * a.Wo + ox : 0;
             }
@@ -324,7 +348,7 @@ conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int ni
                     }
                 }
             } else {
-                constexpr int RB = 8;
+                constexpr int RB = NBLK % 8 == 0 ? 8 : 4;
 #pragma unroll
                 for (int b0 = 0; b0 < NBLK; b0 += RB) {
                     half8 rv[RB];
@@ -366,32 +390,45 @@ conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int ni
     }
 }
 
-// the layers this kernel takes: 3 x 3, stride 1, pad 1, no pixel shuffle, 16-byte epilogue accesses legal, an even number of 32-channel phases, whole-chip grids
-bool convRowsEligible(const ConvArgs& a, int ncu) {
+// the layers these kernels take: 3 x 3, stride 1, pad 1, no pixel shuffle, 16-byte epilogue accesses legal, an even number of 32-channel phases, whole-chip grids.
+// ct4 = false: 128-channel chunks on 16-row items; ct4 = true: 64-channel chunks on 24-row items (layers with <= 64 output rows, or whose last 128-channel chunk
+// would be half empty)
+static bool rowsCommon(const ConvArgs& a) {
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.up != 1 || !a.wide || a.out_f32 || a.xscale) return false;
-    if (a.CoutRows != a.Cout || a.CoutRows <= 64 || a.Cin % 64 != 0 || a.Cin < 64) return false;
-    if (a.Ho != a.H || a.Wo != a.W) return false;
-    if ((size_t)a.nb * a.H * a.W * a.Cin * 2 >= 0xF0000000ull) return false;           // (byte offsets in 32 bits, RK_OOB beyond num_records)
-    const int nwide = cdiv(a.Ho, RK_ROWS) * cdiv(a.Wo, RK_TW) * cdiv(a.CoutRows, 128) * a.nb;
-    return nwide >= ncu;
+    if (a.CoutRows != a.Cout || a.Cin % 64 != 0 || a.Cin < 64 || a.Ho != a.H || a.Wo != a.W) return false;
+    return (size_t)a.nb * a.H * a.W * a.Cin * 2 < 0xF0000000ull;                       // (byte offsets in 32 bits, RK_OOB beyond num_records)
+}
+bool convRowsEligible(const ConvArgs& a, int ncu) {
+    if (!rowsCommon(a) || a.CoutRows <= 64) return false;
+    return cdiv(a.Ho, 16) * cdiv(a.Wo, RK_TW) * cdiv(a.CoutRows, 128) * a.nb >= ncu;
+}
+bool convRows64Eligible(const ConvArgs& a, int ncu) {
+    if (!rowsCommon(a) || a.CoutRows <= 32 || !(a.CoutRows <= 64 || a.CoutRows % 128 == 64)) return false;
+    if (!(a.split_out != 0 || a.res_split != 0)) return false;                         // (the fp16 frame keeps its own kernels)
+    return cdiv(a.Ho, 24) * cdiv(a.Wo, RK_TW) * cdiv(a.CoutRows, 64) * a.nb >= ncu;
 }
 
-int launchConvRows(const ConvArgs& a, const _Float16* Wp, int ncu, hipStream_t stream) {
-    const int tilesX = cdiv(a.Wo, RK_TW), nchunk = cdiv(a.CoutRows, 128);
-    const int nitems = cdiv(a.Ho, RK_ROWS) * tilesX * nchunk * a.nb;
+template <int CT, int RW>
+static int launchRows(const ConvArgs& a, const _Float16* Wp, int ncu, hipStream_t stream) {
+    const int tilesX = cdiv(a.Wo, RK_TW), nchunk = cdiv(a.CoutRows, CT * 16);
+    const int nitems = cdiv(a.Ho, 8 * RW) * tilesX * nchunk * a.nb;
     const bool spl = a.split_out != 0 || a.res_split != 0;
+    const dim3 grid(ncu), block(64 * RK_NW);
     if constexpr (kAblate) {
         static int dbg = -1; if (dbg < 0) dbg = ablateEnv("DSVT_CONV_DBG", 0);
-        if (a.trace && spl) { hipLaunchKernelGGL((conv_rows_kernel<true, true>), dim3(ncu), dim3(64 * RK_NW), 0, stream, a, Wp, tilesX, nitems, nchunk); return lastError(); }
-#define RK_ABL(N_) if (spl && dbg == N_) { hipLaunchKernelGGL((conv_rows_kernel<true, false, N_>), dim3(ncu), dim3(64 * RK_NW), 0, stream, a, Wp, tilesX, nitems, nchunk); return lastError(); }
-        RK_ABL(1) RK_ABL(2) RK_ABL(3) RK_ABL(4) RK_ABL(7) RK_ABL(8) RK_ABL(15)
+        if (a.trace && spl) { hipLaunchKernelGGL((conv_rows_kernel<CT, RW, true, true>), grid, block, 0, stream, a, Wp, tilesX, nitems, nchunk); return lastError(); }
+#define RK_ABL(N_) if (spl && dbg == N_) { hipLaunchKernelGGL((conv_rows_kernel<CT, RW, true, false, N_>), grid, block, 0, stream, a, Wp, tilesX, nitems, nchunk); return lastError(); }
+        RK_ABL(1) RK_ABL(2) RK_ABL(3) RK_ABL(8)
 #undef RK_ABL
     }
-    if (spl && a.split_out && a.x8_out == 3 && !a.res) { hipLaunchKernelGGL((conv_rows_kernel<true, false, 0, 1>), dim3(ncu), dim3(64 * RK_NW), 0, stream, a, Wp, tilesX, nitems, nchunk); return lastError(); }
-    if (spl && a.split_out && a.x8_out == 3 && a.res && a.res_split && !a.res_x8) { hipLaunchKernelGGL((conv_rows_kernel<true, false, 0, 2>), dim3(ncu), dim3(64 * RK_NW), 0, stream, a, Wp, tilesX, nitems, nchunk); return lastError(); }
-    if (spl) hipLaunchKernelGGL(conv_rows_kernel<true>, dim3(ncu), dim3(64 * RK_NW), 0, stream, a, Wp, tilesX, nitems, nchunk);
-    else hipLaunchKernelGGL(conv_rows_kernel<false>, dim3(ncu), dim3(64 * RK_NW), 0, stream, a, Wp, tilesX, nitems, nchunk);
+    if (spl && a.split_out && a.x8_out == 3 && !a.res) { hipLaunchKernelGGL((conv_rows_kernel<CT, RW, true, false, 0, 1>), grid, block, 0, stream, a, Wp, tilesX, nitems, nchunk); return lastError(); }
+    if (spl && a.split_out && a.x8_out == 3 && a.res && a.res_split && !a.res_x8) { hipLaunchKernelGGL((conv_rows_kernel<CT, RW, true, false, 0, 2>), grid, block, 0, stream, a, Wp, tilesX, nitems, nchunk); return lastError(); }
+    if (spl) hipLaunchKernelGGL((conv_rows_kernel<CT, RW, true>), grid, block, 0, stream, a, Wp, tilesX, nitems, nchunk);
+    else if constexpr (CT == 8) hipLaunchKernelGGL((conv_rows_kernel<CT, RW, false>), grid, block, 0, stream, a, Wp, tilesX, nitems, nchunk);
+    else return -3;
     return lastError();
 }
+int launchConvRows(const ConvArgs& a, const _Float16* Wp, int ncu, hipStream_t stream) { return launchRows<8, 2>(a, Wp, ncu, stream); }
+int launchConvRows64(const ConvArgs& a, const _Float16* Wp, int ncu, hipStream_t stream) { return launchRows<4, 3>(a, Wp, ncu, stream); }
 
 }  // namespace dsvt

@@ -361,11 +361,13 @@ def test_shared_head_conv_on_24_row_items_equals_its_16_row_form(pkg):
     (468, 468, 192, 128, False, 1, 1),     # the first block's entry: 18 phases; [hi | lo | hi] output
     (150, 140, 128, 256, True, 4, 4),      # two channel chunks per tile, image edges inside the last tile column / row
     (117, 117, 256, 256, False, 4, 4),     # the third stage at four frames: exactly 256 items
-    (200, 190, 64, 320, False, 2, 4),      # six phases, a half-empty last channel chunk (ctn = 4)
+    (200, 190, 64, 320, False, 2, 4),      # the head stems' shape, small: six phases, five 64-channel chunks on 24-row items (conv_rows_kernel<4, 3>; waves 0-3 request two weight rows, 4-7 one)
+    (468, 468, 64, 320, False, 1, 4),      # ... at full size
+    (468, 468, 384, 64, False, 3, 4),      # the shared head convolution, three images: 36 phases, ONE 64-channel chunk, 24-row items (two images would take 16-row ones)
 ])
 def test_rows_kernel_equals_wide_kernel(pkg, H, W, cin, cout, res, B, split_out):
-    """conv_rows_kernel (round 6, csrc/conv_rows.hip: ky-row slabs, requests through buffer descriptors, 34-pixel halo rows) against round 5's
-    conv_wide_kernel<8, 8, 36, 4, 2, 2, SPL> on the same three-product layer: both walk the (phase, tap) steps in the same order into the same accumulators,
+    """conv_rows_kernel<8, 2> / <4, 3> (round 6, csrc/conv_rows.hip: ky-row slabs, requests through buffer descriptors, 34-pixel halo rows) against round 5's
+    conv_wide_kernel<8, 8, 36, 4, 2, 2, SPL> / <4, 8, 36, 4, 2, 3, SPL> on the same three-product layer: both walk the (phase, tap) steps in the same order into the same accumulators,
     so every output bit must agree (kernel_variant = 1 keeps a layer on the round-5 kernel); and against a float64 convolution (5e-6 of scale)."""
     P = pkg.plugin
     g = torch.Generator(device="cpu").manual_seed(H * 7 + cin + cout + B)
