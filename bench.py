@@ -73,7 +73,7 @@ PEAK_HBM_GBS = 8000.0               # same guide: "HBM3E peak BW 8.0 TB/s spec" 
 N_POINTS = 180000
 # FETCH_SIZE / WRITE_SIZE passes (profiles/), by (mode, frames per forward())
 PMC_FILES = {("f16", 1): "r02_g_batch1_pmc_traffic.json", ("f16", 2): "r02_g_pmc_traffic.json", ("f16", 4): "r04_f16_pmc_traffic.json",
-             ("split", 4): "r05_split_pmc_traffic.json", ("split", 1): "r05_split_batch1_pmc_traffic.json",
+             ("split", 4): "r06_split_pmc_traffic.json", ("split", 1): "r05_split_batch1_pmc_traffic.json",
              ("splitmx", 4): "r04_split_pmc_traffic.json"}          # (round 4's split frame had the fp8 head: today's `splitmx`)
 FRAME_POOL = 4                      # distinct synthetic clouds cycled through by the steps
 MIN_TIMED_S = 0.5                   # K steps shorter than this are repeated
@@ -598,7 +598,7 @@ def roofline_rows(prof, sampled, counts, pool_len, FB, mode, n_points_per_launch
                                        "set_attention_f16_kernel" if f16 else "set_attention_split_kernel" if split else "set_attention_kernel("),
             "DsvtPosEmbedPlugin": ("posembed_batched_kernel (8 position-embedding MLPs, v_mfma_f32_16x16x32_f16)", "hbm", "posembed_batched_kernel"),
             "DsvtPillarFeatureNetPlugin": ("pfn_kernel (both PFN layers + scatter-max, v_mfma_f32_16x16x4_f32 + 16x16x32_f16; peak = the mix of the two matrix rates; a wave owns a work-balanced group of up to 16 pillars; bound by dependent LDS / L2 round trips at two waves per SIMD, not by either)" + sp_, "mfma", "pfn_kernel"),
-            "DsvtConv2dPlugin": ("conv_wide_kernel / conv_halo_kernel / conv_f16_kernel / conv1x1_resident(_mx)_kernel / conv3x3_grouped_narrow(_split)_kernel (implicit GEMM, v_mfma_f32_16x16x32_f16)" +
+            "DsvtConv2dPlugin": ("conv_rows_kernel<8, 2> / <4, 3> (round 6: the 3 x 3 stride-1 layers of the fp32-grade frame) / conv_wide_kernel / conv_halo_kernel / conv_f16_kernel / conv1x1_resident(_split / _mx)_kernel / conv3x3_grouped_narrow(_split)_kernel (implicit GEMM, v_mfma_f32_16x16x32_f16)" +
                                  (" -- 3 x 3 stride-1 layers with > 32 output channels (93 % of the products) on the fp16 + fp8 K loop over [hi | x8]: one fp16 MFMA product + "
                                   "two e4m3 correction products (v_mfma_scale_f32_16x16x128_f8f6f4) per fp32-grade product; the other layers walk [hi | lo | hi] x "
                                   "[w_hi | w_hi | w_lo], three fp16 MFMAs per product; peak = the launch-weighted mix of the two" if (split and head_mx) else

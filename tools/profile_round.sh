@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 24 --warmup 3 --repeats 1 --no-cpu-baseline --no-latency-mode --no-parity-mode $*"
+B="python $R/bench.py --steps 24 --warmup 3 --repeats 1 --no-cpu-baseline --no-latency-mode --no-parity-mode --no-other-configs --no-cpp-host $*"
 rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- $B > $O/trace.log 2>&1
 grep '^{' $O/trace.log | tail -1 > $O/bench_line.json
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pmc -- $B --no-graph --streams 1 > $O/pmc_fetch.log 2>&1
