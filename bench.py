@@ -443,6 +443,18 @@ class ModeRun:
         self.pkg.plugin.PROFILE = None
         return 1
 
+    def gather_forward(self, j, results):
+        """the product loop of BASELINE configs[3] (src/dsvt-ai-trt.cpp:1884-1970: a result per frame, every frame): the rows of forward j -- FB frames on every rank:
+        configs[3]'s 32 frames over 8 GPUs -- meet on rank 0; static buffers (parallel.GatherBuffers), no allocation.  The HOST waits for the forward's stream first (the
+        other stream's forward keeps the GPU busy meanwhile): a collective that is only stream-ordered behind graph replays on side streams is one of the two triggers of
+        the fault bisected in round 6 (profiles/r06_gather_fault_bisect.txt; the other, the order of the pipelines' first forwards, is removed in prepare()) -- with one
+        GPU both forms ran clean for thousands of gathers, no N > 1 run exists yet, and the host wait costs nothing measurable."""
+        par, FB = self.par, self.FB
+        self.streams[j % self.NS].synchronize()
+        g = par.gather_results(results[j * FB:(j + 1) * FB], FB * self.world, self.rank, self.world, force_collective=self.args.rccl_single, buffers=self.batch_buffers)
+        if g is not None:
+            self.gathered_all[j * FB * self.world:(j + 1) * FB * self.world].copy_(g)
+
     def timed(self, results, K, gather):
         """exactly K steps (K / FB forwards), timed on THIS rank between two stream synchronisations; no collective inside unless `gather`
         (the last repeat: the path's one collective, the result gather).  Returns (seconds, per-forward ms, gathered rows, gather ms)."""
@@ -458,14 +470,10 @@ class ModeRun:
                 marks[i][0].record()
                 self.run_frame(i, results[i * FB:(i + 1) * FB])
                 marks[i][1].record()
-            if every:
-                # the product loop of BASELINE configs[3] (src/dsvt-ai-trt.cpp:1884-1970: a result per frame, every frame): the rows of this batch -- ONE forward of FB
-                # frames on every rank: configs[3]'s 32 frames over 8 GPUs -- meet on rank 0 as soon as the forward's stream has them (the other stream's forward runs
-                # under the collective); static buffers (parallel.GatherBuffers), no allocation
-                torch.cuda.current_stream().wait_stream(self.streams[i % NS])
-                g = par.gather_results(results[i * FB:(i + 1) * FB], FB * self.world, self.rank, self.world, force_collective=self.args.rccl_single, buffers=self.batch_buffers)
-                if g is not None:
-                    self.gathered_all[i * FB * self.world:(i + 1) * FB * self.world].copy_(g)
+            if every and i >= 1:
+                self.gather_forward(i - 1, results)                # (one forward behind: the host waits for forward i - 1 while forward i runs on the other stream)
+        if every:
+            self.gather_forward(KB - 1, results)
         for s in self.streams:
             torch.cuda.current_stream().wait_stream(s)
         if every:
