@@ -63,6 +63,9 @@ constexpr uint32_t RK_OOB = 0xFFFFFFF0u;           // byte offset of a lane whos
 #ifndef RK_SETPRIO
 #define RK_SETPRIO 0
 #endif
+#ifndef RK_SKEW
+#define RK_SKEW 10
+#endif
 // TR: the instrumented instantiation (ablation build, DSVT_CONV_TRACE=1, tools/trace_conv_rows.py): s_memtime stamps of waves 0 and 4 -- per slab [start, MFMAs
 // issued, own requests landed, barrier passed], per item [K loop done, epilogue done]
 // ABL: timing ablations (instantiated in the -DDSVT_ABLATE build only, DSVT_CONV_DBG; wrong results): 1 = no halo requests, 2 = no weight requests, 4 = no epilogue,
@@ -131,6 +134,19 @@ conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int ni
 
     int item = blockIdx.x;
     if (item >= nitems) return;
+#if RK_SKEW
+    // Start skew (round 6).  Every item takes the same time, so the 256 persistent workgroups of a launch reach their item ends -- the store burst of 512 pixels x 128 channels
+    // x two planes, the residual read -- together, round after round: HBM sees bursts and idles in between.  A launch whose item count is not a multiple of the grid has
+    // workgroups that do one item FEWER than the others (b >= nitems % grid) and wait for the launch's last round anyway: those start late by ((b - rem) % 8) x
+    // NP x RK_SKEW x 64 cycles (up to ~0.6 item times), which spreads the item ends of the chip over the item period at no cost to the launch.  468 x 468 128 -> 128, four
+    // images (1800 items = 7 rounds + 8): -2.4 %, with a residual -4 %, one image -2.5 %, the 64-channel layers -0.4 .. -1.2 % (RK_SKEW = 10; 20: the same within noise; 35: loses on the
+    // two-round layers; tools/ab_variants.sh, profiles/r06_conv_rows_ablations.txt).  A launch with whole rounds is not skewed.
+    {
+        const int rem = nitems % (int)gridDim.x;
+        if (rem != 0 && (int)blockIdx.x >= rem && nitems > (int)gridDim.x)
+            for (int k = (((int)blockIdx.x - rem) & 7) * NP * RK_SKEW; k > 0; k -= 100) __builtin_amdgcn_s_sleep(100);
+    }
+#endif
 #if RK_SETPRIO
     if (upper) __builtin_amdgcn_s_setprio(1);                     // (MI355X_MICROARCH "Two waves per SIMD" item 4: static priority for the younger half)
 #endif
