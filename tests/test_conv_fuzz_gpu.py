@@ -99,3 +99,44 @@ def test_fuzz_conv3x3_wide_kernels_with_residual(pkg, H, W, B, seed):
     got = P.add_conv2d_op(P.conv_weight_rows(w.numpy()), b.numpy(), H, W, cin, cout, 3, 1, 1, relu=True, has_residual=True)(_nhwc(x), _nhwc(r))[0]
     torch.cuda.synchronize()
     assert (got.permute(0, 3, 1, 2).float() - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_rows_kernel_fuzz_against_the_round5_kernel(pkg):
+    """conv_rows_kernel<8, 2> / <4, 3> on random three-product layers that reach them (whole-chip grids: enough images), against round 5's kernels of the same layers
+    (kernel_variant = 1) bit for bit: odd heights / widths (partial last tile row and column, images that end inside a tile), every phase count from 6 to 24, channel
+    counts with a half-empty last chunk, residuals, one to several channel chunks, item counts that are and are not a multiple of the grid (the start skew)."""
+    import torch
+    P = pkg.plugin
+    rng = np.random.default_rng(2024)
+    done = {"rows": 0, "rows64": 0}
+    for trial in range(10):
+        cin = int(rng.choice([64, 128, 192, 256]))
+        cout = int(rng.choice([64, 128, 192, 256, 320]))
+        H, W = int(rng.integers(97, 230)), int(rng.integers(97, 230))
+        res = bool(rng.integers(0, 2))
+        ct4 = cout <= 64 or cout % 128 == 64
+        tiles = -(-H // (24 if ct4 else 16)) * -(-W // 32) * -(-cout // (64 if ct4 else 128))
+        B = max(1, -(-256 // tiles)) + int(rng.integers(0, 2))
+        g = torch.Generator(device="cpu").manual_seed(1000 + trial)
+        x = torch.relu(torch.randn(B, H, W, cin, generator=g) * 2.0)
+        hi = x.half(); x3 = torch.cat([hi, (x - hi.float()).half(), torch.full_like(hi, float("nan"))], -1).to(DEV)      # (the third plane aliases plane 0: never read)
+        w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+        b = torch.randn(cout, generator=g) * 0.1
+        rows = P.split_weight_rows(P.conv_weight_rows(w.numpy()), 9, cin)
+        r3 = None
+        if res:
+            r = torch.randn(B, H, W, cout, generator=g); rh = r.half()
+            r3 = torch.cat([rh, (r - rh.float()).half(), torch.full_like(rh, float("nan"))], -1).to(DEV)
+        outs = []
+        for variant in (0, 1):
+            op = P.add_conv2d_op(rows, b.numpy(), H, W, 3 * cin, cout, 3, 1, 1, relu=bool(trial % 3), has_residual=res, split_residual=1 if res else 0, split_input=1,
+                                 split_output=4, out_channel_stride=3 * cout, kernel_variant=variant)
+            out = torch.full((B, H, W, 3 * cout), 7.0, dtype=torch.float16, device=DEV)
+            op(*([x3] + ([r3] if res else [])), out=[out])
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+        a, c = outs[0].view(torch.int16), outs[1].view(torch.int16)
+        assert torch.equal(a, c), (trial, H, W, cin, cout, B, res, int((a != c).sum()))
+        assert not torch.isnan(outs[0][..., :2 * cout].float()).any() and (outs[0][..., 2 * cout:] == 7.0).all()
+        done["rows64" if ct4 else "rows"] += 1
+    assert done["rows"] >= 2 and done["rows64"] >= 2, done
