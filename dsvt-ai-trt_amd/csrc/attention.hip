@@ -207,7 +207,8 @@ set_attention_kernel(AttnArgs a)
 //   * scores, softmax and the output accumulation stay fp32.
 typedef _Float16 ahalf8 __attribute__((ext_vector_type(8)));
 typedef _Float16 ahalf4 __attribute__((ext_vector_type(4)));
-constexpr int AQL = 104;      // halfs per staged Q / K row
+constexpr int AQL = 112;      // halfs per staged Q / K row: the 16-byte fragment reads (row r, lane group g < 3) are conflict-free under ds_read_b128's lane groups
+                              // {0-3, 12-15, 20-27}, ... for a stride of 112 (enumerated; 104 -- rounds 1-5 -- costs two extra LDS cycles per read, 96 four, 128 twenty-eight)
 constexpr int AVL = 40;       // halfs per staged V^T row (36 keys + 4: 80-byte rows, conflict-free 8-byte fragment reads; the reads of
                               // keys >= 40 -- lane groups g >= 2 of the third key tile -- run into the next row and are discarded)
 
@@ -381,7 +382,7 @@ set_attention_f16_kernel(AttnArgs a)
 // in fp32 LDS images; here every operand is the pair hi = fp16(v), lo = fp16(v - hi) and a product is three 16x16x32 fp16 MFMAs:
 //     S^T = K_hi Q_hi^T + K_lo Q_hi^T + K_hi Q_lo^T            (27 MFMAs per head)
 //     O^T = V_hi^T P_hi^T + V_lo^T P_hi^T + V_hi^T P_lo^T      (36 MFMAs per head; P split in registers after the fp32 softmax)
-// Layouts are set_attention_f16_kernel's (Q / K rows of 104 halfs, V transposed in 40-half rows), twice: 46.8 KB of LDS, three
+// Layouts are set_attention_f16_kernel's (Q / K rows of 112 halfs, V transposed in 40-half rows), twice: 48.4 KB of LDS, three
 // workgroups per CU.  Softmax in fp32 with v_exp_f32 / v_rcp_f32 (1 ulp each: fp32 grade).
 __global__ void __launch_bounds__(256, 3)
 set_attention_split_kernel(AttnArgs a)
@@ -404,7 +405,10 @@ set_attention_split_kernel(AttnArgs a)
     if (tid < AHB * AL) myMask = a.mask[(size_t)set * a.mask_set_stride + (size_t)(hq * AHB + tid / AL) * a.mask_head_stride + tid % AL];
     // ---- stage the 36 gathered fp32 rows as hi / lo fp16: Q, K as rows, V transposed (see set_attention_f16_kernel for the order of the
     // loads: all indices, all rows, then the LDS writes).  Item = (slot, Q | K, 4-channel chunk) / (4-channel chunk, slot) for V.
-    constexpr int NQK = (AL * 2 * 24 + 255) / 256, NV = (24 * AL + 255) / 256, NIT = NQK + NV;
+    // V items are (4-channel chunk, PAIR of slots): the two slots' values of a channel are one 4-byte LDS store.  (Until round 6 a V item was one slot and stored eight
+    // single halfs: two lanes of every pair wrote the two halves of one dword -- 5.1 M bank-conflict cycles per four-frame launch, a third of the kernel's LDS-active cycles.)
+    constexpr int NQK = (AL * 2 * 24 + 255) / 256, NVP = (24 * (AL / 2) + 255) / 256, NIT = NQK + 2 * NVP;
+    static_assert(AL % 2 == 0, "slot pairs");
     int slotOf[NIT], segOf[NIT], c4Of[NIT]; bool live[NIT];
 #pragma unroll
     for (int k = 0; k < NQK; ++k) {
@@ -413,10 +417,13 @@ set_attention_split_kernel(AttnArgs a)
         slotOf[k] = ii / 48; segOf[k] = rem / 24; c4Of[k] = (rem % 24) * 4;
     }
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const int i = tid + 256 * k; live[NQK + k] = i < 24 * AL;
-        const int ii = live[NQK + k] ? i : 0;
-        slotOf[NQK + k] = ii % AL; segOf[NQK + k] = 2; c4Of[NQK + k] = (ii / AL) * 4;
+    for (int k = 0; k < NVP; ++k) {
+        const int i = tid + 256 * k; const bool lv = i < 24 * (AL / 2);
+        const int ii = lv ? i : 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {                                    // items NQK + 2k, NQK + 2k + 1: the even and the odd slot of the pair
+            live[NQK + 2 * k + e] = lv; slotOf[NQK + 2 * k + e] = 2 * (ii % (AL / 2)) + e; segOf[NQK + 2 * k + e] = 2; c4Of[NQK + 2 * k + e] = (ii / (AL / 2)) * 4;
+        }
     }
     uint32_t rowOf[NIT];
     if (a.inds) {
@@ -432,23 +439,34 @@ set_attention_split_kernel(AttnArgs a)
         val[k] = *reinterpret_cast<const floatx4*>(static_cast<const float*>(a.qkv) + (size_t)rowOf[k] * a.qkv_ld + segOf[k] * a.C + hq * (AHB * ADH) + c4Of[k]);
     if (tid < AL) sRow[tid] = myRow;
     if (tid < AHB * AL) sMask[tid / AL][tid % AL] = myMask;
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-        if (!live[k]) continue;
-        _Float16 h[4], l[4];
+    auto split4 = [](const floatx4& v, _Float16 (&h)[4], _Float16 (&l)[4]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            h[j] = (_Float16)__builtin_fminf(__builtin_fmaxf(val[k][j], -65504.f), 65504.f);
-            l[j] = (_Float16)__builtin_fminf(__builtin_fmaxf(val[k][j] - (float)h[j], -65504.f), 65504.f);
+            h[j] = (_Float16)__builtin_fminf(__builtin_fmaxf(v[j], -65504.f), 65504.f);
+            l[j] = (_Float16)__builtin_fminf(__builtin_fmaxf(v[j] - (float)h[j], -65504.f), 65504.f);
         }
-        if (k < NQK) {
-            _Float16* dh = (segOf[k] == 0 ? sQ[0] : sK[0]) + slotOf[k] * AQL + c4Of[k];
-            _Float16* dl = (segOf[k] == 0 ? sQ[1] : sK[1]) + slotOf[k] * AQL + c4Of[k];
-            *reinterpret_cast<ahalf4*>(dh) = ahalf4{h[0], h[1], h[2], h[3]};
-            *reinterpret_cast<ahalf4*>(dl) = ahalf4{l[0], l[1], l[2], l[3]};
-        } else {
+    };
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { sVt[0][(c4Of[k] + j) * AVL + slotOf[k]] = h[j]; sVt[1][(c4Of[k] + j) * AVL + slotOf[k]] = l[j]; }
+    for (int k = 0; k < NQK; ++k) {
+        if (!live[k]) continue;
+        _Float16 h[4], l[4];
+        split4(val[k], h, l);
+        _Float16* dh = (segOf[k] == 0 ? sQ[0] : sK[0]) + slotOf[k] * AQL + c4Of[k];
+        _Float16* dl = (segOf[k] == 0 ? sQ[1] : sK[1]) + slotOf[k] * AQL + c4Of[k];
+        *reinterpret_cast<ahalf4*>(dh) = ahalf4{h[0], h[1], h[2], h[3]};
+        *reinterpret_cast<ahalf4*>(dl) = ahalf4{l[0], l[1], l[2], l[3]};
+    }
+#pragma unroll
+    for (int k = 0; k < NVP; ++k) {
+        const int e0 = NQK + 2 * k;
+        if (!live[e0]) continue;
+        _Float16 h0[4], l0[4], h1[4], l1[4];
+        split4(val[e0], h0, l0); split4(val[e0 + 1], h1, l1);
+        typedef _Float16 ahalf2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                    // (slotOf[e0] is even and AVL is even: 4-byte aligned)
+            *reinterpret_cast<ahalf2*>(&sVt[0][(c4Of[e0] + j) * AVL + slotOf[e0]]) = ahalf2{h0[j], h1[j]};
+            *reinterpret_cast<ahalf2*>(&sVt[1][(c4Of[e0] + j) * AVL + slotOf[e0]]) = ahalf2{l0[j], l1[j]};
         }
     }
     __syncthreads();
