@@ -2136,6 +2136,11 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
 #undef DSVT_WIDE_MX
     if (a.KH == 3 && ctWide >= 4) {
         const int nwide = cdiv(a.Ho, 16) * tilesX * nchunk * NBI;
+        // round 6: launches too small for the 128-channel / 24-row items run the ky-row slab loop on the 64-channel items chosen below (DSVT_CONV_ROWS_SMALL=0: round 5's kernels)
+        auto rowsSmall = [&](const ConvArgs& q) {
+            static int on = -1; if (on < 0) on = ablateEnv("DSVT_CONV_ROWS", 1) && ablateEnv("DSVT_CONV_ROWS_SMALL", 1);
+            return on && spl && q.variant != 1 && !q.trace && convRowsSmallEligible(q);
+        };
         // short K (the 64 -> 320 head stems: 9 slabs per item, the epilogue weighs as much as the MFMAs): 8-row x 128-channel tiles on
         // four waves, two independent workgroups per CU, 2655 items: 116-122 vs 130 us (no gain on the K >= 1152 layers)
         if (ctWide == 8 && a.Cin <= 64) {
@@ -2192,6 +2197,7 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
                     hipLaunchKernelGGL((conv_wide_kernel<4, 8, 36, 4, 2, 3, false, true>), dim3(ncu), dim3(512), 0, stream, a, Wp, zeros, tilesX, n24, nchunk, dbg);
                     return lastError();
                 }
+                if (rowsSmall(a)) return launchConvRowsSmall(a, Wp, 2, ncu, stream);                              // round 6: the same items on conv_rows_kernel<4, 2>
                 DSVT_WIDE(ncu, 512, nwide, nchunk, 4, 8, 40, 4, 2, 2);
             }
         }
@@ -2199,7 +2205,11 @@ static int launchConvHalo(const ConvArgs& a, const _Float16* Wp, const _Float16*
         // 16-row x 64-channel items on eight waves when they nearly fill the CUs (234x234x128: 240 items, one per CU, 40 LDS-DMA
         // pieces per wave and item instead of 59)
         const int n16 = cdiv(a.Ho, 16) * tilesX * nch64 * NBI;
-        if (n16 * 10 >= ncu * 9 && n16 <= ncu) DSVT_WIDE(n16, 512, n16, nch64, 4, 8, 40, 4, 2, 2);
+        if (n16 * 10 >= ncu * 9 && n16 <= ncu) {
+            if (rowsSmall(a)) return launchConvRowsSmall(a, Wp, 2, ncu, stream);                                  // round 6: conv_rows_kernel<4, 2>
+            DSVT_WIDE(n16, 512, n16, nch64, 4, 8, 40, 4, 2, 2);
+        }
+        if (rowsSmall(a)) return launchConvRowsSmall(a, Wp, 1, ncu, stream);                                      // round 6: conv_rows_kernel<4, 1>
         // 8 rows x 32 pixels x 64 channels: eight waves of ONE row each (117x117x256: 31.4 us; four waves of two rows: 35.6 us --
         // one wave per SIMD cannot hide its own LDS-DMA issue and wait time)
         DSVT_WIDE(nsmall < 2 * ncu ? nsmall : 2 * ncu, 512, nsmall, nch64, 4, 8, 36, 4, 2, 1);

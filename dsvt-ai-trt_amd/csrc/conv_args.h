@@ -126,5 +126,7 @@ bool convRowsEligible(const ConvArgs& a, int ncu);
 int launchConvRows(const ConvArgs& a, const _Float16* Wp, int ncu, hipStream_t stream);
 bool convRows64Eligible(const ConvArgs& a, int ncu);          // (64-channel chunks on 24-row items)
 int launchConvRows64(const ConvArgs& a, const _Float16* Wp, int ncu, hipStream_t stream);
+bool convRowsSmallEligible(const ConvArgs& a);                    // (64-channel chunks on 16- or 8-row items: launches that do not fill the chip with the items above)
+int launchConvRowsSmall(const ConvArgs& a, const _Float16* Wp, int rowsPerWave, int ncu, hipStream_t stream);
 
 }  // namespace dsvt

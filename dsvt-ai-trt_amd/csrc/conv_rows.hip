@@ -429,7 +429,7 @@ static int launchRows(const ConvArgs& a, const _Float16* Wp, int ncu, hipStream_
     const int tilesX = cdiv(a.Wo, RK_TW), nchunk = cdiv(a.CoutRows, CT * 16);
     const int nitems = cdiv(a.Ho, 8 * RW) * tilesX * nchunk * a.nb;
     const bool spl = a.split_out != 0 || a.res_split != 0;
-    const dim3 grid(ncu), block(64 * RK_NW);
+    const dim3 grid(nitems < ncu ? nitems : ncu), block(64 * RK_NW);
     if constexpr (kAblate) {
         static int dbg = -1; if (dbg < 0) dbg = ablateEnv("DSVT_CONV_DBG", 0);
         if (a.trace && spl) { hipLaunchKernelGGL((conv_rows_kernel<CT, RW, true, true>), grid, block, 0, stream, a, Wp, tilesX, nitems, nchunk); return lastError(); }
@@ -446,5 +446,17 @@ static int launchRows(const ConvArgs& a, const _Float16* Wp, int ncu, hipStream_
 }
 int launchConvRows(const ConvArgs& a, const _Float16* Wp, int ncu, hipStream_t stream) { return launchRows<8, 2>(a, Wp, ncu, stream); }
 int launchConvRows64(const ConvArgs& a, const _Float16* Wp, int ncu, hipStream_t stream) { return launchRows<4, 3>(a, Wp, ncu, stream); }
+
+// Launches that do not fill the chip with the items above (one frame per forward: 234 x 234 x 128 = 120 items of 16 rows x 128 channels, 117 x 117 x 256 = 64; the shared
+// 384 -> 64 convolution = 300 items of 24 rows, a second round for 44 of them): 64-channel chunks on 16-row items (conv_rows_kernel<4, 2>: 240 / 450 items) or 8-row items
+// (<4, 1>: 240 items at 117 x 117 x 256) -- the items round 5's launcher already chose for conv_wide_kernel<4, 8, 40, 4, 2, 2> / <4, 8, 36, 4, 2, 1>, on the ky-row slab loop.
+// Same (phase, tap) order into the same accumulators: bit-identical to those and to every other tile shape (tests/test_conv_gpu.py::test_rows_kernel_equals_wide_kernel).
+bool convRowsSmallEligible(const ConvArgs& a) {
+    if (!rowsCommon(a) || a.CoutRows % 64 != 0) return false;
+    return a.split_out != 0 || a.res_split != 0;                                       // (the fp16 frame keeps its own kernels)
+}
+int launchConvRowsSmall(const ConvArgs& a, const _Float16* Wp, int rowsPerWave, int ncu, hipStream_t stream) {
+    return rowsPerWave == 1 ? launchRows<4, 1>(a, Wp, ncu, stream) : launchRows<4, 2>(a, Wp, ncu, stream);
+}
 
 }  // namespace dsvt

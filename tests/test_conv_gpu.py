@@ -364,10 +364,16 @@ def test_shared_head_conv_on_24_row_items_equals_its_16_row_form(pkg):
     (200, 190, 64, 320, False, 2, 4),      # the head stems' shape, small: six phases, five 64-channel chunks on 24-row items (conv_rows_kernel<4, 3>; waves 0-3 request two weight rows, 4-7 one)
     (468, 468, 64, 320, False, 1, 4),      # ... at full size
     (468, 468, 384, 64, False, 3, 4),      # the shared head convolution, three images: 36 phases, ONE 64-channel chunk, 24-row items (two images would take 16-row ones)
+    (468, 468, 384, 64, False, 1, 4),      # ... one image: 450 16-row items (conv_rows_kernel<4, 2>; round 5: conv_wide_kernel<4, 8, 40, 4, 2, 2>)
+    (234, 234, 128, 128, True, 1, 4),      # the second stage at one frame: 240 items of 16 rows x 64 channels (<4, 2>), fewer items than workgroups
+    (117, 117, 256, 256, True, 2, 4),      # the third stage at two frames: 256 items of 16 rows x 64 channels (<4, 2>)
+    (117, 117, 256, 256, False, 1, 4),     # ... at one frame: 240 items of 8 rows x 64 channels (conv_rows_kernel<4, 1>; round 5: conv_wide_kernel<4, 8, 36, 4, 2, 1>)
+    (117, 117, 256, 256, True, 3, 4),      # ... at three frames: 720 8-row items, three rounds
+    (40, 50, 64, 64, False, 1, 1),         # a small image: 10 items of 8 rows, a grid of 10 workgroups, [hi | lo | hi] output
 ])
 def test_rows_kernel_equals_wide_kernel(pkg, H, W, cin, cout, res, B, split_out):
-    """conv_rows_kernel<8, 2> / <4, 3> (round 6, csrc/conv_rows.hip: ky-row slabs, requests through buffer descriptors, 34-pixel halo rows) against round 5's
-    conv_wide_kernel<8, 8, 36, 4, 2, 2, SPL> / <4, 8, 36, 4, 2, 3, SPL> on the same three-product layer: both walk the (phase, tap) steps in the same order into the same accumulators,
+    """conv_rows_kernel<8, 2> / <4, 3> / <4, 2> / <4, 1> (round 6, csrc/conv_rows.hip: ky-row slabs, requests through buffer descriptors, 34-pixel halo rows) against round 5's
+    conv_wide_kernel<8, 8, 36, 4, 2, 2, SPL> / <4, 8, 36, 4, 2, 3, SPL> / <4, 8, 40, 4, 2, 2, SPL> / <4, 8, 36, 4, 2, 1, SPL> on the same three-product layer: both walk the (phase, tap) steps in the same order into the same accumulators,
     so every output bit must agree (kernel_variant = 1 keeps a layer on the round-5 kernel); and against a float64 convolution (5e-6 of scale)."""
     P = pkg.plugin
     g = torch.Generator(device="cpu").manual_seed(H * 7 + cin + cout + B)
