@@ -74,7 +74,7 @@ constexpr uint32_t RK_OOB = 0xFFFFFFF0u;           // byte offset of a lane whos
 // code, more than half of the 64 KB instruction cache): 0 = generic; 1 = no residual, output [hi | lo | -] (split_output = 4); 2 = [hi | lo] residual, output [hi | lo | -]
 template <int CT, int RW, bool SPL, bool TR = false, int ABL = 0, int EPI = 0>
 __global__ void __launch_bounds__(64 * RK_NW, 1)
-conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int nitems, int nchunk)
+conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int nitems, int nchunk, int yBase)
 {
     using C = RowsCfg<CT, RW>;
     constexpr int RK_ROWS = C::ROWS, RK_HH = C::HH, NM = C::NM, RK_PPW = C::PPW, RK_HBYTES = C::HBYTES, RK_WBYTES = C::WBYTES, RK_WOFF = C::WOFF, RK_BIAS = C::BIAS;
@@ -88,7 +88,7 @@ conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int ni
     auto decode = [&](int it, int& yy, int& xx, int& ch, int& bb) {
         bb = it / perImg; it -= bb * perImg;
         ch = it % nchunk; const int t = it / nchunk;
-        yy = (t / tilesX) * RK_ROWS; xx = (t % tilesX) * RK_TW;
+        yy = yBase + (t / tilesX) * RK_ROWS; xx = (t % tilesX) * RK_TW;      // (yBase: the launch covers the tile rows from image row yBase on)
     };
     const __amdgpu_buffer_rsrc_t inRsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.in), 0, (int)((size_t)a.nb * a.H * a.W * a.Cin * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t wRsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Wp), 0, 0x7FFFFFF0, 0x00020000);
@@ -425,26 +425,45 @@ bool convRows64Eligible(const ConvArgs& a, int ncu) {
 }
 
 template <int CT, int RW>
-static int launchRows(const ConvArgs& a, const _Float16* Wp, int ncu, hipStream_t stream) {
+static int launchRows(const ConvArgs& a, const _Float16* Wp, int ncu, hipStream_t stream, int yBase = 0, int tileRows = -1) {
     const int tilesX = cdiv(a.Wo, RK_TW), nchunk = cdiv(a.CoutRows, CT * 16);
-    const int nitems = cdiv(a.Ho, 8 * RW) * tilesX * nchunk * a.nb;
+    if (tileRows < 0) tileRows = cdiv(a.Ho - yBase, 8 * RW);                    // (default: every tile row from yBase to the image's last row)
+    const int nitems = tileRows * tilesX * nchunk * a.nb;
     const bool spl = a.split_out != 0 || a.res_split != 0;
     const dim3 grid(nitems < ncu ? nitems : ncu), block(64 * RK_NW);
+#define RK_LAUNCH(...) hipLaunchKernelGGL((conv_rows_kernel<CT, RW, __VA_ARGS__>), grid, block, 0, stream, a, Wp, tilesX, nitems, nchunk, yBase)
     if constexpr (kAblate) {
         static int dbg = -1; if (dbg < 0) dbg = ablateEnv("DSVT_CONV_DBG", 0);
-        if (a.trace && spl) { hipLaunchKernelGGL((conv_rows_kernel<CT, RW, true, true>), grid, block, 0, stream, a, Wp, tilesX, nitems, nchunk); return lastError(); }
-#define RK_ABL(N_) if (spl && dbg == N_) { hipLaunchKernelGGL((conv_rows_kernel<CT, RW, true, false, N_>), grid, block, 0, stream, a, Wp, tilesX, nitems, nchunk); return lastError(); }
+        if (a.trace && spl) { RK_LAUNCH(true, true); return lastError(); }
+#define RK_ABL(N_) if (spl && dbg == N_) { RK_LAUNCH(true, false, N_); return lastError(); }
         RK_ABL(1) RK_ABL(2) RK_ABL(3) RK_ABL(8)
 #undef RK_ABL
     }
-    if (spl && a.split_out && a.x8_out == 3 && !a.res) { hipLaunchKernelGGL((conv_rows_kernel<CT, RW, true, false, 0, 1>), grid, block, 0, stream, a, Wp, tilesX, nitems, nchunk); return lastError(); }
-    if (spl && a.split_out && a.x8_out == 3 && a.res && a.res_split && !a.res_x8) { hipLaunchKernelGGL((conv_rows_kernel<CT, RW, true, false, 0, 2>), grid, block, 0, stream, a, Wp, tilesX, nitems, nchunk); return lastError(); }
-    if (spl) hipLaunchKernelGGL((conv_rows_kernel<CT, RW, true>), grid, block, 0, stream, a, Wp, tilesX, nitems, nchunk);
-    else if constexpr (CT == 8) hipLaunchKernelGGL((conv_rows_kernel<CT, RW, false>), grid, block, 0, stream, a, Wp, tilesX, nitems, nchunk);
+    if (spl && a.split_out && a.x8_out == 3 && !a.res) { RK_LAUNCH(true, false, 0, 1); return lastError(); }
+    if (spl && a.split_out && a.x8_out == 3 && a.res && a.res_split && !a.res_x8) { RK_LAUNCH(true, false, 0, 2); return lastError(); }
+    if (spl) RK_LAUNCH(true);
+    else if constexpr (CT == 8) RK_LAUNCH(false);
     else return -3;
+#undef RK_LAUNCH
     return lastError();
 }
-int launchConvRows(const ConvArgs& a, const _Float16* Wp, int ncu, hipStream_t stream) { return launchRows<8, 2>(a, Wp, ncu, stream); }
+// The 128-channel items, with the image's partial last tile row as its own launch when that saves a round of the chip.  468 rows are 29 tile rows of 16 and FOUR more:
+// at four images per launch 1800 items = 7 rounds of 256 workgroups + 8 items that run alone for an item time (75 us of ~600), and 60 of the 1800 compute twelve rows of
+// padding each.  Without the partial tile row the launch is 1740 items = 7 rounds; the four rows go to conv_rows_kernel<4, 1> (8-row x 64-channel items: 120 items, one
+// partial round of ~25 us) behind it.  Same (phase, tap) order in every item shape: the bits do not depend on the split.
+static int launchRows128(const ConvArgs& a, const _Float16* Wp, int ncu, hipStream_t stream) {
+    const int tilesX = cdiv(a.Wo, RK_TW), nchunk = cdiv(a.CoutRows, 128), per = tilesX * nchunk * a.nb;
+    const int rest = a.Ho % 16, fullRows = a.Ho / 16;
+    static int on = -1; if (on < 0) on = ablateEnv("DSVT_CONV_ROWS_LASTROW", 1);
+    const bool spl = a.split_out != 0 || a.res_split != 0;
+    if (on && spl && !a.trace && rest != 0 && rest <= 8 && fullRows > 0 && a.CoutRows % 64 == 0 && cdiv(fullRows * per, ncu) < cdiv((fullRows + 1) * per, ncu)) {
+        const int rc = launchRows<8, 2>(a, Wp, ncu, stream, 0, fullRows);
+        if (rc != 0) return rc;
+        return launchRows<4, 1>(a, Wp, ncu, stream, fullRows * 16, 1);
+    }
+    return launchRows<8, 2>(a, Wp, ncu, stream);
+}
+int launchConvRows(const ConvArgs& a, const _Float16* Wp, int ncu, hipStream_t stream) { return launchRows128(a, Wp, ncu, stream); }
 int launchConvRows64(const ConvArgs& a, const _Float16* Wp, int ncu, hipStream_t stream) { return launchRows<4, 3>(a, Wp, ncu, stream); }
 
 // Launches that do not fill the chip with the items above (one frame per forward: 234 x 234 x 128 = 120 items of 16 rows x 128 channels, 117 x 117 x 256 = 64; the shared

@@ -358,6 +358,7 @@ def test_shared_head_conv_on_24_row_items_equals_its_16_row_form(pkg):
 @pytest.mark.parametrize("H,W,cin,cout,res,B,split_out", [
     (468, 468, 128, 128, False, 1, 4),     # the BEV ResNet layer (14 of the frame's launches): 450 items on 256 CUs, the last round partial
     (468, 468, 128, 128, True, 2, 4),      # ... with a residual, two images: items walk image after image
+    (468, 468, 128, 128, True, 4, 4),      # ... four images: 1800 items would be 7 rounds + 8; the partial last tile row (four rows) is a second launch of 8-row x 64-channel items
     (468, 468, 192, 128, False, 1, 1),     # the first block's entry: 18 phases; [hi | lo | hi] output
     (150, 140, 128, 256, True, 4, 4),      # two channel chunks per tile, image edges inside the last tile column / row
     (117, 117, 256, 256, False, 4, 4),     # the third stage at four frames: exactly 256 items
