@@ -310,7 +310,8 @@ conv_rows_kernel(ConvArgs a, const _Float16* __restrict__ Wp, int tilesX, int ni
             }
             const bool hasRes = EPI == 0 ? a.res != nullptr : EPI == 2;
             if constexpr (SPL) {
-                constexpr int RS = 2;
+                constexpr int RS = 2;                              // residual blocks in flight.  4 / 8 / 16 (27 / 52 / 130 spilled registers): 676 / 700 / 753 us against 669 on the
+                                                                   // 468 x 468 128 -> 128 residual layer -- the chip reads its residuals in one burst either way (profiles/r06_conv_rows_ablations.txt 9)
                 const bool splitRes = EPI == 0 ? (hasRes && a.res_split != 0) : EPI == 2, resX8 = EPI == 0 && splitRes && a.res_x8 != 0;
 #pragma unroll
                 for (int b0 = 0; b0 < NBLK; b0 += RS) {
