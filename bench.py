@@ -532,7 +532,10 @@ def roofline_rows(prof, sampled, counts, pool_len, FB, mode, n_points_per_launch
             return None
         if chain:
             return round(sum(pm[k]["traffic_mb_per_launch"] for k in ks) * 1e6)
-        n = sum(pm[k]["launches"] for k in ks)
+        # (round 6: at four frames per forward a 468-row 128-channel convolution is TWO launches -- the whole tile rows on conv_rows_kernel<8, 2>, the partial last tile row on
+        # conv_rows_kernel<4, 1>, csrc/conv_rows.hip launchRows128 --; the second launch's bytes belong to the same enqueue, its launch count does not)
+        second = [k for k in ks if FB == 4 and "conv_rows_kernelILi4ELi1" in k]
+        n = sum(pm[k]["launches"] for k in ks if k not in second)
         return round(sum(pm[k]["traffic_mb_per_launch"] * pm[k]["launches"] for k in ks) / max(n, 1) * 1e6)
 
     def work(pl, c):
@@ -606,7 +609,7 @@ def roofline_rows(prof, sampled, counts, pool_len, FB, mode, n_points_per_launch
                                        "set_attention_f16_kernel" if f16 else "set_attention_split_kernel" if split else "set_attention_kernel("),
             "DsvtPosEmbedPlugin": ("posembed_batched_kernel (8 position-embedding MLPs, v_mfma_f32_16x16x32_f16)", "hbm", "posembed_batched_kernel"),
             "DsvtPillarFeatureNetPlugin": ("pfn_kernel (both PFN layers + scatter-max, v_mfma_f32_16x16x4_f32 + 16x16x32_f16; peak = the mix of the two matrix rates; a wave owns a work-balanced group of up to 16 pillars; bound by dependent LDS / L2 round trips at two waves per SIMD, not by either)" + sp_, "mfma", "pfn_kernel"),
-            "DsvtConv2dPlugin": ("conv_rows_kernel<8, 2> / <4, 3> (round 6: the 3 x 3 stride-1 layers of the fp32-grade frame) / conv_wide_kernel / conv_halo_kernel / conv_f16_kernel / conv1x1_resident(_split / _mx)_kernel / conv3x3_grouped_narrow(_split)_kernel (implicit GEMM, v_mfma_f32_16x16x32_f16)" +
+            "DsvtConv2dPlugin": ("conv_rows_kernel<8, 2> / <4, 3> / <4, 2> / <4, 1> (round 6: the 3 x 3 stride-1 layers of the fp32-grade frame) / conv_wide_kernel / conv_halo_kernel / conv_f16_kernel / conv1x1_resident(_split / _mx)_kernel / conv3x3_grouped_narrow(_split)_kernel (implicit GEMM, v_mfma_f32_16x16x32_f16)" +
                                  (" -- 3 x 3 stride-1 layers with > 32 output channels (93 % of the products) on the fp16 + fp8 K loop over [hi | x8]: one fp16 MFMA product + "
                                   "two e4m3 correction products (v_mfma_scale_f32_16x16x128_f8f6f4) per fp32-grade product; the other layers walk [hi | lo | hi] x "
                                   "[w_hi | w_hi | w_lo], three fp16 MFMAs per product; peak = the launch-weighted mix of the two" if (split and head_mx) else
