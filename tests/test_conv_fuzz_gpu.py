@@ -140,3 +140,49 @@ def test_rows_kernel_fuzz_against_the_round5_kernel(pkg):
         assert not torch.isnan(outs[0][..., :2 * cout].float()).any() and (outs[0][..., 2 * cout:] == 7.0).all()
         done["rows64" if ct4 else "rows"] += 1
     assert done["rows"] >= 2 and done["rows64"] >= 2, done
+
+
+def test_small_rows_kernels_fuzz_against_the_round5_kernels(pkg):
+    """conv_rows_kernel<4, 2> / <4, 1> (the launches that do not fill the chip: few images, small maps) and the two-launch form of a 128-channel layer whose partial last
+    tile row saves a round of the chip (csrc/conv_rows.hip launchRows128), against round 5's kernels of the same layers (kernel_variant = 1) bit for bit: one to three images,
+    maps from a single tile up, odd sizes, 64 .. 384 output channels, residuals."""
+    import torch
+    P = pkg.plugin
+    rng = np.random.default_rng(77)
+    shapes = [(20, 1024, 128, 256, 4, True),       # 1 full tile row + 4 rows, 512 items: 256 on <8, 2> + the four rows on <4, 1> (two launches)
+              (36, 500, 64, 128, 8, False),        # 2 full tile rows + 4 rows, 384 items: 256 + 128 small ones
+              (9, 30, 64, 64, 1, False)]           # one item
+    for trial in range(9):
+        cin = int(rng.choice([64, 128, 256])); cout = int(rng.choice([64, 128, 192, 256, 384]))
+        shapes.append((int(rng.integers(17, 120)), int(rng.integers(17, 120)), cin, cout, int(rng.integers(1, 4)), bool(rng.integers(0, 2))))
+    for trial, (H, W, cin, cout, B, res) in enumerate(shapes):
+        g = torch.Generator(device="cpu").manual_seed(5000 + trial)
+        x = torch.relu(torch.randn(B, H, W, cin, generator=g) * 2.0)
+        hi = x.half(); x3 = torch.cat([hi, (x - hi.float()).half(), torch.full_like(hi, float("nan"))], -1).to(DEV)
+        w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+        b = torch.randn(cout, generator=g) * 0.1
+        rows = P.split_weight_rows(P.conv_weight_rows(w.numpy()), 9, cin)
+        r3 = None
+        if res:
+            r = torch.randn(B, H, W, cout, generator=g); rh = r.half()
+            r3 = torch.cat([rh, (r - rh.float()).half(), torch.full_like(rh, float("nan"))], -1).to(DEV)
+        outs = []
+        for variant in (0, 1):
+            op = P.add_conv2d_op(rows, b.numpy(), H, W, 3 * cin, cout, 3, 1, 1, relu=bool(trial % 2), has_residual=res, split_residual=1 if res else 0, split_input=1,
+                                 split_output=4, out_channel_stride=3 * cout, kernel_variant=variant)
+            out = torch.full((B, H, W, 3 * cout), 7.0, dtype=torch.float16, device=DEV)
+            op(*([x3] + ([r3] if res else [])), out=[out])
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+        a, c = outs[0].view(torch.int16), outs[1].view(torch.int16)
+        assert torch.equal(a, c), (trial, H, W, cin, cout, B, res, int((a != c).sum()))
+        assert not torch.isnan(outs[0][..., :2 * cout].float()).any() and (outs[0][..., 2 * cout:] == 7.0).all()
+        # and against float64 on image 0
+        ref = F.conv2d(x[:1].permute(0, 3, 1, 2).double(), w.double(), b.double(), 1, 1)
+        if res:
+            ref = ref + (r3[:1, ..., :cout].cpu().double() + r3[:1, ..., cout:2 * cout].cpu().double()).permute(0, 3, 1, 2)
+        if trial % 2:
+            ref = torch.relu(ref)
+        o = outs[0][:1]
+        got = (o[..., :cout].double() + o[..., cout:2 * cout].double()).permute(0, 3, 1, 2)
+        assert (got - ref).abs().max().item() < 5e-6 * max(1.0, ref.abs().max().item()), (trial, H, W, cin, cout)
