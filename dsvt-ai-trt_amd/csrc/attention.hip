@@ -384,14 +384,22 @@ set_attention_f16_kernel(AttnArgs a)
 //     O^T = V_hi^T P_hi^T + V_lo^T P_hi^T + V_hi^T P_lo^T      (36 MFMAs per head; P split in registers after the fp32 softmax)
 // Layouts are set_attention_f16_kernel's (Q / K rows of 112 halfs, V transposed in 40-half rows), twice: 48.4 KB of LDS, three
 // workgroups per CU.  Softmax in fp32 with v_exp_f32 / v_rcp_f32 (1 ulp each: fp32 grade).
-__global__ void __launch_bounds__(256, 3)
+__global__ void __launch_bounds__(256, 5)
 set_attention_split_kernel(AttnArgs a)
 {
     __shared__ __attribute__((aligned(16))) _Float16 sQ[2][AL * AQL];                 // [hi | lo]
     __shared__ __attribute__((aligned(16))) _Float16 sK[2][AL * AQL];
-    __shared__ __attribute__((aligned(16))) _Float16 sVt[2][AHB * ADH * AVL + 16];
-    __shared__ uint32_t sRow[AL];
-    __shared__ float sMask[AHB][AL];
+    // V^T lives where Q was (round 6, late): the Q / K fragments are in registers after one read, so V^T is written into Q's rows behind a barrier while the S^T products
+    // run -- 32 KB of LDS instead of 48 KB, FIVE workgroups per CU instead of three (the kernel waits for its gathers: more sets in flight per CU;
+    // four: 157 / 121 us per four-frame launch of the two window configurations against 173 / 130, tools/ab_attn_split.py)
+    constexpr int SVT = AHB * ADH * AVL + 16;
+    static_assert(2 * SVT <= 2 * AL * AQL, "V^T fits in Q's rows");
+    _Float16 (*sVt)[SVT] = reinterpret_cast<_Float16 (*)[SVT]>(&sQ[0][0]);
+    // the slots' row indices and the heads' key masks live in the 32 padding bytes of K's rows (columns 96 .. 111 of a 112-half row: no fragment read touches them):
+    // 32,256 B of LDS per workgroup = FIVE workgroups per CU (160 KB)
+    static_assert(AQL - AHB * ADH >= 2 * AHB && AQL % 2 == 0, "padding columns");
+    auto sRow = [&](int q) -> uint32_t& { return *reinterpret_cast<uint32_t*>(&sK[1][q * AQL + AHB * ADH]); };
+    auto sMask = [&](int w, int q) -> float& { return *reinterpret_cast<float*>(&sK[0][q * AQL + AHB * ADH + 2 * w]); };
 
     const int nhb = a.H / AHB;
     const int set = blockIdx.x / nhb, hq = blockIdx.x % nhb;
@@ -407,22 +415,29 @@ set_attention_split_kernel(AttnArgs a)
     // loads: all indices, all rows, then the LDS writes).  Item = (slot, Q | K, 4-channel chunk) / (4-channel chunk, slot) for V.
     // V items are (4-channel chunk, PAIR of slots): the two slots' values of a channel are one 4-byte LDS store.  (Until round 6 a V item was one slot and stored eight
     // single halfs: two lanes of every pair wrote the two halves of one dword -- 5.1 M bank-conflict cycles per four-frame launch, a third of the kernel's LDS-active cycles.)
-    constexpr int NQK = (AL * 2 * 24 + 255) / 256, NVP = (24 * (AL / 2) + 255) / 256, NIT = NQK + 2 * NVP;
+    // Item -> thread mapping (round 6, late): a thread keeps ONE (Q | K, 4-channel chunk) and walks the slots in steps of five (240 threads x 8 steps cover 36 slots x 48
+    // chunks), and ONE slot pair of V and walks the 4-channel chunks in steps of fourteen (252 threads x 2 steps cover 18 pairs x 24 chunks): the division / modulo decode
+    // of an item happens once per thread instead of once per item (eleven items: the kernel issues 20 VALU instructions per MFMA and is bound by them).
+    constexpr int QKT = 2 * 24, QKS = 256 / QKT, NQK = (AL + QKS - 1) / QKS;          // 48 chunks per slot, 5 slots per step, 8 steps
+    constexpr int VPT = AL / 2, VCS = 256 / VPT, NVP = (24 + VCS - 1) / VCS, NIT = NQK + 2 * NVP;      // 18 pairs, 14 chunks per step, 2 steps
     static_assert(AL % 2 == 0, "slot pairs");
     int slotOf[NIT], segOf[NIT], c4Of[NIT]; bool live[NIT];
+    {
+        const int u = tid % QKT, s0 = tid / QKT;
 #pragma unroll
-    for (int k = 0; k < NQK; ++k) {
-        const int i = tid + 256 * k; live[k] = i < AL * 2 * 24;
-        const int ii = live[k] ? i : 0, rem = ii % 48;
-        slotOf[k] = ii / 48; segOf[k] = rem / 24; c4Of[k] = (rem % 24) * 4;
-    }
+        for (int k = 0; k < NQK; ++k) {
+            const int slot = s0 + QKS * k;
+            live[k] = tid < QKT * QKS && slot < AL;
+            slotOf[k] = live[k] ? slot : 0; segOf[k] = u / 24; c4Of[k] = (u % 24) * 4;
+        }
+        const int sp = tid % VPT, c0 = tid / VPT;
 #pragma unroll
-    for (int k = 0; k < NVP; ++k) {
-        const int i = tid + 256 * k; const bool lv = i < 24 * (AL / 2);
-        const int ii = lv ? i : 0;
+        for (int k = 0; k < NVP; ++k) {
+            const int c = c0 + VCS * k; const bool lv = tid < VPT * VCS && c < 24;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {                                    // items NQK + 2k, NQK + 2k + 1: the even and the odd slot of the pair
-            live[NQK + 2 * k + e] = lv; slotOf[NQK + 2 * k + e] = 2 * (ii % (AL / 2)) + e; segOf[NQK + 2 * k + e] = 2; c4Of[NQK + 2 * k + e] = (ii / (AL / 2)) * 4;
+            for (int e = 0; e < 2; ++e) {                                    // items NQK + 2k, NQK + 2k + 1: the even and the odd slot of the pair
+                live[NQK + 2 * k + e] = lv; slotOf[NQK + 2 * k + e] = 2 * sp + e; segOf[NQK + 2 * k + e] = 2; c4Of[NQK + 2 * k + e] = (lv ? c : 0) * 4;
+            }
         }
     }
     uint32_t rowOf[NIT];
@@ -437,8 +452,8 @@ set_attention_split_kernel(AttnArgs a)
 #pragma unroll
     for (int k = 0; k < NIT; ++k)
         val[k] = *reinterpret_cast<const floatx4*>(static_cast<const float*>(a.qkv) + (size_t)rowOf[k] * a.qkv_ld + segOf[k] * a.C + hq * (AHB * ADH) + c4Of[k]);
-    if (tid < AL) sRow[tid] = myRow;
-    if (tid < AHB * AL) sMask[tid / AL][tid % AL] = myMask;
+    if (tid < AL) sRow(tid) = myRow;
+    if (tid < AHB * AL) sMask(tid / AL, tid % AL) = myMask;
     auto split4 = [](const floatx4& v, _Float16 (&h)[4], _Float16 (&l)[4]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -456,19 +471,6 @@ set_attention_split_kernel(AttnArgs a)
         *reinterpret_cast<ahalf4*>(dh) = ahalf4{h[0], h[1], h[2], h[3]};
         *reinterpret_cast<ahalf4*>(dl) = ahalf4{l[0], l[1], l[2], l[3]};
     }
-#pragma unroll
-    for (int k = 0; k < NVP; ++k) {
-        const int e0 = NQK + 2 * k;
-        if (!live[e0]) continue;
-        _Float16 h0[4], l0[4], h1[4], l1[4];
-        split4(val[e0], h0, l0); split4(val[e0 + 1], h1, l1);
-        typedef _Float16 ahalf2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {                                    // (slotOf[e0] is even and AVL is even: 4-byte aligned)
-            *reinterpret_cast<ahalf2*>(&sVt[0][(c4Of[e0] + j) * AVL + slotOf[e0]]) = ahalf2{h0[j], h1[j]};
-            *reinterpret_cast<ahalf2*>(&sVt[1][(c4Of[e0] + j) * AVL + slotOf[e0]]) = ahalf2{l0[j], l1[j]};
-        }
-    }
     __syncthreads();
 
     const int hoff = wave * ADH;
@@ -484,6 +486,21 @@ set_attention_split_kernel(AttnArgs a)
             kh[t] = g < 3 ? *reinterpret_cast<const ahalf8*>(&sK[0][o]) : zero8; kl[t] = g < 3 ? *reinterpret_cast<const ahalf8*>(&sK[1][o]) : zero8;
             qh[t] = g < 3 ? *reinterpret_cast<const ahalf8*>(&sQ[0][o]) : zero8; ql[t] = g < 3 ? *reinterpret_cast<const ahalf8*>(&sQ[1][o]) : zero8;
         }
+        // every wave has its Q / K fragments: Q's rows become V^T
+        __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NVP; ++k) {
+        const int e0 = NQK + 2 * k;
+        if (!live[e0]) continue;
+        _Float16 h0[4], l0[4], h1[4], l1[4];
+        split4(val[e0], h0, l0); split4(val[e0 + 1], h1, l1);
+        typedef _Float16 ahalf2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                    // (slotOf[e0] is even and AVL is even: 4-byte aligned)
+            *reinterpret_cast<ahalf2*>(&sVt[0][(c4Of[e0] + j) * AVL + slotOf[e0]]) = ahalf2{h0[j], h1[j]};
+            *reinterpret_cast<ahalf2*>(&sVt[1][(c4Of[e0] + j) * AVL + slotOf[e0]]) = ahalf2{l0[j], l1[j]};
+        }
+    }
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -499,7 +516,7 @@ set_attention_split_kernel(AttnArgs a)
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { int key = 16 * t + 4 * g + i; mk[t][i] = key < AL ? sMask[wave][key] : -INFINITY; }
+        for (int i = 0; i < 4; ++i) { int key = 16 * t + 4 * g + i; mk[t][i] = key < AL ? sMask(wave, key) : -INFINITY; }
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         float mx = -INFINITY;
@@ -526,8 +543,8 @@ set_attention_split_kernel(AttnArgs a)
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int q = 16 * u + r;
-            if (q >= AL || (a.inds && sMask[wave][q] < 0.f)) continue;
-            float* dst = static_cast<float*>(a.out) + (size_t)sRow[q] * a.out_ld + h_ * ADH;
+            if (q >= AL || (a.inds && sMask(wave, q) < 0.f)) continue;
+            float* dst = static_cast<float*>(a.out) + (size_t)sRow(q) * a.out_ld + h_ * ADH;
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -540,8 +557,8 @@ set_attention_split_kernel(AttnArgs a)
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int q = 16 * u + r;
-            if (q >= AL || (a.inds && sMask[wave][q] < 0.f)) continue;
-            float* dst = static_cast<float*>(a.out) + (size_t)sRow[q] * a.out_ld + h_ * ADH;
+            if (q >= AL || (a.inds && sMask(wave, q) < 0.f)) continue;
+            float* dst = static_cast<float*>(a.out) + (size_t)sRow(q) * a.out_ld + h_ * ADH;
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -555,6 +572,7 @@ set_attention_split_kernel(AttnArgs a)
     }
 #endif
     // ---- O[query][d] = sum_key P[query][key] V[key][d] -------------------------------------------------
+    __syncthreads();                     // V^T is staged
     ahalf8 vb[2][2][2];                  // [hi | lo][channel tile][k-step]
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl)
@@ -603,8 +621,8 @@ set_attention_split_kernel(AttnArgs a)
     for (int u = 0; u < 3; ++u) {
         const int q = 16 * u + r;
         if (q >= AL) continue;
-        if (a.inds && sMask[wave][q] < 0.f) continue;      // duplicate slot: the first occurrence writes the identical row
-        float* dst = static_cast<float*>(a.out) + (size_t)sRow[q] * a.out_ld + h * ADH + 4 * g;
+        if (a.inds && sMask(wave, q) < 0.f) continue;      // duplicate slot: the first occurrence writes the identical row
+        float* dst = static_cast<float*>(a.out) + (size_t)sRow(q) * a.out_ld + h * ADH + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
             if (16 * dt + 4 * g >= ADH) continue;
