@@ -392,6 +392,9 @@ set_attention_split_kernel(AttnArgs a)
     // V^T lives where Q was (round 6, late): the Q / K fragments are in registers after one read, so V^T is written into Q's rows behind a barrier while the S^T products
     // run -- 32 KB of LDS instead of 48 KB, FIVE workgroups per CU instead of three (the kernel waits for its gathers: more sets in flight per CU;
     // four: 157 / 121 us per four-frame launch of the two window configurations against 173 / 130, tools/ab_attn_split.py)
+    // Measured and dropped the same day: persistent workgroups (grid = workgroups per CU x CUs, the next item's slot indices and masks prefetched into second copies of the
+    // LDS tables, so that only a workgroup's first item waits index -> rows): the loop keeps ~12 more registers alive -- at five workgroups per CU 28 spilled registers and
+    // 233 / 181 us, at four (126 registers) 161 / 120 against 156.5 / 118 for this kernel: the other workgroups of the CU already cover the index wait.
     constexpr int SVT = AHB * ADH * AVL + 16;
     static_assert(2 * SVT <= 2 * AL * AQL, "V^T fits in Q's rows");
     _Float16 (*sVt)[SVT] = reinterpret_cast<_Float16 (*)[SVT]>(&sQ[0][0]);
